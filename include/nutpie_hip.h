@@ -1,0 +1,168 @@
+/*
+ * nutpie_hip.h — C-ABI of libnutpie_hip.so, the MI355X-native NUTS engine.
+ *
+ * Drop-in boundary: these entry points are what nutpie's PyO3 layer
+ * (reference src/wrapper.rs) would bind instead of `nuts_rs::Sampler`.  Every
+ * function is `extern "C"`, takes plain pointers/sizes, never throws, and
+ * reports failure through an int status + nphip_last_error().
+ *
+ *   reference interface                                 replaced by
+ *   --------------------------------------------------  -------------------------------
+ *   PyNutsSettings::Diag / apply_update / as_dict       nphip_settings_*
+ *     (src/wrapper.rs:525-533, 563-620, 210-451, 751-769)
+ *   LogpFunc / RawLogpFunc  (src/pymc.rs:21-62)         nphip_model_host_callback
+ *   PyModel  (src/pyfunc.rs:206-230, 517-570)           nphip_model_device_callback
+ *   StanModel::logp (src/stan.rs:454-463)               nphip_model_host_callback (adapter)
+ *   nuts_rs::Sampler::new (src/wrapper.rs:977-1085)     nphip_sampler_create
+ *   PySampler::{wait,pause,resume,abort,is_finished,    nphip_sampler_{wait,pause,resume,abort,
+ *     inspect,take_results} (src/wrapper.rs:1252-1456)    is_finished,trace_*}
+ *   ChainProgress (src/wrapper.rs:47-104)               nphip_chain_progress_t
+ *
+ * Threading: every entry point may be called from any host thread; a sampler is
+ * guarded by one mutex (as the reference's Mutex<SamplerState>, wrapper.rs:954).
+ * The engine owns one host driver thread per sampler; `wait` blocks the caller
+ * (the Python binding releases the GIL around it, as wrapper.rs:1305-1330 does).
+ */
+#ifndef NUTPIE_HIP_H
+#define NUTPIE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NPHIP_OK 0
+#define NPHIP_ERR (-1)
+/* settings errors mirror the two Python exception classes of wrapper.rs:138-145, 610-614 */
+#define NPHIP_ERR_UNKNOWN_ATTR (-2)   /* AttributeError("Unknown settings attribute: ...")            */
+#define NPHIP_ERR_NOT_AVAILABLE (-3)  /* ValueError("Option ... not available for ... adaptation")     */
+#define NPHIP_ERR_BAD_VALUE (-4)      /* ValueError(...)                                               */
+
+/* nphip_sampler_wait results (SamplerWaitResult, wrapper.rs:1099-1143) */
+#define NPHIP_WAIT_DONE 0
+#define NPHIP_WAIT_TIMEOUT 1
+#define NPHIP_WAIT_ERROR 2
+
+const char* nphip_last_error(void);
+const char* nphip_version(void);
+int nphip_device_count(void);
+
+/* ------------------------------------------------------------------ settings */
+typedef struct nphip_settings nphip_settings_t;
+
+/* PyNutsSettings.Diag(seed) — wrapper.rs:721-723.  adaptation "diag"/"draw_diag" only;
+ * LowRank/Flow/MCLMC are out of scope for this engine. */
+nphip_settings_t* nphip_settings_new_diag(uint64_t seed);
+nphip_settings_t* nphip_settings_clone(const nphip_settings_t*);
+void nphip_settings_free(nphip_settings_t*);
+/* Flat attribute names exactly as wrapper.rs:213-447, 565-609 accepts them. */
+int nphip_settings_set_f64(nphip_settings_t*, const char* name, double v);
+int nphip_settings_set_u64(nphip_settings_t*, const char* name, uint64_t v);
+int nphip_settings_set_bool(nphip_settings_t*, const char* name, int v);
+int nphip_settings_set_str(nphip_settings_t*, const char* name, const char* v);
+int nphip_settings_get_f64(const nphip_settings_t*, const char* name, double* out);
+int nphip_settings_get_u64(const nphip_settings_t*, const char* name, uint64_t* out);
+/* JSON of the nested settings (the "settings" value of as_dict(), wrapper.rs:755-769);
+ * returns needed length incl. NUL; writes at most cap bytes. */
+int64_t nphip_settings_to_json(const nphip_settings_t*, char* buf, int64_t cap);
+
+/* ------------------------------------------------------------------ models */
+typedef struct nphip_model nphip_model_t;
+
+/* The reference's raw C logp callback, verbatim: src/pymc.rs:23-29 /
+ * python/nutpie/compile_pymc.py:975-981.  0 ok, >0 recoverable (=> divergence), <0 fatal
+ * (src/pymc.rs:166-180).  Must be re-entrant: called concurrently from n_threads host threads. */
+typedef int64_t (*nphip_raw_logp_fn)(uint64_t dim, const double* x, double* grad_out, double* logp_out, void* user_data);
+
+/* Batched device callback (the GPU form of src/pyfunc.rs:206-230): when called, the engine's
+ * staging buffer q[n_chains][dim] (device, fp64, row-major) holds the positions; the callee must
+ * fill grad[n_chains][dim] and logp[n_chains] (device) with work enqueued on `stream`.
+ * Non-finite logp => recoverable (src/pyfunc.rs:218-220).  Return 0, or <0 for a fatal error. */
+typedef int (*nphip_device_logp_fn)(uint64_t n_chains, uint64_t dim, const double* q, double* grad, double* logp,
+                                    void* stream, void* user_data);
+
+/* Fused analytic model: logp(x) = -1/2 (x-mu)' L (x-mu), L symmetric tridiagonal (diag[dim],
+ * offdiag[dim-1]); mu/offdiag may be NULL.  Covers N(0,I), diagonal and AR(1) Gaussians.
+ * Host pointers; copied. */
+nphip_model_t* nphip_model_tridiag_gaussian(uint64_t dim, const double* mu, const double* diag, const double* offdiag);
+nphip_model_t* nphip_model_host_callback(uint64_t dim, nphip_raw_logp_fn fn, void* user_data, int n_threads);
+nphip_model_t* nphip_model_device_callback(uint64_t dim, nphip_device_logp_fn fn, void* user_data);
+/* Initial positions: kind 0 = U(-2,2) (src/pyfunc.rs:540-544), 1 = N(0,1) (src/stan.rs:798-808),
+ * 2 = explicit host array points[n_chains_total][dim] indexed by GLOBAL chain id
+ * (src/pymc.rs:505-534 evaluates the user's init function per chain on the host). */
+int nphip_model_set_init(nphip_model_t*, int kind, const double* points, uint64_t n_points);
+uint64_t nphip_model_dim(const nphip_model_t*);
+void nphip_model_free(nphip_model_t*);
+
+/* ------------------------------------------------------------------ sampler */
+typedef struct nphip_sampler nphip_sampler_t;
+
+/* ChainProgress, wrapper.rs:47-104 */
+typedef struct {
+    uint64_t finished_draws;
+    uint64_t total_draws;
+    uint64_t divergences;
+    int32_t tuning;
+    int32_t started;
+    uint64_t latest_num_steps;
+    uint64_t total_num_steps;
+    double step_size;
+    uint64_t runtime_ms;
+} nphip_chain_progress_t;
+
+/* Engine/launch options beyond the reference's settings. */
+typedef struct {
+    int32_t device;            /* HIP device ordinal */
+    int32_t waves_per_chain;   /* 0 = choose from dim; else 1,2,4,8,16 (fixes the reduction order) */
+    uint64_t chain_offset;     /* global id of local chain 0 (multi-GPU chain sharding)            */
+    uint64_t n_local_chains;   /* 0 = settings.num_chains                                          */
+    void* stream;              /* hipStream_t to run on; NULL = engine-owned stream                 */
+    int32_t store_draws;       /* keep [chain][draw][dim] positions in HBM (default 1)             */
+    int32_t evals_per_launch;  /* fused models: leapfrogs per chain per kernel launch (0 = default) */
+    int32_t start_paused;
+    int32_t reserved;
+} nphip_launch_t;
+
+void nphip_launch_defaults(nphip_launch_t*);
+
+/* nuts_rs::Sampler::new — starts the driver thread; sampling begins immediately. */
+nphip_sampler_t* nphip_sampler_create(const nphip_settings_t*, const nphip_model_t*, const nphip_launch_t*);
+void nphip_sampler_free(nphip_sampler_t*);                 /* aborts if still running */
+int nphip_sampler_wait(nphip_sampler_t*, int64_t timeout_ms); /* <0: no timeout; resumes a paused sampler */
+int nphip_sampler_pause(nphip_sampler_t*);
+int nphip_sampler_resume(nphip_sampler_t*);
+int nphip_sampler_abort(nphip_sampler_t*);                 /* stop; partial trace stays readable */
+int nphip_sampler_is_finished(nphip_sampler_t*);
+int nphip_sampler_progress(nphip_sampler_t*, uint64_t local_chain, nphip_chain_progress_t* out);
+int nphip_sampler_waves_per_chain(const nphip_sampler_t*);
+uint64_t nphip_sampler_num_chains(const nphip_sampler_t*); /* local */
+uint64_t nphip_sampler_dim(const nphip_sampler_t*);
+uint64_t nphip_sampler_total_draws(const nphip_sampler_t*); /* num_tune + num_draws */
+/* wall-clock seconds spent in the sampling loop (excludes allocation) and kernel launches issued */
+double nphip_sampler_seconds(const nphip_sampler_t*);
+uint64_t nphip_sampler_launches(const nphip_sampler_t*);
+
+/* Trace hand-off (PyTrace / take_results, wrapper.rs:1431-1494).  All copies are D2H into host
+ * memory laid out [local_chain][draw](...).  `finished[local_chain]` (optional) receives the number
+ * of completed draws per chain (chains may be unequal after abort, python/nutpie/sample.py:192-199).
+ * Names: "draws"(f64[dim]) "depth" "n_steps" "index_in_trajectory"(i64) "diverging" "maxdepth_reached"
+ * "tuning"(u8) "energy" "energy_error" "logp" "step_size" "step_size_bar" "mean_tree_accept"
+ * "mean_tree_accept_sym"(f64) and, when enabled, "gradient" "mass_matrix_inv" "divergence_start"
+ * "divergence_end" "divergence_momentum" "divergence_start_gradient"(f64[dim]). */
+int nphip_sampler_finished_draws(nphip_sampler_t*, uint64_t* finished);
+int nphip_sampler_copy_stat(nphip_sampler_t*, const char* name, void* host_out, uint64_t nbytes);
+/* Device pointer of a trace array (for zero-copy wrapping / RCCL gathers); NULL if absent. */
+void* nphip_sampler_device_ptr(nphip_sampler_t*, const char* name);
+
+/* ------------------------------------------------------------------ test hooks */
+/* Evaluate the device implementations of include/nphip_spec.h on arrays (parity tests).
+ * fn: 0 exp 1 log 2 log1p 3 sin2pi 4 cos2pi 5 sqrt 6 reciprocal 7 normals(seed=x[0],chain=x[1],draw=x[2],purpose=x[3]) */
+int nphip_test_detmath(int device, int fn, uint64_t n, const double* x, double* y);
+/* dot product in the engine's summation order with W waves */
+int nphip_test_dot(int device, int waves, uint64_t n, const double* x, const double* y, double* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

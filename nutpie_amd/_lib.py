@@ -1,0 +1,603 @@
+"""ctypes binding of ``libnutpie_hip.so`` shaped like the reference's ``nutpie._lib``.
+
+The reference's ``_lib`` is a PyO3 module (``src/wrapper.rs``); this module exposes
+objects with the same names and methods for the diag-NUTS path, implemented on top of
+the C-ABI declared in ``include/nutpie_hip.h``:
+
+========================  ==========================================================
+reference (file:line)     here
+========================  ==========================================================
+``PyNutsSettings``        :class:`PyNutsSettings`  (wrapper.rs:106-826)
+``PyChainProgress``       :class:`PyChainProgress` (wrapper.rs:47-104)
+``PySampler``             :class:`PySampler`       (wrapper.rs:953-1457)
+``PyMcModel``/``LogpFunc``  :class:`HostCallbackModel` (src/pymc.rs:21-62, 188-215)
+``PyModel``               :class:`DeviceCallbackModel` (src/pyfunc.rs:201-230, batched)
+``PyTrace``               :class:`PyTrace`         (wrapper.rs:1459-1495)
+========================  ==========================================================
+
+There is no CPU fallback: creating a sampler without the HIP library or without a GPU
+raises.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+import subprocess
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libnutpie_hip.so")
+_CSRC = os.path.join(_HERE, "csrc")
+
+__version__ = "0.1.0"
+
+NPHIP_OK = 0
+NPHIP_ERR_UNKNOWN_ATTR = -2
+NPHIP_ERR_NOT_AVAILABLE = -3
+NPHIP_ERR_BAD_VALUE = -4
+WAIT_DONE, WAIT_TIMEOUT, WAIT_ERROR = 0, 1, 2
+
+RAW_LOGP_FN = C.CFUNCTYPE(C.c_int64, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p)
+DEVICE_LOGP_FN = C.CFUNCTYPE(C.c_int, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
+
+
+class _Launch(C.Structure):
+    _fields_ = [
+        ("device", C.c_int32),
+        ("waves_per_chain", C.c_int32),
+        ("chain_offset", C.c_uint64),
+        ("n_local_chains", C.c_uint64),
+        ("stream", C.c_void_p),
+        ("store_draws", C.c_int32),
+        ("evals_per_launch", C.c_int32),
+        ("start_paused", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+class _Progress(C.Structure):
+    _fields_ = [
+        ("finished_draws", C.c_uint64),
+        ("total_draws", C.c_uint64),
+        ("divergences", C.c_uint64),
+        ("tuning", C.c_int32),
+        ("started", C.c_int32),
+        ("latest_num_steps", C.c_uint64),
+        ("total_num_steps", C.c_uint64),
+        ("step_size", C.c_double),
+        ("runtime_ms", C.c_uint64),
+    ]
+
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(_CSRC, f) for f in ("kernels.hip", "host.hip", "engine_types.h", "Makefile")]
+    srcs += [os.path.join(_HERE, "..", "include", f) for f in ("nutpie_hip.h", "nphip_spec.h")]
+    stale = not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(s) for s in srcs)
+    if force or stale:
+        r = subprocess.run(["make", "-C", _CSRC] + (["-B"] if force else []), capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("building libnutpie_hip.so failed:\n" + r.stdout + r.stderr)
+    return _LIB_PATH
+
+
+def lib():
+    """Load the HIP engine.  Fails loudly if the extension is missing."""
+    global _lib
+    with _lib_lock:
+        if _lib is None:
+            if not os.path.exists(_LIB_PATH):
+                raise ImportError(
+                    f"{_LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                    "(the nutpie-hip engine has no CPU fallback)"
+                )
+            L = C.CDLL(_LIB_PATH)
+            L.nphip_last_error.restype = C.c_char_p
+            L.nphip_version.restype = C.c_char_p
+            L.nphip_settings_new_diag.restype = C.c_void_p
+            L.nphip_settings_new_diag.argtypes = [C.c_uint64]
+            L.nphip_settings_clone.restype = C.c_void_p
+            L.nphip_settings_clone.argtypes = [C.c_void_p]
+            L.nphip_settings_free.argtypes = [C.c_void_p]
+            L.nphip_settings_set_f64.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
+            L.nphip_settings_set_u64.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64]
+            L.nphip_settings_set_bool.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+            L.nphip_settings_set_str.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+            L.nphip_settings_get_f64.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double)]
+            L.nphip_settings_get_u64.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64)]
+            L.nphip_settings_to_json.restype = C.c_int64
+            L.nphip_settings_to_json.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+            L.nphip_model_tridiag_gaussian.restype = C.c_void_p
+            L.nphip_model_tridiag_gaussian.argtypes = [C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+            L.nphip_model_host_callback.restype = C.c_void_p
+            L.nphip_model_host_callback.argtypes = [C.c_uint64, C.c_void_p, C.c_void_p, C.c_int]
+            L.nphip_model_device_callback.restype = C.c_void_p
+            L.nphip_model_device_callback.argtypes = [C.c_uint64, C.c_void_p, C.c_void_p]
+            L.nphip_model_set_init.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64]
+            L.nphip_model_free.argtypes = [C.c_void_p]
+            L.nphip_launch_defaults.argtypes = [C.POINTER(_Launch)]
+            L.nphip_sampler_create.restype = C.c_void_p
+            L.nphip_sampler_create.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(_Launch)]
+            L.nphip_sampler_free.argtypes = [C.c_void_p]
+            L.nphip_sampler_wait.argtypes = [C.c_void_p, C.c_int64]
+            for f in ("pause", "resume", "abort", "is_finished", "waves_per_chain"):
+                getattr(L, "nphip_sampler_" + f).argtypes = [C.c_void_p]
+            for f in ("num_chains", "dim", "total_draws", "launches"):
+                getattr(L, "nphip_sampler_" + f).argtypes = [C.c_void_p]
+                getattr(L, "nphip_sampler_" + f).restype = C.c_uint64
+            L.nphip_sampler_seconds.argtypes = [C.c_void_p]
+            L.nphip_sampler_seconds.restype = C.c_double
+            L.nphip_sampler_progress.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(_Progress)]
+            L.nphip_sampler_finished_draws.argtypes = [C.c_void_p, C.c_void_p]
+            L.nphip_sampler_copy_stat.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64]
+            L.nphip_sampler_device_ptr.restype = C.c_void_p
+            L.nphip_sampler_device_ptr.argtypes = [C.c_void_p, C.c_char_p]
+            L.nphip_test_detmath.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p]
+            L.nphip_test_dot.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+            _lib = L
+    return _lib
+
+
+def _err() -> str:
+    return lib().nphip_last_error().decode()
+
+
+def _check_setting(rc: int):
+    # same two exception classes as wrapper.rs:138-145 (ValueError) and 610-614 (AttributeError)
+    if rc == NPHIP_OK:
+        return
+    if rc == NPHIP_ERR_UNKNOWN_ATTR:
+        raise AttributeError(_err())
+    raise ValueError(_err())
+
+
+# --------------------------------------------------------------------------- settings
+_BOOL_KEYS = {
+    "check_turning", "store_mass_matrix", "use_grad_based_mass_matrix", "store_unconstrained", "store_gradient",
+    "store_transformed", "store_divergences", "train_on_orbit", "microcanonical_trajectory",
+    "exact_normal_trajectory", "adapt_mass_matrix",
+}
+_U64_KEYS = {
+    "num_tune", "num_draws", "num_chains", "maxdepth", "mindepth", "window_switch_freq", "mass_matrix_switch_freq",
+    "early_window_switch_freq", "mass_matrix_update_freq", "extra_doublings", "seed", "num_try_init",
+}
+_OPT_F64_KEYS = {"target_integration_time", "mass_matrix_eigval_cutoff", "mass_matrix_gamma", "step_size_adam_learning_rate", "step_size_jitter"}
+
+
+class PyNutsSettings:
+    """Settings object with the reference's flat attribute names (wrapper.rs:210-451, 563-620)."""
+
+    __slots__ = ("_h", "_adaptation")
+
+    def __init__(self, handle, adaptation="diag"):
+        object.__setattr__(self, "_h", handle)
+        object.__setattr__(self, "_adaptation", adaptation)
+
+    # wrapper.rs:717-737
+    @staticmethod
+    def Diag(seed=None):
+        if seed is None:
+            seed = int.from_bytes(os.urandom(8), "little")  # random_seed(), wrapper.rs:453-458
+        return PyNutsSettings(C.c_void_p(lib().nphip_settings_new_diag(C.c_uint64(int(seed)))))
+
+    @staticmethod
+    def LowRank(seed=None):
+        raise NotImplementedError("adaptation='low_rank' is outside the scope of the HIP engine (diag / draw_diag only)")
+
+    @staticmethod
+    def Flow(seed=None):
+        raise NotImplementedError("adaptation='flow' is outside the scope of the HIP engine (diag / draw_diag only)")
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().nphip_settings_free(self._h)
+        except Exception:
+            pass
+
+    def clone(self):
+        return PyNutsSettings(C.c_void_p(lib().nphip_settings_clone(self._h)), self._adaptation)
+
+    def _apply_update(self, name: str, value):
+        L = lib()
+        key = name.encode()
+        if name == "step_size_adapt_method":
+            if not isinstance(value, str):
+                raise ValueError("step_size_adapt_method must be a string")
+            return _check_setting(L.nphip_settings_set_str(self._h, key, value.encode()))
+        if name in _OPT_F64_KEYS:
+            if value is None:
+                if name == "step_size_jitter":
+                    value = 0.0
+                else:
+                    return
+            return _check_setting(L.nphip_settings_set_f64(self._h, key, float(value)))
+        if name in _BOOL_KEYS:
+            if not isinstance(value, (bool, np.bool_)):
+                raise TypeError(f"'{type(value).__name__}' object cannot be converted to 'bool'")
+            return _check_setting(L.nphip_settings_set_bool(self._h, key, int(bool(value))))
+        if name in _U64_KEYS:
+            if isinstance(value, (bool, np.bool_)) or not isinstance(value, (int, np.integer)) or int(value) < 0:
+                raise TypeError(f"can't convert {value!r} to a non-negative integer for {name}")
+            return _check_setting(L.nphip_settings_set_u64(self._h, key, int(value)))
+        return _check_setting(L.nphip_settings_set_f64(self._h, key, float(value)))
+
+    def update(self, kwargs=None, **kw):
+        """``settings.update(dict)`` as in wrapper.rs:739-745."""
+        items = dict(kwargs or {})
+        items.update(kw)
+        for k, v in items.items():
+            self._apply_update(k, v)
+
+    def __setattr__(self, name, value):
+        self._apply_update(name, value)
+
+    def __getattr__(self, name):
+        L = lib()
+        out = C.c_uint64()
+        if L.nphip_settings_get_u64(self._h, name.encode(), C.byref(out)) == NPHIP_OK:
+            return bool(out.value) if name in _BOOL_KEYS else out.value
+        outf = C.c_double()
+        if L.nphip_settings_get_f64(self._h, name.encode(), C.byref(outf)) == NPHIP_OK:
+            return outf.value
+        raise AttributeError(_err())
+
+    def as_dict(self):
+        """``{"sampler", "adaptation", "settings": nested}`` as wrapper.rs:755-769."""
+        L = lib()
+        need = L.nphip_settings_to_json(self._h, None, 0)
+        buf = C.create_string_buffer(int(need))
+        L.nphip_settings_to_json(self._h, buf, need)
+        return {"sampler": "nuts", "adaptation": "diag", "settings": json.loads(buf.value.decode())}
+
+
+class PyMclmcSettings:
+    @staticmethod
+    def _no(*_a, **_k):
+        raise NotImplementedError("sampler='mclmc' is outside the scope of the HIP engine")
+
+    Diag = LowRank = Flow = _no
+
+
+# --------------------------------------------------------------------------- models
+class _Model:
+    def __init__(self, handle, dim, keep=None):
+        if not handle:
+            raise RuntimeError(_err())
+        self._h = C.c_void_p(handle)
+        self.dim = int(dim)
+        self._keep = keep
+
+    def set_init(self, kind: str, points=None):
+        code = {"uniform": 0, "normal": 1, "explicit": 2}[kind]
+        if code == 2:
+            pts = np.ascontiguousarray(points, dtype=np.float64)
+            if pts.ndim != 2 or pts.shape[1] != self.dim:
+                raise ValueError("Initial point has incorrect length")  # src/pyfunc.rs:561-563
+            rc = lib().nphip_model_set_init(self._h, 2, pts.ctypes.data_as(C.c_void_p), C.c_uint64(pts.shape[0]))
+        else:
+            rc = lib().nphip_model_set_init(self._h, code, None, C.c_uint64(0))
+        if rc != NPHIP_OK:
+            raise ValueError(_err())
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().nphip_model_free(self._h)
+        except Exception:
+            pass
+
+
+class TridiagGaussianModel(_Model):
+    """Fused analytic model: ``logp(x) = -1/2 (x-mu)' L (x-mu)``, L tridiagonal."""
+
+    def __init__(self, diag, offdiag=None, mu=None):
+        diag = np.ascontiguousarray(diag, dtype=np.float64)
+        dim = diag.shape[0]
+        off = None if offdiag is None or dim < 2 else np.ascontiguousarray(offdiag, dtype=np.float64)
+        m = None if mu is None else np.ascontiguousarray(mu, dtype=np.float64)
+        if off is not None and off.shape != (dim - 1,):
+            raise ValueError("offdiag must have length dim-1")
+        if m is not None and m.shape != (dim,):
+            raise ValueError("mu must have length dim")
+        p = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        super().__init__(lib().nphip_model_tridiag_gaussian(C.c_uint64(dim), p(m), p(diag), p(off)), dim)
+
+
+class HostCallbackModel(_Model):
+    """Raw C logp callback with the reference's exact signature (src/pymc.rs:23-29).
+
+    ``fn`` may be an integer address (e.g. ``numba.cfunc(...).address``), a ctypes function
+    pointer, or a Python callable ``f(x) -> (logp, grad)`` (wrapped; slow, test use only)."""
+
+    def __init__(self, dim, fn, user_data=0, n_threads=0, keep_alive=None):
+        keep = [keep_alive]
+        if isinstance(fn, int):
+            addr = C.c_void_p(fn)
+        elif isinstance(fn, C._CFuncPtr):
+            keep.append(fn)
+            addr = C.cast(fn, C.c_void_p)
+        else:
+            pyfn = fn
+
+            def _cb(d, x, g, lp, _u):
+                xs = np.ctypeslib.as_array(x, shape=(d,))
+                try:
+                    val, grad = pyfn(xs.copy())
+                except Exception as e:  # recoverable iff flagged, as src/pyfunc.rs:100-116
+                    return 1 if getattr(e, "is_recoverable", False) else -1
+                np.ctypeslib.as_array(g, shape=(d,))[:] = grad
+                lp[0] = val
+                return 0
+
+            cb = RAW_LOGP_FN(_cb)
+            keep.append(cb)
+            addr = C.cast(cb, C.c_void_p)
+            n_threads = 1
+        super().__init__(lib().nphip_model_host_callback(C.c_uint64(dim), addr, C.c_void_p(user_data), int(n_threads)), dim, keep)
+
+
+class DeviceCallbackModel(_Model):
+    """Batched device callback: ``fn(n_chains, dim, q_ptr, grad_ptr, logp_ptr, stream_ptr) -> int``."""
+
+    def __init__(self, dim, fn):
+        def _cb(n, d, q, g, lp, stream, _u):
+            try:
+                rc = fn(int(n), int(d), q, g, lp, stream)
+                return 0 if rc is None else int(rc)
+            except BaseException as e:  # noqa: BLE001 - must not unwind through C
+                self.exception = e
+                return -1
+
+        self.exception = None
+        cb = DEVICE_LOGP_FN(_cb)
+        super().__init__(lib().nphip_model_device_callback(C.c_uint64(dim), C.cast(cb, C.c_void_p), None), dim, [cb, fn])
+
+
+# --------------------------------------------------------------------------- progress / trace
+class PyChainProgress:
+    """Field set of ``ChainProgress`` (wrapper.rs:47-104)."""
+
+    __slots__ = ("finished_draws", "total_draws", "divergences", "tuning", "started", "latest_num_steps",
+                 "total_num_steps", "step_size", "runtime_ms", "divergent_draws")
+
+    def __init__(self, p: _Progress, divergent_draws):
+        self.finished_draws = int(p.finished_draws)
+        self.total_draws = int(p.total_draws)
+        self.divergences = int(p.divergences)
+        self.tuning = bool(p.tuning)
+        self.started = bool(p.started)
+        self.latest_num_steps = int(p.latest_num_steps)
+        self.total_num_steps = int(p.total_num_steps)
+        self.step_size = float(p.step_size)
+        self.runtime_ms = int(p.runtime_ms)
+        self.divergent_draws = list(divergent_draws)
+
+    @property
+    def num_steps(self):  # backward-compatible alias, wrapper.rs:78-82
+        return self.latest_num_steps
+
+
+_STAT_DTYPES = {
+    "depth": np.int64, "n_steps": np.int64, "index_in_trajectory": np.int64,
+    "diverging": np.bool_, "maxdepth_reached": np.bool_, "tuning": np.bool_,
+    "energy": np.float64, "energy_error": np.float64, "logp": np.float64, "step_size": np.float64,
+    "step_size_bar": np.float64, "mean_tree_accept": np.float64, "mean_tree_accept_sym": np.float64,
+}
+_VECTOR_STATS = ("gradient", "mass_matrix_inv", "divergence_start", "divergence_end", "divergence_momentum", "divergence_start_gradient")
+
+
+class PyTrace:
+    """Dense trace: ``draws[chain, draw, dim]`` + ``stats[name][chain, draw(, dim)]`` + ``finished[chain]``."""
+
+    def __init__(self, draws, stats, finished, chain_offset=0):
+        self.draws = draws
+        self.stats = stats
+        self.finished = finished
+        self.chain_offset = chain_offset
+
+    def is_arrow(self):
+        return False
+
+    def is_zarr(self):
+        return False
+
+    def is_dense(self):
+        return True
+
+
+class PySampler:
+    """Sampler handle (wrapper.rs:953-1457)."""
+
+    def __init__(self, settings: PyNutsSettings, model: _Model, *, device=0, waves_per_chain=0, chain_offset=0,
+                 n_local_chains=0, stream=None, store_draws=True, evals_per_launch=0, start_paused=False):
+        L = lib()
+        la = _Launch()
+        L.nphip_launch_defaults(C.byref(la))
+        la.device = int(device)
+        la.waves_per_chain = int(waves_per_chain)
+        la.chain_offset = int(chain_offset)
+        la.n_local_chains = int(n_local_chains)
+        la.stream = C.c_void_p(stream) if stream else None
+        la.store_draws = int(bool(store_draws))
+        la.evals_per_launch = int(evals_per_launch)
+        la.start_paused = int(bool(start_paused))
+        self._model = model
+        self._settings = settings
+        self._chain_offset = int(chain_offset)
+        self._store_draws = bool(store_draws)
+        h = L.nphip_sampler_create(settings._h, model._h, C.byref(la))
+        if not h:
+            raise RuntimeError(_err())
+        self._h = C.c_void_p(h)
+        self._results = None
+
+    # constructors named as the reference's (wrapper.rs:1189-1250)
+    @classmethod
+    def from_pyfunc(cls, settings, cores, model, progress_type=None, extra_callback=None, extra_callback_rate=None, store=None, **kw):
+        return cls(settings, model, **kw)
+
+    from_pymc = from_pyfunc
+    from_stan = from_pyfunc
+
+    def _require(self):
+        if self._h is None:
+            raise RuntimeError("Sampler is empty (results were taken)")
+
+    @property
+    def num_chains(self):
+        return int(lib().nphip_sampler_num_chains(self._h))
+
+    @property
+    def dim(self):
+        return int(lib().nphip_sampler_dim(self._h))
+
+    @property
+    def total_draws(self):
+        return int(lib().nphip_sampler_total_draws(self._h))
+
+    @property
+    def waves_per_chain(self):
+        return int(lib().nphip_sampler_waves_per_chain(self._h))
+
+    @property
+    def seconds(self):
+        return float(lib().nphip_sampler_seconds(self._h))
+
+    @property
+    def launches(self):
+        return int(lib().nphip_sampler_launches(self._h))
+
+    def wait(self, timeout_seconds=None):
+        """Blocks (GIL released by ctypes) — raises ``TimeoutError`` and leaves the sampler running
+        on timeout (wrapper.rs:1112-1117, 1305-1330)."""
+        self._require()
+        ms = -1 if timeout_seconds is None else max(0, int(timeout_seconds * 1000))
+        # poll in 100 ms slices so KeyboardInterrupt is seen (wrapper.rs:1139-1141)
+        remaining = ms
+        while True:
+            step = 100 if ms < 0 else min(100, remaining)
+            rc = lib().nphip_sampler_wait(self._h, step)
+            if rc == WAIT_DONE:
+                return
+            if rc == WAIT_ERROR:
+                exc = getattr(self._model, "exception", None)
+                if exc is not None:
+                    raise RuntimeError(f"logp callback raised: {exc!r}") from exc
+                raise RuntimeError(_err())
+            if ms >= 0:
+                remaining -= step
+                if remaining <= 0:
+                    raise TimeoutError("Timeout while waiting for sampler to finish")
+
+    def pause(self):
+        self._require()
+        lib().nphip_sampler_pause(self._h)
+
+    def resume(self):
+        self._require()
+        lib().nphip_sampler_resume(self._h)
+
+    def abort(self):
+        self._require()
+        lib().nphip_sampler_abort(self._h)
+
+    def is_finished(self):
+        self._require()
+        return bool(lib().nphip_sampler_is_finished(self._h))
+
+    def is_empty(self, ignore_error=False):
+        return self._h is None
+
+    def progress(self):
+        """list[PyChainProgress], one per local chain."""
+        self._require()
+        n = self.num_chains
+        arr = (_Progress * n)()
+        if lib().nphip_sampler_progress(self._h, C.c_uint64(2**64 - 1), arr) != NPHIP_OK:
+            raise RuntimeError(_err())
+        div = self._copy("diverging", np.bool_)
+        fin = [int(p.finished_draws) for p in arr]
+        return [PyChainProgress(arr[i], np.nonzero(div[i, : fin[i]])[0].tolist()) for i in range(n)]
+
+    def _copy(self, name, dtype, vec=False):
+        n, T, d = self.num_chains, self.total_draws, self.dim
+        shape = (n, T, d) if vec else (n, T)
+        out = np.empty(shape, dtype=dtype)
+        rc = lib().nphip_sampler_copy_stat(self._h, name.encode(), out.ctypes.data_as(C.c_void_p), C.c_uint64(out.nbytes))
+        if rc != NPHIP_OK:
+            raise RuntimeError(_err())
+        return out
+
+    def device_ptr(self, name):
+        return lib().nphip_sampler_device_ptr(self._h, name.encode())
+
+    def _snapshot(self):
+        n = self.num_chains
+        fin = np.zeros(n, dtype=np.uint64)
+        if lib().nphip_sampler_finished_draws(self._h, fin.ctypes.data_as(C.c_void_p)) != NPHIP_OK:
+            raise RuntimeError(_err())
+        stats = {k: self._copy(k, dt) for k, dt in _STAT_DTYPES.items()}
+        for k in _VECTOR_STATS:
+            if self.device_ptr(k):
+                stats[k] = self._copy(k, np.float64, vec=True)
+        draws = self._copy("draws", np.float64, vec=True) if self._store_draws else None
+        return PyTrace(draws, stats, fin.astype(np.int64), self._chain_offset)
+
+    def inspect(self):
+        """Copy of the current state of the trace (wrapper.rs:1401-1429)."""
+        self._require()
+        return self._snapshot()
+
+    def take_results(self):
+        """Transfers the trace and empties the sampler (wrapper.rs:1431-1456)."""
+        self._require()
+        res = self._snapshot()
+        self.close()
+        return res
+
+    def close(self):
+        if self._h is not None:
+            lib().nphip_sampler_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# --------------------------------------------------------------------------- test hooks
+def test_detmath(fn: str, x, device=0):
+    code = {"exp": 0, "log": 1, "log1p": 2, "sin2pi": 3, "cos2pi": 4, "sqrt": 5, "recip": 6}[fn]
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.empty_like(x)
+    if lib().nphip_test_detmath(device, code, C.c_uint64(x.size), x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p)) != NPHIP_OK:
+        raise RuntimeError(_err())
+    return y
+
+
+def test_normals(seed, chain, draw, purpose, n, device=0):
+    x = np.array([seed, chain, draw, purpose], dtype=np.float64)
+    y = np.empty(n)
+    if lib().nphip_test_detmath(device, 7, C.c_uint64(n), x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p)) != NPHIP_OK:
+        raise RuntimeError(_err())
+    return y
+
+
+def test_dot(x, y, waves=1, device=0):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    out = C.c_double()
+    if lib().nphip_test_dot(device, waves, C.c_uint64(x.size), x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), C.byref(out)) != NPHIP_OK:
+        raise RuntimeError(_err())
+    return out.value

@@ -1,0 +1,146 @@
+// engine_types.h — data layout shared by the HIP kernels and the host driver.
+//
+// Everything a chain owns lives in HBM in chain-major order ("[chain][slot][vector][ld]"),
+// so one workgroup streams contiguous rows.  See DESIGN.md §3 for the layout rationale.
+#pragma once
+
+#include <stdint.h>
+
+namespace nphip {
+
+constexpr int kMaxDepthCap = 16;  // settings.maxdepth <= 16 (2^16 leapfrogs per draw)
+
+// ---- phases of the per-chain state machine (Ctl::phase) -------------------------------
+enum Phase : int64_t {
+    PH_START = 0,      // nothing evaluated yet: generate the first initial point
+    PH_INIT_EVAL = 1,  // waiting for logp at an initial point
+    PH_SS_FIRST = 2,   // waiting for the first leapfrog of the step-size search
+    PH_SS_ITER = 3,    // waiting for an iteration leapfrog of the step-size search
+    PH_TREE = 4,       // waiting for a leapfrog inside the NUTS tree
+    PH_DONE = 5,
+    PH_ERROR = 6,
+};
+
+enum ChainError : int64_t {
+    CE_NONE = 0,
+    CE_INIT_FAILED = 1,  // no finite initial point after num_try_init attempts
+    CE_FATAL_LOGP = 2,   // logp callback returned a negative code
+};
+
+// ---- P-slots: (p, rho) pairs.  Assignment is a pure function of the leaf index ---------
+// slot 0            : momentum at the trajectory origin
+// slot 1..4         : trajectory ends, END[dirbit][parity]
+// slot 5 + k        : FIRST[k], k = 0..cap   (first leaf of an open sub-tree of level k)
+// slot 5+cap+1 + k  : LAST[k],  k = 0..cap   (last leaf of a completed sub-tree of level k)
+constexpr int kSlotInit = 0;
+__host__ __device__ inline int slot_end(int dirbit, int parity) { return 1 + 2 * dirbit + parity; }
+__host__ __device__ inline int slot_first(int k) { return 5 + k; }
+__host__ __device__ inline int slot_last(int k, int cap) { return 5 + cap + 1 + k; }
+__host__ __device__ inline int num_pslots(int cap) { return 5 + 2 * (cap + 1); }
+// Q-pool: (q, grad) pairs, allocated by bitmask.  ends(2) + candidate(1) + sub-tree draws(cap) + new leaf(1)
+__host__ __device__ inline int num_qpool(int cap) { return cap + 4; }
+
+// ---- per-chain control block: 8-byte words only (copied HBM <-> LDS word-wise) ----------
+struct Ctl {
+    int64_t phase;
+    int64_t err;
+    int64_t draw;          // draw in progress (== finished draws)
+    int64_t init_attempt;
+    int64_t total_steps;   // cumulative leapfrogs incl. step-size search
+    int64_t n_div;         // cumulative divergent draws
+    int64_t latest_steps;  // n_steps of the last finished draw
+    int64_t eval_buf;      // Q-pool index whose q is (being) evaluated
+    // hamiltonian
+    double step_size;
+    // dual averaging [oracle: struct DualAverage]
+    double da_log_step, da_log_step_adapted, da_hbar, da_mu;
+    int64_t da_count;
+    // adaptation schedule
+    int64_t tuning;
+    int64_t has_initial_mm;
+    int64_t last_update;
+    int64_t fg, fg_count, bg_count;  // fg = index (0/1) of the foreground estimator
+    // step-size search
+    int64_t ss_iter, ss_dir, ss_id;
+    // pending leapfrog
+    int64_t lf_srcq, lf_srcp, lf_newq, lf_newp, lf_sign;
+    // trajectory / tree
+    double H0;
+    double ls_main;
+    int64_t depth, dir, nleaf;
+    int64_t idx_left, idx_right, idx_cur;
+    int64_t endq[2], endp[2], endpar[2];
+    int64_t curq, curp;
+    int64_t cand_q, cand_idx;
+    double cand_U, cand_E;
+    // acceptance collector (incremental means over the leapfrogs of the current draw)
+    double acc_mean, acc_sym_mean;
+    int64_t n_steps;
+    // info of the draw being finished (kept across a mid-adapt step-size search)
+    int64_t fin_depth, fin_flags;
+    double fin_eerr;
+    // sub-tree stack
+    double sub_ls[kMaxDepthCap];
+    double sub_U[kMaxDepthCap];
+    double sub_E[kMaxDepthCap];
+    int64_t sub_q[kMaxDepthCap];
+    int64_t sub_idx[kMaxDepthCap];
+};
+static_assert(sizeof(Ctl) % 8 == 0, "Ctl must be made of 8-byte words");
+constexpr int kCtlWords = sizeof(Ctl) / 8;
+
+// ---- settings as the kernels see them -------------------------------------------------
+struct DevSettings {
+    uint64_t seed;
+    int64_t num_tune, num_draws;
+    int64_t maxdepth, mindepth;
+    int32_t check_turning, use_grad_based, adapt_mass_matrix, fixed_step_size;
+    double max_energy_error;
+    int64_t early_end, final_window;  // derived window bounds
+    int64_t mm_switch_freq, early_mm_switch_freq, mm_update_freq;
+    double initial_step, target_accept, jitter, max_step_size;
+    double da_k, da_t0, da_gamma;
+    int32_t init_kind, num_try_init;
+    int32_t store_draws, store_gradient, store_mass_matrix, store_divergences;
+};
+
+// ---- kernel arguments -------------------------------------------------------------------
+struct Args {
+    DevSettings s;
+    int64_t n_chains;      // local
+    int64_t chain_offset;  // global id of local chain 0
+    int64_t dim, ld;       // ld = dim rounded up to 128
+    int32_t cap;           // maxdepth (slot/pool sizing)
+    int32_t npslots, nqpool;
+    // per-chain state
+    Ctl* ctl;
+    double* qpool;   // [n][nqpool][2][ld]   (q, grad)
+    double* pslots;  // [n][npslots][2][ld]  (p, rho)
+    double* sig2;    // [n][ld]
+    double* est;     // [n][2][4][ld]        (mean_q, m2_q, mean_g, m2_g) x {est0, est1}
+    // model: fused tridiagonal Gaussian
+    const double* m_mu;   // [ld]
+    const double* m_a;    // [ld]
+    const double* m_b;    // [ld]
+    // model: callbacks (dense staging, ld = dim)
+    double* qeval;   // [n][dim]
+    double* geval;   // [n][dim]
+    double* ueval;   // [n]   logp values
+    int64_t* ecode;  // [n]   per-chain callback codes (host callback) or NULL
+    const double* init_points;  // [n][dim] local slice, or NULL
+    // trace
+    double* tr_draws;  // [n][T][dim] or NULL
+    double* tr_grad;   // [n][T][dim] or NULL
+    double* tr_mm;     // [n][T][dim] or NULL
+    double* tr_div[4]; // start, end, momentum, start_gradient: [n][T][dim] or NULL
+    int64_t* st_depth; int64_t* st_nsteps; int64_t* st_idx;
+    uint8_t* st_diverging; uint8_t* st_maxdepth; uint8_t* st_tuning;
+    double* st_energy; double* st_energy_error; double* st_logp; double* st_step; double* st_step_bar;
+    double* st_accept; double* st_accept_sym;
+    // launch control
+    int32_t max_evals;    // fused: evaluations per chain this launch
+    int32_t have_result;  // callbacks: geval/ueval hold the answer to the pending request
+    unsigned long long* counters;  // [0] chains done, [1] chains in error
+};
+
+}  // namespace nphip

@@ -1,0 +1,809 @@
+// host.hip — host driver and C-ABI of libnutpie_hip.so (see include/nutpie_hip.h).
+//
+// Mirrors, for the diag-NUTS path only, what the reference's PyO3 layer does around
+// nuts_rs::Sampler (src/wrapper.rs): a settings object with flat attribute names
+// (wrapper.rs:210-451, 563-620), three model flavours (src/pymc.rs raw C callback,
+// src/pyfunc.rs callable -> batched device callback, fused analytic Gaussian), and a sampler
+// handle with wait/pause/resume/abort/inspect semantics (wrapper.rs:1252-1456).
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <condition_variable>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/nutpie_hip.h"
+#include "engine_types.h"
+
+namespace nphip {
+hipError_t launch_advance(const Args& a, bool fused, int W, hipStream_t st);
+hipError_t launch_test_detmath(int fn, uint64_t n, const double* x, double* y, hipStream_t st);
+hipError_t launch_test_dot(int W, uint64_t n, const double* x, const double* y, double* out, hipStream_t st);
+}  // namespace nphip
+
+using namespace nphip;
+
+namespace {
+
+thread_local std::string t_error;
+void set_error(const std::string& e) { t_error = e; }
+bool hip_ok(hipError_t e, const char* what) {
+    if (e == hipSuccess) return true;
+    set_error(std::string(what) + ": " + hipGetErrorString(e));
+    return false;
+}
+#define HIP_TRY(x) do { if (!hip_ok((x), #x)) return false; } while (0)
+
+}  // namespace
+
+// =========================================================================== settings
+struct nphip_settings {
+    // DiagNutsSettings (reference src/wrapper.rs:19,120,525-533); defaults: SURVEY.md §8c / App. A
+    uint64_t seed = 0;
+    uint64_t num_tune = 400, num_draws = 1000, num_chains = 6;
+    uint64_t maxdepth = 10, mindepth = 0;
+    bool check_turning = true;
+    bool store_unconstrained = false, store_gradient = false, store_transformed = false, store_divergences = false;
+    double max_energy_error = 1000.0;
+    // adapt_options
+    double early_window = 0.3, step_size_window = 0.15;
+    uint64_t mass_matrix_switch_freq = 80, early_mass_matrix_switch_freq = 10, mass_matrix_update_freq = 1;
+    bool store_mass_matrix = false, use_grad_based_estimate = true;
+    // step_size_settings
+    double initial_step = 0.1, target_accept = 0.8;
+    double jitter = 0.0;  // 0 => None
+    double max_step_size = INFINITY;
+    double da_k = 0.75, da_t0 = 10.0, da_gamma = 0.05;
+    bool fixed_step = false;
+    double adam_learning_rate = 0.05;
+    // engine knobs (not in the reference)
+    bool adapt_mass_matrix = true;
+    uint64_t num_try_init = 100;
+};
+
+static int unknown_attr(const char* name) {
+    set_error(std::string("Unknown settings attribute: ") + name);
+    return NPHIP_ERR_UNKNOWN_ATTR;
+}
+static int not_available(const char* name, const char* adaptation) {
+    // wrapper.rs:138-145
+    set_error(std::string("Option ") + name + " not available for " + adaptation + " adaptation");
+    return NPHIP_ERR_NOT_AVAILABLE;
+}
+static int bad_value(const std::string& msg) { set_error(msg); return NPHIP_ERR_BAD_VALUE; }
+
+extern "C" {
+
+const char* nphip_last_error(void) { return t_error.c_str(); }
+const char* nphip_version(void) { return "0.1.0"; }
+int nphip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+nphip_settings_t* nphip_settings_new_diag(uint64_t seed) {
+    auto* s = new nphip_settings();
+    s->seed = seed;
+    return s;
+}
+nphip_settings_t* nphip_settings_clone(const nphip_settings_t* s) { return new nphip_settings(*s); }
+void nphip_settings_free(nphip_settings_t* s) { delete s; }
+
+int nphip_settings_set_f64(nphip_settings_t* s, const char* name, double v) {
+    std::string n(name);
+    if (n == "initial_step") s->initial_step = v;
+    else if (n == "target_accept") s->target_accept = v;
+    else if (n == "max_step_size") s->max_step_size = v;
+    else if (n == "max_energy_error") s->max_energy_error = v;
+    else if (n == "step_size_jitter") {
+        if (v < 0.0) return bad_value("step_size_jitter must be positive");  // wrapper.rs:394-396
+        s->jitter = v;
+    }
+    else if (n == "step_size_adam_learning_rate") s->adam_learning_rate = v;
+    else if (n == "mass_matrix_eigval_cutoff" || n == "mass_matrix_gamma") return not_available(name, "diag");
+    else if (n == "target_integration_time") return bad_value("target_integration_time is not supported by the HIP engine");
+    else if (n == "early_window") s->early_window = v;
+    else if (n == "step_size_window") s->step_size_window = v;
+    else if (n == "da_k") s->da_k = v;
+    else if (n == "da_t0") s->da_t0 = v;
+    else if (n == "da_gamma") s->da_gamma = v;
+    else return unknown_attr(name);
+    return NPHIP_OK;
+}
+
+int nphip_settings_set_u64(nphip_settings_t* s, const char* name, uint64_t v) {
+    std::string n(name);
+    if (n == "num_tune") s->num_tune = v;
+    else if (n == "num_draws") s->num_draws = v;
+    else if (n == "num_chains") s->num_chains = v;
+    else if (n == "maxdepth") {
+        if (v < 1 || v > (uint64_t)kMaxDepthCap) return bad_value("maxdepth must be between 1 and 16 for the HIP engine");
+        s->maxdepth = v;
+    }
+    else if (n == "mindepth") s->mindepth = v;
+    else if (n == "window_switch_freq" || n == "mass_matrix_switch_freq") s->mass_matrix_switch_freq = v;  // wrapper.rs:214-229, 291-303
+    else if (n == "early_window_switch_freq") s->early_mass_matrix_switch_freq = v;
+    else if (n == "mass_matrix_update_freq") s->mass_matrix_update_freq = v;
+    else if (n == "extra_doublings") { if (v != 0) return bad_value("extra_doublings is not supported by the HIP engine"); }
+    else if (n == "seed") s->seed = v;
+    else if (n == "num_try_init") s->num_try_init = v;
+    else return unknown_attr(name);
+    return NPHIP_OK;
+}
+
+int nphip_settings_set_bool(nphip_settings_t* s, const char* name, int v) {
+    std::string n(name);
+    const bool b = v != 0;
+    if (n == "check_turning") s->check_turning = b;
+    else if (n == "store_mass_matrix") s->store_mass_matrix = b;
+    else if (n == "use_grad_based_mass_matrix") s->use_grad_based_estimate = b;
+    else if (n == "store_unconstrained") s->store_unconstrained = b;
+    else if (n == "store_gradient") s->store_gradient = b;
+    else if (n == "store_transformed") s->store_transformed = b;
+    else if (n == "store_divergences") s->store_divergences = b;
+    else if (n == "train_on_orbit") return not_available(name, "diag");  // wrapper.rs:331-343
+    else if (n == "microcanonical_trajectory" || n == "exact_normal_trajectory") {
+        if (b) return bad_value(std::string(name) + " is not supported by the HIP engine");
+    }
+    else if (n == "adapt_mass_matrix") s->adapt_mass_matrix = b;
+    else return unknown_attr(name);
+    return NPHIP_OK;
+}
+
+int nphip_settings_set_str(nphip_settings_t* s, const char* name, const char* v) {
+    std::string n(name), val(v);
+    if (n == "step_size_adapt_method") {  // wrapper.rs:344-376
+        if (val == "dual_average") { s->fixed_step = false; return NPHIP_OK; }
+        if (val == "adam") return bad_value("step_size_adapt_method 'adam' is not supported by the HIP engine");
+        char* end = nullptr;
+        double step = strtod(v, &end);
+        if (end == v || *end != '\0' || !(step > 0.0))
+            return bad_value("step_size_adapt_method must be a positive float when using fixed step size");
+        s->fixed_step = true;
+        s->initial_step = step;
+        return NPHIP_OK;
+    }
+    return unknown_attr(name);
+}
+
+int nphip_settings_get_f64(const nphip_settings_t* s, const char* name, double* out) {
+    std::string n(name);
+    if (n == "initial_step") *out = s->initial_step;
+    else if (n == "target_accept") *out = s->target_accept;
+    else if (n == "max_step_size") *out = s->max_step_size;
+    else if (n == "max_energy_error") *out = s->max_energy_error;
+    else if (n == "step_size_jitter") *out = s->jitter;
+    else if (n == "early_window") *out = s->early_window;
+    else if (n == "step_size_window") *out = s->step_size_window;
+    else return unknown_attr(name);
+    return NPHIP_OK;
+}
+
+int nphip_settings_get_u64(const nphip_settings_t* s, const char* name, uint64_t* out) {
+    std::string n(name);
+    if (n == "num_tune") *out = s->num_tune;
+    else if (n == "num_draws") *out = s->num_draws;
+    else if (n == "num_chains") *out = s->num_chains;
+    else if (n == "maxdepth") *out = s->maxdepth;
+    else if (n == "mindepth") *out = s->mindepth;
+    else if (n == "seed") *out = s->seed;
+    else if (n == "mass_matrix_switch_freq" || n == "window_switch_freq") *out = s->mass_matrix_switch_freq;
+    else if (n == "early_window_switch_freq") *out = s->early_mass_matrix_switch_freq;
+    else if (n == "check_turning") *out = s->check_turning;
+    else if (n == "store_mass_matrix") *out = s->store_mass_matrix;
+    else if (n == "use_grad_based_mass_matrix") *out = s->use_grad_based_estimate;
+    else if (n == "store_unconstrained") *out = s->store_unconstrained;
+    else if (n == "store_gradient") *out = s->store_gradient;
+    else if (n == "store_divergences") *out = s->store_divergences;
+    else if (n == "store_transformed") *out = s->store_transformed;
+    else return unknown_attr(name);
+    return NPHIP_OK;
+}
+
+static std::string jnum(double v) {
+    if (!std::isfinite(v)) return "null";
+    char b[64];
+    snprintf(b, sizeof(b), "%.17g", v);
+    return b;
+}
+static const char* jb(bool v) { return v ? "true" : "false"; }
+
+int64_t nphip_settings_to_json(const nphip_settings_t* s, char* buf, int64_t cap) {
+    // nested layout of DiagNutsSettings as serde writes it (field paths: wrapper.rs:217-447)
+    std::string j = "{";
+    j += "\"num_tune\":" + std::to_string(s->num_tune);
+    j += ",\"num_draws\":" + std::to_string(s->num_draws);
+    j += ",\"maxdepth\":" + std::to_string(s->maxdepth);
+    j += ",\"mindepth\":" + std::to_string(s->mindepth);
+    j += std::string(",\"store_gradient\":") + jb(s->store_gradient);
+    j += std::string(",\"store_unconstrained\":") + jb(s->store_unconstrained);
+    j += std::string(",\"store_transformed\":") + jb(s->store_transformed);
+    j += ",\"max_energy_error\":" + jnum(s->max_energy_error);
+    j += std::string(",\"store_divergences\":") + jb(s->store_divergences);
+    j += ",\"adapt_options\":{";
+    j += "\"step_size_settings\":{\"initial_step\":" + jnum(s->initial_step) + ",\"target_accept\":" + jnum(s->target_accept);
+    j += ",\"jitter\":" + (s->jitter > 0 ? jnum(s->jitter) : std::string("null"));
+    j += ",\"adapt_options\":{\"method\":" + (s->fixed_step ? "{\"fixed\":" + jnum(s->initial_step) + "}" : std::string("\"dual_average\""));
+    j += ",\"dual_average\":{\"k\":" + jnum(s->da_k) + ",\"t0\":" + jnum(s->da_t0) + ",\"gamma\":" + jnum(s->da_gamma) +
+         ",\"max_step_size\":" + jnum(s->max_step_size) + "}";
+    j += ",\"adam\":{\"learning_rate\":" + jnum(s->adam_learning_rate) + "}}}";
+    j += std::string(",\"mass_matrix_options\":{\"store_mass_matrix\":") + jb(s->store_mass_matrix) +
+         ",\"use_grad_based_estimate\":" + jb(s->use_grad_based_estimate) + "}";
+    j += ",\"early_window\":" + jnum(s->early_window) + ",\"step_size_window\":" + jnum(s->step_size_window);
+    j += ",\"mass_matrix_switch_freq\":" + std::to_string(s->mass_matrix_switch_freq);
+    j += ",\"early_mass_matrix_switch_freq\":" + std::to_string(s->early_mass_matrix_switch_freq);
+    j += ",\"mass_matrix_update_freq\":" + std::to_string(s->mass_matrix_update_freq) + "}";
+    j += std::string(",\"check_turning\":") + jb(s->check_turning);
+    j += ",\"target_integration_time\":null,\"extra_doublings\":0,\"trajectory_kind\":\"euclidean\"";
+    j += ",\"num_chains\":" + std::to_string(s->num_chains);
+    j += ",\"seed\":" + std::to_string(s->seed);
+    j += "}";
+    int64_t need = (int64_t)j.size() + 1;
+    if (buf && cap > 0) {
+        int64_t n = need <= cap ? need - 1 : cap - 1;
+        memcpy(buf, j.data(), (size_t)n);
+        buf[n] = 0;
+    }
+    return need;
+}
+
+}  // extern "C"
+
+// =========================================================================== models
+struct nphip_model {
+    int kind = 0;  // 0 fused tridiag, 1 host callback, 2 device callback
+    uint64_t dim = 0;
+    std::vector<double> mu, a, b;
+    nphip_raw_logp_fn host_fn = nullptr;
+    nphip_device_logp_fn dev_fn = nullptr;
+    void* user = nullptr;
+    int n_threads = 0;
+    int init_kind = 0;
+    std::vector<double> init_points;
+    uint64_t n_init_points = 0;
+};
+
+extern "C" {
+
+nphip_model_t* nphip_model_tridiag_gaussian(uint64_t dim, const double* mu, const double* diag, const double* offdiag) {
+    if (dim == 0 || !diag) { set_error("tridiag model needs dim > 0 and a diagonal"); return nullptr; }
+    auto* m = new nphip_model();
+    m->kind = 0; m->dim = dim;
+    m->mu.assign(dim, 0.0); if (mu) m->mu.assign(mu, mu + dim);
+    m->a.assign(diag, diag + dim);
+    m->b.assign(dim, 0.0); if (offdiag && dim > 1) std::copy(offdiag, offdiag + dim - 1, m->b.begin());
+    return m;
+}
+nphip_model_t* nphip_model_host_callback(uint64_t dim, nphip_raw_logp_fn fn, void* user_data, int n_threads) {
+    if (dim == 0 || !fn) { set_error("host callback model needs dim > 0 and a function"); return nullptr; }
+    auto* m = new nphip_model();
+    m->kind = 1; m->dim = dim; m->host_fn = fn; m->user = user_data; m->n_threads = n_threads;
+    return m;
+}
+nphip_model_t* nphip_model_device_callback(uint64_t dim, nphip_device_logp_fn fn, void* user_data) {
+    if (dim == 0 || !fn) { set_error("device callback model needs dim > 0 and a function"); return nullptr; }
+    auto* m = new nphip_model();
+    m->kind = 2; m->dim = dim; m->dev_fn = fn; m->user = user_data;
+    return m;
+}
+int nphip_model_set_init(nphip_model_t* m, int kind, const double* points, uint64_t n_points) {
+    if (kind < 0 || kind > 2) return bad_value("init kind must be 0, 1 or 2");
+    if (kind == 2 && (!points || n_points == 0)) return bad_value("explicit init needs points");
+    m->init_kind = kind;
+    m->init_points.clear();
+    m->n_init_points = 0;
+    if (kind == 2) { m->init_points.assign(points, points + n_points * m->dim); m->n_init_points = n_points; }
+    return NPHIP_OK;
+}
+uint64_t nphip_model_dim(const nphip_model_t* m) { return m->dim; }
+void nphip_model_free(nphip_model_t* m) { delete m; }
+
+void nphip_launch_defaults(nphip_launch_t* l) {
+    memset(l, 0, sizeof(*l));
+    l->store_draws = 1;
+}
+
+}  // extern "C"
+
+// =========================================================================== sampler
+namespace {
+
+// tiny persistent pool for the host-callback flavour: rows of the batch are evaluated
+// concurrently, exactly as the reference evaluates chains on `cores` threads (sample.py:856-857)
+struct RowPool {
+    std::vector<std::thread> threads;
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    uint64_t generation = 0;
+    std::atomic<uint64_t> next{0};
+    uint64_t n_rows = 0;
+    int pending = 0;
+    bool stop = false;
+    std::function<void(uint64_t)> job;
+    explicit RowPool(int n) {
+        for (int i = 0; i < n; ++i) threads.emplace_back([this] { loop(); });
+    }
+    ~RowPool() {
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        cv_work.notify_all();
+        for (auto& t : threads) t.join();
+    }
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_work.wait(lk, [&] { return stop || generation != seen; });
+                if (stop) return;
+                seen = generation;
+            }
+            for (;;) {
+                uint64_t r = next.fetch_add(1);
+                if (r >= n_rows) break;
+                job(r);
+            }
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (--pending == 0) cv_done.notify_all();
+            }
+        }
+    }
+    void run(uint64_t rows, std::function<void(uint64_t)> f) {
+        if (threads.empty()) { for (uint64_t r = 0; r < rows; ++r) f(r); return; }
+        std::unique_lock<std::mutex> lk(mu);
+        job = std::move(f);
+        n_rows = rows;
+        next.store(0);
+        pending = (int)threads.size();
+        ++generation;
+        cv_work.notify_all();
+        cv_done.wait(lk, [&] { return pending == 0; });
+    }
+};
+
+}  // namespace
+
+struct nphip_sampler {
+    nphip_settings set;
+    nphip_model model;
+    nphip_launch_t launch;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    Args args;
+    int W = 1;
+    bool fused = true;
+    uint64_t n = 0, T = 0, dim = 0;
+    std::vector<void*> allocs;
+    std::vector<void*> pinned;
+    unsigned long long* h_counters = nullptr;  // pinned
+    double *h_q = nullptr, *h_g = nullptr, *h_u = nullptr;  // pinned staging (host callback)
+    int64_t* h_code = nullptr;
+    std::unique_ptr<RowPool> pool;
+
+    std::thread th;
+    std::mutex mu;       // state
+    std::mutex mu_run;   // held by the driver for one launch iteration; by readers while copying
+    std::condition_variable cv;
+    bool want_pause = false, want_abort = false;
+    bool finished = false, failed = false, thread_done = false;
+    std::string error;
+    std::chrono::steady_clock::time_point t_start;
+    std::atomic<double> seconds{0.0};
+    std::atomic<uint64_t> launches{0};
+
+    template <class Tp>
+    bool dalloc(Tp** p, size_t count, int fill = 0) {
+        void* d = nullptr;
+        size_t bytes = count * sizeof(Tp);
+        if (bytes == 0) bytes = 8;
+        if (!hip_ok(hipMalloc(&d, bytes), "hipMalloc")) return false;
+        allocs.push_back(d);
+        if (!hip_ok(hipMemsetAsync(d, fill, bytes, stream), "hipMemset")) return false;
+        *p = reinterpret_cast<Tp*>(d);
+        return true;
+    }
+    template <class Tp>
+    bool palloc(Tp** p, size_t count) {
+        void* h = nullptr;
+        if (!hip_ok(hipHostMalloc(&h, count * sizeof(Tp) + 8, hipHostMallocDefault), "hipHostMalloc")) return false;
+        pinned.push_back(h);
+        memset(h, 0, count * sizeof(Tp) + 8);
+        *p = reinterpret_cast<Tp*>(h);
+        return true;
+    }
+
+    bool setup();
+    void run();
+    bool iteration_fused(bool& all_done);
+    bool iteration_callback(bool& all_done, int& have);
+    void fail(const std::string& msg) {
+        std::lock_guard<std::mutex> lk(mu);
+        failed = true;
+        error = msg;
+    }
+    std::string chain_error_message();
+    void release() {
+        for (void* d : allocs) (void)hipFree(d);
+        allocs.clear();
+        for (void* h : pinned) (void)hipHostFree(h);
+        pinned.clear();
+        if (own_stream && stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
+    }
+};
+
+static int choose_waves(uint64_t dim) {
+    if (dim <= 2048) return 1;
+    if (dim <= 4096) return 2;
+    if (dim <= 16384) return 4;
+    if (dim <= 65536) return 8;
+    return 16;
+}
+
+bool nphip_sampler::setup() {
+    HIP_TRY(hipSetDevice(device));
+    if (launch.stream) { stream = (hipStream_t)launch.stream; own_stream = false; }
+    else { HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)); own_stream = true; }
+    dim = model.dim;
+    n = launch.n_local_chains ? launch.n_local_chains : set.num_chains;
+    T = set.num_tune + set.num_draws;
+    fused = model.kind == 0;
+    W = launch.waves_per_chain ? launch.waves_per_chain : choose_waves(dim);
+    if (!(W == 1 || W == 2 || W == 4 || W == 8 || W == 16)) { set_error("waves_per_chain must be 1, 2, 4, 8 or 16"); return false; }
+    if (n == 0 || dim == 0) { set_error("need at least one chain and one dimension"); return false; }
+
+    memset(&args, 0, sizeof(args));
+    DevSettings& s = args.s;
+    s.seed = set.seed;
+    s.num_tune = (int64_t)set.num_tune; s.num_draws = (int64_t)set.num_draws;
+    s.maxdepth = (int64_t)set.maxdepth; s.mindepth = (int64_t)set.mindepth;
+    s.check_turning = set.check_turning; s.use_grad_based = set.use_grad_based_estimate;
+    s.adapt_mass_matrix = set.adapt_mass_matrix; s.fixed_step_size = set.fixed_step;
+    s.max_energy_error = set.max_energy_error;
+    // window bounds
+    s.early_end = (int64_t)std::ceil((double)set.num_tune * set.early_window);
+    {
+        uint64_t ssw = (uint64_t)std::ceil((double)set.num_tune * set.step_size_window);
+        s.final_window = (int64_t)((set.num_tune > ssw ? set.num_tune - ssw : 0) + 1);
+    }
+    s.mm_switch_freq = (int64_t)set.mass_matrix_switch_freq;
+    s.early_mm_switch_freq = (int64_t)set.early_mass_matrix_switch_freq;
+    s.mm_update_freq = (int64_t)set.mass_matrix_update_freq;
+    s.initial_step = set.initial_step; s.target_accept = set.target_accept;
+    s.jitter = set.jitter; s.max_step_size = set.max_step_size;
+    s.da_k = set.da_k; s.da_t0 = set.da_t0; s.da_gamma = set.da_gamma;
+    s.init_kind = model.init_kind; s.num_try_init = (int32_t)set.num_try_init;
+    s.store_draws = launch.store_draws; s.store_gradient = set.store_gradient;
+    s.store_mass_matrix = set.store_mass_matrix; s.store_divergences = set.store_divergences;
+
+    args.n_chains = (int64_t)n;
+    args.chain_offset = (int64_t)launch.chain_offset;
+    args.dim = (int64_t)dim;
+    args.ld = (int64_t)((dim + 127) / 128 * 128);
+    args.cap = (int32_t)set.maxdepth;
+    args.npslots = num_pslots(args.cap);
+    args.nqpool = num_qpool(args.cap);
+    const size_t ld = (size_t)args.ld;
+
+    if (!dalloc(&args.ctl, n)) return false;
+    if (!dalloc(&args.qpool, n * args.nqpool * 2 * ld)) return false;
+    if (!dalloc(&args.pslots, n * args.npslots * 2 * ld)) return false;
+    if (!dalloc(&args.sig2, n * ld)) return false;
+    if (!dalloc(&args.est, n * 8 * ld)) return false;
+    if (!dalloc(&args.counters, 2)) return false;
+    if (fused) {
+        double *mu = nullptr, *a = nullptr, *b = nullptr;
+        if (!dalloc(&mu, ld) || !dalloc(&a, ld) || !dalloc(&b, ld)) return false;
+        HIP_TRY(hipMemcpyAsync(mu, model.mu.data(), dim * 8, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(a, model.a.data(), dim * 8, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(b, model.b.data(), dim * 8, hipMemcpyHostToDevice, stream));
+        args.m_mu = mu; args.m_a = a; args.m_b = b;
+    } else {
+        if (!dalloc(&args.qeval, n * dim) || !dalloc(&args.geval, n * dim) || !dalloc(&args.ueval, n)) return false;
+        if (model.kind == 1) {
+            if (!dalloc(&args.ecode, n)) return false;
+            if (!palloc(&h_q, n * dim) || !palloc(&h_g, n * dim) || !palloc(&h_u, n) || !palloc(&h_code, n)) return false;
+            int nt = model.n_threads > 0 ? model.n_threads : (int)std::thread::hardware_concurrency();
+            if (nt < 1) nt = 1;
+            if ((uint64_t)nt > n) nt = (int)n;
+            pool.reset(new RowPool(nt > 1 ? nt : 0));
+        }
+    }
+    if (model.init_kind == 2) {
+        if (model.n_init_points < launch.chain_offset + n) { set_error("explicit init points do not cover all chains"); return false; }
+        double* ip = nullptr;
+        if (!dalloc(&ip, n * dim)) return false;
+        HIP_TRY(hipMemcpyAsync(ip, model.init_points.data() + launch.chain_offset * dim, n * dim * 8, hipMemcpyHostToDevice, stream));
+        args.init_points = ip;
+    }
+    const size_t nt = (size_t)n * T;
+    if (launch.store_draws && !dalloc(&args.tr_draws, nt * dim)) return false;
+    if (set.store_gradient && !dalloc(&args.tr_grad, nt * dim)) return false;
+    if (set.store_mass_matrix && !dalloc(&args.tr_mm, nt * dim)) return false;
+    if (set.store_divergences)
+        for (int k = 0; k < 4; ++k)
+            if (!dalloc(&args.tr_div[k], nt * dim, 0xFF)) return false;  // all-ones = NaN
+    if (!dalloc(&args.st_depth, nt) || !dalloc(&args.st_nsteps, nt) || !dalloc(&args.st_idx, nt)) return false;
+    if (!dalloc(&args.st_diverging, nt) || !dalloc(&args.st_maxdepth, nt) || !dalloc(&args.st_tuning, nt)) return false;
+    if (!dalloc(&args.st_energy, nt) || !dalloc(&args.st_energy_error, nt) || !dalloc(&args.st_logp, nt)) return false;
+    if (!dalloc(&args.st_step, nt) || !dalloc(&args.st_step_bar, nt)) return false;
+    if (!dalloc(&args.st_accept, nt) || !dalloc(&args.st_accept_sym, nt)) return false;
+    if (!palloc(&h_counters, 2)) return false;
+    HIP_TRY(hipStreamSynchronize(stream));
+    return true;
+}
+
+std::string nphip_sampler::chain_error_message() {
+    std::vector<Ctl> h(n);
+    if (hipMemcpy(h.data(), args.ctl, n * sizeof(Ctl), hipMemcpyDeviceToHost) != hipSuccess) return "chain error";
+    for (uint64_t i = 0; i < n; ++i) {
+        if (h[i].phase == PH_ERROR) {
+            std::string c = "chain " + std::to_string(launch.chain_offset + i) + ": ";
+            if (h[i].err == CE_INIT_FAILED) return c + "could not find a finite initial point (logp or gradient not finite)";
+            if (h[i].err == CE_FATAL_LOGP) return c + "logp function returned a fatal error";
+            return c + "unknown error";
+        }
+    }
+    return "chain error";
+}
+
+bool nphip_sampler::iteration_fused(bool& all_done) {
+    args.max_evals = launch.evals_per_launch > 0 ? launch.evals_per_launch : 512;
+    args.have_result = 0;
+    if (!hip_ok(launch_advance(args, true, W, stream), "launch k_advance")) return false;
+    launches.fetch_add(1);
+    if (!hip_ok(hipMemcpyAsync(h_counters, args.counters, 16, hipMemcpyDeviceToHost, stream), "copy counters")) return false;
+    if (!hip_ok(hipStreamSynchronize(stream), "hipStreamSynchronize")) return false;
+    if (h_counters[1] > 0) { set_error(chain_error_message()); return false; }
+    all_done = h_counters[0] >= n;
+    return true;
+}
+
+bool nphip_sampler::iteration_callback(bool& all_done, int& have) {
+    args.max_evals = 0;
+    args.have_result = have;
+    if (!hip_ok(launch_advance(args, false, W, stream), "launch k_advance")) return false;
+    launches.fetch_add(1);
+    if (model.kind == 1) {
+        // host callback: D2H positions, evaluate rows on the host pool, H2D gradients
+        // (pinned hipMemcpyAsync; the reference calls the same function pointer once per
+        // chain-step from its worker threads: src/pymc.rs:197-215)
+        if (!hip_ok(hipMemcpyAsync(h_q, args.qeval, n * dim * 8, hipMemcpyDeviceToHost, stream), "D2H q")) return false;
+        if (!hip_ok(hipMemcpyAsync(h_counters, args.counters, 16, hipMemcpyDeviceToHost, stream), "copy counters")) return false;
+        if (!hip_ok(hipStreamSynchronize(stream), "hipStreamSynchronize")) return false;
+        if (h_counters[1] > 0) { set_error(chain_error_message()); return false; }
+        if (h_counters[0] >= n) { all_done = true; return true; }
+        const uint64_t d = dim;
+        pool->run(n, [this, d](uint64_t r) {
+            double lp = NAN;
+            h_code[r] = model.host_fn(d, h_q + r * d, h_g + r * d, &lp, model.user);
+            h_u[r] = lp;
+        });
+        if (!hip_ok(hipMemcpyAsync(args.geval, h_g, n * dim * 8, hipMemcpyHostToDevice, stream), "H2D grad")) return false;
+        if (!hip_ok(hipMemcpyAsync(args.ueval, h_u, n * 8, hipMemcpyHostToDevice, stream), "H2D logp")) return false;
+        if (!hip_ok(hipMemcpyAsync(args.ecode, h_code, n * 8, hipMemcpyHostToDevice, stream), "H2D code")) return false;
+    } else {
+        // device callback: counters are polled without synchronising (stale values only delay exit)
+        if (!hip_ok(hipMemcpyAsync(h_counters, args.counters, 16, hipMemcpyDeviceToHost, stream), "copy counters")) return false;
+        volatile unsigned long long* hc = h_counters;
+        if (hc[1] > 0) {
+            (void)hipStreamSynchronize(stream);
+            set_error(chain_error_message());
+            return false;
+        }
+        if (hc[0] >= n) { all_done = true; return hip_ok(hipStreamSynchronize(stream), "hipStreamSynchronize"); }
+        int rc = model.dev_fn(n, dim, args.qeval, args.geval, args.ueval, (void*)stream, model.user);
+        if (rc < 0) {
+            (void)hipStreamSynchronize(stream);
+            set_error("device logp callback failed (code " + std::to_string(rc) + ")");
+            return false;
+        }
+    }
+    have = 1;
+    return true;
+}
+
+void nphip_sampler::run() {
+    (void)hipSetDevice(device);
+    t_start = std::chrono::steady_clock::now();
+    int have = 0;
+    bool all_done = false;
+    for (;;) {
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return !want_pause || want_abort; });
+            if (want_abort) break;
+        }
+        bool ok;
+        {
+            std::lock_guard<std::mutex> run_lk(mu_run);
+            ok = fused ? iteration_fused(all_done) : iteration_callback(all_done, have);
+        }
+        seconds.store(std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count());
+        if (!ok) { fail(t_error); break; }
+        if (all_done) break;
+    }
+    (void)hipStreamSynchronize(stream);
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        finished = all_done && !failed;
+        thread_done = true;
+    }
+    cv.notify_all();
+}
+
+extern "C" {
+
+nphip_sampler_t* nphip_sampler_create(const nphip_settings_t* set, const nphip_model_t* model, const nphip_launch_t* launch) {
+    if (!set || !model) { set_error("null settings or model"); return nullptr; }
+    auto* s = new nphip_sampler();
+    s->set = *set;
+    s->model = *model;
+    if (launch) s->launch = *launch; else nphip_launch_defaults(&s->launch);
+    s->device = s->launch.device;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        set_error("no HIP device available: the nutpie-hip engine requires an AMD GPU (no CPU fallback)");
+        delete s;
+        return nullptr;
+    }
+    if (!s->setup()) { s->release(); delete s; return nullptr; }
+    s->want_pause = s->launch.start_paused != 0;
+    s->th = std::thread([s] { s->run(); });
+    return s;
+}
+
+void nphip_sampler_free(nphip_sampler_t* s) {
+    if (!s) return;
+    { std::lock_guard<std::mutex> lk(s->mu); s->want_abort = true; }
+    s->cv.notify_all();
+    if (s->th.joinable()) s->th.join();
+    (void)hipSetDevice(s->device);
+    s->pool.reset();
+    s->release();
+    delete s;
+}
+
+int nphip_sampler_wait(nphip_sampler_t* s, int64_t timeout_ms) {
+    std::unique_lock<std::mutex> lk(s->mu);
+    if (s->want_pause) { s->want_pause = false; s->cv.notify_all(); }  // wait resumes (sample.py:596-608)
+    auto done = [&] { return s->thread_done; };
+    if (timeout_ms < 0) s->cv.wait(lk, done);
+    else if (!s->cv.wait_for(lk, std::chrono::milliseconds(timeout_ms), done)) return NPHIP_WAIT_TIMEOUT;
+    if (s->failed) { set_error(s->error); return NPHIP_WAIT_ERROR; }
+    return NPHIP_WAIT_DONE;
+}
+int nphip_sampler_pause(nphip_sampler_t* s) {
+    std::lock_guard<std::mutex> lk(s->mu);
+    s->want_pause = true;
+    return NPHIP_OK;
+}
+int nphip_sampler_resume(nphip_sampler_t* s) {
+    { std::lock_guard<std::mutex> lk(s->mu); s->want_pause = false; }
+    s->cv.notify_all();
+    return NPHIP_OK;
+}
+int nphip_sampler_abort(nphip_sampler_t* s) {
+    { std::lock_guard<std::mutex> lk(s->mu); s->want_abort = true; }
+    s->cv.notify_all();
+    if (s->th.joinable()) s->th.join();
+    return NPHIP_OK;
+}
+int nphip_sampler_is_finished(nphip_sampler_t* s) {
+    std::lock_guard<std::mutex> lk(s->mu);
+    return s->thread_done ? 1 : 0;
+}
+int nphip_sampler_waves_per_chain(const nphip_sampler_t* s) { return s->W; }
+uint64_t nphip_sampler_num_chains(const nphip_sampler_t* s) { return s->n; }
+uint64_t nphip_sampler_dim(const nphip_sampler_t* s) { return s->dim; }
+uint64_t nphip_sampler_total_draws(const nphip_sampler_t* s) { return s->T; }
+double nphip_sampler_seconds(const nphip_sampler_t* s) { return s->seconds.load(); }
+uint64_t nphip_sampler_launches(const nphip_sampler_t* s) { return s->launches.load(); }
+
+static bool read_ctl(nphip_sampler_t* s, std::vector<Ctl>& h) {
+    h.resize(s->n);
+    std::lock_guard<std::mutex> run_lk(s->mu_run);
+    (void)hipSetDevice(s->device);
+    if (!hip_ok(hipStreamSynchronize(s->stream), "sync")) return false;
+    return hip_ok(hipMemcpy(h.data(), s->args.ctl, s->n * sizeof(Ctl), hipMemcpyDeviceToHost), "copy ctl");
+}
+
+int nphip_sampler_progress(nphip_sampler_t* s, uint64_t chain, nphip_chain_progress_t* out) {
+    // chain == UINT64_MAX: fill out[0..n) for all local chains
+    std::vector<Ctl> h;
+    if (!read_ctl(s, h)) return NPHIP_ERR;
+    const uint64_t lo = chain == UINT64_MAX ? 0 : chain, hi = chain == UINT64_MAX ? s->n : chain + 1;
+    if (hi > s->n) { set_error("chain index out of range"); return NPHIP_ERR; }
+    const uint64_t ms = (uint64_t)(s->seconds.load() * 1000.0);
+    for (uint64_t i = lo; i < hi; ++i) {
+        nphip_chain_progress_t& p = out[i - lo];
+        p.finished_draws = (uint64_t)h[i].draw;
+        p.total_draws = s->T;
+        p.divergences = (uint64_t)h[i].n_div;
+        p.tuning = h[i].draw < (int64_t)s->set.num_tune;
+        p.started = h[i].phase != PH_START;
+        p.latest_num_steps = (uint64_t)h[i].latest_steps;
+        p.total_num_steps = (uint64_t)h[i].total_steps;
+        p.step_size = h[i].step_size;
+        p.runtime_ms = ms;
+    }
+    return NPHIP_OK;
+}
+
+int nphip_sampler_finished_draws(nphip_sampler_t* s, uint64_t* finished) {
+    std::vector<Ctl> h;
+    if (!read_ctl(s, h)) return NPHIP_ERR;
+    for (uint64_t i = 0; i < s->n; ++i) finished[i] = (uint64_t)h[i].draw;
+    return NPHIP_OK;
+}
+
+static void* stat_ptr(nphip_sampler_t* s, const std::string& n, size_t* bytes) {
+    const Args& a = s->args;
+    const size_t nt = (size_t)s->n * s->T, d = s->dim;
+    struct E { const char* name; void* p; size_t b; };
+    const E table[] = {
+        {"draws", a.tr_draws, nt * d * 8}, {"gradient", a.tr_grad, nt * d * 8}, {"mass_matrix_inv", a.tr_mm, nt * d * 8},
+        {"divergence_start", a.tr_div[0], nt * d * 8}, {"divergence_end", a.tr_div[1], nt * d * 8},
+        {"divergence_momentum", a.tr_div[2], nt * d * 8}, {"divergence_start_gradient", a.tr_div[3], nt * d * 8},
+        {"depth", a.st_depth, nt * 8}, {"n_steps", a.st_nsteps, nt * 8}, {"index_in_trajectory", a.st_idx, nt * 8},
+        {"diverging", a.st_diverging, nt}, {"maxdepth_reached", a.st_maxdepth, nt}, {"tuning", a.st_tuning, nt},
+        {"energy", a.st_energy, nt * 8}, {"energy_error", a.st_energy_error, nt * 8}, {"logp", a.st_logp, nt * 8},
+        {"step_size", a.st_step, nt * 8}, {"step_size_bar", a.st_step_bar, nt * 8},
+        {"mean_tree_accept", a.st_accept, nt * 8}, {"mean_tree_accept_sym", a.st_accept_sym, nt * 8},
+    };
+    for (const E& e : table)
+        if (n == e.name) { *bytes = e.b; return e.p; }
+    return nullptr;
+}
+
+int nphip_sampler_copy_stat(nphip_sampler_t* s, const char* name, void* host_out, uint64_t nbytes) {
+    size_t bytes = 0;
+    void* p = stat_ptr(s, name, &bytes);
+    if (!p) { set_error(std::string("trace has no array named ") + name); return NPHIP_ERR; }
+    if (nbytes != bytes) { set_error("size mismatch for " + std::string(name)); return NPHIP_ERR; }
+    std::lock_guard<std::mutex> run_lk(s->mu_run);
+    (void)hipSetDevice(s->device);
+    if (!hip_ok(hipStreamSynchronize(s->stream), "sync")) return NPHIP_ERR;
+    if (!hip_ok(hipMemcpy(host_out, p, bytes, hipMemcpyDeviceToHost), "copy trace")) return NPHIP_ERR;
+    return NPHIP_OK;
+}
+
+void* nphip_sampler_device_ptr(nphip_sampler_t* s, const char* name) {
+    size_t bytes = 0;
+    return stat_ptr(s, name, &bytes);
+}
+
+// ---- test hooks ------------------------------------------------------------------------
+int nphip_test_detmath(int device, int fn, uint64_t n, const double* x, double* y) {
+    if (hipSetDevice(device) != hipSuccess) { set_error("no HIP device"); return NPHIP_ERR; }
+    double *dx = nullptr, *dy = nullptr;
+    const uint64_t nx = fn == 7 ? 4 : n;
+    if (!hip_ok(hipMalloc((void**)&dx, nx * 8), "hipMalloc") || !hip_ok(hipMalloc((void**)&dy, n * 8 + 8), "hipMalloc")) return NPHIP_ERR;
+    bool ok = hip_ok(hipMemcpy(dx, x, nx * 8, hipMemcpyHostToDevice), "H2D") &&
+              hip_ok(launch_test_detmath(fn, n, dx, dy, nullptr), "launch") &&
+              hip_ok(hipMemcpy(y, dy, n * 8, hipMemcpyDeviceToHost), "D2H");
+    (void)hipFree(dx); (void)hipFree(dy);
+    return ok ? NPHIP_OK : NPHIP_ERR;
+}
+
+int nphip_test_dot(int device, int waves, uint64_t n, const double* x, const double* y, double* out) {
+    if (hipSetDevice(device) != hipSuccess) { set_error("no HIP device"); return NPHIP_ERR; }
+    double *dx = nullptr, *dy = nullptr, *dout = nullptr;
+    if (!hip_ok(hipMalloc((void**)&dx, n * 8 + 8), "hipMalloc") || !hip_ok(hipMalloc((void**)&dy, n * 8 + 8), "hipMalloc") ||
+        !hip_ok(hipMalloc((void**)&dout, 8), "hipMalloc")) return NPHIP_ERR;
+    bool ok = hip_ok(hipMemcpy(dx, x, n * 8, hipMemcpyHostToDevice), "H2D") && hip_ok(hipMemcpy(dy, y, n * 8, hipMemcpyHostToDevice), "H2D") &&
+              hip_ok(launch_test_dot(waves, n, dx, dy, dout, nullptr), "launch") && hip_ok(hipMemcpy(out, dout, 8, hipMemcpyDeviceToHost), "D2H");
+    (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(dout);
+    return ok ? NPHIP_OK : NPHIP_ERR;
+}
+
+}  // extern "C"

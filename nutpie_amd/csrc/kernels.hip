@@ -1,0 +1,838 @@
+// kernels.hip — the NUTS hot path as HIP kernels for gfx950 (CDNA4).
+//
+// One chain is owned by W wavefronts (W=1: one wavefront per chain, four independent chains per
+// 256-thread workgroup; W>1: one workgroup of W waves per chain, cross-wave reductions through
+// LDS).  A chain is a small state machine (engine_types.h: Phase) that runs leapfrogs, the
+// iterative (non-recursive) NUTS tree, dual averaging and the diagonal mass-matrix update
+// entirely on the device.  Lane l of a wave owns element pairs (128c + 2l, 128c + 2l + 1): every
+// vector access is one 16-byte load/store per lane = 1 KiB contiguous per wave instruction.
+//
+// What this replaces (reference): nuts-rs' per-chain CPU worker that nutpie starts through
+// `nuts_rs::Sampler::new` (src/wrapper.rs:977-1085) and feeds through `CpuLogpFunc::logp`
+// (src/pymc.rs:197-215, src/stan.rs:454-463, src/pyfunc.rs:206-230).  Algorithm: SURVEY.md
+// Appendix A; the numbers are defined by include/nphip_spec.h.  The tree here is NOT the crate's
+// recursion: leaves are numbered inside a doubling and the (p, rho) summaries needed by later
+// U-turn checks are written once, by the leapfrog itself, into a slot that is a pure function of
+// the leaf number (engine_types.h), so no state is ever copied.
+//
+// MFMA is unused on purpose: the path is axpy/dot (0.2 flop/byte), bounded by memory bandwidth.
+#include <hip/hip_runtime.h>
+
+#include "../../include/nphip_spec.h"
+#include "engine_types.h"
+
+namespace nphip {
+
+// ----------------------------------------------------------------------------------------
+// wave / workgroup primitives
+// ----------------------------------------------------------------------------------------
+
+template <int W>
+__device__ __forceinline__ void chain_sync() {
+    // make this chain's global stores visible to all of its lanes/waves
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    if (W > 1) __syncthreads();
+}
+
+// Sum two values over the chain in the contract order of nphip_spec.h.
+template <int W>
+__device__ __forceinline__ void reduce2(double& a, double& b, double* red) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        double pa = __shfl_xor(a, off);
+        double pb = __shfl_xor(b, off);
+        a = a + pa;
+        b = b + pb;
+    }
+    if (W > 1) {
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        if (lane == 0) { red[2 * wave] = a; red[2 * wave + 1] = b; }
+        __syncthreads();
+        double ta = red[0], tb = red[1];
+        for (int w = 1; w < W; ++w) { ta = ta + red[2 * w]; tb = tb + red[2 * w + 1]; }
+        __syncthreads();
+        a = ta; b = tb;
+    }
+}
+
+__device__ __forceinline__ double2 ld2(const double* p, int64_t i) { return *reinterpret_cast<const double2*>(p + i); }
+__device__ __forceinline__ void st2(double* p, int64_t i, double2 v) { *reinterpret_cast<double2*>(p + i) = v; }
+// dense rows (ld == dim, possibly odd / unaligned): guarded scalar accesses
+__device__ __forceinline__ double2 ld2_dense(const double* p, int64_t i, int64_t D) {
+    double2 v;
+    v.x = (i < D) ? p[i] : 0.0;
+    v.y = (i + 1 < D) ? p[i + 1] : 0.0;
+    return v;
+}
+__device__ __forceinline__ void st2_dense(double* p, int64_t i, int64_t D, double2 v) {
+    if (i < D) p[i] = v.x;
+    if (i + 1 < D) p[i + 1] = v.y;
+}
+__device__ __forceinline__ double clamp_mm(double v) { return v < 1e-20 ? 1e-20 : (v > 1e20 ? 1e20 : v); }
+
+// ----------------------------------------------------------------------------------------
+// the per-chain machine
+// ----------------------------------------------------------------------------------------
+
+template <bool FUSED, int W>
+struct Machine {
+    const Args& A;
+    Ctl* c;          // this wave's private LDS copy
+    double* red;     // LDS reduction scratch [2*W]
+    int64_t chain;   // local chain index
+    uint32_t gchain; // global chain id (RNG key)
+    int lane, wave;
+    int64_t D, ld, nch;
+    double* qp;      // Q-pool base of this chain
+    double* pp;      // P-slot base of this chain
+    double* sig2;
+    double* est;
+    int64_t T;
+
+    __device__ Machine(const Args& a, Ctl* ctl, double* r, int64_t ch, int wv, int ln)
+        : A(a), c(ctl), red(r), chain(ch), gchain((uint32_t)(a.chain_offset + ch)), lane(ln), wave(wv) {
+        D = a.dim; ld = a.ld; nch = ld / NPHIP_CHUNK;
+        qp = a.qpool + (size_t)ch * a.nqpool * 2 * ld;
+        pp = a.pslots + (size_t)ch * a.npslots * 2 * ld;
+        sig2 = a.sig2 + (size_t)ch * ld;
+        est = a.est + (size_t)ch * 8 * ld;
+        T = a.s.num_tune + a.s.num_draws;
+    }
+
+    __device__ __forceinline__ double* Q(int64_t b) const { return qp + (size_t)b * 2 * ld; }
+    __device__ __forceinline__ double* G(int64_t b) const { return qp + (size_t)b * 2 * ld + ld; }
+    __device__ __forceinline__ double* P(int64_t s) const { return pp + (size_t)s * 2 * ld; }
+    __device__ __forceinline__ double* R(int64_t s) const { return pp + (size_t)s * 2 * ld + ld; }
+    __device__ __forceinline__ double* EST(int64_t e, int k) const { return est + (size_t)(e * 4 + k) * ld; }
+    __device__ __forceinline__ bool leader() const { return lane == 0 && wave == 0; }
+
+#define NPHIP_FOR_CHUNKS(i) for (int64_t cc_ = wave, i = cc_ * NPHIP_CHUNK + 2 * lane; cc_ < nch; cc_ += W, i = cc_ * NPHIP_CHUNK + 2 * lane)
+
+    // ------------------------------------------------------------------ scalar helpers
+    __device__ void da_init(double step) {
+        c->da_log_step = nphip_log(step);
+        c->da_log_step_adapted = c->da_log_step;
+        c->da_hbar = 0.0;
+        c->da_mu = nphip_log(10.0 * step);
+        c->da_count = 1;
+    }
+    __device__ void da_advance(double accept) {
+        const double cnt = (double)c->da_count;
+        double w = 1.0 / (cnt + A.s.da_t0);
+        c->da_hbar = (1.0 - w) * c->da_hbar + w * (A.s.target_accept - accept);
+        c->da_log_step = c->da_mu - c->da_hbar * sqrt(cnt) / A.s.da_gamma;
+        double mk = nphip_exp(-A.s.da_k * nphip_log(cnt));
+        c->da_log_step_adapted = mk * c->da_log_step + (1.0 - mk) * c->da_log_step_adapted;
+        c->da_count += 1;
+    }
+    __device__ void update_stepsize(int64_t draw, bool best) {
+        if (A.s.fixed_step_size) return;
+        double step = best ? nphip_exp(c->da_log_step_adapted) : nphip_exp(c->da_log_step);
+        if (A.s.jitter > 0.0) {
+            nphip_u32x4 r = nphip_philox(A.s.seed, 0u, gchain, (uint32_t)draw, NPHIP_RNG_JITTER);
+            double u = nphip_u01(r.v[0], r.v[1]);
+            step *= fma(2.0 * A.s.jitter, u, 1.0 - A.s.jitter);
+        }
+        if (step > A.s.max_step_size) step = A.s.max_step_size;
+        c->step_size = step;
+    }
+    __device__ int64_t alloc_q(bool in_tree) const {
+        uint32_t used = 1u << c->cand_q;
+        if (in_tree) {
+            used |= (1u << c->endq[0]) | (1u << c->endq[1]) | (1u << c->curq);
+            const int64_t j = c->nleaf;
+            for (int k = 0; k < kMaxDepthCap; ++k)
+                if ((j >> k) & 1) used |= 1u << c->sub_q[k];
+        }
+        return (int64_t)__builtin_ctz(~used);
+    }
+    __device__ void finish_chain(int64_t phase, int64_t err) {
+        c->phase = phase;
+        c->err = err;
+        if (leader()) atomicAdd(&A.counters[phase == PH_ERROR ? 1 : 0], 1ull);
+    }
+
+    // ------------------------------------------------------------------ vector passes
+    // Initial position (Model::init_position: src/pyfunc.rs:540-544, src/stan.rs:798-808, src/pymc.rs:505-534)
+    __device__ void gen_init(int64_t attempt) {
+        double* q = Q(0);
+        NPHIP_FOR_CHUNKS(i) {
+            double2 v = {0.0, 0.0};
+            if (A.s.init_kind == 2) {
+                v = ld2_dense(A.init_points + (size_t)chain * D, i, D);
+            } else if (i < D) {
+                nphip_u32x4 r = nphip_philox(A.s.seed, (uint32_t)(i >> 1), gchain, (uint32_t)attempt, NPHIP_RNG_INIT);
+                if (A.s.init_kind == 0) {
+                    v.x = fma(4.0, nphip_u01(r.v[0], r.v[1]), -2.0);
+                    v.y = fma(4.0, nphip_u01(r.v[2], r.v[3]), -2.0);
+                } else {
+                    nphip_normal_pair(r, &v.x, &v.y);
+                }
+                if (i + 1 >= D) v.y = 0.0;
+            }
+            st2(q, i, v);
+            if (!FUSED) st2_dense(A.qeval + (size_t)chain * D, i, D, v);
+        }
+        c->eval_buf = 0;
+    }
+
+    // Momentum refresh (initialize_trajectory): p = z * sqrt(1/sig2); rho = p.  Returns K.
+    __device__ double sample_momentum(uint32_t purpose, uint32_t id) {
+        double* p = P(kSlotInit);
+        double* r = R(kSlotInit);
+        double2 acc = {0.0, 0.0};
+        NPHIP_FOR_CHUNKS(i) {
+            double2 s2 = ld2(sig2, i);
+            double2 v = {0.0, 0.0};
+            if (i < D) {
+                double z0, z1;
+                nphip_normal_pair(nphip_philox(A.s.seed, (uint32_t)(i >> 1), gchain, id, purpose), &z0, &z1);
+                v.x = z0 * sqrt(1.0 / s2.x);
+                if (i + 1 < D) v.y = z1 * sqrt(1.0 / s2.y);
+            }
+            st2(p, i, v);
+            st2(r, i, v);
+            acc.x = fma(v.x, s2.x * v.x, acc.x);
+            acc.y = fma(v.y, s2.y * v.y, acc.y);
+        }
+        double a = acc.x + acc.y, b = 0.0;
+        reduce2<W>(a, b, red);
+        return 0.5 * a;
+    }
+
+    // Leapfrog, first half: p_half = p + eps/2 g ; q' = q + eps sig2 p_half   
+    __device__ void lf1(int64_t srcq, int64_t srcp, int64_t newq, int64_t newp, int64_t sign) {
+        c->lf_srcq = srcq; c->lf_srcp = srcp; c->lf_newq = newq; c->lf_newp = newp; c->lf_sign = sign;
+        c->eval_buf = newq;
+        const double eps = (double)sign * c->step_size;
+        const double h = 0.5 * eps;
+        const double *q = Q(srcq), *g = G(srcq), *p = P(srcp);
+        double *qn = Q(newq), *pn = P(newp);
+        NPHIP_FOR_CHUNKS(i) {
+            double2 q2 = ld2(q, i), g2 = ld2(g, i), p2 = ld2(p, i), s2 = ld2(sig2, i);
+            double2 ph, qq;
+            ph.x = fma(h, g2.x, p2.x);
+            ph.y = fma(h, g2.y, p2.y);
+            qq.x = fma(eps, s2.x * ph.x, q2.x);
+            qq.y = fma(eps, s2.y * ph.y, q2.y);
+            st2(qn, i, qq);
+            st2(pn, i, ph);
+            if (!FUSED) st2_dense(A.qeval + (size_t)chain * D, i, D, qq);
+        }
+        if (FUSED) chain_sync<W>();  // the fused model reads neighbouring elements of q'
+    }
+
+    // Fused tridiagonal-Gaussian gradient for the pair at i (nphip model contract).
+    __device__ __forceinline__ void tridiag_pair(const double* q, int64_t i, double2& z, double2& g) const {
+        double2 q2 = ld2(q, i), mu = ld2(A.m_mu, i), a = ld2(A.m_a, i), b = ld2(A.m_b, i);
+        z.x = q2.x - mu.x;
+        z.y = q2.y - mu.y;
+        double tx = a.x * z.x;
+        if (i > 0) tx = fma(A.m_b[i - 1], q[i - 1] - A.m_mu[i - 1], tx);
+        if (i + 1 < D) tx = fma(b.x, z.y, tx);
+        double ty = a.y * z.y;
+        ty = fma(b.x, z.x, ty);
+        if (i + 2 < D) ty = fma(b.y, q[i + 2] - A.m_mu[i + 2], ty);
+        g.x = -tx;
+        g.y = (i + 1 < D) ? -ty : 0.0;
+        if (i >= D) g.x = 0.0;
+    }
+
+    // Position-only evaluation (initial point).  FUSED: compute; callback: copy staged gradient.
+    __device__ void eval_position(int64_t buf, double& lp, int64_t& code) {
+        double* g = G(buf);
+        if (FUSED) {
+            const double* q = Q(buf);
+            double2 acc = {0.0, 0.0};
+            NPHIP_FOR_CHUNKS(i) {
+                double2 z, gg;
+                tridiag_pair(q, i, z, gg);
+                st2(g, i, gg);
+                acc.x = fma(z.x, gg.x, acc.x);
+                acc.y = fma(z.y, gg.y, acc.y);
+            }
+            double a = acc.x + acc.y, b = 0.0;
+            reduce2<W>(a, b, red);
+            lp = 0.5 * a;
+            code = 0;
+        } else {
+            lp = A.ueval[chain];
+            code = A.ecode ? A.ecode[chain] : 0;
+            NPHIP_FOR_CHUNKS(i) st2(g, i, ld2_dense(A.geval + (size_t)chain * D, i, D));
+        }
+    }
+
+    // Leapfrog, second half (+ fused gradient): p' = p_half + eps/2 g' ; K' ; rho' = rho + p'.
+    // Returns kinetic energy; lp/code describe the logp evaluation.
+    __device__ double lf2(double& lp, int64_t& code, int64_t idx_new) {
+        const int64_t newq = c->lf_newq, newp = c->lf_newp;
+        const double h = 0.5 * (double)c->lf_sign * c->step_size;
+        double *g = G(newq), *pn = P(newp), *rn = R(newp);
+        const double* rp = R(c->lf_srcp);
+        const bool copy_rho = (idx_new == -1);
+        double2 accK = {0.0, 0.0}, accL = {0.0, 0.0};
+        if (!FUSED) {
+            lp = A.ueval[chain];
+            code = A.ecode ? A.ecode[chain] : 0;
+            if (code != 0 || !isfinite(lp)) return 0.0;
+        }
+        const double* q = Q(newq);
+        NPHIP_FOR_CHUNKS(i) {
+            double2 gg;
+            if (FUSED) {
+                double2 z;
+                tridiag_pair(q, i, z, gg);
+                accL.x = fma(z.x, gg.x, accL.x);
+                accL.y = fma(z.y, gg.y, accL.y);
+            } else {
+                gg = ld2_dense(A.geval + (size_t)chain * D, i, D);
+            }
+            double2 ph = ld2(pn, i), s2 = ld2(sig2, i), r2 = ld2(rp, i);
+            double2 pv, rr;
+            pv.x = fma(h, gg.x, ph.x);
+            pv.y = fma(h, gg.y, ph.y);
+            accK.x = fma(pv.x, s2.x * pv.x, accK.x);
+            accK.y = fma(pv.y, s2.y * pv.y, accK.y);
+            rr.x = copy_rho ? pv.x : r2.x + pv.x;
+            rr.y = copy_rho ? pv.y : r2.y + pv.y;
+            st2(g, i, gg);
+            st2(pn, i, pv);
+            st2(rn, i, rr);
+        }
+        double a = accK.x + accK.y, b = accL.x + accL.y;
+        reduce2<W>(a, b, red);
+        if (FUSED) { lp = 0.5 * b; code = 0; }
+        return 0.5 * a;
+    }
+
+    // EuclideanHamiltonian::is_turning on two P-slots.
+    __device__ bool turning(int64_t s1, int64_t i1, int64_t s2_, int64_t i2) {
+        int64_t ss = s1, se = s2_, a = i1, b = i2;
+        if (!(i1 < i2)) { ss = s2_; se = s1; a = i2; b = i1; }
+        const double *ps = P(ss), *rs = R(ss), *pe = P(se), *re = R(se);
+        const int mode = (a >= 0 && b >= 0) ? 0 : ((b >= 0 && a < 0) ? 1 : 2);
+        double2 acc1 = {0.0, 0.0}, acc2 = {0.0, 0.0};
+        NPHIP_FOR_CHUNKS(i) {
+            double2 vps = ld2(ps, i), vrs = ld2(rs, i), vpe = ld2(pe, i), vre = ld2(re, i), s2 = ld2(sig2, i);
+            double2 t;
+            if (mode == 0) { t.x = (vre.x - vrs.x) + vps.x; t.y = (vre.y - vrs.y) + vps.y; }
+            else if (mode == 1) { t.x = vre.x + vrs.x; t.y = vre.y + vrs.y; }
+            else { t.x = (vrs.x - vre.x) + vpe.x; t.y = (vrs.y - vre.y) + vpe.y; }
+            acc1.x = fma(t.x, s2.x * vpe.x, acc1.x);
+            acc1.y = fma(t.y, s2.y * vpe.y, acc1.y);
+            acc2.x = fma(t.x, s2.x * vps.x, acc2.x);
+            acc2.y = fma(t.y, s2.y * vps.y, acc2.y);
+        }
+        double t1 = acc1.x + acc1.y, t2 = acc2.x + acc2.y;
+        reduce2<W>(t1, t2, red);
+        return (t1 < 0.0) || (t2 < 0.0);
+    }
+
+    // Mass-matrix strategy init: estimators see the initial point; sig2 = 1/clamp(|g|).
+    __device__ void init_mass_matrix(int64_t buf) {
+        const double *q = Q(buf), *g = G(buf);
+        NPHIP_FOR_CHUNKS(i) {
+            double2 q2 = ld2(q, i), g2 = ld2(g, i);
+            double2 s;
+            if (A.s.adapt_mass_matrix) {
+                double2 zero = {0.0, 0.0};
+                for (int e = 0; e < 2; ++e) {
+                    st2(EST(e, 0), i, q2); st2(EST(e, 1), i, zero);
+                    st2(EST(e, 2), i, g2); st2(EST(e, 3), i, zero);
+                }
+                double vx = 1.0 / clamp_mm(fabs(g2.x)), vy = 1.0 / clamp_mm(fabs(g2.y));
+                s.x = isfinite(vx) ? vx : 1.0;
+                s.y = isfinite(vy) ? vy : 1.0;
+            } else {
+                s.x = 1.0; s.y = 1.0;
+            }
+            st2(sig2, i, s);
+        }
+        c->fg = 0;
+        c->fg_count = A.s.adapt_mass_matrix ? 1 : 0;
+        c->bg_count = c->fg_count;
+    }
+
+    // End-of-draw vector pass: trace row, Welford updates of both estimators, mass-matrix refresh.
+    __device__ void position_pass(int64_t draw, bool do_add, bool do_switch, bool do_update, int64_t n_fg, int64_t n_bg) {
+        const int64_t cq = c->cand_q;
+        const double *q = Q(cq), *g = G(cq);
+        const size_t row = ((size_t)chain * T + draw) * D;
+        const int64_t efg = c->fg, ebg = 1 - c->fg;
+        const int64_t esrc = do_switch ? ebg : efg;
+        NPHIP_FOR_CHUNKS(i) {
+            double2 q2 = ld2(q, i), g2 = ld2(g, i);
+            if (A.tr_draws) st2_dense(A.tr_draws + row, i, D, q2);
+            if (A.tr_grad) st2_dense(A.tr_grad + row, i, D, g2);
+            double2 src_m2q = {0.0, 0.0}, src_m2g = {0.0, 0.0};
+            if (do_add) {
+                for (int t = 0; t < 2; ++t) {
+                    const int64_t e = t == 0 ? efg : ebg;
+                    const int64_t n = t == 0 ? n_fg : n_bg;  // count after adding
+                    double2 mq, vq, mg, vg;
+                    if (n == 1) {
+                        mq = q2; mg = g2; vq.x = vq.y = 0.0; vg.x = vg.y = 0.0;
+                    } else {
+                        const double inv = 1.0 / (double)n;
+                        mq = ld2(EST(e, 0), i); vq = ld2(EST(e, 1), i); mg = ld2(EST(e, 2), i); vg = ld2(EST(e, 3), i);
+                        double d;
+                        d = q2.x - mq.x; mq.x = fma(d, inv, mq.x); vq.x = fma(d, q2.x - mq.x, vq.x);
+                        d = q2.y - mq.y; mq.y = fma(d, inv, mq.y); vq.y = fma(d, q2.y - mq.y, vq.y);
+                        d = g2.x - mg.x; mg.x = fma(d, inv, mg.x); vg.x = fma(d, g2.x - mg.x, vg.x);
+                        d = g2.y - mg.y; mg.y = fma(d, inv, mg.y); vg.y = fma(d, g2.y - mg.y, vg.y);
+                    }
+                    st2(EST(e, 0), i, mq); st2(EST(e, 1), i, vq); st2(EST(e, 2), i, mg); st2(EST(e, 3), i, vg);
+                    if (e == esrc) { src_m2q = vq; src_m2g = vg; }
+                }
+            } else if (do_update) {
+                src_m2q = ld2(EST(esrc, 1), i);
+                src_m2g = ld2(EST(esrc, 3), i);
+            }
+            double2 s = ld2(sig2, i);
+            if (do_update) {
+                const int64_t n_src = do_switch ? n_bg : n_fg;
+                double vx, vy;
+                if (A.s.use_grad_based) {
+                    vx = sqrt(src_m2q.x / src_m2g.x);
+                    vy = sqrt(src_m2q.y / src_m2g.y);
+                } else {
+                    const double scale = 1.0 / (double)(n_src - 1);
+                    vx = src_m2q.x * scale;
+                    vy = src_m2q.y * scale;
+                }
+                if (isfinite(vx)) s.x = clamp_mm(vx);
+                if (isfinite(vy)) s.y = clamp_mm(vy);
+                st2(sig2, i, s);
+            }
+            if (A.tr_mm) st2_dense(A.tr_mm + row, i, D, s);
+        }
+    }
+
+    __device__ void store_divergence(bool have_end) {
+        if (!A.tr_div[0]) return;
+        const size_t row = ((size_t)chain * T + c->draw) * D;
+        const double *q = Q(c->lf_srcq), *g = G(c->lf_srcq), *p = P(c->lf_srcp), *qe = Q(c->lf_newq);
+        NPHIP_FOR_CHUNKS(i) {
+            st2_dense(A.tr_div[0] + row, i, D, ld2(q, i));
+            if (have_end) st2_dense(A.tr_div[1] + row, i, D, ld2(qe, i));
+            st2_dense(A.tr_div[2] + row, i, D, ld2(p, i));
+            st2_dense(A.tr_div[3] + row, i, D, ld2(g, i));
+        }
+    }
+
+    // ------------------------------------------------------------------ control flow
+    __device__ void start_ss(int64_t ss_id) {
+        c->ss_id = ss_id;
+        c->step_size = A.s.initial_step;
+        if (A.s.fixed_step_size) { da_init(A.s.initial_step); after_ss(); return; }
+        double K0 = sample_momentum(NPHIP_RNG_SS_MOMENTUM, (uint32_t)ss_id);
+        c->H0 = K0 + c->cand_U;
+        lf1(c->cand_q, kSlotInit, alloc_q(false), slot_first(0), +1);
+        c->phase = PH_SS_FIRST;
+    }
+
+    __device__ void after_ss() {
+        if (c->ss_id == 0xffffffffll) begin_draw();
+        else finish_draw();
+    }
+
+    __device__ void cont_ss(double K, double lp, int64_t code, bool first) {
+        c->total_steps += 1;
+        const bool ok = (code == 0) && isfinite(lp);
+        const double dE = (K - lp) - c->H0;
+        const bool diverged = !ok || (dE > A.s.max_energy_error) || !isfinite(dE);
+        if (diverged) {
+            c->step_size = A.s.initial_step;
+            da_init(A.s.initial_step);
+            after_ss();
+            return;
+        }
+        const double e = nphip_exp(-dE);
+        const double accept = e < 1.0 ? e : 1.0;
+        if (first) {
+            c->ss_dir = accept > A.s.target_accept ? 1 : -1;
+            c->ss_iter = 0;
+        } else {
+            if (c->ss_dir > 0) {
+                if (accept <= A.s.target_accept || c->step_size > 1e5) { da_init(c->step_size); after_ss(); return; }
+                c->step_size *= 2.0;
+            } else {
+                if (accept >= A.s.target_accept || c->step_size < 1e-10) { da_init(c->step_size); after_ss(); return; }
+                c->step_size /= 2.0;
+            }
+            c->ss_iter += 1;
+            if (c->ss_iter >= 100) {
+                c->step_size = A.s.initial_step;
+                da_init(A.s.initial_step);
+                after_ss();
+                return;
+            }
+        }
+        lf1(c->cand_q, kSlotInit, c->lf_newq, slot_first(0), c->ss_dir);
+        c->phase = PH_SS_ITER;
+    }
+
+    __device__ void cont_init(double lp, int64_t code) {
+        if (code < 0) { finish_chain(PH_ERROR, CE_FATAL_LOGP); return; }
+        if (code != 0 || !isfinite(lp)) {
+            c->init_attempt += 1;
+            if (c->init_attempt >= A.s.num_try_init) { finish_chain(PH_ERROR, CE_INIT_FAILED); return; }
+            gen_init(c->init_attempt);
+            return;  // phase stays PH_INIT_EVAL
+        }
+        c->cand_q = 0;
+        c->cand_U = -lp;
+        init_mass_matrix(0);
+        c->has_initial_mm = 1;
+        c->last_update = 0;
+        c->tuning = 1;
+        da_init(A.s.initial_step);
+        start_ss(0xffffffffll);
+    }
+
+    __device__ void begin_draw() {
+        if (c->draw >= T) { finish_chain(PH_DONE, CE_NONE); return; }
+        double K0 = sample_momentum(NPHIP_RNG_MOMENTUM, (uint32_t)c->draw);
+        c->H0 = K0 + c->cand_U;
+        c->depth = 0; c->ls_main = 0.0;
+        c->idx_left = 0; c->idx_right = 0;
+        c->endq[0] = c->endq[1] = c->cand_q;
+        c->endp[0] = c->endp[1] = kSlotInit;
+        c->endpar[0] = c->endpar[1] = 0;
+        c->cand_idx = 0; c->cand_E = c->H0;
+        c->acc_mean = 0.0; c->acc_sym_mean = 0.0; c->n_steps = 0;
+        start_doubling();
+    }
+
+    __device__ void start_doubling() {
+        nphip_u32x4 r = nphip_philox(A.s.seed, (uint32_t)c->depth, gchain, (uint32_t)c->draw, NPHIP_RNG_DIRECTION);
+        c->dir = (r.v[0] & 1u) ? 1 : -1;
+        const int db = c->dir > 0 ? 1 : 0;
+        c->nleaf = 0;
+        c->curq = c->endq[db];
+        c->curp = c->endp[db];
+        c->idx_cur = c->dir > 0 ? c->idx_right : c->idx_left;
+        issue_leaf();
+    }
+
+    __device__ void issue_leaf() {
+        const int64_t j = c->nleaf + 1, d = c->depth;
+        const int db = c->dir > 0 ? 1 : 0;
+        int64_t newp;
+        if (j == (1ll << d)) newp = slot_end(db, (int)(c->endpar[db] ^ 1));
+        else if (j & 1) newp = (j == 1) ? slot_first((int)d) : slot_first(__builtin_ctzll((unsigned long long)(j - 1)));
+        else newp = slot_last(__builtin_ctzll((unsigned long long)j), A.cap);
+        lf1(c->curq, c->curp, alloc_q(true), newp, c->dir);
+        c->phase = PH_TREE;
+    }
+
+    __device__ double merge_uniform(int64_t j, int64_t d, int64_t k) const {
+        uint32_t c3 = (uint32_t)NPHIP_RNG_MERGE | ((uint32_t)d << 8) | ((uint32_t)k << 16);
+        nphip_u32x4 r = nphip_philox(A.s.seed, (uint32_t)j, gchain, (uint32_t)c->draw, c3);
+        return nphip_u01(r.v[0], r.v[1]);
+    }
+
+    // one leapfrog of the tree has been evaluated: NutsTree::extend / merge_into, unrolled
+    __device__ void cont_tree(double K, double lp, int64_t code) {
+        if (code < 0) { finish_chain(PH_ERROR, CE_FATAL_LOGP); return; }
+        c->nleaf += 1;
+        c->n_steps += 1;
+        c->total_steps += 1;
+        const int64_t j = c->nleaf, d = c->depth, dir = c->dir;
+        const int db = dir > 0 ? 1 : 0;
+        const int64_t idx_new = c->idx_cur + dir;
+        const bool ok = (code == 0) && isfinite(lp);
+        const double Unew = -lp, E = K + Unew, dE = E - c->H0;
+        const bool diverged = !ok || (dE > A.s.max_energy_error) || !isfinite(dE);
+        // AcceptanceRateCollector
+        {
+            double a = 0.0, asym = 0.0;
+            if (!diverged) {
+                double e = nphip_exp(-dE);
+                a = e < 1.0 ? e : 1.0;
+                asym = 2.0 * a / (1.0 + e);
+            }
+            const double cnt = (double)c->n_steps;
+            c->acc_mean += (a - c->acc_mean) / cnt;
+            c->acc_sym_mean += (asym - c->acc_sym_mean) / cnt;
+        }
+        if (diverged) { store_divergence(ok); end_draw(true, false); return; }
+
+        const int64_t near_idx = dir > 0 ? c->idx_right : c->idx_left;
+        const int64_t sT_last = c->lf_newp;
+        double T_ls = -dE, T_U = Unew, T_E = E;
+        int64_t T_q = c->lf_newq, T_idx = idx_new;
+        c->curq = c->lf_newq; c->curp = c->lf_newp; c->idx_cur = idx_new;
+        const bool check = A.s.check_turning && (d + 1 > A.s.mindepth);
+
+        int64_t k = 0;
+        while (k < d && (((j - 1) >> k) & 1)) {
+            if (check) {
+                const int64_t a = j - (2ll << k) + 1;  // first leaf of the waiting sub-tree A
+                const int64_t sA_first = (a == 1) ? slot_first((int)d) : slot_first(__builtin_ctzll((unsigned long long)(a - 1)));
+                const int64_t iA_first = near_idx + dir * a;
+                bool turn = turning(sA_first, iA_first, sT_last, idx_new);
+                if (k > 0) {
+                    if (!turn) {
+                        const int64_t al = j - (1ll << k);  // last leaf of A
+                        turn = turning(slot_last(__builtin_ctzll((unsigned long long)al), A.cap), near_idx + dir * al, sT_last, idx_new);
+                    }
+                    if (!turn) {
+                        const int64_t tf = j - (1ll << k) + 1;  // first leaf of T
+                        turn = turning(sA_first, iA_first, slot_first(__builtin_ctzll((unsigned long long)(tf - 1))), near_idx + dir * tf);
+                    }
+                }
+                if (turn) { end_draw(false, false); return; }
+            }
+            const double ls = nphip_logaddexp(c->sub_ls[k], T_ls);
+            bool take = T_ls >= ls;
+            if (!take) take = merge_uniform(j, d, k) < nphip_exp(T_ls - ls);
+            if (!take) { T_q = c->sub_q[k]; T_U = c->sub_U[k]; T_E = c->sub_E[k]; T_idx = c->sub_idx[k]; }
+            T_ls = ls;
+            ++k;
+        }
+        if (k < d) {
+            c->sub_ls[k] = T_ls; c->sub_q[k] = T_q; c->sub_U[k] = T_U; c->sub_E[k] = T_E; c->sub_idx[k] = T_idx;
+            issue_leaf();
+            return;
+        }
+        // the new sub-tree of depth d is complete: merge into the main tree
+        bool turn = false;
+        if (check) {
+            const int64_t far_slot = c->endp[1 - db], far_idx = dir > 0 ? c->idx_left : c->idx_right;
+            turn = turning(far_slot, far_idx, sT_last, idx_new);
+            if (d > 0) {
+                if (!turn) turn = turning(c->endp[db], near_idx, sT_last, idx_new);
+                if (!turn) turn = turning(far_slot, far_idx, slot_first((int)d), near_idx + dir);
+            }
+        }
+        c->endq[db] = c->lf_newq;
+        c->endp[db] = c->lf_newp;
+        c->endpar[db] ^= 1;
+        if (dir > 0) c->idx_right = idx_new; else c->idx_left = idx_new;
+        {
+            const double ls = nphip_logaddexp(c->ls_main, T_ls);
+            bool take = T_ls >= c->ls_main;
+            if (!take) take = merge_uniform(j, d, d) < nphip_exp(T_ls - c->ls_main);
+            if (take) { c->cand_q = T_q; c->cand_U = T_U; c->cand_E = T_E; c->cand_idx = T_idx; }
+            c->ls_main = ls;
+            c->depth = d + 1;
+        }
+        if (turn) { end_draw(false, false); return; }
+        if (c->depth >= A.s.maxdepth) { end_draw(false, true); return; }
+        start_doubling();
+    }
+
+    // GlobalStrategy::adapt
+    __device__ void end_draw(bool diverging, bool maxdepth) {
+        c->fin_depth = c->depth;
+        c->fin_flags = (diverging ? 1 : 0) | (maxdepth ? 2 : 0);
+        c->fin_eerr = c->cand_E - c->H0;  // H0 is reused by a mid-adapt step-size search
+        c->n_div += diverging ? 1 : 0;
+        c->latest_steps = c->n_steps;
+        const bool good = diverging ? (c->cand_idx != 0) : true;
+        const int64_t draw = c->draw;
+        bool need_search = false;
+        if (draw >= A.s.num_tune) {
+            c->tuning = 0;
+            position_pass(draw, false, false, false, 0, 0);
+        } else if (draw < A.s.final_window) {
+            const bool is_early = draw < A.s.early_end;
+            const int64_t switch_freq = is_early ? A.s.early_mm_switch_freq : A.s.mm_switch_freq;
+            const bool is_late = switch_freq + draw > A.s.final_window;
+            bool did_change = false;
+            if (A.s.adapt_mass_matrix) {
+                const bool do_add = good;
+                const int64_t n_fg = c->fg_count + (do_add ? 1 : 0), n_bg = c->bg_count + (do_add ? 1 : 0);
+                const bool do_switch = (n_bg >= switch_freq) && !is_late;
+                const bool want = do_switch || (draw - c->last_update >= A.s.mm_update_freq);
+                const int64_t n_src = do_switch ? n_bg : n_fg;
+                const bool do_update = want && n_src >= 3;
+                position_pass(draw, do_add, do_switch, do_update, n_fg, n_bg);
+                if (do_switch) { c->fg = 1 - c->fg; c->fg_count = n_bg; c->bg_count = 0; }
+                else { c->fg_count = n_fg; c->bg_count = n_bg; }
+                if (do_update) { did_change = true; c->last_update = draw; }
+            } else {
+                position_pass(draw, false, false, false, 0, 0);
+            }
+            da_advance(is_late ? c->acc_sym_mean : c->acc_mean);
+            if (did_change && c->has_initial_mm) { c->has_initial_mm = 0; need_search = true; }
+            else update_stepsize(draw, false);
+        } else {
+            position_pass(draw, false, false, false, 0, 0);
+            da_advance(c->acc_sym_mean);
+            update_stepsize(draw, draw == A.s.num_tune - 1);
+        }
+        if (need_search) { start_ss(draw); return; }
+        finish_draw();
+    }
+
+    __device__ void finish_draw() {
+        const int64_t draw = c->draw;
+        if (leader()) {
+            const size_t o = (size_t)chain * T + draw;
+            A.st_depth[o] = c->fin_depth;
+            A.st_nsteps[o] = c->latest_steps;
+            A.st_idx[o] = c->cand_idx;
+            A.st_diverging[o] = (uint8_t)(c->fin_flags & 1);
+            A.st_maxdepth[o] = (uint8_t)((c->fin_flags >> 1) & 1);
+            A.st_tuning[o] = (uint8_t)c->tuning;
+            A.st_energy[o] = c->cand_E;
+            A.st_energy_error[o] = c->fin_eerr;
+            A.st_logp[o] = -c->cand_U;
+            A.st_step[o] = c->step_size;
+            A.st_step_bar[o] = nphip_exp(c->da_log_step_adapted);
+            A.st_accept[o] = c->acc_mean;
+            A.st_accept_sym[o] = c->acc_sym_mean;
+        }
+        c->draw = draw + 1;
+        begin_draw();
+    }
+
+    __device__ void run() {
+        int budget = A.max_evals;
+        bool have = A.have_result != 0;
+        for (;;) {
+            const int64_t ph = c->phase;
+            if (ph == PH_DONE || ph == PH_ERROR) break;
+            if (ph == PH_START) {
+                c->init_attempt = 0;
+                gen_init(0);
+                c->phase = PH_INIT_EVAL;
+                if (FUSED) chain_sync<W>();
+                continue;
+            }
+            if (FUSED) {
+                if (budget <= 0) break;
+                --budget;
+            } else {
+                if (!have) break;
+                have = false;
+            }
+            double lp = 0.0;
+            int64_t code = 0;
+            if (ph == PH_INIT_EVAL) {
+                eval_position(c->eval_buf, lp, code);
+                cont_init(lp, code);
+                if (FUSED && c->phase == PH_INIT_EVAL) chain_sync<W>();
+            } else if (ph == PH_TREE) {
+                double K = lf2(lp, code, c->idx_cur + c->dir);
+                cont_tree(K, lp, code);
+            } else {  // PH_SS_FIRST / PH_SS_ITER
+                double K = lf2(lp, code, c->lf_sign);
+                if (code < 0) { finish_chain(PH_ERROR, CE_FATAL_LOGP); continue; }
+                cont_ss(K, lp, code, ph == PH_SS_FIRST);
+            }
+        }
+    }
+#undef NPHIP_FOR_CHUNKS
+};
+
+template <bool FUSED, int W>
+__global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k_advance(const Args A) {
+    constexpr int WAVES = (W == 1) ? 4 : W;
+    __shared__ Ctl s_ctl[WAVES];
+    __shared__ double s_red[2 * WAVES];
+    const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t chain = (W == 1) ? (int64_t)blockIdx.x * 4 + wib : (int64_t)blockIdx.x;
+    if (chain >= A.n_chains) return;
+    Ctl* c = &s_ctl[wib];
+    {
+        const uint64_t* src = reinterpret_cast<const uint64_t*>(A.ctl + chain);
+        uint64_t* dst = reinterpret_cast<uint64_t*>(c);
+        for (int w = lane; w < kCtlWords; w += 64) dst[w] = src[w];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    Machine<FUSED, W> m(A, c, s_red, chain, (W == 1) ? 0 : wib, lane);
+    m.run();
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    if (W == 1 || wib == 0) {
+        uint64_t* dst = reinterpret_cast<uint64_t*>(A.ctl + chain);
+        const uint64_t* src = reinterpret_cast<const uint64_t*>(c);
+        for (int w = lane; w < kCtlWords; w += 64) dst[w] = src[w];
+    }
+}
+
+template <bool FUSED>
+static hipError_t launch_w(const Args& a, int W, hipStream_t st) {
+    const unsigned n = (unsigned)a.n_chains;
+    switch (W) {
+        case 1: hipLaunchKernelGGL((k_advance<FUSED, 1>), dim3((n + 3) / 4), dim3(256), 0, st, a); break;
+        case 2: hipLaunchKernelGGL((k_advance<FUSED, 2>), dim3(n), dim3(128), 0, st, a); break;
+        case 4: hipLaunchKernelGGL((k_advance<FUSED, 4>), dim3(n), dim3(256), 0, st, a); break;
+        case 8: hipLaunchKernelGGL((k_advance<FUSED, 8>), dim3(n), dim3(512), 0, st, a); break;
+        case 16: hipLaunchKernelGGL((k_advance<FUSED, 16>), dim3(n), dim3(1024), 0, st, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_advance(const Args& a, bool fused, int W, hipStream_t st) {
+    return fused ? launch_w<true>(a, W, st) : launch_w<false>(a, W, st);
+}
+
+// ----------------------------------------------------------------------------------------
+// test hooks: device implementations of the nphip_spec.h contract
+// ----------------------------------------------------------------------------------------
+__global__ void k_test_detmath(int fn, uint64_t n, const double* x, double* y) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (fn == 7) {
+        const uint64_t seed = (uint64_t)x[0];
+        const uint32_t chain = (uint32_t)x[1], draw = (uint32_t)x[2], purpose = (uint32_t)x[3];
+        if (2 * i < n) {
+            double z0, z1;
+            nphip_normal_pair(nphip_philox(seed, (uint32_t)i, chain, draw, purpose), &z0, &z1);
+            y[2 * i] = z0;
+            if (2 * i + 1 < n) y[2 * i + 1] = z1;
+        }
+        return;
+    }
+    if (i >= n) return;
+    double s, cs;
+    switch (fn) {
+        case 0: y[i] = nphip_exp(x[i]); break;
+        case 1: y[i] = nphip_log(x[i]); break;
+        case 2: y[i] = nphip_log1p(x[i]); break;
+        case 3: nphip_sincos2pi(x[i], &s, &cs); y[i] = s; break;
+        case 4: nphip_sincos2pi(x[i], &s, &cs); y[i] = cs; break;
+        case 5: y[i] = sqrt(x[i]); break;
+        default: y[i] = 1.0 / x[i]; break;
+    }
+}
+
+template <int W>
+__global__ void k_test_dot(uint64_t n, const double* x, const double* y, double* out) {
+    __shared__ double red[2 * W];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t nch = (int64_t)((n + 127) / 128);
+    double2 acc = {0.0, 0.0};
+    for (int64_t cc = wave; cc < nch; cc += W) {
+        int64_t i = cc * 128 + 2 * lane;
+        double2 a = ld2_dense(x, i, (int64_t)n), b = ld2_dense(y, i, (int64_t)n);
+        acc.x = fma(a.x, b.x, acc.x);
+        acc.y = fma(a.y, b.y, acc.y);
+    }
+    double a = acc.x + acc.y, b = 0.0;
+    reduce2<W>(a, b, red);
+    if (threadIdx.x == 0) *out = a;
+}
+
+hipError_t launch_test_detmath(int fn, uint64_t n, const double* x, double* y, hipStream_t st) {
+    uint64_t work = (fn == 7) ? (n + 1) / 2 : n;
+    hipLaunchKernelGGL(k_test_detmath, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, fn, n, x, y);
+    return hipGetLastError();
+}
+
+hipError_t launch_test_dot(int W, uint64_t n, const double* x, const double* y, double* out, hipStream_t st) {
+    switch (W) {
+        case 1: hipLaunchKernelGGL(k_test_dot<1>, dim3(1), dim3(64), 0, st, n, x, y, out); break;
+        case 2: hipLaunchKernelGGL(k_test_dot<2>, dim3(1), dim3(128), 0, st, n, x, y, out); break;
+        case 4: hipLaunchKernelGGL(k_test_dot<4>, dim3(1), dim3(256), 0, st, n, x, y, out); break;
+        case 8: hipLaunchKernelGGL(k_test_dot<8>, dim3(1), dim3(512), 0, st, n, x, y, out); break;
+        case 16: hipLaunchKernelGGL(k_test_dot<16>, dim3(1), dim3(1024), 0, st, n, x, y, out); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace nphip

@@ -1,0 +1,289 @@
+"""ctypes front-end of the CPU oracle (oracle/nuts_oracle.cpp).
+
+TEST INFRASTRUCTURE ONLY — imported by tests/, ``__graft_entry__.smoke()`` and
+``bench.py``'s ``cpu_baseline`` leg; never by the ``nutpie_amd`` package.
+
+PARITY UNPINNED: see the header of ``oracle/nuts_oracle.h``.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass, field
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libnuts_oracle.so")
+
+LOGP_FN = C.CFUNCTYPE(C.c_int64, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p)
+
+
+class Settings(C.Structure):
+    _fields_ = [
+        ("seed", C.c_uint64),
+        ("num_tune", C.c_uint64),
+        ("num_draws", C.c_uint64),
+        ("num_chains", C.c_uint64),
+        ("maxdepth", C.c_uint64),
+        ("mindepth", C.c_uint64),
+        ("check_turning", C.c_int32),
+        ("use_grad_based_mass_matrix", C.c_int32),
+        ("max_energy_error", C.c_double),
+        ("early_window", C.c_double),
+        ("step_size_window", C.c_double),
+        ("mass_matrix_switch_freq", C.c_uint64),
+        ("early_mass_matrix_switch_freq", C.c_uint64),
+        ("mass_matrix_update_freq", C.c_uint64),
+        ("initial_step", C.c_double),
+        ("target_accept", C.c_double),
+        ("step_size_jitter", C.c_double),
+        ("max_step_size", C.c_double),
+        ("da_k", C.c_double),
+        ("da_t0", C.c_double),
+        ("da_gamma", C.c_double),
+        ("fixed_step_size", C.c_int32),
+        ("adapt_mass_matrix", C.c_int32),
+        ("init_kind", C.c_int32),
+        ("num_try_init", C.c_int32),
+        ("waves_per_chain", C.c_int32),
+        ("n_threads", C.c_int32),
+        ("chain_offset", C.c_uint64),
+        ("store_gradient", C.c_int32),
+        ("store_mass_matrix", C.c_int32),
+    ]
+
+
+class _Trace(C.Structure):
+    _fields_ = [
+        ("draws", C.c_void_p),
+        ("depth", C.c_void_p),
+        ("n_steps", C.c_void_p),
+        ("index_in_trajectory", C.c_void_p),
+        ("diverging", C.c_void_p),
+        ("maxdepth_reached", C.c_void_p),
+        ("tuning", C.c_void_p),
+        ("energy", C.c_void_p),
+        ("energy_error", C.c_void_p),
+        ("logp", C.c_void_p),
+        ("step_size", C.c_void_p),
+        ("step_size_bar", C.c_void_p),
+        ("mean_tree_accept", C.c_void_p),
+        ("mean_tree_accept_sym", C.c_void_p),
+        ("gradient", C.c_void_p),
+        ("mass_matrix_inv", C.c_void_p),
+    ]
+
+
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with its Makefile (g++ only)."""
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(
+        os.path.getmtime(os.path.join(_HERE, f)) for f in ("nuts_oracle.cpp", "nuts_oracle.h", "Makefile")
+    ):
+        subprocess.run(["make", "-C", _HERE, "-B", "libnuts_oracle.so"], check=True, capture_output=True)
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.oracle_last_error.restype = C.c_char_p
+        _lib.oracle_logaddexp.restype = C.c_double
+        _lib.oracle_logaddexp.argtypes = [C.c_double, C.c_double]
+        _lib.oracle_dot.restype = C.c_double
+        _lib.oracle_leapfrog_tridiag.restype = C.c_double
+    return _lib
+
+
+def default_settings(**kw) -> Settings:
+    s = Settings()
+    lib().oracle_default_settings(C.byref(s))
+    for k, v in kw.items():
+        if not hasattr(s, k):
+            raise AttributeError(k)
+        setattr(s, k, v)
+    return s
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+@dataclass
+class Trace:
+    draws: np.ndarray
+    stats: dict = field(default_factory=dict)
+    seconds: float = 0.0
+
+    def __getattr__(self, name):
+        try:
+            return self.stats[name]
+        except KeyError as e:
+            raise AttributeError(name) from e
+
+
+def _alloc(s: Settings, dim: int):
+    n, T = int(s.num_chains), int(s.num_tune + s.num_draws)
+    st = {
+        "depth": np.zeros((n, T), np.int64),
+        "n_steps": np.zeros((n, T), np.int64),
+        "index_in_trajectory": np.zeros((n, T), np.int64),
+        "diverging": np.zeros((n, T), np.uint8),
+        "maxdepth_reached": np.zeros((n, T), np.uint8),
+        "tuning": np.zeros((n, T), np.uint8),
+        "energy": np.zeros((n, T)),
+        "energy_error": np.zeros((n, T)),
+        "logp": np.zeros((n, T)),
+        "step_size": np.zeros((n, T)),
+        "step_size_bar": np.zeros((n, T)),
+        "mean_tree_accept": np.zeros((n, T)),
+        "mean_tree_accept_sym": np.zeros((n, T)),
+    }
+    if s.store_gradient:
+        st["gradient"] = np.zeros((n, T, dim))
+    if s.store_mass_matrix:
+        st["mass_matrix_inv"] = np.zeros((n, T, dim))
+    draws = np.zeros((n, T, dim))
+    tr = _Trace()
+    tr.draws = _p(draws)
+    for k, v in st.items():
+        setattr(tr, k, _p(v))
+    return draws, st, tr
+
+
+def _vec(x, n):
+    if x is None:
+        return None
+    x = np.ascontiguousarray(np.asarray(x, dtype=np.float64))
+    assert x.shape == (n,), (x.shape, n)
+    return x
+
+
+def sample_tridiag(settings: Settings, diag, offdiag=None, mu=None, init_points=None) -> Trace:
+    diag = np.ascontiguousarray(np.asarray(diag, dtype=np.float64))
+    dim = diag.shape[0]
+    offdiag = _vec(offdiag, max(dim - 1, 0)) if offdiag is not None and dim > 1 else None
+    mu = _vec(mu, dim)
+    ip = None
+    if init_points is not None:
+        ip = np.ascontiguousarray(np.asarray(init_points, dtype=np.float64))
+        assert ip.shape == (int(settings.num_chains), dim)
+    draws, st, tr = _alloc(settings, dim)
+    secs = C.c_double(0)
+    rc = lib().oracle_sample_tridiag(C.byref(settings), C.c_uint64(dim), _p(mu), _p(diag), _p(offdiag), _p(ip), C.byref(tr), C.byref(secs))
+    if rc != 0:
+        raise RuntimeError(lib().oracle_last_error().decode())
+    return Trace(draws, st, secs.value)
+
+
+def sample_callback(settings: Settings, dim: int, fn, user=None, init_points=None) -> Trace:
+    """fn: either a ctypes function pointer (LOGP_FN / raw address) or a Python callable
+    ``f(x: ndarray) -> (logp, grad)`` wrapped here."""
+    keep = None
+    if callable(fn) and not isinstance(fn, (int, C._CFuncPtr)):
+        pyfn = fn
+
+        def _cb(d, x, g, lp, _u):
+            xs = np.ctypeslib.as_array(x, shape=(d,))
+            try:
+                val, grad = pyfn(xs.copy())
+            except Exception:
+                return 1
+            np.ctypeslib.as_array(g, shape=(d,))[:] = grad
+            lp[0] = val
+            return 0
+
+        keep = LOGP_FN(_cb)
+        fnptr = C.cast(keep, C.c_void_p)
+    elif isinstance(fn, int):
+        fnptr = C.c_void_p(fn)
+    else:
+        fnptr = C.cast(fn, C.c_void_p)
+    ip = None
+    if init_points is not None:
+        ip = np.ascontiguousarray(np.asarray(init_points, dtype=np.float64))
+    draws, st, tr = _alloc(settings, dim)
+    secs = C.c_double(0)
+    rc = lib().oracle_sample_callback(C.byref(settings), C.c_uint64(dim), fnptr, C.c_void_p(user), _p(ip), C.byref(tr), C.byref(secs))
+    del keep
+    if rc != 0:
+        raise RuntimeError(lib().oracle_last_error().decode())
+    return Trace(draws, st, secs.value)
+
+
+# ---- unit-level helpers -----------------------------------------------------
+
+
+def philox(seed, c0, c1, c2, c3):
+    out = (C.c_uint32 * 4)()
+    lib().oracle_philox(C.c_uint64(seed), C.c_uint32(c0), C.c_uint32(c1), C.c_uint32(c2), C.c_uint32(c3), out)
+    return tuple(out)
+
+
+def detmath(fn: str, x):
+    code = {"exp": 0, "log": 1, "log1p": 2, "sin2pi": 3, "cos2pi": 4}[fn]
+    x = np.ascontiguousarray(np.asarray(x, dtype=np.float64))
+    y = np.empty_like(x)
+    lib().oracle_detmath(code, C.c_uint64(x.size), _p(x), _p(y))
+    return y
+
+
+def logaddexp(a, b):
+    return lib().oracle_logaddexp(a, b)
+
+
+def normals(seed, chain, draw, purpose, n):
+    out = np.empty(n)
+    lib().oracle_normals(C.c_uint64(seed), C.c_uint32(chain), C.c_uint32(draw), C.c_uint32(purpose), C.c_uint64(n), _p(out))
+    return out
+
+
+def dot(x, y, waves=1):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    return lib().oracle_dot(_p(x), _p(y), C.c_uint64(x.size), C.c_int(waves))
+
+
+def leapfrog_tridiag(q, p, g, sig2, eps, diag, offdiag=None, mu=None, waves=1):
+    dim = len(q)
+    q = np.array(q, dtype=np.float64)
+    p = np.array(p, dtype=np.float64)
+    g = np.array(g, dtype=np.float64)
+    sig2 = _vec(sig2, dim)
+    diag = _vec(diag, dim)
+    offdiag = _vec(offdiag, dim - 1) if offdiag is not None and dim > 1 else None
+    mu = _vec(mu, dim)
+    K, U = C.c_double(), C.c_double()
+    e = lib().oracle_leapfrog_tridiag(C.c_uint64(dim), _p(mu), _p(diag), _p(offdiag), _p(sig2), C.c_double(eps), C.c_int(waves), _p(q), _p(p), _p(g), C.byref(K), C.byref(U))
+    return q, p, g, K.value, U.value, e
+
+
+def dual_average(accept, initial_step=0.1, target=0.8, k=0.75, t0=10.0, gamma=0.05):
+    accept = np.ascontiguousarray(accept, dtype=np.float64)
+    step = np.empty_like(accept)
+    bar = np.empty_like(accept)
+    lib().oracle_dual_average(C.c_double(initial_step), C.c_double(target), C.c_double(k), C.c_double(t0), C.c_double(gamma), C.c_uint64(accept.size), _p(accept), _p(step), _p(bar))
+    return step, bar
+
+
+def welford(samples):
+    samples = np.ascontiguousarray(samples, dtype=np.float64)
+    n, dim = samples.shape
+    mean = np.empty(dim)
+    m2 = np.empty(dim)
+    lib().oracle_welford(C.c_uint64(n), C.c_uint64(dim), _p(samples), _p(mean), _p(m2))
+    return mean, m2
+
+
+def is_turning(sig2, idx1, p1, psum1, idx2, p2, psum2, waves=1):
+    sig2 = np.ascontiguousarray(sig2, dtype=np.float64)
+    a = [np.ascontiguousarray(v, dtype=np.float64) for v in (p1, psum1, p2, psum2)]
+    return bool(lib().oracle_is_turning(C.c_uint64(sig2.size), _p(sig2), C.c_int(waves), C.c_int64(idx1), _p(a[0]), _p(a[1]), C.c_int64(idx2), _p(a[2]), _p(a[3])))

@@ -1,0 +1,123 @@
+/*
+ * nuts_oracle.h — C interface of the CPU oracle.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
+ *
+ * PARITY UNPINNED: the algorithm this file restates lives in the crates.io
+ * dependency `nuts-rs 0.18.3` (reference Cargo.toml:24, Cargo.lock:2295-2298),
+ * whose source is not in /root/reference and cannot be built here (no Rust
+ * toolchain, no network).  The oracle follows SURVEY.md Appendix A (a restatement
+ * of the crate's published diag-NUTS algorithm) and the in-tree evidence cited
+ * next to each function in nuts_oracle.cpp.  Its RNG stream is the engine's own
+ * contract (include/nphip_spec.h), not nuts-rs's ChaCha8 stream, so the three
+ * golden files in the reference's tests/reference/ can only be used as
+ * distributional fixtures (tests/test_oracle_statistics.py).
+ */
+#ifndef NUTS_ORACLE_H
+#define NUTS_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Same signature as the reference's raw C logp callback (src/pymc.rs:23-29,
+ * python/nutpie/compile_pymc.py:975-981): 0 ok, >0 recoverable, <0 fatal. */
+typedef int64_t (*oracle_logp_fn)(uint64_t dim, const double* x, double* grad, double* logp, void* user);
+
+typedef struct {
+    /* DiagNutsSettings (reference src/wrapper.rs:525-533, 563-620, 213-447) */
+    uint64_t seed;
+    uint64_t num_tune;
+    uint64_t num_draws;
+    uint64_t num_chains;
+    uint64_t maxdepth;
+    uint64_t mindepth;
+    int32_t check_turning;
+    int32_t use_grad_based_mass_matrix;
+    double max_energy_error;
+    /* adapt_options */
+    double early_window;
+    double step_size_window;
+    uint64_t mass_matrix_switch_freq;
+    uint64_t early_mass_matrix_switch_freq;
+    uint64_t mass_matrix_update_freq;
+    /* step_size_settings */
+    double initial_step;
+    double target_accept;
+    double step_size_jitter;   /* 0 => none */
+    double max_step_size;
+    double da_k, da_t0, da_gamma;
+    int32_t fixed_step_size;   /* !=0: step_size_adapt_method = "<float>" */
+    int32_t adapt_mass_matrix; /* 0: keep the initial (identity/explicit) matrix; test knob */
+    /* init */
+    int32_t init_kind;         /* 0: U(-2,2) (src/pyfunc.rs:540-544)  1: N(0,1) (src/stan.rs:798-808)  2: explicit */
+    int32_t num_try_init;
+    /* engine geometry */
+    int32_t waves_per_chain;
+    int32_t n_threads;
+    /* global chain id of local chain 0 (multi-GPU sharding invariance) */
+    uint64_t chain_offset;
+    /* optional outputs */
+    int32_t store_gradient;
+    int32_t store_mass_matrix;
+} oracle_settings_t;
+
+typedef struct {
+    /* all arrays [chains][T] (T = num_tune + num_draws) unless noted */
+    double* draws;            /* [chains][T][dim] */
+    int64_t* depth;
+    int64_t* n_steps;
+    int64_t* index_in_trajectory;
+    uint8_t* diverging;
+    uint8_t* maxdepth_reached;
+    uint8_t* tuning;
+    double* energy;
+    double* energy_error;
+    double* logp;
+    double* step_size;
+    double* step_size_bar;
+    double* mean_tree_accept;
+    double* mean_tree_accept_sym;
+    double* gradient;         /* [chains][T][dim] or NULL */
+    double* mass_matrix_inv;  /* [chains][T][dim] or NULL */
+} oracle_trace_t;
+
+void oracle_default_settings(oracle_settings_t* s);
+
+/* Tridiagonal-precision Gaussian  logp(x) = -1/2 (x-mu)' L (x-mu),
+ * L = tridiag(offdiag, diag, offdiag).  mu may be NULL (zero), offdiag may be NULL. */
+int oracle_sample_tridiag(const oracle_settings_t* s, uint64_t dim, const double* mu, const double* diag,
+                          const double* offdiag, const double* init_points, oracle_trace_t* out, double* seconds);
+
+/* Arbitrary host callback model. */
+int oracle_sample_callback(const oracle_settings_t* s, uint64_t dim, oracle_logp_fn fn, void* user,
+                           const double* init_points, oracle_trace_t* out, double* seconds);
+
+const char* oracle_last_error(void);
+
+/* ---- unit-level entry points for known-answer tests ---- */
+void oracle_philox(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t out[4]);
+void oracle_detmath(int fn, uint64_t n, const double* x, double* y); /* 0 exp 1 log 2 log1p 3 sin2pi 4 cos2pi */
+double oracle_logaddexp(double a, double b);
+void oracle_normals(uint64_t seed, uint32_t chain, uint32_t draw, uint32_t purpose, uint64_t n, double* out);
+double oracle_dot(const double* x, const double* y, uint64_t n, int waves);
+/* one leapfrog on the tridiag model; state arrays are in/out. returns energy U'+K'. */
+double oracle_leapfrog_tridiag(uint64_t dim, const double* mu, const double* diag, const double* offdiag,
+                               const double* sig2, double eps, int waves, double* q, double* p, double* g,
+                               double* kinetic, double* potential);
+/* dual averaging trajectory: feeds accept[i], writes step_size[i], step_size_bar[i] after each advance */
+void oracle_dual_average(double initial_step, double target, double k, double t0, double gamma, uint64_t n,
+                         const double* accept, double* step, double* step_bar);
+/* Welford running variance over n samples of dimension dim: outputs mean, M2 */
+void oracle_welford(uint64_t n, uint64_t dim, const double* samples, double* mean, double* m2);
+/* U-turn criterion on two trajectory points */
+int oracle_is_turning(uint64_t dim, const double* sig2, int waves, int64_t idx1, const double* p1,
+                      const double* psum1, int64_t idx2, const double* p2, const double* psum2);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
