@@ -88,6 +88,12 @@ typedef int (*nphip_device_logp_fn)(uint64_t n_chains, uint64_t dim, const doubl
 nphip_model_t* nphip_model_tridiag_gaussian(uint64_t dim, const double* mu, const double* diag, const double* offdiag);
 nphip_model_t* nphip_model_host_callback(uint64_t dim, nphip_raw_logp_fn fn, void* user_data, int n_threads);
 nphip_model_t* nphip_model_device_callback(uint64_t dim, nphip_device_logp_fn fn, void* user_data);
+/* BridgeStan flavour (reference src/stan.rs:454-463): each row is evaluated as
+ *   bs_log_density_gradient(bs_model, propto=true, jacobian=true, theta, &val, grad, &err)
+ * on the host pool; any Stan error or a non-finite density is recoverable (src/stan.rs:392-396,
+ * 459-461).  `log_density_gradient` / `free_error_msg` are the addresses of the BridgeStan C API
+ * functions of the loaded model library (bridgestan.h), `bs_model` the model handle. */
+nphip_model_t* nphip_model_bridgestan(uint64_t dim, void* bs_model, void* log_density_gradient, void* free_error_msg, int n_threads);
 /* Initial positions: kind 0 = U(-2,2) (src/pyfunc.rs:540-544), 1 = N(0,1) (src/stan.rs:798-808),
  * 2 = explicit host array points[n_chains_total][dim] indexed by GLOBAL chain id
  * (src/pymc.rs:505-534 evaluates the user's init function per chain on the host). */
@@ -121,7 +127,12 @@ typedef struct {
     int32_t store_draws;       /* keep [chain][draw][dim] positions in HBM (default 1)             */
     int32_t evals_per_launch;  /* fused models: leapfrogs per chain per kernel launch (0 = default) */
     int32_t start_paused;
-    int32_t reserved;
+    int32_t manual;            /* 1: no driver thread; the caller advances with nphip_sampler_step  */
+    /* Device-callback models: caller-owned staging buffers q[n][dim], grad[n][dim], logp[n] (device,
+     * fp64).  NULL = engine-owned.  Lets a PyTorch caller hand in tensors it allocated itself. */
+    void* staging_q;
+    void* staging_grad;
+    void* staging_logp;
 } nphip_launch_t;
 
 void nphip_launch_defaults(nphip_launch_t*);
@@ -130,6 +141,12 @@ void nphip_launch_defaults(nphip_launch_t*);
 nphip_sampler_t* nphip_sampler_create(const nphip_settings_t*, const nphip_model_t*, const nphip_launch_t*);
 void nphip_sampler_free(nphip_sampler_t*);                 /* aborts if still running */
 int nphip_sampler_wait(nphip_sampler_t*, int64_t timeout_ms); /* <0: no timeout; resumes a paused sampler */
+/* Manual mode only: perform up to n_launches engine iterations (one kernel launch each; for callback
+ * models one leapfrog per chain incl. the callback) on the calling thread and synchronise.  Stops early
+ * when all chains are done.  kernel_ms (optional) receives the summed duration of the k_advance kernels
+ * measured with HIP events on the engine's stream; launches_done (optional) the count performed.
+ * Returns NPHIP_WAIT_DONE when every chain has finished, NPHIP_WAIT_TIMEOUT otherwise, NPHIP_WAIT_ERROR. */
+int nphip_sampler_step(nphip_sampler_t*, uint64_t n_launches, double* kernel_ms, uint64_t* launches_done);
 int nphip_sampler_pause(nphip_sampler_t*);
 int nphip_sampler_resume(nphip_sampler_t*);
 int nphip_sampler_abort(nphip_sampler_t*);                 /* stop; partial trace stays readable */

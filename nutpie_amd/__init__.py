@@ -1,2 +1,33 @@
-"""nutpie_amd — MI355X-native NUTS engine behind nutpie's Python API."""
-from nutpie_amd._lib import __version__  # noqa: F401
+"""nutpie_amd — an MI355X-native NUTS engine behind nutpie's Python API.
+
+Public surface mirrors the reference's ``python/nutpie/__init__.py:10-18``
+(``compile_pymc_model``, ``compile_stan_model``, ``sample``, ``ChainProgress``) and adds the
+batched front-ends the GPU engine is built for (``from_torchfunc``, analytic Gaussians).
+See DESIGN.md for the hot path and INTEGRATION.md for the C-ABI boundary.
+"""
+
+from nutpie_amd import _lib
+from nutpie_amd._lib import __version__
+from nutpie_amd.compile_pymc import compile_pymc_model
+from nutpie_amd.compile_stan import compile_stan_model, prune_stan_cache
+from nutpie_amd.compiled_pyfunc import from_pyfunc, from_torchfunc
+from nutpie_amd.gaussian import ar1_gaussian, dense_gaussian, diag_gaussian, std_normal
+from nutpie_amd.sample import CompiledModel, sample
+
+ChainProgress = _lib.PyChainProgress
+
+__all__ = [
+    "__version__",
+    "ChainProgress",
+    "CompiledModel",
+    "compile_pymc_model",
+    "compile_stan_model",
+    "prune_stan_cache",
+    "sample",
+    "from_pyfunc",
+    "from_torchfunc",
+    "std_normal",
+    "diag_gaussian",
+    "ar1_gaussian",
+    "dense_gaussian",
+]

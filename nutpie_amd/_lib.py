@@ -55,7 +55,10 @@ class _Launch(C.Structure):
         ("store_draws", C.c_int32),
         ("evals_per_launch", C.c_int32),
         ("start_paused", C.c_int32),
-        ("reserved", C.c_int32),
+        ("manual", C.c_int32),
+        ("staging_q", C.c_void_p),
+        ("staging_grad", C.c_void_p),
+        ("staging_logp", C.c_void_p),
     ]
 
 
@@ -121,6 +124,8 @@ def lib():
             L.nphip_model_host_callback.argtypes = [C.c_uint64, C.c_void_p, C.c_void_p, C.c_int]
             L.nphip_model_device_callback.restype = C.c_void_p
             L.nphip_model_device_callback.argtypes = [C.c_uint64, C.c_void_p, C.c_void_p]
+            L.nphip_model_bridgestan.restype = C.c_void_p
+            L.nphip_model_bridgestan.argtypes = [C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
             L.nphip_model_set_init.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64]
             L.nphip_model_free.argtypes = [C.c_void_p]
             L.nphip_launch_defaults.argtypes = [C.POINTER(_Launch)]
@@ -128,6 +133,7 @@ def lib():
             L.nphip_sampler_create.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(_Launch)]
             L.nphip_sampler_free.argtypes = [C.c_void_p]
             L.nphip_sampler_wait.argtypes = [C.c_void_p, C.c_int64]
+            L.nphip_sampler_step.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
             for f in ("pause", "resume", "abort", "is_finished", "waves_per_chain"):
                 getattr(L, "nphip_sampler_" + f).argtypes = [C.c_void_p]
             for f in ("num_chains", "dim", "total_draws", "launches"):
@@ -345,6 +351,18 @@ class HostCallbackModel(_Model):
         super().__init__(lib().nphip_model_host_callback(C.c_uint64(dim), addr, C.c_void_p(user_data), int(n_threads)), dim, keep)
 
 
+class BridgeStanModel(_Model):
+    """BridgeStan model handle evaluated on the host pool (src/stan.rs:454-463).
+
+    ``stanlib`` is the loaded model library (``ctypes.CDLL``), ``bs_model`` its ``bs_model*``."""
+
+    def __init__(self, dim, stanlib, bs_model, n_threads=0, keep_alive=None):
+        ldg = C.cast(stanlib.bs_log_density_gradient, C.c_void_p)
+        free = C.cast(stanlib.bs_free_error_msg, C.c_void_p) if hasattr(stanlib, "bs_free_error_msg") else None
+        ptr = bs_model if isinstance(bs_model, C.c_void_p) else C.cast(bs_model, C.c_void_p)
+        super().__init__(lib().nphip_model_bridgestan(C.c_uint64(dim), ptr, ldg, free, int(n_threads)), dim, [stanlib, bs_model, keep_alive])
+
+
 class DeviceCallbackModel(_Model):
     """Batched device callback: ``fn(n_chains, dim, q_ptr, grad_ptr, logp_ptr, stream_ptr) -> int``."""
 
@@ -418,7 +436,8 @@ class PySampler:
     """Sampler handle (wrapper.rs:953-1457)."""
 
     def __init__(self, settings: PyNutsSettings, model: _Model, *, device=0, waves_per_chain=0, chain_offset=0,
-                 n_local_chains=0, stream=None, store_draws=True, evals_per_launch=0, start_paused=False):
+                 n_local_chains=0, stream=None, store_draws=True, evals_per_launch=0, start_paused=False, manual=False,
+                 staging=None):
         L = lib()
         la = _Launch()
         L.nphip_launch_defaults(C.byref(la))
@@ -430,6 +449,9 @@ class PySampler:
         la.store_draws = int(bool(store_draws))
         la.evals_per_launch = int(evals_per_launch)
         la.start_paused = int(bool(start_paused))
+        la.manual = int(bool(manual))
+        if staging is not None:
+            la.staging_q, la.staging_grad, la.staging_logp = (C.c_void_p(int(p)) for p in staging)
         self._model = model
         self._settings = settings
         self._chain_offset = int(chain_offset)
@@ -497,6 +519,20 @@ class PySampler:
                 remaining -= step
                 if remaining <= 0:
                     raise TimeoutError("Timeout while waiting for sampler to finish")
+
+    def step(self, n_launches=1):
+        """Manual mode: run ``n_launches`` engine iterations on this thread.
+        Returns ``(done, launches_performed, kernel_ms)`` — kernel_ms from HIP events on the engine stream."""
+        self._require()
+        ms = C.c_double(0.0)
+        cnt = C.c_uint64(0)
+        rc = lib().nphip_sampler_step(self._h, C.c_uint64(int(n_launches)), C.byref(ms), C.byref(cnt))
+        if rc == WAIT_ERROR:
+            exc = getattr(self._model, "exception", None)
+            if exc is not None:
+                raise RuntimeError(f"logp callback raised: {exc!r}") from exc
+            raise RuntimeError(_err())
+        return rc == WAIT_DONE, int(cnt.value), float(ms.value)
 
     def pause(self):
         self._require()

@@ -1,0 +1,125 @@
+"""``compile_stan_model`` — API shell of the reference's ``python/nutpie/compile_stan.py``.
+
+The reference compiles Stan code with BridgeStan (``compile_stan.py:250-386``) and evaluates
+``log_density_gradient(position, propto=True, jacobian=True)`` per chain-step from Rust
+(``src/stan.rs:454-463``).  Here the same BridgeStan entry point is called, row by row on a host
+thread pool, behind the engine's host-callback path (pinned ``hipMemcpyAsync`` both ways).
+
+BridgeStan and the Stan toolchain are not installable in the build image, so model compilation
+and its sha256 cache (``compile_stan.py:151-224``) are OUT OF SCOPE: this module needs an
+importable ``bridgestan`` and otherwise raises ``ImportError``.  The native adapter underneath
+(``nphip_model_bridgestan``) is tested with a stand-in library that exports BridgeStan's C API
+for the eight-schools model (tests/fixtures/eight_schools.c).
+"""
+
+from __future__ import annotations
+
+import dataclasses
+import json
+from dataclasses import dataclass
+from importlib.util import find_spec
+from typing import Any, Optional
+
+import numpy as np
+
+from nutpie_amd import _lib
+from nutpie_amd.sample import CompiledModel
+
+
+@dataclass(frozen=True)
+class CompiledStanModel(CompiledModel):
+    """Mirror of the reference's ``CompiledStanModel`` (compile_stan.py:17-148)."""
+
+    code: str = ""
+    data: Optional[dict[str, Any]] = None
+    library: Any = None           # path of the compiled BridgeStan model library
+    model: Any = None             # bridgestan.StanModel bound to `data`
+    _coords: Optional[dict[str, Any]] = None
+
+    def with_data(self, *, seed=None, **updates):
+        import bridgestan
+
+        data = dict(self.data or {})
+        data.update(updates)
+        model = bridgestan.StanModel(self.library, data=json.dumps({k: np.asarray(v).tolist() for k, v in data.items()}), seed=seed or 0)
+        return dataclasses.replace(self, data=data, model=model)
+
+    def with_coords(self, **coords):
+        c = dict(self._coords or {})
+        c.update(coords)
+        return dataclasses.replace(self, _coords=c)
+
+    def with_dims(self, **dims):
+        d = dict(self.dims or {})
+        d.update(dims)
+        return dataclasses.replace(self, dims=d)
+
+    def _bound(self):
+        return self.model if self.model is not None else self.with_data().model
+
+    @property
+    def n_dim(self):
+        return int(self._bound().param_unc_num())
+
+    @property
+    def shapes(self):
+        return {"params": (int(self._bound().param_num(include_tp=True, include_gq=True)),)}
+
+    @property
+    def coords(self):
+        return dict(self._coords or {})
+
+    def _make_model(self, init_mean=None, settings=None):
+        m = self._bound()
+        model = _lib.BridgeStanModel(self.n_dim, m.stanlib, m.model_rng if hasattr(m, "model_rng") else m.model, keep_alive=m)
+        model.set_init("normal")  # src/stan.rs:798-808
+        return model
+
+    def _make_sampler(self, settings, init_mean, cores, progress_type, extra_callback, extra_callback_rate, store, **engine_kw):
+        return _lib.PySampler.from_stan(settings, cores, self._make_model(), progress_type, extra_callback, extra_callback_rate, store, **engine_kw)
+
+    def _expand_draws(self, draws):
+        # param_constrain per draw; BridgeStan returns column-major blocks which the reference
+        # transposes in Rust (src/stan.rs:473-520, 671-711).  The flat vector is returned here.
+        m = self._bound()
+        n, T, _ = draws.shape
+        k = int(m.param_num(include_tp=True, include_gq=True))
+        out = np.empty((n, T, k))
+        for c in range(n):
+            for t in range(T):
+                out[c, t] = m.param_constrain(draws[c, t], include_tp=True, include_gq=True)
+        return {"params": out}
+
+
+def compile_stan_model(*, code: Optional[str] = None, filename: Optional[str] = None, extra_compile_args=None,
+                       extra_stanc_args=None, dims=None, coords=None, model_name=None, cleanup: bool = True,
+                       cache: bool = False, prune_cache: bool = True) -> CompiledStanModel:
+    """Same keyword signature as the reference (compile_stan.py:250-262)."""
+    if find_spec("bridgestan") is None:
+        raise ImportError(
+            "BridgeStan is not installed, please install it with something like 'pip install bridgestan'. "
+            "(Stan compilation is outside the scope of the HIP engine; the BridgeStan *evaluation* path is "
+            "nutpie_amd._lib.BridgeStanModel.)"
+        )
+    import pathlib
+    import tempfile
+
+    import bridgestan
+
+    if code is not None and filename is not None:
+        raise ValueError("Specify exactly one of `code` and `filename`")
+    if code is None:
+        if filename is None:
+            raise ValueError("Either code or filename have to be specified")
+        code = pathlib.Path(filename).read_text()
+    basedir = pathlib.Path(tempfile.mkdtemp())
+    name = model_name or "model"
+    path = basedir / f"{name}.stan"
+    path.write_text(code)
+    so = bridgestan.compile_model(path, make_args=["STAN_THREADS=true", *(extra_compile_args or [])], stanc_args=extra_stanc_args or [])
+    return CompiledStanModel(dims=dims or {}, code=code, data=None, library=str(so), model=None, _coords=coords or {})
+
+
+def prune_stan_cache(*a, **k):
+    """The compile cache is out of scope (see module docstring)."""
+    return 0

@@ -1,0 +1,271 @@
+"""Generic models from Python callables.
+
+``from_pyfunc`` / ``PyFuncModel`` keep the reference's signature and semantics
+(``python/nutpie/compiled_pyfunc.py:14-155``; binding ``src/pyfunc.rs``): one
+``logp_fn(x: float64[D]) -> (logp, grad)`` per chain, Uniform(-2, 2) default initial
+points (``src/pyfunc.rs:540-544``), dict-returning expand function
+(``src/pyfunc.rs:236-268``).  On the HIP engine such a model is evaluated through the
+host-callback path (rows of the batch looped on the host) — a drop-in, not a fast path.
+
+``from_torchfunc`` / ``TorchFuncModel`` is the batched device form the engine is built
+for: ``logp_fn(x: Tensor[chains, D]) -> (logp[chains], grad[chains, D])`` on the GPU;
+tensors never leave HBM.
+"""
+
+from __future__ import annotations
+
+import dataclasses
+from dataclasses import dataclass
+from functools import partial
+from typing import Any, Callable
+
+import numpy as np
+
+from nutpie_amd import _lib
+from nutpie_amd.sample import CompiledModel
+
+SeedType = int
+
+
+def _shapes_dict(names, shapes):
+    return {n: tuple(int(s) for s in shp) for n, shp in zip(names, shapes)}
+
+
+@dataclass(frozen=True)
+class PyFuncModel(CompiledModel):
+    _make_logp_func: Callable
+    _make_expand_func: Callable
+    _make_initial_points: Callable[[SeedType], np.ndarray] | None
+    _shared_data: dict[str, Any]
+    _n_dim: int
+    _names: list[str]
+    _shapes: list[tuple[int, ...]]
+    _dtypes: list[Any]
+    _coords: dict[str, Any]
+    _raw_logp_fn: Callable | None = None
+
+    @property
+    def shapes(self) -> dict[str, tuple[int, ...]]:
+        return _shapes_dict(self._names, self._shapes)
+
+    @property
+    def coords(self):
+        return self._coords
+
+    @property
+    def n_dim(self):
+        return self._n_dim
+
+    def with_data(self, **updates):
+        for name in updates:
+            if name not in self._shared_data:
+                raise ValueError(f"Unknown data variable: {name}")
+        updated = self._shared_data.copy()
+        updated.update(**updates)
+        return dataclasses.replace(self, _shared_data=updated)
+
+    def _init_points(self, settings) -> np.ndarray | None:
+        """The reference calls ``init_point_func(seed)`` once per chain with a seed drawn from the
+        chain's RNG (src/pyfunc.rs:546-568); here seeds derive from (seed, chain)."""
+        if self._make_initial_points is None:
+            return None
+        n = int(settings.num_chains)
+        base = int(settings.seed)
+        pts = np.empty((n, self._n_dim))
+        for c in range(n):
+            p = np.asarray(self._make_initial_points((base * 0x9E3779B97F4A7C15 + c) % (1 << 64)), dtype=np.float64)
+            if p.shape != (self._n_dim,):
+                raise ValueError("Initial point has incorrect length")
+            pts[c] = p
+        return pts
+
+    def _make_model(self, init_mean, settings=None):
+        logp_fn = partial(self._make_logp_func(), **self._shared_data)
+
+        def row_fn(x):
+            val, grad = logp_fn(x)
+            grad = np.asarray(grad)
+            if grad.dtype != np.float64 or grad.shape != x.shape:
+                raise TypeError("Return type of logp function should be (float, float64 array)")  # src/pyfunc.rs ReturnTypeError
+            return float(val), grad
+
+        model = _lib.HostCallbackModel(self._n_dim, row_fn)
+        pts = self._init_points(settings) if settings is not None else None
+        if pts is not None:
+            model.set_init("explicit", pts)
+        return model
+
+    def _make_sampler(self, settings, init_mean, cores, progress_type, extra_callback, extra_callback_rate, store, **engine_kw):
+        model = self._make_model(init_mean, settings)
+        return _lib.PySampler.from_pyfunc(settings, cores, model, progress_type, extra_callback, extra_callback_rate, store, **engine_kw)
+
+    def _expand_draws(self, draws):
+        n, T, _ = draws.shape
+        expand = partial(self._make_expand_func(0, 0, 0), **self._shared_data)
+        out = {name: np.empty((n, T, *shape), dtype=dt) for name, shape, dt in zip(self._names, self._shapes, self._dtypes)}
+        for c in range(n):
+            for t in range(T):
+                vals = expand(draws[c, t])
+                for name, shape, dt in zip(self._names, self._shapes, self._dtypes):
+                    v = np.asarray(vals[name])
+                    if v.dtype != np.dtype(dt):
+                        raise TypeError(f"Expanded variable {name} has dtype {v.dtype}, expected {np.dtype(dt)}")  # src/pyfunc.rs:290-380
+                    if v.size != int(np.prod(shape, dtype=np.int64)):
+                        raise ValueError(f"Expanded variable {name} has incorrect shape")
+                    out[name][c, t] = v.reshape(shape)
+        return out
+
+
+def from_pyfunc(
+    ndim: int,
+    make_logp_fn: Callable,
+    make_expand_fn: Callable,
+    expanded_dtypes: list[np.dtype],
+    expanded_shapes: list[tuple[int, ...]],
+    expanded_names: list[str],
+    *,
+    coords: dict[str, Any] | None = None,
+    dims: dict[str, tuple[str, ...]] | None = None,
+    shared_data: dict[str, Any] | None = None,
+    make_initial_point_fn: Callable[[SeedType], np.ndarray] | None = None,
+    make_transform_adapter=None,
+    raw_logp_fn=None,
+    reparameterized_names=None,
+):
+    """Same signature as the reference's ``from_pyfunc`` (compiled_pyfunc.py:108-155)."""
+    if make_transform_adapter is not None:
+        raise NotImplementedError("normalizing-flow adaptation is outside the scope of the HIP engine")
+    return PyFuncModel(
+        _n_dim=ndim,
+        dims=dict(dims or {}),
+        _coords=dict(coords or {}),
+        _make_logp_func=make_logp_fn,
+        _make_expand_func=make_expand_fn,
+        _make_initial_points=make_initial_point_fn,
+        _names=list(expanded_names),
+        _shapes=[tuple(s) for s in expanded_shapes],
+        _dtypes=[np.dtype(d) for d in expanded_dtypes],
+        _shared_data=dict(shared_data or {}),
+        _raw_logp_fn=raw_logp_fn,
+        reparameterized_names=reparameterized_names,
+    )
+
+
+# ----------------------------------------------------------------------------- batched torch models
+@dataclass(frozen=True)
+class TorchFuncModel(CompiledModel):
+    """Batched device model: all chains evaluated by one torch call per leapfrog."""
+
+    _make_logp_func: Callable           # () -> f(x[chains, D]) -> (logp[chains], grad[chains, D])
+    _expand_func: Callable | None       # (x[N, D] numpy) -> dict name -> [N, *shape]; None = identity variable "x"
+    _n_dim: int
+    _names: list[str]
+    _shapes: list[tuple[int, ...]]
+    _coords: dict[str, Any]
+    _shared_data: dict[str, Any]
+    _init: Any = "uniform"              # "uniform" | "normal" | ndarray [chains, D]
+
+    @property
+    def shapes(self):
+        return _shapes_dict(self._names, self._shapes)
+
+    @property
+    def coords(self):
+        return self._coords
+
+    @property
+    def n_dim(self):
+        return self._n_dim
+
+    def with_data(self, **updates):
+        for name in updates:
+            if name not in self._shared_data:
+                raise ValueError(f"Unknown data variable: {name}")
+        updated = self._shared_data.copy()
+        updated.update(**updates)
+        return dataclasses.replace(self, _shared_data=updated)
+
+    def _make_sampler(self, settings, init_mean, cores, progress_type, extra_callback, extra_callback_rate, store, **engine_kw):
+        import torch
+
+        if not torch.cuda.is_available():
+            raise RuntimeError("TorchFuncModel needs a GPU: the nutpie-hip engine has no CPU fallback")
+        device = int(engine_kw.get("device", 0) or 0)
+        n = int(engine_kw.get("n_local_chains") or settings.num_chains)
+        D = self._n_dim
+        dev = torch.device("cuda", device)
+        q = torch.zeros((n, D), dtype=torch.float64, device=dev)
+        g = torch.zeros((n, D), dtype=torch.float64, device=dev)
+        lp = torch.zeros((n,), dtype=torch.float64, device=dev)
+        logp_fn = partial(self._make_logp_func(), **self._shared_data)
+        streams = {}
+
+        def cb(n_chains, dim, _q, _g, _lp, stream_ptr):
+            # run the torch graph on the engine's stream: no cross-stream synchronisation needed
+            st = streams.get(stream_ptr)
+            if st is None:
+                st = torch.cuda.ExternalStream(stream_ptr, device=dev) if stream_ptr else torch.cuda.default_stream(dev)
+                streams[stream_ptr] = st
+            with torch.cuda.stream(st):
+                val, grad = logp_fn(q)
+                lp.copy_(val.reshape(n).to(torch.float64))
+                g.copy_(grad.reshape(n, D).to(torch.float64))
+            return 0
+
+        model = _lib.DeviceCallbackModel(D, cb)
+        if isinstance(self._init, str):
+            model.set_init(self._init)
+        else:
+            model.set_init("explicit", np.asarray(self._init, dtype=np.float64))
+        sampler = _lib.PySampler.from_pyfunc(
+            settings, cores, model, progress_type, extra_callback, extra_callback_rate, store,
+            staging=(q.data_ptr(), g.data_ptr(), lp.data_ptr()), **engine_kw,
+        )
+        sampler._keep_tensors = (q, g, lp)
+        return sampler
+
+    def _make_model(self, *a, **k):
+        raise NotImplementedError("TorchFuncModel builds its model inside _make_sampler (staging tensors are per sampler)")
+
+    def _expand_draws(self, draws):
+        n, T, D = draws.shape
+        if self._expand_func is None:
+            return {self._names[0]: draws.reshape(n, T, *self._shapes[0])}
+        flat = self._expand_func(draws.reshape(n * T, D), **self._shared_data)
+        out = {}
+        for name, shape in zip(self._names, self._shapes):
+            out[name] = np.asarray(flat[name]).reshape(n, T, *shape)
+        return out
+
+
+def from_torchfunc(
+    ndim: int,
+    make_logp_fn: Callable,
+    expand_fn: Callable | None = None,
+    expanded_shapes: list[tuple[int, ...]] | None = None,
+    expanded_names: list[str] | None = None,
+    *,
+    coords: dict[str, Any] | None = None,
+    dims: dict[str, tuple[str, ...]] | None = None,
+    shared_data: dict[str, Any] | None = None,
+    init="uniform",
+    reparameterized_names=None,
+):
+    """Batched analogue of :func:`from_pyfunc`: ``make_logp_fn() -> f`` with
+    ``f(x: Tensor[chains, ndim]) -> (logp: Tensor[chains], grad: Tensor[chains, ndim])`` on the GPU."""
+    if expanded_names is None:
+        expanded_names, expanded_shapes = ["x"], [(ndim,)]
+        if expand_fn is not None:
+            raise ValueError("expand_fn needs expanded_names and expanded_shapes")
+    return TorchFuncModel(
+        dims=dict(dims or {}),
+        _make_logp_func=make_logp_fn,
+        _expand_func=expand_fn,
+        _n_dim=ndim,
+        _names=list(expanded_names),
+        _shapes=[tuple(s) for s in expanded_shapes],
+        _coords=dict(coords or {}),
+        _shared_data=dict(shared_data or {}),
+        _init=init,
+        reparameterized_names=reparameterized_names,
+    )

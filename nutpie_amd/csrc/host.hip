@@ -259,8 +259,21 @@ int64_t nphip_settings_to_json(const nphip_settings_t* s, char* buf, int64_t cap
 }  // extern "C"
 
 // =========================================================================== models
+// BridgeStan C API (bridgestan.h) as the reference calls it through the `bridgestan` crate (src/stan.rs:454-463)
+typedef int (*bs_ldg_fn)(const void* model, bool propto, bool jacobian, const double* theta, double* val, double* grad, char** err);
+typedef void (*bs_free_err_fn)(char* err);
+struct BsAdapter { void* model; bs_ldg_fn ldg; bs_free_err_fn free_err; };
+static int64_t bs_trampoline(uint64_t, const double* x, double* grad, double* logp, void* user) {
+    auto* b = static_cast<BsAdapter*>(user);
+    char* err = nullptr;
+    int rc = b->ldg(b->model, true, true, x, logp, grad, &err);
+    if (rc != 0) { if (err && b->free_err) b->free_err(err); return 1; }  // Stan errors are recoverable
+    return std::isfinite(*logp) ? 0 : 4;                                     // BadLogp, recoverable
+}
+
 struct nphip_model {
     int kind = 0;  // 0 fused tridiag, 1 host callback, 2 device callback
+    std::shared_ptr<BsAdapter> bs;
     uint64_t dim = 0;
     std::vector<double> mu, a, b;
     nphip_raw_logp_fn host_fn = nullptr;
@@ -287,6 +300,15 @@ nphip_model_t* nphip_model_host_callback(uint64_t dim, nphip_raw_logp_fn fn, voi
     if (dim == 0 || !fn) { set_error("host callback model needs dim > 0 and a function"); return nullptr; }
     auto* m = new nphip_model();
     m->kind = 1; m->dim = dim; m->host_fn = fn; m->user = user_data; m->n_threads = n_threads;
+    return m;
+}
+nphip_model_t* nphip_model_bridgestan(uint64_t dim, void* bs_model, void* log_density_gradient, void* free_error_msg, int n_threads) {
+    if (dim == 0 || !bs_model || !log_density_gradient) { set_error("bridgestan model needs dim > 0, a model handle and bs_log_density_gradient"); return nullptr; }
+    auto* m = new nphip_model();
+    m->kind = 1; m->dim = dim; m->n_threads = n_threads;
+    m->bs = std::make_shared<BsAdapter>(BsAdapter{bs_model, (bs_ldg_fn)log_density_gradient, (bs_free_err_fn)free_error_msg});
+    m->host_fn = bs_trampoline;
+    m->user = m->bs.get();
     return m;
 }
 nphip_model_t* nphip_model_device_callback(uint64_t dim, nphip_device_logp_fn fn, void* user_data) {
@@ -424,6 +446,11 @@ struct nphip_sampler {
 
     bool setup();
     void run();
+    bool manual = false;
+    int manual_have = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double* kernel_ms_acc = nullptr;  // when set, iterations time their kernel with HIP events
+    bool launch_kernel(bool fused_, int have);
     bool iteration_fused(bool& all_done);
     bool iteration_callback(bool& all_done, int& have);
     void fail(const std::string& msg) {
@@ -437,6 +464,7 @@ struct nphip_sampler {
         allocs.clear();
         for (void* h : pinned) (void)hipHostFree(h);
         pinned.clear();
+        if (ev0) { (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1); ev0 = ev1 = nullptr; }
         if (own_stream && stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
     }
 };
@@ -508,7 +536,9 @@ bool nphip_sampler::setup() {
         HIP_TRY(hipMemcpyAsync(b, model.b.data(), dim * 8, hipMemcpyHostToDevice, stream));
         args.m_mu = mu; args.m_a = a; args.m_b = b;
     } else {
-        if (!dalloc(&args.qeval, n * dim) || !dalloc(&args.geval, n * dim) || !dalloc(&args.ueval, n)) return false;
+        if (launch.staging_q && launch.staging_grad && launch.staging_logp) {
+            args.qeval = (double*)launch.staging_q; args.geval = (double*)launch.staging_grad; args.ueval = (double*)launch.staging_logp;
+        } else if (!dalloc(&args.qeval, n * dim) || !dalloc(&args.geval, n * dim) || !dalloc(&args.ueval, n)) return false;
         if (model.kind == 1) {
             if (!dalloc(&args.ecode, n)) return false;
             if (!palloc(&h_q, n * dim) || !palloc(&h_g, n * dim) || !palloc(&h_u, n) || !palloc(&h_code, n)) return false;
@@ -556,11 +586,29 @@ std::string nphip_sampler::chain_error_message() {
     return "chain error";
 }
 
-bool nphip_sampler::iteration_fused(bool& all_done) {
-    args.max_evals = launch.evals_per_launch > 0 ? launch.evals_per_launch : 512;
-    args.have_result = 0;
-    if (!hip_ok(launch_advance(args, true, W, stream), "launch k_advance")) return false;
+bool nphip_sampler::launch_kernel(bool fused_, int have) {
+    args.max_evals = fused_ ? (launch.evals_per_launch > 0 ? launch.evals_per_launch : 512) : 0;
+    args.have_result = have;
+    if (kernel_ms_acc) {
+        if (!ev0) {
+            if (!hip_ok(hipEventCreate(&ev0), "hipEventCreate") || !hip_ok(hipEventCreate(&ev1), "hipEventCreate")) return false;
+        }
+        if (!hip_ok(hipEventRecord(ev0, stream), "hipEventRecord")) return false;
+    }
+    if (!hip_ok(launch_advance(args, fused_, W, stream), "launch k_advance")) return false;
+    if (kernel_ms_acc) {
+        if (!hip_ok(hipEventRecord(ev1, stream), "hipEventRecord")) return false;
+        if (!hip_ok(hipEventSynchronize(ev1), "hipEventSynchronize")) return false;
+        float ms = 0.f;
+        if (!hip_ok(hipEventElapsedTime(&ms, ev0, ev1), "hipEventElapsedTime")) return false;
+        *kernel_ms_acc += (double)ms;
+    }
     launches.fetch_add(1);
+    return true;
+}
+
+bool nphip_sampler::iteration_fused(bool& all_done) {
+    if (!launch_kernel(true, 0)) return false;
     if (!hip_ok(hipMemcpyAsync(h_counters, args.counters, 16, hipMemcpyDeviceToHost, stream), "copy counters")) return false;
     if (!hip_ok(hipStreamSynchronize(stream), "hipStreamSynchronize")) return false;
     if (h_counters[1] > 0) { set_error(chain_error_message()); return false; }
@@ -569,10 +617,7 @@ bool nphip_sampler::iteration_fused(bool& all_done) {
 }
 
 bool nphip_sampler::iteration_callback(bool& all_done, int& have) {
-    args.max_evals = 0;
-    args.have_result = have;
-    if (!hip_ok(launch_advance(args, false, W, stream), "launch k_advance")) return false;
-    launches.fetch_add(1);
+    if (!launch_kernel(false, have)) return false;
     if (model.kind == 1) {
         // host callback: D2H positions, evaluate rows on the host pool, H2D gradients
         // (pinned hipMemcpyAsync; the reference calls the same function pointer once per
@@ -658,7 +703,9 @@ nphip_sampler_t* nphip_sampler_create(const nphip_settings_t* set, const nphip_m
     }
     if (!s->setup()) { s->release(); delete s; return nullptr; }
     s->want_pause = s->launch.start_paused != 0;
-    s->th = std::thread([s] { s->run(); });
+    s->manual = s->launch.manual != 0;
+    if (!s->manual) s->th = std::thread([s] { s->run(); });
+    else s->t_start = std::chrono::steady_clock::now();
     return s;
 }
 
@@ -673,7 +720,46 @@ void nphip_sampler_free(nphip_sampler_t* s) {
     delete s;
 }
 
+int nphip_sampler_step(nphip_sampler_t* s, uint64_t n_launches, double* kernel_ms, uint64_t* launches_done) {
+    if (!s->manual) { set_error("nphip_sampler_step needs a sampler created with launch.manual = 1"); return NPHIP_WAIT_ERROR; }
+    if (launches_done) *launches_done = 0;
+    if (kernel_ms) *kernel_ms = 0.0;
+    {
+        std::lock_guard<std::mutex> lk(s->mu);
+        if (s->failed) { set_error(s->error); return NPHIP_WAIT_ERROR; }
+        if (s->thread_done) return NPHIP_WAIT_DONE;
+    }
+    (void)hipSetDevice(s->device);
+    std::lock_guard<std::mutex> run_lk(s->mu_run);
+    s->kernel_ms_acc = kernel_ms;
+    bool all_done = false, ok = true;
+    auto t0 = std::chrono::steady_clock::now();
+    for (uint64_t i = 0; i < n_launches && !all_done; ++i) {
+        ok = s->fused ? s->iteration_fused(all_done) : s->iteration_callback(all_done, s->manual_have);
+        if (!ok) break;
+        if (launches_done) *launches_done += 1;
+    }
+    s->kernel_ms_acc = nullptr;
+    if (ok) ok = hip_ok(hipStreamSynchronize(s->stream), "hipStreamSynchronize");
+    s->seconds.store(s->seconds.load() + std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    if (!ok) { s->fail(t_error); return NPHIP_WAIT_ERROR; }
+    if (all_done) {
+        std::lock_guard<std::mutex> lk(s->mu);
+        s->finished = true;
+        s->thread_done = true;
+    }
+    return all_done ? NPHIP_WAIT_DONE : NPHIP_WAIT_TIMEOUT;
+}
+
 int nphip_sampler_wait(nphip_sampler_t* s, int64_t timeout_ms) {
+    if (s->manual) {
+        auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            int rc = nphip_sampler_step(s, 1, nullptr, nullptr);
+            if (rc != NPHIP_WAIT_TIMEOUT) return rc;
+            if (timeout_ms >= 0 && std::chrono::steady_clock::now() - t0 >= std::chrono::milliseconds(timeout_ms)) return NPHIP_WAIT_TIMEOUT;
+        }
+    }
     std::unique_lock<std::mutex> lk(s->mu);
     if (s->want_pause) { s->want_pause = false; s->cv.notify_all(); }  // wait resumes (sample.py:596-608)
     auto done = [&] { return s->thread_done; };
@@ -693,7 +779,7 @@ int nphip_sampler_resume(nphip_sampler_t* s) {
     return NPHIP_OK;
 }
 int nphip_sampler_abort(nphip_sampler_t* s) {
-    { std::lock_guard<std::mutex> lk(s->mu); s->want_abort = true; }
+    { std::lock_guard<std::mutex> lk(s->mu); s->want_abort = true; if (s->manual) s->thread_done = true; }
     s->cv.notify_all();
     if (s->th.joinable()) s->th.join();
     return NPHIP_OK;

@@ -1,0 +1,104 @@
+"""Chain sharding across GPUs: one process per GPU, no collective while sampling.
+
+Chains are independent in the reference (each ``ChainProgress`` carries its own step size,
+``src/wrapper.rs:90-93``; the mass matrix is per chain, ``docs/sample-stats.qmd:67-83``) and every
+random number in the engine is keyed by the GLOBAL chain id (``include/nphip_spec.h``), so a
+chain's draws do not depend on how many GPUs share the job.  The only communication is one
+gather of the (optionally thinned) trace to rank 0 at the end — ``torch.distributed.gather``,
+which RCCL executes as direct sends to the root and therefore uses all of the root's inbound
+xGMI links at once instead of a per-link-bound ring.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+
+def shard_chains(num_chains: int, world_size: int, rank: int) -> tuple[int, int]:
+    """Contiguous block partition: returns (chain_offset, n_local)."""
+    base, rem = divmod(int(num_chains), int(world_size))
+    n_local = base + (1 if rank < rem else 0)
+    offset = rank * base + min(rank, rem)
+    return offset, n_local
+
+
+def device_tensor(ptr: int, shape, dtype="float64", device=0):
+    """Zero-copy torch view of an engine-owned device buffer (``PySampler.device_ptr``)."""
+    import torch
+
+    typestr = {"float64": "<f8", "int64": "<i8", "uint8": "|u1"}[dtype]
+
+    class _Arr:
+        __cuda_array_interface__ = {"shape": tuple(int(s) for s in shape), "typestr": typestr, "data": (int(ptr), False), "version": 2, "strides": None}
+
+    return torch.as_tensor(_Arr(), device=torch.device("cuda", device))
+
+
+def gather_arrays(local: dict, n_local: int, group=None, dst: int = 0):
+    """Gather per-rank arrays whose leading axis is the local chain axis.
+
+    ``local``: name -> torch.Tensor (CPU for gloo, GPU for nccl/RCCL) or numpy array, leading dim
+    ``n_local``.  Returns name -> concatenated tensor (global chain order) on ``dst``, None elsewhere.
+    """
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    counts = [None] * world
+    dist.all_gather_object(counts, int(n_local), group=group)
+    nmax = max(counts)
+    out = {} if rank == dst else None
+    for name in sorted(local):
+        t = local[name]
+        if isinstance(t, np.ndarray):
+            t = torch.from_numpy(np.ascontiguousarray(t))
+        t = t.contiguous()
+        if t.shape[0] != nmax:  # pad ragged shards so every rank sends the same shape
+            pad = torch.zeros((nmax - t.shape[0], *t.shape[1:]), dtype=t.dtype, device=t.device)
+            t = torch.cat([t, pad], 0)
+        bufs = [torch.empty_like(t) for _ in range(world)] if rank == dst else None
+        dist.gather(t, bufs, dst=dst, group=group)
+        if rank == dst:
+            out[name] = torch.cat([b[: counts[r]] for r, b in enumerate(bufs)], 0)
+    return out
+
+
+def sample_sharded(make_sampler, num_chains: int, *, group=None, thin: int = 1, dims=None, gather_draws: bool = True,
+                   stats=("depth", "n_steps", "diverging", "tuning", "step_size", "energy", "logp"), device=None):
+    """Run this rank's shard to completion and gather the trace on rank 0.
+
+    ``make_sampler(chain_offset, n_local) -> PySampler``.  Draws are thinned by ``thin`` and restricted to
+    ``dims`` ON DEVICE before the gather (a full config-5 trace is 82 GB per GPU).
+    Returns ``(sampler, gathered)``; ``gathered`` is a dict of tensors on rank 0 and None elsewhere.
+    """
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    offset, n_local = shard_chains(num_chains, world, rank)
+    sampler = make_sampler(offset, n_local)
+    sampler.wait()
+    T, D = sampler.total_draws, sampler.dim
+    on_gpu = dist.get_backend(group) == "nccl"
+    dev = device if device is not None else (torch.cuda.current_device() if on_gpu else None)
+    local = {}
+    dtypes = {"depth": "int64", "n_steps": "int64", "index_in_trajectory": "int64", "diverging": "uint8", "maxdepth_reached": "uint8", "tuning": "uint8"}
+    for name in stats:
+        ptr = sampler.device_ptr(name)
+        if on_gpu:
+            local[name] = device_tensor(ptr, (n_local, T), dtypes.get(name, "float64"), dev)
+        else:
+            local[name] = sampler._copy(name, np.dtype(dtypes.get(name, "float64")))
+    if gather_draws and sampler.device_ptr("draws"):
+        if on_gpu:
+            d = device_tensor(sampler.device_ptr("draws"), (n_local, T, D), "float64", dev)
+        else:
+            d = torch.from_numpy(sampler._copy("draws", np.float64, vec=True))
+        d = d[:, ::thin]
+        if dims is not None:
+            d = d[:, :, torch.as_tensor(list(dims), device=d.device)]
+        local["draws"] = d.contiguous()
+    gathered = gather_arrays(local, n_local, group=group)
+    return sampler, gathered

@@ -1,0 +1,115 @@
+"""Analytic Gaussian targets (BASELINE.json configs 1, 2 and 5).
+
+``TridiagGaussian`` is evaluated inside the leapfrog kernel (fused analytic gradient);
+``dense_gaussian`` goes through the batched torch callback (its gradient is an fp64 GEMM and
+is deliberately kept out of the leapfrog kernel — SURVEY.md §7 "hard parts").
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+from nutpie_amd import _lib
+from nutpie_amd.sample import CompiledModel
+
+BENCH_RNG_SEED = 20260926  # inputs from numpy.random.default_rng(20260926)
+
+
+@dataclass(frozen=True)
+class TridiagGaussian(CompiledModel):
+    """logp(x) = -1/2 (x - mu)' L (x - mu) with L = tridiag(offdiag, diag, offdiag)."""
+
+    diag: np.ndarray = None
+    offdiag: np.ndarray | None = None
+    mu: np.ndarray | None = None
+    name: str = "x"
+    init: str = "uniform"
+
+    @property
+    def n_dim(self):
+        return int(len(self.diag))
+
+    @property
+    def shapes(self):
+        return {self.name: (self.n_dim,)}
+
+    @property
+    def coords(self):
+        return {}
+
+    def _make_model(self, init_mean=None, settings=None):
+        m = _lib.TridiagGaussianModel(self.diag, self.offdiag, self.mu)
+        m.set_init(self.init)
+        return m
+
+    def _make_sampler(self, settings, init_mean, cores, progress_type, extra_callback, extra_callback_rate, store, **engine_kw):
+        return _lib.PySampler.from_pyfunc(settings, cores, self._make_model(), progress_type, extra_callback, extra_callback_rate, store, **engine_kw)
+
+    def _expand_draws(self, draws):
+        return {self.name: draws}
+
+    # analytic moments, used by the statistical tests
+    def covariance(self):
+        n = self.n_dim
+        L = np.diag(np.asarray(self.diag, dtype=np.float64))
+        if self.offdiag is not None and n > 1:
+            L += np.diag(self.offdiag, 1) + np.diag(self.offdiag, -1)
+        return np.linalg.inv(L)
+
+
+def std_normal(dim: int) -> TridiagGaussian:
+    """Config 1: D-dimensional standard normal."""
+    return TridiagGaussian(dims={}, diag=np.ones(dim))
+
+
+def diag_gaussian(sd, mu=None) -> TridiagGaussian:
+    sd = np.asarray(sd, dtype=np.float64)
+    return TridiagGaussian(dims={}, diag=1.0 / sd**2, mu=None if mu is None else np.asarray(mu, dtype=np.float64))
+
+
+def ar1_gaussian(dim: int, rho: float = 0.9, scales=None, seed: int = BENCH_RNG_SEED) -> TridiagGaussian:
+    """Config 2/5 (variant i of SURVEY.md §8d): x_i = s_i y_i, y a stationary AR(1) process with
+    correlation rho — tridiagonal precision, per-dimension scales s_i = exp(N(0,1))."""
+    if scales is None:
+        scales = np.exp(np.random.default_rng(seed).normal(size=dim))
+    s = np.asarray(scales, dtype=np.float64)
+    c = 1.0 / (1.0 - rho * rho)
+    d = np.full(dim, (1.0 + rho * rho) * c)
+    d[0] = d[-1] = c
+    if dim == 1:
+        d[0] = 1.0
+    off = np.full(max(dim - 1, 0), -rho * c)
+    diag = d / s**2
+    offdiag = off / (s[:-1] * s[1:])
+    return TridiagGaussian(dims={}, diag=diag, offdiag=offdiag if dim > 1 else None)
+
+
+def dense_gaussian(dim: int, seed: int = BENCH_RNG_SEED, cond_lo=1e-2, cond_hi=1e2, device=0):
+    """Config 2 variant (ii): dense covariance S C S with C = Q diag(lam) Q', lam log-uniform.
+    Returns a batched torch model (gradient = fp64 GEMM via rocBLAS, outside the leapfrog kernel)."""
+    import torch
+
+    from nutpie_amd.compiled_pyfunc import from_torchfunc
+
+    rng = np.random.default_rng(seed)
+    s = np.exp(rng.normal(size=dim))
+    Q, _ = np.linalg.qr(rng.normal(size=(dim, dim)))
+    lam = np.exp(rng.uniform(np.log(cond_lo), np.log(cond_hi), size=dim))
+    prec = (Q / lam) @ Q.T
+    prec = prec / np.outer(s, s)
+    prec = 0.5 * (prec + prec.T)
+
+    def make_logp():
+        P = torch.as_tensor(prec, dtype=torch.float64, device=torch.device("cuda", device))
+
+        def logp(x):
+            g = -(x @ P)
+            return 0.5 * (x * g).sum(-1), g
+
+        return logp
+
+    model = from_torchfunc(dim, make_logp)
+    object.__setattr__(model, "_precision", prec)
+    return model

@@ -1,0 +1,78 @@
+import ctypes
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FIXTURES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fixtures")
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import oracle as _oracle
+
+    _oracle.build()
+    return _oracle
+
+
+@pytest.fixture(scope="session")
+def fixture_lib():
+    """gcc-built shared library with the eight-schools test model (tests/fixtures/eight_schools.c)."""
+    src = os.path.join(FIXTURES, "eight_schools.c")
+    out = os.path.join(FIXTURES, "libeight_schools.so")
+    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        subprocess.run(["gcc", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-o", out, src, "-lm"], check=True)
+    lib = ctypes.CDLL(out)
+    lib.bs_model_construct.restype = ctypes.c_void_p
+    lib.bs_model_construct.argtypes = [ctypes.c_char_p, ctypes.c_uint, ctypes.c_void_p]
+    lib.bs_model_destruct.argtypes = [ctypes.c_void_p]
+    return lib
+
+
+@pytest.fixture(scope="session")
+def hip():
+    """The HIP engine binding; GPU tests fail (not skip) if the extension is missing."""
+    from nutpie_amd import _lib
+
+    _lib.lib()
+    return _lib
+
+
+def fn_addr(cfunc):
+    return ctypes.cast(cfunc, ctypes.c_void_p).value
+
+
+INT_STATS = ("depth", "n_steps", "index_in_trajectory", "diverging", "maxdepth_reached", "tuning")
+FLOAT_STATS = ("energy", "energy_error", "logp", "step_size", "step_size_bar", "mean_tree_accept", "mean_tree_accept_sym")
+
+
+def assert_trace_equal(got, want, *, draws=True, float_rtol=0.0):
+    """got: nutpie_amd PyTrace, want: oracle Trace.  Integer statistics must be bit-identical;
+    floating-point statistics/draws bit-identical by default (float_rtol=0)."""
+    for k in INT_STATS:
+        a = np.asarray(got.stats[k]).astype(np.int64)
+        b = np.asarray(want.stats[k]).astype(np.int64)
+        bad = np.argwhere(a != b)
+        assert bad.size == 0, f"{k}: {len(bad)} mismatches, first at {bad[0]}: {a[tuple(bad[0])]} != {b[tuple(bad[0])]}"
+    for k in FLOAT_STATS:
+        a, b = np.asarray(got.stats[k]), np.asarray(want.stats[k])
+        if float_rtol == 0.0:
+            assert np.array_equal(a, b), f"{k}: max abs diff {np.nanmax(np.abs(a - b))}"
+        else:
+            np.testing.assert_allclose(a, b, rtol=float_rtol, atol=0, err_msg=k)
+    if draws:
+        if float_rtol == 0.0:
+            assert np.array_equal(got.draws, want.draws), f"draws: max abs diff {np.abs(got.draws - want.draws).max()}"
+        else:
+            np.testing.assert_allclose(got.draws, want.draws, rtol=float_rtol, atol=0)

@@ -1,0 +1,152 @@
+"""nutpie_amd.sample end to end on the GPU — the behavioural pins of the reference's own tests
+(tests/test_pymc.py, tests/test_stan.py) that do not depend on nuts-rs' RNG stream."""
+import time
+
+import numpy as np
+import pytest
+
+import nutpie_amd
+
+pytestmark = pytest.mark.gpu
+
+
+def test_sample_shapes_and_groups():
+    # tests/test_pymc.py:189-191: draws=17, tune=100, chains=1 -> posterior shape (1, 17, ...)
+    tr = nutpie_amd.sample(nutpie_amd.std_normal(5), chains=1, draws=17, tune=100, seed=1, progress_bar=False)
+    assert tr.posterior.x.shape == (1, 17, 5)
+    assert tr.warmup_posterior.x.shape == (1, 100, 5)
+    for k in ("depth", "maxdepth_reached", "logp", "energy", "diverging", "step_size", "step_size_bar", "n_steps"):  # docs/sample-stats.qmd:47-56
+        assert k in tr.sample_stats, k
+    assert tr.sample_stats.attrs["inference_library"] == "nutpie"
+    tr = nutpie_amd.sample(nutpie_amd.std_normal(5), chains=2, draws=10, tune=20, seed=1, progress_bar=False, save_warmup=False)
+    assert "warmup_posterior" not in tr and tr.posterior.x.shape == (2, 10, 5)
+    # default sizes: 6 chains x 1000 draws (tests/test_stan.py:241)
+    tr = nutpie_amd.sample(nutpie_amd.std_normal(2), seed=1, progress_bar=False)
+    assert tr.posterior.x.shape == (6, 1000, 2)
+
+
+def test_seed_semantics():
+    # tests/test_stan.py:67-101
+    m = nutpie_amd.std_normal(3)
+    a = nutpie_amd.sample(m, seed=42, chains=4, draws=50, tune=50, progress_bar=False)
+    b = nutpie_amd.sample(m, seed=42, chains=4, draws=50, tune=50, progress_bar=False)
+    c = nutpie_amd.sample(m, seed=43, chains=4, draws=50, tune=50, progress_bar=False)
+    assert np.array_equal(a.posterior.x.values, b.posterior.x.values)      # max-ULP identical (test_stan.py:298-301)
+    assert not np.allclose(a.posterior.x.values, c.posterior.x.values)
+    for i in range(4):
+        for j in range(i + 1, 4):
+            assert not np.allclose(a.posterior.x.values[i], a.posterior.x.values[j])
+
+
+def test_store_flags_add_exactly_the_listed_stats():
+    # tests/test_pymc.py:303-349
+    m = nutpie_amd.diag_gaussian([1.0, 100.0, 0.01])
+    base = nutpie_amd.sample(m, chains=2, draws=20, tune=50, seed=1, progress_bar=False)
+    for k in ("gradient", "unconstrained_draw", "mass_matrix_inv", "divergence_start"):
+        assert k not in base.sample_stats
+    tr = nutpie_amd.sample(m, chains=2, draws=20, tune=50, seed=1, progress_bar=False, store_gradient=True, store_unconstrained=True,
+                           store_mass_matrix=True, store_divergences=True, max_energy_error=0.3)
+    assert tr.sample_stats.gradient.shape == (2, 20, 3) and tr.sample_stats.unconstrained_draw.shape == (2, 20, 3)
+    assert tr.sample_stats.mass_matrix_inv.shape == (2, 20, 3)
+    np.testing.assert_allclose(tr.sample_stats.gradient.values, -tr.posterior.x.values / np.array([1.0, 100.0, 0.01]) ** 2, rtol=1e-12)
+    assert np.array_equal(tr.sample_stats.unconstrained_draw.values, tr.posterior.x.values)
+    for k in ("divergence_start", "divergence_end", "divergence_momentum", "divergence_start_gradient"):
+        assert k in tr.warmup_sample_stats
+    div = tr.warmup_sample_stats.diverging.values
+    assert div.sum() > 0
+    ds = tr.warmup_sample_stats.divergence_start.values
+    assert np.all(np.isfinite(ds[div])) and np.all(np.isnan(ds[~div]))
+
+
+def test_adaptation_draw_diag_and_settings_attr():
+    m = nutpie_amd.diag_gaussian([0.1, 1.0, 10.0])
+    tr = nutpie_amd.sample(m, chains=4, draws=300, tune=300, seed=3, progress_bar=False, adaptation="draw_diag", store_mass_matrix=True)
+    import json
+
+    st = json.loads(tr.sample_stats.attrs["inference_library_settings"])
+    assert st["settings"]["adapt_options"]["mass_matrix_options"]["use_grad_based_estimate"] is False
+    mm = tr.sample_stats.mass_matrix_inv.values[:, -1]
+    assert np.all(np.abs(np.log(mm / np.array([0.01, 1.0, 100.0]))) < 1.0)
+    sd = tr.posterior.x.values.std((0, 1))
+    np.testing.assert_allclose(sd, [0.1, 1.0, 10.0], rtol=0.15)
+
+
+def test_progress_callback_final_state():
+    # tests/test_pymc.py:37-66
+    seen = []
+    tr = nutpie_amd.sample(nutpie_amd.std_normal(50), chains=3, draws=200, tune=200, seed=1, progress_bar=False,
+                           progress_callback=seen.append, progress_rate=10)
+    assert tr.posterior.x.shape == (3, 200, 50)
+    assert len(seen) >= 1
+    last = seen[-1]
+    assert len(last) == 3
+    for p in last:
+        assert isinstance(p, nutpie_amd.ChainProgress)
+        assert p.finished_draws == p.total_draws == 400
+        assert isinstance(p.divergences, int) and isinstance(p.tuning, bool) and isinstance(p.started, bool)
+        assert isinstance(p.step_size, float) and p.step_size > 0
+        assert p.total_num_steps >= p.latest_num_steps >= 1 and p.num_steps == p.latest_num_steps
+        assert isinstance(p.runtime_ms, int) and isinstance(p.divergent_draws, list)
+
+
+def test_non_blocking_timeout_pause_abort():
+    # tests/test_pymc.py:224-286: blocking=False, wait(timeout) raises TimeoutError, cancel returns fast,
+    # pause/resume, abort returns the partial trace
+    from nutpie_amd.gaussian import ar1_gaussian
+
+    m = ar1_gaussian(2000, rho=0.99)   # slow enough to observe
+    smp = nutpie_amd.sample(m, chains=256, draws=100000, tune=1000, seed=1, progress_bar=False, blocking=False, maxdepth=10)
+    with pytest.raises(TimeoutError):
+        smp.wait(timeout=0.3)
+    assert not smp.is_finished
+    smp.pause()
+    time.sleep(0.2)
+    part = smp.inspect()
+    n1 = int(np.isfinite(part.warmup_posterior.x.values[:, :, 0]).sum() + np.isfinite(part.posterior.x.values[:, :, 0]).sum()) if "posterior" in part else 0
+    time.sleep(0.3)
+    part2 = smp.inspect()
+    n2 = int(np.isfinite(part2.warmup_posterior.x.values[:, :, 0]).sum())
+    assert n2 == n1 or n2 - n1 <= 256 * 2       # paused: (almost) no progress
+    smp.resume()
+    time.sleep(0.3)
+    t0 = time.time()
+    tr = smp.abort()
+    assert time.time() - t0 < 20
+    wx = tr.warmup_posterior.x.values
+    assert wx.shape[0] == 256 and np.isfinite(wx[:, 0, 0]).all()      # every chain produced at least one draw
+    assert np.isnan(wx).any() or wx.shape[1] < 1000                     # but not the whole run
+    # cancel: discards and returns quickly
+    smp2 = nutpie_amd.sample(m, chains=64, draws=100000, tune=1000, seed=1, progress_bar=False, blocking=False)
+    time.sleep(0.2)
+    t0 = time.time()
+    smp2.cancel()
+    assert time.time() - t0 < 10
+
+
+def test_from_pyfunc_drop_in():
+    # the reference's generic model API (compiled_pyfunc.py:108-155) on the GPU engine (host-callback path)
+    def make_logp():
+        return lambda x: (-0.5 * float(x @ x) - 0.5 * float((x[0] - 1) ** 2), -x - np.array([x[0] - 1, 0.0]))
+
+    def make_expand(seed1, seed2, chain):
+        return lambda x: {"y": x, "ysq": np.array(x[0] ** 2)}
+
+    m = nutpie_amd.from_pyfunc(2, make_logp, make_expand, [np.float64, np.float64], [(2,), ()], ["y", "ysq"],
+                               make_initial_point_fn=lambda seed: np.zeros(2))
+    tr = nutpie_amd.sample(m, chains=2, draws=150, tune=150, seed=1, progress_bar=False)
+    assert tr.posterior.y.shape == (2, 150, 2) and tr.posterior.ysq.shape == (2, 150)
+    assert abs(tr.posterior.y.values[..., 0].mean() - 0.5) < 0.3   # N(0.5, 1/2) in the first coordinate
+    assert np.array_equal(tr.posterior.ysq.values, tr.posterior.y.values[..., 0] ** 2)
+
+
+def test_raw_callback_front_end(fixture_lib):
+    # the pointer a reference-compiled PyMC model carries (numba cfunc address) plugs in unchanged
+    from nutpie_amd.compile_pymc import from_raw_callback
+    from tests.conftest import fn_addr
+
+    m = from_raw_callback(10, fn_addr(fixture_lib.eight_schools_logp), name="theta", n_threads=4, init="normal", keep_alive=fixture_lib)
+    tr = nutpie_amd.sample(m, chains=256, draws=200, tune=300, seed=4, progress_bar=False)  # BASELINE.json config 4 sizes
+    assert tr.posterior.theta.shape == (256, 200, 10)
+    mu = tr.posterior.theta.values[..., 0]
+    assert 3.0 < mu.mean() < 6.0 and 2.0 < mu.std() < 5.0          # eight schools: mu ~ 4.4 +- 3.3
+    assert tr.sample_stats.diverging.values.mean() < 0.05

@@ -1,0 +1,322 @@
+"""Parity of the HIP engine with the CPU oracle, through the C-ABI, on a real MI355X.
+
+Bar (north star): tree depth, n_steps, divergences, index_in_trajectory and the tuning flag bit-identical;
+draws, energies and step sizes within a stated fp64 tolerance.  Because host and device share one numerics
+contract (include/nphip_spec.h: counter-based RNG, fma-only elementary functions, fixed summation order) the
+tolerance used for the fused analytic models is ZERO: every float is compared bit-for-bit.  Models whose
+gradient comes from another library (torch GEMM) use rtol = 1e-9 on floats and equality on integers is then
+not required (documented in the test).
+"""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from tests.conftest import GOLDEN, assert_trace_equal, fn_addr
+
+pytestmark = pytest.mark.gpu
+
+
+def run_engine(hip, model, *, chains, tune, draws, seed, waves=0, init=None, launch=None, **settings):
+    s = hip.PyNutsSettings.Diag(seed)
+    s.update(num_tune=tune, num_draws=draws, num_chains=chains, **settings)
+    if init is not None:
+        model.set_init(*init) if isinstance(init, tuple) else model.set_init(init)
+    smp = hip.PySampler(s, model, waves_per_chain=waves, **(launch or {}))
+    smp.wait()
+    W = smp.waves_per_chain
+    return smp.take_results(), W
+
+
+ORACLE_KEYS = {"use_grad_based_mass_matrix": "use_grad_based_mass_matrix", "max_energy_error": "max_energy_error", "maxdepth": "maxdepth",
+               "mindepth": "mindepth", "check_turning": "check_turning", "target_accept": "target_accept", "initial_step": "initial_step",
+               "step_size_jitter": "step_size_jitter", "window_switch_freq": "mass_matrix_switch_freq",
+               "early_window_switch_freq": "early_mass_matrix_switch_freq", "max_step_size": "max_step_size",
+               "adapt_mass_matrix": "adapt_mass_matrix", "num_try_init": "num_try_init"}
+
+
+def oracle_settings(oracle, *, chains, tune, draws, seed, W, init_kind=0, chain_offset=0, **settings):
+    kw = {}
+    for k, v in settings.items():
+        if k == "step_size_adapt_method":
+            kw["fixed_step_size"] = 1
+            kw["initial_step"] = float(v)
+        elif k in ("store_gradient", "store_mass_matrix"):
+            kw[k] = int(v)
+        elif k in ("store_divergences", "store_unconstrained"):
+            continue
+        else:
+            kw[ORACLE_KEYS[k]] = int(v) if isinstance(v, bool) else v
+    return oracle.default_settings(seed=seed, num_chains=chains, num_tune=tune, num_draws=draws, n_threads=8, waves_per_chain=W,
+                                   init_kind=init_kind, chain_offset=chain_offset, **kw)
+
+
+# ------------------------------------------------------------------------------------ numerics contract
+def test_device_detmath_is_bit_identical_to_the_oracle(hip, oracle):
+    rng = np.random.default_rng(0)
+    cases = [("exp", rng.uniform(-745, 710, 300000)), ("exp", rng.uniform(-3, 3, 100000)),
+             ("log", np.exp(rng.uniform(-700, 700, 300000))), ("log", 1 + rng.uniform(-1e-3, 1e-3, 100000)),
+             ("log", np.array([5e-324, 1e-310, 2.2250738585072014e-308, 1.0, np.inf, 0.0])),
+             ("log1p", rng.uniform(0, 1, 200000)), ("sin2pi", rng.uniform(0, 1, 200000)), ("cos2pi", rng.uniform(0, 1, 200000))]
+    for fn, x in cases:
+        a, b = hip.test_detmath(fn, x), oracle.detmath(fn, x)
+        assert np.array_equal(a.view(np.uint64), b.view(np.uint64)), fn
+
+
+def test_device_sqrt_and_division_are_correctly_rounded(hip):
+    rng = np.random.default_rng(1)
+    x = np.exp(rng.uniform(-600, 600, 500000))
+    assert np.array_equal(hip.test_detmath("sqrt", x), np.sqrt(x))
+    assert np.array_equal(hip.test_detmath("recip", x), 1.0 / x)
+
+
+def test_device_normals_and_dot(hip, oracle):
+    for n in (1, 2, 7, 1000, 4097):
+        assert np.array_equal(hip.test_normals(123, 5, 7, 1, n), oracle.normals(123, 5, 7, 1, n))
+    rng = np.random.default_rng(2)
+    for W in (1, 2, 4, 8, 16):
+        for n in (1, 63, 128, 129, 1000, 10000, 40001):
+            x, y = rng.normal(size=n), rng.normal(size=n)
+            assert hip.test_dot(x, y, W) == oracle.dot(x, y, W), (W, n)
+
+
+# ------------------------------------------------------------------------------------ sampler parity
+def test_config1_std_normal_bit_identical(hip, oracle):
+    # BASELINE.json config 1 through the GPU engine (the reference runs it on the CPU)
+    got, W = run_engine(hip, hip.TridiagGaussianModel(np.ones(10)), chains=4, tune=400, draws=1000, seed=123)
+    want = oracle.sample_tridiag(oracle_settings(oracle, chains=4, tune=400, draws=1000, seed=123, W=W), np.ones(10))
+    assert_trace_equal(got, want)
+    assert got.finished.tolist() == [1400] * 4
+
+
+@pytest.mark.parametrize("name", ["stdnormal_d10", "ar1_d257", "diag_d1000_w2", "divergent_d3", "maxdepth3_d64"])
+def test_engine_matches_committed_golden_vectors(hip, name):
+    # golden vectors produced by the repo's CPU oracle (tests/golden/make_golden.py); no oracle run needed here
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(GOLDEN, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    kw, mspec = mg.CASES[name]
+    kw = dict(kw)
+    margs = mg.model_args(mspec)
+    W = kw.pop("waves_per_chain", 1)
+    extra = {k: kw.pop(k) for k in list(kw) if k in ("maxdepth", "max_energy_error")}
+    got, _ = run_engine(hip, hip.TridiagGaussianModel(margs["diag"], margs.get("offdiag"), margs.get("mu")), chains=kw["num_chains"],
+                        tune=kw["num_tune"], draws=kw["num_draws"], seed=kw["seed"], waves=W, **extra)
+    gold = np.load(os.path.join(GOLDEN, f"oracle_{name}.npz"))
+    for k in ("depth", "n_steps", "index_in_trajectory", "diverging", "maxdepth_reached", "tuning"):
+        assert np.array_equal(np.asarray(got.stats[k]).astype(gold[k].dtype), gold[k]), k
+    for k in ("energy", "logp", "step_size", "step_size_bar", "mean_tree_accept"):
+        assert np.array_equal(got.stats[k], gold[k]), k
+    assert np.array_equal(got.draws[:, ::10, :8], gold["draws_thin"])
+
+
+@pytest.mark.parametrize("dim,waves", [(1, 1), (2, 1), (127, 1), (128, 1), (129, 2), (1000, 1), (1000, 4), (2500, 2), (5003, 8), (9000, 16)])
+def test_correlated_gaussian_all_geometries(hip, oracle, dim, waves):
+    rng = np.random.default_rng(dim)
+    sd = np.exp(0.7 * rng.normal(size=dim))
+    rho = 0.8
+    c = 1 / (1 - rho * rho)
+    d = np.full(dim, (1 + rho * rho) * c); d[0] = d[-1] = c
+    if dim == 1:
+        d[:] = 1.0
+    diag = d / sd**2
+    off = -rho * c / (sd[:-1] * sd[1:]) if dim > 1 else None
+    mu = rng.normal(size=dim)
+    chains, tune, draws = (8, 120, 40) if dim <= 1000 else (4, 40, 10)
+    got, W = run_engine(hip, hip.TridiagGaussianModel(diag, off, mu), chains=chains, tune=tune, draws=draws, seed=dim + 1, waves=waves,
+                        store_gradient=True, store_mass_matrix=True)
+    assert W == waves
+    want = oracle.sample_tridiag(oracle_settings(oracle, chains=chains, tune=tune, draws=draws, seed=dim + 1, W=W, store_gradient=True, store_mass_matrix=True), diag, off, mu)
+    assert_trace_equal(got, want)
+    assert np.array_equal(got.stats["gradient"], want.stats["gradient"])
+    assert np.array_equal(got.stats["mass_matrix_inv"], want.stats["mass_matrix_inv"])
+
+
+@pytest.mark.parametrize("settings", [
+    dict(use_grad_based_mass_matrix=False),                 # adaptation="draw_diag"
+    dict(max_energy_error=0.2),                             # many divergences
+    dict(maxdepth=2),                                       # maxdepth_reached path
+    dict(maxdepth=12, target_accept=0.99),                  # deep trees
+    dict(mindepth=3),
+    dict(check_turning=False, maxdepth=4),
+    dict(step_size_jitter=0.3),
+    dict(step_size_adapt_method="0.3"),                     # fixed step size
+    dict(window_switch_freq=20, early_window_switch_freq=4),
+    dict(adapt_mass_matrix=False),
+    dict(max_step_size=0.2),
+    dict(initial_step=5.0),                                 # search goes downwards
+    dict(initial_step=1e-4),                                # search goes upwards
+])
+def test_settings_variants_bit_identical(hip, oracle, settings):
+    rng = np.random.default_rng(5)
+    diag = np.exp(rng.normal(size=24) * 1.5)
+    got, W = run_engine(hip, hip.TridiagGaussianModel(diag), chains=6, tune=150, draws=60, seed=99, **settings)
+    want = oracle.sample_tridiag(oracle_settings(oracle, chains=6, tune=150, draws=60, seed=99, W=W, **settings), diag)
+    assert_trace_equal(got, want)
+    if "max_energy_error" in settings:
+        assert got.stats["diverging"].sum() > 20
+    if settings.get("maxdepth") == 2:
+        assert got.stats["maxdepth_reached"].sum() > 0 and got.stats["depth"].max() == 2
+
+
+def test_init_strategies(hip, oracle):
+    diag = np.array([1.0, 4.0, 0.25])
+    # N(0,1) initial points: src/stan.rs:798-808
+    got, W = run_engine(hip, hip.TridiagGaussianModel(diag), chains=4, tune=30, draws=10, seed=3, init="normal")
+    want = oracle.sample_tridiag(oracle_settings(oracle, chains=4, tune=30, draws=10, seed=3, W=W, init_kind=1), diag)
+    assert_trace_equal(got, want)
+    # explicit initial points: src/pymc.rs:505-534
+    pts = np.random.default_rng(0).normal(size=(4, 3))
+    got, W = run_engine(hip, hip.TridiagGaussianModel(diag), chains=4, tune=30, draws=10, seed=3, init=("explicit", pts))
+    want = oracle.sample_tridiag(oracle_settings(oracle, chains=4, tune=30, draws=10, seed=3, W=W, init_kind=2), diag, init_points=pts)
+    assert_trace_equal(got, want)
+
+
+def test_chain_sharding_is_invariant(hip, oracle):
+    # two "GPUs" = two samplers with chain offsets; concatenation equals the single job
+    diag = np.linspace(0.5, 3.0, 40)
+    full, W = run_engine(hip, hip.TridiagGaussianModel(diag), chains=10, tune=60, draws=20, seed=8)
+    lo, _ = run_engine(hip, hip.TridiagGaussianModel(diag), chains=10, tune=60, draws=20, seed=8, launch=dict(chain_offset=0, n_local_chains=6))
+    hi, _ = run_engine(hip, hip.TridiagGaussianModel(diag), chains=10, tune=60, draws=20, seed=8, launch=dict(chain_offset=6, n_local_chains=4))
+    assert np.array_equal(full.draws, np.concatenate([lo.draws, hi.draws]))
+    for k in ("depth", "n_steps", "step_size"):
+        assert np.array_equal(full.stats[k], np.concatenate([lo.stats[k], hi.stats[k]]))
+
+
+def test_result_does_not_depend_on_launch_slicing(hip):
+    diag = np.exp(np.random.default_rng(1).normal(size=300))
+    a, _ = run_engine(hip, hip.TridiagGaussianModel(diag), chains=8, tune=50, draws=20, seed=4, launch=dict(evals_per_launch=1))
+    b, _ = run_engine(hip, hip.TridiagGaussianModel(diag), chains=8, tune=50, draws=20, seed=4, launch=dict(evals_per_launch=7))
+    c, _ = run_engine(hip, hip.TridiagGaussianModel(diag), chains=8, tune=50, draws=20, seed=4, launch=dict(evals_per_launch=100000))
+    for x in (b, c):
+        assert np.array_equal(a.draws, x.draws) and np.array_equal(a.stats["n_steps"], x.stats["n_steps"])
+
+
+# ------------------------------------------------------------------------------------ callback flavours
+def test_host_callback_eight_schools_bit_identical(hip, oracle, fixture_lib):
+    # BASELINE.json config 4 at test size: raw C callback (src/pymc.rs:23-29 signature), pinned D2H/H2D per step
+    addr = fn_addr(fixture_lib.eight_schools_logp)
+    got, W = run_engine(hip, hip.HostCallbackModel(10, addr, n_threads=4), chains=16, tune=200, draws=100, seed=21, init="normal")
+    want = oracle.sample_callback(oracle_settings(oracle, chains=16, tune=200, draws=100, seed=21, W=W, init_kind=1), 10, addr)
+    assert_trace_equal(got, want)
+    # sanity of the posterior: mu around 4.4, tau positive
+    mu = got.draws[:, 200:, 0]
+    assert 2.0 < mu.mean() < 7.0
+
+
+def test_bridgestan_adapter_matches_raw_callback(hip, oracle, fixture_lib):
+    # the BridgeStan C API stand-in evaluates the same density: identical trace through nphip_model_bridgestan
+    model_ptr = fixture_lib.bs_model_construct(None, 0, None)
+    try:
+        m = hip.BridgeStanModel(10, fixture_lib, ctypes.c_void_p(model_ptr), n_threads=2)
+        got, W = run_engine(hip, m, chains=8, tune=120, draws=40, seed=22, init="normal")
+    finally:
+        fixture_lib.bs_model_destruct(ctypes.c_void_p(model_ptr))
+    want = oracle.sample_callback(oracle_settings(oracle, chains=8, tune=120, draws=40, seed=22, W=W, init_kind=1), 10, fn_addr(fixture_lib.eight_schools_logp))
+    assert_trace_equal(got, want)
+
+
+def test_recoverable_and_fatal_callback_codes(hip, oracle, fixture_lib):
+    addr = fn_addr(fixture_lib.failing_logp)
+    got, W = run_engine(hip, hip.HostCallbackModel(3, addr, n_threads=2), chains=4, tune=60, draws=60, seed=8, init="normal")
+    want = oracle.sample_callback(oracle_settings(oracle, chains=4, tune=60, draws=60, seed=8, W=W, init_kind=1), 3, addr)
+    assert_trace_equal(got, want)
+    assert got.stats["diverging"].sum() > 0 and got.draws[:, :, 0].max() <= 2.5 + 1e-12
+    # a negative code is fatal: wait() raises, as src/pymc.rs:166-180 + wrapper.rs:1131-1136
+    s = hip.PyNutsSettings.Diag(1)
+    s.update(num_tune=10, num_draws=10, num_chains=2)
+    smp = hip.PySampler(s, hip.HostCallbackModel(3, fn_addr(fixture_lib.fatal_logp)))
+    with pytest.raises(RuntimeError, match="fatal"):
+        smp.wait()
+
+
+def test_python_callable_through_host_callback(hip, oracle):
+    def logp(x):
+        return -0.5 * float(x @ x), -x
+
+    got, W = run_engine(hip, hip.HostCallbackModel(4, logp), chains=3, tune=40, draws=20, seed=2)
+    want = oracle.sample_callback(oracle_settings(oracle, chains=3, tune=40, draws=20, seed=2, W=W), 4, logp)
+    assert_trace_equal(got, want)
+
+
+def test_torch_device_callback_matches_fused_model(hip, oracle):
+    """Batched torch logp (BASELINE.json config 3 flavour).  The diagonal Gaussian evaluated by torch uses the same
+    IEEE operations per element (mul, neg) but torch reduces logp in its own order: integer statistics can
+    legitimately differ once a U-turn dot product rounds differently, so the comparison is statistical plus a
+    tight tolerance on the first draws, where no reordering has accumulated."""
+    import torch
+
+    import nutpie_amd
+
+    sd = np.array([0.5, 1.0, 2.0, 4.0, 0.1, 10.0])
+
+    def make_logp():
+        prec = torch.as_tensor(1 / sd**2, device="cuda")
+
+        def f(x):
+            g = -(x * prec)
+            return 0.5 * (x * g).sum(-1), g
+
+        return f
+
+    m = nutpie_amd.from_torchfunc(6, make_logp)
+    tr = nutpie_amd.sample(m, chains=64, tune=300, draws=300, seed=5, progress_bar=False, return_raw_trace=True)
+    want = oracle.sample_tridiag(oracle_settings(oracle, chains=64, tune=300, draws=300, seed=5, W=1), 1 / sd**2)
+    np.testing.assert_allclose(tr.draws[:, :3], want.draws[:, :3], rtol=1e-9)
+    d = tr.draws[:, 300:]
+    assert np.abs(d.mean((0, 1)) / sd).max() < 0.08
+    assert np.abs(d.std((0, 1)) / sd - 1).max() < 0.06
+    assert tr.stats["diverging"][:, 300:].sum() == 0
+
+
+def test_torch_callback_exception_and_nonfinite_logp(hip):
+    import torch
+
+    import nutpie_amd
+
+    def make_bad():
+        def f(x):
+            raise ValueError("boom")
+
+        return f
+
+    with pytest.raises(RuntimeError, match="boom"):
+        nutpie_amd.sample(nutpie_amd.from_torchfunc(3, make_bad), chains=2, tune=5, draws=5, progress_bar=False)
+
+    def make_wall():
+        def f(x):  # -inf beyond a wall at x0 = 1.5: non-finite logp is recoverable (src/pyfunc.rs:218-220)
+            lp = -0.5 * (x * x).sum(-1)
+            lp = torch.where(x[:, 0] > 1.5, torch.full_like(lp, -float("inf")), lp)
+            return lp, -x
+
+        return f
+
+    tr = nutpie_amd.sample(nutpie_amd.from_torchfunc(3, make_wall, init="normal"), chains=8, tune=100, draws=100, seed=1, progress_bar=False)
+    assert tr.sample_stats.diverging.sum() + tr.warmup_sample_stats.diverging.sum() > 0
+    assert np.nanmax(tr.posterior.x.values[..., 0]) <= 1.5
+
+
+# ------------------------------------------------------------------------------------ full-size properties (config 2)
+def test_config2_full_size_properties(hip):
+    """BASELINE.json config 2 at full width (1000-dim AR(1) Gaussian, 1024 chains), short run: properties that do not
+    need the oracle — determinism, per-chain independence from batch composition, analytic moments."""
+    from nutpie_amd.gaussian import ar1_gaussian
+
+    m = ar1_gaussian(1000)
+    a, W = run_engine(hip, hip.TridiagGaussianModel(m.diag, m.offdiag), chains=1024, tune=150, draws=50, seed=20260926)
+    assert W == 1 and a.finished.min() == 200
+    # same seed, only the first 32 chains: identical rows (a chain never depends on its neighbours)
+    b, _ = run_engine(hip, hip.TridiagGaussianModel(m.diag, m.offdiag), chains=32, tune=150, draws=50, seed=20260926)
+    assert np.array_equal(a.draws[:32], b.draws) and np.array_equal(a.stats["n_steps"][:32], b.stats["n_steps"])
+    d = a.draws[:, 150:]
+    var = np.diag(m.covariance())
+    z = d.mean((0, 1)) / np.sqrt(var)
+    assert np.abs(z).max() < 0.15                       # 51200 draws per dim, autocorrelated
+    ratio = d.var((0, 1)) / var
+    assert 0.85 < ratio.min() and ratio.max() < 1.15
+    assert a.stats["diverging"][:, 150:].mean() < 0.01
+    # energy conservation of accepted points: |energy_error| is O(1), never near max_energy_error
+    assert np.abs(a.stats["energy_error"][:, 150:]).max() < 50

@@ -1,0 +1,147 @@
+"""Host-side logic that runs without a GPU: trace assembly, ESS, sample() argument handling, Gaussian targets."""
+import warnings
+
+import numpy as np
+import pytest
+
+
+def test_trace_warmup_split_and_nan_padding():
+    # reference layout rules: python/nutpie/sample.py:62-214 (split by `tuning`, NaN-pad unequal chains)
+    from nutpie_amd.trace import build_trace
+
+    n, T, D = 3, 10, 2
+    draws = np.arange(n * T * D, dtype=float).reshape(n, T, D)
+    tuning = np.zeros((n, T), bool)
+    tuning[:, :4] = True
+    stats = {"tuning": tuning, "depth": np.ones((n, T), np.int64), "energy": np.full((n, T), 2.5),
+             "diverging": np.zeros((n, T), bool), "gradient": draws * 2}
+    finished = np.array([10, 7, 3])  # chains 1, 2 were aborted early (chain 2 inside warm-up)
+    tr = build_trace({"x": draws}, stats, finished, save_warmup=True, skip_vars=["gradient"], use_arviz=False)
+    assert set(tr.groups()) == {"posterior", "sample_stats", "warmup_posterior", "warmup_sample_stats"}
+    assert tr.posterior.x.shape == (3, 6, 2) and tr.warmup_posterior.x.shape == (3, 4, 2)
+    assert np.array_equal(tr.posterior.x.values[0], draws[0, 4:])
+    assert np.array_equal(tr.posterior.x.values[1, :3], draws[1, 4:7]) and np.all(np.isnan(tr.posterior.x.values[1, 3:]))
+    assert np.all(np.isnan(tr.posterior.x.values[2]))
+    assert np.array_equal(tr.warmup_posterior.x.values[2, :3], draws[2, :3]) and np.all(np.isnan(tr.warmup_posterior.x.values[2, 3:]))
+    assert "gradient" not in tr.sample_stats and tr.sample_stats.depth.dtype == np.int64
+    assert tr.sample_stats.depth.values[1, 3:].sum() == 0          # integer columns are zero padded
+    assert tr.posterior.x.dims == ("chain", "draw", "x_dim_0")
+    tr2 = build_trace({"x": draws}, stats, finished, save_warmup=False, use_arviz=False)
+    assert set(tr2.groups()) == {"posterior", "sample_stats"} and "gradient" in tr2.sample_stats
+
+
+def test_trace_unconstrained_groups():
+    from nutpie_amd.trace import build_trace
+
+    n, T = 2, 6
+    tuning = np.zeros((n, T), bool); tuning[:, :2] = True
+    ex = {"a": np.ones((n, T)), "a_log__": np.zeros((n, T))}
+    tr = build_trace(ex, {"tuning": tuning}, [T, T], reparameterized_names=["a_log__"], keep_unconstrained_draw=True, use_arviz=False)
+    assert "a_log__" not in tr.posterior and "a_log__" in tr.unconstrained_posterior and "a_log__" in tr.warmup_unconstrained_posterior
+
+
+def test_ess_iid_and_ar1():
+    from nutpie_amd.ess import ess_bulk, ess_bulk_min
+
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=(4, 1000))
+    assert 3200 < ess_bulk(x) < 4800                      # iid: ESS ~ N
+    phi = 0.9                                             # AR(1): tau = (1+phi)/(1-phi) = 19
+    y = np.zeros((4, 4000))
+    e = rng.normal(size=y.shape)
+    for t in range(1, y.shape[1]):
+        y[:, t] = phi * y[:, t - 1] + e[:, t]
+    ess = ess_bulk(y)
+    assert 16000 / 19 * 0.6 < ess < 16000 / 19 * 1.6
+    # a chain stuck elsewhere collapses the ESS (between-chain variance enters var_plus)
+    z = x.copy(); z[0] += 5
+    assert ess_bulk(z) < 50
+    m, vals = ess_bulk_min(np.stack([x, y[:, :1000]], -1))
+    assert m == vals.min() and vals[0] > vals[1]
+
+
+def test_sample_argument_handling():
+    import nutpie_amd
+
+    m = nutpie_amd.std_normal(3)
+    with pytest.raises(ValueError, match="Unknown adaptation strategy 'foo'"):     # sample.py:1026-1030
+        nutpie_amd.sample(m, adaptation="foo")
+    with pytest.raises(ValueError, match="Unknown sampler 'hmc'"):                 # sample.py:1044-1047
+        nutpie_amd.sample(m, sampler="hmc")
+    with pytest.raises(NotImplementedError):
+        nutpie_amd.sample(m, adaptation="low_rank")
+    with pytest.raises(NotImplementedError):
+        nutpie_amd.sample(m, adaptation="flow")
+    with pytest.raises(NotImplementedError):
+        nutpie_amd.sample(m, sampler="mclmc")
+    with pytest.raises(AttributeError, match="Unknown settings attribute: bogus"):
+        nutpie_amd.sample(m, bogus=1)
+    with pytest.raises(ValueError, match="not available for diag adaptation"):
+        nutpie_amd.sample(m, mass_matrix_gamma=1e-5)
+    with warnings.catch_warnings(record=True) as w:                                # deprecated aliases, sample.py:979-1013
+        warnings.simplefilter("always")
+        with pytest.raises(NotImplementedError):
+            nutpie_amd.sample(m, low_rank_modified_mass_matrix=True)
+        assert any(issubclass(x.category, FutureWarning) for x in w)
+    with pytest.raises(ValueError, match="cannot be combined"):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            nutpie_amd.sample(m, transform_adapt=True, adaptation="draw_diag")
+    with pytest.raises(NotImplementedError):
+        nutpie_amd.sample(m, zarr_store=object(), chains=1)
+
+
+def test_front_end_shells_raise_import_errors():
+    import nutpie_amd
+
+    with pytest.raises(ImportError, match="pymc"):
+        nutpie_amd.compile_pymc_model(object())
+    with pytest.raises(ImportError, match="BridgeStan"):
+        nutpie_amd.compile_stan_model(code="parameters { real a; } model { a ~ normal(0,1); }")
+
+
+def test_from_pyfunc_contract():
+    import nutpie_amd
+
+    def make_logp():
+        return lambda x, scale: (-0.5 * float(x @ x) / scale, -x / scale)
+
+    def make_expand(seed1, seed2, chain):
+        return lambda x, scale: {"y": x, "ysum": np.array(x.sum())}
+
+    m = nutpie_amd.from_pyfunc(3, make_logp, make_expand, [np.float64, np.float64], [(3,), ()], ["y", "ysum"], shared_data={"scale": 2.0})
+    assert m.n_dim == 3 and m.shapes == {"y": (3,), "ysum": ()}
+    with pytest.raises(ValueError, match="Unknown data variable"):                   # compiled_pyfunc.py:39-46
+        m.with_data(nope=1)
+    m2 = m.with_data(scale=4.0)
+    assert m2._shared_data["scale"] == 4.0 and m._shared_data["scale"] == 2.0
+    ex = m._expand_draws(np.arange(12.0).reshape(2, 2, 3))
+    assert ex["y"].shape == (2, 2, 3) and ex["ysum"].shape == (2, 2) and ex["ysum"][1, 1] == 9 + 10 + 11
+    bad = nutpie_amd.from_pyfunc(3, make_logp, lambda *a: (lambda x: {"y": x.astype(np.float32)}), [np.float64], [(3,)], ["y"])
+    with pytest.raises(TypeError, match="dtype"):
+        bad._expand_draws(np.zeros((1, 1, 3)))
+
+
+def test_gaussian_targets():
+    from nutpie_amd.gaussian import ar1_gaussian, diag_gaussian, std_normal
+
+    assert np.array_equal(std_normal(5).diag, np.ones(5))
+    np.testing.assert_allclose(diag_gaussian([2.0, 0.5]).covariance(), np.diag([4.0, 0.25]))
+    m = ar1_gaussian(6, rho=0.9, scales=np.array([1, 2, 3, 1, 2, 3.0]))
+    cov = m.covariance()
+    s = np.array([1, 2, 3, 1, 2, 3.0])
+    want = 0.9 ** np.abs(np.subtract.outer(np.arange(6), np.arange(6))) * np.outer(s, s)
+    np.testing.assert_allclose(cov, want, rtol=1e-10)
+    # default scales come from numpy.random.default_rng(20260926)
+    a, b = ar1_gaussian(1000), ar1_gaussian(1000)
+    assert np.array_equal(a.diag, b.diag) and a.n_dim == 1000
+
+
+def test_shard_chains():
+    from nutpie_amd.distributed import shard_chains
+
+    for n, w in [(1024, 8), (10, 4), (3, 8), (8192, 8), (7, 1)]:
+        parts = [shard_chains(n, w, r) for r in range(w)]
+        assert sum(p[1] for p in parts) == n
+        assert parts[0][0] == 0 and all(parts[i][0] + parts[i][1] == parts[i + 1][0] for i in range(w - 1))
+        assert max(p[1] for p in parts) - min(p[1] for p in parts) <= 1

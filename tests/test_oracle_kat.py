@@ -1,0 +1,195 @@
+"""Known-answer tests of the oracle's building blocks (the reference holds none)."""
+import math
+
+import numpy as np
+import pytest
+
+
+def test_leapfrog_harmonic_oscillator_energy_and_reversibility(oracle):
+    # H = q^2/2 + p^2/2 ; analytic solution is a rotation
+    q0, p0 = np.array([1.0]), np.array([0.3])
+    sig2, diag = np.ones(1), np.ones(1)
+    drifts = []
+    for eps in (0.1, 0.05, 0.025):
+        q, p, g = q0.copy(), p0.copy(), -q0.copy()
+        n = int(round(1.0 / eps))
+        e0 = 0.5 * (q0[0] ** 2 + p0[0] ** 2)
+        worst = 0.0
+        for _ in range(n):
+            q, p, g, K, U, e = oracle.leapfrog_tridiag(q, p, g, sig2, eps, diag)
+            worst = max(worst, abs(e - e0))
+        drifts.append(worst)
+        # position close to the exact rotation by t = n*eps
+        t = n * eps
+        assert q[0] == pytest.approx(q0[0] * math.cos(t) + p0[0] * math.sin(t), abs=eps**2)
+    # second-order integrator: energy error shrinks ~4x when eps halves
+    assert 3.0 < drifts[0] / drifts[1] < 5.0 and 3.0 < drifts[1] / drifts[2] < 5.0
+    # reversibility: integrate forward, flip momentum, integrate again -> back at the start
+    q, p, g = q0.copy(), p0.copy(), -q0.copy()
+    for _ in range(25):
+        q, p, g, *_ = oracle.leapfrog_tridiag(q, p, g, sig2, 0.1, diag)
+    p = -p
+    for _ in range(25):
+        q, p, g, *_ = oracle.leapfrog_tridiag(q, p, g, sig2, 0.1, diag)
+    assert q[0] == pytest.approx(q0[0], abs=1e-13) and -p[0] == pytest.approx(p0[0], abs=1e-13)
+
+
+def test_leapfrog_formula_matches_plain_numpy(oracle):
+    rng = np.random.default_rng(0)
+    D = 37
+    a = np.exp(rng.normal(size=D)); b = 0.1 * rng.normal(size=D - 1); mu = rng.normal(size=D)
+    L = np.diag(a) + np.diag(b, 1) + np.diag(b, -1)
+    sig2 = np.exp(rng.normal(size=D))
+    q = rng.normal(size=D); p = rng.normal(size=D); g = -L @ (q - mu)
+    eps = -0.07
+    q1, p1, g1, K, U, e = oracle.leapfrog_tridiag(q, p, g, sig2, eps, a, b, mu)
+    ph = p + eps / 2 * g
+    qn = q + eps * sig2 * ph
+    gn = -L @ (qn - mu)
+    pn = ph + eps / 2 * gn
+    np.testing.assert_allclose(q1, qn, rtol=1e-14)
+    np.testing.assert_allclose(g1, gn, rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(p1, pn, rtol=1e-12, atol=1e-13)
+    assert K == pytest.approx(0.5 * np.sum(pn * sig2 * pn), rel=1e-13)
+    assert U == pytest.approx(0.5 * (qn - mu) @ L @ (qn - mu), rel=1e-12)
+
+
+def test_uturn_triggers_when_the_trajectory_turns_back(oracle):
+    # harmonic oscillator, unit mass, q0=0, p0=1: q = sin t, p = cos t, rho(t) ~ sum p ~ sin t / eps.
+    # rho . v_end = sin t cos t < 0 first holds just after t = pi/2, where the particle turns around.
+    eps = 0.1
+    q, p, g = np.array([0.0]), np.array([1.0]), np.array([0.0])
+    sig2 = np.ones(1)
+    p0 = p.copy()
+    psum = p.copy()
+    first = None
+    for k in range(1, 80):
+        q, p, g, *_ = oracle.leapfrog_tridiag(q, p, g, sig2, eps, np.ones(1))
+        psum = psum + p
+        if oracle.is_turning(sig2, 0, p0, p0, k, p, psum):
+            first = k
+            break
+    assert first is not None
+    assert abs(first * eps - math.pi / 2) < 0.2
+
+
+def test_is_turning_index_cases(oracle):
+    rng = np.random.default_rng(1)
+    D = 5
+    sig2 = np.exp(rng.normal(size=D))
+    ps = rng.normal(size=(7, D))            # momenta at trajectory indices -3..3
+    idx = np.arange(-3, 4)
+    # one-sided running sums: rho_k for k>=0 includes p_0; for k<0 it does not
+    rho = {}
+    for k in idx:
+        rho[k] = ps[3:3 + k + 1].sum(0) if k >= 0 else ps[3 + k:3].sum(0)
+    for a in idx:
+        for b in idx:
+            if a >= b:
+                continue
+            span = ps[3 + a:3 + b + 1].sum(0)
+            want = (span @ (sig2 * ps[3 + b]) < 0) or (span @ (sig2 * ps[3 + a]) < 0)
+            got = oracle.is_turning(sig2, int(a), ps[3 + a], rho[a], int(b), ps[3 + b], rho[b])
+            assert got == want, (a, b)
+            # argument order must not matter
+            assert oracle.is_turning(sig2, int(b), ps[3 + b], rho[b], int(a), ps[3 + a], rho[a]) == want
+
+
+def test_dual_averaging_matches_recurrence(oracle):
+    rng = np.random.default_rng(2)
+    acc = rng.uniform(0, 1, 300)
+    step, bar = oracle.dual_average(acc, initial_step=0.25, target=0.8)
+    k, t0, gamma, mu = 0.75, 10.0, 0.05, math.log(10 * 0.25)
+    hbar, log_bar = 0.0, math.log(0.25)
+    for i, a in enumerate(acc):
+        n = i + 1
+        w = 1.0 / (n + t0)
+        hbar = (1 - w) * hbar + w * (0.8 - a)
+        log_step = mu - hbar * math.sqrt(n) / gamma
+        m = n ** (-k)
+        log_bar = m * log_step + (1 - m) * log_bar
+        assert step[i] == pytest.approx(math.exp(log_step), rel=1e-12)
+        assert bar[i] == pytest.approx(math.exp(log_bar), rel=1e-12)
+    # feeding the target acceptance forever keeps the step at 10x the initial value (mu)
+    step, _ = oracle.dual_average(np.full(50, 0.8), initial_step=0.1)
+    assert step[-1] == pytest.approx(1.0, rel=1e-12)
+
+
+def test_welford_matches_numpy(oracle):
+    rng = np.random.default_rng(3)
+    x = rng.normal(size=(50, 7)) * np.arange(1, 8)
+    mean, m2 = oracle.welford(x)
+    np.testing.assert_allclose(mean, x.mean(0), rtol=1e-13)
+    np.testing.assert_allclose(m2 / (len(x) - 1), x.var(0, ddof=1), rtol=1e-12)
+    mean1, m21 = oracle.welford(x[:1])
+    assert np.array_equal(mean1, x[0]) and np.all(m21 == 0)
+
+
+def test_mass_matrix_formula(oracle):
+    # After tuning on a diagonal Gaussian the grad-based estimate sqrt(Var q / Var g) equals the posterior
+    # variance: g = -q/s^2 => Var g = Var q / s^4 => sqrt(ratio) = s^2 exactly, whatever the draws were.
+    # (in-tree corroboration: python/nutpie/normalizing_flow.py:1906-1915)
+    sd = np.array([0.01, 0.3, 1.0, 7.0, 120.0])
+    s = oracle.default_settings(seed=4, num_chains=2, num_tune=120, num_draws=5, store_mass_matrix=1)
+    tr = oracle.sample_tridiag(s, 1 / sd**2)
+    mm = tr.stats["mass_matrix_inv"][:, 100, :]
+    np.testing.assert_allclose(mm, np.broadcast_to(sd**2, mm.shape), rtol=1e-9)
+    # draw_diag variant estimates the plain draw variance -> only statistically close
+    s = oracle.default_settings(seed=4, num_chains=2, num_tune=400, num_draws=5, store_mass_matrix=1, use_grad_based_mass_matrix=0)
+    tr = oracle.sample_tridiag(s, 1 / sd**2)
+    mm = tr.stats["mass_matrix_inv"][:, 330, :]
+    assert np.all(np.abs(np.log(mm / sd**2)) < 1.0)
+    # the matrix is frozen during the final step-size window (docs/sample-stats.qmd:85-88)
+    assert np.array_equal(tr.stats["mass_matrix_inv"][:, 345, :], tr.stats["mass_matrix_inv"][:, 399, :])
+
+
+def test_initial_mass_matrix_from_gradient(oracle):
+    # first matrix: sig2 = 1/|g| at the initial point (normalizing_flow.py:1906-1908: diag = 1/sqrt|g|)
+    sd = np.array([0.5, 2.0, 10.0])
+    init = np.array([[1.0, -3.0, 20.0]])
+    s = oracle.default_settings(seed=1, num_chains=1, num_tune=3, num_draws=1, store_mass_matrix=1, init_kind=2)
+    tr = oracle.sample_tridiag(s, 1 / sd**2, init_points=init)
+    g0 = -init[0] / sd**2
+    np.testing.assert_allclose(tr.stats["mass_matrix_inv"][0, 0], 1 / np.abs(g0), rtol=1e-15)
+
+
+def test_fixed_step_size_and_schedule(oracle):
+    s = oracle.default_settings(seed=2, num_chains=2, num_tune=50, num_draws=20, fixed_step_size=1, initial_step=0.37)
+    tr = oracle.sample_tridiag(s, np.ones(4))
+    assert np.all(tr.stats["step_size"] == 0.37)
+    # tuning flag: exactly num_tune draws are warm-up
+    assert np.all(tr.stats["tuning"].sum(1) == 50)
+    # last tuning draw switches to the averaged step size and sampling keeps it
+    s = oracle.default_settings(seed=2, num_chains=2, num_tune=50, num_draws=20)
+    tr = oracle.sample_tridiag(s, np.ones(4))
+    assert np.array_equal(tr.stats["step_size"][:, 49], tr.stats["step_size_bar"][:, 49])
+    assert np.all(tr.stats["step_size"][:, 50:] == tr.stats["step_size"][:, 49:50])
+
+
+def test_tree_bookkeeping_invariants(oracle):
+    s = oracle.default_settings(seed=3, num_chains=4, num_tune=100, num_draws=100, maxdepth=3)
+    tr = oracle.sample_tridiag(s, np.exp(np.random.default_rng(0).normal(size=20)))
+    depth, n_steps, div, md = tr.stats["depth"], tr.stats["n_steps"], tr.stats["diverging"], tr.stats["maxdepth_reached"]
+    assert depth.max() <= 3
+    ok = div == 0
+    # a finished doubling sequence of depth d used between 2^(d-1) (turn inside the last sub-tree) ... 2^d - 1 steps,
+    # or up to 2^(d+1) - 1 when the last sub-tree was abandoned
+    assert np.all(n_steps[ok] >= 2.0 ** depth[ok] - 1)
+    assert np.all(n_steps[ok] <= 2.0 ** (depth[ok] + 1) - 1)
+    assert np.all(depth[md == 1] == 3) and md.sum() > 0  # a U-turn at the last doubling is not 'maxdepth reached'
+    idx = tr.stats["index_in_trajectory"]
+    assert np.all(np.abs(idx) <= n_steps)
+    # energy bookkeeping: energy_error == energy - H0 and |error| small for accepted points
+    assert np.all(np.isfinite(tr.stats["energy"]))
+    assert np.all(tr.stats["mean_tree_accept"] >= 0) and np.all(tr.stats["mean_tree_accept"] <= 1)
+
+
+def test_recoverable_error_is_divergence_and_fatal_raises(oracle, fixture_lib):
+    from tests.conftest import fn_addr
+
+    s = oracle.default_settings(seed=8, num_chains=2, num_tune=60, num_draws=60, init_kind=1)
+    tr = oracle.sample_callback(s, 3, fn_addr(fixture_lib.failing_logp))
+    assert tr.stats["diverging"].sum() > 0          # x0 > 2.5 is refused -> divergences
+    assert tr.draws[:, :, 0].max() <= 2.5 + 1e-12   # and never accepted
+    with pytest.raises(RuntimeError, match="fatal"):
+        oracle.sample_callback(s, 3, fn_addr(fixture_lib.fatal_logp))
