@@ -146,8 +146,10 @@ def main():
     hip.lib()
     model = ar1_gaussian(args.dim)
     s = hip.PyNutsSettings.Diag(args.seed)
-    # enough draws that no chain finishes inside the timed region; positions are not stored for this leg
-    s.update(num_tune=400, num_draws=10_000_000, num_chains=args.chains * world)
+    # enough draws that no chain can finish inside the timed region (>= 1 leapfrog per draw); positions are
+    # not stored for this leg, the per-draw statistics are (13 small arrays)
+    n_draws = (args.warmup + args.steps + 2) * args.evals_per_launch
+    s.update(num_tune=400, num_draws=n_draws, num_chains=args.chains * world)
     m = hip.TridiagGaussianModel(model.diag, model.offdiag)
     smp = hip.PySampler(s, m, device=device, waves_per_chain=args.waves, chain_offset=rank * args.chains, n_local_chains=args.chains,
                         store_draws=False, evals_per_launch=args.evals_per_launch, manual=True)

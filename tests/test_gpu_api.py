@@ -94,8 +94,8 @@ def test_non_blocking_timeout_pause_abort():
     # pause/resume, abort returns the partial trace
     from nutpie_amd.gaussian import ar1_gaussian
 
-    m = ar1_gaussian(2000, rho=0.99)   # slow enough to observe
-    smp = nutpie_amd.sample(m, chains=256, draws=100000, tune=1000, seed=1, progress_bar=False, blocking=False, maxdepth=10)
+    m = ar1_gaussian(500, rho=0.99)   # deep trees: slow enough to observe (trace: 256 x 21000 x 500 x 8 B = 21 GB)
+    smp = nutpie_amd.sample(m, chains=256, draws=20000, tune=1000, seed=1, progress_bar=False, blocking=False, maxdepth=10)
     with pytest.raises(TimeoutError):
         smp.wait(timeout=0.3)
     assert not smp.is_finished
@@ -116,7 +116,7 @@ def test_non_blocking_timeout_pause_abort():
     assert wx.shape[0] == 256 and np.isfinite(wx[:, 0, 0]).all()      # every chain produced at least one draw
     assert np.isnan(wx).any() or wx.shape[1] < 1000                     # but not the whole run
     # cancel: discards and returns quickly
-    smp2 = nutpie_amd.sample(m, chains=64, draws=100000, tune=1000, seed=1, progress_bar=False, blocking=False)
+    smp2 = nutpie_amd.sample(m, chains=64, draws=20000, tune=1000, seed=1, progress_bar=False, blocking=False)
     time.sleep(0.2)
     t0 = time.time()
     smp2.cancel()
