@@ -133,6 +133,9 @@ typedef struct {
     void* staging_q;
     void* staging_grad;
     void* staging_logp;
+    int32_t no_register_kernel; /* 1: force the memory-resident kernel even where the register-resident
+                                 * specialisation applies (A/B measurements, tests) */
+    int32_t reserved;
 } nphip_launch_t;
 
 void nphip_launch_defaults(nphip_launch_t*);
@@ -169,6 +172,9 @@ uint64_t nphip_sampler_launches(const nphip_sampler_t*);
  * "divergence_end" "divergence_momentum" "divergence_start_gradient"(f64[dim]). */
 int nphip_sampler_finished_draws(nphip_sampler_t*, uint64_t* finished);
 int nphip_sampler_copy_stat(nphip_sampler_t*, const char* name, void* host_out, uint64_t nbytes);
+/* Developer aid: per-section cycle counters summed over chains; all zero unless the library was built
+ * with -DNPHIP_PROFILE.  [0] leapfrog cycles [1] tree cycles (hot) [2] draw-end cycles [3..5] their counts. */
+int nphip_sampler_profile(nphip_sampler_t*, int64_t out[8]);
 /* Device pointer of a trace array (for zero-copy wrapping / RCCL gathers); NULL if absent. */
 void* nphip_sampler_device_ptr(nphip_sampler_t*, const char* name);
 

@@ -59,6 +59,8 @@ class _Launch(C.Structure):
         ("staging_q", C.c_void_p),
         ("staging_grad", C.c_void_p),
         ("staging_logp", C.c_void_p),
+        ("no_register_kernel", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 
@@ -437,7 +439,7 @@ class PySampler:
 
     def __init__(self, settings: PyNutsSettings, model: _Model, *, device=0, waves_per_chain=0, chain_offset=0,
                  n_local_chains=0, stream=None, store_draws=True, evals_per_launch=0, start_paused=False, manual=False,
-                 staging=None):
+                 staging=None, no_register_kernel=False):
         L = lib()
         la = _Launch()
         L.nphip_launch_defaults(C.byref(la))
@@ -450,6 +452,7 @@ class PySampler:
         la.evals_per_launch = int(evals_per_launch)
         la.start_paused = int(bool(start_paused))
         la.manual = int(bool(manual))
+        la.no_register_kernel = int(bool(no_register_kernel))
         if staging is not None:
             la.staging_q, la.staging_grad, la.staging_logp = (C.c_void_p(int(p)) for p in staging)
         self._model = model

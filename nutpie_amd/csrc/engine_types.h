@@ -79,6 +79,8 @@ struct Ctl {
     // info of the draw being finished (kept across a mid-adapt step-size search)
     int64_t fin_depth, fin_flags;
     double fin_eerr;
+    // cycle counters per section (only advanced when built with -DNPHIP_PROFILE): leapfrog, tree, rare, count
+    int64_t prof[8];
     // sub-tree stack
     double sub_ls[kMaxDepthCap];
     double sub_U[kMaxDepthCap];
@@ -138,6 +140,7 @@ struct Args {
     double* st_energy; double* st_energy_error; double* st_logp; double* st_step; double* st_step_bar;
     double* st_accept; double* st_accept_sym;
     // launch control
+    int32_t reg_nv;       // >0: register-resident kernel with NV = reg_nv chunks per lane (fused, W == 1)
     int32_t max_evals;    // fused: evaluations per chain this launch
     int32_t have_result;  // callbacks: geval/ueval hold the answer to the pending request
     unsigned long long* counters;  // [0] chains done, [1] chains in error

@@ -24,7 +24,7 @@
 #include "engine_types.h"
 
 namespace nphip {
-hipError_t launch_advance(const Args& a, bool fused, int W, hipStream_t st);
+hipError_t launch_advance(const Args& a, const Args* d_args, bool fused, int W, hipStream_t st);
 hipError_t launch_test_detmath(int fn, uint64_t n, const double* x, double* y, hipStream_t st);
 hipError_t launch_test_dot(int W, uint64_t n, const double* x, const double* y, double* out, hipStream_t st);
 }  // namespace nphip
@@ -402,6 +402,7 @@ struct nphip_sampler {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     Args args;
+    Args* d_args = nullptr;  // device copy, read by the kernels through the constant address space
     int W = 1;
     bool fused = true;
     uint64_t n = 0, T = 0, dim = 0;
@@ -521,6 +522,14 @@ bool nphip_sampler::setup() {
     args.npslots = num_pslots(args.cap);
     args.nqpool = num_qpool(args.cap);
     const size_t ld = (size_t)args.ld;
+    // register-resident specialisation: one wave per chain, state in VGPRs (dim <= 2048)
+    args.reg_nv = 0;
+    if (fused && W == 1 && !launch.no_register_kernel) {
+        const int nchunks = (int)(args.ld / 128);
+        int nv = 1;
+        while (nv < nchunks) nv *= 2;
+        if (nv <= 16) args.reg_nv = nv;
+    }
 
     if (!dalloc(&args.ctl, n)) return false;
     if (!dalloc(&args.qpool, n * args.nqpool * 2 * ld)) return false;
@@ -568,6 +577,8 @@ bool nphip_sampler::setup() {
     if (!dalloc(&args.st_step, nt) || !dalloc(&args.st_step_bar, nt)) return false;
     if (!dalloc(&args.st_accept, nt) || !dalloc(&args.st_accept_sym, nt)) return false;
     if (!palloc(&h_counters, 2)) return false;
+    if (!dalloc(&d_args, 1)) return false;
+    HIP_TRY(hipMemcpyAsync(d_args, &args, sizeof(Args), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     return true;
 }
@@ -595,7 +606,7 @@ bool nphip_sampler::launch_kernel(bool fused_, int have) {
         }
         if (!hip_ok(hipEventRecord(ev0, stream), "hipEventRecord")) return false;
     }
-    if (!hip_ok(launch_advance(args, fused_, W, stream), "launch k_advance")) return false;
+    if (!hip_ok(launch_advance(args, d_args, fused_, W, stream), "launch k_advance")) return false;
     if (kernel_ms_acc) {
         if (!hip_ok(hipEventRecord(ev1, stream), "hipEventRecord")) return false;
         if (!hip_ok(hipEventSynchronize(ev1), "hipEventSynchronize")) return false;
@@ -860,6 +871,14 @@ int nphip_sampler_copy_stat(nphip_sampler_t* s, const char* name, void* host_out
     (void)hipSetDevice(s->device);
     if (!hip_ok(hipStreamSynchronize(s->stream), "sync")) return NPHIP_ERR;
     if (!hip_ok(hipMemcpy(host_out, p, bytes, hipMemcpyDeviceToHost), "copy trace")) return NPHIP_ERR;
+    return NPHIP_OK;
+}
+
+int nphip_sampler_profile(nphip_sampler_t* s, int64_t out[8]) {
+    std::vector<Ctl> h;
+    if (!read_ctl(s, h)) return NPHIP_ERR;
+    for (int k = 0; k < 8; ++k) out[k] = 0;
+    for (auto& c : h) for (int k = 0; k < 8; ++k) out[k] += c.prof[k];
     return NPHIP_OK;
 }
 

@@ -21,6 +21,17 @@
 #include "../../include/nphip_spec.h"
 #include "engine_types.h"
 
+// address-space qualifiers only exist in the device pass (the host pass merely parses the kernels)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define NPHIP_GLOBAL __attribute__((address_space(1)))
+#define NPHIP_LDS __attribute__((address_space(3)))
+#define NPHIP_CONST __attribute__((address_space(4)))
+#else
+#define NPHIP_GLOBAL
+#define NPHIP_LDS
+#define NPHIP_CONST
+#endif
+
 namespace nphip {
 
 // ----------------------------------------------------------------------------------------
@@ -36,7 +47,7 @@ __device__ __forceinline__ void chain_sync() {
 
 // Sum two values over the chain in the contract order of nphip_spec.h.
 template <int W>
-__device__ __forceinline__ void reduce2(double& a, double& b, double* red) {
+__device__ __forceinline__ void reduce2(double& a, double& b, NPHIP_LDS double* red) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
         double pa = __shfl_xor(a, off);
@@ -55,18 +66,25 @@ __device__ __forceinline__ void reduce2(double& a, double& b, double* red) {
     }
 }
 
-__device__ __forceinline__ double2 ld2(const double* p, int64_t i) { return *reinterpret_cast<const double2*>(p + i); }
-__device__ __forceinline__ void st2(double* p, int64_t i, double2 v) { *reinterpret_cast<double2*>(p + i) = v; }
+// Explicit address spaces: the engine's pointers arrive inside a by-value struct, so clang cannot infer
+// that they are global and would emit flat_load/flat_store (slower, and they tie vmcnt to lgkmcnt).
+typedef NPHIP_LDS Ctl* LdsCtl;
+typedef NPHIP_LDS double* LdsDouble;
+
+__device__ __forceinline__ double2 ld2(const double* p, int64_t i) { return *(const NPHIP_GLOBAL double2*)(p + i); }
+__device__ __forceinline__ void st2(double* p, int64_t i, double2 v) { *(NPHIP_GLOBAL double2*)(p + i) = v; }
+__device__ __forceinline__ double ld1(const double* p, int64_t i) { return *(const NPHIP_GLOBAL double*)(p + i); }
+__device__ __forceinline__ void st1(double* p, int64_t i, double v) { *(NPHIP_GLOBAL double*)(p + i) = v; }
 // dense rows (ld == dim, possibly odd / unaligned): guarded scalar accesses
 __device__ __forceinline__ double2 ld2_dense(const double* p, int64_t i, int64_t D) {
     double2 v;
-    v.x = (i < D) ? p[i] : 0.0;
-    v.y = (i + 1 < D) ? p[i + 1] : 0.0;
+    v.x = (i < D) ? ld1(p, i) : 0.0;
+    v.y = (i + 1 < D) ? ld1(p, i + 1) : 0.0;
     return v;
 }
 __device__ __forceinline__ void st2_dense(double* p, int64_t i, int64_t D, double2 v) {
-    if (i < D) p[i] = v.x;
-    if (i + 1 < D) p[i + 1] = v.y;
+    if (i < D) st1(p, i, v.x);
+    if (i + 1 < D) st1(p, i + 1, v.y);
 }
 __device__ __forceinline__ double clamp_mm(double v) { return v < 1e-20 ? 1e-20 : (v > 1e20 ? 1e20 : v); }
 
@@ -74,11 +92,26 @@ __device__ __forceinline__ double clamp_mm(double v) { return v < 1e-20 ? 1e-20 
 // the per-chain machine
 // ----------------------------------------------------------------------------------------
 
-template <bool FUSED, int W>
+// Register mirror of the cursor state: lives in locals of Machine::run() (never escapes to a
+// noinline function, so it stays in VGPRs).  reg_q / reg_p name the Q-pool buffer / P-slot mirrored.
+template <int NV>
+struct Regs {
+    double2 q[NV], g[NV], p[NV], r[NV], s[NV];
+    int64_t reg_q = -1, reg_p = -1;
+    bool sig_ok = false;
+    __device__ __forceinline__ void invalidate() { reg_q = -1; reg_p = -1; sig_ok = false; }
+};
+
+// NV > 0 selects the register-resident specialisation (requires FUSED and W == 1, dim <= 128 * NV):
+// the cursor state (q, grad, p, rho) and sigma^2 live in VGPRs across leapfrogs, so a leapfrog issues
+// no loads at all — only the stores of the new state, which later U-turn checks / draws may read.
+template <bool FUSED, int W, int NV = 0>
 struct Machine {
-    const Args& A;
-    Ctl* c;          // this wave's private LDS copy
-    double* red;     // LDS reduction scratch [2*W]
+    static constexpr int NVX = NV > 0 ? NV : 1;
+    // kernel arguments, read through the constant address space: s_load into SGPRs (uniform), never flat
+    const NPHIP_CONST Args& A;
+    LdsCtl c;        // this wave's private LDS copy
+    LdsDouble red;   // LDS reduction scratch [2*W]
     int64_t chain;   // local chain index
     uint32_t gchain; // global chain id (RNG key)
     int lane, wave;
@@ -88,9 +121,12 @@ struct Machine {
     double* sig2;
     double* est;
     int64_t T;
+    using RegsT = Regs<NVX>;
 
-    __device__ Machine(const Args& a, Ctl* ctl, double* r, int64_t ch, int wv, int ln)
-        : A(a), c(ctl), red(r), chain(ch), gchain((uint32_t)(a.chain_offset + ch)), lane(ln), wave(wv) {
+    __device__ __forceinline__ Machine(const NPHIP_CONST Args& a, LdsCtl ctl, LdsDouble r, int64_t ch)
+        : A(a), c(ctl), red(r), chain(ch), gchain((uint32_t)(a.chain_offset + ch)) {
+        lane = threadIdx.x & 63;
+        wave = (W == 1) ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
         D = a.dim; ld = a.ld; nch = ld / NPHIP_CHUNK;
         qp = a.qpool + (size_t)ch * a.nqpool * 2 * ld;
         pp = a.pslots + (size_t)ch * a.npslots * 2 * ld;
@@ -201,9 +237,10 @@ struct Machine {
     }
 
     // Leapfrog, first half: p_half = p + eps/2 g ; q' = q + eps sig2 p_half   
-    __device__ void lf1(int64_t srcq, int64_t srcp, int64_t newq, int64_t newp, int64_t sign) {
+    __device__ __forceinline__ void lf1(int64_t srcq, int64_t srcp, int64_t newq, int64_t newp, int64_t sign, bool defer = false) {
         c->lf_srcq = srcq; c->lf_srcp = srcp; c->lf_newq = newq; c->lf_newp = newp; c->lf_sign = sign;
         c->eval_buf = newq;
+        if (NV > 0 && defer) return;  // register-resident: the whole leapfrog runs in leapfrog_reg()
         const double eps = (double)sign * c->step_size;
         const double h = 0.5 * eps;
         const double *q = Q(srcq), *g = G(srcq), *p = P(srcp);
@@ -228,11 +265,11 @@ struct Machine {
         z.x = q2.x - mu.x;
         z.y = q2.y - mu.y;
         double tx = a.x * z.x;
-        if (i > 0) tx = fma(A.m_b[i - 1], q[i - 1] - A.m_mu[i - 1], tx);
+        if (i > 0) tx = fma(ld1(A.m_b, i - 1), ld1(q, i - 1) - ld1(A.m_mu, i - 1), tx);
         if (i + 1 < D) tx = fma(b.x, z.y, tx);
         double ty = a.y * z.y;
         ty = fma(b.x, z.x, ty);
-        if (i + 2 < D) ty = fma(b.y, q[i + 2] - A.m_mu[i + 2], ty);
+        if (i + 2 < D) ty = fma(b.y, ld1(q, i + 2) - ld1(A.m_mu, i + 2), ty);
         g.x = -tx;
         g.y = (i + 1 < D) ? -ty : 0.0;
         if (i >= D) g.x = 0.0;
@@ -305,8 +342,127 @@ struct Machine {
         return 0.5 * a;
     }
 
+    // ---- register-resident leapfrog (NV > 0): one fused pass, no loads when continuing from the cursor ----
+    __device__ __forceinline__ int64_t ridx(int k) const { return (int64_t)k * NPHIP_CHUNK + 2 * lane; }
+
+    __device__ __forceinline__ double leapfrog_reg(RegsT& X, double& lp, int64_t& code, int64_t idx_new) {
+        const int64_t srcq = c->lf_srcq, srcp = c->lf_srcp, newq = c->lf_newq, newp = c->lf_newp;
+        const int nk = (int)nch;
+        if (X.reg_q != srcq) {
+            const double *q = Q(srcq), *g = G(srcq);
+#pragma unroll
+            for (int k = 0; k < NVX; ++k) if (k < nk) { X.q[k] = ld2(q, ridx(k)); X.g[k] = ld2(g, ridx(k)); }
+        }
+        if (X.reg_p != srcp) {
+            const double *p = P(srcp), *r = R(srcp);
+#pragma unroll
+            for (int k = 0; k < NVX; ++k) if (k < nk) { X.p[k] = ld2(p, ridx(k)); X.r[k] = ld2(r, ridx(k)); }
+        }
+        if (!X.sig_ok) {
+#pragma unroll
+            for (int k = 0; k < NVX; ++k) if (k < nk) X.s[k] = ld2(sig2, ridx(k));
+            X.sig_ok = true;
+        }
+        const double eps = (double)c->lf_sign * c->step_size;
+        const double h = 0.5 * eps;
+        const bool copy_rho = (idx_new == -1);
+        double2 z[NVX];
+        // first half kick + drift, z = q' - mu
+#pragma unroll
+        for (int k = 0; k < NVX; ++k) if (k < nk) {
+            double2 mu = ld2(A.m_mu, ridx(k));
+            X.p[k].x = fma(h, X.g[k].x, X.p[k].x);
+            X.p[k].y = fma(h, X.g[k].y, X.p[k].y);
+            X.q[k].x = fma(eps, X.s[k].x * X.p[k].x, X.q[k].x);
+            X.q[k].y = fma(eps, X.s[k].y * X.p[k].y, X.q[k].y);
+            z[k].x = X.q[k].x - mu.x;
+            z[k].y = X.q[k].y - mu.y;
+        }
+        // tridiagonal gradient: neighbours come from adjacent lanes (wave shuffles), chunk borders wrap
+        double2 accK = {0.0, 0.0}, accL = {0.0, 0.0};
+        double *qn = Q(newq), *gn = G(newq), *pn = P(newp), *rn = R(newp);
+#pragma unroll
+        for (int k = 0; k < NVX; ++k) if (k < nk) {
+            const int64_t i = ridx(k);
+            double2 a = ld2(A.m_a, i), b = ld2(A.m_b, i);
+            double bl = __shfl_up(b.y, 1);                       // b_{i-1}
+            double zl = __shfl_up(z[k].y, 1);                    // z_{i-1}
+            double zr = __shfl_down(z[k].x, 1);                  // z_{i+2}
+            if (k > 0) {
+                double wz = __shfl(z[k - 1].y, 63);
+                double wb = __shfl(ld2(A.m_b, ridx(k - 1)).y, 63);
+                if (lane == 0) { zl = wz; bl = wb; }
+            }
+            if (k + 1 < NVX) {
+                double wz = (k + 1 < nk) ? __shfl(z[k + 1].x, 0) : 0.0;
+                if (lane == 63) zr = wz;
+            }
+            double tx = a.x * z[k].x;
+            if (i > 0) tx = fma(bl, zl, tx);
+            if (i + 1 < D) tx = fma(b.x, z[k].y, tx);
+            double ty = a.y * z[k].y;
+            ty = fma(b.x, z[k].x, ty);
+            if (i + 2 < D) ty = fma(b.y, zr, ty);
+            double2 gg;
+            gg.x = (i < D) ? -tx : 0.0;
+            gg.y = (i + 1 < D) ? -ty : 0.0;
+            accL.x = fma(z[k].x, gg.x, accL.x);
+            accL.y = fma(z[k].y, gg.y, accL.y);
+            X.g[k] = gg;
+            // second half kick, kinetic energy, running momentum sum
+            X.p[k].x = fma(h, gg.x, X.p[k].x);
+            X.p[k].y = fma(h, gg.y, X.p[k].y);
+            accK.x = fma(X.p[k].x, X.s[k].x * X.p[k].x, accK.x);
+            accK.y = fma(X.p[k].y, X.s[k].y * X.p[k].y, accK.y);
+            X.r[k].x = copy_rho ? X.p[k].x : X.r[k].x + X.p[k].x;
+            X.r[k].y = copy_rho ? X.p[k].y : X.r[k].y + X.p[k].y;
+            st2(qn, i, X.q[k]); st2(gn, i, X.g[k]); st2(pn, i, X.p[k]); st2(rn, i, X.r[k]);
+        }
+        X.reg_q = newq;
+        X.reg_p = newp;
+        double a = accK.x + accK.y, b = accL.x + accL.y;
+        reduce2<W>(a, b, red);
+        lp = 0.5 * b;
+        code = 0;
+        return 0.5 * a;
+    }
+
+    // U-turn criterion with operands taken from the register mirror when possible
+    __device__ __forceinline__ bool turning_reg(RegsT& X, int64_t s1, int64_t i1, int64_t s2_, int64_t i2) {
+        int64_t ss = s1, se = s2_, a = i1, b = i2;
+        if (!(i1 < i2)) { ss = s2_; se = s1; a = i2; b = i1; }
+        const int mode = (a >= 0 && b >= 0) ? 0 : ((b >= 0 && a < 0) ? 1 : 2);
+        const int nk = (int)nch;
+        double2 vps[NVX], vrs[NVX], vpe[NVX], vre[NVX];
+        const bool s_reg = (ss == X.reg_p), e_reg = (se == X.reg_p);
+        const double *ps = P(ss), *rsv = R(ss), *pe = P(se), *re = R(se);
+#pragma unroll
+        for (int k = 0; k < NVX; ++k) if (k < nk) {
+            if (!s_reg) { vps[k] = ld2(ps, ridx(k)); vrs[k] = ld2(rsv, ridx(k)); }
+            if (!e_reg) { vpe[k] = ld2(pe, ridx(k)); vre[k] = ld2(re, ridx(k)); }
+        }
+        double2 acc1 = {0.0, 0.0}, acc2 = {0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < NVX; ++k) if (k < nk) {
+            const double2 xps = s_reg ? X.p[k] : vps[k], xrs = s_reg ? X.r[k] : vrs[k];
+            const double2 xpe = e_reg ? X.p[k] : vpe[k], xre = e_reg ? X.r[k] : vre[k];
+            double2 t;
+            if (mode == 0) { t.x = (xre.x - xrs.x) + xps.x; t.y = (xre.y - xrs.y) + xps.y; }
+            else if (mode == 1) { t.x = xre.x + xrs.x; t.y = xre.y + xrs.y; }
+            else { t.x = (xrs.x - xre.x) + xpe.x; t.y = (xrs.y - xre.y) + xpe.y; }
+            acc1.x = fma(t.x, X.s[k].x * xpe.x, acc1.x);
+            acc1.y = fma(t.y, X.s[k].y * xpe.y, acc1.y);
+            acc2.x = fma(t.x, X.s[k].x * xps.x, acc2.x);
+            acc2.y = fma(t.y, X.s[k].y * xps.y, acc2.y);
+        }
+        double t1 = acc1.x + acc1.y, t2 = acc2.x + acc2.y;
+        reduce2<W>(t1, t2, red);
+        return (t1 < 0.0) || (t2 < 0.0);
+    }
+
     // EuclideanHamiltonian::is_turning on two P-slots.
-    __device__ bool turning(int64_t s1, int64_t i1, int64_t s2_, int64_t i2) {
+    __device__ __forceinline__ bool turning(RegsT& X, int64_t s1, int64_t i1, int64_t s2_, int64_t i2) {
+        if (NV > 0 && X.sig_ok) return turning_reg(X, s1, i1, s2_, i2);
         int64_t ss = s1, se = s2_, a = i1, b = i2;
         if (!(i1 < i2)) { ss = s2_; se = s1; a = i2; b = i1; }
         const double *ps = P(ss), *rs = R(ss), *pe = P(se), *re = R(se);
@@ -408,7 +564,7 @@ struct Machine {
         }
     }
 
-    __device__ void store_divergence(bool have_end) {
+    __device__ __forceinline__ void store_divergence(bool have_end) {
         if (!A.tr_div[0]) return;
         const size_t row = ((size_t)chain * T + c->draw) * D;
         const double *q = Q(c->lf_srcq), *g = G(c->lf_srcq), *p = P(c->lf_srcp), *qe = Q(c->lf_newq);
@@ -436,7 +592,7 @@ struct Machine {
         else finish_draw();
     }
 
-    __device__ void cont_ss(double K, double lp, int64_t code, bool first) {
+    __device__ __forceinline__ void cont_ss(double K, double lp, int64_t code, bool first) {
         c->total_steps += 1;
         const bool ok = (code == 0) && isfinite(lp);
         const double dE = (K - lp) - c->H0;
@@ -472,7 +628,7 @@ struct Machine {
         c->phase = PH_SS_ITER;
     }
 
-    __device__ void cont_init(double lp, int64_t code) {
+    __device__ __forceinline__ void cont_init(double lp, int64_t code) {
         if (code < 0) { finish_chain(PH_ERROR, CE_FATAL_LOGP); return; }
         if (code != 0 || !isfinite(lp)) {
             c->init_attempt += 1;
@@ -522,7 +678,7 @@ struct Machine {
         if (j == (1ll << d)) newp = slot_end(db, (int)(c->endpar[db] ^ 1));
         else if (j & 1) newp = (j == 1) ? slot_first((int)d) : slot_first(__builtin_ctzll((unsigned long long)(j - 1)));
         else newp = slot_last(__builtin_ctzll((unsigned long long)j), A.cap);
-        lf1(c->curq, c->curp, alloc_q(true), newp, c->dir);
+        lf1(c->curq, c->curp, alloc_q(true), newp, c->dir, true);
         c->phase = PH_TREE;
     }
 
@@ -533,8 +689,9 @@ struct Machine {
     }
 
     // one leapfrog of the tree has been evaluated: NutsTree::extend / merge_into, unrolled
-    __device__ void cont_tree(double K, double lp, int64_t code) {
-        if (code < 0) { finish_chain(PH_ERROR, CE_FATAL_LOGP); return; }
+    // returns true when a rare, non-inlined path ran (the register mirror must then be dropped)
+    __device__ __forceinline__ bool cont_tree(RegsT& X, double K, double lp, int64_t code) {
+        if (code < 0) { finish_chain(PH_ERROR, CE_FATAL_LOGP); return true; }
         c->nleaf += 1;
         c->n_steps += 1;
         c->total_steps += 1;
@@ -556,7 +713,7 @@ struct Machine {
             c->acc_mean += (a - c->acc_mean) / cnt;
             c->acc_sym_mean += (asym - c->acc_sym_mean) / cnt;
         }
-        if (diverged) { store_divergence(ok); end_draw(true, false); return; }
+        if (diverged) { rare_end_draw(A, c, red, chain, true, false, true, ok); return true; }
 
         const int64_t near_idx = dir > 0 ? c->idx_right : c->idx_left;
         const int64_t sT_last = c->lf_newp;
@@ -571,18 +728,18 @@ struct Machine {
                 const int64_t a = j - (2ll << k) + 1;  // first leaf of the waiting sub-tree A
                 const int64_t sA_first = (a == 1) ? slot_first((int)d) : slot_first(__builtin_ctzll((unsigned long long)(a - 1)));
                 const int64_t iA_first = near_idx + dir * a;
-                bool turn = turning(sA_first, iA_first, sT_last, idx_new);
+                bool turn = turning(X, sA_first, iA_first, sT_last, idx_new);
                 if (k > 0) {
                     if (!turn) {
                         const int64_t al = j - (1ll << k);  // last leaf of A
-                        turn = turning(slot_last(__builtin_ctzll((unsigned long long)al), A.cap), near_idx + dir * al, sT_last, idx_new);
+                        turn = turning(X, slot_last(__builtin_ctzll((unsigned long long)al), A.cap), near_idx + dir * al, sT_last, idx_new);
                     }
                     if (!turn) {
                         const int64_t tf = j - (1ll << k) + 1;  // first leaf of T
-                        turn = turning(sA_first, iA_first, slot_first(__builtin_ctzll((unsigned long long)(tf - 1))), near_idx + dir * tf);
+                        turn = turning(X, sA_first, iA_first, slot_first(__builtin_ctzll((unsigned long long)(tf - 1))), near_idx + dir * tf);
                     }
                 }
-                if (turn) { end_draw(false, false); return; }
+                if (turn) { rare_end_draw(A, c, red, chain, false, false, false, false); return true; }
             }
             const double ls = nphip_logaddexp(c->sub_ls[k], T_ls);
             bool take = T_ls >= ls;
@@ -594,16 +751,16 @@ struct Machine {
         if (k < d) {
             c->sub_ls[k] = T_ls; c->sub_q[k] = T_q; c->sub_U[k] = T_U; c->sub_E[k] = T_E; c->sub_idx[k] = T_idx;
             issue_leaf();
-            return;
+            return false;
         }
         // the new sub-tree of depth d is complete: merge into the main tree
         bool turn = false;
         if (check) {
             const int64_t far_slot = c->endp[1 - db], far_idx = dir > 0 ? c->idx_left : c->idx_right;
-            turn = turning(far_slot, far_idx, sT_last, idx_new);
+            turn = turning(X, far_slot, far_idx, sT_last, idx_new);
             if (d > 0) {
-                if (!turn) turn = turning(c->endp[db], near_idx, sT_last, idx_new);
-                if (!turn) turn = turning(far_slot, far_idx, slot_first((int)d), near_idx + dir);
+                if (!turn) turn = turning(X, c->endp[db], near_idx, sT_last, idx_new);
+                if (!turn) turn = turning(X, far_slot, far_idx, slot_first((int)d), near_idx + dir);
             }
         }
         c->endq[db] = c->lf_newq;
@@ -618,13 +775,27 @@ struct Machine {
             c->ls_main = ls;
             c->depth = d + 1;
         }
-        if (turn) { end_draw(false, false); return; }
-        if (c->depth >= A.s.maxdepth) { end_draw(false, true); return; }
+        if (turn) { rare_end_draw(A, c, red, chain, false, false, false, false); return true; }
+        if (c->depth >= A.s.maxdepth) { rare_end_draw(A, c, red, chain, false, true, false, false); return true; }
         start_doubling();
+        return false;
     }
 
     // GlobalStrategy::adapt
-    __device__ void end_draw(bool diverging, bool maxdepth) {
+    // The rare paths are compiled as separate functions that rebuild their own Machine from uniform
+    // arguments: the hot Machine object never escapes, so its members stay in (S/V)GPRs.
+    static __device__ __attribute__((noinline)) void rare_end_draw(const NPHIP_CONST Args& a, LdsCtl ctl, LdsDouble r, int64_t ch,
+                                                                  bool diverging, bool maxdepth, bool store_div, bool div_has_end) {
+        Machine m(a, ctl, r, ch);
+        if (store_div) m.store_divergence(div_has_end);
+        m.end_draw(diverging, maxdepth);
+    }
+    static __device__ __attribute__((noinline)) void rare_phase_fn(const NPHIP_CONST Args& a, LdsCtl ctl, LdsDouble r, int64_t ch, int64_t ph) {
+        Machine m(a, ctl, r, ch);
+        m.rare_phase(ph);
+    }
+
+    __device__ __forceinline__ void end_draw(bool diverging, bool maxdepth) {
         c->fin_depth = c->depth;
         c->fin_flags = (diverging ? 1 : 0) | (maxdepth ? 2 : 0);
         c->fin_eerr = c->cand_E - c->H0;  // H0 is reused by a mid-adapt step-size search
@@ -689,86 +860,124 @@ struct Machine {
         begin_draw();
     }
 
-    __device__ void run() {
-        int budget = A.max_evals;
-        bool have = A.have_result != 0;
+    // rare phases: initial point, step-size search (memory-resident passes; not performance critical)
+    __device__ __forceinline__ void rare_phase(int64_t ph) {
+        double lp = 0.0;
+        int64_t code = 0;
+        if (ph == PH_START) {
+            c->init_attempt = 0;
+            gen_init(0);
+            c->phase = PH_INIT_EVAL;
+            if (FUSED) chain_sync<W>();
+        } else if (ph == PH_INIT_EVAL) {
+            eval_position(c->eval_buf, lp, code);
+            cont_init(lp, code);
+            if (FUSED && c->phase == PH_INIT_EVAL) chain_sync<W>();
+        } else {  // PH_SS_FIRST / PH_SS_ITER
+            double K = lf2(lp, code, c->lf_sign);
+            if (code < 0) { finish_chain(PH_ERROR, CE_FATAL_LOGP); return; }
+            cont_ss(K, lp, code, ph == PH_SS_FIRST);
+        }
+    }
+
+    __device__ __forceinline__ void run(int budget, bool have) {
+        RegsT X;
         for (;;) {
             const int64_t ph = c->phase;
             if (ph == PH_DONE || ph == PH_ERROR) break;
-            if (ph == PH_START) {
-                c->init_attempt = 0;
-                gen_init(0);
-                c->phase = PH_INIT_EVAL;
-                if (FUSED) chain_sync<W>();
-                continue;
+            if (ph != PH_START) {
+                if (FUSED) {
+                    if (budget <= 0) break;
+                    --budget;
+                } else {
+                    if (!have) break;
+                    have = false;
+                }
             }
-            if (FUSED) {
-                if (budget <= 0) break;
-                --budget;
+#ifdef NPHIP_PROFILE
+            const int64_t t0 = (int64_t)__builtin_readcyclecounter();
+#endif
+            if (ph == PH_TREE) {
+                double lp = 0.0;
+                int64_t code = 0;
+                const int64_t idx_new = c->idx_cur + c->dir;
+                double K = (NV > 0) ? leapfrog_reg(X, lp, code, idx_new) : lf2(lp, code, idx_new);
+#ifdef NPHIP_PROFILE
+                const int64_t t1 = (int64_t)__builtin_readcyclecounter();
+#endif
+                const bool rare = cont_tree(X, K, lp, code);
+                if (rare) X.invalidate();
+#ifdef NPHIP_PROFILE
+                const int64_t t2 = (int64_t)__builtin_readcyclecounter();
+                c->prof[0] += t1 - t0; c->prof[3] += 1;
+                if (rare) { c->prof[2] += t2 - t1; c->prof[5] += 1; } else { c->prof[1] += t2 - t1; c->prof[4] += 1; }
+#endif
             } else {
-                if (!have) break;
-                have = false;
-            }
-            double lp = 0.0;
-            int64_t code = 0;
-            if (ph == PH_INIT_EVAL) {
-                eval_position(c->eval_buf, lp, code);
-                cont_init(lp, code);
-                if (FUSED && c->phase == PH_INIT_EVAL) chain_sync<W>();
-            } else if (ph == PH_TREE) {
-                double K = lf2(lp, code, c->idx_cur + c->dir);
-                cont_tree(K, lp, code);
-            } else {  // PH_SS_FIRST / PH_SS_ITER
-                double K = lf2(lp, code, c->lf_sign);
-                if (code < 0) { finish_chain(PH_ERROR, CE_FATAL_LOGP); continue; }
-                cont_ss(K, lp, code, ph == PH_SS_FIRST);
+                rare_phase_fn(A, c, red, chain, ph);
+                X.invalidate();
             }
         }
     }
 #undef NPHIP_FOR_CHUNKS
 };
 
-template <bool FUSED, int W>
-__global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k_advance(const Args A) {
+// `Ap` points to the engine's argument block in device memory (written once at set-up); it is read through
+// the constant address space, i.e. with scalar loads into SGPRs.  Per-launch scalars are kernel parameters.
+template <bool FUSED, int W, int NV>
+__global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k_advance(const Args* __restrict__ Ap, int max_evals, int have_result) {
+    const NPHIP_CONST Args& A = *(const NPHIP_CONST Args*)Ap;
     constexpr int WAVES = (W == 1) ? 4 : W;
     __shared__ Ctl s_ctl[WAVES];
     __shared__ double s_red[2 * WAVES];
-    const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int64_t chain = (W == 1) ? (int64_t)blockIdx.x * 4 + wib : (int64_t)blockIdx.x;
     if (chain >= A.n_chains) return;
-    Ctl* c = &s_ctl[wib];
+    LdsCtl c = (LdsCtl)&s_ctl[wib];
     {
-        const uint64_t* src = reinterpret_cast<const uint64_t*>(A.ctl + chain);
-        uint64_t* dst = reinterpret_cast<uint64_t*>(c);
+        const NPHIP_GLOBAL uint64_t* src = (const NPHIP_GLOBAL uint64_t*)(A.ctl + chain);
+        NPHIP_LDS uint64_t* dst = (NPHIP_LDS uint64_t*)c;
         for (int w = lane; w < kCtlWords; w += 64) dst[w] = src[w];
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    Machine<FUSED, W> m(A, c, s_red, chain, (W == 1) ? 0 : wib, lane);
-    m.run();
+    Machine<FUSED, W, NV> m(A, c, (LdsDouble)s_red, chain);
+    m.run(max_evals, have_result != 0);
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     if (W == 1 || wib == 0) {
-        uint64_t* dst = reinterpret_cast<uint64_t*>(A.ctl + chain);
-        const uint64_t* src = reinterpret_cast<const uint64_t*>(c);
+        NPHIP_GLOBAL uint64_t* dst = (NPHIP_GLOBAL uint64_t*)(A.ctl + chain);
+        const NPHIP_LDS uint64_t* src = (const NPHIP_LDS uint64_t*)c;
         for (int w = lane; w < kCtlWords; w += 64) dst[w] = src[w];
     }
 }
 
 template <bool FUSED>
-static hipError_t launch_w(const Args& a, int W, hipStream_t st) {
+static hipError_t launch_w(const Args& a, const Args* d_args, int W, hipStream_t st) {
     const unsigned n = (unsigned)a.n_chains;
+    const int me = a.max_evals, hr = a.have_result;
+    if (FUSED && W == 1 && a.reg_nv > 0) {
+        const dim3 g((n + 3) / 4), b(256);
+        switch (a.reg_nv) {
+            case 1: hipLaunchKernelGGL((k_advance<true, 1, 1>), g, b, 0, st, d_args, me, hr); break;
+            case 2: hipLaunchKernelGGL((k_advance<true, 1, 2>), g, b, 0, st, d_args, me, hr); break;
+            case 4: hipLaunchKernelGGL((k_advance<true, 1, 4>), g, b, 0, st, d_args, me, hr); break;
+            case 8: hipLaunchKernelGGL((k_advance<true, 1, 8>), g, b, 0, st, d_args, me, hr); break;
+            case 16: hipLaunchKernelGGL((k_advance<true, 1, 16>), g, b, 0, st, d_args, me, hr); break;
+            default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     switch (W) {
-        case 1: hipLaunchKernelGGL((k_advance<FUSED, 1>), dim3((n + 3) / 4), dim3(256), 0, st, a); break;
-        case 2: hipLaunchKernelGGL((k_advance<FUSED, 2>), dim3(n), dim3(128), 0, st, a); break;
-        case 4: hipLaunchKernelGGL((k_advance<FUSED, 4>), dim3(n), dim3(256), 0, st, a); break;
-        case 8: hipLaunchKernelGGL((k_advance<FUSED, 8>), dim3(n), dim3(512), 0, st, a); break;
-        case 16: hipLaunchKernelGGL((k_advance<FUSED, 16>), dim3(n), dim3(1024), 0, st, a); break;
+        case 1: hipLaunchKernelGGL((k_advance<FUSED, 1, 0>), dim3((n + 3) / 4), dim3(256), 0, st, d_args, me, hr); break;
+        case 2: hipLaunchKernelGGL((k_advance<FUSED, 2, 0>), dim3(n), dim3(128), 0, st, d_args, me, hr); break;
+        case 4: hipLaunchKernelGGL((k_advance<FUSED, 4, 0>), dim3(n), dim3(256), 0, st, d_args, me, hr); break;
+        case 8: hipLaunchKernelGGL((k_advance<FUSED, 8, 0>), dim3(n), dim3(512), 0, st, d_args, me, hr); break;
+        case 16: hipLaunchKernelGGL((k_advance<FUSED, 16, 0>), dim3(n), dim3(1024), 0, st, d_args, me, hr); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }
 
-hipError_t launch_advance(const Args& a, bool fused, int W, hipStream_t st) {
-    return fused ? launch_w<true>(a, W, st) : launch_w<false>(a, W, st);
+hipError_t launch_advance(const Args& a, const Args* d_args, bool fused, int W, hipStream_t st) {
+    return fused ? launch_w<true>(a, d_args, W, st) : launch_w<false>(a, d_args, W, st);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -802,7 +1011,8 @@ __global__ void k_test_detmath(int fn, uint64_t n, const double* x, double* y) {
 
 template <int W>
 __global__ void k_test_dot(uint64_t n, const double* x, const double* y, double* out) {
-    __shared__ double red[2 * W];
+    __shared__ double red_[2 * W];
+    LdsDouble red = (LdsDouble)red_;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t nch = (int64_t)((n + 127) / 128);
     double2 acc = {0.0, 0.0};
