@@ -223,7 +223,9 @@ NPHIP_HD void nphip_normal_pair(nphip_u32x4 r, double* z0, double* z1) {
  *   - per (wave, lane, component) accumulator, acc = fma(x_i, y_i, acc) over the
  *     owned elements in increasing i, starting from +0.0;
  *   - lane value = acc[component 0] + acc[component 1];
- *   - xor-butterfly over lanes with offsets 32,16,8,4,2,1: v = v + v_partner;
+ *   - five butterfly stages v = v + v_partner with partner(l) = l^1, l^2, (l&~7)|(7-(l&7)),
+ *     (l&~15)|(15-(l&15)), l^16  (the cheap DPP patterns quad_perm / row_half_mirror / row_mirror of
+ *     gfx950 plus one ds_swizzle), then wave total = v[lane 0] + v[lane 32];
  *   - wave totals summed in wave order: ((w0 + w1) + w2) + ...
  * W is reported by the engine (nphip_sampler_waves_per_chain) and is an input
  * of the oracle.

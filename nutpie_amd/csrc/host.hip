@@ -542,7 +542,11 @@ bool nphip_sampler::setup() {
         if (!dalloc(&mu, ld) || !dalloc(&a, ld) || !dalloc(&b, ld)) return false;
         HIP_TRY(hipMemcpyAsync(mu, model.mu.data(), dim * 8, hipMemcpyHostToDevice, stream));
         HIP_TRY(hipMemcpyAsync(a, model.a.data(), dim * 8, hipMemcpyHostToDevice, stream));
-        HIP_TRY(hipMemcpyAsync(b, model.b.data(), dim * 8, hipMemcpyHostToDevice, stream));
+        {   // b[dim-1 ..] = -0.0: lets the register kernel add boundary terms unconditionally (t + (-0.0) == t)
+            std::vector<double> bpad(ld, -0.0);
+            std::copy(model.b.begin(), model.b.begin() + (dim > 0 ? dim - 1 : 0), bpad.begin());
+            HIP_TRY(hipMemcpy(b, bpad.data(), ld * 8, hipMemcpyHostToDevice));
+        }
         args.m_mu = mu; args.m_a = a; args.m_b = b;
     } else {
         if (launch.staging_q && launch.staging_grad && launch.staging_logp) {

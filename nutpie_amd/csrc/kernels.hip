@@ -45,25 +45,69 @@ __device__ __forceinline__ void chain_sync() {
     if (W > 1) __syncthreads();
 }
 
-// Sum two values over the chain in the contract order of nphip_spec.h.
-template <int W>
-__device__ __forceinline__ void reduce2(double& a, double& b, NPHIP_LDS double* red) {
+// ---- wave reduction in the contract order of nphip_spec.h (DPP, no LDS traffic) ---------------------
+// stage partners: l^1, l^2, mirror within 8, mirror within 16, l^16, then lanes {0, 32}.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double swz16_f64(double x) {  // value of lane l ^ 16
+    int lo = __builtin_amdgcn_ds_swizzle(__double2loint(x), 0x401F);
+    int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(x), 0x401F);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double x, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
+}
+// value of lane l-1 (lane 0 receives `edge`) / lane l+1 (lane 63 receives `edge`): DPP wave shifts
+__device__ __forceinline__ double wave_shr1(double x, double edge) {
+    int lo = __builtin_amdgcn_update_dpp(__double2loint(edge), __double2loint(x), 0x138, 0xF, 0xF, false);
+    int hi = __builtin_amdgcn_update_dpp(__double2hiint(edge), __double2hiint(x), 0x138, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_shl1(double x, double edge) {
+    int lo = __builtin_amdgcn_update_dpp(__double2loint(edge), __double2loint(x), 0x130, 0xF, 0xF, false);
+    int hi = __builtin_amdgcn_update_dpp(__double2hiint(edge), __double2hiint(x), 0x130, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum(double v) {
+    v = v + dpp_f64<0xB1>(v);    // quad_perm [1,0,3,2]  : l ^ 1
+    v = v + dpp_f64<0x4E>(v);    // quad_perm [2,3,0,1]  : l ^ 2
+    v = v + dpp_f64<0x141>(v);   // row_half_mirror      : 7 - l  (within 8)
+    v = v + dpp_f64<0x140>(v);   // row_mirror           : 15 - l (within 16)
+    v = v + swz16_f64(v);        // l ^ 16
+    return readlane_f64(v, 0) + readlane_f64(v, 32);
+}
+
+// Sum N values over the chain: wave_sum per value, then (W > 1) wave totals in wave order through LDS.
+template <int W, int N>
+__device__ __forceinline__ void reduceN(double (&v)[N], NPHIP_LDS double* red) {
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        double pa = __shfl_xor(a, off);
-        double pb = __shfl_xor(b, off);
-        a = a + pa;
-        b = b + pb;
-    }
+    for (int n = 0; n < N; ++n) v[n] = wave_sum(v[n]);
     if (W > 1) {
         const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-        if (lane == 0) { red[2 * wave] = a; red[2 * wave + 1] = b; }
+        if (lane == 0) {
+#pragma unroll
+            for (int n = 0; n < N; ++n) red[N * wave + n] = v[n];
+        }
         __syncthreads();
-        double ta = red[0], tb = red[1];
-        for (int w = 1; w < W; ++w) { ta = ta + red[2 * w]; tb = tb + red[2 * w + 1]; }
+#pragma unroll
+        for (int n = 0; n < N; ++n) {
+            double t = red[n];
+            for (int w = 1; w < W; ++w) t = t + red[N * w + n];
+            v[n] = t;
+        }
         __syncthreads();
-        a = ta; b = tb;
     }
+}
+template <int W>
+__device__ __forceinline__ void reduce2(double& a, double& b, NPHIP_LDS double* red) {
+    double v[2] = {a, b};
+    reduceN<W, 2>(v, red);
+    a = v[0]; b = v[1];
 }
 
 // Explicit address spaces: the engine's pointers arrive inside a by-value struct, so clang cannot infer
@@ -345,7 +389,11 @@ struct Machine {
     // ---- register-resident leapfrog (NV > 0): one fused pass, no loads when continuing from the cursor ----
     __device__ __forceinline__ int64_t ridx(int k) const { return (int64_t)k * NPHIP_CHUNK + 2 * lane; }
 
-    __device__ __forceinline__ double leapfrog_reg(RegsT& X, double& lp, int64_t& code, int64_t idx_new) {
+    // FUSE0: also accumulate the level-0 U-turn criterion between the source leaf and the new leaf — its
+    // operands are exactly the registers before/after the update ((rho' - rho) + p works for both directions,
+    // SURVEY A.4 modes 0 and 2), so that check costs no loads and shares the reduction.  turn0 = its result.
+    template <bool FUSE0>
+    __device__ __forceinline__ double leapfrog_reg(RegsT& X, double& lp, int64_t& code, int64_t idx_new, bool& turn0) {
         const int64_t srcq = c->lf_srcq, srcp = c->lf_srcp, newq = c->lf_newq, newp = c->lf_newp;
         const int nk = (int)nch;
         if (X.reg_q != srcq) {
@@ -365,12 +413,16 @@ struct Machine {
         }
         const double eps = (double)c->lf_sign * c->step_size;
         const double h = 0.5 * eps;
-        const bool copy_rho = (idx_new == -1);
-        double2 z[NVX];
+        if (idx_new == -1) {  // first backward step: rho' = p'  (-0.0 + p == p exactly, also for signed zeros)
+#pragma unroll
+            for (int k = 0; k < NVX; ++k) if (k < nk) { X.r[k].x = -0.0; X.r[k].y = -0.0; }
+        }
+        double2 z[NVX], pold[NVX];
         // first half kick + drift, z = q' - mu
 #pragma unroll
         for (int k = 0; k < NVX; ++k) if (k < nk) {
             double2 mu = ld2(A.m_mu, ridx(k));
+            if (FUSE0) pold[k] = X.p[k];
             X.p[k].x = fma(h, X.g[k].x, X.p[k].x);
             X.p[k].y = fma(h, X.g[k].y, X.p[k].y);
             X.q[k].x = fma(eps, X.s[k].x * X.p[k].x, X.q[k].x);
@@ -378,91 +430,157 @@ struct Machine {
             z[k].x = X.q[k].x - mu.x;
             z[k].y = X.q[k].y - mu.y;
         }
-        // tridiagonal gradient: neighbours come from adjacent lanes (wave shuffles), chunk borders wrap
-        double2 accK = {0.0, 0.0}, accL = {0.0, 0.0};
+        // tridiagonal gradient: neighbours come from adjacent lanes (DPP wave shifts); chunk borders via readlane.
+        // Boundary terms need no branches: the host pads b with -0.0 (and b_{-1} := -0.0), and t + (-0.0) == t.
+        double2 accK = {0.0, 0.0}, accL = {0.0, 0.0}, accE = {0.0, 0.0}, accS = {0.0, 0.0};
         double *qn = Q(newq), *gn = G(newq), *pn = P(newp), *rn = R(newp);
 #pragma unroll
         for (int k = 0; k < NVX; ++k) if (k < nk) {
             const int64_t i = ridx(k);
-            double2 a = ld2(A.m_a, i), b = ld2(A.m_b, i);
-            double bl = __shfl_up(b.y, 1);                       // b_{i-1}
-            double zl = __shfl_up(z[k].y, 1);                    // z_{i-1}
-            double zr = __shfl_down(z[k].x, 1);                  // z_{i+2}
+            const double2 a = ld2(A.m_a, i), b = ld2(A.m_b, i);
+            double edge_bl = -0.0, edge_zl = 0.0, edge_zr = 0.0;
             if (k > 0) {
-                double wz = __shfl(z[k - 1].y, 63);
-                double wb = __shfl(ld2(A.m_b, ridx(k - 1)).y, 63);
-                if (lane == 0) { zl = wz; bl = wb; }
+                edge_zl = readlane_f64(z[k - 1].y, 63);
+                edge_bl = readlane_f64(ld2(A.m_b, ridx(k - 1)).y, 63);
             }
-            if (k + 1 < NVX) {
-                double wz = (k + 1 < nk) ? __shfl(z[k + 1].x, 0) : 0.0;
-                if (lane == 63) zr = wz;
-            }
+            if (k + 1 < NVX) { if (k + 1 < nk) edge_zr = readlane_f64(z[k + 1].x, 0); }
+            const double bl = wave_shr1(b.y, edge_bl);      // b_{i-1}
+            const double zl = wave_shr1(z[k].y, edge_zl);   // z_{i-1}
+            const double zr = wave_shl1(z[k].x, edge_zr);   // z_{i+2}
             double tx = a.x * z[k].x;
-            if (i > 0) tx = fma(bl, zl, tx);
-            if (i + 1 < D) tx = fma(b.x, z[k].y, tx);
+            tx = fma(bl, zl, tx);
+            tx = fma(b.x, z[k].y, tx);
             double ty = a.y * z[k].y;
             ty = fma(b.x, z[k].x, ty);
-            if (i + 2 < D) ty = fma(b.y, zr, ty);
+            ty = fma(b.y, zr, ty);
             double2 gg;
-            gg.x = (i < D) ? -tx : 0.0;
-            gg.y = (i + 1 < D) ? -ty : 0.0;
+            gg.x = -tx;
+            gg.y = -ty;
             accL.x = fma(z[k].x, gg.x, accL.x);
             accL.y = fma(z[k].y, gg.y, accL.y);
             X.g[k] = gg;
             // second half kick, kinetic energy, running momentum sum
+            const double2 rold = X.r[k];
             X.p[k].x = fma(h, gg.x, X.p[k].x);
             X.p[k].y = fma(h, gg.y, X.p[k].y);
-            accK.x = fma(X.p[k].x, X.s[k].x * X.p[k].x, accK.x);
-            accK.y = fma(X.p[k].y, X.s[k].y * X.p[k].y, accK.y);
-            X.r[k].x = copy_rho ? X.p[k].x : X.r[k].x + X.p[k].x;
-            X.r[k].y = copy_rho ? X.p[k].y : X.r[k].y + X.p[k].y;
-            st2(qn, i, X.q[k]); st2(gn, i, X.g[k]); st2(pn, i, X.p[k]); st2(rn, i, X.r[k]);
+            const double vx = X.s[k].x * X.p[k].x, vy = X.s[k].y * X.p[k].y;
+            accK.x = fma(X.p[k].x, vx, accK.x);
+            accK.y = fma(X.p[k].y, vy, accK.y);
+            X.r[k].x = rold.x + X.p[k].x;
+            X.r[k].y = rold.y + X.p[k].y;
+            if (FUSE0) {
+                const double tx0 = (X.r[k].x - rold.x) + pold[k].x, ty0 = (X.r[k].y - rold.y) + pold[k].y;
+                accE.x = fma(tx0, vx, accE.x);
+                accE.y = fma(ty0, vy, accE.y);
+                accS.x = fma(tx0, X.s[k].x * pold[k].x, accS.x);
+                accS.y = fma(ty0, X.s[k].y * pold[k].y, accS.y);
+            }
+#ifndef NPHIP_EXP_NOQG
+            st2(qn, i, X.q[k]); st2(gn, i, X.g[k]);
+#endif
+#ifndef NPHIP_EXP_NOPR
+            st2(pn, i, X.p[k]); st2(rn, i, X.r[k]);
+#endif
         }
         X.reg_q = newq;
         X.reg_p = newp;
-        double a = accK.x + accK.y, b = accL.x + accL.y;
-        reduce2<W>(a, b, red);
-        lp = 0.5 * b;
         code = 0;
-        return 0.5 * a;
+        if (FUSE0) {
+            double v[4] = {accK.x + accK.y, accL.x + accL.y, accE.x + accE.y, accS.x + accS.y};
+            reduceN<W, 4>(v, red);
+            lp = 0.5 * v[1];
+            turn0 = (v[2] < 0.0) || (v[3] < 0.0);
+            return 0.5 * v[0];
+        }
+        double v[2] = {accK.x + accK.y, accL.x + accL.y};
+        reduceN<W, 2>(v, red);
+        lp = 0.5 * v[1];
+        turn0 = false;
+        return 0.5 * v[0];
     }
 
-    // U-turn criterion with operands taken from the register mirror when possible
-    __device__ __forceinline__ bool turning_reg(RegsT& X, int64_t s1, int64_t i1, int64_t s2_, int64_t i2) {
-        int64_t ss = s1, se = s2_, a = i1, b = i2;
-        if (!(i1 < i2)) { ss = s2_; se = s1; a = i2; b = i1; }
-        const int mode = (a >= 0 && b >= 0) ? 0 : ((b >= 0 && a < 0) ? 1 : 2);
+    // ---- fused U-turn checks (NV > 0).  One merge needs up to three criteria that share operands:
+    //   (A, TL), (B, TL), (A, TF)   with TL = the leaf just integrated (register mirror),
+    // so all six dot products are accumulated in ONE pass and reduced together.  Each dot keeps the contract
+    // order (per-lane fma chain over k, then wave_sum), hence the booleans equal three separate passes.
+    struct Pair { int mode; bool first_is_start; };
+    __device__ __forceinline__ Pair pair_of(int64_t i1, int64_t i2) const {
+        Pair pr;
+        pr.first_is_start = i1 < i2;
+        const int64_t a = pr.first_is_start ? i1 : i2, b = pr.first_is_start ? i2 : i1;
+        pr.mode = (a >= 0 && b >= 0) ? 0 : ((b >= 0 && a < 0) ? 1 : 2);
+        return pr;
+    }
+    // accumulate span . v_end (acc_e) and span . v_start (acc_s) for the pair (1, 2)
+    __device__ __forceinline__ void pair_acc(const Pair pr, double p1, double r1, double p2, double r2, double s2v, double& acc_e, double& acc_s) const {
+        const double ps = pr.first_is_start ? p1 : p2, rs = pr.first_is_start ? r1 : r2;
+        const double pe = pr.first_is_start ? p2 : p1, re = pr.first_is_start ? r2 : r1;
+        double t;
+        if (pr.mode == 0) t = (re - rs) + ps;
+        else if (pr.mode == 1) t = re + rs;
+        else t = (rs - re) + pe;
+        acc_e = fma(t, s2v * pe, acc_e);
+        acc_s = fma(t, s2v * ps, acc_s);
+    }
+
+    // n_checks == 1: (A, TL) only.  n_checks == 3: (A, TL) || (B, TL) || (A, TF).  Operands A, B, TF come
+    // from their P-slots in global memory (L2 / Infinity-Cache resident: written a few leaves ago).
+    __device__ __forceinline__ bool check_fused(RegsT& X, int n_checks, int64_t sA, int64_t iA, int64_t sB, int64_t iB,
+                                                int64_t sTF, int64_t iTF, int64_t iTL) {
         const int nk = (int)nch;
-        double2 vps[NVX], vrs[NVX], vpe[NVX], vre[NVX];
-        const bool s_reg = (ss == X.reg_p), e_reg = (se == X.reg_p);
-        const double *ps = P(ss), *rsv = R(ss), *pe = P(se), *re = R(se);
+        double2 pa[NVX], ra[NVX], pb[NVX], rb[NVX], pf[NVX], rf[NVX];
+        const double *gpa = P(sA), *gra = R(sA);
+#pragma unroll
+        for (int k = 0; k < NVX; ++k) if (k < nk) { pa[k] = ld2(gpa, ridx(k)); ra[k] = ld2(gra, ridx(k)); }
+        if (n_checks == 3) {
+            const double *gpb = P(sB), *grb = R(sB), *gpf = P(sTF), *grf = R(sTF);
+#pragma unroll
+            for (int k = 0; k < NVX; ++k) if (k < nk) {
+                pb[k] = ld2(gpb, ridx(k)); rb[k] = ld2(grb, ridx(k));
+                pf[k] = ld2(gpf, ridx(k)); rf[k] = ld2(grf, ridx(k));
+            }
+        }
+        const Pair p1 = pair_of(iA, iTL), p2 = pair_of(iB, iTL), p3 = pair_of(iA, iTF);
+        double2 acc[6];
+#pragma unroll
+        for (int n = 0; n < 6; ++n) { acc[n].x = 0.0; acc[n].y = 0.0; }
 #pragma unroll
         for (int k = 0; k < NVX; ++k) if (k < nk) {
-            if (!s_reg) { vps[k] = ld2(ps, ridx(k)); vrs[k] = ld2(rsv, ridx(k)); }
-            if (!e_reg) { vpe[k] = ld2(pe, ridx(k)); vre[k] = ld2(re, ridx(k)); }
+            pair_acc(p1, pa[k].x, ra[k].x, X.p[k].x, X.r[k].x, X.s[k].x, acc[0].x, acc[1].x);
+            pair_acc(p1, pa[k].y, ra[k].y, X.p[k].y, X.r[k].y, X.s[k].y, acc[0].y, acc[1].y);
+            if (n_checks == 3) {
+                pair_acc(p2, pb[k].x, rb[k].x, X.p[k].x, X.r[k].x, X.s[k].x, acc[2].x, acc[3].x);
+                pair_acc(p2, pb[k].y, rb[k].y, X.p[k].y, X.r[k].y, X.s[k].y, acc[2].y, acc[3].y);
+                pair_acc(p3, pa[k].x, ra[k].x, pf[k].x, rf[k].x, X.s[k].x, acc[4].x, acc[5].x);
+                pair_acc(p3, pa[k].y, ra[k].y, pf[k].y, rf[k].y, X.s[k].y, acc[4].y, acc[5].y);
+            }
         }
-        double2 acc1 = {0.0, 0.0}, acc2 = {0.0, 0.0};
+        if (n_checks == 3) {
+            double v[6];
 #pragma unroll
-        for (int k = 0; k < NVX; ++k) if (k < nk) {
-            const double2 xps = s_reg ? X.p[k] : vps[k], xrs = s_reg ? X.r[k] : vrs[k];
-            const double2 xpe = e_reg ? X.p[k] : vpe[k], xre = e_reg ? X.r[k] : vre[k];
-            double2 t;
-            if (mode == 0) { t.x = (xre.x - xrs.x) + xps.x; t.y = (xre.y - xrs.y) + xps.y; }
-            else if (mode == 1) { t.x = xre.x + xrs.x; t.y = xre.y + xrs.y; }
-            else { t.x = (xrs.x - xre.x) + xpe.x; t.y = (xrs.y - xre.y) + xpe.y; }
-            acc1.x = fma(t.x, X.s[k].x * xpe.x, acc1.x);
-            acc1.y = fma(t.y, X.s[k].y * xpe.y, acc1.y);
-            acc2.x = fma(t.x, X.s[k].x * xps.x, acc2.x);
-            acc2.y = fma(t.y, X.s[k].y * xps.y, acc2.y);
+            for (int n = 0; n < 6; ++n) v[n] = acc[n].x + acc[n].y;
+            reduceN<W, 6>(v, red);
+            return (v[0] < 0.0) || (v[1] < 0.0) || (v[2] < 0.0) || (v[3] < 0.0) || (v[4] < 0.0) || (v[5] < 0.0);
         }
-        double t1 = acc1.x + acc1.y, t2 = acc2.x + acc2.y;
-        reduce2<W>(t1, t2, red);
-        return (t1 < 0.0) || (t2 < 0.0);
+        double v[2] = {acc[0].x + acc[0].y, acc[1].x + acc[1].y};
+        reduceN<W, 2>(v, red);
+        return (v[0] < 0.0) || (v[1] < 0.0);
+    }
+
+    // memory-resident equivalent (NV == 0): the same criteria, one pass each
+    __device__ __forceinline__ bool check_merge(RegsT& X, int n_checks, int64_t sA, int64_t iA, int64_t sB, int64_t iB,
+                                                int64_t sTF, int64_t iTF, int64_t sTL, int64_t iTL) {
+        if (NV > 0 && X.sig_ok && X.reg_p == sTL) return check_fused(X, n_checks, sA, iA, sB, iB, sTF, iTF, iTL);
+        bool turn = turning(sA, iA, sTL, iTL);
+        if (n_checks == 3) {
+            if (!turn) turn = turning(sB, iB, sTL, iTL);
+            if (!turn) turn = turning(sA, iA, sTF, iTF);
+        }
+        return turn;
     }
 
     // EuclideanHamiltonian::is_turning on two P-slots.
-    __device__ __forceinline__ bool turning(RegsT& X, int64_t s1, int64_t i1, int64_t s2_, int64_t i2) {
-        if (NV > 0 && X.sig_ok) return turning_reg(X, s1, i1, s2_, i2);
+    __device__ __forceinline__ bool turning(int64_t s1, int64_t i1, int64_t s2_, int64_t i2) {
         int64_t ss = s1, se = s2_, a = i1, b = i2;
         if (!(i1 < i2)) { ss = s2_; se = s1; a = i2; b = i1; }
         const double *ps = P(ss), *rs = R(ss), *pe = P(se), *re = R(se);
@@ -690,7 +808,7 @@ struct Machine {
 
     // one leapfrog of the tree has been evaluated: NutsTree::extend / merge_into, unrolled
     // returns true when a rare, non-inlined path ran (the register mirror must then be dropped)
-    __device__ __forceinline__ bool cont_tree(RegsT& X, double K, double lp, int64_t code) {
+    __device__ __forceinline__ bool cont_tree(RegsT& X, double K, double lp, int64_t code, bool have_turn0, bool turn0) {
         if (code < 0) { finish_chain(PH_ERROR, CE_FATAL_LOGP); return true; }
         c->nleaf += 1;
         c->n_steps += 1;
@@ -728,16 +846,14 @@ struct Machine {
                 const int64_t a = j - (2ll << k) + 1;  // first leaf of the waiting sub-tree A
                 const int64_t sA_first = (a == 1) ? slot_first((int)d) : slot_first(__builtin_ctzll((unsigned long long)(a - 1)));
                 const int64_t iA_first = near_idx + dir * a;
-                bool turn = turning(X, sA_first, iA_first, sT_last, idx_new);
-                if (k > 0) {
-                    if (!turn) {
-                        const int64_t al = j - (1ll << k);  // last leaf of A
-                        turn = turning(X, slot_last(__builtin_ctzll((unsigned long long)al), A.cap), near_idx + dir * al, sT_last, idx_new);
-                    }
-                    if (!turn) {
-                        const int64_t tf = j - (1ll << k) + 1;  // first leaf of T
-                        turn = turning(X, sA_first, iA_first, slot_first(__builtin_ctzll((unsigned long long)(tf - 1))), near_idx + dir * tf);
-                    }
+                bool turn;
+                if (k == 0) {
+                    turn = have_turn0 ? turn0 : check_merge(X, 1, sA_first, iA_first, 0, 0, 0, 0, sT_last, idx_new);
+                } else {
+                    const int64_t al = j - (1ll << k);      // last leaf of A
+                    const int64_t tf = j - (1ll << k) + 1;  // first leaf of T
+                    turn = check_merge(X, 3, sA_first, iA_first, slot_last(__builtin_ctzll((unsigned long long)al), A.cap), near_idx + dir * al,
+                                       slot_first(__builtin_ctzll((unsigned long long)(tf - 1))), near_idx + dir * tf, sT_last, idx_new);
                 }
                 if (turn) { rare_end_draw(A, c, red, chain, false, false, false, false); return true; }
             }
@@ -757,11 +873,8 @@ struct Machine {
         bool turn = false;
         if (check) {
             const int64_t far_slot = c->endp[1 - db], far_idx = dir > 0 ? c->idx_left : c->idx_right;
-            turn = turning(X, far_slot, far_idx, sT_last, idx_new);
-            if (d > 0) {
-                if (!turn) turn = turning(X, c->endp[db], near_idx, sT_last, idx_new);
-                if (!turn) turn = turning(X, far_slot, far_idx, slot_first((int)d), near_idx + dir);
-            }
+            if (d == 0) turn = check_merge(X, 1, far_slot, far_idx, 0, 0, 0, 0, sT_last, idx_new);
+            else turn = check_merge(X, 3, far_slot, far_idx, c->endp[db], near_idx, slot_first((int)d), near_idx + dir, sT_last, idx_new);
         }
         c->endq[db] = c->lf_newq;
         c->endp[db] = c->lf_newp;
@@ -901,11 +1014,16 @@ struct Machine {
                 double lp = 0.0;
                 int64_t code = 0;
                 const int64_t idx_new = c->idx_cur + c->dir;
-                double K = (NV > 0) ? leapfrog_reg(X, lp, code, idx_new) : lf2(lp, code, idx_new);
+                // the level-0 merge (even leaf, check enabled) is fused into the register-resident leapfrog
+                bool turn0 = false;
+                const bool fuse0 = (NV > 0) && (((c->nleaf + 1) & 1) == 0) && A.s.check_turning && (c->depth + 1 > A.s.mindepth);
+                double K;
+                if (NV > 0) K = fuse0 ? leapfrog_reg<true>(X, lp, code, idx_new, turn0) : leapfrog_reg<false>(X, lp, code, idx_new, turn0);
+                else K = lf2(lp, code, idx_new);
 #ifdef NPHIP_PROFILE
                 const int64_t t1 = (int64_t)__builtin_readcyclecounter();
 #endif
-                const bool rare = cont_tree(X, K, lp, code);
+                const bool rare = cont_tree(X, K, lp, code, fuse0, turn0);
                 if (rare) X.invalidate();
 #ifdef NPHIP_PROFILE
                 const int64_t t2 = (int64_t)__builtin_readcyclecounter();
@@ -928,7 +1046,7 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k_advance(const Args* _
     const NPHIP_CONST Args& A = *(const NPHIP_CONST Args*)Ap;
     constexpr int WAVES = (W == 1) ? 4 : W;
     __shared__ Ctl s_ctl[WAVES];
-    __shared__ double s_red[2 * WAVES];
+    __shared__ double s_red[8 * WAVES];
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int64_t chain = (W == 1) ? (int64_t)blockIdx.x * 4 + wib : (int64_t)blockIdx.x;
     if (chain >= A.n_chains) return;
@@ -1011,7 +1129,7 @@ __global__ void k_test_detmath(int fn, uint64_t n, const double* x, double* y) {
 
 template <int W>
 __global__ void k_test_dot(uint64_t n, const double* x, const double* y, double* out) {
-    __shared__ double red_[2 * W];
+    __shared__ double red_[8 * W];
     LdsDouble red = (LdsDouble)red_;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t nch = (int64_t)((n + 127) / 128);

@@ -164,7 +164,7 @@ void normal_pair(const U4& r, double* z0, double* z1) {
 enum { RNG_MOMENTUM = 1, RNG_DIRECTION = 2, RNG_MERGE = 3, RNG_INIT = 4, RNG_SS_MOMENTUM = 5, RNG_JITTER = 6 };
 
 // --- reductions in the engine's summation order (nphip_spec.h "geometry") ----
-// 128*W interleaved accumulators, component add, xor butterfly, wave-order sum.
+// 128*W interleaved accumulators, component add, DPP-order butterfly, wave-order sum.
 struct Geometry { int W; };
 
 template <class F>
@@ -182,12 +182,24 @@ double det_reduce(size_t n, Geometry geo, F term_fma /* (i, acc) -> fma(x_i, y_i
     for (int w = 0; w < W; ++w) {
         double lane[64];
         for (int l = 0; l < 64; ++l) lane[l] = acc[(size_t)128 * w + 2 * l] + acc[(size_t)128 * w + 2 * l + 1];
-        for (int off = 32; off >= 1; off >>= 1) {
+        // stage partners of the engine's DPP reduction: l^1, l^2, mirror in 8, mirror in 16, l^16, lanes {0,32}
+        for (int stage = 0; stage < 5; ++stage) {
             double nxt[64];
-            for (int l = 0; l < 64; ++l) nxt[l] = lane[l] + lane[l ^ off];
+            for (int l = 0; l < 64; ++l) {
+                int partner;
+                switch (stage) {
+                    case 0: partner = l ^ 1; break;
+                    case 1: partner = l ^ 2; break;
+                    case 2: partner = (l & ~7) | (7 - (l & 7)); break;
+                    case 3: partner = (l & ~15) | (15 - (l & 15)); break;
+                    default: partner = l ^ 16; break;
+                }
+                nxt[l] = lane[l] + lane[partner];
+            }
             memcpy(lane, nxt, sizeof(lane));
         }
-        total = (w == 0) ? lane[0] : total + lane[0];
+        const double wsum = lane[0] + lane[32];
+        total = (w == 0) ? wsum : total + wsum;
     }
     return total;
 }

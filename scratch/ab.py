@@ -1,5 +1,5 @@
 import sys, time, numpy as np
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nutpie_amd import _lib as hip
 from nutpie_amd.gaussian import ar1_gaussian
 def run(dim, chains, noreg, W=0, E=256, steps=40, warm=40):

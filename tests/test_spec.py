@@ -89,7 +89,7 @@ def test_dot_order_is_the_contract(oracle):
     # so the result is the pairwise tree (x0*y0 + x1*y1) combined by the xor butterfly
     x = np.array([1e16, 1.0, -1e16, 1.0])
     y = np.ones(4)
-    # lanes: l0 = 1e16 + 1 = 1e16 ; l1 = -1e16 + 1 = -1e16 ; butterfly: l0 + l1 = 0
+    # lanes: l0 = 1e16 + 1 = 1e16 ; l1 = -1e16 + 1 = -1e16 ; first butterfly stage pairs lanes 0 and 1: 0
     assert oracle.dot(x, y, 1) == 0.0
     # different geometry (element 2,3 -> still lane 1): same here
     assert oracle.dot(x, y, 2) == 0.0
