@@ -408,6 +408,7 @@ struct nphip_sampler {
     uint64_t n = 0, T = 0, dim = 0;
     std::vector<void*> allocs;
     std::vector<void*> pinned;
+    std::vector<double> bpad;  // staging of the padded off-diagonal (must outlive the async copy)
     unsigned long long* h_counters = nullptr;  // pinned
     double *h_q = nullptr, *h_g = nullptr, *h_u = nullptr;  // pinned staging (host callback)
     int64_t* h_code = nullptr;
@@ -471,7 +472,8 @@ struct nphip_sampler {
 };
 
 static int choose_waves(uint64_t dim) {
-    if (dim <= 2048) return 1;
+    if (dim <= 1024) return 1;
+    if (dim <= 2048) return 2;
     if (dim <= 4096) return 2;
     if (dim <= 16384) return 4;
     if (dim <= 65536) return 8;
@@ -524,11 +526,13 @@ bool nphip_sampler::setup() {
     const size_t ld = (size_t)args.ld;
     // register-resident specialisation: one wave per chain, state in VGPRs (dim <= 2048)
     args.reg_nv = 0;
-    if (fused && W == 1 && !launch.no_register_kernel) {
+    // (not with store_divergences: the divergence record needs the pre-step state, which only the
+    //  memory-resident kernel keeps)
+    if (fused && W == 1 && !launch.no_register_kernel && !set.store_divergences) {
         const int nchunks = (int)(args.ld / 128);
         int nv = 1;
         while (nv < nchunks) nv *= 2;
-        if (nv <= 16) args.reg_nv = nv;
+        if (nv <= 8) args.reg_nv = nv;
     }
 
     if (!dalloc(&args.ctl, n)) return false;
@@ -542,11 +546,11 @@ bool nphip_sampler::setup() {
         if (!dalloc(&mu, ld) || !dalloc(&a, ld) || !dalloc(&b, ld)) return false;
         HIP_TRY(hipMemcpyAsync(mu, model.mu.data(), dim * 8, hipMemcpyHostToDevice, stream));
         HIP_TRY(hipMemcpyAsync(a, model.a.data(), dim * 8, hipMemcpyHostToDevice, stream));
-        {   // b[dim-1 ..] = -0.0: lets the register kernel add boundary terms unconditionally (t + (-0.0) == t)
-            std::vector<double> bpad(ld, -0.0);
-            std::copy(model.b.begin(), model.b.begin() + (dim > 0 ? dim - 1 : 0), bpad.begin());
-            HIP_TRY(hipMemcpy(b, bpad.data(), ld * 8, hipMemcpyHostToDevice));
-        }
+        // b[dim-1 ..] = -0.0: lets the register kernel add boundary terms unconditionally (t + (-0.0) == t).
+        // Same stream as the zero-fill of the buffer (the engine stream does not synchronise with the null stream).
+        bpad.assign(ld, -0.0);
+        std::copy(model.b.begin(), model.b.begin() + (dim > 0 ? dim - 1 : 0), bpad.begin());
+        HIP_TRY(hipMemcpyAsync(b, bpad.data(), ld * 8, hipMemcpyHostToDevice, stream));
         args.m_mu = mu; args.m_a = a; args.m_b = b;
     } else {
         if (launch.staging_q && launch.staging_grad && launch.staging_logp) {

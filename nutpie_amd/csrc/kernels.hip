@@ -143,7 +143,8 @@ struct Regs {
     double2 q[NV], g[NV], p[NV], r[NV], s[NV];
     int64_t reg_q = -1, reg_p = -1;
     bool sig_ok = false;
-    __device__ __forceinline__ void invalidate() { reg_q = -1; reg_p = -1; sig_ok = false; }
+    bool dirty_qg = false, dirty_pr = false;  // the registers hold the only copy (stores were elided)
+    __device__ __forceinline__ void invalidate() { reg_q = -1; reg_p = -1; sig_ok = false; dirty_qg = false; dirty_pr = false; }
 };
 
 // NV > 0 selects the register-resident specialisation (requires FUSED and W == 1, dim <= 128 * NV):
@@ -155,7 +156,8 @@ struct Machine {
     // kernel arguments, read through the constant address space: s_load into SGPRs (uniform), never flat
     const NPHIP_CONST Args& A;
     LdsCtl c;        // this wave's private LDS copy
-    LdsDouble red;   // LDS reduction scratch [2*W]
+    LdsDouble red;   // LDS reduction scratch [8*W]
+    LdsDouble par;   // NV > 0: LDS copy of the fused model: mu[ld], a[ld], then b shifted by one (par_b[i] = b_{i-1})
     int64_t chain;   // local chain index
     uint32_t gchain; // global chain id (RNG key)
     int lane, wave;
@@ -167,8 +169,8 @@ struct Machine {
     int64_t T;
     using RegsT = Regs<NVX>;
 
-    __device__ __forceinline__ Machine(const NPHIP_CONST Args& a, LdsCtl ctl, LdsDouble r, int64_t ch)
-        : A(a), c(ctl), red(r), chain(ch), gchain((uint32_t)(a.chain_offset + ch)) {
+    __device__ __forceinline__ Machine(const NPHIP_CONST Args& a, LdsCtl ctl, LdsDouble r, int64_t ch, LdsDouble par_ = nullptr)
+        : A(a), c(ctl), red(r), par(par_), chain(ch), gchain((uint32_t)(a.chain_offset + ch)) {
         lane = threadIdx.x & 63;
         wave = (W == 1) ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
         D = a.dim; ld = a.ld; nch = ld / NPHIP_CHUNK;
@@ -389,120 +391,20 @@ struct Machine {
     // ---- register-resident leapfrog (NV > 0): one fused pass, no loads when continuing from the cursor ----
     __device__ __forceinline__ int64_t ridx(int k) const { return (int64_t)k * NPHIP_CHUNK + 2 * lane; }
 
-    // FUSE0: also accumulate the level-0 U-turn criterion between the source leaf and the new leaf — its
-    // operands are exactly the registers before/after the update ((rho' - rho) + p works for both directions,
-    // SURVEY A.4 modes 0 and 2), so that check costs no loads and shares the reduction.  turn0 = its result.
-    template <bool FUSE0>
-    __device__ __forceinline__ double leapfrog_reg(RegsT& X, double& lp, int64_t& code, int64_t idx_new, bool& turn0) {
-        const int64_t srcq = c->lf_srcq, srcp = c->lf_srcp, newq = c->lf_newq, newp = c->lf_newp;
-        const int nk = (int)nch;
-        if (X.reg_q != srcq) {
-            const double *q = Q(srcq), *g = G(srcq);
-#pragma unroll
-            for (int k = 0; k < NVX; ++k) if (k < nk) { X.q[k] = ld2(q, ridx(k)); X.g[k] = ld2(g, ridx(k)); }
-        }
-        if (X.reg_p != srcp) {
-            const double *p = P(srcp), *r = R(srcp);
-#pragma unroll
-            for (int k = 0; k < NVX; ++k) if (k < nk) { X.p[k] = ld2(p, ridx(k)); X.r[k] = ld2(r, ridx(k)); }
-        }
-        if (!X.sig_ok) {
-#pragma unroll
-            for (int k = 0; k < NVX; ++k) if (k < nk) X.s[k] = ld2(sig2, ridx(k));
-            X.sig_ok = true;
-        }
-        const double eps = (double)c->lf_sign * c->step_size;
-        const double h = 0.5 * eps;
-        if (idx_new == -1) {  // first backward step: rho' = p'  (-0.0 + p == p exactly, also for signed zeros)
-#pragma unroll
-            for (int k = 0; k < NVX; ++k) if (k < nk) { X.r[k].x = -0.0; X.r[k].y = -0.0; }
-        }
-        double2 z[NVX], pold[NVX];
-        // first half kick + drift, z = q' - mu
-#pragma unroll
-        for (int k = 0; k < NVX; ++k) if (k < nk) {
-            double2 mu = ld2(A.m_mu, ridx(k));
-            if (FUSE0) pold[k] = X.p[k];
-            X.p[k].x = fma(h, X.g[k].x, X.p[k].x);
-            X.p[k].y = fma(h, X.g[k].y, X.p[k].y);
-            X.q[k].x = fma(eps, X.s[k].x * X.p[k].x, X.q[k].x);
-            X.q[k].y = fma(eps, X.s[k].y * X.p[k].y, X.q[k].y);
-            z[k].x = X.q[k].x - mu.x;
-            z[k].y = X.q[k].y - mu.y;
-        }
-        // tridiagonal gradient: neighbours come from adjacent lanes (DPP wave shifts); chunk borders via readlane.
-        // Boundary terms need no branches: the host pads b with -0.0 (and b_{-1} := -0.0), and t + (-0.0) == t.
-        double2 accK = {0.0, 0.0}, accL = {0.0, 0.0}, accE = {0.0, 0.0}, accS = {0.0, 0.0};
-        double *qn = Q(newq), *gn = G(newq), *pn = P(newp), *rn = R(newp);
-#pragma unroll
-        for (int k = 0; k < NVX; ++k) if (k < nk) {
-            const int64_t i = ridx(k);
-            const double2 a = ld2(A.m_a, i), b = ld2(A.m_b, i);
-            double edge_bl = -0.0, edge_zl = 0.0, edge_zr = 0.0;
-            if (k > 0) {
-                edge_zl = readlane_f64(z[k - 1].y, 63);
-                edge_bl = readlane_f64(ld2(A.m_b, ridx(k - 1)).y, 63);
-            }
-            if (k + 1 < NVX) { if (k + 1 < nk) edge_zr = readlane_f64(z[k + 1].x, 0); }
-            const double bl = wave_shr1(b.y, edge_bl);      // b_{i-1}
-            const double zl = wave_shr1(z[k].y, edge_zl);   // z_{i-1}
-            const double zr = wave_shl1(z[k].x, edge_zr);   // z_{i+2}
-            double tx = a.x * z[k].x;
-            tx = fma(bl, zl, tx);
-            tx = fma(b.x, z[k].y, tx);
-            double ty = a.y * z[k].y;
-            ty = fma(b.x, z[k].x, ty);
-            ty = fma(b.y, zr, ty);
-            double2 gg;
-            gg.x = -tx;
-            gg.y = -ty;
-            accL.x = fma(z[k].x, gg.x, accL.x);
-            accL.y = fma(z[k].y, gg.y, accL.y);
-            X.g[k] = gg;
-            // second half kick, kinetic energy, running momentum sum
-            const double2 rold = X.r[k];
-            X.p[k].x = fma(h, gg.x, X.p[k].x);
-            X.p[k].y = fma(h, gg.y, X.p[k].y);
-            const double vx = X.s[k].x * X.p[k].x, vy = X.s[k].y * X.p[k].y;
-            accK.x = fma(X.p[k].x, vx, accK.x);
-            accK.y = fma(X.p[k].y, vy, accK.y);
-            X.r[k].x = rold.x + X.p[k].x;
-            X.r[k].y = rold.y + X.p[k].y;
-            if (FUSE0) {
-                const double tx0 = (X.r[k].x - rold.x) + pold[k].x, ty0 = (X.r[k].y - rold.y) + pold[k].y;
-                accE.x = fma(tx0, vx, accE.x);
-                accE.y = fma(ty0, vy, accE.y);
-                accS.x = fma(tx0, X.s[k].x * pold[k].x, accS.x);
-                accS.y = fma(ty0, X.s[k].y * pold[k].y, accS.y);
-            }
-#ifndef NPHIP_EXP_NOQG
-            st2(qn, i, X.q[k]); st2(gn, i, X.g[k]);
-#endif
-#ifndef NPHIP_EXP_NOPR
-            st2(pn, i, X.p[k]); st2(rn, i, X.r[k]);
-#endif
-        }
-        X.reg_q = newq;
-        X.reg_p = newp;
-        code = 0;
-        if (FUSE0) {
-            double v[4] = {accK.x + accK.y, accL.x + accL.y, accE.x + accE.y, accS.x + accS.y};
-            reduceN<W, 4>(v, red);
-            lp = 0.5 * v[1];
-            turn0 = (v[2] < 0.0) || (v[3] < 0.0);
-            return 0.5 * v[0];
-        }
-        double v[2] = {accK.x + accK.y, accL.x + accL.y};
-        reduceN<W, 2>(v, red);
-        lp = 0.5 * v[1];
-        turn0 = false;
-        return 0.5 * v[0];
-    }
-
-    // ---- fused U-turn checks (NV > 0).  One merge needs up to three criteria that share operands:
-    //   (A, TL), (B, TL), (A, TF)   with TL = the leaf just integrated (register mirror),
-    // so all six dot products are accumulated in ONE pass and reduced together.  Each dot keeps the contract
-    // order (per-lane fma chain over k, then wave_sum), hence the booleans equal three separate passes.
+    // ======================================================================================
+    // Register-resident leaf (NV > 0): leapfrog + merge cascade + stores of ONE tree leaf.
+    //
+    // Ordering is chosen for gfx9's single vmcnt counter (loads and stores share it):
+    //   1. prefetch the level-1 U-turn operands (only when this leaf will reach level 1),
+    //   2. leapfrog math — model parameters come from LDS, neighbours from DPP wave shifts; the level-0
+    //      criterion is accumulated in the same pass from the before/after registers,
+    //   3. merge cascade (further operands on demand; T.first of level k is A.first of level k-1 and is reused),
+    //   4. stores of the new state LAST, and only of what can be read back later:
+    //        (q, grad): when the leaf is referenced as a draw candidate or becomes a trajectory end,
+    //        (p, rho) : unless leaf % 4 == 3 (such a leaf is only ever "T.first of level 1" = the source
+    //                   registers of the next leapfrog).
+    //      Elided parts are marked dirty and flushed before any out-of-line path / at kernel exit.
+    // ======================================================================================
     struct Pair { int mode; bool first_is_start; };
     __device__ __forceinline__ Pair pair_of(int64_t i1, int64_t i2) const {
         Pair pr;
@@ -511,7 +413,7 @@ struct Machine {
         pr.mode = (a >= 0 && b >= 0) ? 0 : ((b >= 0 && a < 0) ? 1 : 2);
         return pr;
     }
-    // accumulate span . v_end (acc_e) and span . v_start (acc_s) for the pair (1, 2)
+    // accumulate span . v_end (acc_e) and span . v_start (acc_s) for the pair (1, 2)   
     __device__ __forceinline__ void pair_acc(const Pair pr, double p1, double r1, double p2, double r2, double s2v, double& acc_e, double& acc_s) const {
         const double ps = pr.first_is_start ? p1 : p2, rs = pr.first_is_start ? r1 : r2;
         const double pe = pr.first_is_start ? p2 : p1, re = pr.first_is_start ? r2 : r1;
@@ -522,55 +424,279 @@ struct Machine {
         acc_e = fma(t, s2v * pe, acc_e);
         acc_s = fma(t, s2v * ps, acc_s);
     }
-
-    // n_checks == 1: (A, TL) only.  n_checks == 3: (A, TL) || (B, TL) || (A, TF).  Operands A, B, TF come
-    // from their P-slots in global memory (L2 / Infinity-Cache resident: written a few leaves ago).
-    __device__ __forceinline__ bool check_fused(RegsT& X, int n_checks, int64_t sA, int64_t iA, int64_t sB, int64_t iB,
-                                                int64_t sTF, int64_t iTF, int64_t iTL) {
+    __device__ __forceinline__ void load_slot(int64_t slot, double2 (&p)[NVX], double2 (&r)[NVX]) const {
+        const double *gp = P(slot), *gr = R(slot);
         const int nk = (int)nch;
-        double2 pa[NVX], ra[NVX], pb[NVX], rb[NVX], pf[NVX], rf[NVX];
-        const double *gpa = P(sA), *gra = R(sA);
 #pragma unroll
-        for (int k = 0; k < NVX; ++k) if (k < nk) { pa[k] = ld2(gpa, ridx(k)); ra[k] = ld2(gra, ridx(k)); }
-        if (n_checks == 3) {
-            const double *gpb = P(sB), *grb = R(sB), *gpf = P(sTF), *grf = R(sTF);
-#pragma unroll
-            for (int k = 0; k < NVX; ++k) if (k < nk) {
-                pb[k] = ld2(gpb, ridx(k)); rb[k] = ld2(grb, ridx(k));
-                pf[k] = ld2(gpf, ridx(k)); rf[k] = ld2(grf, ridx(k));
-            }
-        }
+        for (int k = 0; k < NVX; ++k) if (k < nk) { p[k] = ld2(gp, ridx(k)); r[k] = ld2(gr, ridx(k)); }
+    }
+    __device__ __forceinline__ int64_t first_slot_of(int64_t leaf, int64_t d) const {
+        return (leaf == 1) ? slot_first((int)d) : slot_first(__builtin_ctzll((unsigned long long)(leaf - 1)));
+    }
+    // (A, TL) || (B, TL) || (A, TF), TL = register mirror; all six dots in one pass, one reduction
+    __device__ __forceinline__ bool check3(const RegsT& X, const double2 (&ap)[NVX], const double2 (&ar)[NVX], const double2 (&bp)[NVX],
+                                           const double2 (&br)[NVX], const double2 (&fp)[NVX], const double2 (&fr)[NVX],
+                                           int64_t iA, int64_t iB, int64_t iTF, int64_t iTL) {
+        const int nk = (int)nch;
         const Pair p1 = pair_of(iA, iTL), p2 = pair_of(iB, iTL), p3 = pair_of(iA, iTF);
         double2 acc[6];
 #pragma unroll
         for (int n = 0; n < 6; ++n) { acc[n].x = 0.0; acc[n].y = 0.0; }
 #pragma unroll
         for (int k = 0; k < NVX; ++k) if (k < nk) {
-            pair_acc(p1, pa[k].x, ra[k].x, X.p[k].x, X.r[k].x, X.s[k].x, acc[0].x, acc[1].x);
-            pair_acc(p1, pa[k].y, ra[k].y, X.p[k].y, X.r[k].y, X.s[k].y, acc[0].y, acc[1].y);
-            if (n_checks == 3) {
-                pair_acc(p2, pb[k].x, rb[k].x, X.p[k].x, X.r[k].x, X.s[k].x, acc[2].x, acc[3].x);
-                pair_acc(p2, pb[k].y, rb[k].y, X.p[k].y, X.r[k].y, X.s[k].y, acc[2].y, acc[3].y);
-                pair_acc(p3, pa[k].x, ra[k].x, pf[k].x, rf[k].x, X.s[k].x, acc[4].x, acc[5].x);
-                pair_acc(p3, pa[k].y, ra[k].y, pf[k].y, rf[k].y, X.s[k].y, acc[4].y, acc[5].y);
-            }
+            pair_acc(p1, ap[k].x, ar[k].x, X.p[k].x, X.r[k].x, X.s[k].x, acc[0].x, acc[1].x);
+            pair_acc(p1, ap[k].y, ar[k].y, X.p[k].y, X.r[k].y, X.s[k].y, acc[0].y, acc[1].y);
+            pair_acc(p2, bp[k].x, br[k].x, X.p[k].x, X.r[k].x, X.s[k].x, acc[2].x, acc[3].x);
+            pair_acc(p2, bp[k].y, br[k].y, X.p[k].y, X.r[k].y, X.s[k].y, acc[2].y, acc[3].y);
+            pair_acc(p3, ap[k].x, ar[k].x, fp[k].x, fr[k].x, X.s[k].x, acc[4].x, acc[5].x);
+            pair_acc(p3, ap[k].y, ar[k].y, fp[k].y, fr[k].y, X.s[k].y, acc[4].y, acc[5].y);
         }
-        if (n_checks == 3) {
-            double v[6];
+        double v[6];
 #pragma unroll
-            for (int n = 0; n < 6; ++n) v[n] = acc[n].x + acc[n].y;
-            reduceN<W, 6>(v, red);
-            return (v[0] < 0.0) || (v[1] < 0.0) || (v[2] < 0.0) || (v[3] < 0.0) || (v[4] < 0.0) || (v[5] < 0.0);
+        for (int n = 0; n < 6; ++n) v[n] = acc[n].x + acc[n].y;
+        reduceN<W, 6>(v, red);
+        return (v[0] < 0.0) || (v[1] < 0.0) || (v[2] < 0.0) || (v[3] < 0.0) || (v[4] < 0.0) || (v[5] < 0.0);
+    }
+    // (A, TL) || (A, TF): four dots in one pass
+    __device__ __forceinline__ bool check_a(const RegsT& X, const double2 (&ap)[NVX], const double2 (&ar)[NVX], const double2 (&fp)[NVX],
+                                            const double2 (&fr)[NVX], int64_t iA, int64_t iTF, int64_t iTL) {
+        const int nk = (int)nch;
+        const Pair p1 = pair_of(iA, iTL), p3 = pair_of(iA, iTF);
+        double2 acc[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) { acc[n].x = 0.0; acc[n].y = 0.0; }
+#pragma unroll
+        for (int k = 0; k < NVX; ++k) if (k < nk) {
+            pair_acc(p1, ap[k].x, ar[k].x, X.p[k].x, X.r[k].x, X.s[k].x, acc[0].x, acc[1].x);
+            pair_acc(p1, ap[k].y, ar[k].y, X.p[k].y, X.r[k].y, X.s[k].y, acc[0].y, acc[1].y);
+            pair_acc(p3, ap[k].x, ar[k].x, fp[k].x, fr[k].x, X.s[k].x, acc[2].x, acc[3].x);
+            pair_acc(p3, ap[k].y, ar[k].y, fp[k].y, fr[k].y, X.s[k].y, acc[2].y, acc[3].y);
         }
-        double v[2] = {acc[0].x + acc[0].y, acc[1].x + acc[1].y};
+        double v[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) v[n] = acc[n].x + acc[n].y;
+        reduceN<W, 4>(v, red);
+        return (v[0] < 0.0) || (v[1] < 0.0) || (v[2] < 0.0) || (v[3] < 0.0);
+    }
+    __device__ __forceinline__ bool check1(const RegsT& X, const double2 (&ap)[NVX], const double2 (&ar)[NVX], int64_t iA, int64_t iTL) {
+        const int nk = (int)nch;
+        const Pair p1 = pair_of(iA, iTL);
+        double2 e = {0.0, 0.0}, st = {0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < NVX; ++k) if (k < nk) {
+            pair_acc(p1, ap[k].x, ar[k].x, X.p[k].x, X.r[k].x, X.s[k].x, e.x, st.x);
+            pair_acc(p1, ap[k].y, ar[k].y, X.p[k].y, X.r[k].y, X.s[k].y, e.y, st.y);
+        }
+        double v[2] = {e.x + e.y, st.x + st.y};
         reduceN<W, 2>(v, red);
         return (v[0] < 0.0) || (v[1] < 0.0);
+    }
+    __device__ __forceinline__ void store_state(RegsT& X, bool qg, bool pr) {
+        const int nk = (int)nch;
+        if (qg) {
+            double *qn = Q(X.reg_q), *gn = G(X.reg_q);
+#pragma unroll
+            for (int k = 0; k < NVX; ++k) if (k < nk) { st2(qn, ridx(k), X.q[k]); st2(gn, ridx(k), X.g[k]); }
+            X.dirty_qg = false;
+        }
+        if (pr) {
+            double *pn = P(X.reg_p), *rn = R(X.reg_p);
+#pragma unroll
+            for (int k = 0; k < NVX; ++k) if (k < nk) { st2(pn, ridx(k), X.p[k]); st2(rn, ridx(k), X.r[k]); }
+            X.dirty_pr = false;
+        }
+    }
+    __device__ __forceinline__ void flush(RegsT& X) {
+        if (NV > 0 && (X.dirty_qg || X.dirty_pr)) store_state(X, X.dirty_qg, X.dirty_pr);
+    }
+
+    // returns true when an out-of-line (rare) path ran.  pf1: the level-1 operands are prefetched before the math.
+    __device__ __forceinline__ bool leaf_reg(RegsT& X, const bool pf1) {
+        const int nk = (int)nch;
+        const int64_t j = c->nleaf + 1, d = c->depth, dir = c->dir;
+        const int db = dir > 0 ? 1 : 0;
+        const int64_t near_idx = dir > 0 ? c->idx_right : c->idx_left;
+        const int64_t idx_new = c->idx_cur + dir;
+        const int64_t srcq = c->lf_srcq, srcp = c->lf_srcp, newq = c->lf_newq, newp = c->lf_newp;
+        const bool check = A.s.check_turning && (d + 1 > A.s.mindepth);
+        // ---- source state (already in registers unless the cursor moved or a rare path ran)
+        if (X.reg_q != srcq) {
+            const double *q = Q(srcq), *g = G(srcq);
+#pragma unroll
+            for (int k = 0; k < NVX; ++k) if (k < nk) { X.q[k] = ld2(q, ridx(k)); X.g[k] = ld2(g, ridx(k)); }
+        }
+        if (X.reg_p != srcp) load_slot(srcp, X.p, X.r);
+        if (!X.sig_ok) {
+#pragma unroll
+            for (int k = 0; k < NVX; ++k) if (k < nk) X.s[k] = ld2(sig2, ridx(k));
+            X.sig_ok = true;
+        }
+        // one operand buffer: it holds A.first, then A.last of the merge being checked (register budget at NV = 8)
+        double2 obp[NVX], obr[NVX];
+        // ---- 2. leapfrog (model parameters from LDS, neighbours by DPP, level-0 criterion in the same pass)
+        const double eps = (double)c->lf_sign * c->step_size;
+        const double h = 0.5 * eps;
+        if (idx_new == -1) {  // first backward step: rho' = p'  (-0.0 + p == p exactly, also for signed zeros)
+#pragma unroll
+            for (int k = 0; k < NVX; ++k) if (k < nk) { X.r[k].x = -0.0; X.r[k].y = -0.0; }
+        }
+        const NPHIP_LDS double* pmu = par;
+        const NPHIP_LDS double* pa = par + ld;
+        const NPHIP_LDS double* pb = par + 2 * ld;  // pb[i] = b_{i-1}
+        double2 z[NVX], pold[NVX], rold[NVX];
+#pragma unroll
+        for (int k = 0; k < NVX; ++k) if (k < nk) {
+            const double2 mu = *(const NPHIP_LDS double2*)(pmu + ridx(k));
+            pold[k] = X.p[k];
+            rold[k] = X.r[k];
+            X.p[k].x = fma(h, X.g[k].x, X.p[k].x);
+            X.p[k].y = fma(h, X.g[k].y, X.p[k].y);
+            X.q[k].x = fma(eps, X.s[k].x * X.p[k].x, X.q[k].x);
+            X.q[k].y = fma(eps, X.s[k].y * X.p[k].y, X.q[k].y);
+            z[k].x = X.q[k].x - mu.x;
+            z[k].y = X.q[k].y - mu.y;
+        }
+        double2 accK = {0.0, 0.0}, accL = {0.0, 0.0}, accE = {0.0, 0.0}, accS = {0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < NVX; ++k) if (k < nk) {
+            const int64_t i = ridx(k);
+            const double2 a = *(const NPHIP_LDS double2*)(pa + i);
+            const double2 b01 = *(const NPHIP_LDS double2*)(pb + i);  // b_{i-1}, b_i
+            const double b2 = pb[i + 2];                               // b_{i+1}
+            double edge_zl = 0.0, edge_zr = 0.0;
+            if (k > 0) edge_zl = readlane_f64(z[k - 1].y, 63);
+            if (k + 1 < NVX) { if (k + 1 < nk) edge_zr = readlane_f64(z[k + 1].x, 0); }
+            const double zl = wave_shr1(z[k].y, edge_zl);   // z_{i-1}
+            const double zr = wave_shl1(z[k].x, edge_zr);   // z_{i+2}
+            // boundary terms need no branches: b_{-1} and b_{D-1..} are stored as -0.0 and t + (-0.0) == t
+            double tx = a.x * z[k].x;
+            tx = fma(b01.x, zl, tx);
+            tx = fma(b01.y, z[k].y, tx);
+            double ty = a.y * z[k].y;
+            ty = fma(b01.y, z[k].x, ty);
+            ty = fma(b2, zr, ty);
+            double2 gg;
+            gg.x = -tx;
+            gg.y = -ty;
+            accL.x = fma(z[k].x, gg.x, accL.x);
+            accL.y = fma(z[k].y, gg.y, accL.y);
+            X.g[k] = gg;
+            X.p[k].x = fma(h, gg.x, X.p[k].x);
+            X.p[k].y = fma(h, gg.y, X.p[k].y);
+            const double vx = X.s[k].x * X.p[k].x, vy = X.s[k].y * X.p[k].y;
+            accK.x = fma(X.p[k].x, vx, accK.x);
+            accK.y = fma(X.p[k].y, vy, accK.y);
+            X.r[k].x = rold[k].x + X.p[k].x;
+            X.r[k].y = rold[k].y + X.p[k].y;
+            // level-0 criterion between source and new leaf: span = (rho' - rho) + p  (SURVEY A.4 modes 0 and 2)
+            const double tx0 = (X.r[k].x - rold[k].x) + pold[k].x, ty0 = (X.r[k].y - rold[k].y) + pold[k].y;
+            accE.x = fma(tx0, vx, accE.x);
+            accE.y = fma(ty0, vy, accE.y);
+            accS.x = fma(tx0, X.s[k].x * pold[k].x, accS.x);
+            accS.y = fma(ty0, X.s[k].y * pold[k].y, accS.y);
+        }
+        X.reg_q = newq;
+        X.reg_p = newp;
+        X.dirty_qg = true;
+        X.dirty_pr = true;
+        double v4[4] = {accK.x + accK.y, accL.x + accL.y, accE.x + accE.y, accS.x + accS.y};
+        reduceN<W, 4>(v4, red);
+        const double K = 0.5 * v4[0], lp = 0.5 * v4[1];
+        const bool turn0 = (v4[2] < 0.0) || (v4[3] < 0.0);
+        // ---- 3. NutsTree::extend / merge_into, unrolled (same decisions as cont_tree)
+        c->nleaf += 1;
+        c->n_steps += 1;
+        c->total_steps += 1;
+        const bool ok = isfinite(lp);
+        const double Unew = -lp, E = K + Unew, dE = E - c->H0;
+        const bool diverged = !ok || (dE > A.s.max_energy_error) || !isfinite(dE);
+        {
+            double a = 0.0, asym = 0.0;
+            if (!diverged) {
+                double e = nphip_exp(-dE);
+                a = e < 1.0 ? e : 1.0;
+                asym = 2.0 * a / (1.0 + e);
+            }
+            const double cnt = (double)c->n_steps;
+            c->acc_mean += (a - c->acc_mean) / cnt;
+            c->acc_sym_mean += (asym - c->acc_sym_mean) / cnt;
+        }
+        if (diverged) { X.dirty_qg = X.dirty_pr = false; rare_end_draw(A, c, red, chain, true, false, false, false); return true; }
+
+        double T_ls = -dE, T_U = Unew, T_E = E;
+        int64_t T_q = newq, T_idx = idx_new;
+        c->curq = newq; c->curp = newp; c->idx_cur = idx_new;
+        const int64_t far_slot = c->endp[1 - db], near_slot = c->endp[db];
+        const int64_t far_idx = dir > 0 ? c->idx_left : c->idx_right;
+        bool top_turn = false, reached_top = false;
+        int64_t k = 0;
+        // levels 0..d-1 merge completed sub-trees of the new doubling; level d (only when j == 2^d) merges it into
+        // the main tree.  One loop, so the three-criteria check is instantiated once.
+        for (;;) {
+            const bool top = (k == d);
+            if (!top && !(((j - 1) >> k) & 1)) break;
+            if (check) {
+                bool turn;
+                if (k == 0) {
+                    // top at level 0 (first doubling): both ends are the origin = the source registers, rho_0 == p_0
+                    turn = top ? check1(X, pold, pold, far_idx, idx_new) : turn0;
+                } else {
+                    const int64_t a = j - (2ll << k) + 1, al = j - (1ll << k);
+                    // T.first: at level 1 it is the source of this leapfrog, still held in (pold, rold); at level
+                    // k >= 2 it is A.first of level k-1, which pass 1 of that level moved into (pold, rold)
+                    const int64_t iA = top ? far_idx : near_idx + dir * a;
+                    const int64_t iB = top ? near_idx : near_idx + dir * al;
+                    const int64_t iTF = top ? near_idx + dir : near_idx + dir * (al + 1);
+                    load_slot(top ? far_slot : first_slot_of(a, d), obp, obr);
+                    turn = check_a(X, obp, obr, pold, rold, iA, iTF, idx_new);      // (A, TL) || (A, TF)
+#pragma unroll
+                    for (int q_ = 0; q_ < NVX; ++q_) { pold[q_] = obp[q_]; rold[q_] = obr[q_]; }
+                    if (!turn) {
+                        load_slot(top ? near_slot : slot_last(__builtin_ctzll((unsigned long long)al), A.cap), obp, obr);
+                        turn = check1(X, obp, obr, iB, idx_new);                    // (B, TL)
+                    }
+                }
+                if (top) top_turn = turn;
+                else if (turn) { X.dirty_qg = X.dirty_pr = false; rare_end_draw(A, c, red, chain, false, false, false, false); return true; }
+            }
+            if (top) { reached_top = true; break; }
+            const double ls = nphip_logaddexp(c->sub_ls[k], T_ls);
+            bool take = T_ls >= ls;
+            if (!take) take = merge_uniform(j, d, k) < nphip_exp(T_ls - ls);
+            if (!take) { T_q = c->sub_q[k]; T_U = c->sub_U[k]; T_E = c->sub_E[k]; T_idx = c->sub_idx[k]; }
+            T_ls = ls;
+            ++k;
+        }
+        if (!reached_top) {
+            c->sub_ls[k] = T_ls; c->sub_q[k] = T_q; c->sub_U[k] = T_U; c->sub_E[k] = T_E; c->sub_idx[k] = T_idx;
+            // ---- 4. stores: only what can be read back
+            store_state(X, T_q == newq, (j & 3) != 3);
+            issue_leaf();
+            return false;
+        }
+        // the new sub-tree of depth d is complete (j == 2^d): merge into the main tree
+        c->endq[db] = newq;
+        c->endp[db] = newp;
+        c->endpar[db] ^= 1;
+        if (dir > 0) c->idx_right = idx_new; else c->idx_left = idx_new;
+        {
+            const double ls = nphip_logaddexp(c->ls_main, T_ls);
+            bool take = T_ls >= c->ls_main;
+            if (!take) take = merge_uniform(j, d, d) < nphip_exp(T_ls - c->ls_main);
+            if (take) { c->cand_q = T_q; c->cand_U = T_U; c->cand_E = T_E; c->cand_idx = T_idx; }
+            c->ls_main = ls;
+            c->depth = d + 1;
+        }
+        store_state(X, true, true);  // a new trajectory end is always written back
+        if (top_turn) { rare_end_draw(A, c, red, chain, false, false, false, false); return true; }
+        if (c->depth >= A.s.maxdepth) { rare_end_draw(A, c, red, chain, false, true, false, false); return true; }
+        start_doubling();
+        return false;
     }
 
     // memory-resident equivalent (NV == 0): the same criteria, one pass each
     __device__ __forceinline__ bool check_merge(RegsT& X, int n_checks, int64_t sA, int64_t iA, int64_t sB, int64_t iB,
                                                 int64_t sTF, int64_t iTF, int64_t sTL, int64_t iTL) {
-        if (NV > 0 && X.sig_ok && X.reg_p == sTL) return check_fused(X, n_checks, sA, iA, sB, iB, sTF, iTF, iTL);
         bool turn = turning(sA, iA, sTL, iTL);
         if (n_checks == 3) {
             if (!turn) turn = turning(sB, iB, sTL, iTL);
@@ -1011,30 +1137,30 @@ struct Machine {
             const int64_t t0 = (int64_t)__builtin_readcyclecounter();
 #endif
             if (ph == PH_TREE) {
-                double lp = 0.0;
-                int64_t code = 0;
-                const int64_t idx_new = c->idx_cur + c->dir;
-                // the level-0 merge (even leaf, check enabled) is fused into the register-resident leapfrog
-                bool turn0 = false;
-                const bool fuse0 = (NV > 0) && (((c->nleaf + 1) & 1) == 0) && A.s.check_turning && (c->depth + 1 > A.s.mindepth);
-                double K;
-                if (NV > 0) K = fuse0 ? leapfrog_reg<true>(X, lp, code, idx_new, turn0) : leapfrog_reg<false>(X, lp, code, idx_new, turn0);
-                else K = lf2(lp, code, idx_new);
-#ifdef NPHIP_PROFILE
-                const int64_t t1 = (int64_t)__builtin_readcyclecounter();
-#endif
-                const bool rare = cont_tree(X, K, lp, code, fuse0, turn0);
+                bool rare;
+                if (NV > 0) {
+                    const int64_t j = c->nleaf + 1;
+                    const bool chk = A.s.check_turning && (c->depth + 1 > A.s.mindepth);
+                    const bool pf1 = chk && ((j & 3) == 0) && c->depth >= 2;
+                    rare = leaf_reg(X, pf1);
+                } else {
+                    double lp = 0.0;
+                    int64_t code = 0;
+                    const double K = lf2(lp, code, c->idx_cur + c->dir);
+                    rare = cont_tree(X, K, lp, code, false, false);
+                }
                 if (rare) X.invalidate();
 #ifdef NPHIP_PROFILE
                 const int64_t t2 = (int64_t)__builtin_readcyclecounter();
-                c->prof[0] += t1 - t0; c->prof[3] += 1;
-                if (rare) { c->prof[2] += t2 - t1; c->prof[5] += 1; } else { c->prof[1] += t2 - t1; c->prof[4] += 1; }
+                c->prof[3] += 1;
+                if (rare) { c->prof[2] += t2 - t0; c->prof[5] += 1; } else { c->prof[1] += t2 - t0; c->prof[4] += 1; }
 #endif
             } else {
                 rare_phase_fn(A, c, red, chain, ph);
                 X.invalidate();
             }
         }
+        flush(X);  // launch boundary: registers that hold the only copy of the cursor state go back to HBM
     }
 #undef NPHIP_FOR_CHUNKS
 };
@@ -1047,8 +1173,21 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k_advance(const Args* _
     constexpr int WAVES = (W == 1) ? 4 : W;
     __shared__ Ctl s_ctl[WAVES];
     __shared__ double s_red[8 * WAVES];
+    __shared__ __attribute__((aligned(16))) double s_par[NV > 0 ? 3 * 128 * NV + 8 : 2];
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int64_t chain = (W == 1) ? (int64_t)blockIdx.x * 4 + wib : (int64_t)blockIdx.x;
+    if (NV > 0) {
+        // stage the fused model in LDS once per workgroup: mu | a | b shifted by one with -0.0 sentinels
+        const int64_t ld = A.ld;
+        NPHIP_LDS double* sp = (NPHIP_LDS double*)s_par;
+        for (int64_t i = threadIdx.x; i < ld; i += blockDim.x) {
+            sp[i] = ld1(A.m_mu, i);
+            sp[ld + i] = ld1(A.m_a, i);
+            sp[2 * ld + i] = (i == 0) ? -0.0 : ld1(A.m_b, i - 1);
+        }
+        if (threadIdx.x < 8) sp[3 * ld + threadIdx.x] = -0.0;
+        __syncthreads();
+    }
     if (chain >= A.n_chains) return;
     LdsCtl c = (LdsCtl)&s_ctl[wib];
     {
@@ -1057,7 +1196,7 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k_advance(const Args* _
         for (int w = lane; w < kCtlWords; w += 64) dst[w] = src[w];
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    Machine<FUSED, W, NV> m(A, c, (LdsDouble)s_red, chain);
+    Machine<FUSED, W, NV> m(A, c, (LdsDouble)s_red, chain, (LdsDouble)s_par);
     m.run(max_evals, have_result != 0);
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     if (W == 1 || wib == 0) {
@@ -1078,7 +1217,6 @@ static hipError_t launch_w(const Args& a, const Args* d_args, int W, hipStream_t
             case 2: hipLaunchKernelGGL((k_advance<true, 1, 2>), g, b, 0, st, d_args, me, hr); break;
             case 4: hipLaunchKernelGGL((k_advance<true, 1, 4>), g, b, 0, st, d_args, me, hr); break;
             case 8: hipLaunchKernelGGL((k_advance<true, 1, 8>), g, b, 0, st, d_args, me, hr); break;
-            case 16: hipLaunchKernelGGL((k_advance<true, 1, 16>), g, b, 0, st, d_args, me, hr); break;
             default: return hipErrorInvalidValue;
         }
         return hipGetLastError();
