@@ -60,19 +60,35 @@ def total_leapfrogs(smp):
     return sum(p.total_num_steps for p in smp.progress())
 
 
+def effective_cores():
+    """CPU threads this process may really use: min(cpu_count, affinity mask, cgroup CPU quota)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(model, seed, target_seconds):
     """Oracle ("port") on the host cores: one chain per thread, min(chains, cores) threads — the reference's
     `cores` model (python/nutpie/sample.py:856-857, 1061-1070)."""
     import oracle
 
     oracle.build()
-    cores = os.cpu_count() or 1
+    cores = effective_cores()
     # calibration run, then a bounded sample sized for ~target_seconds of wall time
     s = oracle.default_settings(seed=seed, num_chains=cores, num_tune=60, num_draws=10, n_threads=cores)
     cal = oracle.sample_tridiag(s, model.diag, model.offdiag)
     rate = cal.stats["n_steps"].sum() / max(cal.seconds, 1e-6)
     tune, draws = 400, 100
-    per_chain = 500 * 90  # rough leapfrogs per chain for this sample
+    per_chain = 110_000  # leapfrogs per chain for tune 400 + draws 100 on this target (measured)
     chains = int(min(1024, max(cores, (rate * target_seconds) // per_chain // cores * cores)))
     s = oracle.default_settings(seed=seed, num_chains=chains, num_tune=tune, num_draws=draws, n_threads=cores)
     tr = oracle.sample_tridiag(s, model.diag, model.offdiag)
@@ -80,7 +96,8 @@ def cpu_baseline(model, seed, target_seconds):
     return {
         "value": n / tr.seconds, "unit": "leapfrog steps/s", "cores": cores, "kind": "port",
         "sample": f"CPU oracle (C++ restatement of nuts-rs diag-NUTS, oracle/), {chains} of the workload's chains, "
-                  f"tune {tune} + draws {draws}, one chain per thread on {cores} threads: {n} leapfrogs in {tr.seconds:.2f} s",
+                  f"tune {tune} + draws {draws}, one chain per thread on {cores} threads (host: {os.cpu_count()} logical CPUs, "
+                  f"cgroup/affinity limit {cores}): {n} leapfrogs in {tr.seconds:.2f} s",
     }
 
 
