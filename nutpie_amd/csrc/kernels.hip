@@ -144,7 +144,10 @@ struct Regs {
     int64_t reg_q = -1, reg_p = -1;
     bool sig_ok = false;
     bool dirty_qg = false, dirty_pr = false;  // the registers hold the only copy (stores were elided)
-    __device__ __forceinline__ void invalidate() { reg_q = -1; reg_p = -1; sig_ok = false; dirty_qg = false; dirty_pr = false; }
+    int64_t ring_leaf0 = -1, ring_leaf1 = -1;  // leaf numbers held by the LDS ring (slot 0: leaf%4==1, slot 1: leaf%4==2)
+    __device__ __forceinline__ void invalidate() {
+        reg_q = -1; reg_p = -1; sig_ok = false; dirty_qg = false; dirty_pr = false; ring_leaf0 = -1; ring_leaf1 = -1;
+    }
 };
 
 // NV > 0 selects the register-resident specialisation (requires FUSED and W == 1, dim <= 128 * NV):
@@ -158,6 +161,7 @@ struct Machine {
     LdsCtl c;        // this wave's private LDS copy
     LdsDouble red;   // LDS reduction scratch [8*W]
     LdsDouble par;   // NV > 0: LDS copy of the fused model: mu[ld], a[ld], then b shifted by one (par_b[i] = b_{i-1})
+    LdsDouble ring;  // NV > 0: this wave's LDS ring of two (p, rho) summaries: [slot][p|rho][NV*64 double2]
     int64_t chain;   // local chain index
     uint32_t gchain; // global chain id (RNG key)
     int lane, wave;
@@ -169,8 +173,8 @@ struct Machine {
     int64_t T;
     using RegsT = Regs<NVX>;
 
-    __device__ __forceinline__ Machine(const NPHIP_CONST Args& a, LdsCtl ctl, LdsDouble r, int64_t ch, LdsDouble par_ = nullptr)
-        : A(a), c(ctl), red(r), par(par_), chain(ch), gchain((uint32_t)(a.chain_offset + ch)) {
+    __device__ __forceinline__ Machine(const NPHIP_CONST Args& a, LdsCtl ctl, LdsDouble r, int64_t ch, LdsDouble par_ = nullptr, LdsDouble ring_ = nullptr)
+        : A(a), c(ctl), red(r), par(par_), ring(ring_), chain(ch), gchain((uint32_t)(a.chain_offset + ch)) {
         lane = threadIdx.x & 63;
         wave = (W == 1) ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
         D = a.dim; ld = a.ld; nch = ld / NPHIP_CHUNK;
@@ -433,30 +437,6 @@ struct Machine {
     __device__ __forceinline__ int64_t first_slot_of(int64_t leaf, int64_t d) const {
         return (leaf == 1) ? slot_first((int)d) : slot_first(__builtin_ctzll((unsigned long long)(leaf - 1)));
     }
-    // (A, TL) || (B, TL) || (A, TF), TL = register mirror; all six dots in one pass, one reduction
-    __device__ __forceinline__ bool check3(const RegsT& X, const double2 (&ap)[NVX], const double2 (&ar)[NVX], const double2 (&bp)[NVX],
-                                           const double2 (&br)[NVX], const double2 (&fp)[NVX], const double2 (&fr)[NVX],
-                                           int64_t iA, int64_t iB, int64_t iTF, int64_t iTL) {
-        const int nk = (int)nch;
-        const Pair p1 = pair_of(iA, iTL), p2 = pair_of(iB, iTL), p3 = pair_of(iA, iTF);
-        double2 acc[6];
-#pragma unroll
-        for (int n = 0; n < 6; ++n) { acc[n].x = 0.0; acc[n].y = 0.0; }
-#pragma unroll
-        for (int k = 0; k < NVX; ++k) if (k < nk) {
-            pair_acc(p1, ap[k].x, ar[k].x, X.p[k].x, X.r[k].x, X.s[k].x, acc[0].x, acc[1].x);
-            pair_acc(p1, ap[k].y, ar[k].y, X.p[k].y, X.r[k].y, X.s[k].y, acc[0].y, acc[1].y);
-            pair_acc(p2, bp[k].x, br[k].x, X.p[k].x, X.r[k].x, X.s[k].x, acc[2].x, acc[3].x);
-            pair_acc(p2, bp[k].y, br[k].y, X.p[k].y, X.r[k].y, X.s[k].y, acc[2].y, acc[3].y);
-            pair_acc(p3, ap[k].x, ar[k].x, fp[k].x, fr[k].x, X.s[k].x, acc[4].x, acc[5].x);
-            pair_acc(p3, ap[k].y, ar[k].y, fp[k].y, fr[k].y, X.s[k].y, acc[4].y, acc[5].y);
-        }
-        double v[6];
-#pragma unroll
-        for (int n = 0; n < 6; ++n) v[n] = acc[n].x + acc[n].y;
-        reduceN<W, 6>(v, red);
-        return (v[0] < 0.0) || (v[1] < 0.0) || (v[2] < 0.0) || (v[3] < 0.0) || (v[4] < 0.0) || (v[5] < 0.0);
-    }
     // (A, TL) || (A, TF): four dots in one pass
     __device__ __forceinline__ bool check_a(const RegsT& X, const double2 (&ap)[NVX], const double2 (&ar)[NVX], const double2 (&fp)[NVX],
                                             const double2 (&fr)[NVX], int64_t iA, int64_t iTF, int64_t iTL) {
@@ -491,12 +471,101 @@ struct Machine {
         reduceN<W, 2>(v, red);
         return (v[0] < 0.0) || (v[1] < 0.0);
     }
-    __device__ __forceinline__ void store_state(RegsT& X, bool qg, bool pr) {
+    // ---- criteria of a sub-tree merge INSIDE a doubling (all leaves on one side of the origin): for an
+    // (earlier, later) pair  span = (rho_late - rho_early) + p_early  in both directions (SURVEY A.4 modes 0/2).
+    __device__ __forceinline__ void span_acc(double pe_, double re_, double pl, double rl, double s2v, double& a1, double& a2) const {
+        const double t = (rl - re_) + pe_;
+        a1 = fma(t, s2v * pl, a1);
+        a2 = fma(t, s2v * pe_, a2);
+    }
+    // pass A: (A.first, TL) || (A.first, TF) with TF in registers
+    __device__ __forceinline__ bool sub_a(const RegsT& X, const double2 (&ap)[NVX], const double2 (&ar)[NVX], const double2 (&fp)[NVX], const double2 (&fr)[NVX]) {
         const int nk = (int)nch;
-        if (qg) {
-            double *qn = Q(X.reg_q), *gn = G(X.reg_q);
+        double2 acc[4];
 #pragma unroll
-            for (int k = 0; k < NVX; ++k) if (k < nk) { st2(qn, ridx(k), X.q[k]); st2(gn, ridx(k), X.g[k]); }
+        for (int n = 0; n < 4; ++n) { acc[n].x = 0.0; acc[n].y = 0.0; }
+#pragma unroll
+        for (int k = 0; k < NVX; ++k) if (k < nk) {
+            span_acc(ap[k].x, ar[k].x, X.p[k].x, X.r[k].x, X.s[k].x, acc[0].x, acc[1].x);
+            span_acc(ap[k].y, ar[k].y, X.p[k].y, X.r[k].y, X.s[k].y, acc[0].y, acc[1].y);
+            span_acc(ap[k].x, ar[k].x, fp[k].x, fr[k].x, X.s[k].x, acc[2].x, acc[3].x);
+            span_acc(ap[k].y, ar[k].y, fp[k].y, fr[k].y, X.s[k].y, acc[2].y, acc[3].y);
+        }
+        double v[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) v[n] = acc[n].x + acc[n].y;
+        reduceN<W, 4>(v, red);
+        return (v[0] < 0.0) || (v[1] < 0.0) || (v[2] < 0.0) || (v[3] < 0.0);
+    }
+    // pass B: (A.last, TL)
+    __device__ __forceinline__ bool sub_b(const RegsT& X, const double2 (&ap)[NVX], const double2 (&ar)[NVX]) {
+        const int nk = (int)nch;
+        double2 e = {0.0, 0.0}, st = {0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < NVX; ++k) if (k < nk) {
+            span_acc(ap[k].x, ar[k].x, X.p[k].x, X.r[k].x, X.s[k].x, e.x, st.x);
+            span_acc(ap[k].y, ar[k].y, X.p[k].y, X.r[k].y, X.s[k].y, e.y, st.y);
+        }
+        double v[2] = {e.x + e.y, st.x + st.y};
+        reduceN<W, 2>(v, red);
+        return (v[0] < 0.0) || (v[1] < 0.0);
+    }
+    // ---- LDS ring of recent (p, rho) summaries
+    __device__ __forceinline__ NPHIP_LDS double2* ring_ptr(int slot, int vec) const {
+        return (NPHIP_LDS double2*)(ring + (size_t)(slot * 2 + vec) * NVX * 128) + lane;
+    }
+    __device__ __forceinline__ void ring_write(int slot, const double2 (&p)[NVX], const double2 (&r)[NVX]) {
+        const int nk = (int)nch;
+        NPHIP_LDS double2 *lp = ring_ptr(slot, 0), *lr = ring_ptr(slot, 1);
+#pragma unroll
+        for (int k = 0; k < NVX; ++k) if (k < nk) { lp[k * 64] = p[k]; lr[k * 64] = r[k]; }
+    }
+    __device__ __forceinline__ void ring_read(int slot, double2 (&p)[NVX], double2 (&r)[NVX]) const {
+        const int nk = (int)nch;
+        const NPHIP_LDS double2 *lp = ring_ptr(slot, 0), *lr = ring_ptr(slot, 1);
+#pragma unroll
+        for (int k = 0; k < NVX; ++k) if (k < nk) { p[k] = lp[k * 64]; r[k] = lr[k * 64]; }
+    }
+    // fused-model gradient of the register position (used when a position is reloaded: only q is kept in HBM)
+    __device__ __forceinline__ void regs_grad(RegsT& X) {
+        const int nk = (int)nch;
+        const NPHIP_LDS double* pmu = par;
+        const NPHIP_LDS double* pa = par + ld;
+        const NPHIP_LDS double* pb = par + 2 * ld;
+        double2 z[NVX];
+#pragma unroll
+        for (int k = 0; k < NVX; ++k) if (k < nk) {
+            const double2 mu = *(const NPHIP_LDS double2*)(pmu + ridx(k));
+            z[k].x = X.q[k].x - mu.x;
+            z[k].y = X.q[k].y - mu.y;
+        }
+#pragma unroll
+        for (int k = 0; k < NVX; ++k) if (k < nk) {
+            const int64_t i = ridx(k);
+            const double2 a = *(const NPHIP_LDS double2*)(pa + i);
+            const double2 b01 = *(const NPHIP_LDS double2*)(pb + i);
+            const double b2 = pb[i + 2];
+            double edge_zl = 0.0, edge_zr = 0.0;
+            if (k > 0) edge_zl = readlane_f64(z[k - 1].y, 63);
+            if (k + 1 < NVX) { if (k + 1 < nk) edge_zr = readlane_f64(z[k + 1].x, 0); }
+            const double zl = wave_shr1(z[k].y, edge_zl), zr = wave_shl1(z[k].x, edge_zr);
+            double tx = a.x * z[k].x;
+            tx = fma(b01.x, zl, tx);
+            tx = fma(b01.y, z[k].y, tx);
+            double ty = a.y * z[k].y;
+            ty = fma(b01.y, z[k].x, ty);
+            ty = fma(b2, zr, ty);
+            X.g[k].x = -tx;
+            X.g[k].y = -ty;
+        }
+    }
+    // HBM copies: q only (the gradient is recomputed on reload), (p, rho) into the leaf's P-slot
+    __device__ __forceinline__ void store_state(RegsT& X, bool q_, bool pr) {
+        const int nk = (int)nch;
+        if (q_) {
+            double* qn = Q(X.reg_q);
+#pragma unroll
+            for (int k = 0; k < NVX; ++k) if (k < nk) st2(qn, ridx(k), X.q[k]);
             X.dirty_qg = false;
         }
         if (pr) {
@@ -506,12 +575,27 @@ struct Machine {
             X.dirty_pr = false;
         }
     }
+    // launch boundary: everything that only lives on chip goes back to its HBM slot
     __device__ __forceinline__ void flush(RegsT& X) {
-        if (NV > 0 && (X.dirty_qg || X.dirty_pr)) store_state(X, X.dirty_qg, X.dirty_pr);
+        if (NV == 0) return;
+        if (X.dirty_qg || X.dirty_pr) store_state(X, X.dirty_qg, X.dirty_pr);
+        if (c->phase == PH_TREE) {
+            const int64_t d = c->depth;
+            if (X.ring_leaf0 >= 0) flush_ring_slot(0, first_slot_of(X.ring_leaf0, d));
+            if (X.ring_leaf1 >= 0) flush_ring_slot(1, slot_last(__builtin_ctzll((unsigned long long)X.ring_leaf1), A.cap));
+        }
+    }
+    __device__ __forceinline__ void flush_ring_slot(int sl, int64_t slot) {
+        const int nk = (int)nch;
+        double2 tp[NVX], tr[NVX];
+        ring_read(sl, tp, tr);
+        double *pn = P(slot), *rn = R(slot);
+#pragma unroll
+        for (int k = 0; k < NVX; ++k) if (k < nk) { st2(pn, ridx(k), tp[k]); st2(rn, ridx(k), tr[k]); }
     }
 
-    // returns true when an out-of-line (rare) path ran.  pf1: the level-1 operands are prefetched before the math.
-    __device__ __forceinline__ bool leaf_reg(RegsT& X, const bool pf1) {
+    // returns true when an out-of-line (rare) path ran
+    __device__ __forceinline__ bool leaf_reg(RegsT& X) {
         const int nk = (int)nch;
         const int64_t j = c->nleaf + 1, d = c->depth, dir = c->dir;
         const int db = dir > 0 ? 1 : 0;
@@ -521,9 +605,10 @@ struct Machine {
         const bool check = A.s.check_turning && (d + 1 > A.s.mindepth);
         // ---- source state (already in registers unless the cursor moved or a rare path ran)
         if (X.reg_q != srcq) {
-            const double *q = Q(srcq), *g = G(srcq);
+            const double* q = Q(srcq);
 #pragma unroll
-            for (int k = 0; k < NVX; ++k) if (k < nk) { X.q[k] = ld2(q, ridx(k)); X.g[k] = ld2(g, ridx(k)); }
+            for (int k = 0; k < NVX; ++k) if (k < nk) X.q[k] = ld2(q, ridx(k));
+            regs_grad(X);
         }
         if (X.reg_p != srcp) load_slot(srcp, X.p, X.r);
         if (!X.sig_ok) {
@@ -531,9 +616,8 @@ struct Machine {
             for (int k = 0; k < NVX; ++k) if (k < nk) X.s[k] = ld2(sig2, ridx(k));
             X.sig_ok = true;
         }
-        // one operand buffer: it holds A.first, then A.last of the merge being checked (register budget at NV = 8)
-        double2 obp[NVX], obr[NVX];
-        // ---- 2. leapfrog (model parameters from LDS, neighbours by DPP, level-0 criterion in the same pass)
+        if (j == 1) { X.ring_leaf0 = -1; X.ring_leaf1 = -1; }
+        // ---- leapfrog (model parameters from LDS, neighbours by DPP, level-0 criterion in the same pass)
         const double eps = (double)c->lf_sign * c->step_size;
         const double h = 0.5 * eps;
         if (idx_new == -1) {  // first backward step: rho' = p'  (-0.0 + p == p exactly, also for signed zeros)
@@ -588,7 +672,7 @@ struct Machine {
             accK.y = fma(X.p[k].y, vy, accK.y);
             X.r[k].x = rold[k].x + X.p[k].x;
             X.r[k].y = rold[k].y + X.p[k].y;
-            // level-0 criterion between source and new leaf: span = (rho' - rho) + p  (SURVEY A.4 modes 0 and 2)
+            // level-0 criterion between source and new leaf: span = (rho' - rho) + p
             const double tx0 = (X.r[k].x - rold[k].x) + pold[k].x, ty0 = (X.r[k].y - rold[k].y) + pold[k].y;
             accE.x = fma(tx0, vx, accE.x);
             accE.y = fma(ty0, vy, accE.y);
@@ -599,11 +683,14 @@ struct Machine {
         X.reg_p = newp;
         X.dirty_qg = true;
         X.dirty_pr = true;
+        // the two most recent summaries a level-1 merge needs stay on chip
+        if ((j & 3) == 1) { ring_write(0, X.p, X.r); X.ring_leaf0 = j; }
+        else if ((j & 3) == 2) { ring_write(1, X.p, X.r); X.ring_leaf1 = j; }
         double v4[4] = {accK.x + accK.y, accL.x + accL.y, accE.x + accE.y, accS.x + accS.y};
         reduceN<W, 4>(v4, red);
         const double K = 0.5 * v4[0], lp = 0.5 * v4[1];
         const bool turn0 = (v4[2] < 0.0) || (v4[3] < 0.0);
-        // ---- 3. NutsTree::extend / merge_into, unrolled (same decisions as cont_tree)
+        // ---- NutsTree::extend / merge_into, unrolled (same decisions as cont_tree)
         c->nleaf += 1;
         c->n_steps += 1;
         c->total_steps += 1;
@@ -621,45 +708,42 @@ struct Machine {
             c->acc_mean += (a - c->acc_mean) / cnt;
             c->acc_sym_mean += (asym - c->acc_sym_mean) / cnt;
         }
-        if (diverged) { X.dirty_qg = X.dirty_pr = false; rare_end_draw(A, c, red, chain, true, false, false, false); return true; }
+        if (diverged) { X.dirty_qg = X.dirty_pr = false; rare_end_draw(A, c, red, chain, true, false, false, false, true); return true; }
 
         double T_ls = -dE, T_U = Unew, T_E = E;
         int64_t T_q = newq, T_idx = idx_new;
         c->curq = newq; c->curp = newp; c->idx_cur = idx_new;
-        const int64_t far_slot = c->endp[1 - db], near_slot = c->endp[db];
-        const int64_t far_idx = dir > 0 ? c->idx_left : c->idx_right;
-        bool top_turn = false, reached_top = false;
+        double2 obp[NVX], obr[NVX];  // one operand buffer (A.first, then A.last of the merge being checked)
         int64_t k = 0;
-        // levels 0..d-1 merge completed sub-trees of the new doubling; level d (only when j == 2^d) merges it into
-        // the main tree.  One loop, so the three-criteria check is instantiated once.
-        for (;;) {
-            const bool top = (k == d);
-            if (!top && !(((j - 1) >> k) & 1)) break;
+        while (k < d && (((j - 1) >> k) & 1)) {
             if (check) {
                 bool turn;
                 if (k == 0) {
-                    // top at level 0 (first doubling): both ends are the origin = the source registers, rho_0 == p_0
-                    turn = top ? check1(X, pold, pold, far_idx, idx_new) : turn0;
+                    turn = turn0;
                 } else {
                     const int64_t a = j - (2ll << k) + 1, al = j - (1ll << k);
-                    // T.first: at level 1 it is the source of this leapfrog, still held in (pold, rold); at level
-                    // k >= 2 it is A.first of level k-1, which pass 1 of that level moved into (pold, rold)
-                    const int64_t iA = top ? far_idx : near_idx + dir * a;
-                    const int64_t iB = top ? near_idx : near_idx + dir * al;
-                    const int64_t iTF = top ? near_idx + dir : near_idx + dir * (al + 1);
-                    load_slot(top ? far_slot : first_slot_of(a, d), obp, obr);
-                    turn = check_a(X, obp, obr, pold, rold, iA, iTF, idx_new);      // (A, TL) || (A, TF)
+                    // A.first
+                    if (k == 1 && X.ring_leaf0 == a) ring_read(0, obp, obr);
+                    else load_slot(first_slot_of(a, d), obp, obr);
+                    // T.first: level 1 -> source registers (pold, rold); level 2 -> leaf j-3 (ring slot 0);
+                    // level >= 3 -> A.first of the level below, moved into (pold, rold) there
+                    if (k == 2) {
+                        if (X.ring_leaf0 == al + 1) ring_read(0, pold, rold);
+                        else load_slot(first_slot_of(al + 1, d), pold, rold);
+                    }
+                    turn = sub_a(X, obp, obr, pold, rold);
+                    if (k >= 2) {
 #pragma unroll
-                    for (int q_ = 0; q_ < NVX; ++q_) { pold[q_] = obp[q_]; rold[q_] = obr[q_]; }
+                        for (int q_ = 0; q_ < NVX; ++q_) { pold[q_] = obp[q_]; rold[q_] = obr[q_]; }
+                    }
                     if (!turn) {
-                        load_slot(top ? near_slot : slot_last(__builtin_ctzll((unsigned long long)al), A.cap), obp, obr);
-                        turn = check1(X, obp, obr, iB, idx_new);                    // (B, TL)
+                        if (k == 1 && X.ring_leaf1 == al) ring_read(1, obp, obr);
+                        else load_slot(slot_last(__builtin_ctzll((unsigned long long)al), A.cap), obp, obr);
+                        turn = sub_b(X, obp, obr);
                     }
                 }
-                if (top) top_turn = turn;
-                else if (turn) { X.dirty_qg = X.dirty_pr = false; rare_end_draw(A, c, red, chain, false, false, false, false); return true; }
+                if (turn) { X.dirty_qg = X.dirty_pr = false; rare_end_draw(A, c, red, chain, false, false, false, false, true); return true; }
             }
-            if (top) { reached_top = true; break; }
             const double ls = nphip_logaddexp(c->sub_ls[k], T_ls);
             bool take = T_ls >= ls;
             if (!take) take = merge_uniform(j, d, k) < nphip_exp(T_ls - ls);
@@ -667,14 +751,35 @@ struct Machine {
             T_ls = ls;
             ++k;
         }
-        if (!reached_top) {
+        if (k < d) {
             c->sub_ls[k] = T_ls; c->sub_q[k] = T_q; c->sub_U[k] = T_U; c->sub_E[k] = T_E; c->sub_idx[k] = T_idx;
-            // ---- 4. stores: only what can be read back
-            store_state(X, T_q == newq, (j & 3) != 3);
+            // ---- stores, last: q when the leaf is referenced as a candidate; (p, rho) only for leaves a level >= 2
+            // merge reads back from HBM (leaf % 4 == 0: A.last, leaf % 8 == 1: A.first)
+            store_state(X, T_q == newq, ((j & 3) == 0) || ((j & 7) == 1));
             issue_leaf();
             return false;
         }
-        // the new sub-tree of depth d is complete (j == 2^d): merge into the main tree
+        // ---- the new sub-tree of depth d is complete (j == 2^d): merge into the main tree (general index modes)
+        bool turn = false;
+        if (check) {
+            const int64_t far_slot = c->endp[1 - db], far_idx = dir > 0 ? c->idx_left : c->idx_right;
+            if (d == 0) {
+                // both ends are the origin = the source of this leapfrog, and rho_0 == p_0
+                turn = check1(X, pold, pold, far_idx, idx_new);
+            } else {
+                // T.first = leaf 1: d == 1 -> source registers; d == 2 -> ring slot 0; d >= 3 -> already in (pold, rold)
+                if (d == 2) {
+                    if (X.ring_leaf0 == 1) ring_read(0, pold, rold);
+                    else load_slot(slot_first((int)d), pold, rold);
+                }
+                load_slot(far_slot, obp, obr);
+                turn = check_a(X, obp, obr, pold, rold, far_idx, near_idx + dir, idx_new);   // (far, TL) || (far, TF)
+                if (!turn) {
+                    load_slot(c->endp[db], obp, obr);
+                    turn = check1(X, obp, obr, near_idx, idx_new);                           // (near, TL)
+                }
+            }
+        }
         c->endq[db] = newq;
         c->endp[db] = newp;
         c->endpar[db] ^= 1;
@@ -688,8 +793,8 @@ struct Machine {
             c->depth = d + 1;
         }
         store_state(X, true, true);  // a new trajectory end is always written back
-        if (top_turn) { rare_end_draw(A, c, red, chain, false, false, false, false); return true; }
-        if (c->depth >= A.s.maxdepth) { rare_end_draw(A, c, red, chain, false, true, false, false); return true; }
+        if (turn) { rare_end_draw(A, c, red, chain, false, false, false, false, true); return true; }
+        if (c->depth >= A.s.maxdepth) { rare_end_draw(A, c, red, chain, false, true, false, false, true); return true; }
         start_doubling();
         return false;
     }
@@ -1024,8 +1129,14 @@ struct Machine {
     // The rare paths are compiled as separate functions that rebuild their own Machine from uniform
     // arguments: the hot Machine object never escapes, so its members stay in (S/V)GPRs.
     static __device__ __attribute__((noinline)) void rare_end_draw(const NPHIP_CONST Args& a, LdsCtl ctl, LdsDouble r, int64_t ch,
-                                                                  bool diverging, bool maxdepth, bool store_div, bool div_has_end) {
+                                                                  bool diverging, bool maxdepth, bool store_div, bool div_has_end,
+                                                                  bool regrad = false) {
         Machine m(a, ctl, r, ch);
+        if (regrad) {  // the register kernel keeps only q of candidate draws in HBM: rebuild the gradient of the new point
+            double lp_;
+            int64_t code_;
+            m.eval_position(ctl->cand_q, lp_, code_);
+        }
         if (store_div) m.store_divergence(div_has_end);
         m.end_draw(diverging, maxdepth);
     }
@@ -1139,10 +1250,7 @@ struct Machine {
             if (ph == PH_TREE) {
                 bool rare;
                 if (NV > 0) {
-                    const int64_t j = c->nleaf + 1;
-                    const bool chk = A.s.check_turning && (c->depth + 1 > A.s.mindepth);
-                    const bool pf1 = chk && ((j & 3) == 0) && c->depth >= 2;
-                    rare = leaf_reg(X, pf1);
+                    rare = leaf_reg(X);
                 } else {
                     double lp = 0.0;
                     int64_t code = 0;
@@ -1174,6 +1282,7 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k_advance(const Args* _
     __shared__ Ctl s_ctl[WAVES];
     __shared__ double s_red[8 * WAVES];
     __shared__ __attribute__((aligned(16))) double s_par[NV > 0 ? 3 * 128 * NV + 8 : 2];
+    __shared__ __attribute__((aligned(16))) double s_ring[NV > 0 ? 4 * 4 * 128 * NV : 2];  // per wave: 2 slots x (p, rho)
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int64_t chain = (W == 1) ? (int64_t)blockIdx.x * 4 + wib : (int64_t)blockIdx.x;
     if (NV > 0) {
@@ -1196,7 +1305,7 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k_advance(const Args* _
         for (int w = lane; w < kCtlWords; w += 64) dst[w] = src[w];
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    Machine<FUSED, W, NV> m(A, c, (LdsDouble)s_red, chain, (LdsDouble)s_par);
+    Machine<FUSED, W, NV> m(A, c, (LdsDouble)s_red, chain, (LdsDouble)s_par, (LdsDouble)s_ring + (size_t)wib * 4 * 128 * (NV > 0 ? NV : 1));
     m.run(max_evals, have_result != 0);
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     if (W == 1 || wib == 0) {
