@@ -104,6 +104,17 @@ def lib():
                     f"{_LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                     "(the nutpie-hip engine has no CPU fallback)"
                 )
+            # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64.so.7 / libhsa-runtime64.
+            # If torch is installed, let it load its runtime FIRST; our DT_NEEDED `libamdhip64.so.7` then resolves
+            # (by SONAME) to the copy already in the process instead of pulling /opt/rocm's as a second runtime —
+            # two HSA runtimes initialised in the wrong order leave the later one without devices.
+            from importlib.util import find_spec
+
+            if find_spec("torch") is not None:
+                try:
+                    import torch  # noqa: F401
+                except Exception:  # pragma: no cover - a broken torch must not break the engine
+                    pass
             L = C.CDLL(_LIB_PATH)
             L.nphip_last_error.restype = C.c_char_p
             L.nphip_version.restype = C.c_char_p
