@@ -164,6 +164,7 @@ class TorchFuncModel(CompiledModel):
     _coords: dict[str, Any]
     _shared_data: dict[str, Any]
     _init: Any = "uniform"              # "uniform" | "normal" | ndarray [chains, D]
+    _use_graph: bool = False            # capture logp+grad in a HIP graph (torch.cuda.CUDAGraph) and replay it per step
 
     @property
     def shapes(self):
@@ -199,17 +200,36 @@ class TorchFuncModel(CompiledModel):
         lp = torch.zeros((n,), dtype=torch.float64, device=dev)
         logp_fn = partial(self._make_logp_func(), **self._shared_data)
         streams = {}
+        graph = None
+        if self._use_graph:
+            # launch-bound models (dozens of small torch kernels per evaluation): capture once, replay per leapfrog
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    val, grad = logp_fn(q)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                val, grad = logp_fn(q)
+                lp.copy_(val.reshape(n).to(torch.float64))
+                g.copy_(grad.reshape(n, D).to(torch.float64))
+            q.zero_()
 
         def cb(n_chains, dim, _q, _g, _lp, stream_ptr):
-            # run the torch graph on the engine's stream: no cross-stream synchronisation needed
+            # run the torch work on the engine's stream: no cross-stream synchronisation needed
             st = streams.get(stream_ptr)
             if st is None:
                 st = torch.cuda.ExternalStream(stream_ptr, device=dev) if stream_ptr else torch.cuda.default_stream(dev)
                 streams[stream_ptr] = st
             with torch.cuda.stream(st):
-                val, grad = logp_fn(q)
-                lp.copy_(val.reshape(n).to(torch.float64))
-                g.copy_(grad.reshape(n, D).to(torch.float64))
+                if graph is not None:
+                    graph.replay()
+                else:
+                    val, grad = logp_fn(q)
+                    lp.copy_(val.reshape(n).to(torch.float64))
+                    g.copy_(grad.reshape(n, D).to(torch.float64))
             return 0
 
         model = _lib.DeviceCallbackModel(D, cb)
@@ -221,7 +241,7 @@ class TorchFuncModel(CompiledModel):
             settings, cores, model, progress_type, extra_callback, extra_callback_rate, store,
             staging=(q.data_ptr(), g.data_ptr(), lp.data_ptr()), **engine_kw,
         )
-        sampler._keep_tensors = (q, g, lp)
+        sampler._keep_tensors = (q, g, lp, graph)
         return sampler
 
     def _make_model(self, *a, **k):
@@ -250,6 +270,7 @@ def from_torchfunc(
     shared_data: dict[str, Any] | None = None,
     init="uniform",
     reparameterized_names=None,
+    use_graph: bool = False,
 ):
     """Batched analogue of :func:`from_pyfunc`: ``make_logp_fn() -> f`` with
     ``f(x: Tensor[chains, ndim]) -> (logp: Tensor[chains], grad: Tensor[chains, ndim])`` on the GPU."""
@@ -267,5 +288,6 @@ def from_torchfunc(
         _coords=dict(coords or {}),
         _shared_data=dict(shared_data or {}),
         _init=init,
+        _use_graph=use_graph,
         reparameterized_names=reparameterized_names,
     )

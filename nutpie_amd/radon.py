@@ -1,0 +1,116 @@
+"""Radon hierarchical model (BASELINE.json config 3) as a hand-written batched torch log-density.
+
+The model is the one in the reference's README (``README.md:60-88``): intercept, two ``ZeroSumNormal``
+county effects scaled by ``HalfNormal`` standard deviations, a floor effect and a ``HalfNormal(1.5)``
+observation noise — written directly on the unconstrained scale PyMC would sample on (log transforms
+with their Jacobians; PyMC's isometric zero-sum extension, so the zero-sum block is a standard normal
+in ``n - 1`` free coordinates).  The real ``radon.csv`` is a network download in the reference
+(``README.md:54``); here a synthetic data set of the same shape (85 counties, 919 observations) is drawn
+once from the prior with a fixed seed.
+
+Unconstrained vector (D = 2 n + 3 = 173):
+    [intercept, county_raw (n-1), log county_sd, floor_effect, county_floor_raw (n-1), log county_floor_sd, log sigma]
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from nutpie_amd.compiled_pyfunc import from_torchfunc
+
+N_COUNTIES = 85
+N_OBS = 919
+
+
+def synthetic_radon_data(n_counties=N_COUNTIES, n_obs=N_OBS, seed=20260926):
+    rng = np.random.default_rng(seed)
+    county_idx = rng.integers(0, n_counties, size=n_obs)
+    county_idx[:n_counties] = np.arange(n_counties)  # every county observed at least once
+    floor = (rng.uniform(size=n_obs) < 0.18).astype(np.float64)
+    county_effect = 0.3 * rng.normal(size=n_counties)
+    county_effect -= county_effect.mean()
+    cf_effect = 0.25 * rng.normal(size=n_counties)
+    cf_effect -= cf_effect.mean()
+    mu = 1.3 + county_effect[county_idx] - 0.6 * floor + cf_effect[county_idx] * floor
+    y = mu + 0.75 * rng.normal(size=n_obs)
+    return {"county_idx": county_idx, "floor": floor, "log_radon": y}
+
+
+def _extend_zero_sum(x):
+    """PyMC's ZeroSumTransform.backward (isometric R^{n-1} -> zero-sum R^n), batched over the leading axes."""
+    import torch
+
+    n = x.shape[-1] + 1
+    s = x.sum(-1, keepdim=True)
+    norm = s / (np.sqrt(n) + n)
+    fill = norm - s / np.sqrt(n)
+    return torch.cat([x, fill], -1) - norm
+
+
+def radon_model(data=None, device=0, use_graph=False):
+    """Returns a :class:`~nutpie_amd.compiled_pyfunc.TorchFuncModel` for the radon model."""
+    import torch
+
+    data = data or synthetic_radon_data()
+    n = int(np.max(data["county_idx"])) + 1
+    D = 2 * n + 3
+    o_int, o_raw, o_lsd, o_floor, o_craw, o_lcsd, o_lsig = 0, 1, n, n + 1, n + 2, 2 * n + 1, 2 * n + 2
+
+    def make_logp():
+        dev = torch.device("cuda", device)
+        cidx = torch.as_tensor(data["county_idx"], device=dev, dtype=torch.long)
+        floor = torch.as_tensor(data["floor"], device=dev, dtype=torch.float64)
+        y = torch.as_tensor(data["log_radon"], device=dev, dtype=torch.float64)
+        n_obs = y.shape[0]
+
+        def logp_only(x):
+            intercept = x[:, o_int]
+            raw = x[:, o_raw:o_raw + n - 1]
+            lsd = x[:, o_lsd]
+            fe = x[:, o_floor]
+            craw = x[:, o_craw:o_craw + n - 1]
+            lcsd = x[:, o_lcsd]
+            lsig = x[:, o_lsig]
+            sd, csd, sig = torch.exp(lsd), torch.exp(lcsd), torch.exp(lsig)
+            ce = _extend_zero_sum(raw) * sd[:, None]
+            cfe = _extend_zero_sum(craw) * csd[:, None]
+            mu = intercept[:, None] + ce[:, cidx] + fe[:, None] * floor + cfe[:, cidx] * floor
+            r = (y - mu) / sig[:, None]
+            lp = -0.5 * (intercept / 10.0) ** 2 - 0.5 * (fe / 2.0) ** 2
+            lp = lp - 0.5 * (raw * raw).sum(-1) - 0.5 * (craw * craw).sum(-1)
+            lp = lp - 0.5 * sd * sd + lsd - 0.5 * csd * csd + lcsd - 0.5 * (sig / 1.5) ** 2 + lsig
+            lp = lp - 0.5 * (r * r).sum(-1) - n_obs * lsig
+            return lp
+
+        def logp(x):
+            xg = x.detach().requires_grad_(True)
+            lp = logp_only(xg)
+            (g,) = torch.autograd.grad(lp.sum(), xg)
+            return lp.detach(), g
+
+        return logp
+
+    def expand(x):
+        """unconstrained [N, D] (numpy) -> dict of the model's named variables."""
+        x = np.asarray(x)
+
+        def ext(v):
+            m = v.shape[-1] + 1
+            s = v.sum(-1, keepdims=True)
+            norm = s / (np.sqrt(m) + m)
+            return np.concatenate([v, norm - s / np.sqrt(m)], -1) - norm
+
+        raw, craw = ext(x[:, o_raw:o_raw + n - 1]), ext(x[:, o_craw:o_craw + n - 1])
+        sd, csd = np.exp(x[:, o_lsd]), np.exp(x[:, o_lcsd])
+        return {
+            "intercept": x[:, o_int], "county_raw": raw, "county_sd": sd, "county_effect": raw * sd[:, None],
+            "floor_effect": x[:, o_floor], "county_floor_raw": craw, "county_floor_sd": csd,
+            "county_floor_effect": craw * csd[:, None], "sigma": np.exp(x[:, o_lsig]),
+        }
+
+    names = ["intercept", "county_raw", "county_sd", "county_effect", "floor_effect", "county_floor_raw", "county_floor_sd",
+             "county_floor_effect", "sigma"]
+    shapes = [(), (n,), (), (n,), (), (n,), (), (n,), ()]
+    dims = {k: ("county",) for k in ("county_raw", "county_effect", "county_floor_raw", "county_floor_effect")}
+    model = from_torchfunc(D, make_logp, expand, shapes, names, coords={"county": np.arange(n)}, dims=dims, use_graph=use_graph)
+    return model

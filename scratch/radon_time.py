@@ -1,0 +1,11 @@
+import sys, os, time, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import nutpie_amd
+from nutpie_amd.radon import radon_model
+for g in (False, True):
+    m = radon_model(use_graph=g)
+    t = time.time()
+    tr = nutpie_amd.sample(m, chains=512, tune=400, draws=1000, seed=1, progress_bar=False, return_raw_trace=True)
+    el = time.time() - t
+    n = tr.stats["n_steps"].sum()
+    print(f"radon 512 chains graph={g}: {el:.2f}s, {n} leapfrogs, {n/el/1e6:.2f} M leapfrogs/s, mean depth {tr.stats['depth'][:,400:].mean():.2f}, div {tr.stats['diverging'][:,400:].sum()}")
