@@ -150,14 +150,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    if "RANK" in os.environ:  # launched by torch.distributed.run (also with a single rank: same code path)
         import torch.distributed as dist
 
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
-    device = local_rank if world > 1 else 0
+    device = local_rank if dist is not None else 0
     torch.cuda.set_device(device)
 
     from nutpie_amd import _lib as hip

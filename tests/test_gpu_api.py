@@ -183,3 +183,35 @@ def test_radon_torch_model_config3():
     tr2 = nutpie_amd.sample(radon_model(data, use_graph=True), chains=64, tune=50, draws=20, seed=7, progress_bar=False)
     tr3 = nutpie_amd.sample(radon_model(data), chains=64, tune=50, draws=20, seed=7, progress_bar=False)
     assert np.array_equal(tr2.posterior.sigma.values, tr3.posterior.sigma.values)
+
+
+def test_sharded_sampling_and_rccl_gather_single_rank(tmp_path):
+    """The multi-GPU path (chain shard + RCCL gather of device-resident trace arrays) with a one-rank NCCL group:
+    the same code the 8-GPU job runs, on the one GPU a test box has."""
+    import os
+
+    import torch
+    import torch.distributed as dist
+
+    from nutpie_amd import _lib
+    from nutpie_amd.distributed import sample_sharded
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        diag = np.linspace(0.5, 2.0, 40)
+
+        def make(offset, n_local):
+            s = _lib.PyNutsSettings.Diag(5)
+            s.update(num_tune=40, num_draws=20, num_chains=6)
+            return _lib.PySampler(s, _lib.TridiagGaussianModel(diag), chain_offset=offset, n_local_chains=n_local)
+
+        smp, got = sample_sharded(make, 6, thin=2, dims=[0, 3, 39])
+        ref = smp.take_results()
+        assert got["draws"].shape == (6, 30, 3)
+        assert np.array_equal(got["draws"].cpu().numpy(), ref.draws[:, ::2][:, :, [0, 3, 39]])
+        assert np.array_equal(got["n_steps"].cpu().numpy(), ref.stats["n_steps"])
+        assert np.array_equal(got["diverging"].cpu().numpy().astype(bool), ref.stats["diverging"])
+    finally:
+        dist.destroy_process_group()
