@@ -61,9 +61,14 @@ class CompiledStanModel(CompiledModel):
     def n_dim(self):
         return int(self._bound().param_unc_num())
 
+    def _variables(self):
+        from nutpie_amd.stan_names import parse_stan_variables
+
+        return parse_stan_variables(",".join(self._bound().param_names(include_tp=True, include_gq=True)))
+
     @property
     def shapes(self):
-        return {"params": (int(self._bound().param_num(include_tp=True, include_gq=True)),)}
+        return {v.name: v.shape for v in self._variables()}
 
     @property
     def coords(self):
@@ -88,7 +93,9 @@ class CompiledStanModel(CompiledModel):
         for c in range(n):
             for t in range(T):
                 out[c, t] = m.param_constrain(draws[c, t], include_tp=True, include_gq=True)
-        return {"params": out}
+        from nutpie_amd.stan_names import expand_constrained
+
+        return expand_constrained(out, self._variables())  # names parsed + column-major blocks re-ordered (src/stan.rs:93-251, 671-711)
 
 
 def compile_stan_model(*, code: Optional[str] = None, filename: Optional[str] = None, extra_compile_args=None,
