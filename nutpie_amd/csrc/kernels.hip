@@ -290,7 +290,7 @@ struct Machine {
     __device__ __forceinline__ void lf1(int64_t srcq, int64_t srcp, int64_t newq, int64_t newp, int64_t sign, bool defer = false) {
         c->lf_srcq = srcq; c->lf_srcp = srcp; c->lf_newq = newq; c->lf_newp = newp; c->lf_sign = sign;
         c->eval_buf = newq;
-        if (NV > 0 && defer) return;  // register-resident: the whole leapfrog runs in leapfrog_reg()
+        if (FUSED && defer) return;  // fused models integrate the whole step in leaf_reg() / lf_stream()
         const double eps = (double)sign * c->step_size;
         const double h = 0.5 * eps;
         const double *q = Q(srcq), *g = G(srcq), *p = P(srcp);
@@ -347,6 +347,104 @@ struct Machine {
             code = A.ecode ? A.ecode[chain] : 0;
             NPHIP_FOR_CHUNKS(i) st2(g, i, ld2_dense(A.geval + (size_t)chain * D, i, D));
         }
+    }
+
+    // ---- criteria of a sub-tree merge INSIDE a doubling (all leaves on one side of the origin): for an
+    // (earlier, later) pair  span = (rho_late - rho_early) + p_early  in both directions (SURVEY A.4 modes 0/2).
+    __device__ __forceinline__ void span_acc(double pe_, double re_, double pl, double rl, double s2v, double& a1, double& a2) const {
+        const double t = (rl - re_) + pe_;
+        a1 = fma(t, s2v * pl, a1);
+        a2 = fma(t, s2v * pe_, a2);
+    }
+
+    // ---- Streaming fused leapfrog (FUSED, NV == 0: any D, any W).  ONE pass per leaf: each wave streams its
+    // chunks once — read q, grad, p, rho, sigma^2; write q', grad', p', rho' — interior tridiagonal neighbours come
+    // from DPP wave shifts, the two chunk-edge neighbours are recomputed from their own inputs (bit-identical, so
+    // no cross-wave exchange and no second pass), and the level-0 U-turn criterion is accumulated on the way.
+    __device__ __forceinline__ double edge_z(const double* q, const double* g, const double* p, int64_t e, double eps, double h) const {
+        const double ph = fma(h, ld1(g, e), ld1(p, e));
+        return fma(eps, ld1(sig2, e) * ph, ld1(q, e)) - ld1(A.m_mu, e);
+    }
+    __device__ double lf_stream(double& lp, int64_t idx_new, bool& turn0) {
+        const int64_t srcq = c->lf_srcq, srcp = c->lf_srcp, newq = c->lf_newq, newp = c->lf_newp;
+        const double eps = (double)c->lf_sign * c->step_size;
+        const double h = 0.5 * eps;
+        const bool copy_rho = (idx_new == -1);
+        const double *q = Q(srcq), *g = G(srcq), *p = P(srcp), *r = R(srcp);
+        double *qn = Q(newq), *gn = G(newq), *pn = P(newp), *rn = R(newp);
+        double2 accK = {0.0, 0.0}, accL = {0.0, 0.0}, accE = {0.0, 0.0}, accS = {0.0, 0.0};
+        NPHIP_FOR_CHUNKS(i) {
+            const double2 q2 = ld2(q, i), g2 = ld2(g, i), p2 = ld2(p, i), r2 = ld2(r, i), s2 = ld2(sig2, i);
+            const double2 mu = ld2(A.m_mu, i), a = ld2(A.m_a, i), b = ld2(A.m_b, i);   // b pads are -0.0 (host)
+            const double bl_edge = (i > 0) ? ld1(A.m_b, i - 1) : -0.0;
+            double2 ph, qq, z;
+            ph.x = fma(h, g2.x, p2.x);
+            ph.y = fma(h, g2.y, p2.y);
+            qq.x = fma(eps, s2.x * ph.x, q2.x);
+            qq.y = fma(eps, s2.y * ph.y, q2.y);
+            z.x = qq.x - mu.x;
+            z.y = qq.y - mu.y;
+            // chunk-edge neighbours (uniform addresses: one broadcast transaction each)
+            const int64_t c0 = i - 2 * lane;                 // first element of this chunk
+            const double zl_edge = (c0 > 0) ? edge_z(q, g, p, c0 - 1, eps, h) : 0.0;
+            const double zr_edge = (c0 + NPHIP_CHUNK < ld) ? edge_z(q, g, p, c0 + NPHIP_CHUNK, eps, h) : 0.0;
+            const double bl = wave_shr1(b.y, (c0 > 0) ? ld1(A.m_b, c0 - 1) : -0.0);
+            (void)bl_edge;
+            const double zl = wave_shr1(z.y, zl_edge);
+            const double zr = wave_shl1(z.x, zr_edge);
+            double tx = a.x * z.x;
+            tx = fma(bl, zl, tx);
+            tx = fma(b.x, z.y, tx);
+            double ty = a.y * z.y;
+            ty = fma(b.x, z.x, ty);
+            ty = fma(b.y, zr, ty);
+            double2 gg, pv, rr;
+            gg.x = -tx;
+            gg.y = -ty;
+            accL.x = fma(z.x, gg.x, accL.x);
+            accL.y = fma(z.y, gg.y, accL.y);
+            pv.x = fma(h, gg.x, ph.x);
+            pv.y = fma(h, gg.y, ph.y);
+            const double vx = s2.x * pv.x, vy = s2.y * pv.y;
+            accK.x = fma(pv.x, vx, accK.x);
+            accK.y = fma(pv.y, vy, accK.y);
+            rr.x = (copy_rho ? -0.0 : r2.x) + pv.x;
+            rr.y = (copy_rho ? -0.0 : r2.y) + pv.y;
+            const double tx0 = (rr.x - r2.x) + p2.x, ty0 = (rr.y - r2.y) + p2.y;
+            accE.x = fma(tx0, vx, accE.x);
+            accE.y = fma(ty0, vy, accE.y);
+            accS.x = fma(tx0, s2.x * p2.x, accS.x);
+            accS.y = fma(ty0, s2.y * p2.y, accS.y);
+            st2(qn, i, qq); st2(gn, i, gg); st2(pn, i, pv); st2(rn, i, rr);
+        }
+        double v[4] = {accK.x + accK.y, accL.x + accL.y, accE.x + accE.y, accS.x + accS.y};
+        reduceN<W, 4>(v, red);
+        lp = 0.5 * v[1];
+        turn0 = (v[2] < 0.0) || (v[3] < 0.0);
+        return 0.5 * v[0];
+    }
+    // The three criteria of a sub-tree merge inside a doubling in ONE streaming pass (direction-free span):
+    // (A.first, TL) || (A.last, TL) || (A.first, TF)
+    __device__ bool check3_stream(int64_t sA, int64_t sB, int64_t sTF, int64_t sTL) {
+        const double *pa = P(sA), *ra = R(sA), *pb = P(sB), *rb = R(sB), *pf = P(sTF), *rf = R(sTF), *pl = P(sTL), *rl = R(sTL);
+        double2 acc[6];
+#pragma unroll
+        for (int n = 0; n < 6; ++n) { acc[n].x = 0.0; acc[n].y = 0.0; }
+        NPHIP_FOR_CHUNKS(i) {
+            const double2 xa = ld2(pa, i), xra = ld2(ra, i), xb = ld2(pb, i), xrb = ld2(rb, i), xf = ld2(pf, i), xrf = ld2(rf, i);
+            const double2 xl = ld2(pl, i), xrl = ld2(rl, i), s2 = ld2(sig2, i);
+            span_acc(xa.x, xra.x, xl.x, xrl.x, s2.x, acc[0].x, acc[1].x);
+            span_acc(xa.y, xra.y, xl.y, xrl.y, s2.y, acc[0].y, acc[1].y);
+            span_acc(xb.x, xrb.x, xl.x, xrl.x, s2.x, acc[2].x, acc[3].x);
+            span_acc(xb.y, xrb.y, xl.y, xrl.y, s2.y, acc[2].y, acc[3].y);
+            span_acc(xa.x, xra.x, xf.x, xrf.x, s2.x, acc[4].x, acc[5].x);
+            span_acc(xa.y, xra.y, xf.y, xrf.y, s2.y, acc[4].y, acc[5].y);
+        }
+        double v[6];
+#pragma unroll
+        for (int n = 0; n < 6; ++n) v[n] = acc[n].x + acc[n].y;
+        reduceN<W, 6>(v, red);
+        return (v[0] < 0.0) || (v[1] < 0.0) || (v[2] < 0.0) || (v[3] < 0.0) || (v[4] < 0.0) || (v[5] < 0.0);
     }
 
     // Leapfrog, second half (+ fused gradient): p' = p_half + eps/2 g' ; K' ; rho' = rho + p'.
@@ -470,13 +568,6 @@ struct Machine {
         double v[2] = {e.x + e.y, st.x + st.y};
         reduceN<W, 2>(v, red);
         return (v[0] < 0.0) || (v[1] < 0.0);
-    }
-    // ---- criteria of a sub-tree merge INSIDE a doubling (all leaves on one side of the origin): for an
-    // (earlier, later) pair  span = (rho_late - rho_early) + p_early  in both directions (SURVEY A.4 modes 0/2).
-    __device__ __forceinline__ void span_acc(double pe_, double re_, double pl, double rl, double s2v, double& a1, double& a2) const {
-        const double t = (rl - re_) + pe_;
-        a1 = fma(t, s2v * pl, a1);
-        a2 = fma(t, s2v * pe_, a2);
     }
     // pass A: (A.first, TL) || (A.first, TF) with TF in registers
     __device__ __forceinline__ bool sub_a(const RegsT& X, const double2 (&ap)[NVX], const double2 (&ar)[NVX], const double2 (&fp)[NVX], const double2 (&fr)[NVX]) {
@@ -1083,8 +1174,12 @@ struct Machine {
                 } else {
                     const int64_t al = j - (1ll << k);      // last leaf of A
                     const int64_t tf = j - (1ll << k) + 1;  // first leaf of T
-                    turn = check_merge(X, 3, sA_first, iA_first, slot_last(__builtin_ctzll((unsigned long long)al), A.cap), near_idx + dir * al,
-                                       slot_first(__builtin_ctzll((unsigned long long)(tf - 1))), near_idx + dir * tf, sT_last, idx_new);
+                    if (FUSED)
+                        turn = check3_stream(sA_first, slot_last(__builtin_ctzll((unsigned long long)al), A.cap),
+                                             slot_first(__builtin_ctzll((unsigned long long)(tf - 1))), sT_last);
+                    else
+                        turn = check_merge(X, 3, sA_first, iA_first, slot_last(__builtin_ctzll((unsigned long long)al), A.cap), near_idx + dir * al,
+                                           slot_first(__builtin_ctzll((unsigned long long)(tf - 1))), near_idx + dir * tf, sT_last, idx_new);
                 }
                 if (turn) { rare_end_draw(A, c, red, chain, false, false, false, false); return true; }
             }
@@ -1254,8 +1349,15 @@ struct Machine {
                 } else {
                     double lp = 0.0;
                     int64_t code = 0;
-                    const double K = lf2(lp, code, c->idx_cur + c->dir);
-                    rare = cont_tree(X, K, lp, code, false, false);
+                    if (FUSED) {
+                        bool turn0 = false;
+                        const bool even_leaf = ((c->nleaf + 1) & 1) == 0;
+                        const double K = lf_stream(lp, c->idx_cur + c->dir, turn0);
+                        rare = cont_tree(X, K, lp, code, even_leaf, turn0);
+                    } else {
+                        const double K = lf2(lp, code, c->idx_cur + c->dir);
+                        rare = cont_tree(X, K, lp, code, false, false);
+                    }
                 }
                 if (rare) X.invalidate();
 #ifdef NPHIP_PROFILE

@@ -135,6 +135,19 @@ def test_correlated_gaussian_all_geometries(hip, oracle, dim, waves):
     assert np.array_equal(got.stats["mass_matrix_inv"], want.stats["mass_matrix_inv"])
 
 
+@pytest.mark.parametrize("dim", [5, 300, 1000])
+def test_streaming_kernel_single_wave_bit_identical(hip, oracle, dim):
+    # the memory-resident (streaming) fused kernel with one wave per chain — the family used for D > 1024,
+    # store_divergences and callbacks — forced here where the register-resident kernel would normally run
+    rng = np.random.default_rng(dim + 7)
+    diag = np.exp(rng.normal(size=dim))
+    off = 0.2 * rng.normal(size=dim - 1) * np.sqrt(diag[:-1] * diag[1:])
+    got, W = run_engine(hip, hip.TridiagGaussianModel(diag, off), chains=6, tune=100, draws=40, seed=31, launch=dict(no_register_kernel=True))
+    want = oracle.sample_tridiag(oracle_settings(oracle, chains=6, tune=100, draws=40, seed=31, W=W), diag, off)
+    assert W == 1
+    assert_trace_equal(got, want)
+
+
 @pytest.mark.parametrize("settings", [
     dict(use_grad_based_mass_matrix=False),                 # adaptation="draw_diag"
     dict(max_energy_error=0.2),                             # many divergences
