@@ -174,7 +174,7 @@ int nphip_sampler_finished_draws(nphip_sampler_t*, uint64_t* finished);
 int nphip_sampler_copy_stat(nphip_sampler_t*, const char* name, void* host_out, uint64_t nbytes);
 /* Developer aid: per-section cycle counters summed over chains; all zero unless the library was built
  * with -DNPHIP_PROFILE.  [0] leapfrog cycles [1] tree cycles (hot) [2] draw-end cycles [3..5] their counts. */
-int nphip_sampler_profile(nphip_sampler_t*, int64_t out[8]);
+int nphip_sampler_profile(nphip_sampler_t*, int64_t out[16]);
 /* Device pointer of a trace array (for zero-copy wrapping / RCCL gathers); NULL if absent. */
 void* nphip_sampler_device_ptr(nphip_sampler_t*, const char* name);
 

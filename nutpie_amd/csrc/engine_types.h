@@ -80,7 +80,7 @@ struct Ctl {
     int64_t fin_depth, fin_flags;
     double fin_eerr;
     // cycle counters per section (only advanced when built with -DNPHIP_PROFILE): leapfrog, tree, rare, count
-    int64_t prof[8];
+    int64_t prof[16];
     // sub-tree stack
     double sub_ls[kMaxDepthCap];
     double sub_U[kMaxDepthCap];

@@ -888,11 +888,11 @@ int nphip_sampler_copy_stat(nphip_sampler_t* s, const char* name, void* host_out
     return NPHIP_OK;
 }
 
-int nphip_sampler_profile(nphip_sampler_t* s, int64_t out[8]) {
+int nphip_sampler_profile(nphip_sampler_t* s, int64_t out[16]) {
     std::vector<Ctl> h;
     if (!read_ctl(s, h)) return NPHIP_ERR;
-    for (int k = 0; k < 8; ++k) out[k] = 0;
-    for (auto& c : h) for (int k = 0; k < 8; ++k) out[k] += c.prof[k];
+    for (int k = 0; k < 16; ++k) out[k] = 0;
+    for (auto& c : h) for (int k = 0; k < 16; ++k) out[k] += c.prof[k];
     return NPHIP_OK;
 }
 

@@ -694,6 +694,9 @@ struct Machine {
         const int64_t idx_new = c->idx_cur + dir;
         const int64_t srcq = c->lf_srcq, srcp = c->lf_srcp, newq = c->lf_newq, newp = c->lf_newp;
         const bool check = A.s.check_turning && (d + 1 > A.s.mindepth);
+#ifdef NPHIP_PROFILE
+        const int64_t tp0 = (int64_t)__builtin_readcyclecounter();
+#endif
         // ---- source state (already in registers unless the cursor moved or a rare path ran)
         if (X.reg_q != srcq) {
             const double* q = Q(srcq);
@@ -777,8 +780,15 @@ struct Machine {
         // the two most recent summaries a level-1 merge needs stay on chip
         if ((j & 3) == 1) { ring_write(0, X.p, X.r); X.ring_leaf0 = j; }
         else if ((j & 3) == 2) { ring_write(1, X.p, X.r); X.ring_leaf1 = j; }
+#ifdef NPHIP_PROFILE
+        const int64_t tp1 = (int64_t)__builtin_readcyclecounter();
+#endif
         double v4[4] = {accK.x + accK.y, accL.x + accL.y, accE.x + accE.y, accS.x + accS.y};
         reduceN<W, 4>(v4, red);
+#ifdef NPHIP_PROFILE
+        const int64_t tp2 = (int64_t)__builtin_readcyclecounter();
+        c->prof[0] += tp1 - tp0; c->prof[6] += tp2 - tp1;
+#endif
         const double K = 0.5 * v4[0], lp = 0.5 * v4[1];
         const bool turn0 = (v4[2] < 0.0) || (v4[3] < 0.0);
         // ---- NutsTree::extend / merge_into, unrolled (same decisions as cont_tree)
@@ -800,6 +810,10 @@ struct Machine {
             c->acc_sym_mean += (asym - c->acc_sym_mean) / cnt;
         }
         if (diverged) { X.dirty_qg = X.dirty_pr = false; rare_end_draw(A, c, red, chain, true, false, false, false, true); return true; }
+#ifdef NPHIP_PROFILE
+        int64_t tq = (int64_t)__builtin_readcyclecounter();
+        c->prof[8] += tq - tp2;
+#endif
 
         double T_ls = -dE, T_U = Unew, T_E = E;
         int64_t T_q = newq, T_idx = idx_new;
@@ -835,19 +849,31 @@ struct Machine {
                 }
                 if (turn) { X.dirty_qg = X.dirty_pr = false; rare_end_draw(A, c, red, chain, false, false, false, false, true); return true; }
             }
+#ifdef NPHIP_PROFILE
+            { const int64_t t_ = (int64_t)__builtin_readcyclecounter(); c->prof[k == 0 ? 9 : 10] += t_ - tq; tq = t_; }
+#endif
             const double ls = nphip_logaddexp(c->sub_ls[k], T_ls);
             bool take = T_ls >= ls;
             if (!take) take = merge_uniform(j, d, k) < nphip_exp(T_ls - ls);
             if (!take) { T_q = c->sub_q[k]; T_U = c->sub_U[k]; T_E = c->sub_E[k]; T_idx = c->sub_idx[k]; }
             T_ls = ls;
+#ifdef NPHIP_PROFILE
+            { const int64_t t_ = (int64_t)__builtin_readcyclecounter(); c->prof[11] += t_ - tq; tq = t_; }
+#endif
             ++k;
         }
         if (k < d) {
             c->sub_ls[k] = T_ls; c->sub_q[k] = T_q; c->sub_U[k] = T_U; c->sub_E[k] = T_E; c->sub_idx[k] = T_idx;
             // ---- stores, last: q when the leaf is referenced as a candidate; (p, rho) only for leaves a level >= 2
             // merge reads back from HBM (leaf % 4 == 0: A.last, leaf % 8 == 1: A.first)
+#ifdef NPHIP_PROFILE
+            const int64_t tp3 = (int64_t)__builtin_readcyclecounter();
+#endif
             store_state(X, T_q == newq, ((j & 3) == 0) || ((j & 7) == 1));
             issue_leaf();
+#ifdef NPHIP_PROFILE
+            c->prof[7] += (int64_t)__builtin_readcyclecounter() - tp3;
+#endif
             return false;
         }
         // ---- the new sub-tree of depth d is complete (j == 2^d): merge into the main tree (general index modes)

@@ -13,8 +13,9 @@ def run(dim, chains, noreg, W=0, E=256, steps=40, warm=40):
     n1 = sum(p.total_num_steps for p in smp.progress())
     print(f"dim={dim} chains={chains} W={smp.waves_per_chain} noreg={noreg} E={E}: {(n1-n0)/el/1e6:.1f} M leapfrogs/s, kernel {ms/steps:.3f} ms/launch, {ms/steps/E*1e3:.2f} us/leapfrog/chain, alg {(n1-n0)*40*dim/(ms/1e3)/1e9:.0f} GB/s")
     import ctypes as C
-    out=(C.c_int64*8)(); hip.lib().nphip_sampler_profile(smp._h, out); o=list(out)
-    if o[3]: print(f"   cycles/leapfrog: leap {o[0]/o[3]:.0f}  tree(hot) {o[1]/max(o[4],1):.0f} (n={o[4]})  draw-end {o[2]/max(o[5],1):.0f} (n={o[5]})")
+    out=(C.c_int64*16)(); hip.lib().nphip_sampler_profile(smp._h, out); o=list(out)
+    if o[3]: print(f"   cycles/leaf: total(hot) {o[1]/max(o[4],1):.0f} (n={o[4]}) = math {o[0]/o[3]:.0f} + reduce4 {o[6]/o[3]:.0f} + stores/issue {o[7]/max(o[4],1):.0f} + cascade(rest);  draw-end {o[2]/max(o[5],1):.0f} (n={o[5]})")
+    if o[3]: print(f"   cascade per leaf: collector {o[8]/o[3]:.0f}  level0-check {o[9]/o[3]:.0f}  level>=1 checks {o[10]/o[3]:.0f}  merge scalar {o[11]/o[3]:.0f}")
     smp.close()
 for a in sys.argv[1:]:
     exec(a)
