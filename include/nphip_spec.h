@@ -89,24 +89,35 @@ NPHIP_HD double nphip_pow2i(int k) { return nphip_bits2d((uint64_t)(k + 1023) <<
 
 /* exp(x): k = rint(x/ln2), r = x - k ln2 (Cody-Waite, fma), Taylor degree 13 in
  * Horner/fma form, scaled by 2^k in two exact steps.  <= 2 ulp. */
+/* NPHIP_K(c): a literal of the polynomial kernels.  On the device it is pinned in an SGPR pair at its point of
+ * use (an empty asm the optimiser cannot move): otherwise the ~40 coefficients are hoisted out of the sampler's
+ * main loop into VGPRs and spilled to scratch, and every Horner step waits on a scratch reload.  Same value,
+ * same operation order on both sides. */
+#if defined(__HIP_DEVICE_COMPILE__)
+static __device__ __forceinline__ double nphip_kdev(double c) { asm volatile("" : "+s"(c)); return c; }
+#define NPHIP_K(c) nphip_kdev(c)
+#else
+#define NPHIP_K(c) (c)
+#endif
+
 NPHIP_HD double nphip_exp(double x) {
     if (x != x) return x;
     if (x > 709.782712893384) return INFINITY;
     if (x < -745.2) return 0.0;
-    double k = rint(x * 0x1.71547652b82fep+0);
-    double r = fma(-k, 0x1.62e42fee00000p-1, x);
-    r = fma(-k, 0x1.a39ef35793c76p-33, r);
-    double p = 1.6059043836821613e-10;      /* 1/13! */
-    p = fma(p, r, 2.08767569878681e-09);    /* 1/12! */
-    p = fma(p, r, 2.505210838544172e-08);   /* 1/11! */
-    p = fma(p, r, 2.755731922398589e-07);   /* 1/10! */
-    p = fma(p, r, 2.7557319223985893e-06);  /* 1/9!  */
-    p = fma(p, r, 2.48015873015873e-05);    /* 1/8!  */
-    p = fma(p, r, 0.0001984126984126984);   /* 1/7!  */
-    p = fma(p, r, 0.001388888888888889);    /* 1/6!  */
-    p = fma(p, r, 0.008333333333333333);    /* 1/5!  */
-    p = fma(p, r, 0.041666666666666664);    /* 1/4!  */
-    p = fma(p, r, 0.16666666666666666);     /* 1/3!  */
+    double k = rint(x * NPHIP_K(0x1.71547652b82fep+0));
+    double r = fma(-k, NPHIP_K(0x1.62e42fee00000p-1), x);
+    r = fma(-k, NPHIP_K(0x1.a39ef35793c76p-33), r);
+    double p = NPHIP_K(1.6059043836821613e-10);      /* 1/13! */
+    p = fma(p, r, NPHIP_K(2.08767569878681e-09));    /* 1/12! */
+    p = fma(p, r, NPHIP_K(2.505210838544172e-08));   /* 1/11! */
+    p = fma(p, r, NPHIP_K(2.755731922398589e-07));   /* 1/10! */
+    p = fma(p, r, NPHIP_K(2.7557319223985893e-06));  /* 1/9!  */
+    p = fma(p, r, NPHIP_K(2.48015873015873e-05));    /* 1/8!  */
+    p = fma(p, r, NPHIP_K(0.0001984126984126984));   /* 1/7!  */
+    p = fma(p, r, NPHIP_K(0.001388888888888889));    /* 1/6!  */
+    p = fma(p, r, NPHIP_K(0.008333333333333333));    /* 1/5!  */
+    p = fma(p, r, NPHIP_K(0.041666666666666664));    /* 1/4!  */
+    p = fma(p, r, NPHIP_K(0.16666666666666666));     /* 1/3!  */
     p = fma(p, r, 0.5);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
@@ -131,21 +142,21 @@ NPHIP_HD double nphip_log(double x) {
     double f = m - 1.0;
     double s = f / (2.0 + f);
     double z = s * s;
-    double R = 0.08;                        /* 2/25 */
-    R = fma(R, z, 0.08695652173913043);     /* 2/23 */
-    R = fma(R, z, 0.09523809523809523);     /* 2/21 */
-    R = fma(R, z, 0.10526315789473684);     /* 2/19 */
-    R = fma(R, z, 0.11764705882352941);     /* 2/17 */
-    R = fma(R, z, 0.13333333333333333);     /* 2/15 */
-    R = fma(R, z, 0.15384615384615385);     /* 2/13 */
-    R = fma(R, z, 0.18181818181818182);     /* 2/11 */
-    R = fma(R, z, 0.2222222222222222);      /* 2/9  */
-    R = fma(R, z, 0.2857142857142857);      /* 2/7  */
-    R = fma(R, z, 0.4);                     /* 2/5  */
-    R = fma(R, z, 0.6666666666666666);      /* 2/3  */
+    double R = NPHIP_K(0.08);                        /* 2/25 */
+    R = fma(R, z, NPHIP_K(0.08695652173913043));     /* 2/23 */
+    R = fma(R, z, NPHIP_K(0.09523809523809523));     /* 2/21 */
+    R = fma(R, z, NPHIP_K(0.10526315789473684));     /* 2/19 */
+    R = fma(R, z, NPHIP_K(0.11764705882352941));     /* 2/17 */
+    R = fma(R, z, NPHIP_K(0.13333333333333333));     /* 2/15 */
+    R = fma(R, z, NPHIP_K(0.15384615384615385));     /* 2/13 */
+    R = fma(R, z, NPHIP_K(0.18181818181818182));     /* 2/11 */
+    R = fma(R, z, NPHIP_K(0.2222222222222222));      /* 2/9  */
+    R = fma(R, z, NPHIP_K(0.2857142857142857));      /* 2/7  */
+    R = fma(R, z, NPHIP_K(0.4));                     /* 2/5  */
+    R = fma(R, z, NPHIP_K(0.6666666666666666));      /* 2/3  */
     double logm = fma(s * z, R, 2.0 * s);
     double de = (double)e;
-    return fma(de, 0x1.62e42fee00000p-1, fma(de, 0x1.a39ef35793c76p-33, logm));
+    return fma(de, NPHIP_K(0x1.62e42fee00000p-1), fma(de, NPHIP_K(0x1.a39ef35793c76p-33), logm));
 }
 
 /* log(1+y) for y >= 0 (HP-15C trick). */

@@ -429,11 +429,12 @@ _VECTOR_STATS = ("gradient", "mass_matrix_inv", "divergence_start", "divergence_
 class PyTrace:
     """Dense trace: ``draws[chain, draw, dim]`` + ``stats[name][chain, draw(, dim)]`` + ``finished[chain]``."""
 
-    def __init__(self, draws, stats, finished, chain_offset=0):
+    def __init__(self, draws, stats, finished, chain_offset=0, expanded=None):
         self.draws = draws
         self.stats = stats
         self.finished = finished
         self.chain_offset = chain_offset
+        self.expanded = expanded  # name -> [chain, draw, *shape] when the model expanded the draws on the device
 
     def is_arrow(self):
         return False
@@ -599,8 +600,14 @@ class PySampler:
         for k in _VECTOR_STATS:
             if self.device_ptr(k):
                 stats[k] = self._copy(k, np.float64, vec=True)
-        draws = self._copy("draws", np.float64, vec=True) if self._store_draws else None
-        return PyTrace(draws, stats, fin.astype(np.int64), self._chain_offset)
+        expanded = None
+        expand = getattr(self, "_device_expand", None)
+        if expand is not None and self._store_draws:
+            # expand step batched on the device, straight from the engine's draws buffer
+            expanded = expand(self)
+        need_host_draws = self._store_draws and (expanded is None or getattr(self, "_keep_host_draws", True))
+        draws = self._copy("draws", np.float64, vec=True) if need_host_draws else None
+        return PyTrace(draws, stats, fin.astype(np.int64), self._chain_offset, expanded)
 
     def inspect(self):
         """Copy of the current state of the trace (wrapper.rs:1401-1429)."""

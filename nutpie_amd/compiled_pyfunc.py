@@ -165,6 +165,7 @@ class TorchFuncModel(CompiledModel):
     _shared_data: dict[str, Any]
     _init: Any = "uniform"              # "uniform" | "normal" | ndarray [chains, D]
     _use_graph: bool = False            # capture logp+grad in a HIP graph (torch.cuda.CUDAGraph) and replay it per step
+    _expand_device_func: Callable | None = None  # (x: Tensor[N, D] on the GPU) -> dict name -> Tensor[N, *shape]
 
     @property
     def shapes(self):
@@ -242,7 +243,31 @@ class TorchFuncModel(CompiledModel):
             staging=(q.data_ptr(), g.data_ptr(), lp.data_ptr()), **engine_kw,
         )
         sampler._keep_tensors = (q, g, lp, graph)
+        if self._expand_device_func is not None:
+            sampler._device_expand = partial(self._expand_on_device, device=device)
         return sampler
+
+    def _expand_on_device(self, sampler, device=0, block=1 << 22):
+        """Expand step (reference src/pyfunc.rs:236-391: one Python call per draw per chain) as a few batched
+        torch calls over the engine's ``draws[chain, draw, D]`` buffer in HBM; only the expanded variables are
+        copied to the host."""
+        import torch
+
+        from nutpie_amd.distributed import device_tensor
+
+        n, T, D = sampler.num_chains, sampler.total_draws, self._n_dim
+        ptr = sampler.device_ptr("draws")
+        if not ptr:
+            return None
+        flat = device_tensor(ptr, (n * T, D), "float64", device)
+        out = {name: np.empty((n * T, *shape)) for name, shape in zip(self._names, self._shapes)}
+        rows = max(1, block // max(D, 1))
+        with torch.no_grad():
+            for lo in range(0, n * T, rows):
+                vals = self._expand_device_func(flat[lo:lo + rows], **self._shared_data)
+                for name, shape in zip(self._names, self._shapes):
+                    out[name][lo:lo + rows] = vals[name].reshape(-1, *shape).to(torch.float64).cpu().numpy()
+        return {name: out[name].reshape(n, T, *shape) for name, shape in zip(self._names, self._shapes)}
 
     def _make_model(self, *a, **k):
         raise NotImplementedError("TorchFuncModel builds its model inside _make_sampler (staging tensors are per sampler)")
@@ -271,12 +296,16 @@ def from_torchfunc(
     init="uniform",
     reparameterized_names=None,
     use_graph: bool = False,
+    expand_device_fn: Callable | None = None,
 ):
     """Batched analogue of :func:`from_pyfunc`: ``make_logp_fn() -> f`` with
-    ``f(x: Tensor[chains, ndim]) -> (logp: Tensor[chains], grad: Tensor[chains, ndim])`` on the GPU."""
+    ``f(x: Tensor[chains, ndim]) -> (logp: Tensor[chains], grad: Tensor[chains, ndim])`` on the GPU.
+
+    ``expand_fn`` maps a numpy ``[N, ndim]`` block on the host; ``expand_device_fn`` (optional, preferred) maps a
+    ``Tensor[N, ndim]`` on the GPU to a dict of tensors and is applied to the engine's draws buffer in HBM."""
     if expanded_names is None:
         expanded_names, expanded_shapes = ["x"], [(ndim,)]
-        if expand_fn is not None:
+        if expand_fn is not None or expand_device_fn is not None:
             raise ValueError("expand_fn needs expanded_names and expanded_shapes")
     return TorchFuncModel(
         dims=dict(dims or {}),
@@ -289,5 +318,6 @@ def from_torchfunc(
         _shared_data=dict(shared_data or {}),
         _init=init,
         _use_graph=use_graph,
+        _expand_device_func=expand_device_fn,
         reparameterized_names=reparameterized_names,
     )

@@ -528,10 +528,8 @@ bool nphip_sampler::setup() {
     // (not with store_divergences: the divergence record needs the pre-step state, which only the
     //  memory-resident kernel keeps)
     if (fused && W == 1 && !launch.no_register_kernel && !set.store_divergences) {
-        const int nchunks = (int)(args.ld / 128);
-        int nv = 1;
-        while (nv < nchunks) nv *= 2;
-        if (nv <= 8) args.reg_nv = nv;
+        const int nchunks = (int)(args.ld / 128);  // one kernel instantiation per exact chunk count (straight-line code)
+        if (nchunks <= 8) args.reg_nv = nchunks;
     }
 
     if (!dalloc(&args.ctl, n)) return false;

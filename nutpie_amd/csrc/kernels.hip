@@ -39,6 +39,11 @@ namespace nphip {
 // ----------------------------------------------------------------------------------------
 
 template <int W>
+// The register kernels run one wave per SIMD with (almost) the whole register file live.  Left alone, the
+// scheduler hoists every load of the next phase above the current one and drives the allocator into scratch;
+// a fence between the phases of a leaf keeps each phase's temporaries local to it.
+#define NPHIP_PHASE_FENCE() __builtin_amdgcn_sched_barrier(0)
+
 __device__ __forceinline__ void chain_sync() {
     // make this chain's global stores visible to all of its lanes/waves
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -528,7 +533,7 @@ struct Machine {
     }
     __device__ __forceinline__ void load_slot(int64_t slot, double2 (&p)[NVX], double2 (&r)[NVX]) const {
         const double *gp = P(slot), *gr = R(slot);
-        const int nk = (int)nch;
+        constexpr int nk = NVX;  // the register kernels are instantiated per exact chunk count
 #pragma unroll
         for (int k = 0; k < NVX; ++k) if (k < nk) { p[k] = ld2(gp, ridx(k)); r[k] = ld2(gr, ridx(k)); }
     }
@@ -538,7 +543,7 @@ struct Machine {
     // (A, TL) || (A, TF): four dots in one pass
     __device__ __forceinline__ bool check_a(const RegsT& X, const double2 (&ap)[NVX], const double2 (&ar)[NVX], const double2 (&fp)[NVX],
                                             const double2 (&fr)[NVX], int64_t iA, int64_t iTF, int64_t iTL) {
-        const int nk = (int)nch;
+        constexpr int nk = NVX;  // the register kernels are instantiated per exact chunk count
         const Pair p1 = pair_of(iA, iTL), p3 = pair_of(iA, iTF);
         double2 acc[4];
 #pragma unroll
@@ -557,7 +562,7 @@ struct Machine {
         return (v[0] < 0.0) || (v[1] < 0.0) || (v[2] < 0.0) || (v[3] < 0.0);
     }
     __device__ __forceinline__ bool check1(const RegsT& X, const double2 (&ap)[NVX], const double2 (&ar)[NVX], int64_t iA, int64_t iTL) {
-        const int nk = (int)nch;
+        constexpr int nk = NVX;  // the register kernels are instantiated per exact chunk count
         const Pair p1 = pair_of(iA, iTL);
         double2 e = {0.0, 0.0}, st = {0.0, 0.0};
 #pragma unroll
@@ -571,7 +576,7 @@ struct Machine {
     }
     // pass A: (A.first, TL) || (A.first, TF) with TF in registers
     __device__ __forceinline__ bool sub_a(const RegsT& X, const double2 (&ap)[NVX], const double2 (&ar)[NVX], const double2 (&fp)[NVX], const double2 (&fr)[NVX]) {
-        const int nk = (int)nch;
+        constexpr int nk = NVX;  // the register kernels are instantiated per exact chunk count
         double2 acc[4];
 #pragma unroll
         for (int n = 0; n < 4; ++n) { acc[n].x = 0.0; acc[n].y = 0.0; }
@@ -590,7 +595,7 @@ struct Machine {
     }
     // pass B: (A.last, TL)
     __device__ __forceinline__ bool sub_b(const RegsT& X, const double2 (&ap)[NVX], const double2 (&ar)[NVX]) {
-        const int nk = (int)nch;
+        constexpr int nk = NVX;  // the register kernels are instantiated per exact chunk count
         double2 e = {0.0, 0.0}, st = {0.0, 0.0};
 #pragma unroll
         for (int k = 0; k < NVX; ++k) if (k < nk) {
@@ -606,20 +611,20 @@ struct Machine {
         return (NPHIP_LDS double2*)(ring + (size_t)(slot * 2 + vec) * NVX * 128) + lane;
     }
     __device__ __forceinline__ void ring_write(int slot, const double2 (&p)[NVX], const double2 (&r)[NVX]) {
-        const int nk = (int)nch;
+        constexpr int nk = NVX;  // the register kernels are instantiated per exact chunk count
         NPHIP_LDS double2 *lp = ring_ptr(slot, 0), *lr = ring_ptr(slot, 1);
 #pragma unroll
         for (int k = 0; k < NVX; ++k) if (k < nk) { lp[k * 64] = p[k]; lr[k * 64] = r[k]; }
     }
     __device__ __forceinline__ void ring_read(int slot, double2 (&p)[NVX], double2 (&r)[NVX]) const {
-        const int nk = (int)nch;
+        constexpr int nk = NVX;  // the register kernels are instantiated per exact chunk count
         const NPHIP_LDS double2 *lp = ring_ptr(slot, 0), *lr = ring_ptr(slot, 1);
 #pragma unroll
         for (int k = 0; k < NVX; ++k) if (k < nk) { p[k] = lp[k * 64]; r[k] = lr[k * 64]; }
     }
     // fused-model gradient of the register position (used when a position is reloaded: only q is kept in HBM)
     __device__ __forceinline__ void regs_grad(RegsT& X) {
-        const int nk = (int)nch;
+        constexpr int nk = NVX;  // the register kernels are instantiated per exact chunk count
         const NPHIP_LDS double* pmu = par;
         const NPHIP_LDS double* pa = par + ld;
         const NPHIP_LDS double* pb = par + 2 * ld;
@@ -652,7 +657,7 @@ struct Machine {
     }
     // HBM copies: q only (the gradient is recomputed on reload), (p, rho) into the leaf's P-slot
     __device__ __forceinline__ void store_state(RegsT& X, bool q_, bool pr) {
-        const int nk = (int)nch;
+        constexpr int nk = NVX;  // the register kernels are instantiated per exact chunk count
         if (q_) {
             double* qn = Q(X.reg_q);
 #pragma unroll
@@ -677,7 +682,7 @@ struct Machine {
         }
     }
     __device__ __forceinline__ void flush_ring_slot(int sl, int64_t slot) {
-        const int nk = (int)nch;
+        constexpr int nk = NVX;  // the register kernels are instantiated per exact chunk count
         double2 tp[NVX], tr[NVX];
         ring_read(sl, tp, tr);
         double *pn = P(slot), *rn = R(slot);
@@ -687,7 +692,7 @@ struct Machine {
 
     // returns true when an out-of-line (rare) path ran
     __device__ __forceinline__ bool leaf_reg(RegsT& X) {
-        const int nk = (int)nch;
+        constexpr int nk = NVX;  // the register kernels are instantiated per exact chunk count
         const int64_t j = c->nleaf + 1, d = c->depth, dir = c->dir;
         const int db = dir > 0 ? 1 : 0;
         const int64_t near_idx = dir > 0 ? c->idx_right : c->idx_left;
@@ -711,6 +716,7 @@ struct Machine {
             X.sig_ok = true;
         }
         if (j == 1) { X.ring_leaf0 = -1; X.ring_leaf1 = -1; }
+        NPHIP_PHASE_FENCE();
         // ---- leapfrog (model parameters from LDS, neighbours by DPP, level-0 criterion in the same pass)
         const double eps = (double)c->lf_sign * c->step_size;
         const double h = 0.5 * eps;
@@ -783,8 +789,10 @@ struct Machine {
 #ifdef NPHIP_PROFILE
         const int64_t tp1 = (int64_t)__builtin_readcyclecounter();
 #endif
+        NPHIP_PHASE_FENCE();
         double v4[4] = {accK.x + accK.y, accL.x + accL.y, accE.x + accE.y, accS.x + accS.y};
         reduceN<W, 4>(v4, red);
+        NPHIP_PHASE_FENCE();
 #ifdef NPHIP_PROFILE
         const int64_t tp2 = (int64_t)__builtin_readcyclecounter();
         c->prof[0] += tp1 - tp0; c->prof[6] += tp2 - tp1;
@@ -815,6 +823,7 @@ struct Machine {
         c->prof[8] += tq - tp2;
 #endif
 
+        NPHIP_PHASE_FENCE();
         double T_ls = -dE, T_U = Unew, T_E = E;
         int64_t T_q = newq, T_idx = idx_new;
         c->curq = newq; c->curp = newp; c->idx_cur = idx_new;
@@ -852,11 +861,13 @@ struct Machine {
 #ifdef NPHIP_PROFILE
             { const int64_t t_ = (int64_t)__builtin_readcyclecounter(); c->prof[k == 0 ? 9 : 10] += t_ - tq; tq = t_; }
 #endif
+            NPHIP_PHASE_FENCE();
             const double ls = nphip_logaddexp(c->sub_ls[k], T_ls);
             bool take = T_ls >= ls;
             if (!take) take = merge_uniform(j, d, k) < nphip_exp(T_ls - ls);
             if (!take) { T_q = c->sub_q[k]; T_U = c->sub_U[k]; T_E = c->sub_E[k]; T_idx = c->sub_idx[k]; }
             T_ls = ls;
+            NPHIP_PHASE_FENCE();
 #ifdef NPHIP_PROFILE
             { const int64_t t_ = (int64_t)__builtin_readcyclecounter(); c->prof[11] += t_ - tq; tq = t_; }
 #endif
@@ -1452,7 +1463,11 @@ static hipError_t launch_w(const Args& a, const Args* d_args, int W, hipStream_t
         switch (a.reg_nv) {
             case 1: hipLaunchKernelGGL((k_advance<true, 1, 1>), g, b, 0, st, d_args, me, hr); break;
             case 2: hipLaunchKernelGGL((k_advance<true, 1, 2>), g, b, 0, st, d_args, me, hr); break;
+            case 3: hipLaunchKernelGGL((k_advance<true, 1, 3>), g, b, 0, st, d_args, me, hr); break;
             case 4: hipLaunchKernelGGL((k_advance<true, 1, 4>), g, b, 0, st, d_args, me, hr); break;
+            case 5: hipLaunchKernelGGL((k_advance<true, 1, 5>), g, b, 0, st, d_args, me, hr); break;
+            case 6: hipLaunchKernelGGL((k_advance<true, 1, 6>), g, b, 0, st, d_args, me, hr); break;
+            case 7: hipLaunchKernelGGL((k_advance<true, 1, 7>), g, b, 0, st, d_args, me, hr); break;
             case 8: hipLaunchKernelGGL((k_advance<true, 1, 8>), g, b, 0, st, d_args, me, hr); break;
             default: return hipErrorInvalidValue;
         }

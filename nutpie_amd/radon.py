@@ -47,7 +47,7 @@ def _extend_zero_sum(x):
     return torch.cat([x, fill], -1) - norm
 
 
-def radon_model(data=None, device=0, use_graph=False):
+def radon_model(data=None, device=0, use_graph=False, expand_on_device=True):
     """Returns a :class:`~nutpie_amd.compiled_pyfunc.TorchFuncModel` for the radon model."""
     import torch
 
@@ -108,9 +108,20 @@ def radon_model(data=None, device=0, use_graph=False):
             "county_floor_effect": craw * csd[:, None], "sigma": np.exp(x[:, o_lsig]),
         }
 
+    def expand_device(x):
+        """Same map as :func:`expand`, on the GPU (x: Tensor[N, D])."""
+        raw, craw = _extend_zero_sum(x[:, o_raw:o_raw + n - 1]), _extend_zero_sum(x[:, o_craw:o_craw + n - 1])
+        sd, csd = torch.exp(x[:, o_lsd]), torch.exp(x[:, o_lcsd])
+        return {
+            "intercept": x[:, o_int], "county_raw": raw, "county_sd": sd, "county_effect": raw * sd[:, None],
+            "floor_effect": x[:, o_floor], "county_floor_raw": craw, "county_floor_sd": csd,
+            "county_floor_effect": craw * csd[:, None], "sigma": torch.exp(x[:, o_lsig]),
+        }
+
     names = ["intercept", "county_raw", "county_sd", "county_effect", "floor_effect", "county_floor_raw", "county_floor_sd",
              "county_floor_effect", "sigma"]
     shapes = [(), (n,), (), (n,), (), (n,), (), (n,), ()]
     dims = {k: ("county",) for k in ("county_raw", "county_effect", "county_floor_raw", "county_floor_effect")}
-    model = from_torchfunc(D, make_logp, expand, shapes, names, coords={"county": np.arange(n)}, dims=dims, use_graph=use_graph)
+    model = from_torchfunc(D, make_logp, expand, shapes, names, coords={"county": np.arange(n)}, dims=dims, use_graph=use_graph,
+                           expand_device_fn=expand_device if expand_on_device else None)
     return model

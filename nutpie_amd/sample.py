@@ -81,6 +81,8 @@ class _BackgroundSampler:
         self._sampler = compiled_model._make_sampler(
             settings, init_mean, cores, None, progress_callback, progress_rate, None, **(engine_kwargs or {})
         )
+        # raw unconstrained draws only cross PCIe when somebody asked for them (device-expanding models)
+        self._sampler._keep_host_draws = bool(return_raw_trace or store_unconstrained or settings.store_unconstrained)
         self._stop = threading.Event()
         self._thread = None
         show_bar = bool(progress_bar) and sys.stderr.isatty()
@@ -142,9 +144,11 @@ class _BackgroundSampler:
             skips += ["divergence_start", "divergence_end", "divergence_momentum", "divergence_start_gradient"]
         if st.get("store_unconstrained", False) and results.draws is not None:
             stats["unconstrained_draw"] = results.draws
-        if results.draws is None:
-            raise RuntimeError("the sampler was run with store_draws=False; use return_raw_trace=True")
-        expanded = self._compiled_model._expand_draws(results.draws)
+        expanded = getattr(results, "expanded", None)
+        if expanded is None:
+            if results.draws is None:
+                raise RuntimeError("the sampler was run with store_draws=False; use return_raw_trace=True")
+            expanded = self._compiled_model._expand_draws(results.draws)
         attrs = {
             "inference_library": "nutpie",
             "inference_library_version": _lib.__version__,

@@ -183,6 +183,14 @@ def test_radon_torch_model_config3():
     tr2 = nutpie_amd.sample(radon_model(data, use_graph=True), chains=64, tune=50, draws=20, seed=7, progress_bar=False)
     tr3 = nutpie_amd.sample(radon_model(data), chains=64, tune=50, draws=20, seed=7, progress_bar=False)
     assert np.array_equal(tr2.posterior.sigma.values, tr3.posterior.sigma.values)
+    # expand step on the device (default) == expand step on the host, and only then are raw draws copied back
+    tr4 = nutpie_amd.sample(radon_model(data, expand_on_device=False), chains=64, tune=50, draws=20, seed=7, progress_bar=False,
+                            store_unconstrained=True)
+    for name in ("intercept", "county_effect", "county_floor_effect", "sigma", "county_sd"):
+        np.testing.assert_allclose(tr3.posterior[name].values, tr4.posterior[name].values, rtol=1e-13, atol=1e-15)
+    assert "unconstrained_draw" in tr4.sample_stats and "unconstrained_draw" not in tr3.sample_stats
+    raw = nutpie_amd.sample(radon_model(data), chains=8, tune=20, draws=5, seed=7, progress_bar=False, return_raw_trace=True)
+    assert raw.draws is not None and raw.expanded["sigma"].shape == (8, 25)
 
 
 def test_sharded_sampling_and_rccl_gather_single_rank(tmp_path):
