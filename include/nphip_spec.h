@@ -43,7 +43,8 @@
 enum {
     NPHIP_RNG_MOMENTUM = 1,    /* c0 = pair index j -> elements 2j,2j+1 ; c2 = draw            */
     NPHIP_RNG_DIRECTION = 2,   /* c0 = tree depth before the doubling   ; c2 = draw            */
-    NPHIP_RNG_MERGE = 3,       /* c0 = leaf index in doubling; c3 |= depth<<8 | level<<16      */
+    NPHIP_RNG_MERGE = 3,       /* c0 = leaf index in doubling; c3 |= depth<<8 | (level>>1)<<16; the merge at
+                                `level` uses words 2*(level&1), 2*(level&1)+1 of the block */
     NPHIP_RNG_INIT = 4,        /* c0 = pair index ; c2 = init attempt                          */
     NPHIP_RNG_SS_MOMENTUM = 5, /* c0 = pair index ; c2 = search id (0xffffffff at chain start, */
                                /*                    else the draw index that triggered it)   */
@@ -100,10 +101,9 @@ static __device__ __forceinline__ double nphip_kdev(double c) { asm volatile("" 
 #define NPHIP_K(c) (c)
 #endif
 
-NPHIP_HD double nphip_exp(double x) {
-    if (x != x) return x;
-    if (x > 709.782712893384) return INFINITY;
-    if (x < -745.2) return 0.0;
+/* (p, k) with exp(x) ~= p * 2^k, p in about [0.70, 1.42]: the reduction and the polynomial of nphip_exp, before
+ * the scaling.  |x| <= 1e9 so that k * ln2_hi is exact. */
+NPHIP_HD void nphip_exp_parts(double x, double* p_out, double* k_out) {
     double k = rint(x * NPHIP_K(0x1.71547652b82fep+0));
     double r = fma(-k, NPHIP_K(0x1.62e42fee00000p-1), x);
     r = fma(-k, NPHIP_K(0x1.a39ef35793c76p-33), r);
@@ -121,9 +121,53 @@ NPHIP_HD double nphip_exp(double x) {
     p = fma(p, r, 0.5);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
+    *p_out = p;
+    *k_out = k;
+}
+
+/* exp(x) from its parts (x is the original argument: it decides overflow / underflow) */
+NPHIP_HD double nphip_exp_scale(double x, double p, double k) {
+    if (x > 709.782712893384) return INFINITY;
+    if (x < -745.2) return 0.0;
     int ki = (int)k;
     int k1 = ki / 2, k2 = ki - k1;
     return (p * nphip_pow2i(k1)) * nphip_pow2i(k2);
+}
+
+NPHIP_HD double nphip_exp(double x) {
+    if (x != x) return x;
+    if (x > 709.782712893384) return INFINITY;
+    if (x < -745.2) return 0.0;
+    double p, k;
+    nphip_exp_parts(x, &p, &k);
+    return nphip_exp_scale(x, p, k);
+}
+
+/* ---- extended-range tree weights ---------------------------------------------------------------------------
+ * nuts-rs carries the multinomial weight of a (sub)tree as `log_size`, merges with logaddexp and accepts the
+ * other side's draw with probability exp(log_size_other - log_size_total).  The same weights are carried here
+ * as w = m * 2^e (m > 0 a double, e an integer, so nothing overflows for any finite energy error): a leaf's
+ * weight exp(-energy_error) is the (p, k) pair above, sums are aligned additions, and the acceptance test is
+ * u * w_total < w_other -- no log, exp or division per merge.  Same distribution, different rounding. */
+NPHIP_HD void nphip_w_leaf(double neg_energy_error, double* m, int64_t* e) {
+    double x = neg_energy_error;
+    if (x > 1e9) x = 1e9;
+    if (x < -1e9) x = -1e9;
+    double k;
+    nphip_exp_parts(x, m, &k);
+    *e = (int64_t)k;
+}
+/* m * 2^(e - E) for E >= e; contributions below 2^-1000 of the larger weight are dropped */
+NPHIP_HD double nphip_w_rel(double m, int64_t e, int64_t E) {
+    int64_t d = E - e;
+    if (d >= 1000) return 0.0;
+    return m * nphip_pow2i((int)-d);
+}
+/* (m1, e1) + (m2, e2), operands in this order */
+NPHIP_HD void nphip_w_add(double m1, int64_t e1, double m2, int64_t e2, double* m, int64_t* e) {
+    int64_t E = e1 >= e2 ? e1 : e2;
+    *m = nphip_w_rel(m1, e1, E) + nphip_w_rel(m2, e2, E);
+    *e = E;
 }
 
 /* log(x): x = 2^e m, m in [sqrt(1/2), sqrt(2)); s = (m-1)/(m+1);

@@ -66,15 +66,16 @@ struct Ctl {
     int64_t lf_srcq, lf_srcp, lf_newq, lf_newp, lf_sign;
     // trajectory / tree
     double H0;
-    double ls_main;
+    double main_wm;   // multinomial weight of the main tree = main_wm * 2^main_we (nphip_spec.h)
+    int64_t main_we;
     int64_t depth, dir, nleaf;
     int64_t idx_left, idx_right, idx_cur;
     int64_t endq[2], endp[2], endpar[2];
     int64_t curq, curp;
     int64_t cand_q, cand_idx;
     double cand_U, cand_E;
-    // acceptance collector (incremental means over the leapfrogs of the current draw)
-    double acc_mean, acc_sym_mean;
+    // acceptance collector (sums over the leapfrogs of the current draw; divided by n_steps when read)
+    double acc_sum, acc_sym_sum;
     int64_t n_steps;
     // info of the draw being finished (kept across a mid-adapt step-size search)
     int64_t fin_depth, fin_flags;
@@ -82,7 +83,8 @@ struct Ctl {
     // cycle counters per section (only advanced when built with -DNPHIP_PROFILE): leapfrog, tree, rare, count
     int64_t prof[16];
     // sub-tree stack
-    double sub_ls[kMaxDepthCap];
+    double sub_wm[kMaxDepthCap];
+    int64_t sub_we[kMaxDepthCap];
     double sub_U[kMaxDepthCap];
     double sub_E[kMaxDepthCap];
     int64_t sub_q[kMaxDepthCap];

@@ -806,16 +806,20 @@ struct Machine {
         const bool ok = isfinite(lp);
         const double Unew = -lp, E = K + Unew, dE = E - c->H0;
         const bool diverged = !ok || (dE > A.s.max_energy_error) || !isfinite(dE);
+        double T_wm = 1.0;
+        int64_t T_we = 0;
         {
-            double a = 0.0, asym = 0.0;
             if (!diverged) {
-                double e = nphip_exp(-dE);
-                a = e < 1.0 ? e : 1.0;
-                asym = 2.0 * a / (1.0 + e);
+                // one exp serves the collector and the leaf's multinomial weight (its (p, k) parts)
+                const double x = -dE, xc = x > 1e9 ? 1e9 : (x < -1e9 ? -1e9 : x);
+                double kk;
+                nphip_exp_parts(xc, &T_wm, &kk);
+                T_we = (int64_t)kk;
+                const double e = nphip_exp_scale(x, T_wm, kk);
+                const double a = e < 1.0 ? e : 1.0;
+                c->acc_sum += a;
+                c->acc_sym_sum += 2.0 * a / (1.0 + e);
             }
-            const double cnt = (double)c->n_steps;
-            c->acc_mean += (a - c->acc_mean) / cnt;
-            c->acc_sym_mean += (asym - c->acc_sym_mean) / cnt;
         }
         if (diverged) { X.dirty_qg = X.dirty_pr = false; rare_end_draw(A, c, red, chain, true, false, false, false, true); return true; }
 #ifdef NPHIP_PROFILE
@@ -824,7 +828,9 @@ struct Machine {
 #endif
 
         NPHIP_PHASE_FENCE();
-        double T_ls = -dE, T_U = Unew, T_E = E;
+        double T_U = Unew, T_E = E;
+        nphip_u32x4 mrg_blk = {{0u, 0u, 0u, 0u}};
+        int64_t mrg_id = -1;
         int64_t T_q = newq, T_idx = idx_new;
         c->curq = newq; c->curp = newp; c->idx_cur = idx_new;
         double2 obp[NVX], obr[NVX];  // one operand buffer (A.first, then A.last of the merge being checked)
@@ -862,11 +868,13 @@ struct Machine {
             { const int64_t t_ = (int64_t)__builtin_readcyclecounter(); c->prof[k == 0 ? 9 : 10] += t_ - tq; tq = t_; }
 #endif
             NPHIP_PHASE_FENCE();
-            const double ls = nphip_logaddexp(c->sub_ls[k], T_ls);
-            bool take = T_ls >= ls;
-            if (!take) take = merge_uniform(j, d, k) < nphip_exp(T_ls - ls);
-            if (!take) { T_q = c->sub_q[k]; T_U = c->sub_U[k]; T_E = c->sub_E[k]; T_idx = c->sub_idx[k]; }
-            T_ls = ls;
+            {   // multinomial merge: keep T's draw w.p. w_T / (w_A + w_T)
+                double sm; int64_t se;
+                nphip_w_add(c->sub_wm[k], c->sub_we[k], T_wm, T_we, &sm, &se);
+                const bool take = merge_uniform(j, d, k, mrg_blk, mrg_id) * sm < nphip_w_rel(T_wm, T_we, se);
+                if (!take) { T_q = c->sub_q[k]; T_U = c->sub_U[k]; T_E = c->sub_E[k]; T_idx = c->sub_idx[k]; }
+                T_wm = sm; T_we = se;
+            }
             NPHIP_PHASE_FENCE();
 #ifdef NPHIP_PROFILE
             { const int64_t t_ = (int64_t)__builtin_readcyclecounter(); c->prof[11] += t_ - tq; tq = t_; }
@@ -874,7 +882,7 @@ struct Machine {
             ++k;
         }
         if (k < d) {
-            c->sub_ls[k] = T_ls; c->sub_q[k] = T_q; c->sub_U[k] = T_U; c->sub_E[k] = T_E; c->sub_idx[k] = T_idx;
+            c->sub_wm[k] = T_wm; c->sub_we[k] = T_we; c->sub_q[k] = T_q; c->sub_U[k] = T_U; c->sub_E[k] = T_E; c->sub_idx[k] = T_idx;
             // ---- stores, last: q when the leaf is referenced as a candidate; (p, rho) only for leaves a level >= 2
             // merge reads back from HBM (leaf % 4 == 0: A.last, leaf % 8 == 1: A.first)
 #ifdef NPHIP_PROFILE
@@ -913,11 +921,14 @@ struct Machine {
         c->endpar[db] ^= 1;
         if (dir > 0) c->idx_right = idx_new; else c->idx_left = idx_new;
         {
-            const double ls = nphip_logaddexp(c->ls_main, T_ls);
-            bool take = T_ls >= c->ls_main;
-            if (!take) take = merge_uniform(j, d, d) < nphip_exp(T_ls - c->ls_main);
+            // biased progressive sampling at the top level: take T's draw w.p. min(1, w_T / w_main)
+            double sm; int64_t se;
+            nphip_w_add(c->main_wm, c->main_we, T_wm, T_we, &sm, &se);
+            const double ref = nphip_w_rel(c->main_wm, c->main_we, se), oth = nphip_w_rel(T_wm, T_we, se);
+            bool take = oth >= ref;
+            if (!take) take = merge_uniform(j, d, d, mrg_blk, mrg_id) * ref < oth;
             if (take) { c->cand_q = T_q; c->cand_U = T_U; c->cand_E = T_E; c->cand_idx = T_idx; }
-            c->ls_main = ls;
+            c->main_wm = sm; c->main_we = se;
             c->depth = d + 1;
         }
         store_state(X, true, true);  // a new trajectory end is always written back
@@ -1127,13 +1138,13 @@ struct Machine {
         if (c->draw >= T) { finish_chain(PH_DONE, CE_NONE); return; }
         double K0 = sample_momentum(NPHIP_RNG_MOMENTUM, (uint32_t)c->draw);
         c->H0 = K0 + c->cand_U;
-        c->depth = 0; c->ls_main = 0.0;
+        c->depth = 0; c->main_wm = 1.0; c->main_we = 0;
         c->idx_left = 0; c->idx_right = 0;
         c->endq[0] = c->endq[1] = c->cand_q;
         c->endp[0] = c->endp[1] = kSlotInit;
         c->endpar[0] = c->endpar[1] = 0;
         c->cand_idx = 0; c->cand_E = c->H0;
-        c->acc_mean = 0.0; c->acc_sym_mean = 0.0; c->n_steps = 0;
+        c->acc_sum = 0.0; c->acc_sym_sum = 0.0; c->n_steps = 0;
         start_doubling();
     }
 
@@ -1159,10 +1170,15 @@ struct Machine {
         c->phase = PH_TREE;
     }
 
-    __device__ double merge_uniform(int64_t j, int64_t d, int64_t k) const {
-        uint32_t c3 = (uint32_t)NPHIP_RNG_MERGE | ((uint32_t)d << 8) | ((uint32_t)k << 16);
-        nphip_u32x4 r = nphip_philox(A.s.seed, (uint32_t)j, gchain, (uint32_t)c->draw, c3);
-        return nphip_u01(r.v[0], r.v[1]);
+    // one Philox block serves two merge levels of a leaf (words 0,1 for even levels, 2,3 for odd ones)
+    __device__ __forceinline__ double merge_uniform(int64_t j, int64_t d, int64_t k, nphip_u32x4& blk, int64_t& blk_id) const {
+        const int64_t id = k >> 1;
+        if (blk_id != id) {
+            const uint32_t c3 = (uint32_t)NPHIP_RNG_MERGE | ((uint32_t)d << 8) | ((uint32_t)id << 16);
+            blk = nphip_philox(A.s.seed, (uint32_t)j, gchain, (uint32_t)c->draw, c3);
+            blk_id = id;
+        }
+        return (k & 1) ? nphip_u01(blk.v[2], blk.v[3]) : nphip_u01(blk.v[0], blk.v[1]);
     }
 
     // one leapfrog of the tree has been evaluated: NutsTree::extend / merge_into, unrolled
@@ -1178,23 +1194,29 @@ struct Machine {
         const bool ok = (code == 0) && isfinite(lp);
         const double Unew = -lp, E = K + Unew, dE = E - c->H0;
         const bool diverged = !ok || (dE > A.s.max_energy_error) || !isfinite(dE);
+        double T_wm = 1.0;
+        int64_t T_we = 0;
         // AcceptanceRateCollector
         {
-            double a = 0.0, asym = 0.0;
             if (!diverged) {
-                double e = nphip_exp(-dE);
-                a = e < 1.0 ? e : 1.0;
-                asym = 2.0 * a / (1.0 + e);
+                // one exp serves the collector and the leaf's multinomial weight (its (p, k) parts)
+                const double x = -dE, xc = x > 1e9 ? 1e9 : (x < -1e9 ? -1e9 : x);
+                double kk;
+                nphip_exp_parts(xc, &T_wm, &kk);
+                T_we = (int64_t)kk;
+                const double e = nphip_exp_scale(x, T_wm, kk);
+                const double a = e < 1.0 ? e : 1.0;
+                c->acc_sum += a;
+                c->acc_sym_sum += 2.0 * a / (1.0 + e);
             }
-            const double cnt = (double)c->n_steps;
-            c->acc_mean += (a - c->acc_mean) / cnt;
-            c->acc_sym_mean += (asym - c->acc_sym_mean) / cnt;
         }
         if (diverged) { rare_end_draw(A, c, red, chain, true, false, true, ok); return true; }
 
         const int64_t near_idx = dir > 0 ? c->idx_right : c->idx_left;
         const int64_t sT_last = c->lf_newp;
-        double T_ls = -dE, T_U = Unew, T_E = E;
+        double T_U = Unew, T_E = E;
+        nphip_u32x4 mrg_blk = {{0u, 0u, 0u, 0u}};
+        int64_t mrg_id = -1;
         int64_t T_q = c->lf_newq, T_idx = idx_new;
         c->curq = c->lf_newq; c->curp = c->lf_newp; c->idx_cur = idx_new;
         const bool check = A.s.check_turning && (d + 1 > A.s.mindepth);
@@ -1220,15 +1242,17 @@ struct Machine {
                 }
                 if (turn) { rare_end_draw(A, c, red, chain, false, false, false, false); return true; }
             }
-            const double ls = nphip_logaddexp(c->sub_ls[k], T_ls);
-            bool take = T_ls >= ls;
-            if (!take) take = merge_uniform(j, d, k) < nphip_exp(T_ls - ls);
-            if (!take) { T_q = c->sub_q[k]; T_U = c->sub_U[k]; T_E = c->sub_E[k]; T_idx = c->sub_idx[k]; }
-            T_ls = ls;
+            {   // multinomial merge: keep T's draw w.p. w_T / (w_A + w_T)
+                double sm; int64_t se;
+                nphip_w_add(c->sub_wm[k], c->sub_we[k], T_wm, T_we, &sm, &se);
+                const bool take = merge_uniform(j, d, k, mrg_blk, mrg_id) * sm < nphip_w_rel(T_wm, T_we, se);
+                if (!take) { T_q = c->sub_q[k]; T_U = c->sub_U[k]; T_E = c->sub_E[k]; T_idx = c->sub_idx[k]; }
+                T_wm = sm; T_we = se;
+            }
             ++k;
         }
         if (k < d) {
-            c->sub_ls[k] = T_ls; c->sub_q[k] = T_q; c->sub_U[k] = T_U; c->sub_E[k] = T_E; c->sub_idx[k] = T_idx;
+            c->sub_wm[k] = T_wm; c->sub_we[k] = T_we; c->sub_q[k] = T_q; c->sub_U[k] = T_U; c->sub_E[k] = T_E; c->sub_idx[k] = T_idx;
             issue_leaf();
             return false;
         }
@@ -1244,11 +1268,14 @@ struct Machine {
         c->endpar[db] ^= 1;
         if (dir > 0) c->idx_right = idx_new; else c->idx_left = idx_new;
         {
-            const double ls = nphip_logaddexp(c->ls_main, T_ls);
-            bool take = T_ls >= c->ls_main;
-            if (!take) take = merge_uniform(j, d, d) < nphip_exp(T_ls - c->ls_main);
+            // biased progressive sampling at the top level: take T's draw w.p. min(1, w_T / w_main)
+            double sm; int64_t se;
+            nphip_w_add(c->main_wm, c->main_we, T_wm, T_we, &sm, &se);
+            const double ref = nphip_w_rel(c->main_wm, c->main_we, se), oth = nphip_w_rel(T_wm, T_we, se);
+            bool take = oth >= ref;
+            if (!take) take = merge_uniform(j, d, d, mrg_blk, mrg_id) * ref < oth;
             if (take) { c->cand_q = T_q; c->cand_U = T_U; c->cand_E = T_E; c->cand_idx = T_idx; }
-            c->ls_main = ls;
+            c->main_wm = sm; c->main_we = se;
             c->depth = d + 1;
         }
         if (turn) { rare_end_draw(A, c, red, chain, false, false, false, false); return true; }
@@ -1283,6 +1310,9 @@ struct Machine {
         c->fin_eerr = c->cand_E - c->H0;  // H0 is reused by a mid-adapt step-size search
         c->n_div += diverging ? 1 : 0;
         c->latest_steps = c->n_steps;
+        // the collector's sums become the draw's means (a draw has at least one leapfrog)
+        c->acc_sum = c->acc_sum / (double)c->n_steps;
+        c->acc_sym_sum = c->acc_sym_sum / (double)c->n_steps;
         const bool good = diverging ? (c->cand_idx != 0) : true;
         const int64_t draw = c->draw;
         bool need_search = false;
@@ -1308,12 +1338,12 @@ struct Machine {
             } else {
                 position_pass(draw, false, false, false, 0, 0);
             }
-            da_advance(is_late ? c->acc_sym_mean : c->acc_mean);
+            da_advance(is_late ? c->acc_sym_sum : c->acc_sum);
             if (did_change && c->has_initial_mm) { c->has_initial_mm = 0; need_search = true; }
             else update_stepsize(draw, false);
         } else {
             position_pass(draw, false, false, false, 0, 0);
-            da_advance(c->acc_sym_mean);
+            da_advance(c->acc_sym_sum);
             update_stepsize(draw, draw == A.s.num_tune - 1);
         }
         if (need_search) { start_ss(draw); return; }
@@ -1335,8 +1365,8 @@ struct Machine {
             A.st_logp[o] = -c->cand_U;
             A.st_step[o] = c->step_size;
             A.st_step_bar[o] = nphip_exp(c->da_log_step_adapted);
-            A.st_accept[o] = c->acc_mean;
-            A.st_accept_sym[o] = c->acc_sym_mean;
+            A.st_accept[o] = c->acc_sum;
+            A.st_accept_sym[o] = c->acc_sym_sum;
         }
         c->draw = draw + 1;
         begin_draw();

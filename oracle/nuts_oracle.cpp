@@ -68,6 +68,42 @@ double u01(uint32_t hi, uint32_t lo) {
 
 const double LN2_HI = 0x1.62e42fee00000p-1, LN2_LO = 0x1.a39ef35793c76p-33, INV_LN2 = 0x1.71547652b82fep+0;
 
+static void det_exp_parts(double x, double* p_out, double* k_out);
+
+// Extended-range tree weights w = m * 2^e (restates the "extended-range tree weights" block of nphip_spec.h):
+// the multinomial weights nuts-rs carries as log_size [A.3], without leaving the linear domain.
+struct Weight { double m = 1.0; int64_t e = 0; };
+Weight w_leaf(double neg_energy_error) {
+    double x = std::min(std::max(neg_energy_error, -1e9), 1e9);
+    Weight w; double k;
+    det_exp_parts(x, &w.m, &k);
+    w.e = (int64_t)k;
+    return w;
+}
+double w_rel(const Weight& w, int64_t E) {  // w / 2^E, E >= w.e
+    const int64_t d = E - w.e;
+    return d >= 1000 ? 0.0 : w.m * std::ldexp(1.0, (int)-d);
+}
+Weight w_add(const Weight& a, const Weight& b) {
+    Weight o;
+    o.e = std::max(a.e, b.e);
+    o.m = w_rel(a, o.e) + w_rel(b, o.e);
+    return o;
+}
+
+static void det_exp_parts(double x, double* p_out, double* k_out) {
+    static const double inv_fact[14] = {1.0, 1.0, 0.5, 0.16666666666666666, 0.041666666666666664,
+                                        0.008333333333333333, 0.001388888888888889, 0.0001984126984126984,
+                                        2.48015873015873e-05, 2.7557319223985893e-06, 2.755731922398589e-07,
+                                        2.505210838544172e-08, 2.08767569878681e-09, 1.6059043836821613e-10};
+    double k = std::nearbyint(x * INV_LN2);
+    double r = std::fma(-k, LN2_HI, x);
+    r = std::fma(-k, LN2_LO, r);
+    double p = inv_fact[13];
+    for (int n = 12; n >= 0; --n) p = std::fma(p, r, inv_fact[n]);
+    *p_out = p; *k_out = k;
+}
+
 double det_exp(double x) {
     if (std::isnan(x)) return x;
     if (x > 709.782712893384) return INFINITY;
@@ -286,8 +322,16 @@ struct RunningMean {
     void reset() { sum = 0.0; count = 0; }
     void add(double v) { count += 1; sum += (v - sum) / (double)count; }
 };
+// Acceptance-statistic means are kept as (sum, count) and divided when read (nuts-rs updates a running mean per
+// leapfrog; same value up to rounding, two divisions fewer per leapfrog on the device).
+struct SumMean {
+    uint64_t count = 0; double total = 0.0;
+    void reset() { count = 0; total = 0.0; }
+    void add(double v) { count += 1; total += v; }
+    double value() const { return count ? total / (double)count : 0.0; }
+};
 struct Collector {
-    RunningMean mean, mean_sym;
+    SumMean mean, mean_sym;
     void register_init() { mean.reset(); mean_sym.reset(); }
     void register_leapfrog(const State* end, bool diverged) {
         if (diverged) { mean.add(0.0); mean_sym.add(0.0); return; }
@@ -409,7 +453,9 @@ enum class Ext { Ok, Turning, Diverging, Fatal };
 
 struct Tree {
     StateP left, right, draw;
-    double log_size = 0.0;
+    // multinomial weight of the tree, nuts-rs `log_size`, carried as w.m * 2^w.e (nphip_spec.h, "extended-range
+    // tree weights")
+    Weight w;
     uint64_t depth = 0;
     bool is_main = false;
 
@@ -422,24 +468,28 @@ struct Tree {
         if (r != Leap::Ok) return r;
         out->left = end; out->right = end; out->draw = end;
         out->depth = 0; out->is_main = false;
-        out->log_size = -end->energy_error();
+        out->w = w_leaf(-end->energy_error());
         return Leap::Ok;
     }
 
     // merge_into: multinomial inside sub-trees, biased progressive at the top level
     void merge_into(Tree&& other, int dir, DrawCtx& ctx) {
         if (dir > 0) right = other.right; else left = other.left;
-        double ls = det_logaddexp(log_size, other.log_size);
-        double self_ls = is_main ? log_size : ls;
-        bool take = other.log_size >= self_ls;
+        // sub-trees: accept other's draw w.p. w_other / (w_self + w_other); main tree (biased progressive
+        // sampling): w.p. min(1, w_other / w_self)
+        const Weight sum = w_add(w, other.w);
+        const double ref = is_main ? w_rel(w, sum.e) : sum.m;
+        const double oth = w_rel(other.w, sum.e);
+        bool take = is_main && (oth >= ref);
         if (!take) {
-            uint32_t c3 = (uint32_t)RNG_MERGE | (ctx.doubling_depth << 8) | ((uint32_t)depth << 16);
+            uint32_t c3 = (uint32_t)RNG_MERGE | (ctx.doubling_depth << 8) | ((uint32_t)(depth >> 1) << 16);
             U4 r = philox(ctx.seed, ctx.leaf, ctx.chain, ctx.draw, c3);
-            take = u01(r.v[0], r.v[1]) < det_exp(other.log_size - self_ls);
+            const int w0 = 2 * (int)(depth & 1);
+            take = u01(r.v[w0], r.v[w0 + 1]) * ref < oth;
         }
         if (take) draw = other.draw;
         depth += 1;
-        log_size = ls;
+        w = sum;
     }
 
     // extend (recursive doubling of `this` in direction dir)
@@ -576,14 +626,14 @@ struct Chain {
         Leap r = H.leapfrog(*st, +1, &c, &nxt, &info);
         if (r == Leap::Fatal) return false;
         if (r != Leap::Ok) { da.init(S.initial_step, S.da_k, S.da_t0, S.da_gamma); return true; }
-        double accept = c.mean.sum;
+        double accept = c.mean.value();
         int dir = accept > S.target_accept ? +1 : -1;
         for (int it = 0; it < 100; ++it) {
             Collector c2; c2.register_init();
             r = H.leapfrog(*st, dir, &c2, &nxt, &info);
             if (r == Leap::Fatal) return false;
             if (r != Leap::Ok) { H.step_size = S.initial_step; da.init(S.initial_step, S.da_k, S.da_t0, S.da_gamma); return true; }
-            accept = c2.mean.sum;
+            accept = c2.mean.value();
             if (dir > 0) {
                 if (accept <= S.target_accept || H.step_size > 1e5) { da.init(H.step_size, S.da_k, S.da_t0, S.da_gamma); return true; }
                 H.step_size *= 2.0;
@@ -661,8 +711,8 @@ struct Chain {
 
     // GlobalStrategy::adapt [A.8]
     bool adapt(uint64_t draw, bool draw_is_good) {
-        last_accept = col.mean.sum;
-        last_accept_sym = col.mean_sym.sum;
+        last_accept = col.mean.value();
+        last_accept_sym = col.mean_sym.value();
         if (draw >= S.num_tune) { tuning = false; return true; }
         if (draw < final_window) {
             bool is_early = draw < early_end;
@@ -705,7 +755,7 @@ struct Chain {
         col.register_init();
         Tree tree;
         tree.left = init; tree.right = init; tree.draw = init;
-        tree.depth = 0; tree.log_size = 0.0; tree.is_main = true;
+        tree.depth = 0; tree.w = Weight{}; tree.is_main = true;
         DrawCtx ctx{S.seed, chain_id, (uint32_t)draw_idx};
         DivergenceInfo dinfo;
         while (tree.depth < S.maxdepth) {
@@ -761,7 +811,7 @@ int run_sampler(const oracle_settings_t* S, uint64_t dim, MakeModel make_model, 
                 double energy = st->energy(), eerr = st->energy_error();
                 int64_t idx = st->idx;
                 uint64_t n_steps = chain.col.mean.count;
-                double mta = chain.col.mean.sum, mtas = chain.col.mean_sym.sum;
+                double mta = chain.col.mean.value(), mtas = chain.col.mean_sym.value();
                 chain.cur = st;
                 if (!chain.adapt(d, good)) {
                     std::lock_guard<std::mutex> lk(g_error_mutex);
