@@ -55,8 +55,10 @@ __device__ __forceinline__ void chain_sync() {
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double x) {
     int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    // every lane is active and every source lane of these permutations exists: no "old" value to tie the
+    // destination to (saves the two register copies per stage update_dpp(old = x, ...) costs)
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double swz16_f64(double x) {  // value of lane l ^ 16
@@ -1445,7 +1447,7 @@ struct Machine {
 // `Ap` points to the engine's argument block in device memory (written once at set-up); it is read through
 // the constant address space, i.e. with scalar loads into SGPRs.  Per-launch scalars are kernel parameters.
 template <bool FUSED, int W, int NV>
-__global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k_advance(const Args* __restrict__ Ap, int max_evals, int have_result) {
+__global__ __launch_bounds__(W == 1 ? 256 : 64 * W) __attribute__((amdgpu_waves_per_eu((NV > 0 && NV <= 4) ? 2 : 1, (NV > 0 && NV <= 4) ? 2 : 8))) void k_advance(const Args* __restrict__ Ap, int max_evals, int have_result) {
     const NPHIP_CONST Args& A = *(const NPHIP_CONST Args*)Ap;
     constexpr int WAVES = (W == 1) ? 4 : W;
     __shared__ Ctl s_ctl[WAVES];
