@@ -38,9 +38,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
-# HBM bytes per leapfrog of the register-resident kernel at D = 1000, from the PMC passes in profiles/r1_v3_pmc.txt:
+# HBM bytes per leapfrog of the register-resident kernel at D = 1000, from the PMC passes in profiles/r1_v4_pmc.txt:
 # (2 x FETCH_SIZE + WRITE_SIZE) KB per launch / 262144 leapfrogs  (gfx950 FETCH_SIZE correction, MI355X_MICROARCH.md)
-MEASURED_HBM_BYTES_PER_LEAPFROG_D1000 = 22379.0
+MEASURED_HBM_BYTES_PER_LEAPFROG_D1000 = 21499.0
 
 
 def parse():
@@ -219,7 +219,7 @@ def main():
                    "chains_tuning_at_start": int(tuning0), "chains_tuning_at_end": int(tuning1), "parallelism": f"chains{world}"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": (MEASURED_HBM_BYTES_PER_LEAPFROG_D1000 * leap_per_launch if (args.dim == 1000 and W == 1) else None),
-                     "traffic_source": "rocprofv3 PMC FETCH_SIZE/WRITE_SIZE passes, profiles/r1_v3_pmc.txt (bytes per launch)",
+                     "traffic_source": "rocprofv3 PMC FETCH_SIZE/WRITE_SIZE passes, profiles/r1_v4_pmc.txt (bytes per launch)",
                      "kernel": "k_advance<fused,W=1,NV=8>", "avg_kernel_ms": 1000.0 * avg_kernel_s,
                      "algorithmic_bytes_per_leapfrog": bytes_per_leapfrog},
     }
