@@ -135,7 +135,7 @@ typedef struct {
     void* staging_logp;
     int32_t no_register_kernel; /* 1: force the memory-resident kernel even where the register-resident
                                  * specialisation applies (A/B measurements, tests) */
-    int32_t reserved;
+    int32_t no_stream_cache;    /* 1: memory-resident fused kernels reload the cursor state every leapfrog (A/B, tests) */
 } nphip_launch_t;
 
 void nphip_launch_defaults(nphip_launch_t*);

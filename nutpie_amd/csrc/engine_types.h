@@ -143,6 +143,8 @@ struct Args {
     double* st_accept; double* st_accept_sym;
     // launch control
     int32_t reg_nv;       // >0: register-resident kernel with NV = reg_nv chunks per lane (fused, W == 1)
+    int32_t stream_cache; // 1: memory-resident fused kernel with the cursor's loads cached in VGPRs (NV < 0 instantiations)
+    int32_t pad0_;
     int32_t max_evals;    // fused: evaluations per chain this launch
     int32_t have_result;  // callbacks: geval/ueval hold the answer to the pending request
     unsigned long long* counters;  // [0] chains done, [1] chains in error

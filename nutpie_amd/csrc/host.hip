@@ -531,6 +531,9 @@ bool nphip_sampler::setup() {
         const int nchunks = (int)(args.ld / 128);  // one kernel instantiation per exact chunk count (straight-line code)
         if (nchunks <= 8) args.reg_nv = nchunks;
     }
+    // memory-resident fused kernel, one wave per chain (store_divergences, no_register_kernel): cache the cursor's
+    // (sigma^2, grad, p, rho) in VGPRs between leaves.  With more waves per chain the cache costs occupancy (measured).
+    args.stream_cache = (fused && !args.reg_nv && W == 1 && !launch.no_stream_cache && args.ld / 128 <= 8) ? 1 : 0;
 
     if (!dalloc(&args.ctl, n)) return false;
     if (!dalloc(&args.qpool, n * args.nqpool * 2 * ld)) return false;

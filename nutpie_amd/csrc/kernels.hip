@@ -157,12 +157,25 @@ struct Regs {
     }
 };
 
+// Streaming cache (NV < 0, -NV chunks per wave): sigma^2 and the cursor's (grad, p, rho) of this wave's chunks stay
+// in VGPRs between consecutive leaves of the memory-resident kernels.  Every store still happens — memory stays
+// complete, so rare paths, merge criteria and chunk-edge recomputation are untouched — the loads do not.
+template <int NS, bool CG>
+struct SCache {
+    double2 s[NS], g[CG ? NS : 1], p[NS], r[NS];
+    int64_t tag_q = -1, tag_p = -1;
+    bool sig_ok = false;
+    __device__ __forceinline__ void invalidate() { tag_q = -1; tag_p = -1; sig_ok = false; }
+};
+
 // NV > 0 selects the register-resident specialisation (requires FUSED and W == 1, dim <= 128 * NV):
 // the cursor state (q, grad, p, rho) and sigma^2 live in VGPRs across leapfrogs, so a leapfrog issues
 // no loads at all — only the stores of the new state, which later U-turn checks / draws may read.
 template <bool FUSED, int W, int NV = 0>
 struct Machine {
     static constexpr int NVX = NV > 0 ? NV : 1;
+    static constexpr int NSX = NV < 0 ? (-NV) % 100 : 1;   // NV = -NS: cache (sigma^2, grad, p, rho); NV = -(100 + NS): all but grad
+    static constexpr bool SCG = NV < 0 && (-NV) < 100;
     // kernel arguments, read through the constant address space: s_load into SGPRs (uniform), never flat
     const NPHIP_CONST Args& A;
     LdsCtl c;        // this wave's private LDS copy
@@ -179,6 +192,7 @@ struct Machine {
     double* est;
     int64_t T;
     using RegsT = Regs<NVX>;
+    using SCacheT = SCache<NSX, SCG>;
 
     __device__ __forceinline__ Machine(const NPHIP_CONST Args& a, LdsCtl ctl, LdsDouble r, int64_t ch, LdsDouble par_ = nullptr, LdsDouble ring_ = nullptr)
         : A(a), c(ctl), red(r), par(par_), ring(ring_), chain(ch), gchain((uint32_t)(a.chain_offset + ch)) {
@@ -372,7 +386,7 @@ struct Machine {
         const double ph = fma(h, ld1(g, e), ld1(p, e));
         return fma(eps, ld1(sig2, e) * ph, ld1(q, e)) - ld1(A.m_mu, e);
     }
-    __device__ double lf_stream(double& lp, int64_t idx_new, bool& turn0) {
+    __device__ __forceinline__ double lf_stream(double& lp, int64_t idx_new, bool& turn0, SCacheT& Y) {
         const int64_t srcq = c->lf_srcq, srcp = c->lf_srcp, newq = c->lf_newq, newp = c->lf_newp;
         const double eps = (double)c->lf_sign * c->step_size;
         const double h = 0.5 * eps;
@@ -380,10 +394,28 @@ struct Machine {
         const double *q = Q(srcq), *g = G(srcq), *p = P(srcp), *r = R(srcp);
         double *qn = Q(newq), *gn = G(newq), *pn = P(newp), *rn = R(newp);
         double2 accK = {0.0, 0.0}, accL = {0.0, 0.0}, accE = {0.0, 0.0}, accS = {0.0, 0.0};
-        NPHIP_FOR_CHUNKS(i) {
-            const double2 q2 = ld2(q, i), g2 = ld2(g, i), p2 = ld2(p, i), r2 = ld2(r, i), s2 = ld2(sig2, i);
+        if (NV < 0) {
+            // fill the cache where the cursor moved (new doubling, rare path) — normally nothing to do
+            if (!Y.sig_ok) {
+#pragma unroll
+                for (int k = 0; k < NSX; ++k) { const int64_t cc = wave + (int64_t)k * W; if (cc < nch) Y.s[k] = ld2(sig2, cc * NPHIP_CHUNK + 2 * lane); }
+                Y.sig_ok = true;
+            }
+            if (SCG && Y.tag_q != srcq) {
+#pragma unroll
+                for (int k = 0; k < NSX; ++k) { const int64_t cc = wave + (int64_t)k * W; if (cc < nch) Y.g[k] = ld2(g, cc * NPHIP_CHUNK + 2 * lane); }
+            }
+            if (Y.tag_p != srcp) {
+#pragma unroll
+                for (int k = 0; k < NSX; ++k) {
+                    const int64_t cc = wave + (int64_t)k * W;
+                    if (cc < nch) { Y.p[k] = ld2(p, cc * NPHIP_CHUNK + 2 * lane); Y.r[k] = ld2(r, cc * NPHIP_CHUNK + 2 * lane); }
+                }
+            }
+        }
+        auto body = [&](const int64_t i, const double2 q2, const double2 g2, const double2 p2, const double2 r2, const double2 s2,
+                        double2& gg, double2& pv, double2& rr) {
             const double2 mu = ld2(A.m_mu, i), a = ld2(A.m_a, i), b = ld2(A.m_b, i);   // b pads are -0.0 (host)
-            const double bl_edge = (i > 0) ? ld1(A.m_b, i - 1) : -0.0;
             double2 ph, qq, z;
             ph.x = fma(h, g2.x, p2.x);
             ph.y = fma(h, g2.y, p2.y);
@@ -396,7 +428,6 @@ struct Machine {
             const double zl_edge = (c0 > 0) ? edge_z(q, g, p, c0 - 1, eps, h) : 0.0;
             const double zr_edge = (c0 + NPHIP_CHUNK < ld) ? edge_z(q, g, p, c0 + NPHIP_CHUNK, eps, h) : 0.0;
             const double bl = wave_shr1(b.y, (c0 > 0) ? ld1(A.m_b, c0 - 1) : -0.0);
-            (void)bl_edge;
             const double zl = wave_shr1(z.y, zl_edge);
             const double zr = wave_shl1(z.x, zr_edge);
             double tx = a.x * z.x;
@@ -405,7 +436,6 @@ struct Machine {
             double ty = a.y * z.y;
             ty = fma(b.x, z.x, ty);
             ty = fma(b.y, zr, ty);
-            double2 gg, pv, rr;
             gg.x = -tx;
             gg.y = -ty;
             accL.x = fma(z.x, gg.x, accL.x);
@@ -423,6 +453,35 @@ struct Machine {
             accS.x = fma(tx0, s2.x * p2.x, accS.x);
             accS.y = fma(ty0, s2.y * p2.y, accS.y);
             st2(qn, i, qq); st2(gn, i, gg); st2(pn, i, pv); st2(rn, i, rr);
+        };
+        if (NV < 0) {
+            // the only state loads left: q (and grad where it is not cached) of every chunk, issued back to back so
+            // that they are all in flight together (chunks past the end re-read the last one; never used)
+            double2 qv[NSX], gv[SCG ? 1 : NSX];
+#pragma unroll
+            for (int k = 0; k < NSX; ++k) {
+                int64_t cc = wave + (int64_t)k * W;
+                cc = cc < nch ? cc : nch - 1;
+                qv[k] = ld2(q, cc * NPHIP_CHUNK + 2 * lane);
+                if (!SCG) gv[SCG ? 0 : k] = ld2(g, cc * NPHIP_CHUNK + 2 * lane);
+            }
+#pragma unroll
+            for (int k = 0; k < NSX; ++k) {
+                const int64_t cc = wave + (int64_t)k * W;
+                if (cc < nch) {
+                    double2 gg, pv, rr;
+                    body(cc * NPHIP_CHUNK + 2 * lane, qv[k], SCG ? Y.g[SCG ? k : 0] : gv[SCG ? 0 : k], Y.p[k], Y.r[k], Y.s[k], gg, pv, rr);
+                    if (SCG) Y.g[SCG ? k : 0] = gg;
+                    Y.p[k] = pv; Y.r[k] = rr;
+                }
+            }
+            Y.tag_q = newq;
+            Y.tag_p = newp;
+        } else {
+            NPHIP_FOR_CHUNKS(i) {
+                double2 gg, pv, rr;
+                body(i, ld2(q, i), ld2(g, i), ld2(p, i), ld2(r, i), ld2(sig2, i), gg, pv, rr);
+            }
         }
         double v[4] = {accK.x + accK.y, accL.x + accL.y, accE.x + accE.y, accS.x + accS.y};
         reduceN<W, 4>(v, red);
@@ -432,20 +491,40 @@ struct Machine {
     }
     // The three criteria of a sub-tree merge inside a doubling in ONE streaming pass (direction-free span):
     // (A.first, TL) || (A.last, TL) || (A.first, TF)
-    __device__ bool check3_stream(int64_t sA, int64_t sB, int64_t sTF, int64_t sTL) {
+    __device__ __forceinline__ bool check3_stream(int64_t sA, int64_t sB, int64_t sTF, int64_t sTL, SCacheT& Y) {
         const double *pa = P(sA), *ra = R(sA), *pb = P(sB), *rb = R(sB), *pf = P(sTF), *rf = R(sTF), *pl = P(sTL), *rl = R(sTL);
         double2 acc[6];
 #pragma unroll
         for (int n = 0; n < 6; ++n) { acc[n].x = 0.0; acc[n].y = 0.0; }
-        NPHIP_FOR_CHUNKS(i) {
-            const double2 xa = ld2(pa, i), xra = ld2(ra, i), xb = ld2(pb, i), xrb = ld2(rb, i), xf = ld2(pf, i), xrf = ld2(rf, i);
-            const double2 xl = ld2(pl, i), xrl = ld2(rl, i), s2 = ld2(sig2, i);
+        auto body = [&](const double2 xa, const double2 xra, const double2 xb, const double2 xrb, const double2 xf, const double2 xrf,
+                        const double2 xl, const double2 xrl, const double2 s2) {
             span_acc(xa.x, xra.x, xl.x, xrl.x, s2.x, acc[0].x, acc[1].x);
             span_acc(xa.y, xra.y, xl.y, xrl.y, s2.y, acc[0].y, acc[1].y);
             span_acc(xb.x, xrb.x, xl.x, xrl.x, s2.x, acc[2].x, acc[3].x);
             span_acc(xb.y, xrb.y, xl.y, xrl.y, s2.y, acc[2].y, acc[3].y);
             span_acc(xa.x, xra.x, xf.x, xrf.x, s2.x, acc[4].x, acc[5].x);
             span_acc(xa.y, xra.y, xf.y, xrf.y, s2.y, acc[4].y, acc[5].y);
+        };
+        if (NV < 0 && Y.tag_p == sTL && Y.sig_ok) {   // T.last is the leaf just integrated: still in the cache
+            // operands of two chunks (12 vectors) in flight at a time
+#pragma unroll
+            for (int k0 = 0; k0 < NSX; k0 += 2) {
+                double2 o[2][6];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    int64_t cc = wave + (int64_t)(k0 + u) * W;
+                    cc = cc < nch ? cc : nch - 1;
+                    const int64_t i = cc * NPHIP_CHUNK + 2 * lane;
+                    o[u][0] = ld2(pa, i); o[u][1] = ld2(ra, i); o[u][2] = ld2(pb, i); o[u][3] = ld2(rb, i); o[u][4] = ld2(pf, i); o[u][5] = ld2(rf, i);
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int k = k0 + u;
+                    if (k < NSX && wave + (int64_t)k * W < nch) body(o[u][0], o[u][1], o[u][2], o[u][3], o[u][4], o[u][5], Y.p[k < NSX ? k : 0], Y.r[k < NSX ? k : 0], Y.s[k < NSX ? k : 0]);
+                }
+            }
+        } else {
+            NPHIP_FOR_CHUNKS(i) { body(ld2(pa, i), ld2(ra, i), ld2(pb, i), ld2(rb, i), ld2(pf, i), ld2(rf, i), ld2(pl, i), ld2(rl, i), ld2(sig2, i)); }
         }
         double v[6];
 #pragma unroll
@@ -675,7 +754,7 @@ struct Machine {
     }
     // launch boundary: everything that only lives on chip goes back to its HBM slot
     __device__ __forceinline__ void flush(RegsT& X) {
-        if (NV == 0) return;
+        if (NV <= 0) return;
         if (X.dirty_qg || X.dirty_pr) store_state(X, X.dirty_qg, X.dirty_pr);
         if (c->phase == PH_TREE) {
             const int64_t d = c->depth;
@@ -1185,7 +1264,7 @@ struct Machine {
 
     // one leapfrog of the tree has been evaluated: NutsTree::extend / merge_into, unrolled
     // returns true when a rare, non-inlined path ran (the register mirror must then be dropped)
-    __device__ __forceinline__ bool cont_tree(RegsT& X, double K, double lp, int64_t code, bool have_turn0, bool turn0) {
+    __device__ __forceinline__ bool cont_tree(RegsT& X, SCacheT& Y, double K, double lp, int64_t code, bool have_turn0, bool turn0) {
         if (code < 0) { finish_chain(PH_ERROR, CE_FATAL_LOGP); return true; }
         c->nleaf += 1;
         c->n_steps += 1;
@@ -1237,7 +1316,7 @@ struct Machine {
                     const int64_t tf = j - (1ll << k) + 1;  // first leaf of T
                     if (FUSED)
                         turn = check3_stream(sA_first, slot_last(__builtin_ctzll((unsigned long long)al), A.cap),
-                                             slot_first(__builtin_ctzll((unsigned long long)(tf - 1))), sT_last);
+                                             slot_first(__builtin_ctzll((unsigned long long)(tf - 1))), sT_last, Y);
                     else
                         turn = check_merge(X, 3, sA_first, iA_first, slot_last(__builtin_ctzll((unsigned long long)al), A.cap), near_idx + dir * al,
                                            slot_first(__builtin_ctzll((unsigned long long)(tf - 1))), near_idx + dir * tf, sT_last, idx_new);
@@ -1396,6 +1475,7 @@ struct Machine {
 
     __device__ __forceinline__ void run(int budget, bool have) {
         RegsT X;
+        SCacheT Y;
         for (;;) {
             const int64_t ph = c->phase;
             if (ph == PH_DONE || ph == PH_ERROR) break;
@@ -1421,14 +1501,14 @@ struct Machine {
                     if (FUSED) {
                         bool turn0 = false;
                         const bool even_leaf = ((c->nleaf + 1) & 1) == 0;
-                        const double K = lf_stream(lp, c->idx_cur + c->dir, turn0);
-                        rare = cont_tree(X, K, lp, code, even_leaf, turn0);
+                        const double K = lf_stream(lp, c->idx_cur + c->dir, turn0, Y);
+                        rare = cont_tree(X, Y, K, lp, code, even_leaf, turn0);
                     } else {
                         const double K = lf2(lp, code, c->idx_cur + c->dir);
-                        rare = cont_tree(X, K, lp, code, false, false);
+                        rare = cont_tree(X, Y, K, lp, code, false, false);
                     }
                 }
-                if (rare) X.invalidate();
+                if (rare) { X.invalidate(); Y.invalidate(); }
 #ifdef NPHIP_PROFILE
                 const int64_t t2 = (int64_t)__builtin_readcyclecounter();
                 c->prof[3] += 1;
@@ -1437,6 +1517,7 @@ struct Machine {
             } else {
                 rare_phase_fn(A, c, red, chain, ph);
                 X.invalidate();
+                Y.invalidate();
             }
         }
         flush(X);  // launch boundary: registers that hold the only copy of the cursor state go back to HBM
@@ -1503,6 +1584,12 @@ static hipError_t launch_w(const Args& a, const Args* d_args, int W, hipStream_t
             case 8: hipLaunchKernelGGL((k_advance<true, 1, 8>), g, b, 0, st, d_args, me, hr); break;
             default: return hipErrorInvalidValue;
         }
+        return hipGetLastError();
+    }
+    if (FUSED && a.stream_cache && W == 1) {
+        // memory-resident kernel with the cursor's (sigma^2, grad, p, rho) cached in VGPRs between leaves.  Measured
+        // with more waves per chain (D > 1024) the cache costs occupancy or spills and does not pay; W == 1 only.
+        hipLaunchKernelGGL((k_advance<true, 1, -8>), dim3((n + 3) / 4), dim3(256), 0, st, d_args, me, hr);
         return hipGetLastError();
     }
     switch (W) {

@@ -2,16 +2,16 @@ import sys, time, numpy as np
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nutpie_amd import _lib as hip
 from nutpie_amd.gaussian import ar1_gaussian
-def run(dim, chains, noreg, W=0, E=256, steps=40, warm=40):
+def run(dim, chains, noreg, W=0, E=256, steps=40, warm=40, nocache=False):
     model = ar1_gaussian(dim)
     s = hip.PyNutsSettings.Diag(20260926)
     s.update(num_tune=400, num_draws=(steps+warm+2)*E, num_chains=chains)
-    smp = hip.PySampler(s, hip.TridiagGaussianModel(model.diag, model.offdiag), waves_per_chain=W, store_draws=False, evals_per_launch=E, manual=True, no_register_kernel=noreg)
+    smp = hip.PySampler(s, hip.TridiagGaussianModel(model.diag, model.offdiag), waves_per_chain=W, store_draws=False, evals_per_launch=E, manual=True, no_register_kernel=noreg, no_stream_cache=nocache)
     smp.step(warm)
     n0 = sum(p.total_num_steps for p in smp.progress())
     t=time.perf_counter(); done, l, ms = smp.step(steps); el=time.perf_counter()-t
     n1 = sum(p.total_num_steps for p in smp.progress())
-    print(f"dim={dim} chains={chains} W={smp.waves_per_chain} noreg={noreg} E={E}: {(n1-n0)/el/1e6:.1f} M leapfrogs/s, kernel {ms/steps:.3f} ms/launch, {ms/steps/E*1e3:.2f} us/leapfrog/chain, alg {(n1-n0)*40*dim/(ms/1e3)/1e9:.0f} GB/s")
+    print(f"dim={dim} chains={chains} W={smp.waves_per_chain} noreg={noreg} nocache={nocache} E={E}: {(n1-n0)/el/1e6:.1f} M leapfrogs/s, kernel {ms/steps:.3f} ms/launch, {ms/steps/E*1e3:.2f} us/leapfrog/chain, alg {(n1-n0)*40*dim/(ms/1e3)/1e9:.0f} GB/s")
     import ctypes as C
     out=(C.c_int64*16)(); hip.lib().nphip_sampler_profile(smp._h, out); o=list(out)
     if o[3]: print(f"   cycles/leaf: total(hot) {o[1]/max(o[4],1):.0f} (n={o[4]}) = math {o[0]/o[3]:.0f} + reduce4 {o[6]/o[3]:.0f} + stores/issue {o[7]/max(o[4],1):.0f} + cascade(rest);  draw-end {o[2]/max(o[5],1):.0f} (n={o[5]})")

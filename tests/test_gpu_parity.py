@@ -13,6 +13,7 @@ import os
 import numpy as np
 import pytest
 
+from nutpie_amd.gaussian import ar1_gaussian
 from tests.conftest import GOLDEN, assert_trace_equal, fn_addr
 
 pytestmark = pytest.mark.gpu
@@ -146,6 +147,22 @@ def test_streaming_kernel_single_wave_bit_identical(hip, oracle, dim):
     want = oracle.sample_tridiag(oracle_settings(oracle, chains=6, tune=100, draws=40, seed=31, W=W), diag, off)
     assert W == 1
     assert_trace_equal(got, want)
+
+
+@pytest.mark.parametrize("dim,waves", [(130, 1), (700, 1), (1024, 1), (2000, 2)])
+def test_stream_cache_is_transparent(hip, oracle, dim, waves):
+    # memory-resident fused kernels keep the cursor's (sigma^2, grad, p, rho) in VGPRs between leaves (every store
+    # still happens): same trace as the kernel that reloads everything, and as the oracle
+    model = ar1_gaussian(dim)
+    kw = dict(chains=4, tune=30, draws=8, seed=dim, waves=waves)
+    m = hip.TridiagGaussianModel(model.diag, model.offdiag)
+    cached, W = run_engine(hip, m, launch=dict(no_register_kernel=True), **kw)
+    plain, _ = run_engine(hip, m, launch=dict(no_register_kernel=True, no_stream_cache=True), **kw)
+    assert W == waves
+    assert_trace_equal(cached, plain)
+    if dim <= 2000:
+        want = oracle.sample_tridiag(oracle_settings(oracle, chains=4, tune=30, draws=8, seed=dim, W=W), model.diag, model.offdiag)
+        assert_trace_equal(cached, want)
 
 
 @pytest.mark.parametrize("settings", [
