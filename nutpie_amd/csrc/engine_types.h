@@ -126,6 +126,7 @@ struct Args {
     const double* m_mu;   // [ld]
     const double* m_a;    // [ld]
     const double* m_b;    // [ld]
+    const double* m_bsh;  // [ld + 8]: m_bsh[i] = b_{i-1} (m_bsh[0] and the tail are -0.0): aligned (b_{i-1}, b_i) pairs
     // model: callbacks (dense staging, ld = dim)
     double* qeval;   // [n][dim]
     double* geval;   // [n][dim]

@@ -409,7 +409,7 @@ struct nphip_sampler {
     uint64_t n = 0, T = 0, dim = 0;
     std::vector<void*> allocs;
     std::vector<void*> pinned;
-    std::vector<double> bpad;  // staging of the padded off-diagonal (must outlive the async copy)
+    std::vector<double> bpad, bshpad;  // staging of the padded off-diagonal (must outlive the async copy)
     unsigned long long* h_counters = nullptr;  // pinned
     double *h_q = nullptr, *h_g = nullptr, *h_u = nullptr;  // pinned staging (host callback)
     int64_t* h_code = nullptr;
@@ -519,12 +519,20 @@ bool nphip_sampler::setup() {
     args.chain_offset = (int64_t)launch.chain_offset;
     args.dim = (int64_t)dim;
     args.ld = (int64_t)((dim + 127) / 128 * 128);
+    // register-resident kernels with several waves per chain (1024 < D <= 4096): every wave owns the same number of
+    // chunks, so the leading dimension is padded to a multiple of 128 * W (pads are exact zeros in every reduction)
+    const bool fused_model = (model.kind == 0);
+    int reg_multi = 0;
+    if (fused_model && (W == 2 || W == 4) && !launch.no_register_kernel && !set.store_divergences) {
+        const int64_t per_wave = ((int64_t)((dim + 127) / 128) + W - 1) / W;
+        if (per_wave >= 5 && per_wave <= 8) { reg_multi = (int)per_wave; args.ld = per_wave * W * 128; }
+    }
     args.cap = (int32_t)set.maxdepth;
     args.npslots = num_pslots(args.cap);
     args.nqpool = num_qpool(args.cap);
     const size_t ld = (size_t)args.ld;
     // register-resident specialisation: one wave per chain, state in VGPRs (dim <= 2048)
-    args.reg_nv = 0;
+    args.reg_nv = reg_multi;
     // (not with store_divergences: the divergence record needs the pre-step state, which only the
     //  memory-resident kernel keeps)
     if (fused && W == 1 && !launch.no_register_kernel && !set.store_divergences) {
@@ -552,6 +560,13 @@ bool nphip_sampler::setup() {
         std::copy(model.b.begin(), model.b.begin() + (dim > 0 ? dim - 1 : 0), bpad.begin());
         HIP_TRY(hipMemcpyAsync(b, bpad.data(), ld * 8, hipMemcpyHostToDevice, stream));
         args.m_mu = mu; args.m_a = a; args.m_b = b;
+        // shifted copy: m_bsh[i] = b_{i-1}, so that (b_{i-1}, b_i) is one aligned 16-byte load
+        double* bsh = nullptr;
+        if (!dalloc(&bsh, ld + 8)) return false;
+        bshpad.assign(ld + 8, -0.0);
+        std::copy(model.b.begin(), model.b.begin() + (dim > 0 ? dim - 1 : 0), bshpad.begin() + 1);
+        HIP_TRY(hipMemcpyAsync(bsh, bshpad.data(), (ld + 8) * 8, hipMemcpyHostToDevice, stream));
+        args.m_bsh = bsh;
     } else {
         if (launch.staging_q && launch.staging_grad && launch.staging_logp) {
             args.qeval = (double*)launch.staging_q; args.geval = (double*)launch.staging_grad; args.ueval = (double*)launch.staging_logp;

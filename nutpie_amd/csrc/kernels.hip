@@ -182,6 +182,7 @@ struct Machine {
     LdsDouble red;   // LDS reduction scratch [8*W]
     LdsDouble par;   // NV > 0: LDS copy of the fused model: mu[ld], a[ld], then b shifted by one (par_b[i] = b_{i-1})
     LdsDouble ring;  // NV > 0: this wave's LDS ring of two (p, rho) summaries: [slot][p|rho][NV*64 double2]
+    LdsDouble edge;  // NV > 0, W > 1: chunk-edge exchange buffer of the chain [2 * chunks]
     int64_t chain;   // local chain index
     uint32_t gchain; // global chain id (RNG key)
     int lane, wave;
@@ -194,8 +195,9 @@ struct Machine {
     using RegsT = Regs<NVX>;
     using SCacheT = SCache<NSX, SCG>;
 
-    __device__ __forceinline__ Machine(const NPHIP_CONST Args& a, LdsCtl ctl, LdsDouble r, int64_t ch, LdsDouble par_ = nullptr, LdsDouble ring_ = nullptr)
-        : A(a), c(ctl), red(r), par(par_), ring(ring_), chain(ch), gchain((uint32_t)(a.chain_offset + ch)) {
+    __device__ __forceinline__ Machine(const NPHIP_CONST Args& a, LdsCtl ctl, LdsDouble r, int64_t ch, LdsDouble par_ = nullptr, LdsDouble ring_ = nullptr,
+                                       LdsDouble edge_ = nullptr)
+        : A(a), c(ctl), red(r), par(par_), ring(ring_), edge(edge_), chain(ch), gchain((uint32_t)(a.chain_offset + ch)) {
         lane = threadIdx.x & 63;
         wave = (W == 1) ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
         D = a.dim; ld = a.ld; nch = ld / NPHIP_CHUNK;
@@ -577,7 +579,50 @@ struct Machine {
     }
 
     // ---- register-resident leapfrog (NV > 0): one fused pass, no loads when continuing from the cursor ----
-    __device__ __forceinline__ int64_t ridx(int k) const { return (int64_t)k * NPHIP_CHUNK + 2 * lane; }
+    // element pair of this lane in the k-th chunk this wave owns (chunk c belongs to wave c mod W)
+    __device__ __forceinline__ int64_t ridx(int k) const { return ((int64_t)k * W + wave) * NPHIP_CHUNK + 2 * lane; }
+
+
+    // ---- model parameters / chunk-edge neighbours of the register kernels --------------------------------------
+    // W == 1: parameters from the LDS copy, edges by v_readlane of the neighbouring chunk's registers.
+    // W  > 1: parameters from global memory (L2-resident, shared by all chains), edges through a small LDS buffer:
+    //         every wave publishes the first and last z of its chunks, one workgroup barrier, neighbours read back.
+    __device__ __forceinline__ double2 par_mu(int64_t i) const {
+        if (W == 1) return *(const NPHIP_LDS double2*)(par + i);
+        return ld2(A.m_mu, i);
+    }
+    __device__ __forceinline__ void par_ab(int64_t i, double2& a, double2& b01, double& b2) const {
+        if (W == 1) {
+            a = *(const NPHIP_LDS double2*)(par + ld + i);
+            b01 = *(const NPHIP_LDS double2*)(par + 2 * ld + i);   // b_{i-1}, b_i
+            b2 = par[2 * ld + i + 2];                               // b_{i+1}
+        } else {
+            a = ld2(A.m_a, i);
+            b01 = ld2(A.m_bsh, i);
+            b2 = ld1(A.m_bsh, i + 2);
+        }
+    }
+    __device__ __forceinline__ void publish_edges(const double2 (&z)[NVX]) {
+        if (W == 1) return;
+#pragma unroll
+        for (int k = 0; k < NVX; ++k) {
+            const int64_t cch = (int64_t)k * W + wave;
+            if (lane == 0) edge[2 * cch] = z[k].x;
+            if (lane == 63) edge[2 * cch + 1] = z[k].y;
+        }
+        __syncthreads();
+    }
+    __device__ __forceinline__ void edge_pair(const double2 (&z)[NVX], int k, double& zl, double& zr) const {
+        zl = 0.0; zr = 0.0;
+        if (W == 1) {
+            if (k > 0) zl = readlane_f64(z[k > 0 ? k - 1 : 0].y, 63);
+            if (k + 1 < NVX) zr = readlane_f64(z[k + 1 < NVX ? k + 1 : 0].x, 0);
+        } else {
+            const int64_t cch = (int64_t)k * W + wave;
+            if (cch > 0) zl = edge[2 * (cch - 1) + 1];
+            if (cch + 1 < nch) zr = edge[2 * (cch + 1)];
+        }
+    }
 
     // ======================================================================================
     // Register-resident leaf (NV > 0): leapfrog + merge cascade + stores of ONE tree leaf.
@@ -705,26 +750,20 @@ struct Machine {
     }
     // fused-model gradient of the register position (used when a position is reloaded: only q is kept in HBM)
     __device__ __forceinline__ void regs_grad(RegsT& X) {
-        constexpr int nk = NVX;  // the register kernels are instantiated per exact chunk count
-        const NPHIP_LDS double* pmu = par;
-        const NPHIP_LDS double* pa = par + ld;
-        const NPHIP_LDS double* pb = par + 2 * ld;
         double2 z[NVX];
 #pragma unroll
-        for (int k = 0; k < NVX; ++k) if (k < nk) {
-            const double2 mu = *(const NPHIP_LDS double2*)(pmu + ridx(k));
+        for (int k = 0; k < NVX; ++k) {
+            const double2 mu = par_mu(ridx(k));
             z[k].x = X.q[k].x - mu.x;
             z[k].y = X.q[k].y - mu.y;
         }
+        publish_edges(z);
 #pragma unroll
-        for (int k = 0; k < NVX; ++k) if (k < nk) {
-            const int64_t i = ridx(k);
-            const double2 a = *(const NPHIP_LDS double2*)(pa + i);
-            const double2 b01 = *(const NPHIP_LDS double2*)(pb + i);
-            const double b2 = pb[i + 2];
-            double edge_zl = 0.0, edge_zr = 0.0;
-            if (k > 0) edge_zl = readlane_f64(z[k - 1].y, 63);
-            if (k + 1 < NVX) { if (k + 1 < nk) edge_zr = readlane_f64(z[k + 1].x, 0); }
+        for (int k = 0; k < NVX; ++k) {
+            double2 a, b01;
+            double b2, edge_zl, edge_zr;
+            par_ab(ridx(k), a, b01, b2);
+            edge_pair(z, k, edge_zl, edge_zr);
             const double zl = wave_shr1(z[k].y, edge_zl), zr = wave_shl1(z[k].x, edge_zr);
             double tx = a.x * z[k].x;
             tx = fma(b01.x, zl, tx);
@@ -735,6 +774,7 @@ struct Machine {
             X.g[k].x = -tx;
             X.g[k].y = -ty;
         }
+        if (W > 1) __syncthreads();  // the edge buffer is free again
     }
     // HBM copies: q only (the gradient is recomputed on reload), (p, rho) into the leaf's P-slot
     __device__ __forceinline__ void store_state(RegsT& X, bool q_, bool pr) {
@@ -805,13 +845,10 @@ struct Machine {
 #pragma unroll
             for (int k = 0; k < NVX; ++k) if (k < nk) { X.r[k].x = -0.0; X.r[k].y = -0.0; }
         }
-        const NPHIP_LDS double* pmu = par;
-        const NPHIP_LDS double* pa = par + ld;
-        const NPHIP_LDS double* pb = par + 2 * ld;  // pb[i] = b_{i-1}
         double2 z[NVX], pold[NVX], rold[NVX];
 #pragma unroll
         for (int k = 0; k < NVX; ++k) if (k < nk) {
-            const double2 mu = *(const NPHIP_LDS double2*)(pmu + ridx(k));
+            const double2 mu = par_mu(ridx(k));
             pold[k] = X.p[k];
             rold[k] = X.r[k];
             X.p[k].x = fma(h, X.g[k].x, X.p[k].x);
@@ -821,16 +858,14 @@ struct Machine {
             z[k].x = X.q[k].x - mu.x;
             z[k].y = X.q[k].y - mu.y;
         }
+        publish_edges(z);
         double2 accK = {0.0, 0.0}, accL = {0.0, 0.0}, accE = {0.0, 0.0}, accS = {0.0, 0.0};
 #pragma unroll
         for (int k = 0; k < NVX; ++k) if (k < nk) {
-            const int64_t i = ridx(k);
-            const double2 a = *(const NPHIP_LDS double2*)(pa + i);
-            const double2 b01 = *(const NPHIP_LDS double2*)(pb + i);  // b_{i-1}, b_i
-            const double b2 = pb[i + 2];                               // b_{i+1}
-            double edge_zl = 0.0, edge_zr = 0.0;
-            if (k > 0) edge_zl = readlane_f64(z[k - 1].y, 63);
-            if (k + 1 < NVX) { if (k + 1 < nk) edge_zr = readlane_f64(z[k + 1].x, 0); }
+            double2 a, b01;          // b01 = b_{i-1}, b_i ; b2 = b_{i+1}
+            double b2, edge_zl, edge_zr;
+            par_ab(ridx(k), a, b01, b2);
+            edge_pair(z, k, edge_zl, edge_zr);
             const double zl = wave_shr1(z[k].y, edge_zl);   // z_{i-1}
             const double zr = wave_shl1(z[k].x, edge_zr);   // z_{i+2}
             // boundary terms need no branches: b_{-1} and b_{D-1..} are stored as -0.0 and t + (-0.0) == t
@@ -1533,11 +1568,12 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) __attribute__((amdgpu_waves_
     constexpr int WAVES = (W == 1) ? 4 : W;
     __shared__ Ctl s_ctl[WAVES];
     __shared__ double s_red[8 * WAVES];
-    __shared__ __attribute__((aligned(16))) double s_par[NV > 0 ? 3 * 128 * NV + 8 : 2];
-    __shared__ __attribute__((aligned(16))) double s_ring[NV > 0 ? 4 * 4 * 128 * NV : 2];  // per wave: 2 slots x (p, rho)
+    __shared__ __attribute__((aligned(16))) double s_par[(NV > 0 && W == 1) ? 3 * 128 * NV + 8 : 2];
+    __shared__ __attribute__((aligned(16))) double s_ring[NV > 0 ? WAVES * 4 * 128 * NV : 2];  // per wave: 2 slots x (p, rho)
+    __shared__ double s_edge[(NV > 0 && W > 1) ? 2 * W * NV : 2];
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int64_t chain = (W == 1) ? (int64_t)blockIdx.x * 4 + wib : (int64_t)blockIdx.x;
-    if (NV > 0) {
+    if (NV > 0 && W == 1) {
         // stage the fused model in LDS once per workgroup: mu | a | b shifted by one with -0.0 sentinels
         const int64_t ld = A.ld;
         NPHIP_LDS double* sp = (NPHIP_LDS double*)s_par;
@@ -1557,7 +1593,8 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) __attribute__((amdgpu_waves_
         for (int w = lane; w < kCtlWords; w += 64) dst[w] = src[w];
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    Machine<FUSED, W, NV> m(A, c, (LdsDouble)s_red, chain, (LdsDouble)s_par, (LdsDouble)s_ring + (size_t)wib * 4 * 128 * (NV > 0 ? NV : 1));
+    Machine<FUSED, W, NV> m(A, c, (LdsDouble)s_red, chain, (LdsDouble)s_par, (LdsDouble)s_ring + (size_t)wib * 4 * 128 * (NV > 0 ? NV : 1),
+                            (LdsDouble)s_edge);
     m.run(max_evals, have_result != 0);
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     if (W == 1 || wib == 0) {
@@ -1571,6 +1608,26 @@ template <bool FUSED>
 static hipError_t launch_w(const Args& a, const Args* d_args, int W, hipStream_t st) {
     const unsigned n = (unsigned)a.n_chains;
     const int me = a.max_evals, hr = a.have_result;
+    if (FUSED && (W == 2 || W == 4) && a.reg_nv > 0) {
+        // register-resident, several waves per chain (1024 < D <= 4096): one workgroup = one chain
+        const dim3 g(n), b(64 * W);
+#define NPHIP_LAUNCH_RW(WW, NN) hipLaunchKernelGGL((k_advance<true, WW, NN>), g, b, 0, st, d_args, me, hr)
+        if (W == 2) switch (a.reg_nv) {
+            case 5: NPHIP_LAUNCH_RW(2, 5); break;
+            case 6: NPHIP_LAUNCH_RW(2, 6); break;
+            case 7: NPHIP_LAUNCH_RW(2, 7); break;
+            case 8: NPHIP_LAUNCH_RW(2, 8); break;
+            default: return hipErrorInvalidValue;
+        } else switch (a.reg_nv) {
+            case 5: NPHIP_LAUNCH_RW(4, 5); break;
+            case 6: NPHIP_LAUNCH_RW(4, 6); break;
+            case 7: NPHIP_LAUNCH_RW(4, 7); break;
+            case 8: NPHIP_LAUNCH_RW(4, 8); break;
+            default: return hipErrorInvalidValue;
+        }
+#undef NPHIP_LAUNCH_RW
+        return hipGetLastError();
+    }
     if (FUSED && W == 1 && a.reg_nv > 0) {
         const dim3 g((n + 3) / 4), b(256);
         switch (a.reg_nv) {

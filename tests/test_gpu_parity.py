@@ -114,7 +114,9 @@ def test_engine_matches_committed_golden_vectors(hip, name):
     assert np.array_equal(got.draws[:, ::10, :8], gold["draws_thin"])
 
 
-@pytest.mark.parametrize("dim,waves", [(1, 1), (2, 1), (127, 1), (128, 1), (129, 2), (1000, 1), (1000, 4), (2500, 2), (5003, 8), (9000, 16)])
+@pytest.mark.parametrize("dim,waves", [(1, 1), (2, 1), (127, 1), (128, 1), (129, 2), (1000, 1), (1000, 4), (2500, 2), (5003, 8), (9000, 16),
+                                       # register-resident kernels with several waves per chain (5..8 chunks per wave)
+                                       (1100, 2), (1500, 2), (2048, 2), (2500, 4), (3300, 4), (4096, 4)])
 def test_correlated_gaussian_all_geometries(hip, oracle, dim, waves):
     rng = np.random.default_rng(dim)
     sd = np.exp(0.7 * rng.normal(size=dim))
