@@ -194,6 +194,24 @@ def test_settings_variants_bit_identical(hip, oracle, settings):
         assert got.stats["maxdepth_reached"].sum() > 0 and got.stats["depth"].max() == 2
 
 
+@pytest.mark.parametrize("dim,settings,launch", [
+    (1300, dict(max_energy_error=0.5), {}),                              # divergences end draws from inside leaf_reg
+    (1300, dict(maxdepth=3), dict(evals_per_launch=5)),                  # flush / reload of registers and ring at launch ends
+    (2600, dict(step_size_jitter=0.2, mindepth=2), dict(evals_per_launch=13)),
+    (2600, dict(use_grad_based_mass_matrix=False, store_gradient=True), {}),
+])
+def test_multiwave_register_kernels_variants(hip, oracle, dim, settings, launch):
+    # register-resident kernels with 2 (D = 1300) and 4 (D = 2600) waves per chain under the awkward settings
+    model = ar1_gaussian(dim)
+    kw = dict(chains=3, tune=50, draws=12, seed=dim + 3)
+    got, W = run_engine(hip, hip.TridiagGaussianModel(model.diag, model.offdiag), launch=launch, **kw, **settings)
+    assert W == (2 if dim <= 2048 else 4)
+    want = oracle.sample_tridiag(oracle_settings(oracle, W=W, **kw, **settings), model.diag, model.offdiag)
+    assert_trace_equal(got, want)
+    if "store_gradient" in settings:
+        assert np.array_equal(got.stats["gradient"], want.stats["gradient"])
+
+
 def test_init_strategies(hip, oracle):
     diag = np.array([1.0, 4.0, 0.25])
     # N(0,1) initial points: src/stan.rs:798-808
