@@ -53,7 +53,8 @@ struct Ctl {
     // hamiltonian
     double step_size;
     // dual averaging [oracle: struct DualAverage]
-    double da_log_step, da_log_step_adapted, da_hbar, da_mu;
+    double da_log_step, da_log_step_adapted, da_hbar, da_mu;   // Adam: hbar = first moment, mu = second moment
+    double adam_b1t, adam_b2t;                                // Adam: running powers of beta1, beta2
     int64_t da_count;
     // adaptation schedule
     int64_t tuning;
@@ -104,6 +105,8 @@ struct DevSettings {
     int64_t mm_switch_freq, early_mm_switch_freq, mm_update_freq;
     double initial_step, target_accept, jitter, max_step_size;
     double da_k, da_t0, da_gamma;
+    double adam_lr;            // step_size_adapt_method = "adam": learning rate; adapt_adam selects it
+    int32_t adapt_adam, pad1_;
     int32_t init_kind, num_try_init;
     int32_t store_draws, store_gradient, store_mass_matrix, store_divergences;
 };

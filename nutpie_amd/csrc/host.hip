@@ -65,6 +65,7 @@ struct nphip_settings {
     double da_k = 0.75, da_t0 = 10.0, da_gamma = 0.05;
     bool fixed_step = false;
     double adam_learning_rate = 0.05;
+    bool adam = false;  // step_size_adapt_method = "adam"
     // engine knobs (not in the reference)
     bool adapt_mass_matrix = true;
     uint64_t num_try_init = 100;
@@ -163,13 +164,14 @@ int nphip_settings_set_bool(nphip_settings_t* s, const char* name, int v) {
 int nphip_settings_set_str(nphip_settings_t* s, const char* name, const char* v) {
     std::string n(name), val(v);
     if (n == "step_size_adapt_method") {  // wrapper.rs:344-376
-        if (val == "dual_average") { s->fixed_step = false; return NPHIP_OK; }
-        if (val == "adam") return bad_value("step_size_adapt_method 'adam' is not supported by the HIP engine");
+        if (val == "dual_average") { s->fixed_step = false; s->adam = false; return NPHIP_OK; }
+        if (val == "adam") { s->fixed_step = false; s->adam = true; return NPHIP_OK; }
         char* end = nullptr;
         double step = strtod(v, &end);
         if (end == v || *end != '\0' || !(step > 0.0))
             return bad_value("step_size_adapt_method must be a positive float when using fixed step size");
         s->fixed_step = true;
+        s->adam = false;
         s->initial_step = step;
         return NPHIP_OK;
     }
@@ -233,7 +235,7 @@ int64_t nphip_settings_to_json(const nphip_settings_t* s, char* buf, int64_t cap
     j += ",\"adapt_options\":{";
     j += "\"step_size_settings\":{\"initial_step\":" + jnum(s->initial_step) + ",\"target_accept\":" + jnum(s->target_accept);
     j += ",\"jitter\":" + (s->jitter > 0 ? jnum(s->jitter) : std::string("null"));
-    j += ",\"adapt_options\":{\"method\":" + (s->fixed_step ? "{\"fixed\":" + jnum(s->initial_step) + "}" : std::string("\"dual_average\""));
+    j += ",\"adapt_options\":{\"method\":" + (s->fixed_step ? "{\"fixed\":" + jnum(s->initial_step) + "}" : std::string(s->adam ? "\"adam\"" : "\"dual_average\""));
     j += ",\"dual_average\":{\"k\":" + jnum(s->da_k) + ",\"t0\":" + jnum(s->da_t0) + ",\"gamma\":" + jnum(s->da_gamma) +
          ",\"max_step_size\":" + jnum(s->max_step_size) + "}";
     j += ",\"adam\":{\"learning_rate\":" + jnum(s->adam_learning_rate) + "}}}";
@@ -510,6 +512,7 @@ bool nphip_sampler::setup() {
     s.mm_update_freq = (int64_t)set.mass_matrix_update_freq;
     s.initial_step = set.initial_step; s.target_accept = set.target_accept;
     s.jitter = set.jitter; s.max_step_size = set.max_step_size;
+    s.adapt_adam = set.adam ? 1 : 0; s.adam_lr = set.adam_learning_rate;
     s.da_k = set.da_k; s.da_t0 = set.da_t0; s.da_gamma = set.da_gamma;
     s.init_kind = model.init_kind; s.num_try_init = (int32_t)set.num_try_init;
     s.store_draws = launch.store_draws; s.store_gradient = set.store_gradient;

@@ -222,10 +222,23 @@ struct Machine {
         c->da_log_step = nphip_log(step);
         c->da_log_step_adapted = c->da_log_step;
         c->da_hbar = 0.0;
-        c->da_mu = nphip_log(10.0 * step);
+        c->da_mu = A.s.adapt_adam ? 0.0 : nphip_log(10.0 * step);
+        c->adam_b1t = 1.0; c->adam_b2t = 1.0;
         c->da_count = 1;
     }
     __device__ void da_advance(double accept) {
+        if (A.s.adapt_adam) {
+            // Adam on log(step size) (oracle: DualAverage::advance_adam)
+            const double g = accept - A.s.target_accept;
+            c->da_hbar = 0.9 * c->da_hbar + (1.0 - 0.9) * g;
+            c->da_mu = 0.999 * c->da_mu + (1.0 - 0.999) * (g * g);
+            c->adam_b1t = c->adam_b1t * 0.9; c->adam_b2t = c->adam_b2t * 0.999;
+            const double mhat = c->da_hbar / (1.0 - c->adam_b1t), vhat = c->da_mu / (1.0 - c->adam_b2t);
+            c->da_log_step = c->da_log_step + A.s.adam_lr * mhat / (sqrt(vhat) + 1e-8);
+            c->da_log_step_adapted = c->da_log_step;
+            c->da_count += 1;
+            return;
+        }
         const double cnt = (double)c->da_count;
         double w = 1.0 / (cnt + A.s.da_t0);
         c->da_hbar = (1.0 - w) * c->da_hbar + w * (A.s.target_accept - accept);

@@ -53,6 +53,9 @@ class Settings(C.Structure):
         ("chain_offset", C.c_uint64),
         ("store_gradient", C.c_int32),
         ("store_mass_matrix", C.c_int32),
+        ("adam", C.c_int32),
+        ("pad_", C.c_int32),
+        ("adam_learning_rate", C.c_double),
     ]
 
 

@@ -534,6 +534,7 @@ struct DualAverage {
     double log_step, log_step_adapted, hbar, mu;
     uint64_t count;
     void init(double initial_step, double k_, double t0_, double gamma_) {
+        if (adam) { init_adam(initial_step, lr); return; }
         k = k_; t0 = t0_; gamma = gamma_;
         log_step = det_log(initial_step);
         log_step_adapted = log_step;
@@ -542,6 +543,7 @@ struct DualAverage {
         count = 1;
     }
     void advance(double accept, double target) {
+        if (adam) { advance_adam(accept, target); return; }
         double w = 1.0 / ((double)count + t0);
         hbar = (1.0 - w) * hbar + w * (target - accept);
         log_step = mu - hbar * std::sqrt((double)count) / gamma;
@@ -551,6 +553,28 @@ struct DualAverage {
     }
     double current() const { return det_exp(log_step); }
     double adapted() const { return det_exp(log_step_adapted); }
+
+    // step_size_adapt_method = "adam": Adam on log(step size), gradient = accept - target (the step grows while the
+    // acceptance statistic is above the target); beta1 0.9, beta2 0.999, eps 1e-8; no averaged iterate, so
+    // `step_size_bar` equals the current step.  The fields of the dual-averaging state are reused:
+    // hbar = first moment, mu = second moment, (b1t, b2t) = running powers of the betas.
+    bool adam = false;
+    double lr = 0.05, b1t = 1.0, b2t = 1.0;
+    void init_adam(double initial_step, double learning_rate) {
+        adam = true; lr = learning_rate;
+        log_step = det_log(initial_step); log_step_adapted = log_step;
+        hbar = 0.0; mu = 0.0; b1t = 1.0; b2t = 1.0; count = 1;
+    }
+    void advance_adam(double accept, double target) {
+        const double g = accept - target;
+        hbar = 0.9 * hbar + (1.0 - 0.9) * g;
+        mu = 0.999 * mu + (1.0 - 0.999) * (g * g);
+        b1t = b1t * 0.9; b2t = b2t * 0.999;
+        const double mhat = hbar / (1.0 - b1t), vhat = mu / (1.0 - b2t);
+        log_step = log_step + lr * mhat / (std::sqrt(vhat) + 1e-8);
+        log_step_adapted = log_step;
+        count += 1;
+    }
 };
 
 // RunningVariance (Welford); `current` = (M2, 1/(n-1))
@@ -592,6 +616,8 @@ struct Chain {
         : S(s), model(m), geo{s.waves_per_chain}, H(m, Geometry{s.waves_per_chain}), chain_id(cid),
           fg_q(m->dim), fg_g(m->dim), bg_q(m->dim), bg_g(m->dim) {
         H.max_energy_error = S.max_energy_error;
+        da.adam = S.adam != 0;
+        da.lr = S.adam_learning_rate;
         // window bounds [A.8]
         early_end = (uint64_t)std::ceil((double)S.num_tune * S.early_window);
         uint64_t ssw = (uint64_t)std::ceil((double)S.num_tune * S.step_size_window);
@@ -862,7 +888,7 @@ void oracle_default_settings(oracle_settings_t* s) {
     s->initial_step = 0.1; s->target_accept = 0.8;                              // docs/sampling-options.qmd:71,82
     s->step_size_jitter = 0.0; s->max_step_size = INFINITY;
     s->da_k = 0.75; s->da_t0 = 10.0; s->da_gamma = 0.05;
-    s->fixed_step_size = 0; s->adapt_mass_matrix = 1;
+    s->fixed_step_size = 0; s->adapt_mass_matrix = 1; s->adam = 0; s->adam_learning_rate = 0.05;
     s->init_kind = 0; s->num_try_init = 100;
     s->waves_per_chain = 1; s->n_threads = 1; s->chain_offset = 0;
 }

@@ -63,6 +63,10 @@ typedef struct {
     /* optional outputs */
     int32_t store_gradient;
     int32_t store_mass_matrix;
+    /* step_size_adapt_method = "adam" (src/wrapper.rs:344-376, 391-407): Adam on log(step size) */
+    int32_t adam;
+    int32_t pad_;
+    double adam_learning_rate;
 } oracle_settings_t;
 
 typedef struct {

@@ -83,7 +83,12 @@ def test_settings_flat_attribute_names():
     assert s.as_dict()["settings"]["adapt_options"]["step_size_settings"]["jitter"] is None
     s.step_size_adapt_method = "0.25"       # "<float>" => fixed step size (wrapper.rs:350-357)
     assert s.as_dict()["settings"]["adapt_options"]["step_size_settings"]["adapt_options"]["method"] == {"fixed": 0.25}
+    s.step_size_adapt_method = "adam"       # wrapper.rs:344-349
+    s.step_size_adam_learning_rate = 0.07
+    sss = s.as_dict()["settings"]["adapt_options"]["step_size_settings"]["adapt_options"]
+    assert sss["method"] == "adam" and sss["adam"]["learning_rate"] == 0.07
     s.step_size_adapt_method = "dual_average"
+    assert s.as_dict()["settings"]["adapt_options"]["step_size_settings"]["adapt_options"]["method"] == "dual_average"
     assert s.num_tune == 10 and s.seed == 1 and s.store_gradient is True
 
 

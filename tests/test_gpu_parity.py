@@ -40,7 +40,11 @@ ORACLE_KEYS = {"use_grad_based_mass_matrix": "use_grad_based_mass_matrix", "max_
 def oracle_settings(oracle, *, chains, tune, draws, seed, W, init_kind=0, chain_offset=0, **settings):
     kw = {}
     for k, v in settings.items():
-        if k == "step_size_adapt_method":
+        if k == "step_size_adapt_method" and v == "adam":
+            kw["adam"] = 1
+        elif k == "step_size_adam_learning_rate":
+            kw["adam_learning_rate"] = float(v)
+        elif k == "step_size_adapt_method":
             kw["fixed_step_size"] = 1
             kw["initial_step"] = float(v)
         elif k in ("store_gradient", "store_mass_matrix"):
@@ -176,6 +180,8 @@ def test_stream_cache_is_transparent(hip, oracle, dim, waves):
     dict(check_turning=False, maxdepth=4),
     dict(step_size_jitter=0.3),
     dict(step_size_adapt_method="0.3"),                     # fixed step size
+    dict(step_size_adapt_method="adam"),                    # Adam on log(step size)
+    dict(step_size_adapt_method="adam", step_size_adam_learning_rate=0.1, target_accept=0.9),
     dict(window_switch_freq=20, early_window_switch_freq=4),
     dict(adapt_mass_matrix=False),
     dict(max_step_size=0.2),

@@ -115,6 +115,24 @@ def test_dual_averaging_matches_recurrence(oracle):
     assert step[-1] == pytest.approx(1.0, rel=1e-12)
 
 
+def test_adam_step_size_adaptation_reaches_the_target(oracle):
+    # step_size_adapt_method = "adam": Adam on log(step size), gradient = accept - target; no averaged iterate,
+    # so step_size_bar == step_size; the sampling-phase acceptance statistic sits near the target
+    diag = np.linspace(0.5, 2.0, 30)
+    for target in (0.7, 0.9):
+        s = oracle.default_settings(seed=4, num_chains=8, num_tune=500, num_draws=300, n_threads=8, adam=1, adam_learning_rate=0.05,
+                                    target_accept=target)
+        tr = oracle.sample_tridiag(s, diag)
+        post = ~tr.stats["tuning"].astype(bool)
+        assert abs(tr.stats["mean_tree_accept"][post].mean() - target) < 0.06
+        assert np.array_equal(tr.stats["step_size"][post], tr.stats["step_size_bar"][post])
+        # frozen after tuning
+        assert np.all(tr.stats["step_size"][:, 500:] == tr.stats["step_size"][:, 500:501])
+    lo = oracle.sample_tridiag(oracle.default_settings(seed=4, num_chains=4, num_tune=300, num_draws=50, adam=1, target_accept=0.6), diag)
+    hi = oracle.sample_tridiag(oracle.default_settings(seed=4, num_chains=4, num_tune=300, num_draws=50, adam=1, target_accept=0.95), diag)
+    assert lo.stats["step_size"][:, -1].mean() > 1.5 * hi.stats["step_size"][:, -1].mean()
+
+
 def test_welford_matches_numpy(oracle):
     rng = np.random.default_rng(3)
     x = rng.normal(size=(50, 7)) * np.arange(1, 8)
