@@ -146,7 +146,7 @@ struct Args {
     double* st_energy; double* st_energy_error; double* st_logp; double* st_step; double* st_step_bar;
     double* st_accept; double* st_accept_sym;
     // launch control
-    int32_t reg_nv;       // >0: register-resident kernel with NV = reg_nv chunks per lane (fused, W == 1)
+    int32_t reg_nv;       // >0: register-resident kernel, NV = reg_nv chunks of 128 per wave (fused; W = 1, or W = 2/4 with ld = 128 * W * NV)
     int32_t stream_cache; // 1: memory-resident fused kernel with the cursor's loads cached in VGPRs (NV < 0 instantiations)
     int32_t pad0_;
     int32_t max_evals;    // fused: evaluations per chain this launch

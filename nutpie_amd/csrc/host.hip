@@ -534,7 +534,7 @@ bool nphip_sampler::setup() {
     args.npslots = num_pslots(args.cap);
     args.nqpool = num_qpool(args.cap);
     const size_t ld = (size_t)args.ld;
-    // register-resident specialisation: one wave per chain, state in VGPRs (dim <= 2048)
+    // register-resident specialisation, one wave per chain: state in VGPRs (dim <= 1024, one instantiation per chunk count)
     args.reg_nv = reg_multi;
     // (not with store_divergences: the divergence record needs the pre-step state, which only the
     //  memory-resident kernel keeps)

@@ -168,9 +168,9 @@ struct SCache {
     __device__ __forceinline__ void invalidate() { tag_q = -1; tag_p = -1; sig_ok = false; }
 };
 
-// NV > 0 selects the register-resident specialisation (requires FUSED and W == 1, dim <= 128 * NV):
-// the cursor state (q, grad, p, rho) and sigma^2 live in VGPRs across leapfrogs, so a leapfrog issues
-// no loads at all — only the stores of the new state, which later U-turn checks / draws may read.
+// NV > 0 selects the register-resident specialisation (requires FUSED; W = 1 with dim <= 128 * NV, or W = 2 / 4 waves
+// per chain with ld == 128 * W * NV): the cursor state (q, grad, p, rho) and sigma^2 live in VGPRs across leapfrogs,
+// so a leapfrog issues no loads at all — only the stores of the new state, which later U-turn checks / draws may read.
 template <bool FUSED, int W, int NV = 0>
 struct Machine {
     static constexpr int NVX = NV > 0 ? NV : 1;
