@@ -148,7 +148,7 @@ struct Args {
     // launch control
     int32_t reg_nv;       // >0: register-resident kernel, NV = reg_nv chunks of 128 per wave (fused; W = 1, or W = 2/4 with ld = 128 * W * NV)
     int32_t stream_cache; // 1: memory-resident fused kernel with the cursor's loads cached in VGPRs (NV < 0 instantiations)
-    int32_t pad0_;
+    int32_t sig_lds;      // 1: memory-resident kernels with W >= 8 keep the chain's sigma^2 in (dynamic) LDS
     int32_t max_evals;    // fused: evaluations per chain this launch
     int32_t have_result;  // callbacks: geval/ueval hold the answer to the pending request
     unsigned long long* counters;  // [0] chains done, [1] chains in error

@@ -546,6 +546,9 @@ bool nphip_sampler::setup() {
     // (sigma^2, grad, p, rho) in VGPRs between leaves.  With more waves per chain the cache costs occupancy (measured).
     args.stream_cache = (fused && !args.reg_nv && W == 1 && !launch.no_stream_cache && args.ld / 128 <= 8) ? 1 : 0;
 
+    // D > 4096 (one chain per CU): sigma^2 of the chain in LDS instead of one more HBM stream per pass
+    args.sig_lds = (fused && !args.reg_nv && W >= 8 && args.ld * 8 <= 128 * 1024 && !launch.no_stream_cache) ? 1 : 0;
+
     if (!dalloc(&args.ctl, n)) return false;
     if (!dalloc(&args.qpool, n * args.nqpool * 2 * ld)) return false;
     if (!dalloc(&args.pslots, n * args.npslots * 2 * ld)) return false;

@@ -183,6 +183,7 @@ struct Machine {
     LdsDouble par;   // NV > 0: LDS copy of the fused model: mu[ld], a[ld], then b shifted by one (par_b[i] = b_{i-1})
     LdsDouble ring;  // NV > 0: this wave's LDS ring of two (p, rho) summaries: [slot][p|rho][NV*64 double2]
     LdsDouble edge;  // NV > 0, W > 1: chunk-edge exchange buffer of the chain [2 * chunks]
+    LdsDouble sig_lds = nullptr;  // memory-resident kernels with W >= 8: LDS copy of this chain's sigma^2 (set by run())
     int64_t chain;   // local chain index
     uint32_t gchain; // global chain id (RNG key)
     int lane, wave;
@@ -214,6 +215,12 @@ struct Machine {
     __device__ __forceinline__ double* R(int64_t s) const { return pp + (size_t)s * 2 * ld + ld; }
     __device__ __forceinline__ double* EST(int64_t e, int k) const { return est + (size_t)(e * 4 + k) * ld; }
     __device__ __forceinline__ bool leader() const { return lane == 0 && wave == 0; }
+    // sigma^2 of the hot streaming passes: from the chain's LDS copy where there is one (one chain per CU at W >= 8)
+    __device__ __forceinline__ double2 sg2(int64_t i) const {
+        if (sig_lds) { const double2 v = *(const NPHIP_LDS double2*)(sig_lds + i); return v; }
+        return ld2(sig2, i);
+    }
+    __device__ __forceinline__ double sg1(int64_t i) const { return sig_lds ? sig_lds[i] : ld1(sig2, i); }
 
 #define NPHIP_FOR_CHUNKS(i) for (int64_t cc_ = wave, i = cc_ * NPHIP_CHUNK + 2 * lane; cc_ < nch; cc_ += W, i = cc_ * NPHIP_CHUNK + 2 * lane)
 
@@ -399,7 +406,7 @@ struct Machine {
     // no cross-wave exchange and no second pass), and the level-0 U-turn criterion is accumulated on the way.
     __device__ __forceinline__ double edge_z(const double* q, const double* g, const double* p, int64_t e, double eps, double h) const {
         const double ph = fma(h, ld1(g, e), ld1(p, e));
-        return fma(eps, ld1(sig2, e) * ph, ld1(q, e)) - ld1(A.m_mu, e);
+        return fma(eps, sg1(e) * ph, ld1(q, e)) - ld1(A.m_mu, e);
     }
     __device__ __forceinline__ double lf_stream(double& lp, int64_t idx_new, bool& turn0, SCacheT& Y) {
         const int64_t srcq = c->lf_srcq, srcp = c->lf_srcp, newq = c->lf_newq, newp = c->lf_newp;
@@ -495,7 +502,7 @@ struct Machine {
         } else {
             NPHIP_FOR_CHUNKS(i) {
                 double2 gg, pv, rr;
-                body(i, ld2(q, i), ld2(g, i), ld2(p, i), ld2(r, i), ld2(sig2, i), gg, pv, rr);
+                body(i, ld2(q, i), ld2(g, i), ld2(p, i), ld2(r, i), sg2(i), gg, pv, rr);
             }
         }
         double v[4] = {accK.x + accK.y, accL.x + accL.y, accE.x + accE.y, accS.x + accS.y};
@@ -539,7 +546,7 @@ struct Machine {
                 }
             }
         } else {
-            NPHIP_FOR_CHUNKS(i) { body(ld2(pa, i), ld2(ra, i), ld2(pb, i), ld2(rb, i), ld2(pf, i), ld2(rf, i), ld2(pl, i), ld2(rl, i), ld2(sig2, i)); }
+            NPHIP_FOR_CHUNKS(i) { body(ld2(pa, i), ld2(ra, i), ld2(pb, i), ld2(rb, i), ld2(pf, i), ld2(rf, i), ld2(pl, i), ld2(rl, i), sg2(i)); }
         }
         double v[6];
 #pragma unroll
@@ -1086,7 +1093,7 @@ struct Machine {
         const int mode = (a >= 0 && b >= 0) ? 0 : ((b >= 0 && a < 0) ? 1 : 2);
         double2 acc1 = {0.0, 0.0}, acc2 = {0.0, 0.0};
         NPHIP_FOR_CHUNKS(i) {
-            double2 vps = ld2(ps, i), vrs = ld2(rs, i), vpe = ld2(pe, i), vre = ld2(re, i), s2 = ld2(sig2, i);
+            double2 vps = ld2(ps, i), vrs = ld2(rs, i), vpe = ld2(pe, i), vre = ld2(re, i), s2 = sg2(i);
             double2 t;
             if (mode == 0) { t.x = (vre.x - vrs.x) + vps.x; t.y = (vre.y - vrs.y) + vps.y; }
             else if (mode == 1) { t.x = vre.x + vrs.x; t.y = vre.y + vrs.y; }
@@ -1521,9 +1528,10 @@ struct Machine {
         }
     }
 
-    __device__ __forceinline__ void run(int budget, bool have) {
+    __device__ __forceinline__ void run(int budget, bool have, LdsDouble sig_copy = nullptr) {
         RegsT X;
         SCacheT Y;
+        bool sig_copy_ok = false;
         for (;;) {
             const int64_t ph = c->phase;
             if (ph == PH_DONE || ph == PH_ERROR) break;
@@ -1541,6 +1549,14 @@ struct Machine {
 #endif
             if (ph == PH_TREE) {
                 bool rare;
+                if (NV == 0 && sig_copy != nullptr && !sig_copy_ok) {
+                    // (re)stage sigma^2 in LDS: it only changes in the rare draw-end path
+                    for (int64_t i = 2 * (int64_t)threadIdx.x; i < ld; i += 2 * (int64_t)blockDim.x)
+                        *(NPHIP_LDS double2*)(sig_copy + i) = ld2(sig2, i);
+                    __syncthreads();
+                    sig_lds = sig_copy;
+                    sig_copy_ok = true;
+                }
                 if (NV > 0) {
                     rare = leaf_reg(X);
                 } else {
@@ -1556,7 +1572,7 @@ struct Machine {
                         rare = cont_tree(X, Y, K, lp, code, false, false);
                     }
                 }
-                if (rare) { X.invalidate(); Y.invalidate(); }
+                if (rare) { X.invalidate(); Y.invalidate(); sig_copy_ok = false; sig_lds = nullptr; }
 #ifdef NPHIP_PROFILE
                 const int64_t t2 = (int64_t)__builtin_readcyclecounter();
                 c->prof[3] += 1;
@@ -1566,6 +1582,8 @@ struct Machine {
                 rare_phase_fn(A, c, red, chain, ph);
                 X.invalidate();
                 Y.invalidate();
+                sig_copy_ok = false;
+                sig_lds = nullptr;
             }
         }
         flush(X);  // launch boundary: registers that hold the only copy of the cursor state go back to HBM
@@ -1584,6 +1602,7 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) __attribute__((amdgpu_waves_
     __shared__ __attribute__((aligned(16))) double s_par[(NV > 0 && W == 1) ? 3 * 128 * NV + 8 : 2];
     __shared__ __attribute__((aligned(16))) double s_ring[NV > 0 ? WAVES * 4 * 128 * NV : 2];  // per wave: 2 slots x (p, rho)
     __shared__ double s_edge[(NV > 0 && W > 1) ? 2 * W * NV : 2];
+    extern __shared__ __attribute__((aligned(16))) double s_dyn[];  // a.sig_lds: sigma^2 of the chain [ld]
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int64_t chain = (W == 1) ? (int64_t)blockIdx.x * 4 + wib : (int64_t)blockIdx.x;
     if (NV > 0 && W == 1) {
@@ -1608,7 +1627,7 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) __attribute__((amdgpu_waves_
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     Machine<FUSED, W, NV> m(A, c, (LdsDouble)s_red, chain, (LdsDouble)s_par, (LdsDouble)s_ring + (size_t)wib * 4 * 128 * (NV > 0 ? NV : 1),
                             (LdsDouble)s_edge);
-    m.run(max_evals, have_result != 0);
+    m.run(max_evals, have_result != 0, (NV == 0 && W >= 8 && A.sig_lds) ? (LdsDouble)s_dyn : nullptr);
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     if (W == 1 || wib == 0) {
         NPHIP_GLOBAL uint64_t* dst = (NPHIP_GLOBAL uint64_t*)(A.ctl + chain);
@@ -1666,8 +1685,8 @@ static hipError_t launch_w(const Args& a, const Args* d_args, int W, hipStream_t
         case 1: hipLaunchKernelGGL((k_advance<FUSED, 1, 0>), dim3((n + 3) / 4), dim3(256), 0, st, d_args, me, hr); break;
         case 2: hipLaunchKernelGGL((k_advance<FUSED, 2, 0>), dim3(n), dim3(128), 0, st, d_args, me, hr); break;
         case 4: hipLaunchKernelGGL((k_advance<FUSED, 4, 0>), dim3(n), dim3(256), 0, st, d_args, me, hr); break;
-        case 8: hipLaunchKernelGGL((k_advance<FUSED, 8, 0>), dim3(n), dim3(512), 0, st, d_args, me, hr); break;
-        case 16: hipLaunchKernelGGL((k_advance<FUSED, 16, 0>), dim3(n), dim3(1024), 0, st, d_args, me, hr); break;
+        case 8: hipLaunchKernelGGL((k_advance<FUSED, 8, 0>), dim3(n), dim3(512), a.sig_lds ? (size_t)a.ld * 8 : 0, st, d_args, me, hr); break;
+        case 16: hipLaunchKernelGGL((k_advance<FUSED, 16, 0>), dim3(n), dim3(1024), a.sig_lds ? (size_t)a.ld * 8 : 0, st, d_args, me, hr); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

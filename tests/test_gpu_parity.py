@@ -155,10 +155,10 @@ def test_streaming_kernel_single_wave_bit_identical(hip, oracle, dim):
     assert_trace_equal(got, want)
 
 
-@pytest.mark.parametrize("dim,waves", [(130, 1), (700, 1), (1024, 1), (2000, 2)])
+@pytest.mark.parametrize("dim,waves", [(130, 1), (700, 1), (1024, 1), (2000, 2), (5000, 8), (9000, 16)])
 def test_stream_cache_is_transparent(hip, oracle, dim, waves):
-    # memory-resident fused kernels keep the cursor's (sigma^2, grad, p, rho) in VGPRs between leaves (every store
-    # still happens): same trace as the kernel that reloads everything, and as the oracle
+    # memory-resident fused kernels keep the cursor's (sigma^2, grad, p, rho) in VGPRs between leaves (W = 1; every
+    # store still happens) or sigma^2 in LDS (W >= 8): same trace as the kernel that reloads everything, and as the oracle
     model = ar1_gaussian(dim)
     kw = dict(chains=4, tune=30, draws=8, seed=dim, waves=waves)
     m = hip.TridiagGaussianModel(model.diag, model.offdiag)
