@@ -71,6 +71,10 @@ def _pad_split(arr, n_tune_per_chain, finished, max_tune, max_post):
     as ``_add_arrow_data`` does (sample.py:167-214)."""
     n = arr.shape[0]
     item = arr.shape[2:]
+    if n and np.all(n_tune_per_chain == n_tune_per_chain[0]) and np.all(finished == finished[0]):
+        # every chain got equally far (the normal case): no padding, so no copy of a possibly multi-GB array
+        nt, nf = int(n_tune_per_chain[0]), int(finished[0])
+        return arr[:, :nt], arr[:, nt:nf]
     if arr.dtype.kind == "f":
         tune = np.full((n, max_tune, *item), np.nan, dtype=arr.dtype)
         post = np.full((n, max_post, *item), np.nan, dtype=arr.dtype)
