@@ -1427,11 +1427,17 @@ struct Machine {
                                                                   bool diverging, bool maxdepth, bool store_div, bool div_has_end,
                                                                   bool regrad = false) {
         Machine m(a, ctl, r, ch);
+#ifdef NPHIP_PROFILE
+        const int64_t t0_ = (int64_t)__builtin_readcyclecounter();
+#endif
         if (regrad) {  // the register kernel keeps only q of candidate draws in HBM: rebuild the gradient of the new point
             double lp_;
             int64_t code_;
             m.eval_position(ctl->cand_q, lp_, code_);
         }
+#ifdef NPHIP_PROFILE
+        ctl->prof[12] += (int64_t)__builtin_readcyclecounter() - t0_;
+#endif
         if (store_div) m.store_divergence(div_has_end);
         m.end_draw(diverging, maxdepth);
     }
@@ -1441,6 +1447,9 @@ struct Machine {
     }
 
     __device__ __forceinline__ void end_draw(bool diverging, bool maxdepth) {
+#ifdef NPHIP_PROFILE
+        const int64_t tprof0_ = (int64_t)__builtin_readcyclecounter();
+#endif
         c->fin_depth = c->depth;
         c->fin_flags = (diverging ? 1 : 0) | (maxdepth ? 2 : 0);
         c->fin_eerr = c->cand_E - c->H0;  // H0 is reused by a mid-adapt step-size search
@@ -1482,6 +1491,9 @@ struct Machine {
             da_advance(c->acc_sym_sum);
             update_stepsize(draw, draw == A.s.num_tune - 1);
         }
+#ifdef NPHIP_PROFILE
+        c->prof[13] += (int64_t)__builtin_readcyclecounter() - tprof0_;
+#endif
         if (need_search) { start_ss(draw); return; }
         finish_draw();
     }
@@ -1505,7 +1517,13 @@ struct Machine {
             A.st_accept_sym[o] = c->acc_sym_sum;
         }
         c->draw = draw + 1;
+#ifdef NPHIP_PROFILE
+        const int64_t t0_ = (int64_t)__builtin_readcyclecounter();
+#endif
         begin_draw();
+#ifdef NPHIP_PROFILE
+        c->prof[14] += (int64_t)__builtin_readcyclecounter() - t0_;
+#endif
     }
 
     // rare phases: initial point, step-size search (memory-resident passes; not performance critical)
@@ -1529,9 +1547,6 @@ struct Machine {
     }
 
     __device__ __forceinline__ void run(int budget, bool have, LdsDouble sig_copy = nullptr) {
-        RegsT X;
-        SCacheT Y;
-        bool sig_copy_ok = false;
         for (;;) {
             const int64_t ph = c->phase;
             if (ph == PH_DONE || ph == PH_ERROR) break;
@@ -1544,19 +1559,26 @@ struct Machine {
                     have = false;
                 }
             }
+            if (ph != PH_TREE) {
+                rare_phase_fn(A, c, red, chain, ph);
+                continue;
+            }
+            // ---- a run of consecutive tree leaves.  The register mirror / streaming cache live exactly as long as
+            // the run: a rare (non-inlined) path ends it, so nothing has to be kept alive across those calls.
+            RegsT X;
+            SCacheT Y;
+            bool rare = false, out_of_budget = false;
+            if (NV == 0 && sig_copy != nullptr) {
+                // stage sigma^2 in LDS: it only changes in the rare draw-end path
+                for (int64_t i = 2 * (int64_t)threadIdx.x; i < ld; i += 2 * (int64_t)blockDim.x)
+                    *(NPHIP_LDS double2*)(sig_copy + i) = ld2(sig2, i);
+                __syncthreads();
+                sig_lds = sig_copy;
+            }
+            for (;;) {
 #ifdef NPHIP_PROFILE
-            const int64_t t0 = (int64_t)__builtin_readcyclecounter();
+                const int64_t t0 = (int64_t)__builtin_readcyclecounter();
 #endif
-            if (ph == PH_TREE) {
-                bool rare;
-                if (NV == 0 && sig_copy != nullptr && !sig_copy_ok) {
-                    // (re)stage sigma^2 in LDS: it only changes in the rare draw-end path
-                    for (int64_t i = 2 * (int64_t)threadIdx.x; i < ld; i += 2 * (int64_t)blockDim.x)
-                        *(NPHIP_LDS double2*)(sig_copy + i) = ld2(sig2, i);
-                    __syncthreads();
-                    sig_lds = sig_copy;
-                    sig_copy_ok = true;
-                }
                 if (NV > 0) {
                     rare = leaf_reg(X);
                 } else {
@@ -1572,21 +1594,25 @@ struct Machine {
                         rare = cont_tree(X, Y, K, lp, code, false, false);
                     }
                 }
-                if (rare) { X.invalidate(); Y.invalidate(); sig_copy_ok = false; sig_lds = nullptr; }
 #ifdef NPHIP_PROFILE
                 const int64_t t2 = (int64_t)__builtin_readcyclecounter();
                 c->prof[3] += 1;
                 if (rare) { c->prof[2] += t2 - t0; c->prof[5] += 1; } else { c->prof[1] += t2 - t0; c->prof[4] += 1; }
 #endif
-            } else {
-                rare_phase_fn(A, c, red, chain, ph);
-                X.invalidate();
-                Y.invalidate();
-                sig_copy_ok = false;
-                sig_lds = nullptr;
+                if (rare || c->phase != PH_TREE) break;
+                // the next leaf of the run: same admission test as at the top of the outer loop
+                if (FUSED) {
+                    if (budget <= 0) { out_of_budget = true; break; }
+                    --budget;
+                } else {
+                    out_of_budget = true;   // callbacks: one evaluation per launch
+                    break;
+                }
             }
+            sig_lds = nullptr;
+            if (!rare) flush(X);  // launch boundary: registers that hold the only copy of the cursor state go back to HBM
+            if (out_of_budget) break;
         }
-        flush(X);  // launch boundary: registers that hold the only copy of the cursor state go back to HBM
     }
 #undef NPHIP_FOR_CHUNKS
 };
