@@ -30,7 +30,7 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libnutpie_hip.so")
+_LIB_PATH = os.environ.get("NUTPIE_HIP_LIB") or os.path.join(_HERE, "libnutpie_hip.so")  # override: A/B measurements
 _CSRC = os.path.join(_HERE, "csrc")
 
 __version__ = "0.1.0"
