@@ -57,7 +57,7 @@ def radon_model(data=None, device=0, use_graph=False, expand_on_device=True):
     o_int, o_raw, o_lsd, o_floor, o_craw, o_lcsd, o_lsig = 0, 1, n, n + 1, n + 2, 2 * n + 1, 2 * n + 2
 
     def make_logp():
-        dev = torch.device("cuda", device)
+        dev = torch.device(device) if isinstance(device, str) else torch.device("cuda", device)
         cidx = torch.as_tensor(data["county_idx"], device=dev, dtype=torch.long)
         floor = torch.as_tensor(data["floor"], device=dev, dtype=torch.float64)
         y = torch.as_tensor(data["log_radon"], device=dev, dtype=torch.float64)
@@ -82,12 +82,56 @@ def radon_model(data=None, device=0, use_graph=False, expand_on_device=True):
             lp = lp - 0.5 * (r * r).sum(-1) - n_obs * lsig
             return lp
 
+        # One-hot design matrix of the county effects: row j of `design` spreads county effect j over its
+        # observations, row n + j does the same for the county-specific floor effect (times the floor indicator), so
+        # the gather of both effects is ONE fp64 GEMM forwards and the scatter-add of their gradients ONE backwards.
+        onehot = torch.zeros((n, n_obs), dtype=torch.float64, device=dev)
+        onehot[cidx, torch.arange(n_obs, device=dev)] = 1.0
+        design = torch.cat([onehot, onehot * floor], 0)          # [2n, n_obs]
+        design_t = design.t().contiguous()                       # [n_obs, 2n]
+        c1, c2 = 1.0 / (np.sqrt(n) + n), 1.0 / np.sqrt(n)
+
+        def extend_t(u):
+            """Transpose of the zero-sum extension: R^n -> R^{n-1}, batched."""
+            return u[:, :-1] - (c1 * u[:, :-1].sum(-1, keepdim=True) + c2 * u[:, -1:])
+
         def logp(x):
+            """Log-density and its hand-derived gradient: ~35 kernels instead of the ~190 of autograd (the evaluation
+            is launch-bound: 512 x 919 elements per kernel)."""
+            x = x.detach()
+            intercept, fe = x[:, o_int], x[:, o_floor]
+            raw, craw = x[:, o_raw:o_raw + n - 1], x[:, o_craw:o_craw + n - 1]
+            lsd, lcsd, lsig = x[:, o_lsd], x[:, o_lcsd], x[:, o_lsig]
+            sd, csd, sig = torch.exp(lsd), torch.exp(lcsd), torch.exp(lsig)
+            ext, cext = _extend_zero_sum(raw), _extend_zero_sum(craw)
+            eff = torch.cat([ext * sd[:, None], cext * csd[:, None]], 1)                  # [B, 2n]
+            mu = torch.addmm(intercept[:, None] + fe[:, None] * floor, eff, design)        # [B, n_obs]
+            inv_sig = 1.0 / sig
+            r = (y - mu) * inv_sig[:, None]
+            rr = (r * r).sum(-1)
+            lp = (-0.005 * intercept * intercept - 0.125 * fe * fe - 0.5 * (raw * raw).sum(-1) - 0.5 * (craw * craw).sum(-1)
+                  - 0.5 * sd * sd + lsd - 0.5 * csd * csd + lcsd - (0.5 / 2.25) * sig * sig + lsig - 0.5 * rr - n_obs * lsig)
+            w = r * inv_sig[:, None]                                                       # d lp / d mu
+            gw = w @ design_t                                                              # [B, 2n]
+            g_ext, g_cext = gw[:, :n], gw[:, n:]
+            g = torch.empty_like(x)
+            g[:, o_int] = -0.01 * intercept + w.sum(-1)
+            g[:, o_floor] = -0.25 * fe + (w * floor).sum(-1)
+            g[:, o_raw:o_raw + n - 1] = extend_t(g_ext * sd[:, None]) - raw
+            g[:, o_craw:o_craw + n - 1] = extend_t(g_cext * csd[:, None]) - craw
+            g[:, o_lsd] = 1.0 - sd * sd + sd * (ext * g_ext).sum(-1)
+            g[:, o_lcsd] = 1.0 - csd * csd + csd * (cext * g_cext).sum(-1)
+            g[:, o_lsig] = 1.0 - sig * sig / 2.25 + rr - n_obs
+            return lp, g
+
+        def logp_autograd(x):
+            """The same density differentiated by autograd (kept as the reference of the hand-derived gradient)."""
             xg = x.detach().requires_grad_(True)
             lp = logp_only(xg)
             (g,) = torch.autograd.grad(lp.sum(), xg)
             return lp.detach(), g
 
+        logp.autograd_reference = logp_autograd
         return logp
 
     def expand(x):

@@ -145,3 +145,19 @@ def test_shard_chains():
         assert sum(p[1] for p in parts) == n
         assert parts[0][0] == 0 and all(parts[i][0] + parts[i][1] == parts[i + 1][0] for i in range(w - 1))
         assert max(p[1] for p in parts) - min(p[1] for p in parts) <= 1
+
+
+def test_radon_hand_derived_gradient_matches_autograd():
+    # config 3's log-density (nutpie_amd/radon.py) carries a hand-derived gradient (GEMM gather / scatter-add, ~35
+    # kernels); autograd of the same density is the reference.  Runs on the CPU: the formulas, not the device.
+    import torch
+
+    from nutpie_amd.radon import radon_model
+
+    m = radon_model(device="cpu")
+    f = m._make_logp_func()
+    x = torch.randn(5, m.n_dim, dtype=torch.float64) * 0.4
+    lp, g = f(x)
+    lp_ref, g_ref = f.autograd_reference(x)
+    assert torch.allclose(lp, lp_ref, rtol=1e-12, atol=1e-10)
+    assert torch.allclose(g, g_ref, rtol=1e-10, atol=1e-9)
