@@ -101,6 +101,8 @@ def lib():
         _lib.oracle_last_error.restype = C.c_char_p
         _lib.oracle_logaddexp.restype = C.c_double
         _lib.oracle_logaddexp.argtypes = [C.c_double, C.c_double]
+        _lib.oracle_w_leaf.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+        _lib.oracle_w_add.argtypes = [C.c_double, C.c_int64, C.c_double, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         _lib.oracle_dot.restype = C.c_double
         _lib.oracle_leapfrog_tridiag.restype = C.c_double
     return _lib
@@ -241,6 +243,19 @@ def detmath(fn: str, x):
 
 def logaddexp(a, b):
     return lib().oracle_logaddexp(a, b)
+
+
+def w_leaf(neg_energy_error):
+    """Extended-range weight (m, e) of a leaf: m * 2**e ~= exp(neg_energy_error)."""
+    m, e = C.c_double(), C.c_int64()
+    lib().oracle_w_leaf(float(neg_energy_error), C.byref(m), C.byref(e))
+    return m.value, e.value
+
+
+def w_add(a, b):
+    m, e = C.c_double(), C.c_int64()
+    lib().oracle_w_add(float(a[0]), int(a[1]), float(b[0]), int(b[1]), C.byref(m), C.byref(e))
+    return m.value, e.value
 
 
 def normals(seed, chain, draw, purpose, n):

@@ -939,6 +939,13 @@ void oracle_detmath(int fn, uint64_t n, const double* x, double* y) {
 
 double oracle_logaddexp(double a, double b) { return det_logaddexp(a, b); }
 
+// extended-range tree weights (unit hooks)
+void oracle_w_leaf(double neg_energy_error, double* m, int64_t* e) { Weight w = w_leaf(neg_energy_error); *m = w.m; *e = w.e; }
+void oracle_w_add(double m1, int64_t e1, double m2, int64_t e2, double* m, int64_t* e) {
+    Weight a; a.m = m1; a.e = e1; Weight b; b.m = m2; b.e = e2;
+    Weight o = w_add(a, b); *m = o.m; *e = o.e;
+}
+
 void oracle_normals(uint64_t seed, uint32_t chain, uint32_t draw, uint32_t purpose, uint64_t n, double* out) {
     for (uint64_t j = 0; 2 * j < n; ++j) {
         double z0, z1;

@@ -106,6 +106,8 @@ const char* oracle_last_error(void);
 void oracle_philox(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t out[4]);
 void oracle_detmath(int fn, uint64_t n, const double* x, double* y); /* 0 exp 1 log 2 log1p 3 sin2pi 4 cos2pi */
 double oracle_logaddexp(double a, double b);
+void oracle_w_leaf(double neg_energy_error, double* m, int64_t* e);
+void oracle_w_add(double m1, int64_t e1, double m2, int64_t e2, double* m, int64_t* e);
 void oracle_normals(uint64_t seed, uint32_t chain, uint32_t draw, uint32_t purpose, uint64_t n, double* out);
 double oracle_dot(const double* x, const double* y, uint64_t n, int waves);
 /* one leapfrog on the tridiag model; state arrays are in/out. returns energy U'+K'. */

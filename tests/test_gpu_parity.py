@@ -376,3 +376,24 @@ def test_config2_full_size_properties(hip):
     assert a.stats["diverging"][:, 150:].mean() < 0.01
     # energy conservation of accepted points: |energy_error| is O(1), never near max_energy_error
     assert np.abs(a.stats["energy_error"][:, 150:]).max() < 50
+
+
+@pytest.mark.parametrize("dim,chains", [(10000, 64), (3000, 128)])
+def test_large_dimension_shapes_properties(hip, dim, chains):
+    """BASELINE.json config 5's shape (D = 10 000: memory-resident kernels, 8 waves per chain, sigma^2 in LDS) and the
+    4-wave register kernels (D = 3000), short runs: determinism, independence from the batch, analytic moments."""
+    m = ar1_gaussian(dim)
+    kw = dict(tune=120, draws=40, seed=dim)
+    a, W = run_engine(hip, hip.TridiagGaussianModel(m.diag, m.offdiag), chains=chains, **kw)
+    assert W == (8 if dim > 4096 else 4) and a.finished.min() == 160
+    b, _ = run_engine(hip, hip.TridiagGaussianModel(m.diag, m.offdiag), chains=4, **kw)
+    assert np.array_equal(a.draws[:4], b.draws) and np.array_equal(a.stats["n_steps"][:4], b.stats["n_steps"])
+    d = a.draws[:, 120:]
+    var = np.diag(m.covariance()) if dim <= 3000 else None
+    if var is not None:
+        ratio = d.var((0, 1)) / var
+        assert 0.6 < ratio.min() and ratio.max() < 1.6       # 5120 autocorrelated draws per dimension
+    assert a.stats["diverging"][:, 120:].mean() < 0.02
+    acc = a.stats["mean_tree_accept"][:, 120:].mean()
+    assert 0.7 < acc < 0.95                                   # dual averaging reached the 0.8 target
+    assert np.abs(a.stats["energy_error"][:, 120:]).max() < 50

@@ -133,6 +133,29 @@ def test_adam_step_size_adaptation_reaches_the_target(oracle):
     assert lo.stats["step_size"][:, -1].mean() > 1.5 * hi.stats["step_size"][:, -1].mean()
 
 
+def test_extended_range_tree_weights_equal_log_domain_weights(oracle):
+    # the (m, e) weights (nphip_spec.h) carry the same numbers as nuts-rs's log_size / logaddexp, for any finite
+    # energy error, without overflow
+    import math
+
+    rng = np.random.default_rng(3)
+    for scale in (0.5, 30.0, 3000.0):
+        xs = rng.normal(size=64) * scale             # -energy_error of 64 leaves
+        w = oracle.w_leaf(xs[0])
+        ls = xs[0]
+        for x in xs[1:]:
+            w = oracle.w_add(w, oracle.w_leaf(x))
+            ls = np.logaddexp(ls, x)
+            assert 0.0 < w[0] < 200.0                # mantissa stays O(number of leaves)
+            assert abs(math.log(w[0]) + w[1] * math.log(2.0) - ls) <= 1e-12 * max(1.0, abs(ls))
+    m, e = oracle.w_leaf(-1e300)                     # absurd energy errors are clamped, not propagated
+    assert math.isfinite(m) and m > 0 and e < -10**9
+    big, small = oracle.w_leaf(5000.0), oracle.w_leaf(-5000.0)
+    assert oracle.w_add(big, small) == big and oracle.w_add(small, big) == big   # below 2^-1000 of the total: dropped
+    one = oracle.w_leaf(0.0)
+    assert one == (1.0, 0) and oracle.w_add(one, one) == (2.0, 0)
+
+
 def test_welford_matches_numpy(oracle):
     rng = np.random.default_rng(3)
     x = rng.normal(size=(50, 7)) * np.arange(1, 8)
