@@ -404,9 +404,44 @@ struct Machine {
     // chunks once — read q, grad, p, rho, sigma^2; write q', grad', p', rho' — interior tridiagonal neighbours come
     // from DPP wave shifts, the two chunk-edge neighbours are recomputed from their own inputs (bit-identical, so
     // no cross-wave exchange and no second pass), and the level-0 U-turn criterion is accumulated on the way.
+    // z' = q' - mu of ONE element e (a chunk-edge neighbour owned by another lane / wave), from that element's own inputs.
+    // The cached streaming kernel keeps no gradient in memory inside a tree (NOG): it is rebuilt from q (bit-identical to
+    // the value computed when q was produced: same operations in the same order).
+    static constexpr bool NOG = FUSED && NV < 0;   // measured: pays with the VGPR cache (W = 1), costs 4-8 % at W = 8
+    __device__ __forceinline__ double elem_grad(const double* q, int64_t e) const {
+        const double ze = ld1(q, e) - ld1(A.m_mu, e);
+        double t = ld1(A.m_a, e) * ze;
+        t = fma((e > 0) ? ld1(A.m_b, e - 1) : -0.0, (e > 0) ? ld1(q, e - 1) - ld1(A.m_mu, e - 1) : 0.0, t);
+        t = fma(ld1(A.m_b, e), (e + 1 < ld) ? ld1(q, e + 1) - ld1(A.m_mu, e + 1) : 0.0, t);
+        return -t;
+    }
     __device__ __forceinline__ double edge_z(const double* q, const double* g, const double* p, int64_t e, double eps, double h) const {
-        const double ph = fma(h, ld1(g, e), ld1(p, e));
+        const double ge = NOG ? elem_grad(q, e) : ld1(g, e);
+        const double ph = fma(h, ge, ld1(p, e));
         return fma(eps, sg1(e) * ph, ld1(q, e)) - ld1(A.m_mu, e);
+    }
+    // gradient of the element pair i of this lane from q (the chunk's other pairs by DPP, its neighbours by uniform loads)
+    __device__ __forceinline__ double2 pair_grad(const double* q, int64_t i, const double2 q2) const {
+        const double2 mu = ld2(A.m_mu, i), a = ld2(A.m_a, i), b = ld2(A.m_b, i);
+        const int64_t c0 = i - 2 * lane;
+        double2 z;
+        z.x = q2.x - mu.x;
+        z.y = q2.y - mu.y;
+        const double zl_edge = (c0 > 0) ? ld1(q, c0 - 1) - ld1(A.m_mu, c0 - 1) : 0.0;
+        const double zr_edge = (c0 + NPHIP_CHUNK < ld) ? ld1(q, c0 + NPHIP_CHUNK) - ld1(A.m_mu, c0 + NPHIP_CHUNK) : 0.0;
+        const double bl = wave_shr1(b.y, (c0 > 0) ? ld1(A.m_b, c0 - 1) : -0.0);
+        const double zl = wave_shr1(z.y, zl_edge);
+        const double zr = wave_shl1(z.x, zr_edge);
+        double tx = a.x * z.x;
+        tx = fma(bl, zl, tx);
+        tx = fma(b.x, z.y, tx);
+        double ty = a.y * z.y;
+        ty = fma(b.x, z.x, ty);
+        ty = fma(b.y, zr, ty);
+        double2 gq;
+        gq.x = -tx;
+        gq.y = -ty;
+        return gq;
     }
     __device__ __forceinline__ double lf_stream(double& lp, int64_t idx_new, bool& turn0, SCacheT& Y) {
         const int64_t srcq = c->lf_srcq, srcp = c->lf_srcp, newq = c->lf_newq, newp = c->lf_newp;
@@ -425,7 +460,10 @@ struct Machine {
             }
             if (SCG && Y.tag_q != srcq) {
 #pragma unroll
-                for (int k = 0; k < NSX; ++k) { const int64_t cc = wave + (int64_t)k * W; if (cc < nch) Y.g[k] = ld2(g, cc * NPHIP_CHUNK + 2 * lane); }
+                for (int k = 0; k < NSX; ++k) {
+                    const int64_t cc = wave + (int64_t)k * W;
+                    if (cc < nch) { const int64_t i = cc * NPHIP_CHUNK + 2 * lane; Y.g[k] = pair_grad(q, i, ld2(q, i)); }
+                }
             }
             if (Y.tag_p != srcp) {
 #pragma unroll
@@ -474,7 +512,8 @@ struct Machine {
             accE.y = fma(ty0, vy, accE.y);
             accS.x = fma(tx0, s2.x * p2.x, accS.x);
             accS.y = fma(ty0, s2.y * p2.y, accS.y);
-            st2(qn, i, qq); st2(gn, i, gg); st2(pn, i, pv); st2(rn, i, rr);
+            st2(qn, i, qq); st2(pn, i, pv); st2(rn, i, rr);
+            if (!NOG) st2(gn, i, gg);
         };
         if (NV < 0) {
             // the only state loads left: q (and grad where it is not cached) of every chunk, issued back to back so
@@ -485,7 +524,7 @@ struct Machine {
                 int64_t cc = wave + (int64_t)k * W;
                 cc = cc < nch ? cc : nch - 1;
                 qv[k] = ld2(q, cc * NPHIP_CHUNK + 2 * lane);
-                if (!SCG) gv[SCG ? 0 : k] = ld2(g, cc * NPHIP_CHUNK + 2 * lane);
+                if (!SCG) gv[SCG ? 0 : k] = pair_grad(q, cc * NPHIP_CHUNK + 2 * lane, qv[k]);
             }
 #pragma unroll
             for (int k = 0; k < NSX; ++k) {
@@ -502,7 +541,8 @@ struct Machine {
         } else {
             NPHIP_FOR_CHUNKS(i) {
                 double2 gg, pv, rr;
-                body(i, ld2(q, i), ld2(g, i), ld2(p, i), ld2(r, i), sg2(i), gg, pv, rr);
+                const double2 q2 = ld2(q, i);
+                body(i, q2, NOG ? pair_grad(q, i, q2) : ld2(g, i), ld2(p, i), ld2(r, i), sg2(i), gg, pv, rr);
             }
         }
         double v[4] = {accK.x + accK.y, accL.x + accL.y, accE.x + accE.y, accS.x + accS.y};
@@ -1346,7 +1386,7 @@ struct Machine {
                 c->acc_sym_sum += 2.0 * a / (1.0 + e);
             }
         }
-        if (diverged) { rare_end_draw(A, c, red, chain, true, false, true, ok); return true; }
+        if (diverged) { rare_end_draw(A, c, red, chain, true, false, true, ok, NOG); return true; }
 
         const int64_t near_idx = dir > 0 ? c->idx_right : c->idx_left;
         const int64_t sT_last = c->lf_newp;
@@ -1376,7 +1416,7 @@ struct Machine {
                         turn = check_merge(X, 3, sA_first, iA_first, slot_last(__builtin_ctzll((unsigned long long)al), A.cap), near_idx + dir * al,
                                            slot_first(__builtin_ctzll((unsigned long long)(tf - 1))), near_idx + dir * tf, sT_last, idx_new);
                 }
-                if (turn) { rare_end_draw(A, c, red, chain, false, false, false, false); return true; }
+                if (turn) { rare_end_draw(A, c, red, chain, false, false, false, false, NOG); return true; }
             }
             {   // multinomial merge: keep T's draw w.p. w_T / (w_A + w_T)
                 double sm; int64_t se;
@@ -1414,8 +1454,8 @@ struct Machine {
             c->main_wm = sm; c->main_we = se;
             c->depth = d + 1;
         }
-        if (turn) { rare_end_draw(A, c, red, chain, false, false, false, false); return true; }
-        if (c->depth >= A.s.maxdepth) { rare_end_draw(A, c, red, chain, false, true, false, false); return true; }
+        if (turn) { rare_end_draw(A, c, red, chain, false, false, false, false, NOG); return true; }
+        if (c->depth >= A.s.maxdepth) { rare_end_draw(A, c, red, chain, false, true, false, false, NOG); return true; }
         start_doubling();
         return false;
     }
@@ -1438,7 +1478,14 @@ struct Machine {
 #ifdef NPHIP_PROFILE
         ctl->prof[12] += (int64_t)__builtin_readcyclecounter() - t0_;
 #endif
-        if (store_div) m.store_divergence(div_has_end);
+        if (store_div) {
+            if (regrad && a.tr_div[0]) {   // the divergence record wants the gradient at the start of the failed step
+                double lp_;
+                int64_t code_;
+                m.eval_position(ctl->lf_srcq, lp_, code_);
+            }
+            m.store_divergence(div_has_end);
+        }
         m.end_draw(diverging, maxdepth);
     }
     static __device__ __attribute__((noinline)) void rare_phase_fn(const NPHIP_CONST Args& a, LdsCtl ctl, LdsDouble r, int64_t ch, int64_t ph) {
