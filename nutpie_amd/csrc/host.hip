@@ -474,6 +474,10 @@ struct nphip_sampler {
     }
 };
 
+// Waves per chain: a function of the dimension ONLY.  The summation geometry (hence every float of a chain) depends on
+// it, and a chain's result must not depend on how many other chains run with it or on how they are sharded.  (Measured:
+// with 64..256 chains at D = 1000, waves_per_chain = 4 is 20 % faster — available through nphip_launch_t, not chosen
+// behind the user's back; 2 waves per chain are slower than 1.)
 static int choose_waves(uint64_t dim) {
     if (dim <= 1024) return 1;
     if (dim <= 2048) return 2;
@@ -528,7 +532,7 @@ bool nphip_sampler::setup() {
     int reg_multi = 0;
     if (fused_model && (W == 2 || W == 4) && !launch.no_register_kernel && !set.store_divergences) {
         const int64_t per_wave = ((int64_t)((dim + 127) / 128) + W - 1) / W;
-        if (per_wave >= 5 && per_wave <= 8) { reg_multi = (int)per_wave; args.ld = per_wave * W * 128; }
+        if (per_wave >= 1 && per_wave <= 8) { reg_multi = (int)per_wave; args.ld = per_wave * W * 128; }
     }
     args.cap = (int32_t)set.maxdepth;
     args.npslots = num_pslots(args.cap);

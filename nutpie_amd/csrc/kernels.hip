@@ -1714,16 +1714,24 @@ static hipError_t launch_w(const Args& a, const Args* d_args, int W, hipStream_t
     const unsigned n = (unsigned)a.n_chains;
     const int me = a.max_evals, hr = a.have_result;
     if (FUSED && (W == 2 || W == 4) && a.reg_nv > 0) {
-        // register-resident, several waves per chain (1024 < D <= 4096): one workgroup = one chain
+        // register-resident, several waves per chain (1024 < D <= 4096, or fewer chains than SIMDs): one workgroup = one chain
         const dim3 g(n), b(64 * W);
 #define NPHIP_LAUNCH_RW(WW, NN) hipLaunchKernelGGL((k_advance<true, WW, NN>), g, b, 0, st, d_args, me, hr)
         if (W == 2) switch (a.reg_nv) {
+            case 1: NPHIP_LAUNCH_RW(2, 1); break;
+            case 2: NPHIP_LAUNCH_RW(2, 2); break;
+            case 3: NPHIP_LAUNCH_RW(2, 3); break;
+            case 4: NPHIP_LAUNCH_RW(2, 4); break;
             case 5: NPHIP_LAUNCH_RW(2, 5); break;
             case 6: NPHIP_LAUNCH_RW(2, 6); break;
             case 7: NPHIP_LAUNCH_RW(2, 7); break;
             case 8: NPHIP_LAUNCH_RW(2, 8); break;
             default: return hipErrorInvalidValue;
         } else switch (a.reg_nv) {
+            case 1: NPHIP_LAUNCH_RW(4, 1); break;
+            case 2: NPHIP_LAUNCH_RW(4, 2); break;
+            case 3: NPHIP_LAUNCH_RW(4, 3); break;
+            case 4: NPHIP_LAUNCH_RW(4, 4); break;
             case 5: NPHIP_LAUNCH_RW(4, 5); break;
             case 6: NPHIP_LAUNCH_RW(4, 6); break;
             case 7: NPHIP_LAUNCH_RW(4, 7); break;

@@ -119,8 +119,9 @@ def test_engine_matches_committed_golden_vectors(hip, name):
 
 
 @pytest.mark.parametrize("dim,waves", [(1, 1), (2, 1), (127, 1), (128, 1), (129, 2), (1000, 1), (1000, 4), (2500, 2), (5003, 8), (9000, 16),
-                                       # register-resident kernels with several waves per chain (5..8 chunks per wave)
-                                       (1100, 2), (1500, 2), (2048, 2), (2500, 4), (3300, 4), (4096, 4)])
+                                       # register-resident kernels with several waves per chain
+                                       (1100, 2), (1500, 2), (2048, 2), (2500, 4), (3300, 4), (4096, 4),
+                                       (256, 2), (700, 2), (1000, 2), (512, 4), (900, 4), (1536, 4)])
 def test_correlated_gaussian_all_geometries(hip, oracle, dim, waves):
     rng = np.random.default_rng(dim)
     sd = np.exp(0.7 * rng.normal(size=dim))
@@ -210,12 +211,25 @@ def test_multiwave_register_kernels_variants(hip, oracle, dim, settings, launch)
     # register-resident kernels with 2 (D = 1300) and 4 (D = 2600) waves per chain under the awkward settings
     model = ar1_gaussian(dim)
     kw = dict(chains=3, tune=50, draws=12, seed=dim + 3)
-    got, W = run_engine(hip, hip.TridiagGaussianModel(model.diag, model.offdiag), launch=launch, **kw, **settings)
+    got, W = run_engine(hip, hip.TridiagGaussianModel(model.diag, model.offdiag), launch=launch, waves=2 if dim <= 2048 else 4, **kw, **settings)
     assert W == (2 if dim <= 2048 else 4)
     want = oracle.sample_tridiag(oracle_settings(oracle, W=W, **kw, **settings), model.diag, model.offdiag)
     assert_trace_equal(got, want)
     if "store_gradient" in settings:
         assert np.array_equal(got.stats["gradient"], want.stats["gradient"])
+
+
+def test_four_waves_per_chain_for_small_batches(hip, oracle):
+    # fewer chains than SIMDs: waves_per_chain = 4 (register-resident, +20 % at 64..256 chains) is the caller's choice,
+    # never the engine's: by default a chain's floats do not depend on how many chains run with it
+    model = ar1_gaussian(1000)
+    kw = dict(chains=6, tune=60, draws=20, seed=12)
+    got, W = run_engine(hip, hip.TridiagGaussianModel(model.diag, model.offdiag), waves=4, **kw)
+    assert W == 4
+    want = oracle.sample_tridiag(oracle_settings(oracle, W=W, **kw), model.diag, model.offdiag)
+    assert_trace_equal(got, want)
+    _, Wd = run_engine(hip, hip.TridiagGaussianModel(model.diag, model.offdiag), chains=6, tune=3, draws=2, seed=12)
+    assert Wd == 1
 
 
 def test_init_strategies(hip, oracle):
