@@ -408,6 +408,7 @@ struct nphip_sampler {
     Args* d_args = nullptr;  // device copy, read by the kernels through the constant address space
     int W = 1;
     bool fused = true;
+    bool zero_copy = false;  // host callbacks: staging buffers in pinned host memory, no copies
     uint64_t n = 0, T = 0, dim = 0;
     std::vector<void*> allocs;
     std::vector<void*> pinned;
@@ -578,12 +579,17 @@ bool nphip_sampler::setup() {
         HIP_TRY(hipMemcpyAsync(bsh, bshpad.data(), (ld + 8) * 8, hipMemcpyHostToDevice, stream));
         args.m_bsh = bsh;
     } else {
+        // Host callbacks with small batches are latency-bound (five copies + a synchronisation per leapfrog): there the
+        // staging buffers ARE the pinned host buffers (coherent, GPU-visible on ROCm) and the kernel reads / writes them
+        // over PCIe directly.  Larger batches keep device staging + bulk copies.
+        zero_copy = (model.kind == 1) && !(launch.staging_q && launch.staging_grad && launch.staging_logp) && n * dim * 8 <= (4u << 20);
         if (launch.staging_q && launch.staging_grad && launch.staging_logp) {
             args.qeval = (double*)launch.staging_q; args.geval = (double*)launch.staging_grad; args.ueval = (double*)launch.staging_logp;
-        } else if (!dalloc(&args.qeval, n * dim) || !dalloc(&args.geval, n * dim) || !dalloc(&args.ueval, n)) return false;
+        } else if (!zero_copy && (!dalloc(&args.qeval, n * dim) || !dalloc(&args.geval, n * dim) || !dalloc(&args.ueval, n))) return false;
         if (model.kind == 1) {
-            if (!dalloc(&args.ecode, n)) return false;
+            if (!zero_copy && !dalloc(&args.ecode, n)) return false;
             if (!palloc(&h_q, n * dim) || !palloc(&h_g, n * dim) || !palloc(&h_u, n) || !palloc(&h_code, n)) return false;
+            if (zero_copy) { args.qeval = h_q; args.geval = h_g; args.ueval = h_u; args.ecode = h_code; }
             // n_threads == 0: size the pool by the work per step; waking a thread costs more than a few
             // hundred cheap rows (eight-schools, 256 chains: 1 thread 71 us/step, 16 threads 169 us/step)
             int nt = model.n_threads > 0 ? model.n_threads : (int)std::thread::hardware_concurrency();
@@ -673,7 +679,7 @@ bool nphip_sampler::iteration_callback(bool& all_done, int& have) {
         // host callback: D2H positions, evaluate rows on the host pool, H2D gradients
         // (pinned hipMemcpyAsync; the reference calls the same function pointer once per
         // chain-step from its worker threads: src/pymc.rs:197-215)
-        if (!hip_ok(hipMemcpyAsync(h_q, args.qeval, n * dim * 8, hipMemcpyDeviceToHost, stream), "D2H q")) return false;
+        if (!zero_copy && !hip_ok(hipMemcpyAsync(h_q, args.qeval, n * dim * 8, hipMemcpyDeviceToHost, stream), "D2H q")) return false;
         if (!hip_ok(hipMemcpyAsync(h_counters, args.counters, 16, hipMemcpyDeviceToHost, stream), "copy counters")) return false;
         if (!hip_ok(hipStreamSynchronize(stream), "hipStreamSynchronize")) return false;
         if (h_counters[1] > 0) { set_error(chain_error_message()); return false; }
@@ -684,9 +690,11 @@ bool nphip_sampler::iteration_callback(bool& all_done, int& have) {
             h_code[r] = model.host_fn(d, h_q + r * d, h_g + r * d, &lp, model.user);
             h_u[r] = lp;
         });
-        if (!hip_ok(hipMemcpyAsync(args.geval, h_g, n * dim * 8, hipMemcpyHostToDevice, stream), "H2D grad")) return false;
-        if (!hip_ok(hipMemcpyAsync(args.ueval, h_u, n * 8, hipMemcpyHostToDevice, stream), "H2D logp")) return false;
-        if (!hip_ok(hipMemcpyAsync(args.ecode, h_code, n * 8, hipMemcpyHostToDevice, stream), "H2D code")) return false;
+        if (!zero_copy) {
+            if (!hip_ok(hipMemcpyAsync(args.geval, h_g, n * dim * 8, hipMemcpyHostToDevice, stream), "H2D grad")) return false;
+            if (!hip_ok(hipMemcpyAsync(args.ueval, h_u, n * 8, hipMemcpyHostToDevice, stream), "H2D logp")) return false;
+            if (!hip_ok(hipMemcpyAsync(args.ecode, h_code, n * 8, hipMemcpyHostToDevice, stream), "H2D code")) return false;
+        }
     } else {
         // device callback: counters are polled without synchronising (stale values only delay exit)
         if (!hip_ok(hipMemcpyAsync(h_counters, args.counters, 16, hipMemcpyDeviceToHost, stream), "copy counters")) return false;
