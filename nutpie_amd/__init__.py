@@ -16,6 +16,13 @@ from nutpie_amd.sample import CompiledModel, sample
 
 ChainProgress = _lib.PyChainProgress
 
+
+def zarr_store(*args, **kwargs):
+    """Present for import compatibility (reference ``__init__.py:2``: ``zarr_store = _lib.store``); the HIP engine keeps
+    the trace in HBM and hands it over as dense arrays, so Zarr storage is outside its scope."""
+    raise NotImplementedError("zarr_store is outside the scope of the HIP engine (the trace lives in HBM)")
+
+
 __all__ = [
     "__version__",
     "ChainProgress",
@@ -24,6 +31,7 @@ __all__ = [
     "compile_stan_model",
     "prune_stan_cache",
     "sample",
+    "zarr_store",
     "from_pyfunc",
     "from_torchfunc",
     "std_normal",
