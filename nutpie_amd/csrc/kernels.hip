@@ -160,9 +160,9 @@ struct Regs {
 // Streaming cache (NV < 0, -NV chunks per wave): sigma^2 and the cursor's (grad, p, rho) of this wave's chunks stay
 // in VGPRs between consecutive leaves of the memory-resident kernels.  Every store still happens — memory stays
 // complete, so rare paths, merge criteria and chunk-edge recomputation are untouched — the loads do not.
-template <int NS, bool CG>
+template <int NS>
 struct SCache {
-    double2 s[NS], g[CG ? NS : 1], p[NS], r[NS];
+    double2 s[NS], g[NS], p[NS], r[NS];
     int64_t tag_q = -1, tag_p = -1;
     bool sig_ok = false;
     __device__ __forceinline__ void invalidate() { tag_q = -1; tag_p = -1; sig_ok = false; }
@@ -174,8 +174,7 @@ struct SCache {
 template <bool FUSED, int W, int NV = 0>
 struct Machine {
     static constexpr int NVX = NV > 0 ? NV : 1;
-    static constexpr int NSX = NV < 0 ? (-NV) % 100 : 1;   // NV = -NS: cache (sigma^2, grad, p, rho); NV = -(100 + NS): all but grad
-    static constexpr bool SCG = NV < 0 && (-NV) < 100;
+    static constexpr int NSX = NV < 0 ? -NV : 1;   // NV = -NS: cache (sigma^2, grad, p, rho) of NS chunks per wave
     // kernel arguments, read through the constant address space: s_load into SGPRs (uniform), never flat
     const NPHIP_CONST Args& A;
     LdsCtl c;        // this wave's private LDS copy
@@ -194,7 +193,7 @@ struct Machine {
     double* est;
     int64_t T;
     using RegsT = Regs<NVX>;
-    using SCacheT = SCache<NSX, SCG>;
+    using SCacheT = SCache<NSX>;
 
     __device__ __forceinline__ Machine(const NPHIP_CONST Args& a, LdsCtl ctl, LdsDouble r, int64_t ch, LdsDouble par_ = nullptr, LdsDouble ring_ = nullptr,
                                        LdsDouble edge_ = nullptr)
@@ -458,7 +457,7 @@ struct Machine {
                 for (int k = 0; k < NSX; ++k) { const int64_t cc = wave + (int64_t)k * W; if (cc < nch) Y.s[k] = ld2(sig2, cc * NPHIP_CHUNK + 2 * lane); }
                 Y.sig_ok = true;
             }
-            if (SCG && Y.tag_q != srcq) {
+            if (Y.tag_q != srcq) {
 #pragma unroll
                 for (int k = 0; k < NSX; ++k) {
                     const int64_t cc = wave + (int64_t)k * W;
@@ -516,23 +515,22 @@ struct Machine {
             if (!NOG) st2(gn, i, gg);
         };
         if (NV < 0) {
-            // the only state loads left: q (and grad where it is not cached) of every chunk, issued back to back so
+            // the only state loads left: q of every chunk, issued back to back so
             // that they are all in flight together (chunks past the end re-read the last one; never used)
-            double2 qv[NSX], gv[SCG ? 1 : NSX];
+            double2 qv[NSX];
 #pragma unroll
             for (int k = 0; k < NSX; ++k) {
                 int64_t cc = wave + (int64_t)k * W;
                 cc = cc < nch ? cc : nch - 1;
                 qv[k] = ld2(q, cc * NPHIP_CHUNK + 2 * lane);
-                if (!SCG) gv[SCG ? 0 : k] = pair_grad(q, cc * NPHIP_CHUNK + 2 * lane, qv[k]);
             }
 #pragma unroll
             for (int k = 0; k < NSX; ++k) {
                 const int64_t cc = wave + (int64_t)k * W;
                 if (cc < nch) {
                     double2 gg, pv, rr;
-                    body(cc * NPHIP_CHUNK + 2 * lane, qv[k], SCG ? Y.g[SCG ? k : 0] : gv[SCG ? 0 : k], Y.p[k], Y.r[k], Y.s[k], gg, pv, rr);
-                    if (SCG) Y.g[SCG ? k : 0] = gg;
+                    body(cc * NPHIP_CHUNK + 2 * lane, qv[k], Y.g[k], Y.p[k], Y.r[k], Y.s[k], gg, pv, rr);
+                    Y.g[k] = gg;
                     Y.p[k] = pv; Y.r[k] = rr;
                 }
             }
