@@ -90,7 +90,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 // Sum N values over the chain: wave_sum per value, then (W > 1) wave totals in wave order through LDS.
-template <int W, int N>
+template <int W, int N, bool TRAILING_BARRIER = true>
 __device__ __forceinline__ void reduceN(double (&v)[N], NPHIP_LDS double* red) {
 #pragma unroll
     for (int n = 0; n < N; ++n) v[n] = wave_sum(v[n]);
@@ -107,7 +107,7 @@ __device__ __forceinline__ void reduceN(double (&v)[N], NPHIP_LDS double* red) {
             for (int w = 1; w < W; ++w) t = t + red[N * w + n];
             v[n] = t;
         }
-        __syncthreads();
+        if (TRAILING_BARRIER) __syncthreads();   // (callers that alternate between two scratch areas do not need it)
     }
 }
 template <int W>
@@ -178,7 +178,8 @@ struct Machine {
     // kernel arguments, read through the constant address space: s_load into SGPRs (uniform), never flat
     const NPHIP_CONST Args& A;
     LdsCtl c;        // this wave's private LDS copy
-    LdsDouble red;   // LDS reduction scratch [8*W]
+    LdsDouble red;   // LDS reduction scratch: two areas of [8*W], used alternately (one barrier per reduction)
+    int rflip = 0;
     LdsDouble par;   // NV > 0: LDS copy of the fused model: mu[ld], a[ld], then b shifted by one (par_b[i] = b_{i-1})
     LdsDouble ring;  // NV > 0: this wave's LDS ring of two (p, rho) summaries: [slot][p|rho][NV*64 double2]
     LdsDouble edge;  // NV > 0, W > 1: chunk-edge exchange buffer of the chain [2 * chunks]
@@ -214,6 +215,18 @@ struct Machine {
     __device__ __forceinline__ double* R(int64_t s) const { return pp + (size_t)s * 2 * ld + ld; }
     __device__ __forceinline__ double* EST(int64_t e, int k) const { return est + (size_t)(e * 4 + k) * ld; }
     __device__ __forceinline__ bool leader() const { return lane == 0 && wave == 0; }
+    // chain-wide sums.  Consecutive reductions alternate between two LDS areas: by the time an area is written again
+    // every wave has passed the barrier of the reduction in between, i.e. has finished reading it.
+    template <int N>
+    __device__ __forceinline__ void rsum(double (&v)[N]) {
+        reduceN<W, N, false>(v, red + (W > 1 ? rflip * 8 * W : 0));
+        rflip ^= 1;
+    }
+    __device__ __forceinline__ void rsum2(double& a, double& b) {
+        double v[2] = {a, b};
+        rsum(v);
+        a = v[0]; b = v[1];
+    }
     // sigma^2 of the hot streaming passes: from the chain's LDS copy where there is one (one chain per CU at W >= 8)
     __device__ __forceinline__ double2 sg2(int64_t i) const {
         if (sig_lds) { const double2 v = *(const NPHIP_LDS double2*)(sig_lds + i); return v; }
@@ -324,7 +337,7 @@ struct Machine {
             acc.y = fma(v.y, s2.y * v.y, acc.y);
         }
         double a = acc.x + acc.y, b = 0.0;
-        reduce2<W>(a, b, red);
+        rsum2(a, b);
         return 0.5 * a;
     }
 
@@ -381,7 +394,7 @@ struct Machine {
                 acc.y = fma(z.y, gg.y, acc.y);
             }
             double a = acc.x + acc.y, b = 0.0;
-            reduce2<W>(a, b, red);
+            rsum2(a, b);
             lp = 0.5 * a;
             code = 0;
         } else {
@@ -544,7 +557,7 @@ struct Machine {
             }
         }
         double v[4] = {accK.x + accK.y, accL.x + accL.y, accE.x + accE.y, accS.x + accS.y};
-        reduceN<W, 4>(v, red);
+        rsum(v);
         lp = 0.5 * v[1];
         turn0 = (v[2] < 0.0) || (v[3] < 0.0);
         return 0.5 * v[0];
@@ -589,7 +602,7 @@ struct Machine {
         double v[6];
 #pragma unroll
         for (int n = 0; n < 6; ++n) v[n] = acc[n].x + acc[n].y;
-        reduceN<W, 6>(v, red);
+        rsum(v);
         return (v[0] < 0.0) || (v[1] < 0.0) || (v[2] < 0.0) || (v[3] < 0.0) || (v[4] < 0.0) || (v[5] < 0.0);
     }
 
@@ -631,7 +644,7 @@ struct Machine {
             st2(rn, i, rr);
         }
         double a = accK.x + accK.y, b = accL.x + accL.y;
-        reduce2<W>(a, b, red);
+        rsum2(a, b);
         if (FUSED) { lp = 0.5 * b; code = 0; }
         return 0.5 * a;
     }
@@ -742,7 +755,7 @@ struct Machine {
         double v[4];
 #pragma unroll
         for (int n = 0; n < 4; ++n) v[n] = acc[n].x + acc[n].y;
-        reduceN<W, 4>(v, red);
+        rsum(v);
         return (v[0] < 0.0) || (v[1] < 0.0) || (v[2] < 0.0) || (v[3] < 0.0);
     }
     __device__ __forceinline__ bool check1(const RegsT& X, const double2 (&ap)[NVX], const double2 (&ar)[NVX], int64_t iA, int64_t iTL) {
@@ -755,7 +768,7 @@ struct Machine {
             pair_acc(p1, ap[k].y, ar[k].y, X.p[k].y, X.r[k].y, X.s[k].y, e.y, st.y);
         }
         double v[2] = {e.x + e.y, st.x + st.y};
-        reduceN<W, 2>(v, red);
+        rsum(v);
         return (v[0] < 0.0) || (v[1] < 0.0);
     }
     // pass A: (A.first, TL) || (A.first, TF) with TF in registers
@@ -774,7 +787,7 @@ struct Machine {
         double v[4];
 #pragma unroll
         for (int n = 0; n < 4; ++n) v[n] = acc[n].x + acc[n].y;
-        reduceN<W, 4>(v, red);
+        rsum(v);
         return (v[0] < 0.0) || (v[1] < 0.0) || (v[2] < 0.0) || (v[3] < 0.0);
     }
     // pass B: (A.last, TL)
@@ -787,7 +800,7 @@ struct Machine {
             span_acc(ap[k].y, ar[k].y, X.p[k].y, X.r[k].y, X.s[k].y, e.y, st.y);
         }
         double v[2] = {e.x + e.y, st.x + st.y};
-        reduceN<W, 2>(v, red);
+        rsum(v);
         return (v[0] < 0.0) || (v[1] < 0.0);
     }
     // ---- LDS ring of recent (p, rho) summaries
@@ -965,7 +978,7 @@ struct Machine {
 #endif
         NPHIP_PHASE_FENCE();
         double v4[4] = {accK.x + accK.y, accL.x + accL.y, accE.x + accE.y, accS.x + accS.y};
-        reduceN<W, 4>(v4, red);
+        rsum(v4);
         NPHIP_PHASE_FENCE();
 #ifdef NPHIP_PROFILE
         const int64_t tp2 = (int64_t)__builtin_readcyclecounter();
@@ -1142,7 +1155,7 @@ struct Machine {
             acc2.y = fma(t.y, s2.y * vps.y, acc2.y);
         }
         double t1 = acc1.x + acc1.y, t2 = acc2.x + acc2.y;
-        reduce2<W>(t1, t2, red);
+        rsum2(t1, t2);
         return (t1 < 0.0) || (t2 < 0.0);
     }
 
@@ -1464,6 +1477,7 @@ struct Machine {
     static __device__ __attribute__((noinline)) void rare_end_draw(const NPHIP_CONST Args& a, LdsCtl ctl, LdsDouble r, int64_t ch,
                                                                   bool diverging, bool maxdepth, bool store_div, bool div_has_end,
                                                                   bool regrad = false) {
+        if (W > 1) __syncthreads();   // the caller's last reduction may have used the scratch area this one starts with
         Machine m(a, ctl, r, ch);
 #ifdef NPHIP_PROFILE
         const int64_t t0_ = (int64_t)__builtin_readcyclecounter();
@@ -1485,10 +1499,13 @@ struct Machine {
             m.store_divergence(div_has_end);
         }
         m.end_draw(diverging, maxdepth);
+        if (W > 1) __syncthreads();
     }
     static __device__ __attribute__((noinline)) void rare_phase_fn(const NPHIP_CONST Args& a, LdsCtl ctl, LdsDouble r, int64_t ch, int64_t ph) {
+        if (W > 1) __syncthreads();   // (see rare_end_draw)
         Machine m(a, ctl, r, ch);
         m.rare_phase(ph);
+        if (W > 1) __syncthreads();
     }
 
     __device__ __forceinline__ void end_draw(bool diverging, bool maxdepth) {
@@ -1669,7 +1686,7 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) __attribute__((amdgpu_waves_
     const NPHIP_CONST Args& A = *(const NPHIP_CONST Args*)Ap;
     constexpr int WAVES = (W == 1) ? 4 : W;
     __shared__ Ctl s_ctl[WAVES];
-    __shared__ double s_red[8 * WAVES];
+    __shared__ double s_red[16 * WAVES];   // two alternating reduction areas
     __shared__ __attribute__((aligned(16))) double s_par[(NV > 0 && W == 1) ? 3 * 128 * NV + 8 : 2];
     __shared__ __attribute__((aligned(16))) double s_ring[NV > 0 ? WAVES * 4 * 128 * NV : 2];  // per wave: 2 slots x (p, rho)
     __shared__ double s_edge[(NV > 0 && W > 1) ? 2 * W * NV : 2];
