@@ -64,12 +64,22 @@ def gather_arrays(local: dict, n_local: int, group=None, dst: int = 0):
     return out
 
 
+def chain_moments(draws, n_tune: int):
+    """Per-chain posterior mean and variance of every dimension from ``draws[chain, draw, dim]`` (a torch tensor, on
+    whatever device it lives): the on-device summary SURVEY.md §8e asks for instead of shipping a config-5 trace."""
+    post = draws[:, n_tune:]
+    return post.mean(1), post.var(1, unbiased=True)
+
+
 def sample_sharded(make_sampler, num_chains: int, *, group=None, thin: int = 1, dims=None, gather_draws: bool = True,
-                   stats=("depth", "n_steps", "diverging", "tuning", "step_size", "energy", "logp"), device=None):
+                   stats=("depth", "n_steps", "diverging", "tuning", "step_size", "energy", "logp"), device=None,
+                   moments_after: int | None = None):
     """Run this rank's shard to completion and gather the trace on rank 0.
 
     ``make_sampler(chain_offset, n_local) -> PySampler``.  Draws are thinned by ``thin`` and restricted to
     ``dims`` ON DEVICE before the gather (a full config-5 trace is 82 GB per GPU).
+    ``moments_after=n_tune`` additionally gathers ``draw_mean`` / ``draw_var`` ``[chains, D]`` (per-chain moments of the
+    post-warm-up draws, reduced on the device; megabytes instead of the trace).
     Returns ``(sampler, gathered)``; ``gathered`` is a dict of tensors on rank 0 and None elsewhere.
     """
     import torch
@@ -96,6 +106,8 @@ def sample_sharded(make_sampler, num_chains: int, *, group=None, thin: int = 1, 
             d = device_tensor(sampler.device_ptr("draws"), (n_local, T, D), "float64", dev)
         else:
             d = torch.from_numpy(sampler._copy("draws", np.float64, vec=True))
+        if moments_after is not None:
+            local["draw_mean"], local["draw_var"] = chain_moments(d, int(moments_after))
         d = d[:, ::thin]
         if dims is not None:
             d = d[:, :, torch.as_tensor(list(dims), device=d.device)]

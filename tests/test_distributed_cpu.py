@@ -23,7 +23,7 @@ def _worker(rank, world, port, num_chains, out_path):
     import torch.distributed as dist
 
     import oracle
-    from nutpie_amd.distributed import gather_arrays, shard_chains
+    from nutpie_amd.distributed import chain_moments, gather_arrays, shard_chains
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -33,6 +33,7 @@ def _worker(rank, world, port, num_chains, out_path):
         s = oracle.default_settings(seed=77, num_chains=n_local, chain_offset=offset, num_tune=40, num_draws=30)
         tr = oracle.sample_tridiag(s, np.linspace(0.5, 2.0, 6))
         local = {"draws": tr.draws[:, ::2], "n_steps": tr.stats["n_steps"], "diverging": tr.stats["diverging"]}
+        local["draw_mean"], local["draw_var"] = chain_moments(torch.from_numpy(tr.draws), 40)
         got = gather_arrays(local, n_local)
         # value = total leapfrogs over all ranks (what bench.py aggregates) via an all-reduce
         tot = torch.tensor([float(tr.stats["n_steps"].sum())], dtype=torch.float64)
@@ -59,3 +60,5 @@ def test_two_rank_sharding_and_gather(tmp_path, num_chains):
     assert np.array_equal(got["n_steps"], full.stats["n_steps"])
     assert np.array_equal(got["diverging"], full.stats["diverging"])
     assert got["total"][0] == full.stats["n_steps"].sum()
+    np.testing.assert_allclose(got["draw_mean"], full.draws[:, 40:].mean(1), rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(got["draw_var"], full.draws[:, 40:].var(1, ddof=1), rtol=1e-10)

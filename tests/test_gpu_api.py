@@ -215,9 +215,12 @@ def test_sharded_sampling_and_rccl_gather_single_rank(tmp_path):
             s.update(num_tune=40, num_draws=20, num_chains=6)
             return _lib.PySampler(s, _lib.TridiagGaussianModel(diag), chain_offset=offset, n_local_chains=n_local)
 
-        smp, got = sample_sharded(make, 6, thin=2, dims=[0, 3, 39])
+        smp, got = sample_sharded(make, 6, thin=2, dims=[0, 3, 39], moments_after=40)
         ref = smp.take_results()
         assert got["draws"].shape == (6, 30, 3)
+        # per-chain moments of the post-warm-up draws, reduced on the device
+        np.testing.assert_allclose(got["draw_mean"].cpu().numpy(), ref.draws[:, 40:].mean(1), rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(got["draw_var"].cpu().numpy(), ref.draws[:, 40:].var(1, ddof=1), rtol=1e-10)
         assert np.array_equal(got["draws"].cpu().numpy(), ref.draws[:, ::2][:, :, [0, 3, 39]])
         assert np.array_equal(got["n_steps"].cpu().numpy(), ref.stats["n_steps"])
         assert np.array_equal(got["diverging"].cpu().numpy().astype(bool), ref.stats["diverging"])
