@@ -393,6 +393,15 @@ class DeviceCallbackModel(_Model):
         super().__init__(lib().nphip_model_device_callback(C.c_uint64(dim), C.cast(cb, C.c_void_p), None), dim, [cb, fn])
 
 
+class NativeDeviceCallbackModel(_Model):
+    """Batched device callback given as a raw C function pointer (``nphip_device_logp_fn``) plus its ``user_data``:
+    a model compiled to native code (e.g. a HIP kernel launcher) — no Python on the per-leapfrog path."""
+
+    def __init__(self, dim, fn_addr: int, user_data: int = 0, keep_alive=None):
+        super().__init__(lib().nphip_model_device_callback(C.c_uint64(dim), C.c_void_p(fn_addr), C.c_void_p(user_data)), dim, [keep_alive])
+        self.exception = None
+
+
 # --------------------------------------------------------------------------- progress / trace
 class PyChainProgress:
     """Field set of ``ChainProgress`` (wrapper.rs:47-104)."""

@@ -16,3 +16,20 @@ lib = ctypes.CDLL(so); addr = ctypes.cast(lib.eight_schools_logp, ctypes.c_void_
 for nt in (1, 4, 16):
     m = from_raw_callback(10, addr, name="theta", n_threads=nt, init="normal", keep_alive=lib)
     t=time.time(); tr = nutpie_amd.sample(m, chains=256, tune=400, draws=1000, seed=4, progress_bar=False, return_raw_trace=True); report(f"config4 eight-schools 256 chains host callback ({nt} threads)", tr, time.time()-t)
+# config 3 with a NATIVE device log-density (tests/fixtures/radon_device.hip) instead of torch: what the callback path
+# costs when the model side is one kernel per evaluation
+import ctypes as C
+from nutpie_amd import _lib
+from nutpie_amd.radon import synthetic_radon_data
+fix = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "fixtures")
+_lib.lib()
+rl = C.CDLL(os.path.join(fix, "libradon_device.so"))
+rl.radon_device_create.restype = C.c_void_p; rl.radon_device_create.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+data = synthetic_radon_data(); n = int(data["county_idx"].max()) + 1
+cty = np.ascontiguousarray(data["county_idx"], dtype=np.int32); fl = np.ascontiguousarray(data["floor"]); yy = np.ascontiguousarray(data["log_radon"])
+h = rl.radon_device_create(n, len(yy), cty.ctypes.data, fl.ctypes.data, yy.ctypes.data)
+fn = C.cast(rl.radon_device_logp, C.c_void_p).value
+for chains in (512, 4096):
+    s = _lib.PyNutsSettings.Diag(1); s.update(num_tune=400, num_draws=1000, num_chains=chains)
+    t = time.time(); smp = _lib.PySampler(s, _lib.NativeDeviceCallbackModel(2 * n + 3, fn, h, keep_alive=rl)); smp.wait(); el = time.time() - t
+    tr = smp.take_results(); report(f"config3 radon {chains} chains, native HIP density (device callback)", tr, el)

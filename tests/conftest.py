@@ -27,6 +27,24 @@ def oracle():
 
 
 @pytest.fixture(scope="session")
+def radon_device_lib():
+    """hipcc-built shared library with the native device log-density of the radon model (tests/fixtures/radon_device.hip):
+    a model written against the batched DEVICE callback of the C-ABI."""
+    src = os.path.join(FIXTURES, "radon_device.hip")
+    out = os.path.join(FIXTURES, "libradon_device.so")
+    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-o", out, src], check=True)
+    from nutpie_amd import _lib
+
+    _lib.lib()  # first: it loads torch's HIP runtime before any other library can pull in a second one
+    lib = ctypes.CDLL(out)
+    lib.radon_device_create.restype = ctypes.c_void_p
+    lib.radon_device_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    lib.radon_device_free.argtypes = [ctypes.c_void_p]
+    return lib
+
+
+@pytest.fixture(scope="session")
 def fixture_lib():
     """gcc-built shared library with the eight-schools test model (tests/fixtures/eight_schools.c)."""
     src = os.path.join(FIXTURES, "eight_schools.c")

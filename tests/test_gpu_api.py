@@ -193,6 +193,54 @@ def test_radon_torch_model_config3():
     assert raw.draws is not None and raw.expanded["sigma"].shape == (8, 25)
 
 
+def test_native_device_callback_radon_kernel(radon_device_lib):
+    """A model written in HIP against the batched DEVICE callback of the C-ABI (tests/fixtures/radon_device.hip: the
+    radon density of config 3 as one kernel per evaluation): agrees with the torch density, and samples the same
+    posterior — with no Python and no launch-bound torch graph on the per-leapfrog path."""
+    import ctypes
+
+    import torch
+
+    from nutpie_amd import _lib
+    from nutpie_amd.radon import radon_model, synthetic_radon_data
+
+    data = synthetic_radon_data()
+    n = int(data["county_idx"].max()) + 1
+    cty = np.ascontiguousarray(data["county_idx"], dtype=np.int32)
+    fl, y = np.ascontiguousarray(data["floor"]), np.ascontiguousarray(data["log_radon"])
+    h = radon_device_lib.radon_device_create(n, len(y), cty.ctypes.data, fl.ctypes.data, y.ctypes.data)
+    assert h
+    try:
+        D = 2 * n + 3
+        fn = ctypes.cast(radon_device_lib.radon_device_logp, ctypes.c_void_p).value
+        # 1. the kernel against the torch density (hand-derived gradient) on random points
+        f = radon_model(data)._make_logp_func()
+        x = torch.randn(37, D, dtype=torch.float64, device="cuda") * 0.4
+        g = torch.empty_like(x)
+        lp = torch.empty(37, dtype=torch.float64, device="cuda")
+        call = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                ctypes.c_void_p, ctypes.c_void_p)(fn)
+        assert call(37, D, x.data_ptr(), g.data_ptr(), lp.data_ptr(), 0, h) == 0
+        torch.cuda.synchronize()
+        lp_ref, g_ref = f(x)
+        assert torch.allclose(lp, lp_ref, rtol=1e-12, atol=1e-9) and torch.allclose(g, g_ref, rtol=1e-10, atol=1e-9)
+        # 2. sampling through the engine: deterministic, and the posterior of the synthetic data
+        def run():
+            s = _lib.PyNutsSettings.Diag(7)
+            s.update(num_tune=300, num_draws=200, num_chains=256)
+            smp = _lib.PySampler(s, _lib.NativeDeviceCallbackModel(D, fn, h, keep_alive=radon_device_lib))
+            smp.wait()
+            return smp.take_results()
+        a, b = run(), run()
+        assert np.array_equal(a.draws, b.draws)
+        post = a.draws[:, 300:]
+        assert abs(post[..., 0].mean() - 1.3) < 0.15 and abs(post[..., n + 1].mean() + 0.6) < 0.2
+        assert abs(np.exp(post[..., 2 * n + 2]).mean() - 0.75) < 0.08
+        assert a.stats["diverging"][:, 300:].mean() < 0.02
+    finally:
+        radon_device_lib.radon_device_free(h)
+
+
 def test_sharded_sampling_and_rccl_gather_single_rank(tmp_path):
     """The multi-GPU path (chain shard + RCCL gather of device-resident trace arrays) with a one-rank NCCL group:
     the same code the 8-GPU job runs, on the one GPU a test box has."""
