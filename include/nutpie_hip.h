@@ -136,6 +136,9 @@ typedef struct {
     int32_t no_register_kernel; /* 1: force the memory-resident kernel even where the register-resident
                                  * specialisation applies (A/B measurements, tests) */
     int32_t no_stream_cache;    /* 1: memory-resident fused kernels reload the cursor state every leapfrog (A/B, tests) */
+    int32_t graph_steps;        /* device-callback models: >0 = capture this many (engine kernel + callback) steps in a HIP
+                                 * graph and replay it; the callback must then only enqueue work on the given stream */
+    int32_t reserved;
 } nphip_launch_t;
 
 void nphip_launch_defaults(nphip_launch_t*);

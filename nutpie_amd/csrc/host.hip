@@ -458,6 +458,11 @@ struct nphip_sampler {
     double* kernel_ms_acc = nullptr;  // when set, iterations time their kernel with HIP events
     bool launch_kernel(bool fused_, int have);
     bool iteration_fused(bool& all_done);
+    bool iteration_graph(bool& all_done);
+    hipGraphExec_t cb_graph = nullptr;
+    hipEvent_t cb_ev[2] = {nullptr, nullptr};
+    int cb_graph_steps = 0;
+    uint64_t cb_replays = 0;
     bool iteration_callback(bool& all_done, int& have);
     void fail(const std::string& msg) {
         std::lock_guard<std::mutex> lk(mu);
@@ -471,6 +476,8 @@ struct nphip_sampler {
         for (void* h : pinned) (void)hipHostFree(h);
         pinned.clear();
         if (ev0) { (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1); ev0 = ev1 = nullptr; }
+        if (cb_graph) { (void)hipGraphExecDestroy(cb_graph); cb_graph = nullptr; }
+        for (auto& e : cb_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
         if (own_stream && stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
     }
 };
@@ -673,6 +680,7 @@ bool nphip_sampler::iteration_fused(bool& all_done) {
 }
 
 bool nphip_sampler::iteration_callback(bool& all_done, int& have) {
+    if (model.kind == 2 && cb_graph_steps > 0 && have == 1 && !kernel_ms_acc) return iteration_graph(all_done);
     if (!launch_kernel(false, have)) return false;
     if (model.kind == 1) {
         // host callback: D2H positions, evaluate rows on the host pool, H2D gradients
@@ -712,6 +720,50 @@ bool nphip_sampler::iteration_callback(bool& all_done, int& have) {
         }
     }
     have = 1;
+    return true;
+}
+
+// Device-callback models, steady state: `cb_graph_steps` x (engine kernel, model callback) captured once in a HIP graph
+// and replayed — one host call per run of leapfrogs instead of two launches per leapfrog.  At most two replays are in
+// flight (the host must not run ahead of the done / error counters by more than that).
+bool nphip_sampler::iteration_graph(bool& all_done) {
+    if (!cb_graph) {
+        hipGraph_t g = nullptr;
+        bool ok = hipStreamBeginCapture(stream, hipStreamCaptureModeRelaxed) == hipSuccess;
+        if (ok) {
+            args.max_evals = 0;
+            args.have_result = 1;
+            for (int i = 0; ok && i < cb_graph_steps; ++i) {
+                ok = launch_advance(args, d_args, false, W, stream) == hipSuccess &&
+                     model.dev_fn(n, dim, args.qeval, args.geval, args.ueval, (void*)stream, model.user) >= 0;
+            }
+            ok = (hipStreamEndCapture(stream, &g) == hipSuccess) && ok && g != nullptr;
+        }
+        if (ok) ok = hipGraphInstantiate(&cb_graph, g, nullptr, nullptr, 0) == hipSuccess;
+        if (g) (void)hipGraphDestroy(g);
+        if (!ok) {  // not capturable (e.g. a callback that allocates): keep stepping the plain way
+            (void)hipGetLastError();
+            cb_graph = nullptr;
+            cb_graph_steps = 0;
+            int have = 1;
+            return iteration_callback(all_done, have);
+        }
+        if (!hip_ok(hipEventCreate(&cb_ev[0]), "hipEventCreate") || !hip_ok(hipEventCreate(&cb_ev[1]), "hipEventCreate")) return false;
+    }
+    const int slot = (int)(cb_replays & 1);
+    if (cb_replays >= 2 && !hip_ok(hipEventSynchronize(cb_ev[slot]), "hipEventSynchronize")) return false;
+    if (!hip_ok(hipGraphLaunch(cb_graph, stream), "hipGraphLaunch")) return false;
+    if (!hip_ok(hipMemcpyAsync(h_counters, args.counters, 16, hipMemcpyDeviceToHost, stream), "copy counters")) return false;
+    if (!hip_ok(hipEventRecord(cb_ev[slot], stream), "hipEventRecord")) return false;
+    cb_replays += 1;
+    launches.fetch_add((uint64_t)cb_graph_steps);
+    volatile unsigned long long* hc = h_counters;
+    if (hc[1] > 0) {
+        (void)hipStreamSynchronize(stream);
+        set_error(chain_error_message());
+        return false;
+    }
+    if (hc[0] >= n) { all_done = true; return hip_ok(hipStreamSynchronize(stream), "hipStreamSynchronize"); }
     return true;
 }
 
@@ -760,6 +812,7 @@ nphip_sampler_t* nphip_sampler_create(const nphip_settings_t* set, const nphip_m
         return nullptr;
     }
     if (!s->setup()) { s->release(); delete s; return nullptr; }
+    s->cb_graph_steps = (s->model.kind == 2 && s->launch.graph_steps > 0) ? s->launch.graph_steps : 0;
     s->want_pause = s->launch.start_paused != 0;
     s->manual = s->launch.manual != 0;
     if (!s->manual) s->th = std::thread([s] { s->run(); });

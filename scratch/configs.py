@@ -29,7 +29,11 @@ data = synthetic_radon_data(); n = int(data["county_idx"].max()) + 1
 cty = np.ascontiguousarray(data["county_idx"], dtype=np.int32); fl = np.ascontiguousarray(data["floor"]); yy = np.ascontiguousarray(data["log_radon"])
 h = rl.radon_device_create(n, len(yy), cty.ctypes.data, fl.ctypes.data, yy.ctypes.data)
 fn = C.cast(rl.radon_device_logp, C.c_void_p).value
-for chains in (512, 4096):
-    s = _lib.PyNutsSettings.Diag(1); s.update(num_tune=400, num_draws=1000, num_chains=chains)
-    t = time.time(); smp = _lib.PySampler(s, _lib.NativeDeviceCallbackModel(2 * n + 3, fn, h, keep_alive=rl)); smp.wait(); el = time.time() - t
-    tr = smp.take_results(); report(f"config3 radon {chains} chains, native HIP density (device callback)", tr, el)
+ref = None
+for chains, gs in ((512, 0), (512, 16), (512, 64)):
+    s = _lib.PyNutsSettings.Diag(1); s.update(num_tune=400, num_draws=1000, num_chains=chains, maxdepth=8)
+    t = time.time(); smp = _lib.PySampler(s, _lib.NativeDeviceCallbackModel(2 * n + 3, fn, h, keep_alive=rl), graph_steps=gs); smp.wait(); el = time.time() - t
+    tr = smp.take_results(); report(f"config3 radon {chains} chains, native HIP density (device callback, graph_steps={gs})", tr, el)
+    if chains == 512:
+        if ref is None: ref = tr.draws
+        else: print("   identical to the ungraphed run:", np.array_equal(ref, tr.draws))

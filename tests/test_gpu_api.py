@@ -225,14 +225,17 @@ def test_native_device_callback_radon_kernel(radon_device_lib):
         lp_ref, g_ref = f(x)
         assert torch.allclose(lp, lp_ref, rtol=1e-12, atol=1e-9) and torch.allclose(g, g_ref, rtol=1e-10, atol=1e-9)
         # 2. sampling through the engine: deterministic, and the posterior of the synthetic data
-        def run():
+        def run(graph_steps=0):
             s = _lib.PyNutsSettings.Diag(7)
             s.update(num_tune=300, num_draws=200, num_chains=256)
-            smp = _lib.PySampler(s, _lib.NativeDeviceCallbackModel(D, fn, h, keep_alive=radon_device_lib))
+            smp = _lib.PySampler(s, _lib.NativeDeviceCallbackModel(D, fn, h, keep_alive=radon_device_lib), graph_steps=graph_steps)
             smp.wait()
             return smp.take_results()
         a, b = run(), run()
         assert np.array_equal(a.draws, b.draws)
+        # (engine kernel + callback) x 16 captured in a HIP graph and replayed: same chains
+        c = run(graph_steps=16)
+        assert np.array_equal(a.draws, c.draws) and np.array_equal(a.stats["n_steps"], c.stats["n_steps"])
         post = a.draws[:, 300:]
         assert abs(post[..., 0].mean() - 1.3) < 0.15 and abs(post[..., n + 1].mean() + 0.6) < 0.2
         assert abs(np.exp(post[..., 2 * n + 2]).mean() - 0.75) < 0.08
