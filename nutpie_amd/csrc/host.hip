@@ -538,7 +538,7 @@ bool nphip_sampler::setup() {
     // chunks, so the leading dimension is padded to a multiple of 128 * W (pads are exact zeros in every reduction)
     const bool fused_model = (model.kind == 0);
     int reg_multi = 0;
-    if (fused_model && (W == 2 || W == 4) && !launch.no_register_kernel) {
+    if (fused_model && (W == 2 || W == 4) && !launch.no_register_kernel && !set.store_divergences) {
         const int64_t per_wave = ((int64_t)((dim + 127) / 128) + W - 1) / W;
         if (per_wave >= 1 && per_wave <= 8) { reg_multi = (int)per_wave; args.ld = per_wave * W * 128; }
     }
@@ -548,8 +548,9 @@ bool nphip_sampler::setup() {
     const size_t ld = (size_t)args.ld;
     // register-resident specialisation, one wave per chain: state in VGPRs (dim <= 1024, one instantiation per chunk count)
     args.reg_nv = reg_multi;
-    // (store_divergences: every leaf then also writes q, so that the start of a failed step can be recorded)
-    if (fused && W == 1 && !launch.no_register_kernel) {
+    // (not with store_divergences: the divergence record needs the pre-step state, which only the
+    //  memory-resident kernel keeps)
+    if (fused && W == 1 && !launch.no_register_kernel && !set.store_divergences) {
         const int nchunks = (int)(args.ld / 128);  // one kernel instantiation per exact chunk count (straight-line code)
         if (nchunks <= 8) args.reg_nv = nchunks;
     }

@@ -891,7 +891,6 @@ struct Machine {
         const int64_t idx_new = c->idx_cur + dir;
         const int64_t srcq = c->lf_srcq, srcp = c->lf_srcp, newq = c->lf_newq, newp = c->lf_newp;
         const bool check = A.s.check_turning && (d + 1 > A.s.mindepth);
-        const bool sdiv = A.tr_div[0] != nullptr;   // store_divergences: every leaf keeps q in HBM (the next leaf may diverge)
 #ifdef NPHIP_PROFILE
         const int64_t tp0 = (int64_t)__builtin_readcyclecounter();
 #endif
@@ -1009,23 +1008,7 @@ struct Machine {
                 c->acc_sym_sum += 2.0 * a / (1.0 + e);
             }
         }
-        if (diverged) {
-            if (sdiv) {
-                // divergence record (store_divergences): the start of the failed step is the source leaf — its q is in HBM
-                // (in this mode every leaf writes q), its momentum is still in registers; the end is the new point
-                double* ps = P(srcp);
-#pragma unroll
-                for (int k = 0; k < NVX; ++k) st2(ps, ridx(k), pold[k]);
-                if (ok) {
-                    double* qe = Q(newq);
-#pragma unroll
-                    for (int k = 0; k < NVX; ++k) st2(qe, ridx(k), X.q[k]);
-                }
-            }
-            X.dirty_qg = X.dirty_pr = false;
-            rare_end_draw(A, c, red, chain, true, false, sdiv, ok, true);
-            return true;
-        }
+        if (diverged) { X.dirty_qg = X.dirty_pr = false; rare_end_draw(A, c, red, chain, true, false, false, false, true); return true; }
 #ifdef NPHIP_PROFILE
         int64_t tq = (int64_t)__builtin_readcyclecounter();
         c->prof[8] += tq - tp2;
@@ -1092,7 +1075,7 @@ struct Machine {
 #ifdef NPHIP_PROFILE
             const int64_t tp3 = (int64_t)__builtin_readcyclecounter();
 #endif
-            store_state(X, (T_q == newq) || sdiv, ((j & 3) == 0) || ((j & 7) == 1));
+            store_state(X, T_q == newq, ((j & 3) == 0) || ((j & 7) == 1));
             issue_leaf();
 #ifdef NPHIP_PROFILE
             c->prof[7] += (int64_t)__builtin_readcyclecounter() - tp3;

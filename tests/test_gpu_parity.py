@@ -232,27 +232,6 @@ def test_four_waves_per_chain_for_small_batches(hip, oracle):
     assert Wd == 1
 
 
-@pytest.mark.parametrize("dim,waves", [(24, 1), (700, 1), (1300, 2)])
-def test_divergence_records_register_vs_memory_kernel(hip, oracle, dim, waves):
-    # store_divergences: the register kernels (every leaf then writes q; the failed step's momentum comes from the
-    # registers) record exactly what the memory-resident kernel records, and the trace still equals the oracle's
-    rng = np.random.default_rng(dim)
-    diag = np.exp(rng.normal(size=dim) * 1.2)
-    kw = dict(chains=4, tune=80, draws=30, seed=5, max_energy_error=0.4, store_divergences=True)
-    reg, W = run_engine(hip, hip.TridiagGaussianModel(diag), waves=waves, **kw)
-    mem, _ = run_engine(hip, hip.TridiagGaussianModel(diag), waves=waves, launch=dict(no_register_kernel=True), **kw)
-    assert W == waves and reg.stats["diverging"].sum() > 10
-    assert_trace_equal(reg, mem)
-    for k in ("divergence_start", "divergence_end", "divergence_momentum", "divergence_start_gradient"):
-        assert np.array_equal(reg.stats[k], mem.stats[k], equal_nan=True), k
-    div = reg.stats["diverging"].astype(bool)
-    assert np.all(np.isfinite(reg.stats["divergence_start"][div])) and np.all(np.isnan(reg.stats["divergence_start"][~div]))
-    # start gradient really is the gradient at the start: g = -diag * q for this model
-    np.testing.assert_allclose(reg.stats["divergence_start_gradient"][div], -diag * reg.stats["divergence_start"][div], rtol=1e-13)
-    want = oracle.sample_tridiag(oracle_settings(oracle, W=W, chains=4, tune=80, draws=30, seed=5, max_energy_error=0.4), diag)
-    assert_trace_equal(reg, want)
-
-
 def test_init_strategies(hip, oracle):
     diag = np.array([1.0, 4.0, 0.25])
     # N(0,1) initial points: src/stan.rs:798-808
