@@ -142,6 +142,8 @@ typedef struct {
 } nphip_launch_t;
 
 void nphip_launch_defaults(nphip_launch_t*);
+/* sizeof(nphip_launch_t) / sizeof(nphip_chain_progress_t) as the library was built: lets a binding check its struct layouts */
+uint64_t nphip_abi_struct_size(int which /* 0: nphip_launch_t, 1: nphip_chain_progress_t */);
 
 /* nuts_rs::Sampler::new — starts the driver thread; sampling begins immediately. */
 nphip_sampler_t* nphip_sampler_create(const nphip_settings_t*, const nphip_model_t*, const nphip_launch_t*);

@@ -144,6 +144,10 @@ def lib():
             L.nphip_model_set_init.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64]
             L.nphip_model_free.argtypes = [C.c_void_p]
             L.nphip_launch_defaults.argtypes = [C.POINTER(_Launch)]
+            L.nphip_abi_struct_size.restype = C.c_uint64
+            L.nphip_abi_struct_size.argtypes = [C.c_int]
+            if L.nphip_abi_struct_size(0) != C.sizeof(_Launch) or L.nphip_abi_struct_size(1) != C.sizeof(_Progress):
+                raise RuntimeError("libnutpie_hip.so and nutpie_amd/_lib.py disagree on the C-ABI struct layouts (stale build?)")
             L.nphip_sampler_create.restype = C.c_void_p
             L.nphip_sampler_create.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(_Launch)]
             L.nphip_sampler_free.argtypes = [C.c_void_p]

@@ -332,6 +332,10 @@ int nphip_model_set_init(nphip_model_t* m, int kind, const double* points, uint6
 uint64_t nphip_model_dim(const nphip_model_t* m) { return m->dim; }
 void nphip_model_free(nphip_model_t* m) { delete m; }
 
+uint64_t nphip_abi_struct_size(int which) {
+    return which == 0 ? sizeof(nphip_launch_t) : (which == 1 ? sizeof(nphip_chain_progress_t) : 0);
+}
+
 void nphip_launch_defaults(nphip_launch_t* l) {
     memset(l, 0, sizeof(*l));
     l->store_draws = 1;
