@@ -101,16 +101,17 @@ def sample_sharded(make_sampler, num_chains: int, *, group=None, thin: int = 1, 
             local[name] = device_tensor(ptr, (n_local, T), dtypes.get(name, "float64"), dev)
         else:
             local[name] = sampler._copy(name, np.dtype(dtypes.get(name, "float64")))
-    if gather_draws and sampler.device_ptr("draws"):
+    if (gather_draws or moments_after is not None) and sampler.device_ptr("draws"):
         if on_gpu:
             d = device_tensor(sampler.device_ptr("draws"), (n_local, T, D), "float64", dev)
         else:
             d = torch.from_numpy(sampler._copy("draws", np.float64, vec=True))
         if moments_after is not None:
             local["draw_mean"], local["draw_var"] = chain_moments(d, int(moments_after))
-        d = d[:, ::thin]
-        if dims is not None:
-            d = d[:, :, torch.as_tensor(list(dims), device=d.device)]
-        local["draws"] = d.contiguous()
+        if gather_draws:
+            d = d[:, ::thin]
+            if dims is not None:
+                d = d[:, :, torch.as_tensor(list(dims), device=d.device)]
+            local["draws"] = d.contiguous()
     gathered = gather_arrays(local, n_local, group=group)
     return sampler, gathered

@@ -272,6 +272,10 @@ def test_sharded_sampling_and_rccl_gather_single_rank(tmp_path):
         # per-chain moments of the post-warm-up draws, reduced on the device
         np.testing.assert_allclose(got["draw_mean"].cpu().numpy(), ref.draws[:, 40:].mean(1), rtol=1e-12, atol=1e-14)
         np.testing.assert_allclose(got["draw_var"].cpu().numpy(), ref.draws[:, 40:].var(1, ddof=1), rtol=1e-10)
+        # summary only: no draws cross the wire
+        smp2, got2 = sample_sharded(make, 6, gather_draws=False, moments_after=40)
+        assert "draws" not in got2 and np.array_equal(got2["draw_mean"].cpu().numpy(), got["draw_mean"].cpu().numpy())
+        smp2.close()
         assert np.array_equal(got["draws"].cpu().numpy(), ref.draws[:, ::2][:, :, [0, 3, 39]])
         assert np.array_equal(got["n_steps"].cpu().numpy(), ref.stats["n_steps"])
         assert np.array_equal(got["diverging"].cpu().numpy().astype(bool), ref.stats["diverging"])
