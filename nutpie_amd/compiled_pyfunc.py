@@ -321,3 +321,33 @@ def from_torchfunc(
         _expand_device_func=expand_device_fn,
         reparameterized_names=reparameterized_names,
     )
+
+
+def autograd_logp(density_fn: Callable) -> Callable:
+    """``density_fn(x: Tensor[chains, ndim]) -> Tensor[chains]``  ->  ``f(x) -> (logp, grad)`` through ``torch.autograd``
+    (rows are independent, so the gradient of ``logp.sum()`` is the batch of per-chain gradients)."""
+
+    def logp(x):
+        import torch
+
+        xg = x.detach().requires_grad_(True)
+        with torch.enable_grad():
+            lp = density_fn(xg)
+            (g,) = torch.autograd.grad(lp.sum(), xg)
+        return lp.detach(), g
+
+    return logp
+
+
+def from_torch_density(ndim: int, density_fn: Callable, **kwargs):
+    """Batched device model from a log-density alone: the gradient comes from ``torch.autograd``.  Keyword arguments as
+    :func:`from_torchfunc` (``use_graph=True`` replays the whole evaluation from a HIP graph); ``shared_data`` entries
+    are passed to ``density_fn`` as keyword arguments."""
+
+    def make_logp():
+        def logp(x, **shared):
+            return autograd_logp(lambda t: density_fn(t, **shared))(x)
+
+        return logp
+
+    return from_torchfunc(ndim, make_logp, **kwargs)

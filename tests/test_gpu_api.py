@@ -193,6 +193,18 @@ def test_radon_torch_model_config3():
     assert raw.draws is not None and raw.expanded["sigma"].shape == (8, 25)
 
 
+def test_from_torch_density_autograd_model():
+    import torch
+
+    sd = torch.tensor([0.5, 1.0, 3.0], dtype=torch.float64, device="cuda")
+    m = nutpie_amd.from_torch_density(3, lambda x: -0.5 * ((x / sd) ** 2).sum(-1))
+    tr = nutpie_amd.sample(m, chains=64, tune=300, draws=300, seed=2, progress_bar=False)
+    x = tr.posterior.x.values
+    assert x.shape == (64, 300, 3)
+    np.testing.assert_allclose(x.std((0, 1)), [0.5, 1.0, 3.0], rtol=0.08)
+    assert np.abs(x.mean((0, 1)) / np.array([0.5, 1.0, 3.0])).max() < 0.1
+
+
 def test_native_device_callback_radon_kernel(radon_device_lib):
     """A model written in HIP against the batched DEVICE callback of the C-ABI (tests/fixtures/radon_device.hip: the
     radon density of config 3 as one kernel per evaluation): agrees with the torch density, and samples the same

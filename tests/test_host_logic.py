@@ -161,3 +161,20 @@ def test_radon_hand_derived_gradient_matches_autograd():
     lp_ref, g_ref = f.autograd_reference(x)
     assert torch.allclose(lp, lp_ref, rtol=1e-12, atol=1e-10)
     assert torch.allclose(g, g_ref, rtol=1e-10, atol=1e-9)
+
+
+def test_autograd_logp_wrapper():
+    # from_torch_density: gradient of a batched log-density through torch.autograd, one row per chain
+    import torch
+
+    from nutpie_amd.compiled_pyfunc import autograd_logp, from_torch_density
+
+    scale = torch.tensor([1.0, 2.0, 0.5], dtype=torch.float64)
+    f = autograd_logp(lambda x: -0.5 * ((x / scale) ** 2).sum(-1))
+    x = torch.randn(7, 3, dtype=torch.float64)
+    lp, g = f(x)
+    assert torch.allclose(lp, -0.5 * ((x / scale) ** 2).sum(-1)) and torch.allclose(g, -x / scale**2)
+    assert not lp.requires_grad and not g.requires_grad
+    m = from_torch_density(3, lambda x, s: -0.5 * ((x / s) ** 2).sum(-1), shared_data={"s": scale})
+    lp2, g2 = m._make_logp_func()(x, **m._shared_data)
+    assert torch.equal(lp2, lp) and torch.equal(g2, g) and m.n_dim == 3
