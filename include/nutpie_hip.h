@@ -11,6 +11,8 @@
  *   PyNutsSettings::Diag / apply_update / as_dict       nphip_settings_*
  *     (src/wrapper.rs:525-533, 563-620, 210-451, 751-769)
  *   LogpFunc / RawLogpFunc  (src/pymc.rs:21-62)         nphip_model_host_callback
+ *   ExpandFunc / RawExpandFunc (src/pymc.rs:31-37, 64-95, nphip_model_set_expand, nphip_sampler_copy_expanded
+ *     217-286)
  *   PyModel  (src/pyfunc.rs:206-230, 517-570)           nphip_model_device_callback
  *   StanModel::logp (src/stan.rs:454-463)               nphip_model_host_callback (adapter)
  *   nuts_rs::Sampler::new (src/wrapper.rs:977-1085)     nphip_sampler_create
@@ -73,7 +75,19 @@ typedef struct nphip_model nphip_model_t;
 /* The reference's raw C logp callback, verbatim: src/pymc.rs:23-29 /
  * python/nutpie/compile_pymc.py:975-981.  0 ok, >0 recoverable (=> divergence), <0 fatal
  * (src/pymc.rs:166-180).  Must be re-entrant: called concurrently from n_threads host threads. */
-typedef int64_t (*nphip_raw_logp_fn)(uint64_t dim, const double* x, double* grad_out, double* logp_out, void* user_data);
+typedef int (*nphip_raw_logp_fn)(uint64_t dim, const double* x, double* grad_out, double* logp_out, void* user_data);
+/* (The return type is the reference's `std::os::raw::c_int`.  A numba cfunc declared `int64(...)`, compile_pymc.py:975-981,
+ * leaves its code in the full return register; like the reference, the engine reads the low 32 bits.) */
+
+/* The reference's raw expand callback, verbatim: src/pymc.rs:31-37 (`RawExpandFunc`), numba side
+ * python/nutpie/compile_pymc.py:1018-1041.  Maps ONE unconstrained draw x[dim] to the flat vector of all expanded
+ * (constrained / deterministic) variables out[expanded_dim]; 0 = ok, anything else is an error
+ * ("Expand function returned error code N", src/pymc.rs:276-283).  Re-entrant: rows are expanded concurrently. */
+typedef int (*nphip_raw_expand_fn)(uint64_t dim, uint64_t expanded_dim, const double* x, double* out, void* user_data);
+/* Batched device form of the expand step: x[n_rows][dim] -> out[n_rows][expanded_dim], both device,
+ * fp64, row-major; work enqueued on `stream`.  Return 0, or nonzero for an error. */
+typedef int (*nphip_device_expand_fn)(uint64_t n_rows, uint64_t dim, uint64_t expanded_dim, const double* x, double* out,
+                                      void* stream, void* user_data);
 
 /* Batched device callback (the GPU form of src/pyfunc.rs:206-230): when called, the engine's
  * staging buffer q[n_chains][dim] (device, fp64, row-major) holds the positions; the callee must
@@ -98,6 +112,11 @@ nphip_model_t* nphip_model_bridgestan(uint64_t dim, void* bs_model, void* log_de
  * 2 = explicit host array points[n_chains_total][dim] indexed by GLOBAL chain id
  * (src/pymc.rs:505-534 evaluates the user's init function per chain on the host). */
 int nphip_model_set_init(nphip_model_t*, int kind, const double* points, uint64_t n_points);
+/* ExpandFunc::new(dim, expanded_dim, ptr, user_data_ptr, keep_alive) — src/pymc.rs:74-95.  Any model flavour may carry
+ * an expand function; the host form is evaluated on the model's host thread pool, the device form on the engine's stream. */
+int nphip_model_set_expand(nphip_model_t*, uint64_t expanded_dim, nphip_raw_expand_fn fn, void* user_data);
+int nphip_model_set_device_expand(nphip_model_t*, uint64_t expanded_dim, nphip_device_expand_fn fn, void* user_data);
+uint64_t nphip_model_expanded_dim(const nphip_model_t*);  /* 0 = no expand function */
 uint64_t nphip_model_dim(const nphip_model_t*);
 void nphip_model_free(nphip_model_t*);
 
@@ -177,6 +196,10 @@ uint64_t nphip_sampler_launches(const nphip_sampler_t*);
  * "divergence_end" "divergence_momentum" "divergence_start_gradient"(f64[dim]). */
 int nphip_sampler_finished_draws(nphip_sampler_t*, uint64_t* finished);
 int nphip_sampler_copy_stat(nphip_sampler_t*, const char* name, void* host_out, uint64_t nbytes);
+/* The expand step over the whole stored trace (PyMcModelRef::expand_vector per draw, src/pymc.rs:217-286):
+ * host_out[local_chain][draw][expanded_dim], fp64; rows of draws a chain has not finished are NaN.  Needs store_draws.
+ * Also reachable as nphip_sampler_copy_stat(s, "expanded", ...). */
+int nphip_sampler_copy_expanded(nphip_sampler_t*, void* host_out, uint64_t nbytes);
 /* Developer aid: per-section cycle counters summed over chains; all zero unless the library was built
  * with -DNPHIP_PROFILE.  [0] leapfrog cycles [1] tree cycles (hot) [2] draw-end cycles [3..5] their counts. */
 int nphip_sampler_profile(nphip_sampler_t*, int64_t out[16]);

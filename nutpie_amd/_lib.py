@@ -41,7 +41,10 @@ NPHIP_ERR_NOT_AVAILABLE = -3
 NPHIP_ERR_BAD_VALUE = -4
 WAIT_DONE, WAIT_TIMEOUT, WAIT_ERROR = 0, 1, 2
 
-RAW_LOGP_FN = C.CFUNCTYPE(C.c_int64, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p)
+# src/pymc.rs:23-29 / 31-37: both raw callbacks return `std::os::raw::c_int`
+RAW_LOGP_FN = C.CFUNCTYPE(C.c_int, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p)
+RAW_EXPAND_FN = C.CFUNCTYPE(C.c_int, C.c_uint64, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p)
+DEVICE_EXPAND_FN = C.CFUNCTYPE(C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
 DEVICE_LOGP_FN = C.CFUNCTYPE(C.c_int, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
 
 
@@ -143,6 +146,11 @@ def lib():
             L.nphip_model_bridgestan.argtypes = [C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
             L.nphip_model_set_init.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64]
             L.nphip_model_free.argtypes = [C.c_void_p]
+            L.nphip_model_set_expand.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+            L.nphip_model_set_device_expand.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+            L.nphip_model_expanded_dim.argtypes = [C.c_void_p]
+            L.nphip_model_expanded_dim.restype = C.c_uint64
+            L.nphip_sampler_copy_expanded.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
             L.nphip_launch_defaults.argtypes = [C.POINTER(_Launch)]
             L.nphip_abi_struct_size.restype = C.c_uint64
             L.nphip_abi_struct_size.argtypes = [C.c_int]
@@ -313,6 +321,49 @@ class _Model:
         if rc != NPHIP_OK:
             raise ValueError(_err())
 
+    def set_expand(self, expanded_dim: int, fn, user_data=0, keep_alive=None):
+        """``ExpandFunc(dim, expanded_dim, ptr, user_data_ptr, keep_alive)`` of the reference (src/pymc.rs:74-95).
+
+        ``fn``: address of a raw C expand callback ``int f(dim, expanded_dim, x, out, user_data)`` (src/pymc.rs:31-37, e.g. a
+        numba cfunc address), a ctypes function pointer, or a Python callable ``x[dim] -> flat[expanded_dim]`` (wrapped)."""
+        self._keep = list(self._keep or []) if isinstance(self._keep, (list, tuple)) else [self._keep]
+        self._keep.append(keep_alive)
+        if isinstance(fn, int):
+            addr = C.c_void_p(fn)
+        elif isinstance(fn, C._CFuncPtr):
+            self._keep.append(fn)
+            addr = C.cast(fn, C.c_void_p)
+        else:
+            pyfn, E, model = fn, int(expanded_dim), self
+
+            def _cb(d, e, x, out, _u):
+                if e != E:
+                    return -1
+                try:
+                    np.ctypeslib.as_array(out, shape=(E,))[:] = np.asarray(pyfn(np.ctypeslib.as_array(x, shape=(d,)).copy()), dtype=np.float64).reshape(E)
+                except Exception as exc:  # noqa: BLE001 - must not unwind through C (numba side: compile_pymc.py:1037-1039)
+                    model.expand_exception = exc
+                    return -2
+                return 0
+
+            cb = RAW_EXPAND_FN(_cb)
+            self._keep.append(cb)
+            addr = C.cast(cb, C.c_void_p)
+        self.expand_exception = None
+        if lib().nphip_model_set_expand(self._h, C.c_uint64(int(expanded_dim)), addr, C.c_void_p(user_data)) != NPHIP_OK:
+            raise ValueError(_err())
+
+    def set_device_expand(self, expanded_dim: int, fn_addr: int, user_data: int = 0, keep_alive=None):
+        """Batched device expand (``nphip_device_expand_fn``): ``x[n][dim] -> out[n][expanded_dim]`` on the engine's stream."""
+        self._keep = list(self._keep or []) if isinstance(self._keep, (list, tuple)) else [self._keep]
+        self._keep.append(keep_alive)
+        if lib().nphip_model_set_device_expand(self._h, C.c_uint64(int(expanded_dim)), C.c_void_p(fn_addr), C.c_void_p(user_data)) != NPHIP_OK:
+            raise ValueError(_err())
+
+    @property
+    def expanded_dim(self):
+        return int(lib().nphip_model_expanded_dim(self._h))
+
     def __del__(self):
         try:
             if self._h:
@@ -352,13 +403,17 @@ class HostCallbackModel(_Model):
             addr = C.cast(fn, C.c_void_p)
         else:
             pyfn = fn
+            self.exception = None
 
             def _cb(d, x, g, lp, _u):
                 xs = np.ctypeslib.as_array(x, shape=(d,))
                 try:
                     val, grad = pyfn(xs.copy())
                 except Exception as e:  # recoverable iff flagged, as src/pyfunc.rs:100-116
-                    return 1 if getattr(e, "is_recoverable", False) else -1
+                    if getattr(e, "is_recoverable", False):
+                        return 1
+                    self.exception = e  # re-raised (chained) by PySampler.wait, like DeviceCallbackModel
+                    return -1
                 np.ctypeslib.as_array(g, shape=(d,))[:] = grad
                 lp[0] = val
                 return 0
@@ -501,6 +556,8 @@ class PySampler:
 
     from_pymc = from_pyfunc
     from_stan = from_pyfunc
+    # (progress_type / extra_callback / store of the reference's constructors, wrapper.rs:1189-1250, are handled one layer up:
+    #  nutpie_amd.sample._BackgroundSampler polls progress() and calls the callback; the engine has no storage back-ends)
 
     def _require(self):
         if self._h is None:
@@ -608,6 +665,21 @@ class PySampler:
     def device_ptr(self, name):
         return lib().nphip_sampler_device_ptr(self._h, name.encode())
 
+    def expanded(self):
+        """The model's expand function over the stored trace: ``[chain, draw, expanded_dim]`` (NaN rows for unfinished draws);
+        host rows on the thread pool or one batched device call per block (src/pymc.rs:217-286, per draw in the reference)."""
+        self._require()
+        E = self._model.expanded_dim
+        if E == 0:
+            raise RuntimeError("the model has no expand function")
+        out = np.empty((self.num_chains, self.total_draws, E), dtype=np.float64)
+        if lib().nphip_sampler_copy_expanded(self._h, out.ctypes.data_as(C.c_void_p), C.c_uint64(out.nbytes)) != NPHIP_OK:
+            exc = getattr(self._model, "expand_exception", None)
+            if exc is not None:
+                raise RuntimeError(f"expand function raised: {exc!r}") from exc
+            raise RuntimeError(_err())
+        return out
+
     def _snapshot(self):
         n = self.num_chains
         fin = np.zeros(n, dtype=np.uint64)
@@ -622,6 +694,8 @@ class PySampler:
         if expand is not None and self._store_draws:
             # expand step batched on the device, straight from the engine's draws buffer
             expanded = expand(self)
+        elif self._store_draws and self._model.expanded_dim:
+            expanded = {"__flat__": self.expanded()}   # behind the C-ABI; split into variables by the model's _expand_draws
         need_host_draws = self._store_draws and (expanded is None or getattr(self, "_keep_host_draws", True))
         draws = self._copy("draws", np.float64, vec=True) if need_host_draws else None
         return PyTrace(draws, stats, fin.astype(np.int64), self._chain_offset, expanded)

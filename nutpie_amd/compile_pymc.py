@@ -9,9 +9,10 @@ with ``numba.cfunc`` (``_make_c_logp_func``, compile_pymc.py:970-1006; Rust side
 PyMC model compiled by the reference's own machinery can be sampled unchanged.
 
 PyMC / PyTensor / numba are not installable in the build image, so the graph compilation itself
-is OUT OF SCOPE here: this function requires an importable ``pymc`` and raises ``ImportError``
-otherwise.  When PyMC is present it compiles value-and-gradient through PyTensor's default
-backend and evaluates it behind the host-callback path.
+is OUT OF SCOPE here: ``compile_pymc_model`` raises ``ImportError`` without ``pymc`` and
+``NotImplementedError`` with it (no untested guess at PyMC's internals).  What IS supported is the
+boundary below it: ``from_raw_callback`` takes the two raw C callbacks a reference-compiled model
+carries (logp and expand).
 """
 
 from __future__ import annotations
@@ -22,13 +23,19 @@ from typing import Any
 
 import numpy as np
 
-from nutpie_amd.compiled_pyfunc import from_pyfunc
 
 
 def from_raw_callback(n_dim: int, logp_address: int, user_data: int = 0, *, name: str = "x", n_threads: int = 0,
-                      keep_alive: Any = None, init="uniform"):
-    """Sample a model given the address of a reference-style raw C logp callback
-    (e.g. ``numba.cfunc(c_sig)(logp_numba).address``, compile_pymc.py:334, 975-1004)."""
+                      keep_alive: Any = None, init="uniform", expand_address: int | None = None, expand_user_data: int = 0,
+                      expanded_shapes: dict[str, tuple[int, ...]] | None = None, dims=None, coords=None):
+    """Sample a model given the addresses of the reference-style raw C callbacks a compiled PyMC model carries:
+    the logp function (``numba.cfunc(c_sig)(logp_numba).address``, compile_pymc.py:334, 975-1004 — ``LogpFunc`` in
+    src/pymc.rs:38-62) and, optionally, the expand function (compile_pymc.py:1018-1041 — ``ExpandFunc``,
+    src/pymc.rs:64-95) with the shapes of the variables it writes, in order (``expanded_shapes``)."""
+    if (expand_address is None) != (expanded_shapes is None):
+        raise ValueError("expand_address and expanded_shapes go together")
+    out_shapes = {name: (n_dim,)} if expanded_shapes is None else {k: tuple(int(n) for n in v) for k, v in expanded_shapes.items()}
+    n_expanded = int(sum(np.prod(v, dtype=np.int64) for v in out_shapes.values()))
     from nutpie_amd import _lib
     from nutpie_amd.sample import CompiledModel
 
@@ -40,14 +47,16 @@ def from_raw_callback(n_dim: int, logp_address: int, user_data: int = 0, *, name
 
         @property
         def shapes(self):
-            return {name: (n_dim,)}
+            return out_shapes
 
         @property
         def coords(self):
-            return {}
+            return dict(coords or {})
 
         def _make_model(self, init_mean=None, settings=None):
             m = _lib.HostCallbackModel(n_dim, int(logp_address), user_data, n_threads, keep_alive)
+            if expand_address is not None:
+                m.set_expand(n_expanded, int(expand_address), expand_user_data, keep_alive)
             if isinstance(init, str):
                 m.set_init(init)
             else:
@@ -58,9 +67,11 @@ def from_raw_callback(n_dim: int, logp_address: int, user_data: int = 0, *, name
             return _lib.PySampler.from_pymc(settings, cores, self._make_model(), progress_type, extra_callback, extra_callback_rate, store, **engine_kw)
 
         def _expand_draws(self, draws):
+            if expand_address is not None:
+                raise RuntimeError("this model expands behind the C-ABI (nphip_sampler_copy_expanded); it needs the sampler's stored draws")
             return {name: draws}
 
-    return RawCallbackModel(dims={})
+    return RawCallbackModel(dims=dict(dims or {}))
 
 
 def compile_pymc_model(model, *, backend="numba", gradient_backend="pytensor", initial_points=None, jitter_rvs=None,
@@ -72,42 +83,9 @@ def compile_pymc_model(model, *, backend="numba", gradient_backend="pytensor", i
             "engine; use nutpie_amd.from_torchfunc (batched torch logp), nutpie_amd.from_pyfunc, or "
             "nutpie_amd.compile_pymc.from_raw_callback with the numba cfunc address the reference produces."
         )
-    import pymc as pm  # pragma: no cover - not installable in the build image
-    from pymc.initial_point import make_initial_point_fn  # pragma: no cover
-
-    if backend.lower() not in ("numba", "jax"):  # pragma: no cover
-        raise ValueError(f"Backend must be one of numba and jax. Got {backend}")
-    fn = model.logp_dlogp_function(ravel_inputs=True)  # pragma: no cover
-    n_dim = int(fn._extra_vars_shared and fn.size or fn.size)  # pragma: no cover
-    value_vars = list(model.value_vars)  # pragma: no cover
-    names = [v.name for v in value_vars]  # pragma: no cover
-    ip = model.initial_point()  # pragma: no cover
-    shapes = [tuple(np.shape(ip[nm])) for nm in names]  # pragma: no cover
-    sizes = [int(np.prod(s, dtype=np.int64)) for s in shapes]  # pragma: no cover
-
-    def make_logp():  # pragma: no cover
-        def logp(x, **_):
-            val, grad = fn(x)
-            return float(val), np.asarray(grad, dtype=np.float64)
-
-        return logp
-
-    def make_expand(*_):  # pragma: no cover
-        def expand(x, **_):
-            out, o = {}, 0
-            for nm, shp, sz in zip(names, shapes, sizes):
-                out[nm] = np.asarray(x[o:o + sz]).reshape(shp)
-                o += sz
-            return out
-
-        return expand
-
-    init_fn = make_initial_point_fn(model=model, overrides=initial_points, jitter_rvs=set(model.free_RVs) if jitter_rvs is None else jitter_rvs,
-                                    default_strategy=default_initialization_strategy, return_transformed=True)  # pragma: no cover
-
-    def make_initial_point(seed):  # pragma: no cover
-        pt = init_fn(seed)
-        return np.concatenate([np.ravel(pt[nm]) for nm in names]).astype(np.float64)
-
-    return from_pyfunc(n_dim, make_logp, make_expand, [np.float64] * len(names), shapes, names,
-                       make_initial_point_fn=make_initial_point)  # pragma: no cover
+    raise NotImplementedError(
+        "PyMC graph compilation is outside the scope of the HIP engine (no PyTensor backend was built or tested here). "
+        "Compile the model with the reference and pass its numba cfunc addresses to "
+        "nutpie_amd.compile_pymc.from_raw_callback(n_dim, logp_address, expand_address=..., expanded_shapes=...), or "
+        "write the density for nutpie_amd.from_torchfunc."
+    )

@@ -15,6 +15,7 @@ for the eight-schools model (tests/fixtures/eight_schools.c).
 from __future__ import annotations
 
 import dataclasses
+from functools import cached_property
 import json
 from dataclasses import dataclass
 from importlib.util import find_spec
@@ -54,8 +55,13 @@ class CompiledStanModel(CompiledModel):
         d.update(dims)
         return dataclasses.replace(self, dims=d)
 
+    @cached_property
+    def _default_bound(self):
+        return self.with_data().model
+
     def _bound(self):
-        return self.model if self.model is not None else self.with_data().model
+        # (a model compiled without data is bound once, not on every n_dim / shapes access)
+        return self.model if self.model is not None else self._default_bound
 
     @property
     def n_dim(self):
@@ -83,16 +89,23 @@ class CompiledStanModel(CompiledModel):
     def _make_sampler(self, settings, init_mean, cores, progress_type, extra_callback, extra_callback_rate, store, **engine_kw):
         return _lib.PySampler.from_stan(settings, cores, self._make_model(), progress_type, extra_callback, extra_callback_rate, store, **engine_kw)
 
-    def _expand_draws(self, draws):
+    def _expand_draws(self, draws, seed: int = 0):
         # param_constrain per draw; BridgeStan returns column-major blocks which the reference
         # transposes in Rust (src/stan.rs:473-520, 671-711).  The flat vector is returned here.
+        # BridgeStan needs an rng for generated quantities; the reference creates one per chain from the sampling seed
+        # (`model.new_rng(seed)`, src/stan.rs:476-492, 774-788)
         m = self._bound()
         n, T, _ = draws.shape
         k = int(m.param_num(include_tp=True, include_gq=True))
         out = np.empty((n, T, k))
+        row = np.empty(k)
         for c in range(n):
+            rng = m.new_rng(int(seed) + c)
             for t in range(T):
-                out[c, t] = m.param_constrain(draws[c, t], include_tp=True, include_gq=True)
+                if np.isnan(draws[c, t, 0]):
+                    out[c, t] = np.nan
+                    continue
+                out[c, t] = m.param_constrain(draws[c, t], include_tp=True, include_gq=True, out=row, rng=rng)
         from nutpie_amd.stan_names import expand_constrained
 
         return expand_constrained(out, self._variables())  # names parsed + column-major blocks re-ordered (src/stan.rs:93-251, 671-711)

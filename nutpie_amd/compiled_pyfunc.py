@@ -27,60 +27,104 @@ from nutpie_amd.sample import CompiledModel
 SeedType = int
 
 
-def _shapes_dict(names, shapes):
-    return {n: tuple(int(s) for s in shp) for n, shp in zip(names, shapes)}
+@dataclass(frozen=True)
+class ExpandedLayout:
+    """Names, shapes and dtypes of the expanded variables and their place in the flat fp64 vector the C-ABI expand callback
+    fills (``RawExpandFunc``, src/pymc.rs:31-37; the reference keeps the same information in ``PyVariable`` objects)."""
+
+    names: tuple[str, ...]
+    shapes: tuple[tuple[int, ...], ...]
+    dtypes: tuple[np.dtype, ...]
+
+    @property
+    def sizes(self):
+        return tuple(int(np.prod(shape, dtype=np.int64)) for shape in self.shapes)
+
+    @property
+    def total(self) -> int:
+        return int(sum(self.sizes))
+
+    def as_shapes(self) -> dict[str, tuple[int, ...]]:
+        return dict(zip(self.names, self.shapes))
+
+    def flatten_row(self, values: dict) -> np.ndarray:
+        """One draw's dict of variables -> flat fp64 row; dtype and size are checked (src/pyfunc.rs:290-380)."""
+        parts = []
+        for name, size, dtype in zip(self.names, self.sizes, self.dtypes):
+            v = np.asarray(values[name])
+            if v.dtype != dtype:
+                raise TypeError(f"Expanded variable {name} has dtype {v.dtype}, expected {dtype}")
+            if v.size != size:
+                raise ValueError(f"Expanded variable {name} has incorrect shape")
+            parts.append(v.reshape(size).astype(np.float64, copy=False))
+        return np.concatenate(parts) if parts else np.empty(0)
+
+    def split(self, flat: np.ndarray) -> dict[str, np.ndarray]:
+        """[..., total] fp64 -> dict name -> [..., *shape] in the variable's dtype (one slice + cast per variable)."""
+        out, start = {}, 0
+        lead = flat.shape[:-1]
+        for name, shape, size, dtype in zip(self.names, self.shapes, self.sizes, self.dtypes):
+            block = flat[..., start:start + size].reshape(*lead, *shape)
+            out[name] = block if dtype == np.float64 else _cast_block(block, dtype)
+            start += size
+        return out
+
+
+def _cast_block(block: np.ndarray, dtype: np.dtype) -> np.ndarray:
+    # rows of unfinished draws are NaN in the flat transport; integer / bool variables get 0 / False there
+    filled = np.where(np.isnan(block), 0.0, block)
+    return filled.astype(dtype)
 
 
 @dataclass(frozen=True)
 class PyFuncModel(CompiledModel):
-    _make_logp_func: Callable
-    _make_expand_func: Callable
-    _make_initial_points: Callable[[SeedType], np.ndarray] | None
-    _shared_data: dict[str, Any]
-    _n_dim: int
-    _names: list[str]
-    _shapes: list[tuple[int, ...]]
-    _dtypes: list[Any]
-    _coords: dict[str, Any]
-    _raw_logp_fn: Callable | None = None
+    """A model given by Python callables, one position at a time (the reference's ``PyFuncModel``, compiled_pyfunc.py:14-106)."""
+
+    logp_factory: Callable                      # () -> f(x, **data) -> (logp, grad)
+    expand_factory: Callable                    # (seed1, seed2, chain) -> f(x, **data) -> dict
+    initial_point_fn: Callable[[SeedType], np.ndarray] | None
+    layout: ExpandedLayout
+    unconstrained_dim: int
+    data: dict[str, Any]
+    coordinates: dict[str, Any]
+    raw_logp_fn: Callable | None = None
 
     @property
     def shapes(self) -> dict[str, tuple[int, ...]]:
-        return _shapes_dict(self._names, self._shapes)
+        return self.layout.as_shapes()
 
     @property
     def coords(self):
-        return self._coords
+        return self.coordinates
 
     @property
     def n_dim(self):
-        return self._n_dim
+        return self.unconstrained_dim
 
     def with_data(self, **updates):
-        for name in updates:
-            if name not in self._shared_data:
-                raise ValueError(f"Unknown data variable: {name}")
-        updated = self._shared_data.copy()
-        updated.update(**updates)
-        return dataclasses.replace(self, _shared_data=updated)
+        """A copy of the model with some shared data replaced (``PyFuncModel.with_data`` of the reference)."""
+        unknown = next((name for name in updates if name not in self.data), None)
+        if unknown is not None:
+            raise ValueError(f"Unknown data variable: {unknown}")
+        return dataclasses.replace(self, data={**self.data, **updates})
 
     def _init_points(self, settings) -> np.ndarray | None:
         """The reference calls ``init_point_func(seed)`` once per chain with a seed drawn from the
         chain's RNG (src/pyfunc.rs:546-568); here seeds derive from (seed, chain)."""
-        if self._make_initial_points is None:
+        if self.initial_point_fn is None:
             return None
         n = int(settings.num_chains)
         base = int(settings.seed)
-        pts = np.empty((n, self._n_dim))
+        pts = np.empty((n, self.unconstrained_dim))
         for c in range(n):
-            p = np.asarray(self._make_initial_points((base * 0x9E3779B97F4A7C15 + c) % (1 << 64)), dtype=np.float64)
-            if p.shape != (self._n_dim,):
+            p = np.asarray(self.initial_point_fn((base * 0x9E3779B97F4A7C15 + c) % (1 << 64)), dtype=np.float64)
+            if p.shape != (self.unconstrained_dim,):
                 raise ValueError("Initial point has incorrect length")
             pts[c] = p
         return pts
 
     def _make_model(self, init_mean, settings=None):
-        logp_fn = partial(self._make_logp_func(), **self._shared_data)
+        logp_fn = partial(self.logp_factory(), **self.data)
 
         def row_fn(x):
             val, grad = logp_fn(x)
@@ -89,7 +133,12 @@ class PyFuncModel(CompiledModel):
                 raise TypeError("Return type of logp function should be (float, float64 array)")  # src/pyfunc.rs ReturnTypeError
             return float(val), grad
 
-        model = _lib.HostCallbackModel(self._n_dim, row_fn)
+        model = _lib.HostCallbackModel(self.unconstrained_dim, row_fn)
+        if self.layout.total:
+            # the expand step goes through the C-ABI (nphip_model_set_expand): the engine walks the stored trace and calls
+            # this row function per draw; splitting into variables is one numpy slice per variable afterwards
+            expand_fn = partial(self.expand_factory(0, 0, 0), **self.data)
+            model.set_expand(self.layout.total, lambda x: self.layout.flatten_row(expand_fn(x)))
         pts = self._init_points(settings) if settings is not None else None
         if pts is not None:
             model.set_init("explicit", pts)
@@ -99,21 +148,15 @@ class PyFuncModel(CompiledModel):
         model = self._make_model(init_mean, settings)
         return _lib.PySampler.from_pyfunc(settings, cores, model, progress_type, extra_callback, extra_callback_rate, store, **engine_kw)
 
+    def _unflatten(self, flat):
+        return self.layout.split(flat)
+
     def _expand_draws(self, draws):
-        n, T, _ = draws.shape
-        expand = partial(self._make_expand_func(0, 0, 0), **self._shared_data)
-        out = {name: np.empty((n, T, *shape), dtype=dt) for name, shape, dt in zip(self._names, self._shapes, self._dtypes)}
-        for c in range(n):
-            for t in range(T):
-                vals = expand(draws[c, t])
-                for name, shape, dt in zip(self._names, self._shapes, self._dtypes):
-                    v = np.asarray(vals[name])
-                    if v.dtype != np.dtype(dt):
-                        raise TypeError(f"Expanded variable {name} has dtype {v.dtype}, expected {np.dtype(dt)}")  # src/pyfunc.rs:290-380
-                    if v.size != int(np.prod(shape, dtype=np.int64)):
-                        raise ValueError(f"Expanded variable {name} has incorrect shape")
-                    out[name][c, t] = v.reshape(shape)
-        return out
+        """Host-side expand of an array of draws that did not come out of a sampler (tests, re-expansion)."""
+        expand_fn = partial(self.expand_factory(0, 0, 0), **self.data)
+        rows = draws.reshape(-1, draws.shape[-1])
+        flat = np.stack([self.layout.flatten_row(expand_fn(r)) for r in rows]) if len(rows) else np.empty((0, self.layout.total))
+        return self.layout.split(flat.reshape(*draws.shape[:-1], self.layout.total))
 
 
 def from_pyfunc(
@@ -135,19 +178,22 @@ def from_pyfunc(
     """Same signature as the reference's ``from_pyfunc`` (compiled_pyfunc.py:108-155)."""
     if make_transform_adapter is not None:
         raise NotImplementedError("normalizing-flow adaptation is outside the scope of the HIP engine")
+    layout = ExpandedLayout(
+        names=tuple(expanded_names),
+        shapes=tuple(tuple(int(n) for n in shape) for shape in expanded_shapes),
+        dtypes=tuple(np.dtype(d) for d in expanded_dtypes),
+    )
     return PyFuncModel(
-        _n_dim=ndim,
         dims=dict(dims or {}),
-        _coords=dict(coords or {}),
-        _make_logp_func=make_logp_fn,
-        _make_expand_func=make_expand_fn,
-        _make_initial_points=make_initial_point_fn,
-        _names=list(expanded_names),
-        _shapes=[tuple(s) for s in expanded_shapes],
-        _dtypes=[np.dtype(d) for d in expanded_dtypes],
-        _shared_data=dict(shared_data or {}),
-        _raw_logp_fn=raw_logp_fn,
         reparameterized_names=reparameterized_names,
+        logp_factory=make_logp_fn,
+        expand_factory=make_expand_fn,
+        initial_point_fn=make_initial_point_fn,
+        layout=layout,
+        unconstrained_dim=int(ndim),
+        data=dict(shared_data or {}),
+        coordinates=dict(coords or {}),
+        raw_logp_fn=raw_logp_fn,
     )
 
 
@@ -169,7 +215,7 @@ class TorchFuncModel(CompiledModel):
 
     @property
     def shapes(self):
-        return _shapes_dict(self._names, self._shapes)
+        return {n: tuple(int(v) for v in shp) for n, shp in zip(self._names, self._shapes)}
 
     @property
     def coords(self):
@@ -180,12 +226,10 @@ class TorchFuncModel(CompiledModel):
         return self._n_dim
 
     def with_data(self, **updates):
-        for name in updates:
-            if name not in self._shared_data:
-                raise ValueError(f"Unknown data variable: {name}")
-        updated = self._shared_data.copy()
-        updated.update(**updates)
-        return dataclasses.replace(self, _shared_data=updated)
+        unknown = next((name for name in updates if name not in self._shared_data), None)
+        if unknown is not None:
+            raise ValueError(f"Unknown data variable: {unknown}")
+        return dataclasses.replace(self, _shared_data={**self._shared_data, **updates})
 
     def _make_sampler(self, settings, init_mean, cores, progress_type, extra_callback, extra_callback_rate, store, **engine_kw):
         import torch

@@ -81,6 +81,8 @@ struct Ctl {
     // info of the draw being finished (kept across a mid-adapt step-size search)
     int64_t fin_depth, fin_flags;
     double fin_eerr;
+    // lean register kernels: (A.first, T.first) of the level-1 merge the next leaf will check, evaluated one leaf early
+    int64_t pre_turn;
     // cycle counters per section (only advanced when built with -DNPHIP_PROFILE): leapfrog, tree, rare, count
     int64_t prof[16];
     // sub-tree stack
@@ -149,6 +151,7 @@ struct Args {
     int32_t reg_nv;       // >0: register-resident kernel, NV = reg_nv chunks of 128 per wave (fused; W = 1, or W = 2/4 with ld = 128 * W * NV)
     int32_t stream_cache; // 1: memory-resident fused kernel with the cursor's loads cached in VGPRs (NV < 0 instantiations)
     int32_t sig_lds;      // 1: memory-resident kernels with W >= 8 keep the chain's sigma^2 in (dynamic) LDS
+    int32_t lean;         // 1: lean register-resident kernel (W = 8, reg_nv chunks per wave, sigma^2 in dynamic LDS)
     int32_t max_evals;    // fused: evaluations per chain this launch
     int32_t have_result;  // callbacks: geval/ueval hold the answer to the pending request
     unsigned long long* counters;  // [0] chains done, [1] chains in error

@@ -266,7 +266,7 @@ int64_t nphip_settings_to_json(const nphip_settings_t* s, char* buf, int64_t cap
 typedef int (*bs_ldg_fn)(const void* model, bool propto, bool jacobian, const double* theta, double* val, double* grad, char** err);
 typedef void (*bs_free_err_fn)(char* err);
 struct BsAdapter { void* model; bs_ldg_fn ldg; bs_free_err_fn free_err; };
-static int64_t bs_trampoline(uint64_t, const double* x, double* grad, double* logp, void* user) {
+static int bs_trampoline(uint64_t, const double* x, double* grad, double* logp, void* user) {
     auto* b = static_cast<BsAdapter*>(user);
     char* err = nullptr;
     int rc = b->ldg(b->model, true, true, x, logp, grad, &err);
@@ -286,6 +286,11 @@ struct nphip_model {
     int init_kind = 0;
     std::vector<double> init_points;
     uint64_t n_init_points = 0;
+    // expand step (src/pymc.rs:64-95): host row function or batched device function
+    uint64_t expanded_dim = 0;
+    nphip_raw_expand_fn expand_fn = nullptr;
+    nphip_device_expand_fn expand_dev_fn = nullptr;
+    void* expand_user = nullptr;
 };
 
 extern "C" {
@@ -329,6 +334,17 @@ int nphip_model_set_init(nphip_model_t* m, int kind, const double* points, uint6
     if (kind == 2) { m->init_points.assign(points, points + n_points * m->dim); m->n_init_points = n_points; }
     return NPHIP_OK;
 }
+int nphip_model_set_expand(nphip_model_t* m, uint64_t expanded_dim, nphip_raw_expand_fn fn, void* user_data) {
+    if (!fn || expanded_dim == 0) return bad_value("expand needs a function and expanded_dim > 0");
+    m->expanded_dim = expanded_dim; m->expand_fn = fn; m->expand_dev_fn = nullptr; m->expand_user = user_data;
+    return NPHIP_OK;
+}
+int nphip_model_set_device_expand(nphip_model_t* m, uint64_t expanded_dim, nphip_device_expand_fn fn, void* user_data) {
+    if (!fn || expanded_dim == 0) return bad_value("expand needs a function and expanded_dim > 0");
+    m->expanded_dim = expanded_dim; m->expand_dev_fn = fn; m->expand_fn = nullptr; m->expand_user = user_data;
+    return NPHIP_OK;
+}
+uint64_t nphip_model_expanded_dim(const nphip_model_t* m) { return m->expanded_dim; }
 uint64_t nphip_model_dim(const nphip_model_t* m) { return m->dim; }
 void nphip_model_free(nphip_model_t* m) { delete m; }
 
@@ -509,6 +525,12 @@ bool nphip_sampler::setup() {
     W = launch.waves_per_chain ? launch.waves_per_chain : choose_waves(dim);
     if (!(W == 1 || W == 2 || W == 4 || W == 8 || W == 16)) { set_error("waves_per_chain must be 1, 2, 4, 8 or 16"); return false; }
     if (n == 0 || dim == 0) { set_error("need at least one chain and one dimension"); return false; }
+    if (launch.chain_offset + n > set.num_chains) {
+        // a mis-sharded launch would reuse global chain ids, i.e. RNG streams, without any visible symptom
+        set_error("chain_offset + n_local_chains exceeds settings.num_chains (" + std::to_string(launch.chain_offset) + " + " + std::to_string(n) +
+                  " > " + std::to_string(set.num_chains) + ")");
+        return false;
+    }
 
     memset(&args, 0, sizeof(args));
     DevSettings& s = args.s;
@@ -547,12 +569,22 @@ bool nphip_sampler::setup() {
         const int64_t per_wave = ((int64_t)((dim + 127) / 128) + W - 1) / W;
         if (per_wave >= 1 && per_wave <= 8) { reg_multi = (int)per_wave; args.ld = per_wave * W * 128; }
     }
+    // lean register-resident kernels (8 waves per chain, up to 10 chunks per wave: D <= 10240 — the rows of config 5): state in
+    // VGPRs, sigma^2 in LDS, merge operands streamed (kernels.hip: leaf_lean).  Same padding rule as above.
+    int lean_nc = 0;
+    if (fused_model && (W == 8 || W == 4) && !launch.no_register_kernel && !set.store_divergences) {
+        const int64_t per_wave = ((int64_t)((dim + 127) / 128) + W - 1) / W;
+        if (W == 8 && per_wave >= 1 && per_wave <= 10) { lean_nc = (int)per_wave; args.ld = per_wave * W * 128; }
+        // (experimental geometry: 4 waves per chain with the state spread over VGPRs + AGPRs, one wave per SIMD)
+        if (W == 4 && per_wave > 8 && per_wave <= 20) { lean_nc = (int)per_wave; args.ld = per_wave * W * 128; }
+    }
     args.cap = (int32_t)set.maxdepth;
     args.npslots = num_pslots(args.cap);
     args.nqpool = num_qpool(args.cap);
     const size_t ld = (size_t)args.ld;
     // register-resident specialisation, one wave per chain: state in VGPRs (dim <= 1024, one instantiation per chunk count)
-    args.reg_nv = reg_multi;
+    args.reg_nv = lean_nc ? lean_nc : reg_multi;
+    args.lean = lean_nc ? 1 : 0;
     // (not with store_divergences: the divergence record needs the pre-step state, which only the
     //  memory-resident kernel keeps)
     if (fused && W == 1 && !launch.no_register_kernel && !set.store_divergences) {
@@ -700,7 +732,7 @@ bool nphip_sampler::iteration_callback(bool& all_done, int& have) {
         const uint64_t d = dim;
         pool->run(n, [this, d](uint64_t r) {
             double lp = NAN;
-            h_code[r] = model.host_fn(d, h_q + r * d, h_g + r * d, &lp, model.user);
+            h_code[r] = (int64_t)model.host_fn(d, h_q + r * d, h_g + r * d, &lp, model.user);   // c_int, sign-extended
             h_u[r] = lp;
         });
         if (!zero_copy) {
@@ -970,7 +1002,59 @@ static void* stat_ptr(nphip_sampler_t* s, const std::string& n, size_t* bytes) {
     return nullptr;
 }
 
+int nphip_sampler_copy_expanded(nphip_sampler_t* s, void* host_out, uint64_t nbytes) {
+    const nphip_model& m = s->model;
+    const uint64_t E = m.expanded_dim, d = s->dim, rows = s->n * s->T;
+    if (E == 0) { set_error("the model has no expand function"); return NPHIP_ERR; }
+    if (!s->args.tr_draws) { set_error("the expand step needs the stored draws (store_draws)"); return NPHIP_ERR; }
+    if (nbytes != rows * E * 8) { set_error("size mismatch for expanded"); return NPHIP_ERR; }
+    std::vector<Ctl> h;
+    if (!read_ctl(s, h)) return NPHIP_ERR;
+    double* out = static_cast<double*>(host_out);
+    std::lock_guard<std::mutex> run_lk(s->mu_run);
+    (void)hipSetDevice(s->device);
+    if (!hip_ok(hipStreamSynchronize(s->stream), "sync")) return NPHIP_ERR;
+    // blocks of rows: at most ~64 MB of positions per block
+    const uint64_t block = std::max<uint64_t>(1, std::min<uint64_t>(rows, (64ull << 20) / (d * 8)));
+    std::atomic<int> first_err{0};
+    if (m.expand_fn) {
+        std::vector<double> x(block * d);
+        int nt = (int)std::min<uint64_t>(std::max(1u, std::thread::hardware_concurrency()), 32);
+        if (m.n_threads > 0) nt = m.n_threads;
+        RowPool pool(nt > 1 ? nt : 0);
+        for (uint64_t lo = 0; lo < rows; lo += block) {
+            const uint64_t nb = std::min(block, rows - lo);
+            if (!hip_ok(hipMemcpy(x.data(), s->args.tr_draws + lo * d, nb * d * 8, hipMemcpyDeviceToHost), "copy draws")) return NPHIP_ERR;
+            pool.run(nb, [&](uint64_t r) {
+                const uint64_t row = lo + r, chain = row / s->T, draw = row % s->T;
+                double* o = out + row * E;
+                if ((int64_t)draw >= h[chain].draw) { for (uint64_t e = 0; e < E; ++e) o[e] = NAN; return; }
+                const int rc = m.expand_fn(d, E, x.data() + r * d, o, m.expand_user);
+                if (rc != 0) { int z = 0; first_err.compare_exchange_strong(z, rc); }
+            });
+        }
+    } else {
+        double* dout = nullptr;
+        if (!hip_ok(hipMalloc((void**)&dout, block * E * 8), "hipMalloc")) return NPHIP_ERR;
+        bool ok = true;
+        for (uint64_t lo = 0; ok && lo < rows; lo += block) {
+            const uint64_t nb = std::min(block, rows - lo);
+            const int rc = m.expand_dev_fn(nb, d, E, s->args.tr_draws + lo * d, dout, (void*)s->stream, m.expand_user);
+            if (rc != 0) { first_err.store(rc); break; }
+            ok = hip_ok(hipStreamSynchronize(s->stream), "sync") && hip_ok(hipMemcpy(out + lo * E, dout, nb * E * 8, hipMemcpyDeviceToHost), "copy expanded");
+        }
+        (void)hipFree(dout);
+        if (!ok) return NPHIP_ERR;
+        for (uint64_t row = 0; row < rows; ++row)
+            if ((int64_t)(row % s->T) >= h[row / s->T].draw)
+                for (uint64_t e = 0; e < E; ++e) out[row * E + e] = NAN;
+    }
+    if (first_err.load() != 0) { set_error("Expand function returned error code " + std::to_string(first_err.load())); return NPHIP_ERR; }
+    return NPHIP_OK;
+}
+
 int nphip_sampler_copy_stat(nphip_sampler_t* s, const char* name, void* host_out, uint64_t nbytes) {
+    if (std::string(name) == "expanded") return nphip_sampler_copy_expanded(s, host_out, nbytes);
     size_t bytes = 0;
     void* p = stat_ptr(s, name, &bytes);
     if (!p) { set_error(std::string("trace has no array named ") + name); return NPHIP_ERR; }

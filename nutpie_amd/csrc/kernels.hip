@@ -43,6 +43,13 @@ template <int W>
 // scheduler hoists every load of the next phase above the current one and drives the allocator into scratch;
 // a fence between the phases of a leaf keeps each phase's temporaries local to it.
 #define NPHIP_PHASE_FENCE() __builtin_amdgcn_sched_barrier(0)
+// lean kernels: the unrolled chunk sweeps must stay sweeps — without a fence per chunk the scheduler issues the loads of
+// all chunks first and the allocator spills the resident state to make room for them
+#define NPHIP_CHUNK_FENCE(k) __builtin_amdgcn_sched_barrier(0)
+#ifndef NPHIP_LEAN_OCC
+// waves per SIMD of the lean kernels: 8 waves = one chain per CU at 256 VGPRs per wave (4 waves: 512 = VGPRs + AGPRs)
+#define NPHIP_LEAN_OCC(W) ((W) <= 4 ? 1 : ((W) <= 8 ? 2 : 4))
+#endif
 
 __device__ __forceinline__ void chain_sync() {
     // make this chain's global stores visible to all of its lanes/waves
@@ -171,7 +178,11 @@ struct SCache {
 // NV > 0 selects the register-resident specialisation (requires FUSED; W = 1 with dim <= 128 * NV, or W = 2 / 4 waves
 // per chain with ld == 128 * W * NV): the cursor state (q, grad, p, rho) and sigma^2 live in VGPRs across leapfrogs,
 // so a leapfrog issues no loads at all — only the stores of the new state, which later U-turn checks / draws may read.
-template <bool FUSED, int W, int NV = 0>
+// LEAN (NV > 0, W >= 2, one workgroup = one chain; D up to 128 * W * NV): the register-resident design for rows too long
+// for whole-vector temporaries.  The cursor (q, grad, p, rho) lives in VGPRs, sigma^2 in LDS; EVERY merge operand is
+// streamed from its P-slot chunk by chunk against the resident leaf (leaf_lean), so nothing but the state itself is
+// ever held as a full vector.  The same summation order as every other kernel: chunk c belongs to wave c mod W.
+template <bool FUSED, int W, int NV = 0, bool LEAN = false>
 struct Machine {
     static constexpr int NVX = NV > 0 ? NV : 1;
     static constexpr int NSX = NV < 0 ? -NV : 1;   // NV = -NS: cache (sigma^2, grad, p, rho) of NS chunks per wave
@@ -866,7 +877,7 @@ struct Machine {
     // launch boundary: everything that only lives on chip goes back to its HBM slot
     __device__ __forceinline__ void flush(RegsT& X) {
         if (NV <= 0) return;
-        if (X.dirty_qg || X.dirty_pr) store_state(X, X.dirty_qg, X.dirty_pr);
+        if (X.dirty_qg || X.dirty_pr) { if (LEAN) lean_store(lean_rs(), X, X.dirty_qg, X.dirty_pr); else store_state(X, X.dirty_qg, X.dirty_pr); }
         if (c->phase == PH_TREE) {
             const int64_t d = c->depth;
             if (X.ring_leaf0 >= 0) flush_ring_slot(0, first_slot_of(X.ring_leaf0, d));
@@ -1123,6 +1134,490 @@ struct Machine {
         if (c->depth >= A.s.maxdepth) { rare_end_draw(A, c, red, chain, false, true, false, false, true); return true; }
         start_doubling();
         return false;
+    }
+
+    // ======================================================================================
+    // Lean register-resident leaf (LEAN): the design for long rows (one chain per CU at D = 10 000).
+    //
+    // What differs from leaf_reg: there is no LDS ring and no (pold, rold, operand) whole-vector temporaries — a
+    // wave's registers hold its NV chunks of (q, grad, p, rho) and nothing else that scales with the row:
+    //   * the leapfrog runs in two sweeps over the chunks (position update + edge publication, barrier, gradient +
+    //     second half-kick); the first half-kick is recomputed in the second sweep (bit-identical) instead of kept;
+    //   * the level-0 criterion is accumulated in the second sweep from the before/after values of each chunk;
+    //   * the criteria of a level >= 1 merge stream their operands (A.first, A.last, T.first) from the P-slots chunk by
+    //     chunk against the resident new leaf T.last;  (A.first, T.first) of a level-1 merge — whose T.first is the
+    //     source of the NEXT leapfrog and therefore never written to HBM — is evaluated one leaf early, while that
+    //     T.first is the resident leaf (leaves = 3 mod 4), and kept as one bit in the control block (pre_turn).
+    // Decisions and floats are those of every other kernel: each criterion is its own pair of accumulators, summed per
+    // (lane, component) over the wave's chunks in increasing order, then in the contract's reduction order.
+    // ======================================================================================
+    // Addressing of the lean kernels: buffer instructions — a 128-bit descriptor in SGPRs per array (this chain's Q-pool and
+    // P-slots, the three model vectors), ONE per-lane 32-bit offset (lane * 16) shared by every access, and the (slot, vector,
+    // chunk) position as a scalar offset.  With 64-bit per-lane global addresses the compiler hoists one address pair per
+    // (array, chunk) out of the leaf loop and spills them all (measured: 1000 spilled VGPRs at 10 chunks per wave).
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    struct LeanRs {
+        __amdgpu_buffer_rsrc_t q, p, mu, a, b;
+        uint32_t voff;      // lane * 16
+        uint32_t wave_off;  // byte offset of this wave's first chunk inside a vector
+    };
+    static __device__ __forceinline__ __amdgpu_buffer_rsrc_t mk_rsrc(const void* ptr, uint64_t bytes) {
+        const uint64_t v = (uint64_t)ptr;
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, (int)__builtin_amdgcn_readfirstlane((int)(uint32_t)bytes), 0x00020000);
+    }
+    __device__ __forceinline__ LeanRs lean_rs() const {
+        LeanRs r;
+        r.q = mk_rsrc(qp, (uint64_t)A.nqpool * 2 * ld * 8);
+        r.p = mk_rsrc(pp, (uint64_t)A.npslots * 2 * ld * 8);
+        r.mu = mk_rsrc(A.m_mu, (uint64_t)ld * 8);
+        r.a = mk_rsrc(A.m_a, (uint64_t)ld * 8);
+        r.b = mk_rsrc(A.m_bsh, (uint64_t)(ld + 8) * 8);
+        r.voff = (uint32_t)lane * 16u;
+        r.wave_off = (uint32_t)wave * (NPHIP_CHUNK * 8);
+        return r;
+    }
+    // scalar byte offset of chunk k of this wave inside vector `vec` (0/1) of buffer / slot `slot`
+    __device__ __forceinline__ uint32_t soff(const LeanRs& rs, int64_t slot, int vec, int k) const {
+        const uint32_t s_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);
+        return (s_ * 2u + (uint32_t)vec) * (uint32_t)(ld * 8) + (uint32_t)k * (uint32_t)(W * NPHIP_CHUNK * 8) + rs.wave_off;
+    }
+    static __device__ __forceinline__ double2 bld2(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t so) {
+        return __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)so, 0));
+    }
+    static __device__ __forceinline__ void bst2(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t so, double2 v) {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)voff, (int)so, 0);
+    }
+    // model vectors: chunk k of this wave
+    __device__ __forceinline__ double2 par2(const LeanRs& rs, __amdgpu_buffer_rsrc_t r, int k) const {
+        return bld2(r, rs.voff, (uint32_t)k * (uint32_t)(W * NPHIP_CHUNK * 8) + rs.wave_off);
+    }
+    __device__ __forceinline__ double par_b2(const LeanRs& rs, int k) const {   // b_{i+1} = m_bsh[i + 2]
+        return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs.b, (int)(rs.voff + 16u), (int)((uint32_t)k * (uint32_t)(W * NPHIP_CHUNK * 8) + rs.wave_off), 0));
+    }
+    __device__ __forceinline__ double2 sigl(const LeanRs& rs, int k) const {
+        return *(const NPHIP_LDS double2*)((const NPHIP_LDS char*)sig_lds + ((uint32_t)k * (uint32_t)(W * NPHIP_CHUNK * 8) + rs.wave_off + rs.voff));
+    }
+
+    // gradient of the resident position (after a reload: only q is kept in HBM) — two sweeps, edges through LDS
+    __device__ __forceinline__ void lean_grad(const LeanRs& rs, RegsT& X) {
+#pragma unroll
+        for (int k = 0; k < NVX; ++k) {
+            const double2 mu = par2(rs, rs.mu, k);
+            const int64_t cch = (int64_t)k * W + wave;
+            const double zx = X.q[k].x - mu.x, zy = X.q[k].y - mu.y;
+            if (lane == 0 || lane == 63) edge[2 * cch + (lane == 0 ? 1 : 2)] = (lane == 0) ? zx : zy;
+            NPHIP_CHUNK_FENCE(k);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NVX; ++k) {
+            const int64_t cch = (int64_t)k * W + wave;
+            const double2 mu = par2(rs, rs.mu, k), a = par2(rs, rs.a, k), b01 = par2(rs, rs.b, k);
+            const double b2 = par_b2(rs, k);
+            double2 z;
+            z.x = X.q[k].x - mu.x;
+            z.y = X.q[k].y - mu.y;
+            const double ezl = edge[2 * cch], ezr = edge[2 * cch + 3];   // (the buffer is padded with 0.0 at both ends)
+            const double zl = wave_shr1(z.y, ezl), zr = wave_shl1(z.x, ezr);
+            double tx = a.x * z.x;
+            tx = fma(b01.x, zl, tx);
+            tx = fma(b01.y, z.y, tx);
+            double ty = a.y * z.y;
+            ty = fma(b01.y, z.x, ty);
+            ty = fma(b2, zr, ty);
+            X.g[k].x = -tx;
+            X.g[k].y = -ty;
+            NPHIP_CHUNK_FENCE(k);
+        }
+        __syncthreads();  // the edge buffer is free again
+    }
+
+    // ---- streamed criteria.  PF chunks of look-ahead: the operands of chunk k + PF are requested before chunk k is used.  A
+    // pass is a pure memory phase of the whole CU (one chain per CU: every wave is in it at once), so what bounds it is the
+    // number of bytes in flight: 4 waves with the state parked in AGPRs have VGPRs for 4 chunks x 3 slots, 8 waves for one.
+    static constexpr int PF = (W <= 4) ? 4 : 1;
+    struct SlotChunk { double2 p, r; };
+    __device__ __forceinline__ SlotChunk ldslot(const LeanRs& rs, int64_t slot, int k) const {
+        SlotChunk c_;
+        c_.p = bld2(rs.p, rs.voff, soff(rs, slot, 0, k));
+        c_.r = bld2(rs.p, rs.voff, soff(rs, slot, 1, k));
+        return c_;
+    }
+    // (A, resident) inside a doubling: A earlier, the resident leaf later
+    __device__ __forceinline__ bool lean_pass1(const LeanRs& rs, const RegsT& X, int64_t sAf) {
+        double2 e = {0.0, 0.0}, st = {0.0, 0.0};
+        SlotChunk an[PF];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) if (u < NVX) an[u] = ldslot(rs, sAf, u);
+#pragma unroll
+        for (int k = 0; k < NVX; ++k) {
+            const SlotChunk a = an[k % PF];
+            if (k + PF < NVX) an[k % PF] = ldslot(rs, sAf, k + PF);
+            const double2 s2 = sigl(rs, k);
+            span_acc(a.p.x, a.r.x, X.p[k].x, X.r[k].x, s2.x, e.x, st.x);
+            span_acc(a.p.y, a.r.y, X.p[k].y, X.r[k].y, s2.y, e.y, st.y);
+            NPHIP_CHUNK_FENCE(k);
+        }
+        double v[2] = {e.x + e.y, st.x + st.y};
+        rsum(v);
+        return (v[0] < 0.0) || (v[1] < 0.0);
+    }
+    // (A.first, resident) || (A.last, resident)
+    __device__ __forceinline__ bool lean_pass2(const LeanRs& rs, const RegsT& X, int64_t sAf, int64_t sAl) {
+        double2 acc[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) { acc[n].x = 0.0; acc[n].y = 0.0; }
+        SlotChunk an[PF], bn[PF];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) if (u < NVX) { an[u] = ldslot(rs, sAf, u); bn[u] = ldslot(rs, sAl, u); }
+#pragma unroll
+        for (int k = 0; k < NVX; ++k) {
+            const SlotChunk a = an[k % PF], b = bn[k % PF];
+            if (k + PF < NVX) { an[k % PF] = ldslot(rs, sAf, k + PF); bn[k % PF] = ldslot(rs, sAl, k + PF); }
+            const double2 s2 = sigl(rs, k);
+            span_acc(a.p.x, a.r.x, X.p[k].x, X.r[k].x, s2.x, acc[0].x, acc[1].x);
+            span_acc(a.p.y, a.r.y, X.p[k].y, X.r[k].y, s2.y, acc[0].y, acc[1].y);
+            span_acc(b.p.x, b.r.x, X.p[k].x, X.r[k].x, s2.x, acc[2].x, acc[3].x);
+            span_acc(b.p.y, b.r.y, X.p[k].y, X.r[k].y, s2.y, acc[2].y, acc[3].y);
+            NPHIP_CHUNK_FENCE(k);
+        }
+        double v[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) v[n] = acc[n].x + acc[n].y;
+        rsum(v);
+        return (v[0] < 0.0) || (v[1] < 0.0) || (v[2] < 0.0) || (v[3] < 0.0);
+    }
+    // (A.first, resident) || (A.first, T.first) || (A.last, resident)
+    __device__ __forceinline__ bool lean_pass3(const LeanRs& rs, const RegsT& X, int64_t sAf, int64_t sAl, int64_t sTf) {
+        double2 acc[6];
+#pragma unroll
+        for (int n = 0; n < 6; ++n) { acc[n].x = 0.0; acc[n].y = 0.0; }
+        SlotChunk an[PF], bn[PF], fn[PF];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) if (u < NVX) { an[u] = ldslot(rs, sAf, u); bn[u] = ldslot(rs, sAl, u); fn[u] = ldslot(rs, sTf, u); }
+#pragma unroll
+        for (int k = 0; k < NVX; ++k) {
+            const SlotChunk a = an[k % PF], b = bn[k % PF], f = fn[k % PF];
+            if (k + PF < NVX) { an[k % PF] = ldslot(rs, sAf, k + PF); bn[k % PF] = ldslot(rs, sAl, k + PF); fn[k % PF] = ldslot(rs, sTf, k + PF); }
+            const double2 s2 = sigl(rs, k);
+            span_acc(a.p.x, a.r.x, X.p[k].x, X.r[k].x, s2.x, acc[0].x, acc[1].x);
+            span_acc(a.p.y, a.r.y, X.p[k].y, X.r[k].y, s2.y, acc[0].y, acc[1].y);
+            span_acc(a.p.x, a.r.x, f.p.x, f.r.x, s2.x, acc[2].x, acc[3].x);
+            span_acc(a.p.y, a.r.y, f.p.y, f.r.y, s2.y, acc[2].y, acc[3].y);
+            span_acc(b.p.x, b.r.x, X.p[k].x, X.r[k].x, s2.x, acc[4].x, acc[5].x);
+            span_acc(b.p.y, b.r.y, X.p[k].y, X.r[k].y, s2.y, acc[4].y, acc[5].y);
+            NPHIP_CHUNK_FENCE(k);
+        }
+        double v[6];
+#pragma unroll
+        for (int n = 0; n < 6; ++n) v[n] = acc[n].x + acc[n].y;
+        rsum(v);
+        return (v[0] < 0.0) || (v[1] < 0.0) || (v[2] < 0.0) || (v[3] < 0.0) || (v[4] < 0.0) || (v[5] < 0.0);
+    }
+    // General index modes without branches: the span of every (first_is_start, mode) combination is
+    //   (U - V) + Wv  with  v0: (r2 - r1) + p1   v1: (r1 - r2) + p2   v2: r2 - (-r1) + (-0.0) = r1 + r2  (exact: x + (-0.0) == x),
+    // selected by wave-uniform flags.  acc2 takes span . sigma^2 p2, acc1 span . sigma^2 p1 (which of the two is "end" and
+    // which "start" only names them: both are tested against zero).
+    struct PairU { bool swap, sum; };
+    __device__ __forceinline__ PairU pair_u(const Pair pr) const {
+        PairU u;
+        u.sum = pr.mode == 1;
+        u.swap = pr.first_is_start ? (pr.mode == 2) : (pr.mode == 0);
+        return u;
+    }
+    __device__ __forceinline__ void pair_acc_u(const PairU u, double p1, double r1, double p2, double r2, double s2v, double& acc2, double& acc1) const {
+        const double U = u.swap ? r1 : r2;
+        double V = u.swap ? r2 : r1;
+        V = u.sum ? -V : V;
+        const double Wv = u.sum ? -0.0 : (u.swap ? p2 : p1);
+        const double t = (U - V) + Wv;
+        acc2 = fma(t, s2v * p2, acc2);
+        acc1 = fma(t, s2v * p1, acc1);
+    }
+    // top-level merge (general index modes): (far, resident) q1 || (far, T.first) q3 || (near, resident) qn;
+    // d == 0 (full == false): only (far, resident) — both ends are the origin
+    __device__ __forceinline__ bool lean_top(const LeanRs& rs, const RegsT& X, bool full, int64_t sFar, int64_t sNear, int64_t sTf, const Pair q1,
+                                             const Pair q3, const Pair qn) {
+        const PairU p1 = pair_u(q1), p3 = pair_u(q3), pn = pair_u(qn);
+        double2 acc[6];
+#pragma unroll
+        for (int n = 0; n < 6; ++n) { acc[n].x = 0.0; acc[n].y = 0.0; }
+        if (full) {
+            SlotChunk an[PF], bn[PF], fn[PF];
+#pragma unroll
+            for (int u = 0; u < PF; ++u) if (u < NVX) { an[u] = ldslot(rs, sFar, u); bn[u] = ldslot(rs, sNear, u); fn[u] = ldslot(rs, sTf, u); }
+#pragma unroll
+            for (int k = 0; k < NVX; ++k) {
+                const SlotChunk a = an[k % PF], b = bn[k % PF], f = fn[k % PF];
+                if (k + PF < NVX) { an[k % PF] = ldslot(rs, sFar, k + PF); bn[k % PF] = ldslot(rs, sNear, k + PF); fn[k % PF] = ldslot(rs, sTf, k + PF); }
+                const double2 s2 = sigl(rs, k);
+                pair_acc_u(p1, a.p.x, a.r.x, X.p[k].x, X.r[k].x, s2.x, acc[0].x, acc[1].x);
+                pair_acc_u(p1, a.p.y, a.r.y, X.p[k].y, X.r[k].y, s2.y, acc[0].y, acc[1].y);
+                pair_acc_u(p3, a.p.x, a.r.x, f.p.x, f.r.x, s2.x, acc[2].x, acc[3].x);
+                pair_acc_u(p3, a.p.y, a.r.y, f.p.y, f.r.y, s2.y, acc[2].y, acc[3].y);
+                pair_acc_u(pn, b.p.x, b.r.x, X.p[k].x, X.r[k].x, s2.x, acc[4].x, acc[5].x);
+                pair_acc_u(pn, b.p.y, b.r.y, X.p[k].y, X.r[k].y, s2.y, acc[4].y, acc[5].y);
+                NPHIP_CHUNK_FENCE(k);
+            }
+        } else {
+            SlotChunk an[PF];
+#pragma unroll
+            for (int u = 0; u < PF; ++u) if (u < NVX) an[u] = ldslot(rs, sFar, u);
+#pragma unroll
+            for (int k = 0; k < NVX; ++k) {
+                const SlotChunk a = an[k % PF];
+                if (k + PF < NVX) an[k % PF] = ldslot(rs, sFar, k + PF);
+                const double2 s2 = sigl(rs, k);
+                pair_acc_u(p1, a.p.x, a.r.x, X.p[k].x, X.r[k].x, s2.x, acc[0].x, acc[1].x);
+                pair_acc_u(p1, a.p.y, a.r.y, X.p[k].y, X.r[k].y, s2.y, acc[0].y, acc[1].y);
+                NPHIP_CHUNK_FENCE(k);
+            }
+        }
+        double v[6];
+#pragma unroll
+        for (int n = 0; n < 6; ++n) v[n] = acc[n].x + acc[n].y;
+        rsum(v);
+        return (v[0] < 0.0) || (v[1] < 0.0) || (v[2] < 0.0) || (v[3] < 0.0) || (v[4] < 0.0) || (v[5] < 0.0);
+    }
+
+    __device__ __forceinline__ void lean_store(const LeanRs& rs, RegsT& X, bool q_, bool pr) {
+        if (q_) {
+#pragma unroll
+            for (int k = 0; k < NVX; ++k) bst2(rs.q, rs.voff, soff(rs, X.reg_q, 0, k), X.q[k]);
+            X.dirty_qg = false;
+        }
+        if (pr) {
+#pragma unroll
+            for (int k = 0; k < NVX; ++k) { bst2(rs.p, rs.voff, soff(rs, X.reg_p, 0, k), X.p[k]); bst2(rs.p, rs.voff, soff(rs, X.reg_p, 1, k), X.r[k]); }
+            X.dirty_pr = false;
+        }
+    }
+    // returns 0 (next leaf) or an end code; the caller runs the out-of-line draw end AFTER the register state is dead:
+    // 1 diverged, 2 U-turn, 3 maximum depth
+    __device__ __forceinline__ int leaf_lean(const LeanRs& rs, RegsT& X) {
+        const int64_t j = c->nleaf + 1, d = c->depth, dir = c->dir;
+        const int db = dir > 0 ? 1 : 0;
+        const int64_t near_idx = dir > 0 ? c->idx_right : c->idx_left;
+        const int64_t idx_new = c->idx_cur + dir;
+        const int64_t srcq = c->lf_srcq, srcp = c->lf_srcp, newq = c->lf_newq, newp = c->lf_newp;
+        const bool check = A.s.check_turning && (d + 1 > A.s.mindepth);
+#ifdef NPHIP_PROFILE
+        const int64_t tp0 = (int64_t)__builtin_readcyclecounter();
+#endif
+        // ---- source state (already resident unless the cursor moved or a rare path ran)
+        if (X.reg_q != srcq) {
+#pragma unroll
+            for (int k = 0; k < NVX; ++k) X.q[k] = bld2(rs.q, rs.voff, soff(rs, srcq, 0, k));
+            lean_grad(rs, X);
+        }
+        if (X.reg_p != srcp) {
+#pragma unroll
+            for (int k = 0; k < NVX; ++k) { X.p[k] = bld2(rs.p, rs.voff, soff(rs, srcp, 0, k)); X.r[k] = bld2(rs.p, rs.voff, soff(rs, srcp, 1, k)); }
+        }
+        NPHIP_PHASE_FENCE();
+        // ---- leapfrog, sweep 1: q' = q + eps sigma^2 (p + eps/2 g); publish the chunk-edge z'
+        const double eps = (double)c->lf_sign * c->step_size;
+        const double h = 0.5 * eps;
+        const bool first_back = (idx_new == -1);   // first backward step: rho' = p'  (-0.0 + p == p exactly, also for signed zeros)
+        // (software pipeline, one chunk deep: the L2 loads of chunk k + 1 are issued before chunk k is computed; the fence at the
+        //  end of every chunk keeps the scheduler from issuing them all at once — that spills the resident state)
+        double2 mu_n = par2(rs, rs.mu, 0);
+#pragma unroll
+        for (int k = 0; k < NVX; ++k) {
+            const int64_t cch = (int64_t)k * W + wave;
+            const double2 mu = mu_n;
+            if (k + 1 < NVX) mu_n = par2(rs, rs.mu, k + 1);
+            const double2 s2 = sigl(rs, k);
+            const double phx = fma(h, X.g[k].x, X.p[k].x), phy = fma(h, X.g[k].y, X.p[k].y);
+            X.q[k].x = fma(eps, s2.x * phx, X.q[k].x);
+            X.q[k].y = fma(eps, s2.y * phy, X.q[k].y);
+            const double zx = X.q[k].x - mu.x, zy = X.q[k].y - mu.y;
+            if (lane == 0 || lane == 63) edge[2 * cch + (lane == 0 ? 1 : 2)] = (lane == 0) ? zx : zy;
+            NPHIP_CHUNK_FENCE(k);
+        }
+        __syncthreads();
+#ifdef NPHIP_PROFILE
+        const int64_t tp_s1 = (int64_t)__builtin_readcyclecounter();
+#endif
+        // ---- sweep 2: gradient at q', second half-kick, energies, level-0 criterion
+        double2 accK = {0.0, 0.0}, accL = {0.0, 0.0}, accE = {0.0, 0.0}, accS = {0.0, 0.0};
+        // (an opaque copy of h: with the same SSA value the compiler keeps sweep 1's half-kicked momenta of ALL chunks alive
+        //  across the barrier instead of recomputing them — 4 more registers per chunk than the budget has)
+        double h2 = h;
+        asm volatile("" : "+v"(h2));
+        double2 a_n = par2(rs, rs.a, 0), b01_n = par2(rs, rs.b, 0);
+        double b2_n = par_b2(rs, 0);
+        mu_n = par2(rs, rs.mu, 0);
+#pragma unroll
+        for (int k = 0; k < NVX; ++k) {
+            const int64_t cch = (int64_t)k * W + wave;
+            const double2 mu = mu_n, a = a_n, b01 = b01_n;
+            const double b2 = b2_n;
+            if (k + 1 < NVX) { mu_n = par2(rs, rs.mu, k + 1); a_n = par2(rs, rs.a, k + 1); b01_n = par2(rs, rs.b, k + 1); b2_n = par_b2(rs, k + 1); }
+            const double2 s2 = sigl(rs, k);
+            double2 z;
+            z.x = X.q[k].x - mu.x;
+            z.y = X.q[k].y - mu.y;
+            const double ezl = edge[2 * cch], ezr = edge[2 * cch + 3];   // (the buffer is padded with 0.0 at both ends)
+            const double zl = wave_shr1(z.y, ezl), zr = wave_shl1(z.x, ezr);
+            double tx = a.x * z.x;
+            tx = fma(b01.x, zl, tx);
+            tx = fma(b01.y, z.y, tx);
+            double ty = a.y * z.y;
+            ty = fma(b01.y, z.x, ty);
+            ty = fma(b2, zr, ty);
+            double2 gg;
+            gg.x = -tx;
+            gg.y = -ty;
+            accL.x = fma(z.x, gg.x, accL.x);
+            accL.y = fma(z.y, gg.y, accL.y);
+            const double2 pold = X.p[k];
+            double2 rold;
+            rold.x = first_back ? -0.0 : X.r[k].x;
+            rold.y = first_back ? -0.0 : X.r[k].y;
+            double2 pv;
+            pv.x = fma(h2, gg.x, fma(h2, X.g[k].x, pold.x));   // the first half-kick again: same operands, same bits
+            pv.y = fma(h2, gg.y, fma(h2, X.g[k].y, pold.y));
+            X.g[k] = gg;
+            X.p[k] = pv;
+            const double vx = s2.x * pv.x, vy = s2.y * pv.y;
+            accK.x = fma(pv.x, vx, accK.x);
+            accK.y = fma(pv.y, vy, accK.y);
+            X.r[k].x = rold.x + pv.x;
+            X.r[k].y = rold.y + pv.y;
+            const double tx0 = (X.r[k].x - rold.x) + pold.x, ty0 = (X.r[k].y - rold.y) + pold.y;
+            accE.x = fma(tx0, vx, accE.x);
+            accE.y = fma(ty0, vy, accE.y);
+            accS.x = fma(tx0, s2.x * pold.x, accS.x);
+            accS.y = fma(ty0, s2.y * pold.y, accS.y);
+            NPHIP_CHUNK_FENCE(k);
+        }
+        X.reg_q = newq;
+        X.reg_p = newp;
+        X.dirty_qg = true;
+        X.dirty_pr = true;
+#ifdef NPHIP_PROFILE
+        const int64_t tp1 = (int64_t)__builtin_readcyclecounter();
+#endif
+        NPHIP_PHASE_FENCE();
+        double v4[4] = {accK.x + accK.y, accL.x + accL.y, accE.x + accE.y, accS.x + accS.y};
+        rsum(v4);
+        NPHIP_PHASE_FENCE();
+#ifdef NPHIP_PROFILE
+        const int64_t tp2 = (int64_t)__builtin_readcyclecounter();
+        c->prof[0] += tp1 - tp0; c->prof[15] += tp_s1 - tp0; c->prof[6] += tp2 - tp1;
+#endif
+        const double K = 0.5 * v4[0], lp = 0.5 * v4[1];
+        const bool turn0 = (v4[2] < 0.0) || (v4[3] < 0.0);
+        // ---- NutsTree::extend / merge_into, unrolled (same decisions as leaf_reg / cont_tree)
+        c->nleaf += 1;
+        c->n_steps += 1;
+        c->total_steps += 1;
+        const bool ok = isfinite(lp);
+        const double Unew = -lp, E = K + Unew, dE = E - c->H0;
+        const bool diverged = !ok || (dE > A.s.max_energy_error) || !isfinite(dE);
+        double T_wm = 1.0;
+        int64_t T_we = 0;
+        if (!diverged) {
+            const double x = -dE, xc = x > 1e9 ? 1e9 : (x < -1e9 ? -1e9 : x);
+            double kk;
+            nphip_exp_parts(xc, &T_wm, &kk);
+            T_we = (int64_t)kk;
+            const double e = nphip_exp_scale(x, T_wm, kk);
+            const double a = e < 1.0 ? e : 1.0;
+            c->acc_sum += a;
+            c->acc_sym_sum += 2.0 * a / (1.0 + e);
+        }
+        if (diverged) { X.dirty_qg = X.dirty_pr = false; return 1; }
+#ifdef NPHIP_PROFILE
+        int64_t tq = (int64_t)__builtin_readcyclecounter();
+        c->prof[8] += tq - tp2;
+#endif
+        NPHIP_PHASE_FENCE();
+        double T_U = Unew, T_E = E;
+        nphip_u32x4 mrg_blk = {{0u, 0u, 0u, 0u}};
+        int64_t mrg_id = -1;
+        int64_t T_q = newq, T_idx = idx_new;
+        c->curq = newq; c->curp = newp; c->idx_cur = idx_new;
+        int64_t k = 0;
+        while (k < d && (((j - 1) >> k) & 1)) {
+            if (check) {
+                bool turn;
+                if (k == 0) {
+                    turn = turn0;
+                } else {
+                    const int64_t a = j - (2ll << k) + 1, al = j - (1ll << k);
+                    const int64_t sAf = first_slot_of(a, d), sAl = slot_last(__builtin_ctzll((unsigned long long)al), A.cap);
+                    if (k == 1) turn = (c->pre_turn != 0) | lean_pass2(rs, X, sAf, sAl);
+                    else turn = lean_pass3(rs, X, sAf, sAl, first_slot_of(al + 1, d));
+                }
+                if (turn) { X.dirty_qg = X.dirty_pr = false; return 2; }
+            }
+#ifdef NPHIP_PROFILE
+            { const int64_t t_ = (int64_t)__builtin_readcyclecounter(); c->prof[k == 0 ? 9 : 10] += t_ - tq; tq = t_; }
+#endif
+            NPHIP_PHASE_FENCE();
+            {   // multinomial merge: keep T's draw w.p. w_T / (w_A + w_T)
+                double sm; int64_t se;
+                nphip_w_add(c->sub_wm[k], c->sub_we[k], T_wm, T_we, &sm, &se);
+                const bool take = merge_uniform(j, d, k, mrg_blk, mrg_id) * sm < nphip_w_rel(T_wm, T_we, se);
+                if (!take) { T_q = c->sub_q[k]; T_U = c->sub_U[k]; T_E = c->sub_E[k]; T_idx = c->sub_idx[k]; }
+                T_wm = sm; T_we = se;
+            }
+            NPHIP_PHASE_FENCE();
+#ifdef NPHIP_PROFILE
+            { const int64_t t_ = (int64_t)__builtin_readcyclecounter(); c->prof[11] += t_ - tq; tq = t_; }
+#endif
+            ++k;
+        }
+        if (k < d) {
+            c->sub_wm[k] = T_wm; c->sub_we[k] = T_we; c->sub_q[k] = T_q; c->sub_U[k] = T_U; c->sub_E[k] = T_E; c->sub_idx[k] = T_idx;
+            // (A.first, T.first) of the level-1 merge the next leaf will check: this leaf IS that T.first
+#ifdef NPHIP_PROFILE
+            const int64_t tp3 = (int64_t)__builtin_readcyclecounter();
+#endif
+            if ((j & 3) == 3 && check && d >= 2) c->pre_turn = lean_pass1(rs, X, first_slot_of(j - 2, d)) ? 1 : 0;
+#ifdef NPHIP_PROFILE
+            const int64_t tp4 = (int64_t)__builtin_readcyclecounter();
+            c->prof[10] += tp4 - tp3;
+#endif
+            // ---- stores, last: q when the leaf is referenced as a candidate; (p, rho) unless the leaf is only ever the
+            // source of the next leapfrog (leaf % 4 == 3)
+            lean_store(rs, X, T_q == newq, (j & 3) != 3);
+            issue_leaf();
+#ifdef NPHIP_PROFILE
+            c->prof[7] += (int64_t)__builtin_readcyclecounter() - tp4;
+#endif
+            return 0;
+        }
+        // ---- the new sub-tree of depth d is complete (j == 2^d): merge into the main tree (general index modes)
+        bool turn = false;
+        if (check) {
+            const int64_t far_slot = c->endp[1 - db], far_idx = dir > 0 ? c->idx_left : c->idx_right;
+            turn = lean_top(rs, X, d != 0, far_slot, c->endp[db], slot_first((int)d), pair_of(far_idx, idx_new), pair_of(far_idx, near_idx + dir),
+                            pair_of(near_idx, idx_new));
+        }
+        c->endq[db] = newq;
+        c->endp[db] = newp;
+        c->endpar[db] ^= 1;
+        if (dir > 0) c->idx_right = idx_new; else c->idx_left = idx_new;
+        {
+            double sm; int64_t se;
+            nphip_w_add(c->main_wm, c->main_we, T_wm, T_we, &sm, &se);
+            const double ref = nphip_w_rel(c->main_wm, c->main_we, se), oth = nphip_w_rel(T_wm, T_we, se);
+            bool take = oth >= ref;
+            if (!take) take = merge_uniform(j, d, d, mrg_blk, mrg_id) * ref < oth;
+            if (take) { c->cand_q = T_q; c->cand_U = T_U; c->cand_E = T_E; c->cand_idx = T_idx; }
+            c->main_wm = sm; c->main_we = se;
+            c->depth = d + 1;
+        }
+        lean_store(rs, X, true, true);  // a new trajectory end is always written back
+        if (turn) return 2;
+        if (c->depth >= A.s.maxdepth) return 3;
+        start_doubling();
+        return 0;
     }
 
     // memory-resident equivalent (NV == 0): the same criteria, one pass each
@@ -1630,7 +2125,9 @@ struct Machine {
             RegsT X;
             SCacheT Y;
             bool rare = false, out_of_budget = false;
-            if (NV == 0 && sig_copy != nullptr) {
+            int lean_end = 0;
+            const LeanRs lrs = lean_rs();
+            if ((NV == 0 || LEAN) && sig_copy != nullptr) {
                 // stage sigma^2 in LDS: it only changes in the rare draw-end path
                 for (int64_t i = 2 * (int64_t)threadIdx.x; i < ld; i += 2 * (int64_t)blockDim.x)
                     *(NPHIP_LDS double2*)(sig_copy + i) = ld2(sig2, i);
@@ -1642,7 +2139,8 @@ struct Machine {
                 const int64_t t0 = (int64_t)__builtin_readcyclecounter();
 #endif
                 if (NV > 0) {
-                    rare = leaf_reg(X);
+                    if (LEAN) { lean_end = leaf_lean(lrs, X); rare = lean_end != 0; }
+                    else rare = leaf_reg(X);
                 } else {
                     double lp = 0.0;
                     int64_t code = 0;
@@ -1673,6 +2171,7 @@ struct Machine {
             }
             sig_lds = nullptr;
             if (!rare) flush(X);  // launch boundary: registers that hold the only copy of the cursor state go back to HBM
+            if (LEAN && lean_end != 0) rare_end_draw(A, c, red, chain, lean_end == 1, lean_end == 3, false, false, true);
             if (out_of_budget) break;
         }
     }
@@ -1681,15 +2180,15 @@ struct Machine {
 
 // `Ap` points to the engine's argument block in device memory (written once at set-up); it is read through
 // the constant address space, i.e. with scalar loads into SGPRs.  Per-launch scalars are kernel parameters.
-template <bool FUSED, int W, int NV>
-__global__ __launch_bounds__(W == 1 ? 256 : 64 * W) __attribute__((amdgpu_waves_per_eu((NV > 0 && NV <= 4) ? 2 : 1, (NV > 0 && NV <= 4) ? 2 : 8))) void k_advance(const Args* __restrict__ Ap, int max_evals, int have_result) {
+template <bool FUSED, int W, int NV, bool LEAN = false>
+__global__ __launch_bounds__(W == 1 ? 256 : 64 * W) __attribute__((amdgpu_waves_per_eu(LEAN ? NPHIP_LEAN_OCC(W) : ((NV > 0 && NV <= 4) ? 2 : 1), LEAN ? NPHIP_LEAN_OCC(W) : ((NV > 0 && NV <= 4) ? 2 : 8)))) void k_advance(const Args* __restrict__ Ap, int max_evals, int have_result) {
     const NPHIP_CONST Args& A = *(const NPHIP_CONST Args*)Ap;
     constexpr int WAVES = (W == 1) ? 4 : W;
     __shared__ Ctl s_ctl[WAVES];
     __shared__ double s_red[16 * WAVES];   // two alternating reduction areas
     __shared__ __attribute__((aligned(16))) double s_par[(NV > 0 && W == 1) ? 3 * 128 * NV + 8 : 2];
-    __shared__ __attribute__((aligned(16))) double s_ring[NV > 0 ? WAVES * 4 * 128 * NV : 2];  // per wave: 2 slots x (p, rho)
-    __shared__ double s_edge[(NV > 0 && W > 1) ? 2 * W * NV : 2];
+    __shared__ __attribute__((aligned(16))) double s_ring[(NV > 0 && !LEAN) ? WAVES * 4 * 128 * NV : 2];  // per wave: 2 slots x (p, rho)
+    __shared__ double s_edge[(NV > 0 && W > 1) ? 2 * W * NV + 2 : 2];   // lean kernels: padded with one 0.0 at each end
     extern __shared__ __attribute__((aligned(16))) double s_dyn[];  // a.sig_lds: sigma^2 of the chain [ld]
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int64_t chain = (W == 1) ? (int64_t)blockIdx.x * 4 + wib : (int64_t)blockIdx.x;
@@ -1706,6 +2205,7 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) __attribute__((amdgpu_waves_
         __syncthreads();
     }
     if (chain >= A.n_chains) return;
+    if (LEAN && threadIdx.x == 0) { s_edge[0] = 0.0; s_edge[2 * W * NV + 1] = 0.0; }   // (the first barrier is in the sigma^2 staging)
     LdsCtl c = (LdsCtl)&s_ctl[wib];
     {
         const NPHIP_GLOBAL uint64_t* src = (const NPHIP_GLOBAL uint64_t*)(A.ctl + chain);
@@ -1713,9 +2213,9 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) __attribute__((amdgpu_waves_
         for (int w = lane; w < kCtlWords; w += 64) dst[w] = src[w];
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    Machine<FUSED, W, NV> m(A, c, (LdsDouble)s_red, chain, (LdsDouble)s_par, (LdsDouble)s_ring + (size_t)wib * 4 * 128 * (NV > 0 ? NV : 1),
+    Machine<FUSED, W, NV, LEAN> m(A, c, (LdsDouble)s_red, chain, (LdsDouble)s_par, (LdsDouble)s_ring + (LEAN ? 0 : (size_t)wib * 4 * 128 * (NV > 0 ? NV : 1)),
                             (LdsDouble)s_edge);
-    m.run(max_evals, have_result != 0, (NV == 0 && W >= 8 && A.sig_lds) ? (LdsDouble)s_dyn : nullptr);
+    m.run(max_evals, have_result != 0, (LEAN || (NV == 0 && W >= 8 && A.sig_lds)) ? (LdsDouble)s_dyn : nullptr);
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     if (W == 1 || wib == 0) {
         NPHIP_GLOBAL uint64_t* dst = (NPHIP_GLOBAL uint64_t*)(A.ctl + chain);
@@ -1728,6 +2228,60 @@ template <bool FUSED>
 static hipError_t launch_w(const Args& a, const Args* d_args, int W, hipStream_t st) {
     const unsigned n = (unsigned)a.n_chains;
     const int me = a.max_evals, hr = a.have_result;
+    if (FUSED && a.lean && a.reg_nv > 0) {
+        // lean register-resident kernels (4096 < D <= 10240): one workgroup of 8 waves = one chain, sigma^2 in dynamic LDS
+        const dim3 g(n), b(64 * W);
+        const size_t dyn = (size_t)a.ld * 8;
+#define NPHIP_LAUNCH_LEAN(WW, NN) hipLaunchKernelGGL((k_advance<true, WW, NN, true>), g, b, dyn, st, d_args, me, hr)
+#ifndef NPHIP_DEV_LEAN
+        if (W == 4) {   // 4 waves per chain, state spread over VGPRs + AGPRs (one wave per SIMD): 9..20 chunks per wave
+            switch (a.reg_nv) {
+                case 9: NPHIP_LAUNCH_LEAN(4, 9); break;
+                case 10: NPHIP_LAUNCH_LEAN(4, 10); break;
+                case 11: NPHIP_LAUNCH_LEAN(4, 11); break;
+                case 12: NPHIP_LAUNCH_LEAN(4, 12); break;
+                case 13: NPHIP_LAUNCH_LEAN(4, 13); break;
+                case 14: NPHIP_LAUNCH_LEAN(4, 14); break;
+                case 15: NPHIP_LAUNCH_LEAN(4, 15); break;
+                case 16: NPHIP_LAUNCH_LEAN(4, 16); break;
+                case 17: NPHIP_LAUNCH_LEAN(4, 17); break;
+                case 18: NPHIP_LAUNCH_LEAN(4, 18); break;
+                case 19: NPHIP_LAUNCH_LEAN(4, 19); break;
+                case 20: NPHIP_LAUNCH_LEAN(4, 20); break;
+                default: return hipErrorInvalidValue;
+            }
+            return hipGetLastError();
+        }
+        if (W != 8) return hipErrorInvalidValue;
+#endif
+        switch (a.reg_nv) {
+#ifndef NPHIP_DEV_LEAN   // (developer builds instantiate one kernel only: seconds instead of minutes)
+            case 1: NPHIP_LAUNCH_LEAN(8, 1); break;
+            case 2: NPHIP_LAUNCH_LEAN(8, 2); break;
+            case 3: NPHIP_LAUNCH_LEAN(8, 3); break;
+            case 4: NPHIP_LAUNCH_LEAN(8, 4); break;
+            case 5: NPHIP_LAUNCH_LEAN(8, 5); break;
+            case 6: NPHIP_LAUNCH_LEAN(8, 6); break;
+            case 7: NPHIP_LAUNCH_LEAN(8, 7); break;
+            case 8: NPHIP_LAUNCH_LEAN(8, 8); break;
+            case 9: NPHIP_LAUNCH_LEAN(8, 9); break;
+#endif
+#ifdef NPHIP_DEV_NC
+#ifndef NPHIP_DEV_W
+#define NPHIP_DEV_W 8
+#endif
+            case NPHIP_DEV_NC: NPHIP_LAUNCH_LEAN(NPHIP_DEV_W, NPHIP_DEV_NC); break;
+#else
+            case 10: NPHIP_LAUNCH_LEAN(8, 10); break;
+#endif
+            default: return hipErrorInvalidValue;
+        }
+#undef NPHIP_LAUNCH_LEAN
+        return hipGetLastError();
+    }
+#ifdef NPHIP_DEV_LEAN
+    return hipErrorInvalidValue;
+#else
     if (FUSED && (W == 2 || W == 4) && a.reg_nv > 0) {
         // register-resident, several waves per chain (1024 < D <= 4096, or fewer chains than SIMDs): one workgroup = one chain
         const dim3 g(n), b(64 * W);
@@ -1786,6 +2340,7 @@ static hipError_t launch_w(const Args& a, const Args* d_args, int W, hipStream_t
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
+#endif
 }
 
 hipError_t launch_advance(const Args& a, const Args* d_args, bool fused, int W, hipStream_t st) {

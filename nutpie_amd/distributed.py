@@ -88,6 +88,10 @@ def sample_sharded(make_sampler, num_chains: int, *, group=None, thin: int = 1, 
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     offset, n_local = shard_chains(num_chains, world, rank)
+    if n_local == 0:
+        # more ranks than chains: this rank owns nothing (n_local_chains = 0 would mean "all chains" to the engine); it still
+        # takes part in the gather with empty shards of the shapes rank 0 announces
+        return None, _gather_empty(group)
     sampler = make_sampler(offset, n_local)
     sampler.wait()
     T, D = sampler.total_draws, sampler.dim
@@ -113,5 +117,20 @@ def sample_sharded(make_sampler, num_chains: int, *, group=None, thin: int = 1, 
             if dims is not None:
                 d = d[:, :, torch.as_tensor(list(dims), device=d.device)]
             local["draws"] = d.contiguous()
+    if world > num_chains:   # some ranks are empty: tell them what is being gathered (names, trailing shapes, dtypes)
+        spec = [{k: (tuple(v.shape[1:]), str(v.dtype).replace("torch.", "")) for k, v in sorted(local.items())}] if rank == 0 else [None]
+        dist.broadcast_object_list(spec, src=0, group=group)
     gathered = gather_arrays(local, n_local, group=group)
     return sampler, gathered
+
+
+def _gather_empty(group=None):
+    import torch
+    import torch.distributed as dist
+
+    spec = [None]
+    dist.broadcast_object_list(spec, src=0, group=group)
+    on_gpu = dist.get_backend(group) == "nccl"
+    dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
+    local = {k: torch.empty((0, *shape), dtype=getattr(torch, dt), device=dev) for k, (shape, dt) in spec[0].items()}
+    return gather_arrays(local, 0, group=group)

@@ -52,6 +52,15 @@ class CompiledModel:
         """[chain, draw, n_dim] unconstrained positions -> dict of expanded variables."""
         raise NotImplementedError()
 
+    def _unflatten(self, flat: np.ndarray) -> dict[str, np.ndarray]:
+        """[chain, draw, expanded_dim] flat output of a C-ABI expand callback -> dict of variables (``shapes`` order, fp64)."""
+        out, start = {}, 0
+        for name, shape in self.shapes.items():
+            size = int(np.prod(shape, dtype=np.int64))
+            out[name] = flat[..., start:start + size].reshape(*flat.shape[:-1], *shape)
+            start += size
+        return out
+
     def benchmark_logp(self, point, num_evals, cores):
         raise NotImplementedError("benchmark_logp is not exposed (it is commented out in the reference binding too: src/pymc.rs:474-492)")
 
@@ -145,6 +154,9 @@ class _BackgroundSampler:
         if st.get("store_unconstrained", False) and results.draws is not None:
             stats["unconstrained_draw"] = results.draws
         expanded = getattr(results, "expanded", None)
+        if expanded is not None and "__flat__" in expanded:
+            # the expand step ran behind the C-ABI (nphip_sampler_copy_expanded): one flat fp64 block per draw
+            expanded = self._compiled_model._unflatten(expanded["__flat__"])
         if expanded is None:
             if results.draws is None:
                 raise RuntimeError("the sampler was run with store_draws=False; use return_raw_trace=True")
@@ -201,6 +213,44 @@ class _BackgroundSampler:
         return self._html
 
 
+# the two flags older releases of the reference accepted in place of `adaptation=` (reference sample.py:979-1013)
+_LEGACY_ADAPTATION_FLAGS = {"low_rank_modified_mass_matrix": "low_rank", "transform_adapt": "flow"}
+_ADAPTATIONS = ("diag", "draw_diag", "low_rank", "flow")
+
+
+def _legacy_adaptation(adaptation: str, kwargs: dict):
+    """Pops the deprecated keywords out of ``kwargs``; returns (adaptation, use_grad_based or None).  A set legacy flag
+    selects its adaptation (FutureWarning) unless ``adaptation`` was given too (ValueError)."""
+    for flag, implied in _LEGACY_ADAPTATION_FLAGS.items():
+        if not kwargs.pop(flag, False):
+            continue
+        warnings.warn(f"`{flag}` is deprecated. Use `adaptation='{implied}'` instead.", FutureWarning, stacklevel=3)
+        if adaptation != "diag":
+            raise ValueError(f"`{flag}` is deprecated and cannot be combined with the `adaptation` argument.")
+        adaptation = implied
+    grad_based = None
+    if "use_grad_based_mass_matrix" in kwargs:
+        grad_based = kwargs.pop("use_grad_based_mass_matrix")
+        warnings.warn("`use_grad_based_mass_matrix` is deprecated. Use `adaptation='draw_diag'` instead of "
+                      "`use_grad_based_mass_matrix=False`.", FutureWarning, stacklevel=3)
+    return adaptation, grad_based
+
+
+def _settings_for(sampler: str, adaptation: str, seed):
+    families = {"nuts": _lib.PyNutsSettings, "mclmc": _lib.PyMclmcSettings}
+    if sampler not in families:
+        raise ValueError(f"Unknown sampler '{sampler}'. Expected one of: 'nuts', 'mclmc'.")
+    if adaptation not in _ADAPTATIONS:
+        raise ValueError(f"Unknown adaptation strategy '{adaptation}'. Expected one of: 'diag', 'draw_diag', 'low_rank', 'flow'.")
+    constructor = {"low_rank": "LowRank", "flow": "Flow"}.get(adaptation, "Diag")
+    return getattr(families[sampler], constructor)(seed)
+
+
+def _host_cores() -> int:
+    counter = getattr(os, "process_cpu_count", os.cpu_count)  # process_cpu_count: Python >= 3.13
+    return counter() or 1
+
+
 def sample(
     compiled_model: CompiledModel,
     *,
@@ -239,58 +289,17 @@ def sample(
     depends on how many chains run with it; with fewer than ~256 chains and a fused model of D >= 512,
     ``waves_per_chain=4`` is about 20 % faster), ``store_draws``, ``device``.
     """
-    # Backward-compatible deprecated keyword arguments (reference sample.py:979-1013).
-    _use_grad_based = None
-    for _old_name, _new_adaptation in [("low_rank_modified_mass_matrix", "low_rank"), ("transform_adapt", "flow")]:
-        if _old_name in kwargs:
-            _val = kwargs.pop(_old_name)
-            if _val:
-                warnings.warn(f"`{_old_name}` is deprecated. Use `adaptation='{_new_adaptation}'` instead.", FutureWarning, stacklevel=2)
-                if adaptation == "diag":
-                    adaptation = _new_adaptation
-                else:
-                    raise ValueError(f"`{_old_name}` is deprecated and cannot be combined with the `adaptation` argument.")
-    if "use_grad_based_mass_matrix" in kwargs:
-        _use_grad_based = kwargs.pop("use_grad_based_mass_matrix")
-        warnings.warn(
-            "`use_grad_based_mass_matrix` is deprecated. Use `adaptation='draw_diag'` instead of `use_grad_based_mass_matrix=False`.",
-            FutureWarning, stacklevel=2,
-        )
-
-    if sampler == "nuts":
-        if adaptation == "low_rank":
-            settings = _lib.PyNutsSettings.LowRank(seed)
-        elif adaptation == "flow":
-            settings = _lib.PyNutsSettings.Flow(seed)
-        elif adaptation in ("diag", "draw_diag"):
-            settings = _lib.PyNutsSettings.Diag(seed)
-            if adaptation == "draw_diag" or _use_grad_based is False:
-                settings.use_grad_based_mass_matrix = False
-        else:
-            raise ValueError(f"Unknown adaptation strategy '{adaptation}'. Expected one of: 'diag', 'draw_diag', 'low_rank', 'flow'.")
-    elif sampler == "mclmc":
-        settings = _lib.PyMclmcSettings.Diag(seed)
-    else:
-        raise ValueError(f"Unknown sampler '{sampler}'. Expected one of: 'nuts', 'mclmc'.")
-
-    updates = dict(kwargs)
-    if tune is not None:
-        updates["num_tune"] = tune
-    if draws is not None:
-        updates["num_draws"] = draws
-    if chains is not None:
-        updates["num_chains"] = chains
-    settings.update(updates)
+    # behaviour (accepted keywords, warnings, error texts) documented at reference sample.py:979-1070; written independently
+    adaptation, grad_based = _legacy_adaptation(adaptation, kwargs)
+    settings = _settings_for(sampler, adaptation, seed)
+    if adaptation == "draw_diag" or grad_based is False:
+        settings.use_grad_based_mass_matrix = False
+    overrides = {"num_tune": tune, "num_draws": draws, "num_chains": chains}
+    settings.update({**kwargs, **{k: v for k, v in overrides.items() if v is not None}})
     if store_unconstrained:
         settings.store_unconstrained = True
-
     if cores is None:
-        try:
-            available = os.process_cpu_count()  # type: ignore[attr-defined]
-        except AttributeError:
-            available = os.cpu_count()
-        cores = available if chains is None else min(chains, available)
-
+        cores = _host_cores() if chains is None else min(chains, _host_cores())
     if init_mean is None:
         init_mean = np.zeros(compiled_model.n_dim)
 

@@ -88,6 +88,25 @@ def _pad_split(arr, n_tune_per_chain, finished, max_tune, max_post):
     return tune, post
 
 
+def _to_arviz(groups, dims, coords, attrs):
+    """ArviZ < 1.0 takes the groups as keyword arguments (InferenceData), >= 1.0 as one dict (DataTree); the reference
+    supports both and branches on the installed version (python/nutpie/sample.py:122-147)."""
+    from importlib.metadata import version
+
+    import arviz
+
+    major_minor = tuple(int(x) for x in version("arviz").split(".")[:2])
+    if major_minor >= (1, 0):
+        out = arviz.from_dict(groups, dims=dims, coords=coords)
+    else:
+        out = arviz.from_dict(**groups, dims=dims, coords=coords)
+    try:
+        out["sample_stats"].attrs.update(attrs)
+    except Exception:
+        pass
+    return out
+
+
 def build_trace(expanded, stats, finished, *, dims=None, coords=None, save_warmup=True, skip_vars=(),
                 reparameterized_names=None, keep_unconstrained_draw=False, attrs=None, use_arviz=None):
     """Assemble the output of ``nutpie.sample``.
@@ -126,10 +145,13 @@ def build_trace(expanded, stats, finished, *, dims=None, coords=None, save_warmu
 
     if use_arviz is None:
         use_arviz = find_spec("arviz") is not None
-    if use_arviz:  # pragma: no cover - arviz is absent in the build image
-        import arviz
+    if use_arviz:
+        try:
+            return _to_arviz(groups, dims, coords, attrs or {})
+        except Exception as e:  # the GPU job is done: never lose its trace to a conversion problem
+            import warnings
 
-        return arviz.from_dict(groups, dims=dims, coords=coords, attrs={"sample_stats": attrs or {}})
+            warnings.warn(f"conversion to an ArviZ object failed ({e!r}); returning the built-in DataTree", RuntimeWarning, stacklevel=2)
 
     stat_dims = {
         k: [f"unconstrained_parameter"] for k in ("gradient", "unconstrained_draw", "mass_matrix_inv", "divergence_start",

@@ -15,6 +15,7 @@ def run(dim, chains, noreg, W=0, E=256, steps=40, warm=40, nocache=False):
     import ctypes as C
     out=(C.c_int64*16)(); hip.lib().nphip_sampler_profile(smp._h, out); o=list(out)
     if o[3]: print(f"   cycles/leaf: total(hot) {o[1]/max(o[4],1):.0f} (n={o[4]}) = math {o[0]/o[3]:.0f} + reduce4 {o[6]/o[3]:.0f} + stores/issue {o[7]/max(o[4],1):.0f} + cascade(rest);  draw-end {o[2]/max(o[5],1):.0f} (n={o[5]})")
+    if o[3] and o[15]: print(f"   lean: sweep 1 (+ source reload, barrier) {o[15]/o[3]:.0f} of math {o[0]/o[3]:.0f}")
     if o[3]: print(f"   cascade per leaf: collector {o[8]/o[3]:.0f}  level0-check {o[9]/o[3]:.0f}  level>=1 checks {o[10]/o[3]:.0f}  merge scalar {o[11]/o[3]:.0f}")
     if o[5]: print(f"   draw end per draw: regrad {o[12]/o[5]:.0f}  adapt/position pass {o[13]/o[5]:.0f}  begin_draw (momentum, first leaf issue) {o[14]/o[5]:.0f}")
     smp.close()

@@ -51,6 +51,29 @@ int64_t eight_schools_logp(uint64_t dim, const double* x, double* grad, double* 
     return 0;
 }
 
+/* the same density behind a numba-style `int64` return whose upper half is NOT clean: the reference reads the return as
+ * `c_int` (src/pymc.rs:23-29), i.e. the low 32 bits — so must the engine */
+int64_t eight_schools_logp_dirty_high(uint64_t dim, const double* x, double* grad, double* logp, void* user) {
+    const int64_t rc = eight_schools_logp(dim, x, grad, logp, user);
+    return (int64_t)(((uint64_t)0x5eed0000u << 32) | (uint32_t)rc);
+}
+
+/* raw expand callback (src/pymc.rs:31-37 / compile_pymc.py:1018-1041): unconstrained draw -> (mu, tau, theta_tilde[8], theta[8]) */
+int eight_schools_expand(uint64_t dim, uint64_t expanded, const double* x, double* out, void* user) {
+    (void)user;
+    if (dim != 10) return -1;
+    if (expanded != 18) return -1;
+    const double mu = x[0], tau = exp(x[1]);
+    out[0] = mu;
+    out[1] = tau;
+    for (int j = 0; j < 8; ++j) { out[2 + j] = x[2 + j]; out[10 + j] = mu + tau * x[2 + j]; }
+    return 0;
+}
+int failing_expand(uint64_t dim, uint64_t expanded, const double* x, double* out, void* user) {
+    (void)dim; (void)expanded; (void)x; (void)out; (void)user;
+    return -2;
+}
+
 /* a callback that fails on demand: recoverable when x[0] > 3, fatal when x[0] > 1e6 (never reached) */
 int64_t failing_logp(uint64_t dim, const double* x, double* grad, double* logp, void* user) {
     (void)user;

@@ -62,3 +62,58 @@ def test_two_rank_sharding_and_gather(tmp_path, num_chains):
     assert got["total"][0] == full.stats["n_steps"].sum()
     np.testing.assert_allclose(got["draw_mean"], full.draws[:, 40:].mean(1), rtol=1e-12, atol=1e-14)
     np.testing.assert_allclose(got["draw_var"], full.draws[:, 40:].var(1, ddof=1), rtol=1e-10)
+
+
+class _OracleSampler:
+    """Stands in for PySampler in the CPU test of sample_sharded: the oracle's trace behind the same accessors."""
+
+    def __init__(self, trace, n_local, T, D):
+        self.tr, self.n, self.total_draws, self.dim = trace, n_local, T, D
+
+    def wait(self):
+        pass
+
+    def device_ptr(self, name):
+        return 1
+
+    def _copy(self, name, dtype, vec=False):
+        a = self.tr.draws if name == "draws" else self.tr.stats[name]
+        return np.ascontiguousarray(a).astype(dtype)
+
+
+def _sharded_worker(rank, world, port, num_chains, out_path):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+
+    import oracle
+    from nutpie_amd.distributed import sample_sharded
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        def make(offset, n_local):
+            assert n_local > 0, "ranks without chains must not create a sampler"
+            s = oracle.default_settings(seed=5, num_chains=n_local, chain_offset=offset, num_tune=20, num_draws=10)
+            return _OracleSampler(oracle.sample_tridiag(s, np.ones(4)), n_local, 30, 4)
+
+        smp, got = sample_sharded(make, num_chains, stats=("n_steps", "diverging"), moments_after=20)
+        assert (smp is None) == (rank >= num_chains)
+        if rank == 0:
+            np.savez(out_path, **{k: v.numpy() for k, v in got.items()})
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_more_ranks_than_chains(tmp_path):
+    """world_size 3, two chains: the third rank owns no chain, creates no sampler (n_local_chains = 0 would mean "all" to
+    the engine) and still takes part in the gather."""
+    import oracle
+
+    out = str(tmp_path / "g.npz")
+    mp.spawn(_sharded_worker, args=(3, _free_port(), 2, out), nprocs=3, join=True)
+    got = np.load(out)
+    full = oracle.sample_tridiag(oracle.default_settings(seed=5, num_chains=2, num_tune=20, num_draws=10), np.ones(4))
+    assert np.array_equal(got["draws"], full.draws) and np.array_equal(got["n_steps"], full.stats["n_steps"])
+    assert got["draw_mean"].shape == (2, 4)

@@ -2,6 +2,8 @@
 (tests/test_pymc.py, tests/test_stan.py) that do not depend on nuts-rs' RNG stream."""
 import time
 
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -150,6 +152,98 @@ def test_raw_callback_front_end(fixture_lib):
     mu = tr.posterior.theta.values[..., 0]
     assert 3.0 < mu.mean() < 6.0 and 2.0 < mu.std() < 5.0          # eight schools: mu ~ 4.4 +- 3.3
     assert tr.sample_stats.diverging.values.mean() < 0.05
+
+
+def test_raw_expand_callback_through_the_c_abi(hip, oracle, fixture_lib):
+    """The reference's ExpandFunc (src/pymc.rs:31-37, 64-95, 217-286) behind the C-ABI: a C expand callback evaluated by the
+    engine over the stored trace, rows of unfinished draws NaN; error codes surface as 'Expand function returned error code'."""
+    from tests.conftest import fn_addr
+
+    m = hip.HostCallbackModel(10, fn_addr(fixture_lib.eight_schools_logp), n_threads=2, keep_alive=fixture_lib)
+    m.set_init("normal")
+    m.set_expand(18, fn_addr(fixture_lib.eight_schools_expand))
+    assert m.expanded_dim == 18
+    s = hip.PyNutsSettings.Diag(11)
+    s.update(num_tune=50, num_draws=30, num_chains=5)
+    smp = hip.PySampler(s, m)
+    smp.wait()
+    ex = smp.expanded()
+    raw = smp._copy("draws", np.float64, vec=True)
+    assert ex.shape == (5, 80, 18)
+    assert np.array_equal(ex[..., 0], raw[..., 0]) and np.array_equal(ex[..., 1], np.exp(raw[..., 1]))
+    assert np.array_equal(ex[..., 10:], raw[..., :1] + np.exp(raw[..., 1:2]) * raw[..., 2:])
+    # "expanded" is also a name of the trace hand-off
+    again = np.empty_like(ex)
+    assert hip.lib().nphip_sampler_copy_stat(smp._h, b"expanded", again.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(again.nbytes)) == 0
+    assert np.array_equal(again, ex)
+    smp.close()
+    # a partial trace: unfinished rows are NaN
+    s.update(num_tune=3000, num_draws=3000)
+    smp = hip.PySampler(s, m, evals_per_launch=1)
+    import time
+
+    time.sleep(0.3)
+    smp.abort()
+    ex = smp.expanded()
+    fin = smp.inspect().finished
+    assert fin.max() < 6000
+    for c in range(5):
+        assert np.isfinite(ex[c, : fin[c]]).all() and np.isnan(ex[c, fin[c]:]).all()
+    smp.close()
+    # wrong sizes / failing callbacks
+    bad = hip.HostCallbackModel(10, fn_addr(fixture_lib.eight_schools_logp), n_threads=1)
+    bad.set_init("normal")
+    bad.set_expand(17, fn_addr(fixture_lib.eight_schools_expand))   # the callback checks `expanded` (compile_pymc.py:1026-1029)
+    s.update(num_tune=5, num_draws=5)
+    smp = hip.PySampler(s, bad)
+    smp.wait()
+    with pytest.raises(RuntimeError, match="Expand function returned error code -1"):
+        smp.expanded()
+    smp.close()
+
+
+def test_logp_return_is_read_as_c_int(hip, oracle, fixture_lib):
+    # numba declares the callback int64 (compile_pymc.py:975-981), the reference reads c_int (src/pymc.rs:23-29): a return
+    # register with a dirty upper half and a clean low word is "0 = ok" — identical trace to the clean function
+    from tests.conftest import assert_trace_equal, fn_addr
+    from tests.test_gpu_parity import oracle_settings, run_engine
+
+    got, W = run_engine(hip, hip.HostCallbackModel(10, fn_addr(fixture_lib.eight_schools_logp_dirty_high), n_threads=2), chains=6, tune=80, draws=30,
+                        seed=5, init="normal")
+    want = oracle.sample_callback(oracle_settings(oracle, chains=6, tune=80, draws=30, seed=5, W=W, init_kind=1), 10, fn_addr(fixture_lib.eight_schools_logp))
+    assert_trace_equal(got, want)
+
+
+def test_raw_callback_front_end_with_expand(fixture_lib):
+    # what a reference-compiled PyMC model carries — logp AND expand cfunc addresses — gives the expanded variables
+    from nutpie_amd.compile_pymc import from_raw_callback
+    from tests.conftest import fn_addr
+
+    m = from_raw_callback(10, fn_addr(fixture_lib.eight_schools_logp), n_threads=4, init="normal", keep_alive=fixture_lib,
+                          expand_address=fn_addr(fixture_lib.eight_schools_expand),
+                          expanded_shapes={"mu": (), "tau": (), "theta_tilde": (8,), "theta": (8,)}, dims={"theta": ("school",)},
+                          coords={"school": list("ABCDEFGH")})
+    tr = nutpie_amd.sample(m, chains=32, draws=100, tune=200, seed=4, progress_bar=False, store_unconstrained=True)
+    assert tr.posterior.theta.shape == (32, 100, 8) and tr.posterior.tau.shape == (32, 100)
+    assert (tr.posterior.tau.values > 0).all()
+    assert np.allclose(tr.posterior.theta.values, tr.posterior.mu.values[..., None] + tr.posterior.tau.values[..., None] * tr.posterior.theta_tilde.values)
+    assert 2.0 < tr.posterior.mu.values.mean() < 7.0
+
+
+def test_python_callable_errors_keep_their_traceback(hip):
+    # ADVICE r1: the user's exception is chained, not swallowed into "fatal error"
+    import nutpie_amd
+
+    def make_logp():
+        def f(x):
+            return 0.0, np.zeros(3, dtype=np.float32)   # wrong dtype: ReturnTypeError of src/pyfunc.rs
+
+        return f
+
+    m = nutpie_amd.from_pyfunc(3, make_logp, lambda *a: (lambda x: {"y": x}), [np.float64], [(3,)], ["y"])
+    with pytest.raises(RuntimeError, match="Return type of logp function") as e:
+        nutpie_amd.sample(m, chains=2, tune=5, draws=5, progress_bar=False)
+    assert isinstance(e.value.__cause__, TypeError)
 
 
 def test_radon_torch_model_config3():

@@ -121,7 +121,12 @@ def test_engine_matches_committed_golden_vectors(hip, name):
 @pytest.mark.parametrize("dim,waves", [(1, 1), (2, 1), (127, 1), (128, 1), (129, 2), (1000, 1), (1000, 4), (2500, 2), (5003, 8), (9000, 16),
                                        # register-resident kernels with several waves per chain
                                        (1100, 2), (1500, 2), (2048, 2), (2500, 4), (3300, 4), (4096, 4),
-                                       (256, 2), (700, 2), (1000, 2), (512, 4), (900, 4), (1536, 4)])
+                                       (256, 2), (700, 2), (1000, 2), (512, 4), (900, 4), (1536, 4),
+                                       # lean register-resident kernels (8 waves per chain, 1..10 chunks per wave); (10000, 8) is
+                                       # the default geometry of BASELINE.json config 5
+                                       (900, 8), (2000, 8), (4200, 8), (6000, 8), (7100, 8), (8192, 8), (10000, 8), (10240, 8),
+                                       # lean kernels with 4 waves per chain (state in VGPRs + AGPRs), 9..20 chunks per wave
+                                       (4200, 4), (5000, 4), (7100, 4), (9000, 4), (10000, 4), (10240, 4)])
 def test_correlated_gaussian_all_geometries(hip, oracle, dim, waves):
     rng = np.random.default_rng(dim)
     sd = np.exp(0.7 * rng.normal(size=dim))
@@ -199,6 +204,40 @@ def test_settings_variants_bit_identical(hip, oracle, settings):
         assert got.stats["diverging"].sum() > 20
     if settings.get("maxdepth") == 2:
         assert got.stats["maxdepth_reached"].sum() > 0 and got.stats["depth"].max() == 2
+
+
+@pytest.mark.parametrize("dim,settings,launch", [
+    (5000, dict(max_energy_error=0.5), {}),                              # divergences end draws from inside leaf_lean
+    (5000, dict(maxdepth=3), dict(evals_per_launch=5)),                  # flush / reload of the registers at launch ends
+    (6100, dict(maxdepth=4), dict(evals_per_launch=3)),                  # (a launch boundary between a leaf = 3 mod 4 and the next)
+    (9000, dict(step_size_jitter=0.2, mindepth=2), dict(evals_per_launch=13)),
+    (4500, dict(use_grad_based_mass_matrix=False, store_gradient=True), {}),
+    (4500, dict(check_turning=False, maxdepth=4), {}),
+    (7000, dict(maxdepth=12, target_accept=0.95), {}),                   # deep trees: merges up to level >= 5
+])
+def test_lean_register_kernels_variants(hip, oracle, dim, settings, launch):
+    # lean register-resident kernels (8 waves per chain, 4096 < D <= 10240) under the awkward settings
+    model = ar1_gaussian(dim)
+    kw = dict(chains=3, tune=50, draws=12, seed=dim + 3)
+    got, W = run_engine(hip, hip.TridiagGaussianModel(model.diag, model.offdiag), launch=launch, **kw, **settings)
+    assert W == 8
+    want = oracle.sample_tridiag(oracle_settings(oracle, W=W, **kw, **settings), model.diag, model.offdiag)
+    assert_trace_equal(got, want)
+    if "store_gradient" in settings:
+        assert np.array_equal(got.stats["gradient"], want.stats["gradient"])
+
+
+def test_lean_kernel_equals_streaming_kernel(hip):
+    # same chains through the lean register kernel and through the memory-resident kernel of the same geometry (W = 8)
+    model = ar1_gaussian(10000)
+    kw = dict(chains=6, tune=40, draws=10, seed=77)
+    m = hip.TridiagGaussianModel(model.diag, model.offdiag)
+    a, W = run_engine(hip, m, **kw)
+    b, _ = run_engine(hip, m, launch=dict(no_register_kernel=True), **kw)
+    assert W == 8
+    assert np.array_equal(a.draws, b.draws)
+    for k in ("depth", "n_steps", "index_in_trajectory", "energy", "step_size", "mean_tree_accept"):
+        assert np.array_equal(a.stats[k], b.stats[k]), k
 
 
 @pytest.mark.parametrize("dim,settings,launch", [
@@ -411,3 +450,20 @@ def test_large_dimension_shapes_properties(hip, dim, chains):
     acc = a.stats["mean_tree_accept"][:, 120:].mean()
     assert 0.7 < acc < 0.95                                   # dual averaging reached the 0.8 target
     assert np.abs(a.stats["energy_error"][:, 120:]).max() < 50
+
+
+def test_config5_full_size_properties(hip):
+    """BASELINE.json config 5 on one GPU at full width: 1024 chains x D = 10 000 (the lean register kernel, one chain per CU),
+    short run: every chain finishes, chains do not depend on the batch (the first four equal a 4-chain job bit for bit),
+    dual averaging reaches its target, energy errors stay O(1)."""
+    m = ar1_gaussian(10000)
+    kw = dict(tune=40, draws=10, seed=10000)
+    a, W = run_engine(hip, hip.TridiagGaussianModel(m.diag, m.offdiag), chains=1024, **kw)
+    assert W == 8 and a.finished.min() == 50
+    b, _ = run_engine(hip, hip.TridiagGaussianModel(m.diag, m.offdiag), chains=4, **kw)
+    assert np.array_equal(a.draws[:4], b.draws) and np.array_equal(a.stats["n_steps"][:4], b.stats["n_steps"])
+    assert a.stats["diverging"][:, 30:].mean() < 0.05
+    acc = a.stats["mean_tree_accept"][:, 30:].mean()
+    assert 0.6 < acc < 0.97
+    assert np.abs(a.stats["energy_error"][:, 30:]).max() < 50
+

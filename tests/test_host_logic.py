@@ -114,7 +114,7 @@ def test_from_pyfunc_contract():
     with pytest.raises(ValueError, match="Unknown data variable"):                   # compiled_pyfunc.py:39-46
         m.with_data(nope=1)
     m2 = m.with_data(scale=4.0)
-    assert m2._shared_data["scale"] == 4.0 and m._shared_data["scale"] == 2.0
+    assert m2.data["scale"] == 4.0 and m.data["scale"] == 2.0
     ex = m._expand_draws(np.arange(12.0).reshape(2, 2, 3))
     assert ex["y"].shape == (2, 2, 3) and ex["ysum"].shape == (2, 2) and ex["ysum"][1, 1] == 9 + 10 + 11
     bad = nutpie_amd.from_pyfunc(3, make_logp, lambda *a: (lambda x: {"y": x.astype(np.float32)}), [np.float64], [(3,)], ["y"])
@@ -178,3 +178,92 @@ def test_autograd_logp_wrapper():
     m = from_torch_density(3, lambda x, s: -0.5 * ((x / s) ** 2).sum(-1), shared_data={"s": scale})
     lp2, g2 = m._make_logp_func()(x, **m._shared_data)
     assert torch.equal(lp2, lp) and torch.equal(g2, g) and m.n_dim == 3
+
+
+def test_arviz_conversion_follows_the_installed_version(monkeypatch):
+    """arviz < 1.0 takes the groups as keywords, >= 1.0 as one dict (reference sample.py:122-147); a failing
+    conversion must not lose the trace."""
+    import importlib.metadata
+    import sys
+    import types
+
+    from nutpie_amd import trace as T
+
+    calls = {}
+    stub = types.ModuleType("arviz")
+
+    def from_dict(*args, **kw):
+        calls["args"], calls["kw"] = args, kw
+
+        class Out(dict):
+            pass
+
+        o = Out()
+        o["sample_stats"] = types.SimpleNamespace(attrs={})
+        return o
+
+    stub.from_dict = from_dict
+    monkeypatch.setitem(sys.modules, "arviz", stub)
+    real_version = importlib.metadata.version
+    stats = {"tuning": np.array([[True, False, False]]), "depth": np.array([[1, 2, 3]])}
+    ex = {"x": np.arange(3.0).reshape(1, 3, 1)}
+    for ver, as_kwargs in (("0.23.4", True), ("1.0.0", False), ("1.2", False)):
+        monkeypatch.setattr(importlib.metadata, "version", lambda name, v=ver: v if name == "arviz" else real_version(name))
+        out = T.build_trace(ex, stats, np.array([3]), use_arviz=True, attrs={"inference_library": "nutpie"})
+        assert out["sample_stats"].attrs["inference_library"] == "nutpie"
+        if as_kwargs:
+            assert calls["args"] == () and {"posterior", "sample_stats", "dims", "coords"} <= set(calls["kw"])
+        else:
+            assert len(calls["args"]) == 1 and set(calls["args"][0]) >= {"posterior", "sample_stats"} and "posterior" not in calls["kw"]
+    # a conversion that raises falls back to the built-in container (with a warning) instead of losing the trace
+    stub.from_dict = lambda *a, **k: (_ for _ in ()).throw(TypeError("boom"))
+    with pytest.warns(RuntimeWarning, match="conversion to an ArviZ object failed"):
+        out = T.build_trace(ex, stats, np.array([3]), use_arviz=True)
+    assert out.posterior.x.shape == (1, 2, 1)
+
+
+def test_stan_expand_passes_an_rng(monkeypatch, tmp_path):
+    """BridgeStan >= 2 refuses include_gq=True without an rng; the reference passes model.new_rng(seed)
+    (src/stan.rs:476-492).  A stub bridgestan with that behaviour around a 2-parameter model."""
+    import sys
+    import types
+
+    bs = types.ModuleType("bridgestan")
+    made = {"models": 0}
+
+    class StanModel:
+        def __init__(self, lib, data=None, seed=0):
+            made["models"] += 1
+
+        def param_unc_num(self):
+            return 2
+
+        def param_num(self, include_tp=False, include_gq=False):
+            return 2 + (1 if include_tp else 0) + (2 if include_gq else 0)
+
+        def param_names(self, include_tp=False, include_gq=False):
+            return ["a", "b"] + (["t"] if include_tp else []) + (["g.1", "g.2"] if include_gq else [])
+
+        def new_rng(self, seed):
+            return ("rng", seed)
+
+        def param_constrain(self, theta, include_tp=False, include_gq=False, out=None, rng=None):
+            if include_gq and rng is None:
+                raise ValueError("Error: must provide rng if including generated quantities")
+            r = np.array([theta[0], np.exp(theta[1]), theta[0] + 1, rng[1], -rng[1]], dtype=float)
+            if out is not None:
+                out[:] = r
+                return out
+            return r
+
+    bs.StanModel = StanModel
+    monkeypatch.setitem(sys.modules, "bridgestan", bs)
+    from nutpie_amd.compile_stan import CompiledStanModel
+
+    m = CompiledStanModel(dims={}, code="", data=None, library="x.so", model=None, _coords={})
+    assert m.n_dim == 2 and m.shapes == {"a": (), "b": (), "t": (), "g": (2,)} and m.n_dim == 2
+    assert made["models"] == 1                     # bound once, not per property access
+    draws = np.array([[[0.5, 0.0], [np.nan, np.nan]], [[1.0, 1.0], [2.0, 0.0]]])
+    ex = m._expand_draws(draws, seed=7)
+    assert ex["b"][0, 0] == 1.0 and np.isnan(ex["a"][0, 1]) and ex["t"][1, 1] == 3.0
+    assert ex["g"][0, 0].tolist() == [7, -7] and ex["g"][1, 0].tolist() == [8, -8]      # one rng per chain, from the seed
