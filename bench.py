@@ -4,9 +4,11 @@
 Contract (driver): ``python bench.py --gpus N --steps K --warmup W`` — for N>1 launched by
 ``torch.distributed.run`` with one rank per GPU.  A *step* is one pass of the hot path over the whole
 batch of chains: one launch of the fused leapfrog/tree kernel that advances every chain of this GPU
-by ``evals_per_launch`` leapfrogs (one logp+gradient evaluation each).  W untimed steps, then EXACTLY
-K timed steps bracketed by barrier + synchronize on both sides; time = max over ranks; rank 0 prints
-ONE JSON line.
+by ``evals_per_launch`` leapfrogs (one logp+gradient evaluation each).  Set-up (untimed): inputs to HBM
+and the chains' whole warm-up (tune = 400), so that the timed region lies in the SAMPLING phase with
+positions stored (``--phase tuning`` times inside warm-up instead, as round 1 did).  Then W untimed
+steps, then EXACTLY K timed steps bracketed by barrier + synchronize on both sides; time = max over
+ranks; rank 0 prints ONE JSON line.  With no ``--steps`` K is sized for a timed region of ~1.2 s.
 
 Workload (``config.workload``): BASELINE.json configs[1] — 1000-dimensional correlated Gaussian
 (AR(1) rho = 0.9 with per-dimension scales exp(N(0,1)) from numpy.random.default_rng(20260926),
@@ -20,7 +22,10 @@ Extra objects in the JSON line:
                   SURVEY.md §8d, fused analytic gradient) / mean k_advance duration from HIP events on the
                   engine's stream, against the 8 TB/s HBM peak.
   cpu_baseline  — the CPU oracle (oracle/, "port": the real nuts-rs cannot be built here) timed on this
-                  box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
+                  box's host cores on a bounded sample of the same workload (rank 0, N=1 only);
+  cpu_baseline_tuned — the same C++ sampler built for speed (AVX2 + FMA, free summation order): the honest
+                  CPU number; the port is bit-reproducible scalar code.
+  tuning_phase  — leapfrogs and kernel-time rate of the (untimed) warm-up that precedes the timed region.
   job           — the complete sampling job (tune 400 + draws 1000) wall time, total leapfrogs, min bulk
                   ESS over a subset of dimensions and ESS/s (the second half of BASELINE.json's metric).
 """
@@ -38,24 +43,27 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
-# HBM bytes per leapfrog of the register-resident kernel at D = 1000, from the PMC passes in profiles/r1_v4_pmc.txt:
-# (2 x FETCH_SIZE + WRITE_SIZE) KB per launch / 262144 leapfrogs  (gfx950 FETCH_SIZE correction, MI355X_MICROARCH.md)
-MEASURED_HBM_BYTES_PER_LEAPFROG_D1000 = 21499.0
+# measured HBM bytes per leapfrog per kernel / dimension: profiles/traffic.json, written by profiles/make_traffic.py from the
+# committed rocprofv3 PMC summaries ((2 x FETCH_SIZE + WRITE_SIZE) KB per launch / leapfrogs per launch; gfx950 FETCH_SIZE
+# correction of MI355X_MICROARCH.md)
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "traffic.json")
 
 
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=60)
-    p.add_argument("--warmup", type=int, default=60)
+    p.add_argument("--steps", type=int, default=0, help="timed launches; 0 = enough for a timed region of about 1.2 s")
+    p.add_argument("--warmup", type=int, default=30)
     p.add_argument("--dim", type=int, default=1000)
     p.add_argument("--chains", type=int, default=1024, help="chains PER GPU")
-    p.add_argument("--evals-per-launch", type=int, default=256)
+    p.add_argument("--evals-per-launch", type=int, default=0, help="leapfrogs per chain per launch; 0 = 256 (D <= 2048) or 32")
     p.add_argument("--waves", type=int, default=0)
     p.add_argument("--seed", type=int, default=20260926)
+    p.add_argument("--phase", choices=("sampling", "tuning"), default="sampling",
+                   help="where the timed region lies: after warm-up (default; positions are stored) or inside it")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-job", action="store_true")
-    p.add_argument("--cpu-seconds", type=float, default=15.0)
+    p.add_argument("--cpu-seconds", type=float, default=12.0)
     return p.parse_args()
 
 
@@ -96,7 +104,21 @@ def cpu_baseline(model, seed, target_seconds):
     s = oracle.default_settings(seed=seed, num_chains=chains, num_tune=tune, num_draws=draws, n_threads=cores)
     tr = oracle.sample_tridiag(s, model.diag, model.offdiag)
     n = int(tr.stats["n_steps"].sum())
-    return {
+    tuned = None
+    try:
+        chains_t = int(min(1024, max(cores, chains * 4 // cores * cores)))
+        st = oracle.default_settings(seed=seed, num_chains=chains_t, num_tune=tune, num_draws=draws, n_threads=cores)
+        tt = oracle.sample_tridiag_tuned(st, model.diag, model.offdiag)
+        nt = int(tt.stats["n_steps"].sum())
+        tuned = {
+            "value": nt / tt.seconds, "unit": "leapfrog steps/s", "cores": cores, "kind": "tuned",
+            "sample": f"the same C++ sampler built for speed (oracle/Makefile TUNEDFLAGS: AVX2 + FMA, free summation order, fused "
+                      f"passes — rounding differs from the contract, never used as a checker), {chains_t} chains, tune {tune} + draws "
+                      f"{draws}, {cores} threads: {nt} leapfrogs in {tt.seconds:.2f} s",
+        }
+    except Exception as e:  # the tuned build is optional evidence
+        tuned = {"error": repr(e)}
+    return tuned, {
         "value": n / tr.seconds, "unit": "leapfrog steps/s", "cores": cores, "kind": "port",
         "sample": f"CPU oracle (C++ restatement of nuts-rs diag-NUTS, oracle/), {chains} of the workload's chains, "
                   f"tune {tune} + draws {draws}, one chain per thread on {cores} threads (host: {os.cpu_count()} logical CPUs, "
@@ -142,6 +164,27 @@ def run_job(hip, model, args, device, chain_offset, dims_for_ess):
     }
 
 
+def measured_traffic(dim, W, lean):
+    """HBM bytes per leapfrog of the kernel that runs at this (dim, waves) from the committed PMC summaries, or None."""
+    try:
+        table = json.load(open(TRAFFIC_JSON))
+    except OSError:
+        return None, None
+    e = table.get(f"{dim}:{W}")
+    return (e["bytes_per_leapfrog"], e["source"]) if e else (None, None)
+
+
+def kernel_name(dim, W):
+    nch = (dim + 127) // 128
+    if W == 1 and nch <= 8:
+        return f"k_advance<fused,W=1,NV={nch}>"
+    if W in (2, 4) and (nch + W - 1) // W <= 8:
+        return f"k_advance<fused,W={W},NV={(nch + W - 1) // W}>"
+    if (W == 4 and (nch + 3) // 4 <= 20) or (W == 8 and (nch + 7) // 8 <= 10):
+        return f"k_advance<fused,W={W},NV={(nch + W - 1) // W},lean>"
+    return f"k_advance<fused,W={W},NV=0>"
+
+
 def main():
     args = parse()
     import torch
@@ -165,14 +208,19 @@ def main():
 
     hip.lib()
     model = ar1_gaussian(args.dim)
+    E = args.evals_per_launch or (256 if args.dim <= 2048 else 32)
+    # default number of timed launches: about 1.2 s of kernel time (178 M leapfrogs/s at D = 1000 scales like 1 / D)
+    K = args.steps or max(20, int(1.2 * 1.7e11 / args.dim / (args.chains * E)))
+    num_tune = 400
+    # Draws to allocate: the timed region must end before any chain runs out of draws.  After warm-up a draw of these targets
+    # takes ~200 (D = 1000) to ~500 (D = 10 000) leapfrogs; 1 / 64 of the leapfrogs is a 3x margin, checked below.
+    n_draws = max(64, (args.warmup + K + 2) * E // 64) if args.phase == "sampling" else (args.warmup + K + 2) * E
     s = hip.PyNutsSettings.Diag(args.seed)
-    # enough draws that no chain can finish inside the timed region (>= 1 leapfrog per draw); positions are
-    # not stored for this leg, the per-draw statistics are (13 small arrays)
-    n_draws = (args.warmup + args.steps + 2) * args.evals_per_launch
-    s.update(num_tune=400, num_draws=n_draws, num_chains=args.chains * world)
+    s.update(num_tune=num_tune, num_draws=n_draws, num_chains=args.chains * world)
     m = hip.TridiagGaussianModel(model.diag, model.offdiag)
+    store = args.phase == "sampling"
     smp = hip.PySampler(s, m, device=device, waves_per_chain=args.waves, chain_offset=rank * args.chains, n_local_chains=args.chains,
-                        store_draws=False, evals_per_launch=args.evals_per_launch, manual=True)
+                        store_draws=store, evals_per_launch=E, manual=True)
     W = smp.waves_per_chain
 
     def barrier():
@@ -181,18 +229,40 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # ---- set-up, untimed: the whole warm-up (tune = 400 draws per chain); its rate is reported as `tuning_phase`
+    tuning_phase = None
+    if args.phase == "sampling":
+        t0 = time.perf_counter()
+        n0 = total_leapfrogs(smp)
+        launches = 0
+        kms = 0.0
+        while True:
+            done, l, ms = smp.step(50)
+            launches += l
+            kms += ms
+            if done:
+                raise SystemExit("bench.py: chains finished during warm-up; increase the number of draws")
+            if not any(p.tuning for p in smp.progress()):
+                break
+        torch.cuda.synchronize()
+        n1 = total_leapfrogs(smp)
+        tuning_phase = {"leapfrogs": int(n1 - n0), "launches": launches, "wall_s": time.perf_counter() - t0,
+                        "leapfrogs_per_s_kernel_time": (n1 - n0) / (kms / 1e3), "note": "all chains through tune = 400 draws (untimed set-up of the "
+                        "bench; includes initial points, step-size search, mass-matrix adaptation; wall time includes progress polling)"}
     smp.step(args.warmup)
     barrier()
     n0 = total_leapfrogs(smp)
     tuning0 = sum(p.tuning for p in smp.progress())
     barrier()
     t0 = time.perf_counter()
-    done, launches, kernel_ms = smp.step(args.steps)
+    done, launches, kernel_ms = smp.step(K)
     barrier()
     t1 = time.perf_counter()
     n1 = total_leapfrogs(smp)
-    tuning1 = sum(p.tuning for p in smp.progress())
-    assert launches == args.steps and not done
+    prog = smp.progress()
+    tuning1 = sum(p.tuning for p in prog)
+    if launches != K or done or max(p.finished_draws for p in prog) >= num_tune + n_draws:
+        raise SystemExit("bench.py: a chain ran out of draws inside the timed region — the measurement is invalid; use fewer --steps")
     elapsed = t1 - t0
     leap = float(n1 - n0)
     if dist is not None:
@@ -203,32 +273,42 @@ def main():
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         leap, kernel_ms_sum = float(c[0].item()), float(c[1].item())
         kernel_ms = kernel_ms_sum / world
+    draws_stored = int(sum(p.finished_draws for p in prog)) if store else 0
     smp.close()
 
     bytes_per_leapfrog = 40.0 * args.dim
-    avg_kernel_s = kernel_ms / 1000.0 / args.steps
-    leap_per_launch = leap / world / args.steps
+    avg_kernel_s = kernel_ms / 1000.0 / K
+    leap_per_launch = leap / world / K
     achieved = bytes_per_leapfrog * leap_per_launch / avg_kernel_s / 1e9
+    traffic_bpl, traffic_src = measured_traffic(args.dim, W, None)
     out = {
         "metric": "leapfrog steps/sec (all chains)", "value": leap / elapsed, "unit": "leapfrog steps/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True,
+        "steps": K, "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / K, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{args.dim}-dim correlated Gaussian (AR(1) rho=0.9, analytic logp/grad fused), {args.chains} chains per GPU "
-                               f"(BASELINE.json configs[1])", "dim": args.dim, "chains_per_gpu": args.chains, "waves_per_chain": W,
-                   "evals_per_launch": args.evals_per_launch, "leapfrogs_per_step": leap / args.steps,
+                               f"(BASELINE.json configs[{1 if args.dim == 1000 else 4}])", "dim": args.dim, "chains_per_gpu": args.chains, "waves_per_chain": W,
+                   "evals_per_launch": E, "leapfrogs_per_step": leap / K, "phase": args.phase, "positions_stored": store,
+                   "draws_finished_all_chains": draws_stored, "timed_region_s": elapsed,
                    "chains_tuning_at_start": int(tuning0), "chains_tuning_at_end": int(tuning1), "parallelism": f"chains{world}"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": (MEASURED_HBM_BYTES_PER_LEAPFROG_D1000 * leap_per_launch if (args.dim == 1000 and W == 1) else None),
-                     "traffic_source": "rocprofv3 PMC FETCH_SIZE/WRITE_SIZE passes, profiles/r1_v4_pmc.txt (bytes per launch)",
-                     "kernel": "k_advance<fused,W=1,NV=8>", "avg_kernel_ms": 1000.0 * avg_kernel_s,
+                     "traffic": (traffic_bpl * leap_per_launch if traffic_bpl else None),
+                     "traffic_source": traffic_src, "traffic_bytes_per_leapfrog": traffic_bpl,
+                     "kernel": kernel_name(args.dim, W), "avg_kernel_ms": 1000.0 * avg_kernel_s,
                      "algorithmic_bytes_per_leapfrog": bytes_per_leapfrog},
     }
-    if rank == 0 and world == 1 and not args.no_job:
+    if tuning_phase is not None:
+        out["tuning_phase"] = tuning_phase
+    if rank == 0 and world == 1 and not args.no_job and args.dim <= 2048:
         dims = sorted(set(np.linspace(0, args.dim - 1, 12).astype(int).tolist() + [int(np.argmax(model.diag)), int(np.argmin(model.diag))]))
         out["job"] = run_job(hip, model, args, device, 0, dims)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(model, args.seed, args.cpu_seconds)
-        out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        tuned, port = cpu_baseline(model, args.seed, args.cpu_seconds)
+        out["cpu_baseline"] = port
+        out["gpu_over_cpu"] = out["value"] / port["value"]
+        if tuned:
+            out["cpu_baseline_tuned"] = tuned
+            if "value" in tuned:
+                out["gpu_over_cpu_tuned"] = out["value"] / tuned["value"]
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

@@ -510,8 +510,11 @@ struct nphip_sampler {
 static int choose_waves(uint64_t dim) {
     if (dim <= 1024) return 1;
     if (dim <= 2048) return 2;
-    if (dim <= 4096) return 4;
-    return 8;  // measured at D = 10 000: W = 8 (5.5 M leapfrogs/s) beats 4 (5.0) and 16 (3.6)
+    // 2048 < D <= 4096: register kernels with the LDS ring; 4096 < D <= 10240: lean register kernels, state in VGPRs + AGPRs.
+    // Measured (profiles/r2_grid_b_lean_w8_vs_w4.txt, 1024 chains): 4 waves per chain beat 8 from D = 7000 up (10.2 vs 6.9 M
+    // leapfrogs/s at D = 10 000: at 8 waves the 256-VGPR budget spills the state) and tie below.
+    if (dim <= 10240) return 4;
+    return 8;  // memory-resident kernels; measured at D = 10 000: W = 8 (5.5 M leapfrogs/s) beats 4 (5.0) and 16 (3.6)
 }
 
 bool nphip_sampler::setup() {

@@ -17,6 +17,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libnuts_oracle.so")
+_TUNED_PATH = os.path.join(_HERE, "libnuts_oracle_tuned.so")
 
 LOGP_FN = C.CFUNCTYPE(C.c_int64, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p)
 
@@ -88,8 +89,31 @@ def build(force: bool = False) -> str:
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(
         os.path.getmtime(os.path.join(_HERE, f)) for f in ("nuts_oracle.cpp", "nuts_oracle.h", "Makefile")
     ):
-        subprocess.run(["make", "-C", _HERE, "-B", "libnuts_oracle.so"], check=True, capture_output=True)
+        subprocess.run(["make", "-C", _HERE, "-B", "libnuts_oracle.so", "libnuts_oracle_tuned.so"], check=True, capture_output=True)
     return _LIB_PATH
+
+
+_tuned = None
+
+
+def sample_tridiag_tuned(settings: "Settings", diag, offdiag=None):
+    """The "tuned" CPU build (free summation order, fused AVX2 passes): ONLY a speed baseline for bench.py — its floats are not
+    the contract's, it is never used as a checker.  Returns (total leapfrogs, seconds)."""
+    global _tuned
+    if _tuned is None:
+        if not os.path.exists(_TUNED_PATH):
+            build(force=True)
+        _tuned = C.CDLL(_TUNED_PATH)
+        _tuned.oracle_last_error.restype = C.c_char_p
+    diag = np.ascontiguousarray(np.asarray(diag, dtype=np.float64))
+    dim = diag.shape[0]
+    offdiag = _vec(offdiag, max(dim - 1, 0)) if offdiag is not None and dim > 1 else None
+    draws, st, tr = _alloc(settings, dim)
+    secs = C.c_double(0)
+    rc = _tuned.oracle_sample_tridiag(C.byref(settings), C.c_uint64(dim), None, _p(diag), _p(offdiag), None, C.byref(tr), C.byref(secs))
+    if rc != 0:
+        raise RuntimeError(_tuned.oracle_last_error().decode())
+    return Trace(draws, st, secs.value)
 
 
 def lib():

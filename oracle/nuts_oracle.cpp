@@ -241,7 +241,16 @@ double det_reduce(size_t n, Geometry geo, F term_fma /* (i, acc) -> fma(x_i, y_i
 }
 
 double det_dot(const double* x, const double* y, size_t n, Geometry geo) {
+#ifdef ORACLE_TUNED
+    // "tuned" build (libnuts_oracle_tuned.so, bench.py's second cpu_baseline): free summation order, vectorised
+    (void)geo;
+    double acc = 0.0;
+#pragma omp simd reduction(+ : acc)
+    for (size_t i = 0; i < n; ++i) acc += x[i] * y[i];
+    return acc;
+#else
     return det_reduce(n, geo, [&](size_t i, double a) { return std::fma(x[i], y[i], a); });
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -263,6 +272,29 @@ struct TridiagModel : Model {
     std::vector<double> z;
     int64_t logp(const double* q, double* grad, double* logp_out) override {
         z.resize(dim);
+#ifdef ORACLE_TUNED
+        {   // one vectorised pass: gradient and logp together
+            const size_t n = dim;
+            double* zz = z.data();
+            const double *mm = mu.data(), *aa = a.data(), *bb = b.data();
+#pragma omp simd
+            for (size_t i = 0; i < n; ++i) zz[i] = q[i] - mm[i];
+            double acc = 0.0;
+            if (n == 1) { grad[0] = -(aa[0] * zz[0]); *logp_out = 0.5 * zz[0] * grad[0]; return 0; }
+            grad[0] = -(aa[0] * zz[0] + bb[0] * zz[1]);
+            acc = zz[0] * grad[0];
+#pragma omp simd reduction(+ : acc)
+            for (size_t i = 1; i < n - 1; ++i) {
+                const double t = aa[i] * zz[i] + bb[i - 1] * zz[i - 1] + bb[i] * zz[i + 1];
+                grad[i] = -t;
+                acc -= zz[i] * t;
+            }
+            grad[n - 1] = -(aa[n - 1] * zz[n - 1] + bb[n - 2] * zz[n - 2]);
+            acc += zz[n - 1] * grad[n - 1];
+            *logp_out = 0.5 * acc;
+            return 0;
+        }
+#endif
         for (size_t i = 0; i < dim; ++i) z[i] = q[i] - mu[i];
         for (size_t i = 0; i < dim; ++i) {
             double t = a[i] * z[i];
@@ -362,9 +394,22 @@ struct Hamiltonian {
         StateP o = pl.get();
         const double eps = (double)sign * step_size;
         const double h = 0.5 * eps;
+#ifdef ORACLE_TUNED
+        {
+            double *op = o->p.data(), *oq = o->q.data();
+            const double *sg = s.g.data(), *sp = s.p.data(), *sq = s.q.data(), *s2 = sig2.data();
+#pragma omp simd
+            for (size_t i = 0; i < n; ++i) {
+                const double ph = sp[i] + h * sg[i];
+                op[i] = ph;
+                oq[i] = sq[i] + eps * (s2[i] * ph);
+            }
+        }
+#else
         for (size_t i = 0; i < n; ++i) o->p[i] = std::fma(h, s.g[i], s.p[i]);
         for (size_t i = 0; i < n; ++i) o->v[i] = sig2[i] * o->p[i];
         for (size_t i = 0; i < n; ++i) o->q[i] = std::fma(eps, o->v[i], s.q[i]);
+#endif
         double lp = 0.0;
         int64_t code = model->logp(o->q.data(), o->g.data(), &lp);
         o->idx = s.idx + sign;
@@ -378,6 +423,24 @@ struct Hamiltonian {
             return Leap::Diverge;
         }
         o->U = -lp;
+#ifdef ORACLE_TUNED
+        {
+            double *op = o->p.data(), *ov = o->v.data(), *ops = o->psum.data();
+            const double *og = o->g.data(), *s2 = sig2.data(), *sps = s.psum.data();
+            const double keep = (o->idx == -1) ? 0.0 : 1.0;
+            double kk = 0.0;
+#pragma omp simd reduction(+ : kk)
+            for (size_t i = 0; i < n; ++i) {
+                const double pv = op[i] + h * og[i];
+                const double vv = s2[i] * pv;
+                op[i] = pv;
+                ov[i] = vv;
+                kk += pv * vv;
+                ops[i] = keep * sps[i] + pv;
+            }
+            o->K = 0.5 * kk;
+        }
+#else
         for (size_t i = 0; i < n; ++i) o->p[i] = std::fma(h, o->g[i], o->p[i]);
         for (size_t i = 0; i < n; ++i) o->v[i] = sig2[i] * o->p[i];
         o->K = 0.5 * det_dot(o->p.data(), o->v.data(), n, geo);
@@ -386,6 +449,7 @@ struct Hamiltonian {
         } else {
             for (size_t i = 0; i < n; ++i) o->psum[i] = s.psum[i] + o->p[i];
         }
+#endif
         double de = o->energy_error();
         if (de > max_energy_error || !std::isfinite(de)) {
             info->energy_error = de;
@@ -404,6 +468,24 @@ struct Hamiltonian {
         const int64_t a = start->idx, b = end->idx;
         const size_t n = dim();
         double t1, t2;
+#ifdef ORACLE_TUNED
+        {   // both products in one vectorised pass (nuts-rs: scalar_prods2 / scalar_prods3)
+            const double *eps_ = end->psum.data(), *sps = start->psum.data(), *sp = start->p.data(), *ep = end->p.data();
+            const double *ev = end->v.data(), *sv = start->v.data();
+            double x1 = 0.0, x2 = 0.0;
+            if (a >= 0 && b >= 0) {
+#pragma omp simd reduction(+ : x1, x2)
+                for (size_t i = 0; i < n; ++i) { const double t = (eps_[i] - sps[i]) + sp[i]; x1 += t * ev[i]; x2 += t * sv[i]; }
+            } else if (b >= 0 && a < 0) {
+#pragma omp simd reduction(+ : x1, x2)
+                for (size_t i = 0; i < n; ++i) { const double t = eps_[i] + sps[i]; x1 += t * ev[i]; x2 += t * sv[i]; }
+            } else {
+#pragma omp simd reduction(+ : x1, x2)
+                for (size_t i = 0; i < n; ++i) { const double t = (sps[i] - eps_[i]) + ep[i]; x1 += t * ev[i]; x2 += t * sv[i]; }
+            }
+            return (x1 < 0.0) || (x2 < 0.0);
+        }
+#endif
         if (a >= 0 && b >= 0) {
             // scalar_prods3(end.p_sum, -start.p_sum, +start.p ; end.v, start.v)
             t1 = det_reduce(n, geo, [&](size_t i, double acc) { return std::fma((end->psum[i] - start->psum[i]) + start->p[i], end->v[i], acc); });

@@ -215,12 +215,13 @@ def test_settings_variants_bit_identical(hip, oracle, settings):
     (4500, dict(check_turning=False, maxdepth=4), {}),
     (7000, dict(maxdepth=12, target_accept=0.95), {}),                   # deep trees: merges up to level >= 5
 ])
-def test_lean_register_kernels_variants(hip, oracle, dim, settings, launch):
-    # lean register-resident kernels (8 waves per chain, 4096 < D <= 10240) under the awkward settings
+@pytest.mark.parametrize("waves", [0, 8])
+def test_lean_register_kernels_variants(hip, oracle, dim, settings, launch, waves):
+    # lean register-resident kernels (4096 < D <= 10240: 4 waves per chain by default, 8 on request) under the awkward settings
     model = ar1_gaussian(dim)
     kw = dict(chains=3, tune=50, draws=12, seed=dim + 3)
-    got, W = run_engine(hip, hip.TridiagGaussianModel(model.diag, model.offdiag), launch=launch, **kw, **settings)
-    assert W == 8
+    got, W = run_engine(hip, hip.TridiagGaussianModel(model.diag, model.offdiag), launch=launch, waves=waves, **kw, **settings)
+    assert W == (waves or 4)
     want = oracle.sample_tridiag(oracle_settings(oracle, W=W, **kw, **settings), model.diag, model.offdiag)
     assert_trace_equal(got, want)
     if "store_gradient" in settings:
@@ -234,7 +235,7 @@ def test_lean_kernel_equals_streaming_kernel(hip):
     m = hip.TridiagGaussianModel(model.diag, model.offdiag)
     a, W = run_engine(hip, m, **kw)
     b, _ = run_engine(hip, m, launch=dict(no_register_kernel=True), **kw)
-    assert W == 8
+    assert W == 4
     assert np.array_equal(a.draws, b.draws)
     for k in ("depth", "n_steps", "index_in_trajectory", "energy", "step_size", "mean_tree_accept"):
         assert np.array_equal(a.stats[k], b.stats[k]), k
@@ -433,12 +434,12 @@ def test_config2_full_size_properties(hip):
 
 @pytest.mark.parametrize("dim,chains", [(10000, 64), (3000, 128)])
 def test_large_dimension_shapes_properties(hip, dim, chains):
-    """BASELINE.json config 5's shape (D = 10 000: memory-resident kernels, 8 waves per chain, sigma^2 in LDS) and the
-    4-wave register kernels (D = 3000), short runs: determinism, independence from the batch, analytic moments."""
+    """BASELINE.json config 5's shape (D = 10 000: lean register kernel, 4 waves per chain, sigma^2 in LDS) and the
+    4-wave register kernels with the LDS ring (D = 3000), short runs: determinism, independence from the batch, analytic moments."""
     m = ar1_gaussian(dim)
     kw = dict(tune=120, draws=40, seed=dim)
     a, W = run_engine(hip, hip.TridiagGaussianModel(m.diag, m.offdiag), chains=chains, **kw)
-    assert W == (8 if dim > 4096 else 4) and a.finished.min() == 160
+    assert W == 4 and a.finished.min() == 160
     b, _ = run_engine(hip, hip.TridiagGaussianModel(m.diag, m.offdiag), chains=4, **kw)
     assert np.array_equal(a.draws[:4], b.draws) and np.array_equal(a.stats["n_steps"][:4], b.stats["n_steps"])
     d = a.draws[:, 120:]
@@ -459,7 +460,7 @@ def test_config5_full_size_properties(hip):
     m = ar1_gaussian(10000)
     kw = dict(tune=40, draws=10, seed=10000)
     a, W = run_engine(hip, hip.TridiagGaussianModel(m.diag, m.offdiag), chains=1024, **kw)
-    assert W == 8 and a.finished.min() == 50
+    assert W == 4 and a.finished.min() == 50
     b, _ = run_engine(hip, hip.TridiagGaussianModel(m.diag, m.offdiag), chains=4, **kw)
     assert np.array_equal(a.draws[:4], b.draws) and np.array_equal(a.stats["n_steps"][:4], b.stats["n_steps"])
     assert a.stats["diverging"][:, 30:].mean() < 0.05
