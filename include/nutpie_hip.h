@@ -157,7 +157,9 @@ typedef struct {
     int32_t no_stream_cache;    /* 1: memory-resident fused kernels reload the cursor state every leapfrog (A/B, tests) */
     int32_t graph_steps;        /* device-callback models: >0 = capture this many (engine kernel + callback) steps in a HIP
                                  * graph and replay it; the callback must then only enqueue work on the given stream */
-    int32_t reserved;
+    int32_t host_groups;        /* host-callback models with zero-copy staging: 0 = default (two groups of chains in flight: the
+                                 * kernel of one runs while the host evaluates the rows of the other), 1 = no pipelining,
+                                 * 2..4 = that many groups */
 } nphip_launch_t;
 
 void nphip_launch_defaults(nphip_launch_t*);

@@ -65,7 +65,7 @@ class _Launch(C.Structure):
         ("no_register_kernel", C.c_int32),
         ("no_stream_cache", C.c_int32),
         ("graph_steps", C.c_int32),
-        ("reserved", C.c_int32),
+        ("host_groups", C.c_int32),
     ]
 
 
@@ -521,7 +521,7 @@ class PySampler:
 
     def __init__(self, settings: PyNutsSettings, model: _Model, *, device=0, waves_per_chain=0, chain_offset=0,
                  n_local_chains=0, stream=None, store_draws=True, evals_per_launch=0, start_paused=False, manual=False,
-                 staging=None, no_register_kernel=False, no_stream_cache=False, graph_steps=0):
+                 staging=None, no_register_kernel=False, no_stream_cache=False, graph_steps=0, host_groups=0):
         L = lib()
         la = _Launch()
         L.nphip_launch_defaults(C.byref(la))
@@ -537,6 +537,7 @@ class PySampler:
         la.no_register_kernel = int(bool(no_register_kernel))
         la.no_stream_cache = int(bool(no_stream_cache))
         la.graph_steps = int(graph_steps)
+        la.host_groups = int(host_groups)
         if staging is not None:
             la.staging_q, la.staging_grad, la.staging_logp = (C.c_void_p(int(p)) for p in staging)
         self._model = model

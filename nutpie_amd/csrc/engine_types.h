@@ -155,6 +155,16 @@ struct Args {
     int32_t max_evals;    // fused: evaluations per chain this launch
     int32_t have_result;  // callbacks: geval/ueval hold the answer to the pending request
     unsigned long long* counters;  // [0] chains done, [1] chains in error
+    // pipelined host-callback groups (host.hip: iteration_pipelined)
+    unsigned int* grp_arrive;               // device [groups]: chains of the group that finished the current launch
+    volatile unsigned long long* grp_flag;  // pinned host [groups][4]: launch sequence number, chains done, chains in error, -
+};
+
+// the chains one launch covers (kernel parameter)
+struct LaunchSlice {
+    int chain_lo, chain_n;
+    int grp;       // >= 0: publish completion in Args::grp_flag[grp] (no stream synchronisation on the host)
+    unsigned seq;
 };
 
 }  // namespace nphip

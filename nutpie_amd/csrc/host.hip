@@ -25,7 +25,7 @@
 #include "engine_types.h"
 
 namespace nphip {
-hipError_t launch_advance(const Args& a, const Args* d_args, bool fused, int W, hipStream_t st);
+hipError_t launch_advance(const Args& a, const Args* d_args, bool fused, int W, hipStream_t st, const LaunchSlice* slice = nullptr);
 hipError_t launch_test_detmath(int fn, uint64_t n, const double* x, double* y, hipStream_t st);
 hipError_t launch_test_dot(int W, uint64_t n, const double* x, const double* y, double* out, hipStream_t st);
 }  // namespace nphip
@@ -485,6 +485,23 @@ struct nphip_sampler {
     uint64_t cb_replays = 0;
     uint64_t cb_polls = 0;
     bool iteration_callback(bool& all_done, int& have);
+    // host callbacks, zero-copy staging: chains in groups, each on its own stream, completion by a flag in pinned memory
+    // (no stream synchronisation): the kernel of one group runs while the host evaluates the rows of the other
+    static constexpr int kMaxGroups = 4;
+    int n_groups = 0;
+    hipStream_t grp_stream[kMaxGroups] = {nullptr, nullptr, nullptr, nullptr};
+    uint64_t grp_lo[kMaxGroups + 1] = {0, 0, 0, 0, 0};
+    unsigned grp_seq[kMaxGroups] = {0, 0, 0, 0};
+    bool grp_primed = false;
+    volatile unsigned long long* h_grp_flag = nullptr;  // pinned [groups][4]
+    bool launch_group(int g, int have);
+    bool wait_group(int g);
+    bool iteration_pipelined(bool& all_done);
+    bool sync_all() {
+        bool ok = hip_ok(hipStreamSynchronize(stream), "hipStreamSynchronize");
+        for (int g = 0; g < n_groups; ++g) ok = hip_ok(hipStreamSynchronize(grp_stream[g]), "hipStreamSynchronize") && ok;
+        return ok;
+    }
     void fail(const std::string& msg) {
         std::lock_guard<std::mutex> lk(mu);
         failed = true;
@@ -499,6 +516,7 @@ struct nphip_sampler {
         if (ev0) { (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1); ev0 = ev1 = nullptr; }
         if (cb_graph) { (void)hipGraphExecDestroy(cb_graph); cb_graph = nullptr; }
         for (auto& e : cb_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+        for (auto& gs : grp_stream) if (gs) { (void)hipStreamDestroy(gs); gs = nullptr; }
         if (own_stream && stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
     }
 };
@@ -648,6 +666,22 @@ bool nphip_sampler::setup() {
             if (nt < 1) nt = 1;
             if ((uint64_t)nt > n) nt = (int)n;
             pool.reset(new RowPool(nt > 1 ? nt : 0));
+            // pipelining: two groups of chains in flight — while the host evaluates the rows of one group the
+            // kernel of the other runs.  Zero-copy batches only (they are the latency-bound ones); launch.host_groups = 1 turns it off.
+            if (zero_copy && !launch.manual && launch.host_groups != 1 && n >= 2) {
+                // measured (profiles/r2_config4_host_callback_pipelining.txt): eight schools, 256 chains: 5.7 -> 6.5 (2 groups) -> 6.7 M
+                // leapfrogs/s (4 groups); 1024 chains: 12.3 -> 14.5 -> 16.2.  The rest of a step is fixed latency (launch, the
+                // kernel's PCIe reads of the gradients, the flag), which groups overlap with each other but cannot shorten.
+                n_groups = (n >= 128) ? 4 : ((n >= 32) ? 2 : 1);
+                if (launch.host_groups >= 2 && launch.host_groups <= kMaxGroups) n_groups = (int)std::min<uint64_t>(launch.host_groups, n);
+                for (int g = 0; g <= n_groups; ++g) grp_lo[g] = n * (uint64_t)g / (uint64_t)n_groups;
+                for (int g = 0; g < n_groups; ++g) HIP_TRY(hipStreamCreateWithFlags(&grp_stream[g], hipStreamNonBlocking));
+                if (!dalloc(&args.grp_arrive, kMaxGroups)) return false;
+                unsigned long long* f = nullptr;
+                if (!palloc(&f, 4 * kMaxGroups)) return false;
+                h_grp_flag = f;
+                args.grp_flag = f;
+            }
         }
     }
     if (model.init_kind == 2) {
@@ -810,6 +844,73 @@ bool nphip_sampler::iteration_graph(bool& all_done) {
     return true;
 }
 
+bool nphip_sampler::launch_group(int g, int have) {
+    LaunchSlice sl;
+    sl.chain_lo = (int)grp_lo[g];
+    sl.chain_n = (int)(grp_lo[g + 1] - grp_lo[g]);
+    sl.grp = g;
+    sl.seq = ++grp_seq[g];
+    args.max_evals = 0;
+    args.have_result = have;
+    if (!hip_ok(launch_advance(args, d_args, false, W, grp_stream[g], &sl), "launch k_advance")) return false;
+    launches.fetch_add(1);
+    return true;
+}
+
+bool nphip_sampler::wait_group(int g) {
+    // the kernel's last arriver writes the sequence number of the launch into pinned host memory (kernels.hip: k_advance)
+    const unsigned long long want = grp_seq[g];
+    volatile unsigned long long* f = h_grp_flag + 4 * g;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint64_t spin = 0; f[0] != want; ++spin) {
+        if ((spin & 0x3ff) == 0x3ff) {
+            if (hipStreamQuery(grp_stream[g]) == hipSuccess && f[0] != want) {
+                // the stream is idle and the flag never came: the launch failed
+                if (f[0] != want) { set_error("host-callback group finished without publishing its completion flag"); return false; }
+            }
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) { set_error("timeout waiting for the engine kernel"); return false; }
+        }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return true;
+}
+
+// One round over the groups: for each, wait for its kernel, evaluate its rows on the host pool, relaunch it.
+bool nphip_sampler::iteration_pipelined(bool& all_done) {
+    if (!grp_primed) {
+        if (!hip_ok(hipStreamSynchronize(stream), "hipStreamSynchronize")) return false;   // set-up copies ran on the main stream
+        for (int g = 0; g < n_groups; ++g)
+            if (!launch_group(g, 0)) return false;
+        grp_primed = true;
+    }
+    const uint64_t d = dim;
+    for (int g = 0; g < n_groups; ++g) {
+        if (!wait_group(g)) return false;
+        volatile unsigned long long* f = h_grp_flag + 4 * g;
+        if (f[2] > 0) { (void)sync_all(); set_error(chain_error_message()); return false; }
+        if (f[1] >= n) {
+            // every chain of the job is done; drain the launches still in flight for the other groups
+            for (int o = 0; o < n_groups; ++o)
+                if (o != g && !wait_group(o)) return false;
+            all_done = true;
+            return sync_all();
+        }
+        const uint64_t lo = grp_lo[g], cnt = grp_lo[g + 1] - lo;
+        pool->run(cnt, [this, d, lo](uint64_t r) {
+            const uint64_t row = lo + r;
+            double lp = NAN;
+            h_code[row] = (int64_t)model.host_fn(d, h_q + row * d, h_g + row * d, &lp, model.user);
+            h_u[row] = lp;
+        });
+        std::atomic_thread_fence(std::memory_order_release);
+        if (!launch_group(g, 1)) return false;
+    }
+    return true;
+}
+
 void nphip_sampler::run() {
     (void)hipSetDevice(device);
     t_start = std::chrono::steady_clock::now();
@@ -824,13 +925,13 @@ void nphip_sampler::run() {
         bool ok;
         {
             std::lock_guard<std::mutex> run_lk(mu_run);
-            ok = fused ? iteration_fused(all_done) : iteration_callback(all_done, have);
+            ok = fused ? iteration_fused(all_done) : (n_groups > 0 ? iteration_pipelined(all_done) : iteration_callback(all_done, have));
         }
         seconds.store(std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count());
         if (!ok) { fail(t_error); break; }
         if (all_done) break;
     }
-    (void)hipStreamSynchronize(stream);
+    (void)sync_all();
     {
         std::lock_guard<std::mutex> lk(mu);
         finished = all_done && !failed;
@@ -953,7 +1054,7 @@ static bool read_ctl(nphip_sampler_t* s, std::vector<Ctl>& h) {
     h.resize(s->n);
     std::lock_guard<std::mutex> run_lk(s->mu_run);
     (void)hipSetDevice(s->device);
-    if (!hip_ok(hipStreamSynchronize(s->stream), "sync")) return false;
+    if (!s->sync_all()) return false;
     return hip_ok(hipMemcpy(h.data(), s->args.ctl, s->n * sizeof(Ctl), hipMemcpyDeviceToHost), "copy ctl");
 }
 
@@ -1016,7 +1117,7 @@ int nphip_sampler_copy_expanded(nphip_sampler_t* s, void* host_out, uint64_t nby
     double* out = static_cast<double*>(host_out);
     std::lock_guard<std::mutex> run_lk(s->mu_run);
     (void)hipSetDevice(s->device);
-    if (!hip_ok(hipStreamSynchronize(s->stream), "sync")) return NPHIP_ERR;
+    if (!s->sync_all()) return NPHIP_ERR;
     // blocks of rows: at most ~64 MB of positions per block
     const uint64_t block = std::max<uint64_t>(1, std::min<uint64_t>(rows, (64ull << 20) / (d * 8)));
     std::atomic<int> first_err{0};
@@ -1064,7 +1165,7 @@ int nphip_sampler_copy_stat(nphip_sampler_t* s, const char* name, void* host_out
     if (nbytes != bytes) { set_error("size mismatch for " + std::string(name)); return NPHIP_ERR; }
     std::lock_guard<std::mutex> run_lk(s->mu_run);
     (void)hipSetDevice(s->device);
-    if (!hip_ok(hipStreamSynchronize(s->stream), "sync")) return NPHIP_ERR;
+    if (!s->sync_all()) return NPHIP_ERR;
     if (!hip_ok(hipMemcpy(host_out, p, bytes, hipMemcpyDeviceToHost), "copy trace")) return NPHIP_ERR;
     return NPHIP_OK;
 }

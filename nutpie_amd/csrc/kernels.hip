@@ -1411,68 +1411,33 @@ struct Machine {
             X.dirty_pr = false;
         }
     }
-    // returns 0 (next leaf) or an end code; the caller runs the out-of-line draw end AFTER the register state is dead:
-    // 1 diverged, 2 U-turn, 3 maximum depth
-    __device__ __forceinline__ int leaf_lean(const LeanRs& rs, RegsT& X) {
-        const int64_t j = c->nleaf + 1, d = c->depth, dir = c->dir;
-        const int db = dir > 0 ? 1 : 0;
-        const int64_t near_idx = dir > 0 ? c->idx_right : c->idx_left;
-        const int64_t idx_new = c->idx_cur + dir;
-        const int64_t srcq = c->lf_srcq, srcp = c->lf_srcp, newq = c->lf_newq, newp = c->lf_newp;
-        const bool check = A.s.check_turning && (d + 1 > A.s.mindepth);
-#ifdef NPHIP_PROFILE
-        const int64_t tp0 = (int64_t)__builtin_readcyclecounter();
-#endif
-        // ---- source state (already resident unless the cursor moved or a rare path ran)
-        if (X.reg_q != srcq) {
-#pragma unroll
-            for (int k = 0; k < NVX; ++k) X.q[k] = bld2(rs.q, rs.voff, soff(rs, srcq, 0, k));
-            lean_grad(rs, X);
-        }
-        if (X.reg_p != srcp) {
-#pragma unroll
-            for (int k = 0; k < NVX; ++k) { X.p[k] = bld2(rs.p, rs.voff, soff(rs, srcp, 0, k)); X.r[k] = bld2(rs.p, rs.voff, soff(rs, srcp, 1, k)); }
-        }
-        NPHIP_PHASE_FENCE();
-        // ---- leapfrog, sweep 1: q' = q + eps sigma^2 (p + eps/2 g); publish the chunk-edge z'
-        const double eps = (double)c->lf_sign * c->step_size;
-        const double h = 0.5 * eps;
-        const bool first_back = (idx_new == -1);   // first backward step: rho' = p'  (-0.0 + p == p exactly, also for signed zeros)
-        // (software pipeline, one chunk deep: the L2 loads of chunk k + 1 are issued before chunk k is computed; the fence at the
-        //  end of every chunk keeps the scheduler from issuing them all at once — that spills the resident state)
-        double2 mu_n = par2(rs, rs.mu, 0);
-#pragma unroll
-        for (int k = 0; k < NVX; ++k) {
-            const int64_t cch = (int64_t)k * W + wave;
-            const double2 mu = mu_n;
-            if (k + 1 < NVX) mu_n = par2(rs, rs.mu, k + 1);
-            const double2 s2 = sigl(rs, k);
-            const double phx = fma(h, X.g[k].x, X.p[k].x), phy = fma(h, X.g[k].y, X.p[k].y);
-            X.q[k].x = fma(eps, s2.x * phx, X.q[k].x);
-            X.q[k].y = fma(eps, s2.y * phy, X.q[k].y);
-            const double zx = X.q[k].x - mu.x, zy = X.q[k].y - mu.y;
-            if (lane == 0 || lane == 63) edge[2 * cch + (lane == 0 ? 1 : 2)] = (lane == 0) ? zx : zy;
-            NPHIP_CHUNK_FENCE(k);
-        }
-        __syncthreads();
-#ifdef NPHIP_PROFILE
-        const int64_t tp_s1 = (int64_t)__builtin_readcyclecounter();
-#endif
-        // ---- sweep 2: gradient at q', second half-kick, energies, level-0 criterion
+    // Sweep 2 of the lean leapfrog (see leaf_lean): gradient at q', second half-kick, energies, level-0 criterion.
+    // v = K, logp, level-0 criterion (end, start) — chain-wide sums.
+    struct ParChunk { double2 mu, a, b01; double b2; };
+    __device__ __forceinline__ ParChunk ldpar(const LeanRs& rs, int k) const {
+        ParChunk c_;
+        c_.mu = par2(rs, rs.mu, k); c_.a = par2(rs, rs.a, k); c_.b01 = par2(rs, rs.b, k); c_.b2 = par_b2(rs, k);
+        return c_;
+    }
+    __device__ __forceinline__ void lean_sweep2(const LeanRs& rs, RegsT& X, const double h, const bool first_back, double (&v)[4]) {
         double2 accK = {0.0, 0.0}, accL = {0.0, 0.0}, accE = {0.0, 0.0}, accS = {0.0, 0.0};
         // (an opaque copy of h: with the same SSA value the compiler keeps sweep 1's half-kicked momenta of ALL chunks alive
         //  across the barrier instead of recomputing them — 4 more registers per chunk than the budget has)
         double h2 = h;
         asm volatile("" : "+v"(h2));
-        double2 a_n = par2(rs, rs.a, 0), b01_n = par2(rs, rs.b, 0);
-        double b2_n = par_b2(rs, 0);
-        mu_n = par2(rs, rs.mu, 0);
+        // model vectors come from L2: one chunk of look-ahead (measured, profiles/r2_lean_ab_parameter_prefetch_depth.txt: three
+        // chunks cost 5 % at D = 6000 and D = 10 000 — the extra live registers turn into AGPR moves)
+        constexpr int PFP = 1;
+        ParChunk pn[PFP];
+#pragma unroll
+        for (int u = 0; u < PFP; ++u) if (u < NVX) pn[u] = ldpar(rs, u);
 #pragma unroll
         for (int k = 0; k < NVX; ++k) {
             const int64_t cch = (int64_t)k * W + wave;
-            const double2 mu = mu_n, a = a_n, b01 = b01_n;
-            const double b2 = b2_n;
-            if (k + 1 < NVX) { mu_n = par2(rs, rs.mu, k + 1); a_n = par2(rs, rs.a, k + 1); b01_n = par2(rs, rs.b, k + 1); b2_n = par_b2(rs, k + 1); }
+            const ParChunk pc = pn[k % PFP];
+            if (k + PFP < NVX) pn[k % PFP] = ldpar(rs, k + PFP);
+            const double2 mu = pc.mu, a = pc.a, b01 = pc.b01;
+            const double b2 = pc.b2;
             const double2 s2 = sigl(rs, k);
             double2 z;
             z.x = X.q[k].x - mu.x;
@@ -1511,20 +1476,75 @@ struct Machine {
             accS.y = fma(ty0, s2.y * pold.y, accS.y);
             NPHIP_CHUNK_FENCE(k);
         }
+        NPHIP_PHASE_FENCE();
+        v[0] = accK.x + accK.y; v[1] = accL.x + accL.y; v[2] = accE.x + accE.y; v[3] = accS.x + accS.y;
+        rsum(v);
+        NPHIP_PHASE_FENCE();
+    }
+
+    // returns 0 (next leaf) or an end code; the caller runs the out-of-line draw end AFTER the register state is dead:
+    // 1 diverged, 2 U-turn, 3 maximum depth
+    __device__ __forceinline__ int leaf_lean(const LeanRs& rs, RegsT& X) {
+        const int64_t j = c->nleaf + 1, d = c->depth, dir = c->dir;
+        const int db = dir > 0 ? 1 : 0;
+        const int64_t near_idx = dir > 0 ? c->idx_right : c->idx_left;
+        const int64_t idx_new = c->idx_cur + dir;
+        const int64_t srcq = c->lf_srcq, srcp = c->lf_srcp, newq = c->lf_newq, newp = c->lf_newp;
+        const bool check = A.s.check_turning && (d + 1 > A.s.mindepth);
+#ifdef NPHIP_PROFILE
+        const int64_t tp0 = (int64_t)__builtin_readcyclecounter();
+#endif
+        // ---- source state (already resident unless the cursor moved or a rare path ran)
+        if (X.reg_q != srcq) {
+#pragma unroll
+            for (int k = 0; k < NVX; ++k) X.q[k] = bld2(rs.q, rs.voff, soff(rs, srcq, 0, k));
+            lean_grad(rs, X);
+        }
+        if (X.reg_p != srcp) {
+#pragma unroll
+            for (int k = 0; k < NVX; ++k) { X.p[k] = bld2(rs.p, rs.voff, soff(rs, srcp, 0, k)); X.r[k] = bld2(rs.p, rs.voff, soff(rs, srcp, 1, k)); }
+        }
+        NPHIP_PHASE_FENCE();
+        // ---- leapfrog, sweep 1: q' = q + eps sigma^2 (p + eps/2 g); publish the chunk-edge z'
+        const double eps = (double)c->lf_sign * c->step_size;
+        const double h = 0.5 * eps;
+        const bool first_back = (idx_new == -1);   // first backward step: rho' = p'  (-0.0 + p == p exactly, also for signed zeros)
+        // (software pipeline: the L2 loads of chunk k + PFM are issued before chunk k is computed; the fence at the end of every
+        //  chunk keeps the scheduler from issuing them all at once — that spills the resident state)
+        constexpr int PFM = 1;
+        double2 mu_n[PFM];
+#pragma unroll
+        for (int u = 0; u < PFM; ++u) if (u < NVX) mu_n[u] = par2(rs, rs.mu, u);
+#pragma unroll
+        for (int k = 0; k < NVX; ++k) {
+            const int64_t cch = (int64_t)k * W + wave;
+            const double2 mu = mu_n[k % PFM];
+            if (k + PFM < NVX) mu_n[k % PFM] = par2(rs, rs.mu, k + PFM);
+            const double2 s2 = sigl(rs, k);
+            const double phx = fma(h, X.g[k].x, X.p[k].x), phy = fma(h, X.g[k].y, X.p[k].y);
+            X.q[k].x = fma(eps, s2.x * phx, X.q[k].x);
+            X.q[k].y = fma(eps, s2.y * phy, X.q[k].y);
+            const double zx = X.q[k].x - mu.x, zy = X.q[k].y - mu.y;
+            if (lane == 0 || lane == 63) edge[2 * cch + (lane == 0 ? 1 : 2)] = (lane == 0) ? zx : zy;
+            NPHIP_CHUNK_FENCE(k);
+        }
+        __syncthreads();
+#ifdef NPHIP_PROFILE
+        const int64_t tp_s1 = (int64_t)__builtin_readcyclecounter();
+#endif
+        // ---- sweep 2: gradient at q', second half-kick, energies, level-0 criterion
+        // (Fusing the level-1 criteria of this leaf into the sweep — their operands behind the gradient arithmetic, one shared
+        //  reduction — was built and measured against the allocator: as three instantiations or as a run-time flag it turns the
+        //  resident state into a multi-way phi and spills 800+ VGPRs at 20 chunks per wave.  The criteria stay separate passes.)
+        double v4[4];
+        lean_sweep2(rs, X, h, first_back, v4);
         X.reg_q = newq;
         X.reg_p = newp;
         X.dirty_qg = true;
         X.dirty_pr = true;
 #ifdef NPHIP_PROFILE
-        const int64_t tp1 = (int64_t)__builtin_readcyclecounter();
-#endif
-        NPHIP_PHASE_FENCE();
-        double v4[4] = {accK.x + accK.y, accL.x + accL.y, accE.x + accE.y, accS.x + accS.y};
-        rsum(v4);
-        NPHIP_PHASE_FENCE();
-#ifdef NPHIP_PROFILE
         const int64_t tp2 = (int64_t)__builtin_readcyclecounter();
-        c->prof[0] += tp1 - tp0; c->prof[15] += tp_s1 - tp0; c->prof[6] += tp2 - tp1;
+        c->prof[0] += tp2 - tp0; c->prof[15] += tp_s1 - tp0;
 #endif
         const double K = 0.5 * v4[0], lp = 0.5 * v4[1];
         const bool turn0 = (v4[2] < 0.0) || (v4[3] < 0.0);
@@ -2198,7 +2218,7 @@ struct Machine {
 // `Ap` points to the engine's argument block in device memory (written once at set-up); it is read through
 // the constant address space, i.e. with scalar loads into SGPRs.  Per-launch scalars are kernel parameters.
 template <bool FUSED, int W, int NV, bool LEAN = false>
-__global__ __launch_bounds__(W == 1 ? 256 : 64 * W) __attribute__((amdgpu_waves_per_eu(LEAN ? NPHIP_LEAN_OCC(W) : ((NV > 0 && NV <= 4) ? 2 : 1), LEAN ? NPHIP_LEAN_OCC(W) : ((NV > 0 && NV <= 4) ? 2 : 8)))) void k_advance(const Args* __restrict__ Ap, int max_evals, int have_result) {
+__global__ __launch_bounds__(W == 1 ? 256 : 64 * W) __attribute__((amdgpu_waves_per_eu(LEAN ? NPHIP_LEAN_OCC(W) : ((NV > 0 && NV <= 4) ? 2 : 1), LEAN ? NPHIP_LEAN_OCC(W) : ((NV > 0 && NV <= 4) ? 2 : 8)))) void k_advance(const Args* __restrict__ Ap, int max_evals, int have_result, const LaunchSlice sl) {
     const NPHIP_CONST Args& A = *(const NPHIP_CONST Args*)Ap;
     constexpr int WAVES = (W == 1) ? 4 : W;
     __shared__ Ctl s_ctl[WAVES];
@@ -2208,7 +2228,8 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) __attribute__((amdgpu_waves_
     __shared__ double s_edge[(NV > 0 && W > 1) ? 2 * W * NV + 2 : 2];   // lean kernels: padded with one 0.0 at each end
     extern __shared__ __attribute__((aligned(16))) double s_dyn[];  // a.sig_lds: sigma^2 of the chain [ld]
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    const int64_t chain = (W == 1) ? (int64_t)blockIdx.x * 4 + wib : (int64_t)blockIdx.x;
+    // a launch covers the chains [sl.chain_lo, sl.chain_lo + sl.chain_n): all of them, or one group of a pipelined host-callback job
+    const int64_t chain = sl.chain_lo + ((W == 1) ? (int64_t)blockIdx.x * 4 + wib : (int64_t)blockIdx.x);
     if (NV > 0 && W == 1) {
         // stage the fused model in LDS once per workgroup: mu | a | b shifted by one with -0.0 sentinels
         const int64_t ld = A.ld;
@@ -2221,7 +2242,7 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) __attribute__((amdgpu_waves_
         if (threadIdx.x < 8) sp[3 * ld + threadIdx.x] = -0.0;
         __syncthreads();
     }
-    if (chain >= A.n_chains) return;
+    if (chain >= (int64_t)sl.chain_lo + sl.chain_n) return;
     if (LEAN && threadIdx.x == 0) { s_edge[0] = 0.0; s_edge[2 * W * NV + 1] = 0.0; }   // (the first barrier is in the sigma^2 staging)
     LdsCtl c = (LdsCtl)&s_ctl[wib];
     {
@@ -2239,15 +2260,34 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) __attribute__((amdgpu_waves_
         const NPHIP_LDS uint64_t* src = (const NPHIP_LDS uint64_t*)c;
         for (int w = lane; w < kCtlWords; w += 64) dst[w] = src[w];
     }
+    if (sl.grp >= 0) {
+        // Pipelined host-callback groups: the host does not synchronise with the stream, it polls a word in pinned host memory.
+        // Every chain of the group arrives once (its positions / control block are written and released to the system first);
+        // the last arriver publishes the job-wide done / error counts and then the sequence number of this launch.
+        if (W > 1) __syncthreads();
+        if (lane == 0 && (W == 1 || wib == 0)) {
+            __threadfence_system();
+            const unsigned old = atomicAdd(&A.grp_arrive[sl.grp], 1u);
+            if (old + 1u == (unsigned)sl.chain_n) {
+                A.grp_arrive[sl.grp] = 0u;
+                volatile unsigned long long* f = A.grp_flag + 4 * sl.grp;
+                f[1] = atomicAdd(&A.counters[0], 0ull);
+                f[2] = atomicAdd(&A.counters[1], 0ull);
+                __threadfence_system();
+                f[0] = (unsigned long long)sl.seq;
+                __threadfence_system();
+            }
+        }
+    }
 }
 
 template <bool FUSED>
-static hipError_t launch_w(const Args& a, const Args* d_args, int W, hipStream_t st) {
-    const unsigned n = (unsigned)a.n_chains;
+static hipError_t launch_w(const Args& a, const Args* d_args, int W, hipStream_t st, const LaunchSlice sl) {
+    const unsigned n = (unsigned)sl.chain_n;
     const int me = a.max_evals, hr = a.have_result;
 #ifdef NPHIP_DEV_W1NV   // developer build: only k_advance<true, 1, NPHIP_DEV_W1NV>
     if (FUSED && W == 1 && a.reg_nv == NPHIP_DEV_W1NV) {
-        hipLaunchKernelGGL((k_advance<true, 1, NPHIP_DEV_W1NV>), dim3((n + 3) / 4), dim3(256), 0, st, d_args, me, hr);
+        hipLaunchKernelGGL((k_advance<true, 1, NPHIP_DEV_W1NV>), dim3((n + 3) / 4), dim3(256), 0, st, d_args, me, hr, sl);
         return hipGetLastError();
     }
     return hipErrorInvalidValue;
@@ -2256,7 +2296,7 @@ static hipError_t launch_w(const Args& a, const Args* d_args, int W, hipStream_t
         // lean register-resident kernels (4096 < D <= 10240): one workgroup of 8 waves = one chain, sigma^2 in dynamic LDS
         const dim3 g(n), b(64 * W);
         const size_t dyn = (size_t)a.ld * 8;
-#define NPHIP_LAUNCH_LEAN(WW, NN) hipLaunchKernelGGL((k_advance<true, WW, NN, true>), g, b, dyn, st, d_args, me, hr)
+#define NPHIP_LAUNCH_LEAN(WW, NN) hipLaunchKernelGGL((k_advance<true, WW, NN, true>), g, b, dyn, st, d_args, me, hr, sl)
 #ifndef NPHIP_DEV_LEAN
         if (W == 4) {   // 4 waves per chain, state spread over VGPRs + AGPRs (one wave per SIMD): 9..20 chunks per wave
             switch (a.reg_nv) {
@@ -2309,7 +2349,7 @@ static hipError_t launch_w(const Args& a, const Args* d_args, int W, hipStream_t
     if (FUSED && (W == 2 || W == 4) && a.reg_nv > 0) {
         // register-resident, several waves per chain (1024 < D <= 4096, or fewer chains than SIMDs): one workgroup = one chain
         const dim3 g(n), b(64 * W);
-#define NPHIP_LAUNCH_RW(WW, NN) hipLaunchKernelGGL((k_advance<true, WW, NN>), g, b, 0, st, d_args, me, hr)
+#define NPHIP_LAUNCH_RW(WW, NN) hipLaunchKernelGGL((k_advance<true, WW, NN>), g, b, 0, st, d_args, me, hr, sl)
         if (W == 2) switch (a.reg_nv) {
             case 1: NPHIP_LAUNCH_RW(2, 1); break;
             case 2: NPHIP_LAUNCH_RW(2, 2); break;
@@ -2337,14 +2377,14 @@ static hipError_t launch_w(const Args& a, const Args* d_args, int W, hipStream_t
     if (FUSED && W == 1 && a.reg_nv > 0) {
         const dim3 g((n + 3) / 4), b(256);
         switch (a.reg_nv) {
-            case 1: hipLaunchKernelGGL((k_advance<true, 1, 1>), g, b, 0, st, d_args, me, hr); break;
-            case 2: hipLaunchKernelGGL((k_advance<true, 1, 2>), g, b, 0, st, d_args, me, hr); break;
-            case 3: hipLaunchKernelGGL((k_advance<true, 1, 3>), g, b, 0, st, d_args, me, hr); break;
-            case 4: hipLaunchKernelGGL((k_advance<true, 1, 4>), g, b, 0, st, d_args, me, hr); break;
-            case 5: hipLaunchKernelGGL((k_advance<true, 1, 5>), g, b, 0, st, d_args, me, hr); break;
-            case 6: hipLaunchKernelGGL((k_advance<true, 1, 6>), g, b, 0, st, d_args, me, hr); break;
-            case 7: hipLaunchKernelGGL((k_advance<true, 1, 7>), g, b, 0, st, d_args, me, hr); break;
-            case 8: hipLaunchKernelGGL((k_advance<true, 1, 8>), g, b, 0, st, d_args, me, hr); break;
+            case 1: hipLaunchKernelGGL((k_advance<true, 1, 1>), g, b, 0, st, d_args, me, hr, sl); break;
+            case 2: hipLaunchKernelGGL((k_advance<true, 1, 2>), g, b, 0, st, d_args, me, hr, sl); break;
+            case 3: hipLaunchKernelGGL((k_advance<true, 1, 3>), g, b, 0, st, d_args, me, hr, sl); break;
+            case 4: hipLaunchKernelGGL((k_advance<true, 1, 4>), g, b, 0, st, d_args, me, hr, sl); break;
+            case 5: hipLaunchKernelGGL((k_advance<true, 1, 5>), g, b, 0, st, d_args, me, hr, sl); break;
+            case 6: hipLaunchKernelGGL((k_advance<true, 1, 6>), g, b, 0, st, d_args, me, hr, sl); break;
+            case 7: hipLaunchKernelGGL((k_advance<true, 1, 7>), g, b, 0, st, d_args, me, hr, sl); break;
+            case 8: hipLaunchKernelGGL((k_advance<true, 1, 8>), g, b, 0, st, d_args, me, hr, sl); break;
             default: return hipErrorInvalidValue;
         }
         return hipGetLastError();
@@ -2352,15 +2392,15 @@ static hipError_t launch_w(const Args& a, const Args* d_args, int W, hipStream_t
     if (FUSED && a.stream_cache && W == 1) {
         // memory-resident kernel with the cursor's (sigma^2, grad, p, rho) cached in VGPRs between leaves.  Measured
         // with more waves per chain (D > 1024) the cache costs occupancy or spills and does not pay; W == 1 only.
-        hipLaunchKernelGGL((k_advance<true, 1, -8>), dim3((n + 3) / 4), dim3(256), 0, st, d_args, me, hr);
+        hipLaunchKernelGGL((k_advance<true, 1, -8>), dim3((n + 3) / 4), dim3(256), 0, st, d_args, me, hr, sl);
         return hipGetLastError();
     }
     switch (W) {
-        case 1: hipLaunchKernelGGL((k_advance<FUSED, 1, 0>), dim3((n + 3) / 4), dim3(256), 0, st, d_args, me, hr); break;
-        case 2: hipLaunchKernelGGL((k_advance<FUSED, 2, 0>), dim3(n), dim3(128), 0, st, d_args, me, hr); break;
-        case 4: hipLaunchKernelGGL((k_advance<FUSED, 4, 0>), dim3(n), dim3(256), 0, st, d_args, me, hr); break;
-        case 8: hipLaunchKernelGGL((k_advance<FUSED, 8, 0>), dim3(n), dim3(512), a.sig_lds ? (size_t)a.ld * 8 : 0, st, d_args, me, hr); break;
-        case 16: hipLaunchKernelGGL((k_advance<FUSED, 16, 0>), dim3(n), dim3(1024), a.sig_lds ? (size_t)a.ld * 8 : 0, st, d_args, me, hr); break;
+        case 1: hipLaunchKernelGGL((k_advance<FUSED, 1, 0>), dim3((n + 3) / 4), dim3(256), 0, st, d_args, me, hr, sl); break;
+        case 2: hipLaunchKernelGGL((k_advance<FUSED, 2, 0>), dim3(n), dim3(128), 0, st, d_args, me, hr, sl); break;
+        case 4: hipLaunchKernelGGL((k_advance<FUSED, 4, 0>), dim3(n), dim3(256), 0, st, d_args, me, hr, sl); break;
+        case 8: hipLaunchKernelGGL((k_advance<FUSED, 8, 0>), dim3(n), dim3(512), a.sig_lds ? (size_t)a.ld * 8 : 0, st, d_args, me, hr, sl); break;
+        case 16: hipLaunchKernelGGL((k_advance<FUSED, 16, 0>), dim3(n), dim3(1024), a.sig_lds ? (size_t)a.ld * 8 : 0, st, d_args, me, hr, sl); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -2368,8 +2408,11 @@ static hipError_t launch_w(const Args& a, const Args* d_args, int W, hipStream_t
 #endif
 }
 
-hipError_t launch_advance(const Args& a, const Args* d_args, bool fused, int W, hipStream_t st) {
-    return fused ? launch_w<true>(a, d_args, W, st) : launch_w<false>(a, d_args, W, st);
+hipError_t launch_advance(const Args& a, const Args* d_args, bool fused, int W, hipStream_t st, const LaunchSlice* slice) {
+    LaunchSlice sl;
+    if (slice) sl = *slice;
+    else { sl.chain_lo = 0; sl.chain_n = (int)a.n_chains; sl.grp = -1; sl.seq = 0u; }
+    return fused ? launch_w<true>(a, d_args, W, st, sl) : launch_w<false>(a, d_args, W, st, sl);
 }
 
 // ----------------------------------------------------------------------------------------

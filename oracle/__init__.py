@@ -55,7 +55,7 @@ class Settings(C.Structure):
         ("store_gradient", C.c_int32),
         ("store_mass_matrix", C.c_int32),
         ("adam", C.c_int32),
-        ("pad_", C.c_int32),
+        ("crate_arithmetic", C.c_int32),
         ("adam_learning_rate", C.c_double),
     ]
 

@@ -356,14 +356,20 @@ struct RunningMean {
 };
 // Acceptance-statistic means are kept as (sum, count) and divided when read (nuts-rs updates a running mean per
 // leapfrog; same value up to rounding, two divisions fewer per leapfrog on the device).
+// crate_arithmetic = 1 switches to the crate's own update: an incrementally updated running mean per leapfrog.
 struct SumMean {
-    uint64_t count = 0; double total = 0.0;
+    uint64_t count = 0; double total = 0.0; bool running = false;
     void reset() { count = 0; total = 0.0; }
-    void add(double v) { count += 1; total += v; }
-    double value() const { return count ? total / (double)count : 0.0; }
+    void add(double v) {
+        count += 1;
+        if (running) total += (v - total) / (double)count;   // total IS the mean in this mode (nuts-rs RunningMean::add)
+        else total += v;
+    }
+    double value() const { return running ? total : (count ? total / (double)count : 0.0); }
 };
 struct Collector {
     SumMean mean, mean_sym;
+    void set_running(bool r) { mean.running = r; mean_sym.running = r; }
     void register_init() { mean.reset(); mean_sym.reset(); }
     void register_leapfrog(const State* end, bool diverged) {
         if (diverged) { mean.add(0.0); mean_sym.add(0.0); return; }
@@ -529,6 +535,7 @@ struct DrawCtx {
     uint32_t doubling_depth = 0;  // depth of the main tree when this doubling started
     uint32_t leaf = 0;            // leaves integrated so far in this doubling
     bool check_turning = true;
+    bool log_weights = false;     // crate_arithmetic: tree weights as log_size, merged with logaddexp [A.3 verbatim]
 };
 
 enum class Ext { Ok, Turning, Diverging, Fatal };
@@ -538,6 +545,7 @@ struct Tree {
     // multinomial weight of the tree, nuts-rs `log_size`, carried as w.m * 2^w.e (nphip_spec.h, "extended-range
     // tree weights")
     Weight w;
+    double log_size = 0.0;   // the same weight in the crate's own form (maintained in both modes, used when ctx.log_weights)
     uint64_t depth = 0;
     bool is_main = false;
 
@@ -551,6 +559,7 @@ struct Tree {
         out->left = end; out->right = end; out->draw = end;
         out->depth = 0; out->is_main = false;
         out->w = w_leaf(-end->energy_error());
+        out->log_size = -end->energy_error();
         return Leap::Ok;
     }
 
@@ -560,18 +569,35 @@ struct Tree {
         // sub-trees: accept other's draw w.p. w_other / (w_self + w_other); main tree (biased progressive
         // sampling): w.p. min(1, w_other / w_self)
         const Weight sum = w_add(w, other.w);
-        const double ref = is_main ? w_rel(w, sum.e) : sum.m;
-        const double oth = w_rel(other.w, sum.e);
-        bool take = is_main && (oth >= ref);
-        if (!take) {
-            uint32_t c3 = (uint32_t)RNG_MERGE | (ctx.doubling_depth << 8) | ((uint32_t)(depth >> 1) << 16);
-            U4 r = philox(ctx.seed, ctx.leaf, ctx.chain, ctx.draw, c3);
-            const int w0 = 2 * (int)(depth & 1);
-            take = u01(r.v[w0], r.v[w0 + 1]) * ref < oth;
+        const double log_sum = det_logaddexp(log_size, other.log_size);
+        bool take;
+        if (ctx.log_weights) {
+            // SURVEY A.3 verbatim: self_w = is_main ? self.log_size : log_size;
+            //   take if other.log_size >= self_w or rng.bool_with_prob(exp(other.log_size - self_w))
+            // (the uniform is the contract's: same Philox block and words as the linear form)
+            const double self_w = is_main ? log_size : log_sum;
+            take = other.log_size >= self_w;
+            if (!take) {
+                uint32_t c3 = (uint32_t)RNG_MERGE | (ctx.doubling_depth << 8) | ((uint32_t)(depth >> 1) << 16);
+                U4 r = philox(ctx.seed, ctx.leaf, ctx.chain, ctx.draw, c3);
+                const int w0 = 2 * (int)(depth & 1);
+                take = u01(r.v[w0], r.v[w0 + 1]) < det_exp(other.log_size - self_w);
+            }
+        } else {
+            const double ref = is_main ? w_rel(w, sum.e) : sum.m;
+            const double oth = w_rel(other.w, sum.e);
+            take = is_main && (oth >= ref);
+            if (!take) {
+                uint32_t c3 = (uint32_t)RNG_MERGE | (ctx.doubling_depth << 8) | ((uint32_t)(depth >> 1) << 16);
+                U4 r = philox(ctx.seed, ctx.leaf, ctx.chain, ctx.draw, c3);
+                const int w0 = 2 * (int)(depth & 1);
+                take = u01(r.v[w0], r.v[w0 + 1]) * ref < oth;
+            }
         }
         if (take) draw = other.draw;
         depth += 1;
         w = sum;
+        log_size = log_sum;
     }
 
     // extend (recursive doubling of `this` in direction dir)
@@ -860,11 +886,13 @@ struct Chain {
     // nuts::draw [A.2]
     bool draw(uint64_t draw_idx, SampleInfo* info, StateP* out) {
         StateP init = H.init_trajectory(*cur, S.seed, chain_id, (uint32_t)draw_idx, RNG_MOMENTUM);
+        col.set_running((S.crate_arithmetic & 2) != 0);
         col.register_init();
         Tree tree;
         tree.left = init; tree.right = init; tree.draw = init;
-        tree.depth = 0; tree.w = Weight{}; tree.is_main = true;
+        tree.depth = 0; tree.w = Weight{}; tree.log_size = 0.0; tree.is_main = true;
         DrawCtx ctx{S.seed, chain_id, (uint32_t)draw_idx};
+        ctx.log_weights = (S.crate_arithmetic & 1) != 0;
         DivergenceInfo dinfo;
         while (tree.depth < S.maxdepth) {
             U4 r = philox(S.seed, (uint32_t)tree.depth, chain_id, (uint32_t)draw_idx, RNG_DIRECTION);

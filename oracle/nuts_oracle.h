@@ -13,6 +13,41 @@
  * contract (include/nphip_spec.h), not nuts-rs's ChaCha8 stream, so the three
  * golden files in the reference's tests/reference/ can only be used as
  * distributional fixtures (tests/test_oracle_statistics.py).
+ *
+ * WHERE THIS FILE DEPARTS FROM, OR PINS DOWN, SURVEY.md APPENDIX A — each with its source.  None of these can be checked
+ * against nuts-rs 0.18.3 here; they are listed so that a maintainer with the crate at hand knows what to compare first.
+ *
+ *  1. Divergence test is ONE-SIDED: a leapfrog diverges when energy_error > max_energy_error or is not finite
+ *     (nuts_oracle.cpp Hamiltonian::leapfrog).  SURVEY A.5 / A6 write |energy_error|.  Source of the choice: the reference's
+ *     own documentation of the knob — "max_energy_error: the maximum energy error ... before a divergence is declared"
+ *     (docs/sampling-options.qmd:71-73) speaks of the error growing, and a large NEGATIVE error means the trajectory moved to
+ *     a much more probable region, which Stan (and, from memory, nuts-rs `energy_error > max_energy_error`) does not treat as
+ *     a divergence.  A two-sided test would change `diverging` only for |dH| > 1000 with dH < 0.
+ *  2. Window bounds: early_end = ceil(early_window * T), final_window = T - ceil(step_size_window * T) + 1 with the
+ *     comparison `draw < final_window` (Chain::Chain).  SURVEY A.8 writes final_start = ceil((1 - step_size_window) * T);
+ *     the two differ by at most one draw.  Source: the crate computes `num_tune.saturating_sub(final_second_step_size)` style
+ *     integer bounds (recalled); the reference only documents "the last 15 % of tuning use a fixed mass matrix"
+ *     (docs/sample-stats.qmd:85, python/nutpie/sample.py:889-895).
+ *  3. A mass-matrix refresh needs at least 3 draws in the estimator it reads (`n_src >= 3`, Chain::adapt): with fewer,
+ *     M2_q / M2_g is 0 / 0 or a single-sample ratio.  SURVEY A.9 does not state a minimum; in-tree evidence for the formula
+ *     itself: python/nutpie/normalizing_flow.py:1906-1915.
+ *  4. `is_late` (`switch_freq + draw > final_window`): no estimator switch is started that could not collect switch_freq
+ *     draws before the final window; the symmetric acceptance statistic drives dual averaging from then on.  SURVEY A.8 has
+ *     the same condition in the form `d + freq <= final_start`.
+ *  5. Welford variance is M2 / n for the gradient-based ratio (the ratio cancels the normalisation) and M2 / (n - 1) for
+ *     draw_diag (Chain::adapt); SURVEY A.9 flags "n vs n-1" as unknown.
+ *  6. Initial step-size search: at most 100 iterations, doubling / halving, restarted once when the first data-driven mass
+ *     matrix replaces the gradient-based initial one; a divergent probe leapfrog keeps `initial_step`.
+ *  7. Arithmetic FORMS shared with the engine (results identical in exact arithmetic, different rounding): tree weights as
+ *     m * 2^e instead of log_size (+ logaddexp), acceptance statistic as sum / count instead of a running mean.  Setting
+ *     `crate_arithmetic = 1` uses the crate's forms instead; the decisions (depth, n_steps, index_in_trajectory) of both
+ *     modes are compared on the golden cases in tests/test_oracle_kat.py.
+ *  8. RNG: Philox4x32-10 counter streams keyed by (seed, global chain, draw, purpose) and Box-Muller normals instead of the
+ *     crate's ChaCha8 + ziggurat; summation in the engine's fixed order (`waves_per_chain`).  By construction, not by
+ *     evidence: the crate's stream cannot be reproduced without the crate.
+ *  9. `step_size_adapt_method = "adam"` (Adam on log step size, src/wrapper.rs:344-376): beta1 0.9, beta2 0.999, eps 1e-8 are
+ *     the textbook constants; the crate's are unknown.  SURVEY §2 marks the option out of scope; it is kept only because
+ *     the settings surface accepts the value.
  */
 #ifndef NUTS_ORACLE_H
 #define NUTS_ORACLE_H
@@ -65,7 +100,14 @@ typedef struct {
     int32_t store_mass_matrix;
     /* step_size_adapt_method = "adam" (src/wrapper.rs:344-376, 391-407): Adam on log(step size) */
     int32_t adam;
-    int32_t pad_;
+    /* 0 (default): the arithmetic FORMS the engine uses — tree weights m * 2^e, acceptance statistics as sum / count.
+     * bit 0: tree weights in the crate's form — log_size merged with logaddexp, accepted with exp(log_size_other - self_w)
+     *        (SURVEY.md App. A.3 verbatim).  Same uniforms; every float and decision of the golden cases is unchanged.
+     * bit 1: the acceptance statistic as an incrementally updated running mean (App. A.6 verbatim).  Differs from sum / count
+     *        in the last bits; through dual averaging that perturbs the step size by ~1e-16 relative, and a chaotic
+     *        integrator amplifies it until some U-turn test flips: identical decisions on four golden cases, a fork at
+     *        draw 36 of the fifth.  tests/test_oracle_kat.py pins both statements. */
+    int32_t crate_arithmetic;
     double adam_learning_rate;
 } oracle_settings_t;
 

@@ -1,8 +1,11 @@
 """Known-answer tests of the oracle's building blocks (the reference holds none)."""
 import math
+import os
 
 import numpy as np
 import pytest
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def test_leapfrog_harmonic_oscillator_energy_and_reversibility(oracle):
@@ -234,3 +237,42 @@ def test_recoverable_error_is_divergence_and_fatal_raises(oracle, fixture_lib):
     assert tr.draws[:, :, 0].max() <= 2.5 + 1e-12   # and never accepted
     with pytest.raises(RuntimeError, match="fatal"):
         oracle.sample_callback(s, 3, fn_addr(fixture_lib.fatal_logp))
+
+
+def test_crate_arithmetic_forms_give_the_same_decisions(oracle):
+    """the oracle carries tree weights as m * 2^e and the acceptance statistic as sum / count (the engine's
+    forms).  With the crate's own forms (SURVEY App. A.3 / A.6 verbatim: log_size + logaddexp + exp, running mean) ...
+    * bit 0, log-domain weights: EVERY decision and EVERY float of the five golden cases is unchanged — the weight form is
+      immaterial (same uniforms, thresholds never within rounding of them);
+    * bit 1, running mean: the statistic differs in the last bits, dual averaging passes that on to the step size
+      (~1e-16 relative) and the integrator amplifies it; decisions stay identical on four cases and fork at one draw of the
+      fifth (ar1_d257) — a rounding fork: the first draws agree to 1e-9."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(GOLDEN, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    keys = ("depth", "n_steps", "index_in_trajectory", "diverging", "maxdepth_reached")
+    forks = {}
+    for name, (kw, mspec) in mg.CASES.items():
+        margs = mg.model_args(mspec)
+        base = oracle.sample_tridiag(oracle.default_settings(**kw), **margs)
+        logw = oracle.sample_tridiag(oracle.default_settings(crate_arithmetic=1, **kw), **margs)
+        for k in keys + ("energy", "step_size", "mean_tree_accept"):
+            assert np.array_equal(base.stats[k], logw.stats[k]), (name, k)
+        assert np.array_equal(base.draws, logw.draws), name
+        run = oracle.sample_tridiag(oracle.default_settings(crate_arithmetic=3, **kw), **margs)
+        same = all(np.array_equal(base.stats[k], run.stats[k]) for k in keys)
+        if not same:
+            bad = np.argwhere(base.stats["n_steps"] != run.stats["n_steps"])
+            chain, draw = (int(v) for v in bad[0])
+            forks[name] = (chain, draw)
+            # a rounding fork, not a different algorithm: the first draws agree to 1e-9 (the perturbation then grows
+            # exponentially along the trajectories of the early warm-up — 1e-2 in position by the time a U-turn test flips)
+            assert draw > 10
+            np.testing.assert_allclose(run.draws[chain, :4], base.draws[chain, :4], rtol=1e-9, atol=1e-12)
+            np.testing.assert_allclose(run.stats["mean_tree_accept"][chain, :4], base.stats["mean_tree_accept"][chain, :4], rtol=1e-9)
+        else:
+            np.testing.assert_allclose(run.stats["mean_tree_accept"], base.stats["mean_tree_accept"], rtol=1e-4, atol=1e-9)
+    assert set(forks) <= {"ar1_d257"}, forks
+
