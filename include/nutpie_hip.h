@@ -65,6 +65,10 @@ int nphip_settings_set_bool(nphip_settings_t*, const char* name, int v);
 int nphip_settings_set_str(nphip_settings_t*, const char* name, const char* v);
 int nphip_settings_get_f64(const nphip_settings_t*, const char* name, double* out);
 int nphip_settings_get_u64(const nphip_settings_t*, const char* name, uint64_t* out);
+/* Host-driven adaptation hook (used by the low-rank metric, nutpie_amd/low_rank.py — the N4 row of SURVEY.md §8f): every
+ * chain stops between two draws when it has finished exactly draws[i] draws (at most 16 entries, increasing); see
+ * nphip_sampler_waiting / nphip_sampler_resume_at. */
+int nphip_settings_set_pause_draws(nphip_settings_t*, uint64_t n, const uint64_t* draws);
 /* JSON of the nested settings (the "settings" value of as_dict(), wrapper.rs:755-769);
  * returns needed length incl. NUL; writes at most cap bytes. */
 int64_t nphip_settings_to_json(const nphip_settings_t*, char* buf, int64_t cap);
@@ -202,6 +206,14 @@ int nphip_sampler_copy_stat(nphip_sampler_t*, const char* name, void* host_out, 
  * host_out[local_chain][draw][expanded_dim], fp64; rows of draws a chain has not finished are NaN.  Needs store_draws.
  * Also reachable as nphip_sampler_copy_stat(s, "expanded", ...). */
 int nphip_sampler_copy_expanded(nphip_sampler_t*, void* host_out, uint64_t nbytes);
+/* Chains stopped at a pause draw: mask[local_chain] = 1 (2 = finished or failed, 0 = running; mask may be NULL); returns the
+ * number of waiting chains, or < 0 on error. */
+int64_t nphip_sampler_waiting(nphip_sampler_t*, uint8_t* mask);
+/* Resume waiting chains at new positions (positions[n][dim], host memory, or device memory if on_device): each chain
+ * re-enters the initial-point sequence there — logp and gradient, mass matrix from the gradient, step-size search — and goes
+ * on with its next draw; draw counter, trace and RNG streams continue.  What the host changed in between (e.g. the linear
+ * map a wrapped model applies) is the host's business.  Manual-mode samplers only (the caller drives nphip_sampler_step). */
+int nphip_sampler_resume_at(nphip_sampler_t*, uint64_t n, const uint64_t* local_chains, const double* positions, int on_device);
 /* Developer aid: per-section cycle counters summed over chains; all zero unless the library was built
  * with -DNPHIP_PROFILE.  [0] leapfrog cycles [1] tree cycles (hot) [2] draw-end cycles [3..5] their counts. */
 int nphip_sampler_profile(nphip_sampler_t*, int64_t out[16]);

@@ -151,6 +151,10 @@ def lib():
             L.nphip_model_expanded_dim.argtypes = [C.c_void_p]
             L.nphip_model_expanded_dim.restype = C.c_uint64
             L.nphip_sampler_copy_expanded.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+            L.nphip_settings_set_pause_draws.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
+            L.nphip_sampler_waiting.argtypes = [C.c_void_p, C.c_void_p]
+            L.nphip_sampler_waiting.restype = C.c_int64
+            L.nphip_sampler_resume_at.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int]
             L.nphip_launch_defaults.argtypes = [C.POINTER(_Launch)]
             L.nphip_abi_struct_size.restype = C.c_uint64
             L.nphip_abi_struct_size.argtypes = [C.c_int]
@@ -208,11 +212,13 @@ _OPT_F64_KEYS = {"target_integration_time", "mass_matrix_eigval_cutoff", "mass_m
 class PyNutsSettings:
     """Settings object with the reference's flat attribute names (wrapper.rs:210-451, 563-620)."""
 
-    __slots__ = ("_h", "_adaptation")
+    __slots__ = ("_h", "_adaptation", "_low_rank")
 
-    def __init__(self, handle, adaptation="diag"):
+    def __init__(self, handle, adaptation="diag", low_rank=None):
         object.__setattr__(self, "_h", handle)
         object.__setattr__(self, "_adaptation", adaptation)
+        # options of adaptation="low_rank" (src/wrapper.rs:307-334); kept on the Python side, where that adaptation lives
+        object.__setattr__(self, "_low_rank", dict(low_rank or {}))
 
     # wrapper.rs:717-737
     @staticmethod
@@ -223,7 +229,13 @@ class PyNutsSettings:
 
     @staticmethod
     def LowRank(seed=None):
-        raise NotImplementedError("adaptation='low_rank' is outside the scope of the HIP engine (diag / draw_diag only)")
+        """``PyNutsSettings::LowRank`` (wrapper.rs:725-729).  The engine's diag-NUTS kernels run on linearly transformed
+        coordinates (nutpie_amd/low_rank.py); ``mass_matrix_eigval_cutoff`` (> 1) and ``mass_matrix_gamma`` (> 0) as in
+        python/nutpie/sample.py:921-933 — defaults 2.0 and 1e-5 (the docstring there says 100, its own example uses 3)."""
+        s = PyNutsSettings.Diag(seed)
+        object.__setattr__(s, "_adaptation", "low_rank")
+        object.__setattr__(s, "_low_rank", {"mass_matrix_eigval_cutoff": 2.0, "mass_matrix_gamma": 1e-5})
+        return s
 
     @staticmethod
     def Flow(seed=None):
@@ -237,11 +249,21 @@ class PyNutsSettings:
             pass
 
     def clone(self):
-        return PyNutsSettings(C.c_void_p(lib().nphip_settings_clone(self._h)), self._adaptation)
+        return PyNutsSettings(C.c_void_p(lib().nphip_settings_clone(self._h)), self._adaptation, self._low_rank)
 
     def _apply_update(self, name: str, value):
         L = lib()
         key = name.encode()
+        if self._adaptation == "low_rank" and name in ("mass_matrix_eigval_cutoff", "mass_matrix_gamma"):
+            if value is None:
+                return
+            v = float(value)
+            if name == "mass_matrix_eigval_cutoff" and not v > 1.0:
+                raise ValueError("mass_matrix_eigval_cutoff must be greater than one")
+            if name == "mass_matrix_gamma" and not v > 0.0:
+                raise ValueError("mass_matrix_gamma must be positive")
+            self._low_rank[name] = v
+            return
         if name == "step_size_adapt_method":
             if not isinstance(value, str):
                 raise ValueError("step_size_adapt_method must be a string")
@@ -274,6 +296,8 @@ class PyNutsSettings:
         self._apply_update(name, value)
 
     def __getattr__(self, name):
+        if name in ("mass_matrix_eigval_cutoff", "mass_matrix_gamma") and object.__getattribute__(self, "_adaptation") == "low_rank":
+            return object.__getattribute__(self, "_low_rank")[name]
         L = lib()
         out = C.c_uint64()
         if L.nphip_settings_get_u64(self._h, name.encode(), C.byref(out)) == NPHIP_OK:
@@ -283,13 +307,23 @@ class PyNutsSettings:
             return outf.value
         raise AttributeError(_err())
 
+    def set_pause_draws(self, draws):
+        """Host-driven adaptation hook: chains stop (``PySampler.waiting``) after exactly these numbers of finished draws."""
+        d = np.ascontiguousarray(sorted(int(x) for x in draws), dtype=np.uint64)
+        _check_setting(lib().nphip_settings_set_pause_draws(self._h, C.c_uint64(len(d)), d.ctypes.data_as(C.c_void_p)))
+
     def as_dict(self):
         """``{"sampler", "adaptation", "settings": nested}`` as wrapper.rs:755-769."""
         L = lib()
         need = L.nphip_settings_to_json(self._h, None, 0)
         buf = C.create_string_buffer(int(need))
         L.nphip_settings_to_json(self._h, buf, need)
-        return {"sampler": "nuts", "adaptation": "diag", "settings": json.loads(buf.value.decode())}
+        nested = json.loads(buf.value.decode())
+        if self._adaptation == "low_rank":
+            nested["adapt_options"]["mass_matrix_options"] = {
+                "store_mass_matrix": nested["adapt_options"]["mass_matrix_options"]["store_mass_matrix"],
+                "gamma": self._low_rank["mass_matrix_gamma"], "eigval_cutoff": self._low_rank["mass_matrix_eigval_cutoff"]}
+        return {"sampler": "nuts", "adaptation": self._adaptation, "settings": nested}
 
 
 class PyMclmcSettings:
@@ -665,6 +699,32 @@ class PySampler:
 
     def device_ptr(self, name):
         return lib().nphip_sampler_device_ptr(self._h, name.encode())
+
+    def waiting_codes(self):
+        """Per local chain: 0 running, 1 stopped at a pause draw (``PyNutsSettings.set_pause_draws``), 2 finished / failed."""
+        self._require()
+        mask = np.zeros(self.num_chains, dtype=np.uint8)
+        if lib().nphip_sampler_waiting(self._h, mask.ctypes.data_as(C.c_void_p)) < 0:
+            raise RuntimeError(_err())
+        return mask
+
+    def waiting(self):
+        return self.waiting_codes() == 1
+
+    def resume_at(self, chains, positions):
+        """Resume waiting chains at new positions: ``positions`` is a numpy array ``[n, dim]`` or a CUDA tensor."""
+        self._require()
+        ch = np.ascontiguousarray(chains, dtype=np.uint64)
+        if hasattr(positions, "data_ptr"):
+            pos = positions.contiguous()
+            assert tuple(pos.shape) == (len(ch), self.dim) and str(pos.dtype) == "torch.float64"
+            rc = lib().nphip_sampler_resume_at(self._h, C.c_uint64(len(ch)), ch.ctypes.data_as(C.c_void_p), C.c_void_p(pos.data_ptr()), 1)
+        else:
+            pos = np.ascontiguousarray(positions, dtype=np.float64)
+            assert pos.shape == (len(ch), self.dim)
+            rc = lib().nphip_sampler_resume_at(self._h, C.c_uint64(len(ch)), ch.ctypes.data_as(C.c_void_p), pos.ctypes.data_as(C.c_void_p), 0)
+        if rc != NPHIP_OK:
+            raise RuntimeError(_err())
 
     def expanded(self):
         """The model's expand function over the stored trace: ``[chain, draw, expanded_dim]`` (NaN rows for unfinished draws);

@@ -19,6 +19,7 @@ enum Phase : int64_t {
     PH_TREE = 4,       // waiting for a leapfrog inside the NUTS tree
     PH_DONE = 5,
     PH_ERROR = 6,
+    PH_WAIT_HOST = 7,  // stopped after a draw listed in DevSettings::pause_draws: the host re-parametrises the chain and resumes it
 };
 
 enum ChainError : int64_t {
@@ -111,6 +112,10 @@ struct DevSettings {
     int32_t adapt_adam, pad1_;
     int32_t init_kind, num_try_init;
     int32_t store_draws, store_gradient, store_mass_matrix, store_divergences;
+    // host-driven adaptation (low-rank metric as a linear re-parametrisation, nutpie_amd/low_rank.py): a chain stops
+    // (PH_WAIT_HOST) when it has finished exactly pause_draws[i] draws
+    int32_t n_pause, pad2_;
+    int64_t pause_draws[16];
 };
 
 // ---- kernel arguments -------------------------------------------------------------------
@@ -154,7 +159,7 @@ struct Args {
     int32_t lean;         // 1: lean register-resident kernel (W = 8, reg_nv chunks per wave, sigma^2 in dynamic LDS)
     int32_t max_evals;    // fused: evaluations per chain this launch
     int32_t have_result;  // callbacks: geval/ueval hold the answer to the pending request
-    unsigned long long* counters;  // [0] chains done, [1] chains in error
+    unsigned long long* counters;  // [0] chains done, [1] chains in error, [2] chains that entered PH_WAIT_HOST (cumulative)
     // pipelined host-callback groups (host.hip: iteration_pipelined)
     unsigned int* grp_arrive;               // device [groups]: chains of the group that finished the current launch
     volatile unsigned long long* grp_flag;  // pinned host [groups][4]: launch sequence number, chains done, chains in error, -

@@ -26,6 +26,7 @@
 
 namespace nphip {
 hipError_t launch_advance(const Args& a, const Args* d_args, bool fused, int W, hipStream_t st, const LaunchSlice* slice = nullptr);
+hipError_t launch_resume(const Args* d_args, int n, const int64_t* d_chains, const double* d_pos, bool fused, hipStream_t st);
 hipError_t launch_test_detmath(int fn, uint64_t n, const double* x, double* y, hipStream_t st);
 hipError_t launch_test_dot(int W, uint64_t n, const double* x, const double* y, double* out, hipStream_t st);
 }  // namespace nphip
@@ -69,6 +70,7 @@ struct nphip_settings {
     // engine knobs (not in the reference)
     bool adapt_mass_matrix = true;
     uint64_t num_try_init = 100;
+    std::vector<uint64_t> pause_draws;   // host-driven adaptation hook (nphip_settings_set_pause_draws)
 };
 
 static int unknown_attr(const char* name) {
@@ -139,6 +141,14 @@ int nphip_settings_set_u64(nphip_settings_t* s, const char* name, uint64_t v) {
     else if (n == "seed") s->seed = v;
     else if (n == "num_try_init") s->num_try_init = v;
     else return unknown_attr(name);
+    return NPHIP_OK;
+}
+
+int nphip_settings_set_pause_draws(nphip_settings_t* s, uint64_t n, const uint64_t* draws) {
+    if (n > 16) return bad_value("at most 16 pause draws");
+    for (uint64_t i = 1; i < n; ++i)
+        if (draws[i] <= draws[i - 1]) return bad_value("pause draws must be increasing");
+    s->pause_draws.assign(draws, draws + n);
     return NPHIP_OK;
 }
 
@@ -577,6 +587,8 @@ bool nphip_sampler::setup() {
     s.init_kind = model.init_kind; s.num_try_init = (int32_t)set.num_try_init;
     s.store_draws = launch.store_draws; s.store_gradient = set.store_gradient;
     s.store_mass_matrix = set.store_mass_matrix; s.store_divergences = set.store_divergences;
+    s.n_pause = (int32_t)set.pause_draws.size();
+    for (size_t i = 0; i < set.pause_draws.size(); ++i) s.pause_draws[i] = (int64_t)set.pause_draws[i];
 
     args.n_chains = (int64_t)n;
     args.chain_offset = (int64_t)launch.chain_offset;
@@ -624,7 +636,7 @@ bool nphip_sampler::setup() {
     if (!dalloc(&args.pslots, n * args.npslots * 2 * ld)) return false;
     if (!dalloc(&args.sig2, n * ld)) return false;
     if (!dalloc(&args.est, n * 8 * ld)) return false;
-    if (!dalloc(&args.counters, 2)) return false;
+    if (!dalloc(&args.counters, 4)) return false;
     if (fused) {
         double *mu = nullptr, *a = nullptr, *b = nullptr;
         if (!dalloc(&mu, ld) || !dalloc(&a, ld) || !dalloc(&b, ld)) return false;
@@ -1168,6 +1180,44 @@ int nphip_sampler_copy_stat(nphip_sampler_t* s, const char* name, void* host_out
     if (!s->sync_all()) return NPHIP_ERR;
     if (!hip_ok(hipMemcpy(host_out, p, bytes, hipMemcpyDeviceToHost), "copy trace")) return NPHIP_ERR;
     return NPHIP_OK;
+}
+
+int64_t nphip_sampler_waiting(nphip_sampler_t* s, uint8_t* mask) {
+    std::vector<Ctl> h;
+    if (!read_ctl(s, h)) return -1;
+    int64_t cnt = 0;
+    for (uint64_t i = 0; i < s->n; ++i) {
+        const bool w = h[i].phase == PH_WAIT_HOST;
+        if (mask) mask[i] = w ? 1 : ((h[i].phase == PH_DONE || h[i].phase == PH_ERROR) ? 2 : 0);
+        cnt += w ? 1 : 0;
+    }
+    return cnt;
+}
+
+int nphip_sampler_resume_at(nphip_sampler_t* s, uint64_t n, const uint64_t* chains, const double* positions, int on_device) {
+    if (!s->manual) { set_error("nphip_sampler_resume_at needs a sampler created with launch.manual = 1"); return NPHIP_ERR; }
+    if (n == 0) return NPHIP_OK;
+    for (uint64_t i = 0; i < n; ++i)
+        if (chains[i] >= s->n) { set_error("chain index out of range"); return NPHIP_ERR; }
+    std::lock_guard<std::mutex> run_lk(s->mu_run);
+    (void)hipSetDevice(s->device);
+    if (!s->sync_all()) return NPHIP_ERR;
+    int64_t* d_ch = nullptr;
+    double* d_pos = nullptr;
+    std::vector<int64_t> ch(chains, chains + n);
+    bool ok = hip_ok(hipMalloc((void**)&d_ch, n * 8), "hipMalloc");
+    if (ok) ok = hip_ok(hipMemcpy(d_ch, ch.data(), n * 8, hipMemcpyHostToDevice), "H2D chains");
+    if (ok && !on_device) {
+        ok = hip_ok(hipMalloc((void**)&d_pos, n * s->dim * 8), "hipMalloc") &&
+             hip_ok(hipMemcpy(d_pos, positions, n * s->dim * 8, hipMemcpyHostToDevice), "H2D positions");
+    }
+    if (ok) ok = hip_ok(launch_resume(s->d_args, (int)n, d_ch, on_device ? positions : d_pos, s->fused, s->stream), "launch k_resume") &&
+                 hip_ok(hipStreamSynchronize(s->stream), "hipStreamSynchronize");
+    if (d_ch) (void)hipFree(d_ch);
+    if (d_pos) (void)hipFree(d_pos);
+    // callback models: the staged positions changed after the last evaluation — the next launch must not consume its results
+    s->manual_have = 0;
+    return ok ? NPHIP_OK : NPHIP_ERR;
 }
 
 int nphip_sampler_profile(nphip_sampler_t* s, int64_t out[16]) {

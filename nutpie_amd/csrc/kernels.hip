@@ -2111,6 +2111,13 @@ struct Machine {
             A.st_accept_sym[o] = c->acc_sym_sum;
         }
         c->draw = draw + 1;
+        for (int i = 0; i < A.s.n_pause; ++i) {
+            if (A.s.pause_draws[i] == draw + 1 && draw + 1 < T) {   // the host takes over between two draws (engine_types.h: PH_WAIT_HOST)
+                c->phase = PH_WAIT_HOST;
+                if (leader()) atomicAdd(&A.counters[2], 1ull);
+                return;
+            }
+        }
 #ifdef NPHIP_PROFILE
         const int64_t t0_ = (int64_t)__builtin_readcyclecounter();
 #endif
@@ -2143,7 +2150,7 @@ struct Machine {
     __device__ __forceinline__ void run(int budget, bool have, LdsDouble sig_copy = nullptr) {
         for (;;) {
             const int64_t ph = c->phase;
-            if (ph == PH_DONE || ph == PH_ERROR) break;
+            if (ph == PH_DONE || ph == PH_ERROR || ph == PH_WAIT_HOST) break;
             if (ph != PH_START) {
                 if (FUSED) {
                     if (budget <= 0) break;
@@ -2406,6 +2413,34 @@ static hipError_t launch_w(const Args& a, const Args* d_args, int W, hipStream_t
     return hipGetLastError();
 #endif
 #endif
+}
+
+// Resume chains stopped in PH_WAIT_HOST at new positions (host-driven re-parametrisation): the position goes to Q-pool buffer 0
+// (and the callback staging row), the chain re-enters the initial-point sequence — evaluate, mass matrix from the gradient,
+// step-size search — and continues with its next draw.  One block per resumed chain.
+__global__ void k_resume(const Args* __restrict__ Ap, int n, const int64_t* __restrict__ chains, const double* __restrict__ pos, int fused) {
+    const Args& A = *Ap;
+    if ((int)blockIdx.x >= n) return;
+    const int64_t ch = chains[blockIdx.x];
+    Ctl* c = A.ctl + ch;
+    if (c->phase != PH_WAIT_HOST) return;
+    double* q = A.qpool + (size_t)ch * A.nqpool * 2 * A.ld;
+    for (int64_t i = threadIdx.x; i < A.ld; i += blockDim.x) {
+        const double v = i < A.dim ? pos[(size_t)blockIdx.x * A.dim + i] : 0.0;
+        q[i] = v;
+        if (!fused && i < A.dim) A.qeval[(size_t)ch * A.dim + i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        c->init_attempt = 0;
+        c->eval_buf = 0;
+        c->phase = PH_INIT_EVAL;
+    }
+}
+
+hipError_t launch_resume(const Args* d_args, int n, const int64_t* d_chains, const double* d_pos, bool fused, hipStream_t st) {
+    hipLaunchKernelGGL(k_resume, dim3((unsigned)n), dim3(256), 0, st, d_args, n, d_chains, d_pos, fused ? 1 : 0);
+    return hipGetLastError();
 }
 
 hipError_t launch_advance(const Args& a, const Args* d_args, bool fused, int W, hipStream_t st, const LaunchSlice* slice) {

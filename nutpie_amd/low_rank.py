@@ -1,0 +1,324 @@
+"""``adaptation="low_rank"`` — a low-rank modified mass matrix on the HIP engine.
+
+What the reference does (``PyNutsSettings::LowRank``, src/wrapper.rs:307-334, 725-729; python/nutpie/sample.py:921-933;
+docs/sampling-options.qmd:124-144): nuts-rs adapts a mass matrix ``M^-1 = D^1/2 (I + V (Lambda - I) V') D^1/2`` — a diagonal
+scaling plus a rank-k correction whose eigenvalues are those of the geometric mean of the draw covariance and the inverse
+gradient covariance that lie outside ``[1/cutoff, cutoff]`` (``mass_matrix_eigval_cutoff``), regularised by
+``mass_matrix_gamma``.  The crate is not in the tree; the estimator below follows that published description (Seyboldt et al.,
+"Preconditioning Hamiltonian Monte Carlo by minimizing Fisher divergence") — PARITY UNPINNED, like the rest of the sampler.
+
+How it is built here — MI355X-first, not a translation: HMC with metric ``M^-1 = L L'`` on ``x`` IS HMC with the identity metric
+on ``y = L^-1 (x - m)`` (same trajectories, same energies, same U-turn products), so the engine keeps running its diag-NUTS
+kernels unchanged, on ``y``, and the metric lives in the batched model evaluation:
+
+    x = m + s * (y + V ((sqrt(lambda) - 1) * (V' y)))          one [chains, D] x [chains, D, k] contraction each way,
+    grad_y = L' grad_x                                         on the GPU, inside the callback the engine already calls
+
+The engine contributes one generic hook (include/nutpie_hip.h: ``nphip_settings_set_pause_draws`` / ``nphip_sampler_waiting`` /
+``nphip_sampler_resume_at``): chains stop between two draws at the window boundaries; the host estimates every chain's new
+``(m, s, V, lambda)`` from the window's draws and gradients — batched ``eigh`` on the GPU, all chains at once — rewrites the
+finished part of the trace into model space, maps every chain's position into its new coordinates and resumes.  Inside a
+window the engine's own diagonal adaptation keeps running in ``y`` (it mops up what rank k cannot express), and its step-size
+search restarts after every switch, as nuts-rs does when the mass matrix changes.
+"""
+
+from __future__ import annotations
+
+import threading
+import time
+from dataclasses import dataclass
+
+import numpy as np
+
+K_MAX = 16            # columns kept per chain (the reference has no such knob; windows of <= 64 draws span <= 128 directions)
+WINDOW_MAX = 64       # draws (and gradients) per estimate
+SWITCH_FRACTIONS = (0.08, 0.2, 0.4, 0.65)   # of num_tune: window boundaries; the last leaves 35 % of warm-up to the step size
+
+
+@dataclass
+class Transform:
+    """x = mean + stds * (y + V (d * (V' y))), batched over chains; ``d = sqrt(lambda) - 1`` (0 = column unused)."""
+
+    mean: "object"   # [n, D]
+    stds: "object"   # [n, D]
+    V: "object"      # [n, D, k]
+    d: "object"      # [n, k]
+
+    @staticmethod
+    def identity(n, D, device):
+        import torch
+
+        z = lambda *s: torch.zeros(*s, dtype=torch.float64, device=device)  # noqa: E731
+        return Transform(z(n, D), torch.ones(n, D, dtype=torch.float64, device=device), z(n, D, K_MAX), z(n, K_MAX))
+
+    def _apply(self, v, coef):
+        # v + V (coef * (V' v)), v: [n, (m,) D]
+        import torch
+
+        if v.dim() == 2:
+            t = torch.einsum("ndk,nd->nk", self.V, v) * coef
+            return v + torch.einsum("ndk,nk->nd", self.V, t)
+        t = torch.einsum("ndk,nmd->nmk", self.V, v) * coef[:, None, :]
+        return v + torch.einsum("ndk,nmk->nmd", self.V, t)
+
+    def _b(self, a, like):
+        return a if like.dim() == 2 else a[:, None, :]
+
+    def forward(self, y):
+        return self._b(self.mean, y) + self._b(self.stds, y) * self._apply(y, self.d)
+
+    def inverse(self, x):
+        dinv = 1.0 / (1.0 + self.d) - 1.0
+        return self._apply((x - self._b(self.mean, x)) / self._b(self.stds, x), dinv)
+
+    def grad_to_y(self, gx):   # L' gx
+        return self._apply(self._b(self.stds, gx) * gx, self.d)
+
+    def grad_to_x(self, gy):   # L'^-1 gy
+        dinv = 1.0 / (1.0 + self.d) - 1.0
+        return self._apply(gy, dinv) / self._b(self.stds, gy)
+
+    def eigenvalues(self):
+        return (1.0 + self.d) ** 2
+
+
+def estimate(x, gx, gamma: float, cutoff: float, k_max: int = K_MAX) -> Transform:
+    """The low-rank metric of every chain from its window: ``x``, ``gx``: [n, m, D] draws and gradients in model space.
+
+    scaling      s_i = sqrt(std(x_i) / std(g_i))                       (the diagonal "diag" adaptation uses the same ratio,
+                                                                        python/nutpie/normalizing_flow.py:1906-1915)
+    subspace     orthonormal Q of span{scaled draws, scaled gradients}  (eigh of the 2m x 2m Gram matrix)
+    projected    Cx = Px'Px / m + gamma I,  Cg = Pg'Pg / m + gamma I
+    metric       S = Cx # Cg^-1 (geometric mean: S Cg S = Cx), eigh(S) -> the k_max eigenvalues furthest from 1 in log scale
+                 among those outside [1/cutoff, cutoff]; V = Q W
+    """
+    import torch
+
+    n, m, D = x.shape
+    mean = x.mean(1)
+    sx = x.std(1, unbiased=True)
+    sg = gx.std(1, unbiased=True)
+    stds = torch.sqrt(sx / sg)
+    stds = torch.where(torch.isfinite(stds) & (stds > 0), stds, torch.ones_like(stds)).clamp(1e-10, 1e10)
+    X = (x - mean[:, None, :]) / stds[:, None, :]
+    G = (gx - gx.mean(1, keepdim=True)) * stds[:, None, :]
+    Z = torch.cat([X, G], 1)                                   # [n, 2m, D]
+    ev, U = torch.linalg.eigh(Z @ Z.transpose(1, 2))           # [n, 2m], [n, 2m, 2m]
+    keep = ev > (1e-10 * ev[:, -1:].clamp_min(1e-300))
+    scale = torch.where(keep, ev.clamp_min(1e-300).rsqrt(), torch.zeros_like(ev))
+    Q = Z.transpose(1, 2) @ (U * scale[:, None, :])            # [n, D, 2m], orthonormal columns (zero where dropped)
+    Px, Pg = X @ Q, G @ Q                                      # [n, m, 2m]
+    eye = torch.eye(2 * m, dtype=x.dtype, device=x.device)
+    Cx = Px.transpose(1, 2) @ Px / m + gamma * eye
+    Cg = Pg.transpose(1, 2) @ Pg / m + gamma * eye
+    # S = Cg^-1/2 (Cg^1/2 Cx Cg^1/2)^1/2 Cg^-1/2
+    eg, Ug = torch.linalg.eigh(Cg)
+    eg = eg.clamp_min(1e-300)
+    half = (Ug * eg.sqrt()[:, None, :]) @ Ug.transpose(1, 2)
+    ihalf = (Ug * eg.rsqrt()[:, None, :]) @ Ug.transpose(1, 2)
+    em, Um = torch.linalg.eigh(half @ Cx @ half)
+    mid = (Um * em.clamp_min(0).sqrt()[:, None, :]) @ Um.transpose(1, 2)
+    S = ihalf @ mid @ ihalf
+    es, W = torch.linalg.eigh(0.5 * (S + S.transpose(1, 2)))
+    es = es.clamp_min(1e-300)
+    score = es.log().abs()
+    outside = score > float(np.log(cutoff))
+    score = torch.where(outside, score, torch.full_like(score, -1.0))
+    k = min(k_max, 2 * m)
+    top = torch.topk(score, k, dim=1)
+    sel = top.indices                                           # [n, k]
+    lam = torch.gather(es, 1, sel)
+    used = top.values > 0
+    Wsel = torch.gather(W, 2, sel[:, None, :].expand(n, 2 * m, k))
+    V = Q @ Wsel                                                # [n, D, k]
+    d = torch.where(used, lam.sqrt() - 1.0, torch.zeros_like(lam))
+    V = V * used[:, None, :].to(V.dtype)
+    if k < k_max:
+        V = torch.cat([V, torch.zeros(n, D, k_max - k, dtype=V.dtype, device=V.device)], 2)
+        d = torch.cat([d, torch.zeros(n, k_max - k, dtype=d.dtype, device=d.device)], 1)
+    return Transform(mean, stds, V.contiguous(), d.contiguous())
+
+
+def pause_draws(num_tune: int):
+    out = sorted({int(round(f * num_tune)) for f in SWITCH_FRACTIONS if int(round(f * num_tune)) >= 12})
+    return [d for d in out if d < num_tune]
+
+
+class LowRankSampler:
+    """A ``PySampler`` in manual mode plus the host thread that drives it and adapts the metric at the window boundaries.
+    Same handle surface as ``PySampler`` (wait / pause / resume / abort / is_finished / progress / inspect / take_results)."""
+
+    def __init__(self, inner, state, device, gamma, cutoff, pauses):
+        self._inner = inner
+        self._state = state           # dict shared with the model callback: {"T": Transform, "identity": bool}
+        self._device = device
+        self._gamma, self._cutoff = float(gamma), float(cutoff)
+        self._pauses = list(pauses)
+        self._next = 0                # index of the next pause
+        self._seg_lo = 0              # first draw of the segment still held in y coordinates
+        self._lock = threading.Lock()
+        self._cv = threading.Condition(self._lock)
+        self._paused = False
+        self._abort = False
+        self._done = False
+        self._error = None
+        self.switch_log = []          # (draws finished, mean number of columns used, seconds spent estimating)
+        self._thread = threading.Thread(target=self._run, daemon=True)
+        self._thread.start()
+
+    # ------------------------------------------------------------------ driver
+    def _run(self):
+        try:
+            while True:
+                with self._cv:
+                    while self._paused and not self._abort:
+                        self._cv.wait()
+                    if self._abort:
+                        break
+                done, _, _ = self._inner.step(64)
+                if done:
+                    break
+                if self._next < len(self._pauses):
+                    code = self._inner.waiting_codes()
+                    if (code == 1).any() and not (code == 0).any():
+                        self._adapt(np.nonzero(code == 1)[0])
+            self._convert_tail_in_place()
+        except BaseException as e:  # noqa: BLE001 - reported by wait()
+            self._error = e
+        finally:
+            with self._cv:
+                self._done = True
+                self._cv.notify_all()
+
+    def _views(self):
+        from nutpie_amd.distributed import device_tensor
+
+        n, T, D = self._inner.num_chains, self._inner.total_draws, self._inner.dim
+        draws = device_tensor(self._inner.device_ptr("draws"), (n, T, D), "float64", self._device)
+        gp = self._inner.device_ptr("gradient")
+        grads = device_tensor(gp, (n, T, D), "float64", self._device) if gp else None
+        return draws, grads
+
+    def _adapt(self, chains):
+        import torch
+
+        t0 = time.perf_counter()
+        hi = self._pauses[self._next]
+        lo = self._seg_lo
+        draws, grads = self._views()
+        T_old = self._state["T"]
+        with torch.no_grad():
+            if not self._state["identity"]:
+                draws[:, lo:hi] = T_old.forward(draws[:, lo:hi])
+                grads[:, lo:hi] = T_old.grad_to_x(grads[:, lo:hi])
+            m = min(WINDOW_MAX, max(4, (hi - lo) * 2 // 3))
+            x, gx = draws[:, hi - m:hi], grads[:, hi - m:hi]
+            T_new = estimate(x, gx, self._gamma, self._cutoff)
+            y_new = T_new.inverse(draws[:, hi - 1])
+            torch.cuda.synchronize(self._device)
+        self._state["T"], self._state["identity"] = T_new, False
+        self._seg_lo = hi
+        self._next += 1
+        self._inner.resume_at(chains, y_new[torch.as_tensor(chains, device=y_new.device)] if len(chains) != y_new.shape[0] else y_new)
+        self.switch_log.append((hi, float((T_new.d != 0).sum(1).double().mean()), time.perf_counter() - t0))
+
+    def _convert_tail_in_place(self):
+        """After the last draw: the segment since the last switch goes to model space too (per chain up to its finished draw)."""
+        import torch
+
+        if self._state["identity"]:
+            return
+        draws, grads = self._views()
+        with torch.no_grad():
+            lo = self._seg_lo
+            draws[:, lo:] = self._state["T"].forward(draws[:, lo:])
+            if grads is not None:
+                grads[:, lo:] = self._state["T"].grad_to_x(grads[:, lo:])
+            torch.cuda.synchronize(self._device)
+        self._seg_lo = self._inner.total_draws
+        self._state["identity"] = True   # the trace is in model space now; nothing is evaluated any more
+
+    # ------------------------------------------------------------------ handle surface
+    def wait(self, timeout_seconds=None):
+        with self._cv:
+            if self._paused:
+                self._paused = False
+                self._cv.notify_all()
+            end = None if timeout_seconds is None else time.monotonic() + timeout_seconds
+            while not self._done:
+                left = 0.1 if end is None else min(0.1, end - time.monotonic())
+                if end is not None and left <= 0:
+                    raise TimeoutError("Timeout while waiting for sampler to finish")
+                self._cv.wait(left)
+        if self._error is not None:
+            raise RuntimeError(str(self._error)) from self._error
+
+    def pause(self):
+        with self._cv:
+            self._paused = True
+
+    def resume(self):
+        with self._cv:
+            self._paused = False
+            self._cv.notify_all()
+
+    def abort(self):
+        with self._cv:
+            self._abort = True
+            self._cv.notify_all()
+        self._thread.join()
+        self._inner.abort()
+
+    def is_finished(self):
+        return self._done
+
+    def is_empty(self, ignore_error=False):
+        return self._inner.is_empty(ignore_error)
+
+    def _snapshot_patched(self, res):
+        # a trace read before the end still holds the current segment in y coordinates: patch the host copy
+        import torch
+
+        if self._state["identity"] or res.draws is None:
+            return res
+        lo = self._seg_lo
+        draws, grads = self._views()
+        with torch.no_grad():
+            res.draws[:, lo:] = self._state["T"].forward(draws[:, lo:]).cpu().numpy()
+            if grads is not None and "gradient" in res.stats:
+                res.stats["gradient"][:, lo:] = self._state["T"].grad_to_x(grads[:, lo:]).cpu().numpy()
+        return res
+
+    def inspect(self):
+        with self._cv:
+            was = self._paused
+            self._paused = True
+        try:
+            time.sleep(0.05)
+            dev_expand = self._inner.__dict__.pop("_device_expand", None) if not self._done else None
+            res = self._snapshot_patched(self._inner.inspect())
+            if dev_expand is not None:
+                self._inner._device_expand = dev_expand
+            return res
+        finally:
+            with self._cv:
+                self._paused = was
+                self._cv.notify_all()
+
+    def take_results(self):
+        self._thread.join()
+        return self._snapshot_patched(self._inner.take_results())
+
+    def close(self):
+        if not self._done:
+            self.abort()
+        self._inner.close()
+
+    def __getattr__(self, name):   # num_chains, dim, progress(), device_ptr(), seconds, ...
+        return getattr(self._inner, name)
+
+    def __setattr__(self, name, value):
+        if name.startswith("_") and name in ("_keep_host_draws", "_device_expand", "_keep_tensors"):
+            setattr(self._inner, name, value)
+        else:
+            object.__setattr__(self, name, value)

@@ -281,7 +281,8 @@ def sample(
 
     Keyword arguments, defaults and error behaviour follow ``nutpie.sample``
     (reference sample.py:823-1102).  ``adaptation`` accepts ``"diag"`` (default, draw+gradient
-    variance) and ``"draw_diag"``; ``"low_rank"``, ``"flow"`` and ``sampler="mclmc"`` raise
+    variance), ``"draw_diag"`` and — for batched device models (``from_torchfunc``) — ``"low_rank"`` with
+    ``mass_matrix_eigval_cutoff`` / ``mass_matrix_gamma``; ``"flow"`` and ``sampler="mclmc"`` raise
     ``NotImplementedError`` (out of scope for the HIP engine).  ``cores`` is accepted and ignored:
     all chains run concurrently on the GPU.
 
@@ -292,6 +293,10 @@ def sample(
     # behaviour (accepted keywords, warnings, error texts) documented at reference sample.py:979-1070; written independently
     adaptation, grad_based = _legacy_adaptation(adaptation, kwargs)
     settings = _settings_for(sampler, adaptation, seed)
+    if adaptation == "low_rank" and not getattr(compiled_model, "_supports_low_rank", False):
+        raise NotImplementedError(
+            "adaptation='low_rank' needs a batched device model (nutpie_amd.from_torchfunc / from_torch_density): the metric is "
+            "applied around the density on the GPU (nutpie_amd/low_rank.py)")
     if adaptation == "draw_diag" or grad_based is False:
         settings.use_grad_based_mass_matrix = False
     overrides = {"num_tune": tune, "num_draws": draws, "num_chains": chains}

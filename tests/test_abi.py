@@ -118,8 +118,15 @@ def test_settings_error_classes():
         s.num_tune = -5
     with pytest.raises(TypeError):
         s.store_gradient = 1
-    with pytest.raises(NotImplementedError):
-        PyNutsSettings.LowRank(1)
+    lr = PyNutsSettings.LowRank(1)                                                      # wrapper.rs:725-729, 307-334
+    assert lr.as_dict()["adaptation"] == "low_rank" and lr.mass_matrix_gamma == 1e-5
+    lr.update(mass_matrix_eigval_cutoff=3, mass_matrix_gamma=1e-4)
+    assert lr.as_dict()["settings"]["adapt_options"]["mass_matrix_options"] == {"store_mass_matrix": False, "gamma": 1e-4, "eigval_cutoff": 3.0}
+    with pytest.raises(ValueError, match="greater than one"):
+        lr.mass_matrix_eigval_cutoff = 1.0
+    with pytest.raises(ValueError, match="Option train_on_orbit not available"):
+        lr.train_on_orbit = True
+    assert lr.clone().mass_matrix_eigval_cutoff == 3.0
     with pytest.raises(NotImplementedError):
         PyNutsSettings.Flow(1)
     with pytest.raises(NotImplementedError):

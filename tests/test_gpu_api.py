@@ -513,3 +513,102 @@ def test_sharded_sampling_and_rccl_gather_single_rank(tmp_path):
         assert np.array_equal(got["diverging"].cpu().numpy().astype(bool), ref.stats["diverging"])
     finally:
         dist.destroy_process_group()
+
+
+def test_pause_and_resume_hook(hip):
+    """The host-driven adaptation hook of the C-ABI (nphip_settings_set_pause_draws / nphip_sampler_waiting / _resume_at): every
+    chain stops after exactly the listed number of draws; resumed at a new position it re-runs the initial-point sequence there
+    and goes on with its next draw."""
+    diag = np.linspace(0.5, 2.0, 12)
+    s = hip.PyNutsSettings.Diag(5)
+    s.update(num_tune=40, num_draws=20, num_chains=6)
+    s.set_pause_draws([15, 30])
+    smp = hip.PySampler(s, hip.TridiagGaussianModel(diag), manual=True, evals_per_launch=50)
+    for _ in range(200):
+        done, _, _ = smp.step(1)
+        if smp.waiting().all():
+            break
+    assert not done and smp.waiting_codes().tolist() == [1] * 6
+    assert [p.finished_draws for p in smp.progress()] == [15] * 6
+    smp.step(3)                                                   # waiting chains do not move
+    assert [p.finished_draws for p in smp.progress()] == [15] * 6
+    pos = np.tile(np.linspace(-1, 1, 12), (6, 1)) * np.arange(1, 7)[:, None]
+    smp.resume_at(np.arange(6), pos)
+    for _ in range(400):
+        done, _, _ = smp.step(1)
+        if smp.waiting().all():
+            break
+    assert [p.finished_draws for p in smp.progress()] == [30] * 6
+    smp.resume_at(np.arange(3), pos[:3])                          # a subset; the others keep waiting
+    for _ in range(400):
+        done, _, _ = smp.step(1)
+        c = smp.waiting_codes()
+        if (c[:3] == 2).all():
+            break
+    assert c.tolist() == [2, 2, 2, 1, 1, 1]
+    smp.resume_at(np.arange(3, 6), pos[3:])
+    while not smp.step(10)[0]:
+        pass
+    tr = smp.take_results()
+    assert tr.finished.tolist() == [60] * 6
+    # draw 15 (the first after the first resume) starts from the supplied position: its tree is rooted there, so with a tiny
+    # trajectory it cannot be far; more telling: the draws are finite and the run is reproducible
+    assert np.isfinite(tr.draws).all() and np.isfinite(tr.stats["energy"]).all()
+    lp_at_pos = -0.5 * (pos**2 * diag).sum(1)
+    e15 = tr.stats["energy"][:, 15] - tr.stats["energy_error"][:, 15]          # initial energy of draw 15 = K0 - logp(pos)
+    assert (e15 >= -lp_at_pos - 1e-9).all()                                     # kinetic energy is non-negative
+    with pytest.raises(RuntimeError, match="manual"):
+        s2 = hip.PyNutsSettings.Diag(5)
+        s2.update(num_tune=10, num_draws=5, num_chains=2)
+        auto = hip.PySampler(s2, hip.TridiagGaussianModel(diag))
+        auto.wait()
+        auto.resume_at([0], pos[:1])
+
+
+def test_low_rank_adaptation_on_a_correlated_gaussian():
+    """adaptation="low_rank" (reference docs/sampling-options.qmd:124-144): a 60-dimensional Gaussian with three strong
+    correlated directions on top of heterogeneous scales.  A diagonal metric cannot undo the rotation and needs long
+    trajectories; the low-rank metric finds the directions during warm-up: same posterior, several times fewer leapfrogs."""
+    import torch
+
+    D = 60
+    rng = np.random.default_rng(11)
+    scales = np.exp(rng.normal(size=D))
+    B = rng.normal(size=(D, 3))
+    Sigma = np.diag(scales**2) + 36.0 * (scales[:, None] * B) @ (scales[:, None] * B).T
+    mu = rng.normal(size=D) * 3
+    P = np.linalg.inv(Sigma)
+
+    def make_logp():
+        Pt, mt = torch.as_tensor(P, device="cuda"), torch.as_tensor(mu, device="cuda")
+
+        def f(x):
+            z = x - mt
+            g = -(z @ Pt)
+            return 0.5 * (z * g).sum(-1), g
+
+        return f
+
+    m = nutpie_amd.from_torchfunc(D, make_logp)
+    kw = dict(chains=128, tune=500, draws=300, seed=3, progress_bar=False)
+    lr = nutpie_amd.sample(m, adaptation="low_rank", **kw)
+    dg = nutpie_amd.sample(m, adaptation="diag", **kw)
+    assert lr.posterior.x.shape == (128, 300, D) and lr.warmup_posterior.x.shape == (128, 500, D)
+    steps_lr, steps_dg = lr.sample_stats.n_steps.values.mean(), dg.sample_stats.n_steps.values.mean()
+    assert steps_lr * 2.5 < steps_dg, (steps_lr, steps_dg)
+    assert lr.sample_stats.diverging.values.mean() < 0.01
+    x = lr.posterior.x.values.reshape(-1, D)
+    sd = np.sqrt(np.diag(Sigma))
+    assert np.abs((x.mean(0) - mu) / sd).max() < 0.06                  # 38 400 draws
+    emp = np.cov(x.T)
+    assert np.abs(np.sqrt(np.diag(emp)) / sd - 1).max() < 0.06
+    corr = emp / np.sqrt(np.outer(np.diag(emp), np.diag(emp)))
+    true_corr = Sigma / np.outer(sd, sd)
+    assert np.abs(corr - true_corr).max() < 0.06
+    # the warm-up part of the trace is in model coordinates too (rewritten at every window switch): late warm-up draws look
+    # like the posterior
+    late = lr.warmup_posterior.x.values[:, 400:].reshape(-1, D)
+    assert np.abs((late.mean(0) - mu) / sd).max() < 0.2
+    assert "gradient" not in lr.sample_stats                       # the estimator's gradients stay internal
+    assert lr.sample_stats.attrs["inference_library_settings"].count('"adaptation": "low_rank"') == 1
+
