@@ -121,8 +121,17 @@ def estimate(x, gx, gamma: float, cutoff: float, k_max: int = K_MAX) -> Transfor
     S = ihalf @ mid @ ihalf
     es, W = torch.linalg.eigh(0.5 * (S + S.transpose(1, 2)))
     es = es.clamp_min(1e-300)
+    # Re-centre the spectrum on its bulk.  With strong correlations sqrt(std(x) / std(g)) over-scales EVERY coordinate (std(x)
+    # carries the shared directions, std(g) the conditional precisions): a few eigenvalues end up large and all the others small
+    # (measured: 3 at ~500, 57 at ~0.03) — more directions than k_max columns can repair.  Dividing by the median eigenvalue
+    # (and folding it into the diagonal scaling) leaves the bulk at 1 and only the genuine outliers for the low-rank part.
+    live = ((W * W) * keep[:, :, None].to(W.dtype)).sum(1) > 0.5     # eigenvectors inside the span of the window (not the dropped columns of Q)
+    log_es = torch.where(live, es.log(), torch.full_like(es, float("nan")))
+    centre = torch.nan_to_num(torch.nanmedian(log_es, dim=1).values, nan=0.0).exp()       # [n]
+    es = es / centre[:, None]
+    stds = stds * centre.sqrt()[:, None]
     score = es.log().abs()
-    outside = score > float(np.log(cutoff))
+    outside = (score > float(np.log(cutoff))) & live
     score = torch.where(outside, score, torch.full_like(score, -1.0))
     k = min(k_max, 2 * m)
     top = torch.topk(score, k, dim=1)
