@@ -23,6 +23,23 @@ def zarr_store(*args, **kwargs):
     raise NotImplementedError("zarr_store is outside the scope of the HIP engine (the trace lives in HBM)")
 
 
+def install_as_nutpie(force: bool = False):
+    """Make ``import nutpie`` resolve to this package (``nutpie``, ``nutpie.sample``, ``nutpie.compiled_pyfunc``,
+    ``nutpie.compile_pymc``, ``nutpie.compile_stan``, ``nutpie._lib``): code written against the reference runs on the HIP
+    engine unchanged.  Opt-in, per process; refuses to shadow an installed reference unless ``force``."""
+    import importlib
+    import importlib.util
+    import sys
+
+    if not force and "nutpie" not in sys.modules and importlib.util.find_spec("nutpie") is not None:
+        raise RuntimeError("a real `nutpie` is importable in this environment; pass force=True to shadow it for this process")
+    me = sys.modules[__name__]
+    sys.modules["nutpie"] = me
+    for sub in ("sample", "compiled_pyfunc", "compile_pymc", "compile_stan", "_lib"):
+        sys.modules["nutpie." + sub] = importlib.import_module(__name__ + "." + sub)
+    return me
+
+
 __all__ = [
     "__version__",
     "ChainProgress",
@@ -39,4 +56,5 @@ __all__ = [
     "diag_gaussian",
     "ar1_gaussian",
     "dense_gaussian",
+    "install_as_nutpie",
 ]

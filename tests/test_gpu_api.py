@@ -204,6 +204,40 @@ def test_raw_expand_callback_through_the_c_abi(hip, oracle, fixture_lib):
     smp.close()
 
 
+def test_batched_device_expand_through_the_c_abi(hip):
+    """nphip_model_set_device_expand: the expand step as ONE batched call per block of stored draws, on the engine's stream
+     — here a callback that wraps the device pointers as torch tensors."""
+    import torch
+
+    from nutpie_amd.distributed import device_tensor
+
+    calls = []
+
+    def dev_expand(n_rows, dim, expanded, x_ptr, out_ptr, stream_ptr, _user):
+        x = device_tensor(x_ptr, (n_rows, dim), "float64", 0)
+        out = device_tensor(out_ptr, (n_rows, expanded), "float64", 0)
+        st = torch.cuda.ExternalStream(stream_ptr) if stream_ptr else torch.cuda.current_stream()
+        with torch.cuda.stream(st):
+            out[:, :dim] = x
+            out[:, dim] = (x * x).sum(1)
+        calls.append(int(n_rows))
+        return 0
+
+    cb = hip.DEVICE_EXPAND_FN(dev_expand)
+    m = hip.TridiagGaussianModel(np.linspace(0.5, 2.0, 7))
+    m.set_device_expand(8, ctypes.cast(cb, ctypes.c_void_p).value, keep_alive=cb)
+    s = hip.PyNutsSettings.Diag(2)
+    s.update(num_tune=30, num_draws=20, num_chains=9)
+    smp = hip.PySampler(s, m)
+    smp.wait()
+    ex = smp.expanded()
+    raw = smp._copy("draws", np.float64, vec=True)
+    assert ex.shape == (9, 50, 8) and sum(calls) == 9 * 50
+    assert np.array_equal(ex[..., :7], raw)
+    np.testing.assert_allclose(ex[..., 7], (raw**2).sum(-1), rtol=1e-14)
+    smp.close()
+
+
 def test_logp_return_is_read_as_c_int(hip, oracle, fixture_lib):
     # numba declares the callback int64 (compile_pymc.py:975-981), the reference reads c_int (src/pymc.rs:23-29): a return
     # register with a dirty upper half and a clean low word is "0 = ok" — identical trace to the clean function

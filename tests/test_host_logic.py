@@ -267,3 +267,21 @@ def test_stan_expand_passes_an_rng(monkeypatch, tmp_path):
     ex = m._expand_draws(draws, seed=7)
     assert ex["b"][0, 0] == 1.0 and np.isnan(ex["a"][0, 1]) and ex["t"][1, 1] == 3.0
     assert ex["g"][0, 0].tolist() == [7, -7] and ex["g"][1, 0].tolist() == [8, -8]      # one rng per chain, from the seed
+
+
+def test_install_as_nutpie_alias():
+    """`import nutpie` can resolve to the HIP engine (opt-in): the reference's import lines work unchanged."""
+    import os
+    import subprocess
+    import sys
+
+    code = (
+        "import nutpie_amd; nutpie_amd.install_as_nutpie();"
+        "import nutpie; from nutpie import _lib; from nutpie.sample import sample, CompiledModel;"
+        "from nutpie.compiled_pyfunc import from_pyfunc; from nutpie.compile_pymc import compile_pymc_model;"
+        "assert nutpie.sample is sample and nutpie.ChainProgress is _lib.PyChainProgress and nutpie.__version__;"
+        "print('alias ok')"
+    )
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root)
+    assert r.returncode == 0 and "alias ok" in r.stdout, r.stderr
