@@ -163,7 +163,13 @@ typedef struct {
                                  * graph and replay it; the callback must then only enqueue work on the given stream */
     int32_t host_groups;        /* host-callback models with zero-copy staging: 0 = default (two groups of chains in flight: the
                                  * kernel of one runs while the host evaluates the rows of the other), 1 = no pipelining,
-                                 * 2..4 = that many groups */
+                                 * 2..8 = that many groups */
+    int32_t host_persist;       /* the same models, dim <= 1024, <= 1024 chains: evaluations one kernel launch serves.  0 = default
+                                 * (256: the group's kernel stays on the device with the chain state in registers, publishes its
+                                 * positions, waits for the host's word in pinned memory and goes on), N > 1 = that many,
+                                 * 1 = one launch per evaluation; -N (tests) = leave the resident mode after N evaluations, the
+                                 * way a failed roll call does */
+    int32_t reserved_;
 } nphip_launch_t;
 
 void nphip_launch_defaults(nphip_launch_t*);

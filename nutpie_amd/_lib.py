@@ -66,6 +66,8 @@ class _Launch(C.Structure):
         ("no_stream_cache", C.c_int32),
         ("graph_steps", C.c_int32),
         ("host_groups", C.c_int32),
+        ("host_persist", C.c_int32),
+        ("reserved_", C.c_int32),
     ]
 
 
@@ -456,6 +458,7 @@ class HostCallbackModel(_Model):
             keep.append(cb)
             addr = C.cast(cb, C.c_void_p)
             n_threads = 1
+            self._python_callable = True
         super().__init__(lib().nphip_model_host_callback(C.c_uint64(dim), addr, C.c_void_p(user_data), int(n_threads)), dim, keep)
 
 
@@ -555,7 +558,7 @@ class PySampler:
 
     def __init__(self, settings: PyNutsSettings, model: _Model, *, device=0, waves_per_chain=0, chain_offset=0,
                  n_local_chains=0, stream=None, store_draws=True, evals_per_launch=0, start_paused=False, manual=False,
-                 staging=None, no_register_kernel=False, no_stream_cache=False, graph_steps=0, host_groups=0):
+                 staging=None, no_register_kernel=False, no_stream_cache=False, graph_steps=0, host_groups=0, host_persist=None):
         L = lib()
         la = _Launch()
         L.nphip_launch_defaults(C.byref(la))
@@ -572,6 +575,11 @@ class PySampler:
         la.no_stream_cache = int(bool(no_stream_cache))
         la.graph_steps = int(graph_steps)
         la.host_groups = int(host_groups)
+        if host_persist is None:
+            # resident launches (the kernel waits on the device for the host's evaluation) are for compiled callbacks; a Python
+            # callable may itself submit work to this GPU, which could queue behind the waiting kernel — one launch per evaluation
+            host_persist = 1 if getattr(model, "_python_callable", False) else 0
+        la.host_persist = int(host_persist)
         if staging is not None:
             la.staging_q, la.staging_grad, la.staging_logp = (C.c_void_p(int(p)) for p in staging)
         self._model = model

@@ -84,6 +84,9 @@ struct Ctl {
     double fin_eerr;
     // lean register kernels: (A.first, T.first) of the level-1 merge the next leaf will check, evaluated one leaf early
     int64_t pre_turn;
+    // resident host-callback launches (k_advance<..., REMOTE>): the evaluation this chain publishes next, whether the host
+    // has asked the launch to end at the next boundary, and the group it reports to (set at kernel start; transient)
+    int64_t hs_seq, hs_last, hs_grp, hs_n, hs_wgn;
     // cycle counters per section (only advanced when built with -DNPHIP_PROFILE): leapfrog, tree, rare, count
     int64_t prof[16];
     // sub-tree stack
@@ -162,14 +165,30 @@ struct Args {
     unsigned long long* counters;  // [0] chains done, [1] chains in error, [2] chains that entered PH_WAIT_HOST (cumulative)
     // pipelined host-callback groups (host.hip: iteration_pipelined)
     unsigned int* grp_arrive;               // device [groups]: chains of the group that finished the current launch
-    volatile unsigned long long* grp_flag;  // pinned host [groups][4]: launch sequence number, chains done, chains in error, -
+    volatile unsigned long long* grp_flag;  // pinned host [groups][4]: evaluation sequence number, chains done, chains in error,
+                                            // sequence number of a launch whose roll call failed
+    // resident launches: the kernel stays on the device between evaluations and waits for the host's word
+    volatile unsigned long long* grp_go;    // pinned host [groups][8]: sequence number whose results are ready | kGoLast
+    unsigned long long* grp_go_dev;         // device [groups][16] (a cache line each): [0] the same word, republished by the
+                                            // group's last arriver; of group 0 also [1] roll-call verdict, [2] roll-call count
 };
+constexpr unsigned long long kGoLast = 1ull << 32;      // finish this evaluation's step, then leave the kernel at the boundary
+constexpr unsigned long long kGoSeqMask = 0xffffffffull;
+constexpr unsigned long long kPubAllDone = 1ull << 62, kPubError = 1ull << 63;   // resident launches: flags beside the published sequence number
+constexpr unsigned long long kRollGo = 1, kRollFail = 2;   // verdict = (launch sequence number << 8) | state
 
 // the chains one launch covers (kernel parameter)
 struct LaunchSlice {
     int chain_lo, chain_n;
     int grp;       // >= 0: publish completion in Args::grp_flag[grp] (no stream synchronisation on the host)
     unsigned seq;
+    int materialise;   // 1 (callback kernels): the previous launch was a resident one, which defers the first half of a tree
+                       // leapfrog into the leaf — perform it now so that this launch finds an evaluation pending
+    // resident launches (REMOTE): ONE launch covers every group (streams may share a hardware queue, and a kernel queued behind
+    // a resident one would never start); seq is then the launch's id for the roll call
+    int n_grp;
+    int grp_lo[9];         // group g = chains [grp_lo[g], grp_lo[g + 1])
+    unsigned grp_seq[8];   // sequence number of each group's first evaluation in this launch
 };
 
 }  // namespace nphip

@@ -6,6 +6,7 @@
 // src/pyfunc.rs callable -> batched device callback, fused analytic Gaussian), and a sampler
 // handle with wait/pause/resume/abort/inspect semantics (wrapper.rs:1252-1456).
 #include <hip/hip_runtime.h>
+#include <sched.h>
 
 #include <algorithm>
 #include <atomic>
@@ -27,6 +28,7 @@
 namespace nphip {
 hipError_t launch_advance(const Args& a, const Args* d_args, bool fused, int W, hipStream_t st, const LaunchSlice* slice = nullptr);
 hipError_t launch_resume(const Args* d_args, int n, const int64_t* d_chains, const double* d_pos, bool fused, hipStream_t st);
+hipError_t launch_remote(const Args* d_args, int nv, hipStream_t st, const LaunchSlice& sl);
 hipError_t launch_test_detmath(int fn, uint64_t n, const double* x, double* y, hipStream_t st);
 hipError_t launch_test_dot(int W, uint64_t n, const double* x, const double* y, double* out, hipStream_t st);
 }  // namespace nphip
@@ -374,54 +376,100 @@ namespace {
 
 // tiny persistent pool for the host-callback flavour: rows of the batch are evaluated
 // concurrently, exactly as the reference evaluates chains on `cores` threads (sample.py:856-857)
+// CPUs this process may actually use: the affinity mask and the cgroup CPU quota (a GPU box can show 256 logical CPUs and grant 16)
+static int usable_cores() {
+    int n = (int)std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t cs;
+    CPU_ZERO(&cs);
+    if (sched_getaffinity(0, sizeof(cs), &cs) == 0 && CPU_COUNT(&cs) > 0) n = std::min(n, (int)CPU_COUNT(&cs));
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {   // cgroup v2: "<quota|max> <period>"
+        char q[64];
+        long per = 0;
+        if (fscanf(f, "%63s %ld", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0) n = std::min(n, (int)((atol(q) + per - 1) / per));
+        fclose(f);
+    } else {
+        long quota = -1, per = 0;
+        if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%ld", &quota) != 1) quota = -1; fclose(g); }
+        if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%ld", &per) != 1) per = 0; fclose(g); }
+        if (quota > 0 && per > 0) n = std::min(n, (int)((quota + per - 1) / per));
+    }
+    return std::max(1, n);
+}
+
+// Evaluates the rows of a batch on `n` threads: the caller and n - 1 workers (the reference: one rayon worker per chain,
+// src/pymc.rs:197-215).  A batch of a cheap model is a few microseconds of work, so the workers do not sleep between batches:
+// they spin on a generation counter (a dispatch costs a cache-line transfer, not a futex wake-up of tens of microseconds) and
+// only go to sleep on a condition variable after ~200 us without work.
 struct RowPool {
     std::vector<std::thread> threads;
+    alignas(64) std::atomic<uint64_t> gen{0};
+    alignas(64) std::atomic<uint64_t> next{0};
+    alignas(64) std::atomic<int> acks{0};
+    alignas(64) uint64_t n_rows = 0;
+    uint64_t chunk = 1;
+    const std::function<void(uint64_t)>* job = nullptr;
     std::mutex mu;
-    std::condition_variable cv_work, cv_done;
-    uint64_t generation = 0;
-    std::atomic<uint64_t> next{0};
-    uint64_t n_rows = 0;
-    int pending = 0;
-    bool stop = false;
-    std::function<void(uint64_t)> job;
+    std::condition_variable cv;
+    std::atomic<int> sleepers{0};
+    std::atomic<bool> stop{false};
+    static constexpr int kSpin = 1 << 13;
+    static void relax() {
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#else
+        std::this_thread::yield();
+#endif
+    }
     explicit RowPool(int n) {
-        for (int i = 0; i < n; ++i) threads.emplace_back([this] { loop(); });
+        for (int i = 1; i < n; ++i) threads.emplace_back([this] { loop(); });
     }
     ~RowPool() {
-        { std::lock_guard<std::mutex> lk(mu); stop = true; }
-        cv_work.notify_all();
+        { std::lock_guard<std::mutex> lk(mu); stop.store(true); }
+        cv.notify_all();
         for (auto& t : threads) t.join();
+    }
+    void work() {
+        for (;;) {
+            const uint64_t r0 = next.fetch_add(chunk, std::memory_order_relaxed);
+            if (r0 >= n_rows) break;
+            const uint64_t r1 = std::min(n_rows, r0 + chunk);
+            for (uint64_t r = r0; r < r1; ++r) (*job)(r);
+        }
     }
     void loop() {
         uint64_t seen = 0;
         for (;;) {
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                cv_work.wait(lk, [&] { return stop || generation != seen; });
-                if (stop) return;
-                seen = generation;
+            int spins = 0;
+            while (gen.load() == seen) {
+                if (stop.load(std::memory_order_relaxed)) return;
+                if (++spins > kSpin) {
+                    std::unique_lock<std::mutex> lk(mu);
+                    sleepers.fetch_add(1);
+                    cv.wait(lk, [&] { return stop.load() || gen.load() != seen; });
+                    sleepers.fetch_sub(1);
+                    spins = 0;
+                } else {
+                    relax();
+                }
             }
-            for (;;) {
-                uint64_t r = next.fetch_add(1);
-                if (r >= n_rows) break;
-                job(r);
-            }
-            {
-                std::lock_guard<std::mutex> lk(mu);
-                if (--pending == 0) cv_done.notify_all();
-            }
+            if (stop.load(std::memory_order_relaxed)) return;
+            seen += 1;   // (a new batch starts only after every worker acknowledged the previous one)
+            work();
+            acks.fetch_add(1, std::memory_order_release);
         }
     }
-    void run(uint64_t rows, std::function<void(uint64_t)> f) {
-        if (threads.empty()) { for (uint64_t r = 0; r < rows; ++r) f(r); return; }
-        std::unique_lock<std::mutex> lk(mu);
-        job = std::move(f);
+    void run(uint64_t rows, const std::function<void(uint64_t)>& f) {
+        if (threads.empty() || rows < 2) { for (uint64_t r = 0; r < rows; ++r) f(r); return; }
+        job = &f;
         n_rows = rows;
-        next.store(0);
-        pending = (int)threads.size();
-        ++generation;
-        cv_work.notify_all();
-        cv_done.wait(lk, [&] { return pending == 0; });
+        chunk = std::max<uint64_t>(1, rows / (4 * (threads.size() + 1)));
+        next.store(0, std::memory_order_relaxed);
+        acks.store(0, std::memory_order_relaxed);
+        gen.fetch_add(1);
+        if (sleepers.load() > 0) { std::lock_guard<std::mutex> lk(mu); cv.notify_all(); }
+        work();
+        const int want = (int)threads.size();
+        while (acks.load(std::memory_order_acquire) != want) relax();
     }
 };
 
@@ -447,6 +495,10 @@ struct nphip_sampler {
     double *h_q = nullptr, *h_g = nullptr, *h_u = nullptr;  // pinned staging (host callback)
     int64_t* h_code = nullptr;
     std::unique_ptr<RowPool> pool;
+    void eval_rows(uint64_t lo, uint64_t cnt);
+    double row_ns = 0.0;     // cheapest timed batch so far, per row
+    int timed_batches = 0;
+    int eval_threads = 1;
 
     std::thread th;
     std::mutex mu;       // state
@@ -473,7 +525,7 @@ struct nphip_sampler {
     template <class Tp>
     bool palloc(Tp** p, size_t count) {
         void* h = nullptr;
-        if (!hip_ok(hipHostMalloc(&h, count * sizeof(Tp) + 8, hipHostMallocDefault), "hipHostMalloc")) return false;
+        if (!hip_ok(hipHostMalloc(&h, count * sizeof(Tp) + 8, hipHostMallocCoherent), "hipHostMalloc")) return false;
         pinned.push_back(h);
         memset(h, 0, count * sizeof(Tp) + 8);
         *p = reinterpret_cast<Tp*>(h);
@@ -497,17 +549,41 @@ struct nphip_sampler {
     bool iteration_callback(bool& all_done, int& have);
     // host callbacks, zero-copy staging: chains in groups, each on its own stream, completion by a flag in pinned memory
     // (no stream synchronisation): the kernel of one group runs while the host evaluates the rows of the other
-    static constexpr int kMaxGroups = 4;
+    static constexpr int kMaxGroups = 8;
     int n_groups = 0;
-    hipStream_t grp_stream[kMaxGroups] = {nullptr, nullptr, nullptr, nullptr};
-    uint64_t grp_lo[kMaxGroups + 1] = {0, 0, 0, 0, 0};
-    unsigned grp_seq[kMaxGroups] = {0, 0, 0, 0};
+    hipStream_t grp_stream[kMaxGroups] = {};
+    uint64_t grp_lo[kMaxGroups + 1] = {};
+    unsigned grp_seq[kMaxGroups] = {};
     bool grp_primed = false;
     volatile unsigned long long* h_grp_flag = nullptr;  // pinned [groups][4]
+    // Resident launches (kernels.hip: REMOTE): a group's kernel stays on the device for `persist_evals` evaluations; an evaluation
+    // is a rendezvous — the kernel publishes its positions and the sequence number, the host evaluates the rows and answers
+    // with one word in pinned memory.  grp_seq[g] is then the sequence number the host waits for next.
+    bool remote = false;
+    int remote_nv = 0;
+    int persist_evals = 256;
+    volatile unsigned long long* h_grp_go = nullptr;    // pinned [groups][8]
+    bool grp_running[kMaxGroups] = {};
+    int grp_evals[kMaxGroups] = {};
+    bool materialise = false;   // the next callback launches follow resident ones (LaunchSlice::materialise)
+    int64_t fall_back_after = 0; // tests (launch.host_persist = -N): leave the resident mode after N evaluations, as a failed roll call would
+    int64_t remote_evals = 0;
+    double t_wait_ns = 0.0, t_eval_ns = 0.0;   // NPHIP_TIMING=1: where the driver thread's time goes (printed at the end of the job)
+    unsigned remote_launch_id = 0;
+    bool remote_fresh = false;  // the running launch has not published anything yet (its roll call may still fail)
+    int remote_next = 0;        // round-robin start of the poll
+    bool launch_remote_all();
+    int poll_remote(int g);
+    int wait_remote(int only);
+    void answer_group(int g, bool last);
+    bool drain_groups();
+    bool remote_fall_back();
+    bool iteration_remote(bool& all_done);
     bool launch_group(int g, int have);
     bool wait_group(int g);
     bool iteration_pipelined(bool& all_done);
     bool sync_all() {
+        if (remote && !drain_groups()) return false;
         bool ok = hip_ok(hipStreamSynchronize(stream), "hipStreamSynchronize");
         for (int g = 0; g < n_groups; ++g) ok = hip_ok(hipStreamSynchronize(grp_stream[g]), "hipStreamSynchronize") && ok;
         return ok;
@@ -667,17 +743,12 @@ bool nphip_sampler::setup() {
             if (!zero_copy && !dalloc(&args.ecode, n)) return false;
             if (!palloc(&h_q, n * dim) || !palloc(&h_g, n * dim) || !palloc(&h_u, n) || !palloc(&h_code, n)) return false;
             if (zero_copy) { args.qeval = h_q; args.geval = h_g; args.ueval = h_u; args.ecode = h_code; }
-            // n_threads == 0: size the pool by the work per step; waking a thread costs more than a few
-            // hundred cheap rows (eight-schools, 256 chains: 1 thread 71 us/step, 16 threads 169 us/step)
-            int nt = model.n_threads > 0 ? model.n_threads : (int)std::thread::hardware_concurrency();
-            if (model.n_threads <= 0) {
-                const uint64_t work = n * dim;
-                const int by_work = (int)std::min<uint64_t>(64, work / 32768);
-                nt = std::max(1, std::min(nt, by_work));
+            // n_threads > 0: that many evaluation threads.  n_threads == 0: the first batches are evaluated on the driver thread and
+            // timed, then the pool is sized so that every thread gets ~8 us of rows per batch (eval_rows)
+            if (model.n_threads > 0) {
+                const int nt = (int)std::min<uint64_t>((uint64_t)model.n_threads, n);
+                pool.reset(new RowPool(nt));
             }
-            if (nt < 1) nt = 1;
-            if ((uint64_t)nt > n) nt = (int)n;
-            pool.reset(new RowPool(nt > 1 ? nt : 0));
             // pipelining: two groups of chains in flight — while the host evaluates the rows of one group the
             // kernel of the other runs.  Zero-copy batches only (they are the latency-bound ones); launch.host_groups = 1 turns it off.
             if (zero_copy && !launch.manual && launch.host_groups != 1 && n >= 2) {
@@ -687,12 +758,34 @@ bool nphip_sampler::setup() {
                 n_groups = (n >= 128) ? 4 : ((n >= 32) ? 2 : 1);
                 if (launch.host_groups >= 2 && launch.host_groups <= kMaxGroups) n_groups = (int)std::min<uint64_t>(launch.host_groups, n);
                 for (int g = 0; g <= n_groups; ++g) grp_lo[g] = n * (uint64_t)g / (uint64_t)n_groups;
-                for (int g = 0; g < n_groups; ++g) HIP_TRY(hipStreamCreateWithFlags(&grp_stream[g], hipStreamNonBlocking));
                 if (!dalloc(&args.grp_arrive, kMaxGroups)) return false;
                 unsigned long long* f = nullptr;
                 if (!palloc(&f, 4 * kMaxGroups)) return false;
                 h_grp_flag = f;
                 args.grp_flag = f;
+                // resident launches: one wave per chain with the state in registers (dim <= 1024); every chain of a group must be on
+                // the device at once (<= 1024 chains: a quarter of the wave slots); the adaptation hook edits control blocks
+                // between launches and the divergence record needs the pre-step state in memory — both keep a launch per evaluation
+                unsigned long long* go = nullptr;
+                if (!palloc(&go, 8 * kMaxGroups) || !dalloc(&args.grp_go_dev, 16 * kMaxGroups)) return false;
+                h_grp_go = go;
+                args.grp_go = go;
+                remote_nv = (int)(args.ld / 128);
+                remote = W == 1 && remote_nv <= 8 && n <= 1024 && launch.host_persist != 1 && !launch.no_register_kernel &&
+                         !set.store_divergences && set.pause_draws.empty();
+                persist_evals = launch.host_persist > 1 ? launch.host_persist : 256;
+                if (launch.host_persist < 0) { fall_back_after = -(int64_t)launch.host_persist; persist_evals = 7; }
+                for (int g = 0; g < kMaxGroups; ++g) grp_seq[g] = remote ? 1u : 0u;
+                if (remote) {
+                    // (a step of a resident group is ~20 us of device latency — PCIe round trips and one L2 write-back — and ~3 us of
+                    //  host work per 64 rows: eight groups keep the driver thread busy while seven of them are in flight)
+                    if (launch.host_groups == 0 && n >= 256) n_groups = 8;
+                    // a workgroup holds four chains, and they rendezvous as one (kernels.hip: remote_sync): group bounds on multiples of 4
+                    n_groups = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)n_groups, (n + 3) / 4));
+                    for (int g = 1; g < n_groups; ++g) grp_lo[g] = (((n + 3) / 4) * (uint64_t)g / (uint64_t)n_groups) * 4;
+                    grp_lo[n_groups] = n;
+                }
+                for (int g = 0; g < n_groups; ++g) HIP_TRY(hipStreamCreateWithFlags(&grp_stream[g], hipStreamNonBlocking));
             }
         }
     }
@@ -766,6 +859,32 @@ bool nphip_sampler::iteration_fused(bool& all_done) {
     return true;
 }
 
+// Host callback on the rows [lo, lo + cnt) of the staging buffers (the reference calls the same function pointer once per
+// chain-step from its worker threads: src/pymc.rs:197-215).
+void nphip_sampler::eval_rows(uint64_t lo, uint64_t cnt) {
+    const uint64_t d = dim;
+    const std::function<void(uint64_t)> f = [this, d, lo](uint64_t r) {
+        const uint64_t row = lo + r;
+        double lp = NAN;
+        h_code[row] = (int64_t)model.host_fn(d, h_q + row * d, h_g + row * d, &lp, model.user);   // c_int, sign-extended
+        h_u[row] = lp;
+    };
+    if (pool) { pool->run(cnt, f); return; }
+    // no pool yet: evaluate here and time it; after a few batches the cheapest one sizes the pool
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint64_t r = 0; r < cnt; ++r) f(r);
+    const double ns = std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t0).count() / (double)std::max<uint64_t>(1, cnt);
+    row_ns = (timed_batches == 0) ? ns : std::min(row_ns, ns);
+    if (++timed_batches >= 6) {
+        const double per_thread_ns = 50000.0;   // (measured: handing 64 rows of 40 ns to a second thread costs more than it saves)
+        int nt = (int)std::ceil((double)cnt * row_ns / per_thread_ns);
+        nt = std::max(1, std::min(nt, std::max(1, usable_cores() - 1)));
+        if ((uint64_t)nt > cnt) nt = (int)cnt;
+        pool.reset(new RowPool(nt));
+        eval_threads = nt;
+    }
+}
+
 bool nphip_sampler::iteration_callback(bool& all_done, int& have) {
     if (model.kind == 2 && cb_graph_steps > 0 && have == 1 && !kernel_ms_acc) return iteration_graph(all_done);
     if (!launch_kernel(false, have)) return false;
@@ -779,11 +898,8 @@ bool nphip_sampler::iteration_callback(bool& all_done, int& have) {
         if (h_counters[1] > 0) { set_error(chain_error_message()); return false; }
         if (h_counters[0] >= n) { all_done = true; return true; }
         const uint64_t d = dim;
-        pool->run(n, [this, d](uint64_t r) {
-            double lp = NAN;
-            h_code[r] = (int64_t)model.host_fn(d, h_q + r * d, h_g + r * d, &lp, model.user);   // c_int, sign-extended
-            h_u[r] = lp;
-        });
+        (void)d;
+        eval_rows(0, n);
         if (!zero_copy) {
             if (!hip_ok(hipMemcpyAsync(args.geval, h_g, n * dim * 8, hipMemcpyHostToDevice, stream), "H2D grad")) return false;
             if (!hip_ok(hipMemcpyAsync(args.ueval, h_u, n * 8, hipMemcpyHostToDevice, stream), "H2D logp")) return false;
@@ -862,6 +978,7 @@ bool nphip_sampler::launch_group(int g, int have) {
     sl.chain_n = (int)(grp_lo[g + 1] - grp_lo[g]);
     sl.grp = g;
     sl.seq = ++grp_seq[g];
+    sl.materialise = materialise ? 1 : 0;
     args.max_evals = 0;
     args.have_result = have;
     if (!hip_ok(launch_advance(args, d_args, false, W, grp_stream[g], &sl), "launch k_advance")) return false;
@@ -890,6 +1007,124 @@ bool nphip_sampler::wait_group(int g) {
     return true;
 }
 
+// ---- resident launches ------------------------------------------------------------------------------------------------
+// ONE launch covers all groups: HIP multiplexes streams onto a few hardware queues, and a group's kernel queued behind another
+// group's resident kernel would never start while the host waits for it.
+bool nphip_sampler::launch_remote_all() {
+    LaunchSlice sl;
+    sl.chain_lo = 0;
+    sl.chain_n = (int)n;
+    sl.grp = 0;
+    sl.seq = ++remote_launch_id;
+    sl.materialise = 0;
+    sl.n_grp = n_groups;
+    for (int g = 0; g <= kMaxGroups; ++g) sl.grp_lo[g] = (int)grp_lo[std::min(g, n_groups)];
+    for (int g = 0; g < kMaxGroups; ++g) sl.grp_seq[g] = grp_seq[g];   // a group's first evaluation carries the number the host waits for
+    if (!hip_ok(launch_remote(d_args, remote_nv, grp_stream[0], sl), "launch k_advance (resident)")) return false;
+    for (int g = 0; g < n_groups; ++g) { grp_running[g] = true; grp_evals[g] = 0; }
+    remote_fresh = true;
+    return true;
+}
+
+// 1: group g has published the evaluation the host waits for; 0: not yet
+inline int nphip_sampler::poll_remote(int g) {
+    if ((h_grp_flag[4 * g] & kGoSeqMask) != (unsigned long long)grp_seq[g]) return 0;
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return 1;
+}
+
+// waits until some running group (or, with only >= 0, that group) has published; returns its index, -1 on error, -2 when the
+// launch's roll call failed (nothing ran)
+int nphip_sampler::wait_remote(int only) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint64_t spin = 1;; ++spin) {
+        for (int g = 0; g < n_groups; ++g) {
+            const int o = (remote_next + g) % n_groups;
+            if ((only < 0 || o == only) && grp_running[o] && poll_remote(o)) { remote_next = (o + 1) % n_groups; remote_fresh = false; return o; }
+        }
+        if ((spin & 0xff) == 0) {
+            if (remote_fresh && h_grp_flag[3] == (unsigned long long)remote_launch_id) return -2;
+            if ((spin & 0xffff) == 0) {
+                if (hipStreamQuery(grp_stream[0]) == hipSuccess) {
+                    bool any = false;
+                    for (int g = 0; g < n_groups; ++g) any = any || (grp_running[g] && poll_remote(g));
+                    if (!any && !(remote_fresh && h_grp_flag[3] == (unsigned long long)remote_launch_id)) {
+                        set_error("resident host-callback launch ended without publishing its evaluation");
+                        return -1;
+                    }
+                }
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(600)) { set_error("timeout waiting for the engine kernel"); return -1; }
+            }
+        }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+}
+
+// results of the evaluation grp_seq[g] are in the staging rows: one word to the kernel; `last` ends the group's part of the
+// launch at the next boundary
+void nphip_sampler::answer_group(int g, bool last) {
+    std::atomic_thread_fence(std::memory_order_release);
+    h_grp_go[8 * g] = (unsigned long long)grp_seq[g] | (last ? kGoLast : 0ull);
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+    grp_seq[g] += 1;
+    if (last) grp_running[g] = false;
+    launches.fetch_add(1);
+}
+
+// Bring the resident launch to its next boundary: one more evaluation of every group still in it, answered with kGoLast.  (A
+// chain's state only exists in memory at a boundary — whoever wants to read it, pause, abort or finish goes through here.)
+bool nphip_sampler::drain_groups() {
+    for (int g = 0; g < n_groups; ++g) {
+        if (!grp_running[g]) continue;
+        const int w = wait_remote(g);
+        if (w == -1) return false;
+        if (w == -2) { for (int o = 0; o < n_groups; ++o) grp_running[o] = false; break; }   // nothing ran
+        eval_rows(grp_lo[g], grp_lo[g + 1] - grp_lo[g]);
+        answer_group(g, true);
+    }
+    return true;
+}
+
+// The device could not hold all chains at once (roll call, kernels.hip): back to one launch per evaluation, for good.
+bool nphip_sampler::remote_fall_back() {
+    if (!drain_groups()) return false;
+    remote = false;
+    for (int g = 0; g < n_groups; ++g)
+        if (!hip_ok(hipStreamSynchronize(grp_stream[g]), "hipStreamSynchronize")) return false;
+    materialise = true;
+    grp_primed = false;
+    return true;
+}
+
+// One evaluation of one group: whichever has published first.
+bool nphip_sampler::iteration_remote(bool& all_done) {
+    if (!grp_primed) {
+        if (!hip_ok(hipStreamSynchronize(stream), "hipStreamSynchronize")) return false;   // set-up copies ran on the main stream
+        grp_primed = true;
+    }
+    if (fall_back_after > 0 && remote_evals >= fall_back_after) return remote_fall_back();
+    bool any = false;
+    for (int g = 0; g < n_groups; ++g) any = any || grp_running[g];
+    if (!any && !launch_remote_all()) return false;
+    const auto tw0 = std::chrono::steady_clock::now();
+    const int g = wait_remote(-1);
+    const auto tw1 = std::chrono::steady_clock::now();
+    t_wait_ns += std::chrono::duration<double, std::nano>(tw1 - tw0).count();
+    if (g == -1) return false;
+    if (g == -2) { for (int o = 0; o < n_groups; ++o) grp_running[o] = false; return remote_fall_back(); }
+    const unsigned long long pub = h_grp_flag[4 * g];
+    if (pub & kPubError) { (void)sync_all(); set_error(chain_error_message()); return false; }
+    if (pub & kPubAllDone) { all_done = true; return sync_all(); }
+    eval_rows(grp_lo[g], grp_lo[g + 1] - grp_lo[g]);
+    t_eval_ns += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - tw1).count();
+    grp_evals[g] += 1;
+    remote_evals += 1;
+    answer_group(g, grp_evals[g] >= persist_evals);
+    return true;
+}
+
 // One round over the groups: for each, wait for its kernel, evaluate its rows on the host pool, relaunch it.
 bool nphip_sampler::iteration_pipelined(bool& all_done) {
     if (!grp_primed) {
@@ -897,6 +1132,7 @@ bool nphip_sampler::iteration_pipelined(bool& all_done) {
         for (int g = 0; g < n_groups; ++g)
             if (!launch_group(g, 0)) return false;
         grp_primed = true;
+        materialise = false;
     }
     const uint64_t d = dim;
     for (int g = 0; g < n_groups; ++g) {
@@ -911,12 +1147,8 @@ bool nphip_sampler::iteration_pipelined(bool& all_done) {
             return sync_all();
         }
         const uint64_t lo = grp_lo[g], cnt = grp_lo[g + 1] - lo;
-        pool->run(cnt, [this, d, lo](uint64_t r) {
-            const uint64_t row = lo + r;
-            double lp = NAN;
-            h_code[row] = (int64_t)model.host_fn(d, h_q + row * d, h_g + row * d, &lp, model.user);
-            h_u[row] = lp;
-        });
+        (void)d;
+        eval_rows(lo, cnt);
         std::atomic_thread_fence(std::memory_order_release);
         if (!launch_group(g, 1)) return false;
     }
@@ -937,13 +1169,19 @@ void nphip_sampler::run() {
         bool ok;
         {
             std::lock_guard<std::mutex> run_lk(mu_run);
-            ok = fused ? iteration_fused(all_done) : (n_groups > 0 ? iteration_pipelined(all_done) : iteration_callback(all_done, have));
+            ok = fused ? iteration_fused(all_done) : (remote ? iteration_remote(all_done) : (n_groups > 0 ? iteration_pipelined(all_done) : iteration_callback(all_done, have)));
         }
         seconds.store(std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count());
         if (!ok) { fail(t_error); break; }
         if (all_done) break;
     }
-    (void)sync_all();
+    {
+        std::lock_guard<std::mutex> run_lk(mu_run);
+        (void)sync_all();
+    }
+    if (remote_evals > 0 && getenv("NPHIP_TIMING"))
+        fprintf(stderr, "[nutpie-hip] resident launches: %lld evaluations of a group, driver thread: %.2f us waiting for the device + %.2f us evaluating per evaluation, %d evaluation threads (%.0f ns per row)\n",
+                (long long)remote_evals, t_wait_ns / remote_evals * 1e-3, t_eval_ns / remote_evals * 1e-3, eval_threads, row_ns);
     {
         std::lock_guard<std::mutex> lk(mu);
         finished = all_done && !failed;

@@ -162,6 +162,12 @@ __device__ __forceinline__ void st2_dense(double* p, int64_t i, int64_t D, doubl
     if (i < D) st1(p, i, v.x);
     if (i + 1 < D) st1(p, i + 1, v.y);
 }
+// all of this wave's memory operations are complete (gfx9 encoding: vmcnt(0), expcnt / lgkmcnt untouched)
+__device__ __forceinline__ void wait_vm0() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    asm volatile("" ::: "memory");
+}
 __device__ __forceinline__ double clamp_mm(double v) { return v < 1e-20 ? 1e-20 : (v > 1e20 ? 1e20 : v); }
 
 // ----------------------------------------------------------------------------------------
@@ -200,8 +206,12 @@ struct SCache {
 // for whole-vector temporaries.  The cursor (q, grad, p, rho) lives in VGPRs, sigma^2 in LDS; EVERY merge operand is
 // streamed from its P-slot chunk by chunk against the resident leaf (leaf_lean), so nothing but the state itself is
 // ever held as a full vector.  The same summation order as every other kernel: chunk c belongs to wave c mod W.
-template <bool FUSED, int W, int NV = 0, bool LEAN = false>
+// REMOTE (NV > 0, W == 1, not FUSED): a host-callback model driven like a fused one — the kernel stays resident, and an
+// evaluation is a remote call in the middle of the leaf: publish the position in the host's staging row, arrive, wait for
+// the host's word, read (logp, gradient) back (remote_sync).  The cursor state stays in registers across the call.
+template <bool FUSED, int W, int NV = 0, bool LEAN = false, bool REMOTE = false>
 struct Machine {
+    static constexpr bool INK = FUSED || REMOTE;   // evaluations happen inside the kernel: a launch runs many steps
     static constexpr int NVX = NV > 0 ? NV : 1;
     static constexpr int NSX = NV < 0 ? -NV : 1;   // NV = -NS: cache (sigma^2, grad, p, rho) of NS chunks per wave
     // kernel arguments, read through the constant address space: s_load into SGPRs (uniform), never flat
@@ -373,7 +383,7 @@ struct Machine {
     __device__ __forceinline__ void lf1(int64_t srcq, int64_t srcp, int64_t newq, int64_t newp, int64_t sign, bool defer = false) {
         c->lf_srcq = srcq; c->lf_srcp = srcp; c->lf_newq = newq; c->lf_newp = newp; c->lf_sign = sign;
         c->eval_buf = newq;
-        if (FUSED && defer) return;  // fused models integrate the whole step in leaf_reg() / lf_stream()
+        if (INK && defer) return;  // fused / resident models integrate the whole step in leaf_reg() / lf_stream()
         const double eps = (double)sign * c->step_size;
         const double h = 0.5 * eps;
         const double *q = Q(srcq), *g = G(srcq), *p = P(srcp);
@@ -426,10 +436,67 @@ struct Machine {
             lp = 0.5 * a;
             code = 0;
         } else {
+            if (REMOTE) remote_sync();
             lp = A.ueval[chain];
             code = A.ecode ? A.ecode[chain] : 0;
             NPHIP_FOR_CHUNKS(i) st2(g, i, ld2_dense(A.geval + (size_t)chain * D, i, D));
         }
+    }
+
+    // ---- resident host-callback launches: one evaluation = one rendezvous of the group with the host.
+    // Every chain of the group arrives once (its position is in the host's staging row and released to the system first); the
+    // last arriver publishes the job-wide done / error counts and the evaluation's sequence number in pinned host memory,
+    // polls the host's word over PCIe and republishes it in device memory for the other chains.  The host answers with the
+    // sequence number (results are in the staging rows), optionally | kGoLast: finish this step, then leave the kernel at the
+    // next boundary.  Finished chains keep taking part (run()), so the arrival count is always the group's size.  All chains
+    // of the group are resident: the launch's roll call (k_advance) made sure before anyone got here.
+    // The four chains of a workgroup rendezvous together: each waits for its own stores (they are in this XCD's L2 then), one
+    // workgroup barrier, and wave 0 alone pays for __threadfence_system() — its release half writes back the WHOLE L2
+    // (buffer_wbl2), about a microsecond per wave that issues it on the same XCD, and with every chain doing it it was a third of a
+    // step.  Measured and rejected (profiles/r2_config4_resident_launches.txt): system-scope (sc0 sc1) stores or loads for the
+    // staging rows instead of the fence — they go over PCIe one at a time, ~2.3 us per chain; agent-scope (sc1) stores — correct
+    // but slower than the one fence per workgroup; plain stores and only a vmcnt wait — the flag overtakes the data and the
+    // trace is wrong.
+    __device__ __forceinline__ void remote_sync() {
+        const int grp = (int)c->hs_grp;
+        const unsigned seq = (unsigned)c->hs_seq;
+        NPHIP_LDS unsigned long long* box = (NPHIP_LDS unsigned long long*)red;   // (W == 1: the reductions never touch LDS)
+        wait_vm0();
+        __syncthreads();
+        if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0) {
+            unsigned long long go = 0;
+            __threadfence_system();   // the positions of this workgroup's chains are in the host's staging rows
+            if (lane == 0) {
+                const unsigned cnt = (unsigned)c->hs_wgn;
+                const unsigned old = __hip_atomic_fetch_add(&A.grp_arrive[grp], cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (old + cnt == (unsigned)c->hs_n) {
+                    __hip_atomic_store(&A.grp_arrive[grp], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    // one word: the sequence number, "every chain of the job is done", "some chain is in error" (no second fence)
+                    const unsigned long long done = __hip_atomic_load(&A.counters[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned long long errs = __hip_atomic_load(&A.counters[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    volatile unsigned long long* f = A.grp_flag + 4 * grp;
+                    f[0] = (unsigned long long)seq | (done >= (unsigned long long)A.n_chains ? kPubAllDone : 0ull) | (errs > 0 ? kPubError : 0ull);
+                    for (;;) {
+                        go = __hip_atomic_load((unsigned long long*)(A.grp_go + 8 * grp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        if ((go & kGoSeqMask) == (unsigned long long)seq) break;
+                        __builtin_amdgcn_s_sleep(4);
+                    }
+                    __hip_atomic_store(&A.grp_go_dev[16 * grp], go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    for (;;) {
+                        go = __hip_atomic_load(&A.grp_go_dev[16 * grp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((go & kGoSeqMask) == (unsigned long long)seq) break;
+                        __builtin_amdgcn_s_sleep(8);
+                    }
+                }
+                *box = go;
+            }
+        }
+        __syncthreads();
+        const unsigned long long go = *box;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // system scope: no stale line of the staging rows survives
+        c->hs_seq = (int64_t)(seq + 1u);
+        if (go & kGoLast) c->hs_last = 1;
     }
 
     // ---- criteria of a sub-tree merge INSIDE a doubling (all leaves on one side of the origin): for an
@@ -644,6 +711,7 @@ struct Machine {
         const bool copy_rho = (idx_new == -1);
         double2 accK = {0.0, 0.0}, accL = {0.0, 0.0};
         if (!FUSED) {
+            if (REMOTE) remote_sync();
             lp = A.ueval[chain];
             code = A.ecode ? A.ecode[chain] : 0;
             if (code != 0 || !isfinite(lp)) return 0.0;
@@ -882,6 +950,11 @@ struct Machine {
             double* qn = Q(X.reg_q);
 #pragma unroll
             for (int k = 0; k < NVX; ++k) if (k < nk) st2(qn, ridx(k), X.q[k]);
+            if (REMOTE) {   // a callback model's gradient cannot be rebuilt on reload: it is stored with the position
+                double* gn = G(X.reg_q);
+#pragma unroll
+                for (int k = 0; k < NVX; ++k) if (k < nk) st2(gn, ridx(k), X.g[k]);
+            }
             X.dirty_qg = false;
         }
         if (pr) {
@@ -927,7 +1000,13 @@ struct Machine {
             const double* q = Q(srcq);
 #pragma unroll
             for (int k = 0; k < NVX; ++k) if (k < nk) X.q[k] = ld2(q, ridx(k));
-            regs_grad(X);
+            if (REMOTE) {   // the pool keeps (q, grad) of every stored position of a callback model
+                const double* g = G(srcq);
+#pragma unroll
+                for (int k = 0; k < NVX; ++k) if (k < nk) X.g[k] = ld2(g, ridx(k));
+            } else {
+                regs_grad(X);
+            }
         }
         if (X.reg_p != srcp) load_slot(srcp, X.p, X.r);
         if (!X.sig_ok) {
@@ -947,38 +1026,56 @@ struct Machine {
         double2 z[NVX], pold[NVX], rold[NVX];
 #pragma unroll
         for (int k = 0; k < NVX; ++k) if (k < nk) {
-            const double2 mu = par_mu(ridx(k));
             pold[k] = X.p[k];
             rold[k] = X.r[k];
             X.p[k].x = fma(h, X.g[k].x, X.p[k].x);
             X.p[k].y = fma(h, X.g[k].y, X.p[k].y);
             X.q[k].x = fma(eps, X.s[k].x * X.p[k].x, X.q[k].x);
             X.q[k].y = fma(eps, X.s[k].y * X.p[k].y, X.q[k].y);
-            z[k].x = X.q[k].x - mu.x;
-            z[k].y = X.q[k].y - mu.y;
+            if (!REMOTE) {
+                const double2 mu = par_mu(ridx(k));
+                z[k].x = X.q[k].x - mu.x;
+                z[k].y = X.q[k].y - mu.y;
+            }
         }
-        publish_edges(z);
+        double lp_remote = 0.0;
+        int64_t code_remote = 0;
+        if (REMOTE) {
+            // the evaluation is a remote call: position to the host's staging row, rendezvous, results back (remote_sync)
+            double* qe = A.qeval + (size_t)chain * D;
+#pragma unroll
+            for (int k = 0; k < NVX; ++k) if (k < nk) st2_dense(qe, ridx(k), D, X.q[k]);
+            remote_sync();
+            lp_remote = A.ueval[chain];
+            code_remote = A.ecode ? A.ecode[chain] : 0;
+        } else {
+            publish_edges(z);
+        }
         double2 accK = {0.0, 0.0}, accL = {0.0, 0.0}, accE = {0.0, 0.0}, accS = {0.0, 0.0};
 #pragma unroll
         for (int k = 0; k < NVX; ++k) if (k < nk) {
-            double2 a, b01;          // b01 = b_{i-1}, b_i ; b2 = b_{i+1}
-            double b2, edge_zl, edge_zr;
-            par_ab(ridx(k), a, b01, b2);
-            edge_pair(z, k, edge_zl, edge_zr);
-            const double zl = wave_shr1(z[k].y, edge_zl);   // z_{i-1}
-            const double zr = wave_shl1(z[k].x, edge_zr);   // z_{i+2}
-            // boundary terms need no branches: b_{-1} and b_{D-1..} are stored as -0.0 and t + (-0.0) == t
-            double tx = a.x * z[k].x;
-            tx = fma(b01.x, zl, tx);
-            tx = fma(b01.y, z[k].y, tx);
-            double ty = a.y * z[k].y;
-            ty = fma(b01.y, z[k].x, ty);
-            ty = fma(b2, zr, ty);
             double2 gg;
-            gg.x = -tx;
-            gg.y = -ty;
-            accL.x = fma(z[k].x, gg.x, accL.x);
-            accL.y = fma(z[k].y, gg.y, accL.y);
+            if (REMOTE) {
+                gg = ld2_dense(A.geval + (size_t)chain * D, ridx(k), D);
+            } else {
+                double2 a, b01;          // b01 = b_{i-1}, b_i ; b2 = b_{i+1}
+                double b2, edge_zl, edge_zr;
+                par_ab(ridx(k), a, b01, b2);
+                edge_pair(z, k, edge_zl, edge_zr);
+                const double zl = wave_shr1(z[k].y, edge_zl);   // z_{i-1}
+                const double zr = wave_shl1(z[k].x, edge_zr);   // z_{i+2}
+                // boundary terms need no branches: b_{-1} and b_{D-1..} are stored as -0.0 and t + (-0.0) == t
+                double tx = a.x * z[k].x;
+                tx = fma(b01.x, zl, tx);
+                tx = fma(b01.y, z[k].y, tx);
+                double ty = a.y * z[k].y;
+                ty = fma(b01.y, z[k].x, ty);
+                ty = fma(b2, zr, ty);
+                gg.x = -tx;
+                gg.y = -ty;
+                accL.x = fma(z[k].x, gg.x, accL.x);
+                accL.y = fma(z[k].y, gg.y, accL.y);
+            }
             X.g[k] = gg;
             X.p[k].x = fma(h, gg.x, X.p[k].x);
             X.p[k].y = fma(h, gg.y, X.p[k].y);
@@ -1012,13 +1109,14 @@ struct Machine {
         const int64_t tp2 = (int64_t)__builtin_readcyclecounter();
         c->prof[0] += tp1 - tp0; c->prof[6] += tp2 - tp1;
 #endif
-        const double K = 0.5 * v4[0], lp = 0.5 * v4[1];
+        const double K = 0.5 * v4[0], lp = REMOTE ? lp_remote : 0.5 * v4[1];
         const bool turn0 = (v4[2] < 0.0) || (v4[3] < 0.0);
+        if (REMOTE && code_remote < 0) { X.dirty_qg = X.dirty_pr = false; finish_chain(PH_ERROR, CE_FATAL_LOGP); return true; }
         // ---- NutsTree::extend / merge_into, unrolled (same decisions as cont_tree)
         c->nleaf += 1;
         c->n_steps += 1;
         c->total_steps += 1;
-        const bool ok = isfinite(lp);
+        const bool ok = isfinite(lp) && (!REMOTE || code_remote == 0);
         const double Unew = -lp, E = K + Unew, dE = E - c->H0;
         const bool diverged = !ok || (dE > A.s.max_energy_error) || !isfinite(dE);
         double T_wm = 1.0;
@@ -1036,7 +1134,7 @@ struct Machine {
                 c->acc_sym_sum += 2.0 * a / (1.0 + e);
             }
         }
-        if (diverged) { X.dirty_qg = X.dirty_pr = false; rare_end_draw(A, c, red, chain, true, false, false, false, true); return true; }
+        if (diverged) { X.dirty_qg = X.dirty_pr = false; rare_end_draw(A, c, red, chain, true, false, false, false, !REMOTE); return true; }
 #ifdef NPHIP_PROFILE
         int64_t tq = (int64_t)__builtin_readcyclecounter();
         c->prof[8] += tq - tp2;
@@ -1077,7 +1175,7 @@ struct Machine {
                         turn = sub_b(X, obp, obr);
                     }
                 }
-                if (turn) { X.dirty_qg = X.dirty_pr = false; rare_end_draw(A, c, red, chain, false, false, false, false, true); return true; }
+                if (turn) { X.dirty_qg = X.dirty_pr = false; rare_end_draw(A, c, red, chain, false, false, false, false, !REMOTE); return true; }
             }
 #ifdef NPHIP_PROFILE
             { const int64_t t_ = (int64_t)__builtin_readcyclecounter(); c->prof[k == 0 ? 9 : 10] += t_ - tq; tq = t_; }
@@ -1147,8 +1245,8 @@ struct Machine {
             c->depth = d + 1;
         }
         store_state(X, true, true);  // a new trajectory end is always written back
-        if (turn) { rare_end_draw(A, c, red, chain, false, false, false, false, true); return true; }
-        if (c->depth >= A.s.maxdepth) { rare_end_draw(A, c, red, chain, false, true, false, false, true); return true; }
+        if (turn) { rare_end_draw(A, c, red, chain, false, false, false, false, !REMOTE); return true; }
+        if (c->depth >= A.s.maxdepth) { rare_end_draw(A, c, red, chain, false, true, false, false, !REMOTE); return true; }
         start_doubling();
         return false;
     }
@@ -2147,12 +2245,23 @@ struct Machine {
         }
     }
 
-    __device__ __forceinline__ void run(int budget, bool have, LdsDouble sig_copy = nullptr) {
+    __device__ __forceinline__ void run(int budget, bool have, LdsDouble sig_copy = nullptr, bool materialise = false) {
+        if (!INK && materialise && c->phase == PH_TREE) {
+            // the previous launch was a resident one (its tree leapfrogs are issued deferred): do the first half now, so that
+            // this launch finds what a callback launch expects — an evaluation pending
+            lf1(c->lf_srcq, c->lf_srcp, c->lf_newq, c->lf_newp, c->lf_sign);
+        }
         for (;;) {
             const int64_t ph = c->phase;
-            if (ph == PH_DONE || ph == PH_ERROR || ph == PH_WAIT_HOST) break;
+            if (ph == PH_DONE || ph == PH_ERROR || ph == PH_WAIT_HOST) {
+                // a resident launch: the group's rendezvous counts every chain, so a finished one keeps answering the roll
+                if (REMOTE) { while (c->hs_last == 0) remote_sync(); }
+                break;
+            }
             if (ph != PH_START) {
-                if (FUSED) {
+                if (REMOTE) {
+                    if (c->hs_last != 0) break;   // the host asked the launch to end at this boundary
+                } else if (FUSED) {
                     if (budget <= 0) break;
                     --budget;
                 } else {
@@ -2205,7 +2314,9 @@ struct Machine {
 #endif
                 if (rare || c->phase != PH_TREE) break;
                 // the next leaf of the run: same admission test as at the top of the outer loop
-                if (FUSED) {
+                if (REMOTE) {
+                    if (c->hs_last != 0) { out_of_budget = true; break; }
+                } else if (FUSED) {
                     if (budget <= 0) { out_of_budget = true; break; }
                     --budget;
                 } else {
@@ -2224,7 +2335,7 @@ struct Machine {
 
 // `Ap` points to the engine's argument block in device memory (written once at set-up); it is read through
 // the constant address space, i.e. with scalar loads into SGPRs.  Per-launch scalars are kernel parameters.
-template <bool FUSED, int W, int NV, bool LEAN = false>
+template <bool FUSED, int W, int NV, bool LEAN = false, bool REMOTE = false>
 __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) __attribute__((amdgpu_waves_per_eu(LEAN ? NPHIP_LEAN_OCC(W) : ((NV > 0 && NV <= 4) ? 2 : 1), LEAN ? NPHIP_LEAN_OCC(W) : ((NV > 0 && NV <= 4) ? 2 : 8)))) void k_advance(const Args* __restrict__ Ap, int max_evals, int have_result, const LaunchSlice sl) {
     const NPHIP_CONST Args& A = *(const NPHIP_CONST Args*)Ap;
     constexpr int WAVES = (W == 1) ? 4 : W;
@@ -2237,7 +2348,7 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) __attribute__((amdgpu_waves_
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     // a launch covers the chains [sl.chain_lo, sl.chain_lo + sl.chain_n): all of them, or one group of a pipelined host-callback job
     const int64_t chain = sl.chain_lo + ((W == 1) ? (int64_t)blockIdx.x * 4 + wib : (int64_t)blockIdx.x);
-    if (NV > 0 && W == 1) {
+    if (NV > 0 && W == 1 && !REMOTE) {
         // stage the fused model in LDS once per workgroup: mu | a | b shifted by one with -0.0 sentinels
         const int64_t ld = A.ld;
         NPHIP_LDS double* sp = (NPHIP_LDS double*)s_par;
@@ -2250,6 +2361,45 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) __attribute__((amdgpu_waves_
         __syncthreads();
     }
     if (chain >= (int64_t)sl.chain_lo + sl.chain_n) return;
+    if (REMOTE) {
+        // Roll call: chains of a resident launch wait for each other inside the kernel, so all of them must be on the device
+        // before any starts.  Each arrives once; the last one sets the verdict GO.  A chain that has waited 5 ms sets it to FAIL
+        // (the device is busy with something that does not end: e.g. another sampler's resident launch) and everybody — also
+        // the chains that only get scheduled later — leaves without having touched anything; the host then falls back to one
+        // launch per evaluation.
+        unsigned long long* verdict = A.grp_go_dev + 1;
+        unsigned* cnt = (unsigned*)(A.grp_go_dev + 2);
+        const unsigned long long mine = (unsigned long long)sl.seq << 8;
+        unsigned state = 0;
+        if (lane == 0) {
+            unsigned long long v = __hip_atomic_load(verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((v >> 8) == (unsigned long long)sl.seq) {
+                state = (unsigned)(v & 0xff);
+            } else if (atomicAdd(cnt, 1u) + 1u == (unsigned)sl.chain_n) {
+                atomicExch(cnt, 0u);
+                for (;;) {
+                    if (atomicCAS(verdict, v, mine | kRollGo) == v) { state = (unsigned)kRollGo; break; }
+                    v = __hip_atomic_load(verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((v >> 8) == (unsigned long long)sl.seq) { state = (unsigned)(v & 0xff); break; }
+                }
+            } else {
+                const long long t0 = wall_clock64();   // 100 MHz
+                for (;;) {
+                    v = __hip_atomic_load(verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((v >> 8) == (unsigned long long)sl.seq) { state = (unsigned)(v & 0xff); break; }
+                    if (wall_clock64() - t0 > 500000ll && atomicCAS(verdict, v, mine | kRollFail) == v) {
+                        A.grp_flag[3] = (unsigned long long)sl.seq;
+                        __threadfence_system();
+                        state = (unsigned)kRollFail;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(16);
+                }
+            }
+        }
+        state = (unsigned)__builtin_amdgcn_readfirstlane((int)state);
+        if (state != (unsigned)kRollGo) return;
+    }
     if (LEAN && threadIdx.x == 0) { s_edge[0] = 0.0; s_edge[2 * W * NV + 1] = 0.0; }   // (the first barrier is in the sigma^2 staging)
     LdsCtl c = (LdsCtl)&s_ctl[wib];
     {
@@ -2258,16 +2408,23 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) __attribute__((amdgpu_waves_
         for (int w = lane; w < kCtlWords; w += 64) dst[w] = src[w];
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    Machine<FUSED, W, NV, LEAN> m(A, c, (LdsDouble)s_red, chain, (LdsDouble)s_par, (LdsDouble)s_ring + (LEAN ? 0 : (size_t)wib * 4 * 128 * (NV > 0 ? NV : 1)),
+    if (REMOTE) {
+        int g = 0;
+        for (int o = 1; o < sl.n_grp; ++o) g += ((int)(chain - sl.chain_lo) >= sl.grp_lo[o]) ? 1 : 0;
+        c->hs_seq = (int64_t)sl.grp_seq[g]; c->hs_last = 0; c->hs_grp = g; c->hs_n = sl.grp_lo[g + 1] - sl.grp_lo[g];
+        const int64_t left = (int64_t)sl.chain_n - (int64_t)blockIdx.x * 4;
+        c->hs_wgn = left < 4 ? left : 4;   // chains of this workgroup (group bounds are multiples of 4: one workgroup, one group)
+    }
+    Machine<FUSED, W, NV, LEAN, REMOTE> m(A, c, (LdsDouble)s_red, chain, (LdsDouble)s_par, (LdsDouble)s_ring + (LEAN ? 0 : (size_t)wib * 4 * 128 * (NV > 0 ? NV : 1)),
                             (LdsDouble)s_edge);
-    m.run(max_evals, have_result != 0, (LEAN || (NV == 0 && W >= 8 && A.sig_lds)) ? (LdsDouble)s_dyn : nullptr);
+    m.run(max_evals, have_result != 0, (LEAN || (NV == 0 && W >= 8 && A.sig_lds)) ? (LdsDouble)s_dyn : nullptr, sl.materialise != 0);
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     if (W == 1 || wib == 0) {
         NPHIP_GLOBAL uint64_t* dst = (NPHIP_GLOBAL uint64_t*)(A.ctl + chain);
         const NPHIP_LDS uint64_t* src = (const NPHIP_LDS uint64_t*)c;
         for (int w = lane; w < kCtlWords; w += 64) dst[w] = src[w];
     }
-    if (sl.grp >= 0) {
+    if (sl.grp >= 0 && !REMOTE) {
         // Pipelined host-callback groups: the host does not synchronise with the stream, it polls a word in pinned host memory.
         // Every chain of the group arrives once (its positions / control block are written and released to the system first);
         // the last arriver publishes the job-wide done / error counts and then the sequence number of this launch.
@@ -2446,8 +2603,33 @@ hipError_t launch_resume(const Args* d_args, int n, const int64_t* d_chains, con
 hipError_t launch_advance(const Args& a, const Args* d_args, bool fused, int W, hipStream_t st, const LaunchSlice* slice) {
     LaunchSlice sl;
     if (slice) sl = *slice;
-    else { sl.chain_lo = 0; sl.chain_n = (int)a.n_chains; sl.grp = -1; sl.seq = 0u; }
+    else { sl.chain_lo = 0; sl.chain_n = (int)a.n_chains; sl.grp = -1; sl.seq = 0u; sl.materialise = 0; }
+    sl.n_grp = 0;
     return fused ? launch_w<true>(a, d_args, W, st, sl) : launch_w<false>(a, d_args, W, st, sl);
+}
+
+// Resident launch of a host-callback group (k_advance<..., REMOTE>): one wave per chain, `nv` chunks of 128 elements in
+// registers (dim <= 128 nv <= 1024).  The slice names the group and the sequence number of the launch's first evaluation.
+hipError_t launch_remote(const Args* d_args, int nv, hipStream_t st, const LaunchSlice& sl) {
+#if defined(NPHIP_DEV_LEAN) || defined(NPHIP_DEV_W1NV)
+    return hipErrorInvalidValue;
+#else
+    const dim3 g(((unsigned)sl.chain_n + 3) / 4), b(256);
+#define NPHIP_LAUNCH_REMOTE(NN) hipLaunchKernelGGL((k_advance<false, 1, NN, false, true>), g, b, 0, st, d_args, 0, 0, sl)
+    switch (nv) {
+        case 1: NPHIP_LAUNCH_REMOTE(1); break;
+        case 2: NPHIP_LAUNCH_REMOTE(2); break;
+        case 3: NPHIP_LAUNCH_REMOTE(3); break;
+        case 4: NPHIP_LAUNCH_REMOTE(4); break;
+        case 5: NPHIP_LAUNCH_REMOTE(5); break;
+        case 6: NPHIP_LAUNCH_REMOTE(6); break;
+        case 7: NPHIP_LAUNCH_REMOTE(7); break;
+        case 8: NPHIP_LAUNCH_REMOTE(8); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef NPHIP_LAUNCH_REMOTE
+    return hipGetLastError();
+#endif
 }
 
 // ----------------------------------------------------------------------------------------

@@ -317,6 +317,34 @@ def test_host_callback_eight_schools_bit_identical(hip, oracle, fixture_lib):
     assert 2.0 < mu.mean() < 7.0
 
 
+@pytest.mark.parametrize("persist", [0, 3, 1, -37], ids=["resident", "resident-3-evals-per-launch", "launch-per-eval", "fall-back-after-37"])
+@pytest.mark.parametrize("groups", [0, 3], ids=["default-groups", "3-groups"])
+def test_host_callback_launch_modes_are_bit_identical(hip, oracle, fixture_lib, persist, groups):
+    """The three ways a host-callback job can run — resident launches (the chain state stays in registers across the
+    evaluations, kernels.hip: REMOTE), one launch per evaluation, and a resident job that falls back mid-way the way a failed
+    roll call makes it — give the oracle's trace bit for bit, with launch boundaries every 3 evaluations as well as every 256."""
+    addr = fn_addr(fixture_lib.eight_schools_logp)
+    got, W = run_engine(hip, hip.HostCallbackModel(10, addr), chains=40, tune=120, draws=60, seed=5, init="normal",
+                        launch=dict(host_persist=persist, host_groups=groups), store_gradient=True)
+    want = oracle.sample_callback(oracle_settings(oracle, chains=40, tune=120, draws=60, seed=5, W=W, init_kind=1, store_gradient=True), 10, addr)
+    assert_trace_equal(got, want)
+    assert np.array_equal(got.stats["gradient"], want.stats["gradient"])
+
+
+@pytest.mark.parametrize("dim", [130, 700, 1024])
+def test_resident_host_callback_wider_rows(hip, oracle, dim):
+    """Resident launches with 2, 6 and 8 chunks of registers per chain (Python callable, two groups of chains)."""
+    sd = np.exp(np.random.default_rng(dim).normal(size=dim) * 0.7)
+
+    def logp(x):
+        z = x / sd
+        return -0.5 * float(z @ z), -z / sd
+
+    got, W = run_engine(hip, hip.HostCallbackModel(dim, logp), chains=6, tune=50, draws=25, seed=dim, launch=dict(host_groups=2, host_persist=256))
+    want = oracle.sample_callback(oracle_settings(oracle, chains=6, tune=50, draws=25, seed=dim, W=W), dim, logp)
+    assert_trace_equal(got, want)
+
+
 def test_bridgestan_adapter_matches_raw_callback(hip, oracle, fixture_lib):
     # the BridgeStan C API stand-in evaluates the same density: identical trace through nphip_model_bridgestan
     model_ptr = fixture_lib.bs_model_construct(None, 0, None)
