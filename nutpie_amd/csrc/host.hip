@@ -754,7 +754,9 @@ bool nphip_sampler::setup() {
             if (zero_copy && !launch.manual && launch.host_groups != 1 && n >= 2) {
                 // measured (profiles/r2_config4_host_callback_pipelining.txt): eight schools, 256 chains: 5.7 -> 6.5 (2 groups) -> 6.7 M
                 // leapfrogs/s (4 groups); 1024 chains: 12.3 -> 14.5 -> 16.2.  The rest of a step is fixed latency (launch, the
-                // kernel's PCIe reads of the gradients, the flag), which groups overlap with each other but cannot shorten.
+                // memory-resident kernel's dependent passes, its PCIe reads of the gradients, the flag), which groups overlap with
+                // each other but cannot shorten — the resident launches below can (profiles/r2_config4_resident_launches.txt: 11.3
+                // and 20 M leapfrogs/s).
                 n_groups = (n >= 128) ? 4 : ((n >= 32) ? 2 : 1);
                 if (launch.host_groups >= 2 && launch.host_groups <= kMaxGroups) n_groups = (int)std::min<uint64_t>(launch.host_groups, n);
                 for (int g = 0; g <= n_groups; ++g) grp_lo[g] = n * (uint64_t)g / (uint64_t)n_groups;
@@ -1163,6 +1165,13 @@ void nphip_sampler::run() {
     for (;;) {
         {
             std::unique_lock<std::mutex> lk(mu);
+            if (want_pause && !want_abort && remote) {
+                // a resident launch would sit on the device for the whole pause (and hold up whatever shares its hardware queue):
+                // bring it to its boundary first
+                lk.unlock();
+                { std::lock_guard<std::mutex> run_lk(mu_run); (void)sync_all(); }
+                lk.lock();
+            }
             cv.wait(lk, [&] { return !want_pause || want_abort; });
             if (want_abort) break;
         }

@@ -345,6 +345,50 @@ def test_resident_host_callback_wider_rows(hip, oracle, dim):
     assert_trace_equal(got, want)
 
 
+def test_resident_job_survives_progress_pause_and_partial_reads(hip, oracle, fixture_lib):
+    """Reading a running resident job (progress, partial trace), pausing and resuming it each bring the launch to a boundary
+    and start a new one: the finished job is still the oracle's, and an aborted one is a prefix of it."""
+    import time
+
+    addr = fn_addr(fixture_lib.eight_schools_logp)
+    kw = dict(chains=48, tune=300, draws=300, seed=9)
+    want = oracle.sample_callback(oracle_settings(oracle, W=1, init_kind=1, **kw), 10, addr)
+
+    def start():
+        s = hip.PyNutsSettings.Diag(kw["seed"])
+        s.update(num_tune=kw["tune"], num_draws=kw["draws"], num_chains=kw["chains"])
+        m = hip.HostCallbackModel(10, addr)
+        m.set_init("normal")
+        return hip.PySampler(s, m)
+
+    smp = start()
+    seen = []
+    for _ in range(6):
+        seen.append(sum(p.finished_draws for p in smp.progress()))
+        part = smp.inspect()
+        k = int(part.finished.min())
+        assert np.array_equal(part.draws[:, :k], want.draws[:, :k])
+        smp.pause()
+        time.sleep(0.005)
+        smp.resume()
+    smp.wait()
+    assert seen == sorted(seen)
+    assert_trace_equal(smp.take_results(), want)
+
+    smp = start()
+    time.sleep(0.02)
+    smp.abort()
+    try:
+        smp.wait()
+    except RuntimeError:
+        pass
+    part = smp.take_results()
+    fin = np.asarray(part.finished)
+    assert (fin <= kw["tune"] + kw["draws"]).all()
+    for c in range(kw["chains"]):
+        assert np.array_equal(part.draws[c, : fin[c]], want.draws[c, : fin[c]])
+
+
 def test_bridgestan_adapter_matches_raw_callback(hip, oracle, fixture_lib):
     # the BridgeStan C API stand-in evaluates the same density: identical trace through nphip_model_bridgestan
     model_ptr = fixture_lib.bs_model_construct(None, 0, None)
