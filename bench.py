@@ -294,7 +294,10 @@ def main():
                      "traffic": (traffic_bpl * leap_per_launch if traffic_bpl else None),
                      "traffic_source": traffic_src, "traffic_bytes_per_leapfrog": traffic_bpl,
                      "kernel": kernel_name(args.dim, W), "avg_kernel_ms": 1000.0 * avg_kernel_s,
-                     "algorithmic_bytes_per_leapfrog": bytes_per_leapfrog},
+                     "algorithmic_bytes_per_leapfrog": bytes_per_leapfrog,
+                     "note": ("achieved = algorithmic bytes (40 B x dim per leapfrog: what a stream-everything kernel moves) / kernel time; "
+                              "traffic = HBM bytes actually moved (PMC).  A kernel that keeps the state on chip moves less than the "
+                              "algorithmic bytes, so frac can pass 1: it is then bound by instruction issue, not by HBM (DESIGN.md 4)")},
     }
     if tuning_phase is not None:
         out["tuning_phase"] = tuning_phase

@@ -198,6 +198,12 @@ uint64_t nphip_sampler_total_draws(const nphip_sampler_t*); /* num_tune + num_dr
 /* wall-clock seconds spent in the sampling loop (excludes allocation) and kernel launches issued */
 double nphip_sampler_seconds(const nphip_sampler_t*);
 uint64_t nphip_sampler_launches(const nphip_sampler_t*);
+/* How a host-callback model is being driven: not a host-callback model / one kernel launch per evaluation /
+ * the same with groups of chains pipelined / resident launches / resident launches that fell back to launches per evaluation
+ * because the device could not hold all chains at once. */
+enum { NPHIP_HOST_MODE_NONE = 0, NPHIP_HOST_MODE_LAUNCH_PER_EVALUATION = 1, NPHIP_HOST_MODE_GROUPS = 2, NPHIP_HOST_MODE_RESIDENT = 3,
+       NPHIP_HOST_MODE_FELL_BACK = 4 };
+int nphip_sampler_host_mode(const nphip_sampler_t* s);
 
 /* Trace hand-off (PyTrace / take_results, wrapper.rs:1431-1494).  All copies are D2H into host
  * memory laid out [local_chain][draw](...).  `finished[local_chain]` (optional) receives the number

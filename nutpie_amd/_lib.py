@@ -167,7 +167,7 @@ def lib():
             L.nphip_sampler_free.argtypes = [C.c_void_p]
             L.nphip_sampler_wait.argtypes = [C.c_void_p, C.c_int64]
             L.nphip_sampler_step.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
-            for f in ("pause", "resume", "abort", "is_finished", "waves_per_chain"):
+            for f in ("pause", "resume", "abort", "is_finished", "waves_per_chain", "host_mode"):
                 getattr(L, "nphip_sampler_" + f).argtypes = [C.c_void_p]
             for f in ("num_chains", "dim", "total_draws", "launches"):
                 getattr(L, "nphip_sampler_" + f).argtypes = [C.c_void_p]
@@ -629,6 +629,14 @@ class PySampler:
     @property
     def launches(self):
         return int(lib().nphip_sampler_launches(self._h))
+
+    @property
+    def host_mode(self):
+        """How a host-callback model is being driven: 'none' (not one), 'launch-per-evaluation', 'groups' (the same, groups of
+        chains pipelined), 'resident' (the kernel waits on the device for the evaluations), 'fell-back' (resident launches that
+        went back to a launch per evaluation because the device could not hold all chains at once)."""
+        self._require()
+        return ("none", "launch-per-evaluation", "groups", "resident", "fell-back")[int(lib().nphip_sampler_host_mode(self._h))]
 
     def wait(self, timeout_seconds=None):
         """Blocks (GIL released by ctypes) — raises ``TimeoutError`` and leaves the sampler running

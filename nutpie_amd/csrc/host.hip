@@ -560,6 +560,7 @@ struct nphip_sampler {
     // is a rendezvous — the kernel publishes its positions and the sequence number, the host evaluates the rows and answers
     // with one word in pinned memory.  grp_seq[g] is then the sequence number the host waits for next.
     bool remote = false;
+    bool remote_fell_back = false;
     int remote_nv = 0;
     int persist_evals = 256;
     volatile unsigned long long* h_grp_go = nullptr;    // pinned [groups][8]
@@ -735,7 +736,9 @@ bool nphip_sampler::setup() {
         // Host callbacks with small batches are latency-bound (five copies + a synchronisation per leapfrog): there the
         // staging buffers ARE the pinned host buffers (coherent, GPU-visible on ROCm) and the kernel reads / writes them
         // over PCIe directly.  Larger batches keep device staging + bulk copies.
-        zero_copy = (model.kind == 1) && !(launch.staging_q && launch.staging_grad && launch.staging_logp) && n * dim * 8 <= (4u << 20);
+        // (up to 4 MB of positions per step; 8 MB where resident launches apply — dim <= 1024, <= 1024 chains — which need them)
+        const uint64_t zc_limit = (n <= 1024 && dim <= 1024) ? (8u << 20) : (4u << 20);
+        zero_copy = (model.kind == 1) && !(launch.staging_q && launch.staging_grad && launch.staging_logp) && n * dim * 8 <= zc_limit;
         if (launch.staging_q && launch.staging_grad && launch.staging_logp) {
             args.qeval = (double*)launch.staging_q; args.geval = (double*)launch.staging_grad; args.ueval = (double*)launch.staging_logp;
         } else if (!zero_copy && (!dalloc(&args.qeval, n * dim) || !dalloc(&args.geval, n * dim) || !dalloc(&args.ueval, n))) return false;
@@ -1093,6 +1096,7 @@ bool nphip_sampler::drain_groups() {
 bool nphip_sampler::remote_fall_back() {
     if (!drain_groups()) return false;
     remote = false;
+    remote_fell_back = true;
     for (int g = 0; g < n_groups; ++g)
         if (!hip_ok(hipStreamSynchronize(grp_stream[g]), "hipStreamSynchronize")) return false;
     materialise = true;
@@ -1308,6 +1312,12 @@ uint64_t nphip_sampler_dim(const nphip_sampler_t* s) { return s->dim; }
 uint64_t nphip_sampler_total_draws(const nphip_sampler_t* s) { return s->T; }
 double nphip_sampler_seconds(const nphip_sampler_t* s) { return s->seconds.load(); }
 uint64_t nphip_sampler_launches(const nphip_sampler_t* s) { return s->launches.load(); }
+int nphip_sampler_host_mode(const nphip_sampler_t* s) {
+    if (s->model.kind != 1) return NPHIP_HOST_MODE_NONE;
+    if (s->remote) return NPHIP_HOST_MODE_RESIDENT;
+    if (s->remote_fell_back) return NPHIP_HOST_MODE_FELL_BACK;
+    return s->n_groups > 0 ? NPHIP_HOST_MODE_GROUPS : NPHIP_HOST_MODE_LAUNCH_PER_EVALUATION;
+}
 
 static bool read_ctl(nphip_sampler_t* s, std::vector<Ctl>& h) {
     h.resize(s->n);

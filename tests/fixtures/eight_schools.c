@@ -51,6 +51,21 @@ int64_t eight_schools_logp(uint64_t dim, const double* x, double* grad, double* 
     return 0;
 }
 
+/* any dimension: independent normals with scales 0.5, 0.8, ..., 2.3, 0.5, ... (sums in index order; used for wide rows and many
+ * chains through the host-callback path) */
+int scaled_normal_logp(uint64_t dim, const double* x, double* grad, double* logp, void* user) {
+    (void)user;
+    double lp = 0.0;
+    for (uint64_t i = 0; i < dim; ++i) {
+        const double sd = 0.5 + 0.3 * (double)(i % 7);
+        const double z = x[i] / sd;
+        lp += -0.5 * z * z;
+        grad[i] = -z / sd;
+    }
+    *logp = lp;
+    return 0;
+}
+
 /* the same density behind a numba-style `int64` return whose upper half is NOT clean: the reference reads the return as
  * `c_int` (src/pymc.rs:23-29), i.e. the low 32 bits — so must the engine */
 int64_t eight_schools_logp_dirty_high(uint64_t dim, const double* x, double* grad, double* logp, void* user) {

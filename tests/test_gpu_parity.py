@@ -19,7 +19,7 @@ from tests.conftest import GOLDEN, assert_trace_equal, fn_addr
 pytestmark = pytest.mark.gpu
 
 
-def run_engine(hip, model, *, chains, tune, draws, seed, waves=0, init=None, launch=None, **settings):
+def run_engine(hip, model, *, chains, tune, draws, seed, waves=0, init=None, launch=None, info=None, **settings):
     s = hip.PyNutsSettings.Diag(seed)
     s.update(num_tune=tune, num_draws=draws, num_chains=chains, **settings)
     if init is not None:
@@ -27,6 +27,8 @@ def run_engine(hip, model, *, chains, tune, draws, seed, waves=0, init=None, lau
     smp = hip.PySampler(s, model, waves_per_chain=waves, **(launch or {}))
     smp.wait()
     W = smp.waves_per_chain
+    if info is not None:
+        info["host_mode"] = smp.host_mode
     return smp.take_results(), W
 
 
@@ -324,8 +326,10 @@ def test_host_callback_launch_modes_are_bit_identical(hip, oracle, fixture_lib, 
     evaluations, kernels.hip: REMOTE), one launch per evaluation, and a resident job that falls back mid-way the way a failed
     roll call makes it — give the oracle's trace bit for bit, with launch boundaries every 3 evaluations as well as every 256."""
     addr = fn_addr(fixture_lib.eight_schools_logp)
+    info = {}
     got, W = run_engine(hip, hip.HostCallbackModel(10, addr), chains=40, tune=120, draws=60, seed=5, init="normal",
-                        launch=dict(host_persist=persist, host_groups=groups), store_gradient=True)
+                        launch=dict(host_persist=persist, host_groups=groups), store_gradient=True, info=info)
+    assert info["host_mode"] == {0: "resident", 3: "resident", 1: "groups", -37: "fell-back"}[persist]   # (the path meant is the path taken)
     want = oracle.sample_callback(oracle_settings(oracle, chains=40, tune=120, draws=60, seed=5, W=W, init_kind=1, store_gradient=True), 10, addr)
     assert_trace_equal(got, want)
     assert np.array_equal(got.stats["gradient"], want.stats["gradient"])
@@ -340,8 +344,23 @@ def test_resident_host_callback_wider_rows(hip, oracle, dim):
         z = x / sd
         return -0.5 * float(z @ z), -z / sd
 
-    got, W = run_engine(hip, hip.HostCallbackModel(dim, logp), chains=6, tune=50, draws=25, seed=dim, launch=dict(host_groups=2, host_persist=256))
+    info = {}
+    got, W = run_engine(hip, hip.HostCallbackModel(dim, logp), chains=6, tune=50, draws=25, seed=dim, launch=dict(host_groups=2, host_persist=256), info=info)
+    assert info["host_mode"] == "resident"
     want = oracle.sample_callback(oracle_settings(oracle, chains=6, tune=50, draws=25, seed=dim, W=W), dim, logp)
+    assert_trace_equal(got, want)
+
+
+def test_resident_launch_that_fills_the_device(hip, oracle, fixture_lib):
+    """1000 dimensions x 1024 chains through the host-callback path: 8 register chunks per chain, i.e. one workgroup per CU and
+    256 workgroups — the resident launch needs the whole device.  Whether its roll call succeeds or (a CU is not available) fails
+    and the job falls back to one launch per evaluation, the trace is the oracle's."""
+    addr = fn_addr(fixture_lib.scaled_normal_logp)
+    info = {}
+    got, W = run_engine(hip, hip.HostCallbackModel(1000, addr), chains=1024, tune=24, draws=8, seed=77, info=info)
+    assert info["host_mode"] in ("resident", "fell-back")
+    print("full-device resident launch:", info["host_mode"])
+    want = oracle.sample_callback(oracle_settings(oracle, chains=1024, tune=24, draws=8, seed=77, W=W), 1000, addr)
     assert_trace_equal(got, want)
 
 
