@@ -561,6 +561,15 @@ struct nphip_sampler {
     // with one word in pinned memory.  grp_seq[g] is then the sequence number the host waits for next.
     bool remote = false;
     bool remote_fell_back = false;
+    // resident launches on a large-BAR system: the results (gradient, logp, code) and the go words live in fine-grained DEVICE
+    // memory that the host writes through the PCIe BAR (write-combining stores: 64 rows in ~0.25 us) — the kernel then polls
+    // and reads local memory instead of host memory over PCIe (a read round trip each).  The callback itself still writes
+    // cached host rows (it may read its own output back; a CPU load from the BAR costs 1.2 us).
+    bool bar = false;
+    double *b_g = nullptr, *b_u = nullptr;
+    int64_t* b_code = nullptr;
+    volatile unsigned long long* b_go = nullptr;
+    void publish_rows(uint64_t lo, uint64_t cnt);
     int remote_nv = 0;
     int persist_evals = 256;
     volatile unsigned long long* h_grp_go = nullptr;    // pinned [groups][8]
@@ -781,10 +790,27 @@ bool nphip_sampler::setup() {
                 persist_evals = launch.host_persist > 1 ? launch.host_persist : 256;
                 if (launch.host_persist < 0) { fall_back_after = -(int64_t)launch.host_persist; persist_evals = 7; }
                 for (int g = 0; g < kMaxGroups; ++g) grp_seq[g] = remote ? 1u : 0u;
+                if (remote && !getenv("NPHIP_NO_BAR")) {
+                    int large_bar = 0;
+                    if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, device) != hipSuccess) large_bar = 0;
+                    void *pg = nullptr, *pu = nullptr, *pc = nullptr, *po = nullptr;
+                    if (large_bar && hipExtMallocWithFlags(&pg, std::max<size_t>(8, n * dim * 8), hipDeviceMallocFinegrained) == hipSuccess &&
+                        hipExtMallocWithFlags(&pu, n * 8, hipDeviceMallocFinegrained) == hipSuccess &&
+                        hipExtMallocWithFlags(&pc, n * 8, hipDeviceMallocFinegrained) == hipSuccess &&
+                        hipExtMallocWithFlags(&po, 8 * kMaxGroups * 8, hipDeviceMallocFinegrained) == hipSuccess) {
+                        bar = true;
+                        b_g = (double*)pg; b_u = (double*)pu; b_code = (int64_t*)pc; b_go = (volatile unsigned long long*)po;
+                        for (int i = 0; i < 8 * kMaxGroups; ++i) b_go[i] = 0ull;
+                        args.geval = b_g; args.ueval = b_u; args.ecode = b_code; args.grp_go = b_go;
+                    } else {
+                        (void)hipGetLastError();
+                    }
+                    for (void* q : {pg, pu, pc, po}) if (q) allocs.push_back(q);
+                }
                 if (remote) {
                     // (a step of a resident group is ~20 us of device latency — PCIe round trips and one L2 write-back — and ~3 us of
                     //  host work per 64 rows: eight groups keep the driver thread busy while seven of them are in flight)
-                    if (launch.host_groups == 0 && n >= 256) n_groups = 8;
+                    if (launch.host_groups == 0) n_groups = (int)std::max<uint64_t>(1, std::min<uint64_t>(8, n / 8));
                     // a workgroup holds four chains, and they rendezvous as one (kernels.hip: remote_sync): group bounds on multiples of 4
                     n_groups = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)n_groups, (n + 3) / 4));
                     for (int g = 1; g < n_groups; ++g) grp_lo[g] = (((n + 3) / 4) * (uint64_t)g / (uint64_t)n_groups) * 4;
@@ -1023,6 +1049,19 @@ bool nphip_sampler::launch_remote_all() {
     sl.seq = ++remote_launch_id;
     sl.materialise = 0;
     sl.n_grp = n_groups;
+    if (bar && remote_evals >= 64) {
+        // The BAR copy of the results takes PCIe reads off the device's critical path and costs the driver thread the copy.  It
+        // pays while the device is what the job waits for; once a round of host work (every group's rows) is longer than a
+        // device step (~20 us) the host is the bound and the copy only adds to it: back to results in host memory (launch boundary:
+        // nothing is in flight).  Measured: eight schools, 256 chains 10.5 -> 12.2 M leapfrogs/s with the copy, 1024 chains 19.5 -> 16.3.
+        const double host_round_us = (double)n_groups * (t_eval_ns / (double)remote_evals + 800.0) * 1e-3;
+        if (host_round_us > 25.0) {
+            bar = false;
+            args.geval = h_g; args.ueval = h_u; args.ecode = h_code; args.grp_go = h_grp_go;
+            for (int g = 0; g < n_groups; ++g) h_grp_go[8 * g] = 0ull;
+            if (!hip_ok(hipMemcpyAsync(d_args, &args, sizeof(Args), hipMemcpyHostToDevice, grp_stream[0]), "update args")) return false;
+        }
+    }
     for (int g = 0; g <= kMaxGroups; ++g) sl.grp_lo[g] = (int)grp_lo[std::min(g, n_groups)];
     for (int g = 0; g < kMaxGroups; ++g) sl.grp_seq[g] = grp_seq[g];   // a group's first evaluation carries the number the host waits for
     if (!hip_ok(launch_remote(d_args, remote_nv, grp_stream[0], sl), "launch k_advance (resident)")) return false;
@@ -1067,11 +1106,29 @@ int nphip_sampler::wait_remote(int only) {
     }
 }
 
+static inline void store_fence() {
+#if defined(__x86_64__)
+    __builtin_ia32_sfence();   // write-combining stores (the BAR) become globally visible, in order with what follows
+#else
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+#endif
+}
+
+// large BAR: the rows the callback just wrote (cached host memory) go to the device's copy
+void nphip_sampler::publish_rows(uint64_t lo, uint64_t cnt) {
+    if (!bar) return;
+    memcpy(b_g + lo * dim, h_g + lo * dim, cnt * dim * 8);
+    memcpy(b_u + lo, h_u + lo, cnt * 8);
+    memcpy(b_code + lo, h_code + lo, cnt * 8);
+    store_fence();
+}
+
 // results of the evaluation grp_seq[g] are in the staging rows: one word to the kernel; `last` ends the group's part of the
 // launch at the next boundary
 void nphip_sampler::answer_group(int g, bool last) {
     std::atomic_thread_fence(std::memory_order_release);
-    h_grp_go[8 * g] = (unsigned long long)grp_seq[g] | (last ? kGoLast : 0ull);
+    (bar ? b_go : h_grp_go)[8 * g] = (unsigned long long)grp_seq[g] | (last ? kGoLast : 0ull);
+    if (bar) store_fence();
     std::atomic_thread_fence(std::memory_order_seq_cst);
     grp_seq[g] += 1;
     if (last) grp_running[g] = false;
@@ -1087,6 +1144,7 @@ bool nphip_sampler::drain_groups() {
         if (w == -1) return false;
         if (w == -2) { for (int o = 0; o < n_groups; ++o) grp_running[o] = false; break; }   // nothing ran
         eval_rows(grp_lo[g], grp_lo[g + 1] - grp_lo[g]);
+        publish_rows(grp_lo[g], grp_lo[g + 1] - grp_lo[g]);
         answer_group(g, true);
     }
     return true;
@@ -1099,35 +1157,44 @@ bool nphip_sampler::remote_fall_back() {
     remote_fell_back = true;
     for (int g = 0; g < n_groups; ++g)
         if (!hip_ok(hipStreamSynchronize(grp_stream[g]), "hipStreamSynchronize")) return false;
+    if (bar) {
+        // launches per evaluation read the host's rows directly
+        bar = false;
+        args.geval = h_g; args.ueval = h_u; args.ecode = h_code; args.grp_go = h_grp_go;
+        if (!hip_ok(hipMemcpy(d_args, &args, sizeof(Args), hipMemcpyHostToDevice), "update args")) return false;
+    }
     materialise = true;
     grp_primed = false;
     return true;
 }
 
-// One evaluation of one group: whichever has published first.
+// One evaluation of each group, in the order in which they publish.
 bool nphip_sampler::iteration_remote(bool& all_done) {
     if (!grp_primed) {
         if (!hip_ok(hipStreamSynchronize(stream), "hipStreamSynchronize")) return false;   // set-up copies ran on the main stream
         grp_primed = true;
     }
-    if (fall_back_after > 0 && remote_evals >= fall_back_after) return remote_fall_back();
-    bool any = false;
-    for (int g = 0; g < n_groups; ++g) any = any || grp_running[g];
-    if (!any && !launch_remote_all()) return false;
-    const auto tw0 = std::chrono::steady_clock::now();
-    const int g = wait_remote(-1);
-    const auto tw1 = std::chrono::steady_clock::now();
-    t_wait_ns += std::chrono::duration<double, std::nano>(tw1 - tw0).count();
-    if (g == -1) return false;
-    if (g == -2) { for (int o = 0; o < n_groups; ++o) grp_running[o] = false; return remote_fall_back(); }
-    const unsigned long long pub = h_grp_flag[4 * g];
-    if (pub & kPubError) { (void)sync_all(); set_error(chain_error_message()); return false; }
-    if (pub & kPubAllDone) { all_done = true; return sync_all(); }
-    eval_rows(grp_lo[g], grp_lo[g + 1] - grp_lo[g]);
-    t_eval_ns += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - tw1).count();
-    grp_evals[g] += 1;
-    remote_evals += 1;
-    answer_group(g, grp_evals[g] >= persist_evals);
+    for (int round = 0; round < n_groups; ++round) {
+        if (fall_back_after > 0 && remote_evals >= fall_back_after) return remote_fall_back();
+        bool any = false;
+        for (int g = 0; g < n_groups; ++g) any = any || grp_running[g];
+        if (!any && !launch_remote_all()) return false;
+        const auto tw0 = std::chrono::steady_clock::now();
+        const int g = wait_remote(-1);
+        const auto tw1 = std::chrono::steady_clock::now();
+        t_wait_ns += std::chrono::duration<double, std::nano>(tw1 - tw0).count();
+        if (g == -1) return false;
+        if (g == -2) { for (int o = 0; o < n_groups; ++o) grp_running[o] = false; return remote_fall_back(); }
+        const unsigned long long pub = h_grp_flag[4 * g];
+        if (pub & kPubError) { (void)sync_all(); set_error(chain_error_message()); return false; }
+        if (pub & kPubAllDone) { all_done = true; return sync_all(); }
+        eval_rows(grp_lo[g], grp_lo[g + 1] - grp_lo[g]);
+        publish_rows(grp_lo[g], grp_lo[g + 1] - grp_lo[g]);
+        t_eval_ns += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - tw1).count();
+        grp_evals[g] += 1;
+        remote_evals += 1;
+        answer_group(g, grp_evals[g] >= persist_evals);
+    }
     return true;
 }
 
