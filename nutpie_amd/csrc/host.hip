@@ -1089,7 +1089,9 @@ int nphip_sampler::wait_remote(int only) {
         if ((spin & 0xff) == 0) {
             if (remote_fresh && h_grp_flag[3] == (unsigned long long)remote_launch_id) return -2;
             if ((spin & 0xffff) == 0) {
-                if (hipStreamQuery(grp_stream[0]) == hipSuccess) {
+                const hipError_t q = hipStreamQuery(grp_stream[0]);
+                if (q != hipSuccess && q != hipErrorNotReady) { (void)hip_ok(q, "resident launch"); return -1; }
+                if (q == hipSuccess) {
                     bool any = false;
                     for (int g = 0; g < n_groups; ++g) any = any || (grp_running[g] && poll_remote(g));
                     if (!any && !(remote_fresh && h_grp_flag[3] == (unsigned long long)remote_launch_id)) {
