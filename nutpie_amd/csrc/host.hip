@@ -420,9 +420,11 @@ struct RowPool {
         std::this_thread::yield();
 #endif
     }
+    int active_workers = 0;   // workers taking part in the current batch (the others only acknowledge it)
     explicit RowPool(int n) {
-        for (int i = 1; i < n; ++i) threads.emplace_back([this] { loop(); });
+        for (int i = 1; i < n; ++i) threads.emplace_back([this, i] { loop(i - 1); });
     }
+    int size() const { return (int)threads.size() + 1; }
     ~RowPool() {
         { std::lock_guard<std::mutex> lk(mu); stop.store(true); }
         cv.notify_all();
@@ -436,7 +438,7 @@ struct RowPool {
             for (uint64_t r = r0; r < r1; ++r) (*job)(r);
         }
     }
-    void loop() {
+    void loop(int index) {
         uint64_t seen = 0;
         for (;;) {
             int spins = 0;
@@ -454,15 +456,18 @@ struct RowPool {
             }
             if (stop.load(std::memory_order_relaxed)) return;
             seen += 1;   // (a new batch starts only after every worker acknowledged the previous one)
-            work();
+            if (index < active_workers) work();
             acks.fetch_add(1, std::memory_order_release);
         }
     }
-    void run(uint64_t rows, const std::function<void(uint64_t)>& f) {
-        if (threads.empty() || rows < 2) { for (uint64_t r = 0; r < rows; ++r) f(r); return; }
+    // `use` threads (the caller included) share the rows; 0 = all of them
+    void run(uint64_t rows, const std::function<void(uint64_t)>& f, int use = 0) {
+        if (use <= 0 || use > size()) use = size();
+        if (threads.empty() || rows < 2 || use < 2) { for (uint64_t r = 0; r < rows; ++r) f(r); return; }
         job = &f;
         n_rows = rows;
-        chunk = std::max<uint64_t>(1, rows / (4 * (threads.size() + 1)));
+        active_workers = use - 1;
+        chunk = std::max<uint64_t>(1, rows / (4 * (uint64_t)use));
         next.store(0, std::memory_order_relaxed);
         acks.store(0, std::memory_order_relaxed);
         gen.fetch_add(1);
@@ -495,7 +500,10 @@ struct nphip_sampler {
     double *h_q = nullptr, *h_g = nullptr, *h_u = nullptr;  // pinned staging (host callback)
     int64_t* h_code = nullptr;
     std::unique_ptr<RowPool> pool;
+    struct RowRange { uint64_t lo, cnt; };
     void eval_rows(uint64_t lo, uint64_t cnt);
+    void eval_ranges(const RowRange* rg, int nr);
+    int host_cores = 1;
     double row_ns = 0.0;     // cheapest timed batch so far, per row
     int timed_batches = 0;
     int eval_threads = 1;
@@ -755,12 +763,8 @@ bool nphip_sampler::setup() {
             if (!zero_copy && !dalloc(&args.ecode, n)) return false;
             if (!palloc(&h_q, n * dim) || !palloc(&h_g, n * dim) || !palloc(&h_u, n) || !palloc(&h_code, n)) return false;
             if (zero_copy) { args.qeval = h_q; args.geval = h_g; args.ueval = h_u; args.ecode = h_code; }
-            // n_threads > 0: that many evaluation threads.  n_threads == 0: the first batches are evaluated on the driver thread and
-            // timed, then the pool is sized so that every thread gets ~8 us of rows per batch (eval_rows)
-            if (model.n_threads > 0) {
-                const int nt = (int)std::min<uint64_t>((uint64_t)model.n_threads, n);
-                pool.reset(new RowPool(nt));
-            }
+            // n_threads > 0: that many evaluation threads.  n_threads == 0: threads per batch from the measured cost of a row (eval_ranges)
+            host_cores = usable_cores();
             // pipelining: two groups of chains in flight — while the host evaluates the rows of one group the
             // kernel of the other runs.  Zero-copy batches only (they are the latency-bound ones); launch.host_groups = 1 turns it off.
             if (zero_copy && !launch.manual && launch.host_groups != 1 && n >= 2) {
@@ -785,8 +789,10 @@ bool nphip_sampler::setup() {
                 h_grp_go = go;
                 args.grp_go = go;
                 remote_nv = (int)(args.ld / 128);
+                // (above 4 MB of positions per step the job is bound by PCIe traffic either way, and launches per evaluation were 15 %
+                //  faster at 1024 chains x 1000 dimensions: resident only when asked for)
                 remote = W == 1 && remote_nv <= 8 && n <= 1024 && launch.host_persist != 1 && !launch.no_register_kernel &&
-                         !set.store_divergences && set.pause_draws.empty();
+                         !set.store_divergences && set.pause_draws.empty() && (n * dim * 8 <= (4u << 20) || launch.host_persist > 1);
                 persist_evals = launch.host_persist > 1 ? launch.host_persist : 256;
                 if (launch.host_persist < 0) { fall_back_after = -(int64_t)launch.host_persist; persist_evals = 7; }
                 for (int g = 0; g < kMaxGroups; ++g) grp_seq[g] = remote ? 1u : 0u;
@@ -893,27 +899,40 @@ bool nphip_sampler::iteration_fused(bool& all_done) {
 // Host callback on the rows [lo, lo + cnt) of the staging buffers (the reference calls the same function pointer once per
 // chain-step from its worker threads: src/pymc.rs:197-215).
 void nphip_sampler::eval_rows(uint64_t lo, uint64_t cnt) {
+    const RowRange one{lo, cnt};
+    eval_ranges(&one, 1);
+}
+
+// The rows of several ranges as ONE batch (resident launches: every group that has published by now).  Threads: the model's
+// n_threads when given; otherwise from the measured cost of a row — batches evaluated on this thread are timed — so that every
+// thread gets >= 10 us of rows (a batch of 256 rows of 40 ns is faster on one thread than handed out; 32 rows of 1.6 us are not).
+void nphip_sampler::eval_ranges(const RowRange* rg, int nr) {
     const uint64_t d = dim;
-    const std::function<void(uint64_t)> f = [this, d, lo](uint64_t r) {
-        const uint64_t row = lo + r;
+    uint64_t total = 0;
+    for (int k = 0; k < nr; ++k) total += rg[k].cnt;
+    const std::function<void(uint64_t)> f = [this, d, rg, nr](uint64_t r) {
+        int k = 0;
+        while (k + 1 < nr && r >= rg[k].cnt) { r -= rg[k].cnt; ++k; }
+        const uint64_t row = rg[k].lo + r;
         double lp = NAN;
         h_code[row] = (int64_t)model.host_fn(d, h_q + row * d, h_g + row * d, &lp, model.user);   // c_int, sign-extended
         h_u[row] = lp;
     };
-    if (pool) { pool->run(cnt, f); return; }
-    // no pool yet: evaluate here and time it; after a few batches the cheapest one sizes the pool
-    const auto t0 = std::chrono::steady_clock::now();
-    for (uint64_t r = 0; r < cnt; ++r) f(r);
-    const double ns = std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t0).count() / (double)std::max<uint64_t>(1, cnt);
-    row_ns = (timed_batches == 0) ? ns : std::min(row_ns, ns);
-    if (++timed_batches >= 6) {
-        const double per_thread_ns = 50000.0;   // (measured: handing 64 rows of 40 ns to a second thread costs more than it saves)
-        int nt = (int)std::ceil((double)cnt * row_ns / per_thread_ns);
-        nt = std::max(1, std::min(nt, std::max(1, usable_cores() - 1)));
-        if ((uint64_t)nt > cnt) nt = (int)cnt;
-        pool.reset(new RowPool(nt));
-        eval_threads = nt;
+    int want = 1;
+    if (model.n_threads > 0) want = (int)std::min<uint64_t>((uint64_t)model.n_threads, total);
+    else if (timed_batches >= 4 && row_ns >= 150.0)   // (rows cheaper than that are faster on one thread: measured with 35 ns rows)
+        want = (int)std::min<double>((double)std::max(1, host_cores - 1), std::floor((double)total * row_ns / 10000.0));
+    if (want >= 2) {
+        if (!pool) pool.reset(new RowPool(model.n_threads > 0 ? model.n_threads : std::max(2, host_cores - 1)));
+        eval_threads = std::max(eval_threads, want);
+        pool->run(total, f, want);
+        return;
     }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint64_t r = 0; r < total; ++r) f(r);
+    const double ns = std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t0).count() / (double)std::max<uint64_t>(1, total);
+    row_ns = (timed_batches == 0) ? ns : std::min(row_ns, ns);
+    timed_batches += 1;
 }
 
 bool nphip_sampler::iteration_callback(bool& all_done, int& have) {
@@ -1170,32 +1189,50 @@ bool nphip_sampler::remote_fall_back() {
     return true;
 }
 
-// One evaluation of each group, in the order in which they publish.
+// Every group that has published by now is evaluated as one batch and answered; up to one round of groups per call.  (With a
+// cheap callback the groups come one at a time and the device is what the job waits for; with an expensive one all the other
+// groups publish while a batch is being evaluated, and the batches grow until the evaluation pool is busy.)
 bool nphip_sampler::iteration_remote(bool& all_done) {
     if (!grp_primed) {
         if (!hip_ok(hipStreamSynchronize(stream), "hipStreamSynchronize")) return false;   // set-up copies ran on the main stream
         grp_primed = true;
     }
-    for (int round = 0; round < n_groups; ++round) {
+    for (int served = 0; served < n_groups;) {
         if (fall_back_after > 0 && remote_evals >= fall_back_after) return remote_fall_back();
         bool any = false;
         for (int g = 0; g < n_groups; ++g) any = any || grp_running[g];
         if (!any && !launch_remote_all()) return false;
         const auto tw0 = std::chrono::steady_clock::now();
-        const int g = wait_remote(-1);
+        const int first = wait_remote(-1);
         const auto tw1 = std::chrono::steady_clock::now();
         t_wait_ns += std::chrono::duration<double, std::nano>(tw1 - tw0).count();
-        if (g == -1) return false;
-        if (g == -2) { for (int o = 0; o < n_groups; ++o) grp_running[o] = false; return remote_fall_back(); }
-        const unsigned long long pub = h_grp_flag[4 * g];
-        if (pub & kPubError) { (void)sync_all(); set_error(chain_error_message()); return false; }
-        if (pub & kPubAllDone) { all_done = true; return sync_all(); }
-        eval_rows(grp_lo[g], grp_lo[g + 1] - grp_lo[g]);
-        publish_rows(grp_lo[g], grp_lo[g + 1] - grp_lo[g]);
+        if (first == -1) return false;
+        if (first == -2) { for (int o = 0; o < n_groups; ++o) grp_running[o] = false; return remote_fall_back(); }
+        int ready[kMaxGroups];
+        RowRange rg[kMaxGroups];
+        int nr = 0;
+        // (looking at the other groups' flags costs a cache miss each: only when a batch is long enough for them to have published)
+        const bool gather = model.n_threads > 1 || (timed_batches >= 4 && row_ns * (double)(grp_lo[first + 1] - grp_lo[first]) > 8000.0);
+        for (int k = 0; k < (gather ? n_groups : 1); ++k) {
+            const int g = (first + k) % n_groups;
+            if (!grp_running[g] || (g != first && !poll_remote(g))) continue;
+            const unsigned long long pub = h_grp_flag[4 * g];
+            if (pub & kPubError) { (void)sync_all(); set_error(chain_error_message()); return false; }
+            if (pub & kPubAllDone) { all_done = true; return sync_all(); }
+            ready[nr] = g;
+            rg[nr] = RowRange{grp_lo[g], grp_lo[g + 1] - grp_lo[g]};
+            nr += 1;
+        }
+        eval_ranges(rg, nr);
+        for (int k = 0; k < nr; ++k) publish_rows(rg[k].lo, rg[k].cnt);
         t_eval_ns += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - tw1).count();
-        grp_evals[g] += 1;
-        remote_evals += 1;
-        answer_group(g, grp_evals[g] >= persist_evals);
+        for (int k = 0; k < nr; ++k) {
+            const int g = ready[k];
+            grp_evals[g] += 1;
+            remote_evals += 1;
+            answer_group(g, grp_evals[g] >= persist_evals);
+        }
+        served += nr;
     }
     return true;
 }

@@ -357,7 +357,7 @@ def test_resident_launch_that_fills_the_device(hip, oracle, fixture_lib):
     and the job falls back to one launch per evaluation, the trace is the oracle's."""
     addr = fn_addr(fixture_lib.scaled_normal_logp)
     info = {}
-    got, W = run_engine(hip, hip.HostCallbackModel(1000, addr), chains=1024, tune=24, draws=8, seed=77, info=info)
+    got, W = run_engine(hip, hip.HostCallbackModel(1000, addr), chains=1024, tune=24, draws=8, seed=77, info=info, launch=dict(host_persist=256))
     assert info["host_mode"] in ("resident", "fell-back")
     print("full-device resident launch:", info["host_mode"])
     want = oracle.sample_callback(oracle_settings(oracle, chains=1024, tune=24, draws=8, seed=77, W=W), 1000, addr)
