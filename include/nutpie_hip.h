@@ -238,6 +238,9 @@ void* nphip_sampler_device_ptr(nphip_sampler_t*, const char* name);
 int nphip_test_detmath(int device, int fn, uint64_t n, const double* x, double* y);
 /* dot product in the engine's summation order with W waves */
 int nphip_test_dot(int device, int waves, uint64_t n, const double* x, const double* y, double* out);
+/* host-only: the evaluation pool of the host-callback path (spin-waiting workers, `use` threads per batch); row r of batch b
+ * adds (b + 1) * (r + 1) into out[r]; *usable_cores = the core count the pool is sized against (affinity and cgroup quota) */
+int nphip_test_rowpool(int threads, uint64_t rows, int batches, int use, uint64_t* out, int* usable_cores);
 
 #ifdef __cplusplus
 }

@@ -181,6 +181,7 @@ def lib():
             L.nphip_sampler_device_ptr.argtypes = [C.c_void_p, C.c_char_p]
             L.nphip_test_detmath.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p]
             L.nphip_test_dot.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+            L.nphip_test_rowpool.argtypes = [C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int)]
             _lib = L
     return _lib
 
@@ -802,6 +803,15 @@ class PySampler:
 
 
 # --------------------------------------------------------------------------- test hooks
+def test_rowpool(threads, rows, batches, use=0):
+    """Host-only: run the evaluation pool of the host-callback path; returns (per-row sums, usable cores)."""
+    out = np.zeros(int(rows), dtype=np.uint64)
+    cores = C.c_int(0)
+    if lib().nphip_test_rowpool(int(threads), C.c_uint64(int(rows)), int(batches), int(use), out.ctypes.data_as(C.c_void_p), C.byref(cores)) != NPHIP_OK:
+        raise RuntimeError(_err())
+    return out, int(cores.value)
+
+
 def test_detmath(fn: str, x, device=0):
     code = {"exp": 0, "log": 1, "log1p": 2, "sin2pi": 3, "cos2pi": 4, "sqrt": 5, "recip": 6}[fn]
     x = np.ascontiguousarray(x, dtype=np.float64)

@@ -1620,4 +1620,17 @@ int nphip_test_dot(int device, int waves, uint64_t n, const double* x, const dou
     return ok ? NPHIP_OK : NPHIP_ERR;
 }
 
+// Host-side test hook (no GPU involved): `batches` batches of `rows` rows on an evaluation pool of `threads` threads, `use` of
+// them per batch (0 = all); row r of batch b adds (b + 1) * (r + 1) into out[r].  Also reports the cores the pool sizing sees.
+int nphip_test_rowpool(int threads, uint64_t rows, int batches, int use, uint64_t* out, int* usable_cores_out) {
+    if (usable_cores_out) *usable_cores_out = usable_cores();
+    RowPool pool(threads);
+    for (int b = 0; b < batches; ++b) {
+        const std::function<void(uint64_t)> f = [out, b](uint64_t r) { out[r] += (uint64_t)(b + 1) * (r + 1); };
+        pool.run(rows, f, use);
+        if ((b % 7) == 3) std::this_thread::sleep_for(std::chrono::microseconds(600));   // lets the workers fall asleep in between
+    }
+    return NPHIP_OK;
+}
+
 }  // extern "C"

@@ -1,4 +1,5 @@
 """Host-side logic that runs without a GPU: trace assembly, ESS, sample() argument handling, Gaussian targets."""
+import os
 import warnings
 
 import numpy as np
@@ -285,3 +286,16 @@ def test_install_as_nutpie_alias():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root)
     assert r.returncode == 0 and "alias ok" in r.stdout, r.stderr
+
+
+@pytest.mark.parametrize("threads,use", [(1, 0), (2, 0), (5, 0), (5, 2), (8, 1), (3, 7)])
+def test_evaluation_pool_runs_every_row_exactly_once(threads, use):
+    """The host-callback evaluation pool (spin-waiting workers that fall asleep when idle, a per-batch thread count): every row
+    of every batch is evaluated exactly once, whatever the split."""
+    from nutpie_amd import _lib
+
+    for rows, batches in ((1, 5), (7, 40), (257, 200), (4096, 30)):
+        got, cores = _lib.test_rowpool(threads, rows, batches, use)
+        want = (np.arange(1, rows + 1, dtype=np.uint64) * np.uint64(batches * (batches + 1) // 2))
+        assert np.array_equal(got, want), (rows, batches)
+    assert 1 <= cores <= os.cpu_count()
