@@ -544,8 +544,15 @@ struct nphip_sampler {
     void run();
     bool manual = false;
     int manual_have = 0;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // kernel timing (nphip_sampler_step with kernel_ms): one pair of HIP events around every launch, read after the last one
+    std::vector<hipEvent_t> tev;
+    size_t timed_launches = 0;
     double* kernel_ms_acc = nullptr;  // when set, iterations time their kernel with HIP events
+    // fused models: the next launch is enqueued before the counters of the previous one are looked at (no idle device between
+    // two launches); the "all chains done" / error check therefore runs one launch behind
+    hipEvent_t ev_f[2] = {nullptr, nullptr};
+    uint64_t fused_k = 0;
+    bool check_counters(int slot, bool& all_done);
     bool launch_kernel(bool fused_, int have);
     bool iteration_fused(bool& all_done);
     bool iteration_graph(bool& all_done);
@@ -617,7 +624,9 @@ struct nphip_sampler {
         allocs.clear();
         for (void* h : pinned) (void)hipHostFree(h);
         pinned.clear();
-        if (ev0) { (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1); ev0 = ev1 = nullptr; }
+        for (auto& e : tev) (void)hipEventDestroy(e);
+        tev.clear();
+        for (auto& e : ev_f) if (e) { (void)hipEventDestroy(e); e = nullptr; }
         if (cb_graph) { (void)hipGraphExecDestroy(cb_graph); cb_graph = nullptr; }
         for (auto& e : cb_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
         for (auto& gs : grp_stream) if (gs) { (void)hipStreamDestroy(gs); gs = nullptr; }
@@ -845,7 +854,7 @@ bool nphip_sampler::setup() {
     if (!dalloc(&args.st_energy, nt) || !dalloc(&args.st_energy_error, nt) || !dalloc(&args.st_logp, nt)) return false;
     if (!dalloc(&args.st_step, nt) || !dalloc(&args.st_step_bar, nt)) return false;
     if (!dalloc(&args.st_accept, nt) || !dalloc(&args.st_accept_sym, nt)) return false;
-    if (!palloc(&h_counters, 2)) return false;
+    if (!palloc(&h_counters, 4)) return false;   // two slots of (chains done, chains in error)
     if (!dalloc(&d_args, 1)) return false;
     HIP_TRY(hipMemcpyAsync(d_args, &args, sizeof(Args), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipStreamSynchronize(stream));
@@ -870,30 +879,41 @@ bool nphip_sampler::launch_kernel(bool fused_, int have) {
     args.max_evals = fused_ ? (launch.evals_per_launch > 0 ? launch.evals_per_launch : 512) : 0;
     args.have_result = have;
     if (kernel_ms_acc) {
-        if (!ev0) {
-            if (!hip_ok(hipEventCreate(&ev0), "hipEventCreate") || !hip_ok(hipEventCreate(&ev1), "hipEventCreate")) return false;
+        while (tev.size() < 2 * (timed_launches + 1)) {
+            hipEvent_t e = nullptr;
+            if (!hip_ok(hipEventCreate(&e), "hipEventCreate")) return false;
+            tev.push_back(e);
         }
-        if (!hip_ok(hipEventRecord(ev0, stream), "hipEventRecord")) return false;
+        if (!hip_ok(hipEventRecord(tev[2 * timed_launches], stream), "hipEventRecord")) return false;
     }
     if (!hip_ok(launch_advance(args, d_args, fused_, W, stream), "launch k_advance")) return false;
     if (kernel_ms_acc) {
-        if (!hip_ok(hipEventRecord(ev1, stream), "hipEventRecord")) return false;
-        if (!hip_ok(hipEventSynchronize(ev1), "hipEventSynchronize")) return false;
-        float ms = 0.f;
-        if (!hip_ok(hipEventElapsedTime(&ms, ev0, ev1), "hipEventElapsedTime")) return false;
-        *kernel_ms_acc += (double)ms;
+        if (!hip_ok(hipEventRecord(tev[2 * timed_launches + 1], stream), "hipEventRecord")) return false;
+        timed_launches += 1;
     }
     launches.fetch_add(1);
     return true;
 }
 
-bool nphip_sampler::iteration_fused(bool& all_done) {
-    if (!launch_kernel(true, 0)) return false;
-    if (!hip_ok(hipMemcpyAsync(h_counters, args.counters, 16, hipMemcpyDeviceToHost, stream), "copy counters")) return false;
-    if (!hip_ok(hipStreamSynchronize(stream), "hipStreamSynchronize")) return false;
-    if (h_counters[1] > 0) { set_error(chain_error_message()); return false; }
-    all_done = h_counters[0] >= n;
+bool nphip_sampler::check_counters(int slot, bool& all_done) {
+    const unsigned long long* hc = h_counters + 2 * slot;
+    if (hc[1] > 0) { (void)hipStreamSynchronize(stream); set_error(chain_error_message()); return false; }
+    all_done = hc[0] >= n;
     return true;
+}
+
+bool nphip_sampler::iteration_fused(bool& all_done) {
+    const int slot = (int)(fused_k & 1);
+    if (!ev_f[0] && (!hip_ok(hipEventCreateWithFlags(&ev_f[0], hipEventDisableTiming), "hipEventCreate") ||
+                     !hip_ok(hipEventCreateWithFlags(&ev_f[1], hipEventDisableTiming), "hipEventCreate"))) return false;
+    if (!launch_kernel(true, 0)) return false;
+    if (!hip_ok(hipMemcpyAsync(h_counters + 2 * slot, args.counters, 16, hipMemcpyDeviceToHost, stream), "copy counters")) return false;
+    if (!hip_ok(hipEventRecord(ev_f[slot], stream), "hipEventRecord")) return false;
+    fused_k += 1;
+    if (fused_k < 2) return true;
+    // the launch before this one: by now it has the device to itself no longer — its successor is queued behind it
+    if (!hip_ok(hipEventSynchronize(ev_f[slot ^ 1]), "hipEventSynchronize")) return false;
+    return check_counters(slot ^ 1, all_done);
 }
 
 // Host callback on the rows [lo, lo + cnt) of the staging buffers (the reference calls the same function pointer once per
@@ -1356,6 +1376,7 @@ int nphip_sampler_step(nphip_sampler_t* s, uint64_t n_launches, double* kernel_m
     (void)hipSetDevice(s->device);
     std::lock_guard<std::mutex> run_lk(s->mu_run);
     s->kernel_ms_acc = kernel_ms;
+    s->timed_launches = 0;
     bool all_done = false, ok = true;
     auto t0 = std::chrono::steady_clock::now();
     for (uint64_t i = 0; i < n_launches && !all_done; ++i) {
@@ -1365,6 +1386,14 @@ int nphip_sampler_step(nphip_sampler_t* s, uint64_t n_launches, double* kernel_m
     }
     s->kernel_ms_acc = nullptr;
     if (ok) ok = hip_ok(hipStreamSynchronize(s->stream), "hipStreamSynchronize");
+    if (ok && s->fused && s->fused_k > 0 && !all_done) ok = s->check_counters((int)((s->fused_k - 1) & 1), all_done);   // (the last launch, too)
+    if (ok && kernel_ms) {
+        for (size_t i = 0; i < s->timed_launches && ok; ++i) {
+            float ms = 0.f;
+            ok = hip_ok(hipEventElapsedTime(&ms, s->tev[2 * i], s->tev[2 * i + 1]), "hipEventElapsedTime");
+            *kernel_ms += (double)ms;
+        }
+    }
     s->seconds.store(s->seconds.load() + std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     if (!ok) { s->fail(t_error); return NPHIP_WAIT_ERROR; }
     if (all_done) {
