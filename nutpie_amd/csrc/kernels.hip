@@ -969,9 +969,13 @@ struct Machine {
         if (NV <= 0) return;
         if (X.dirty_qg || X.dirty_pr) { if (LEAN) lean_store(lean_rs(), X, X.dirty_qg, X.dirty_pr); else store_state(X, X.dirty_qg, X.dirty_pr); }
         if (c->phase == PH_TREE) {
-            const int64_t d = c->depth;
-            if (X.ring_leaf0 >= 0) flush_ring_slot(0, first_slot_of(X.ring_leaf0, d));
-            if (X.ring_leaf1 >= 0) flush_ring_slot(1, slot_last(__builtin_ctzll((unsigned long long)X.ring_leaf1), A.cap));
+            if (LEAN) {
+                lean_ring_flush(lean_rs(), X);
+            } else {
+                const int64_t d = c->depth;
+                if (X.ring_leaf0 >= 0) flush_ring_slot(0, first_slot_of(X.ring_leaf0, d));
+                if (X.ring_leaf1 >= 0) flush_ring_slot(1, slot_last(__builtin_ctzll((unsigned long long)X.ring_leaf1), A.cap));
+            }
         }
     }
     __device__ __forceinline__ void flush_ring_slot(int sl, int64_t slot) {
@@ -1315,6 +1319,23 @@ struct Machine {
         return *(const NPHIP_LDS double2*)((const NPHIP_LDS char*)sig_lds + ((uint32_t)k * (uint32_t)(W * NPHIP_CHUNK * 8) + rs.wave_off + rs.voff));
     }
 
+    // One (p, rho) summary on chip where it fits beside sigma^2 (ld <= 6144: 3 x 48 KB): the leaf = 2 mod 4 of a level-1 merge —
+    // A.last, which nothing else ever reads — goes to LDS instead of HBM and is read back from there two leaves later: one slot
+    // write and one slot read less per four leaves (16 % of the traffic of these HBM-bound kernels).  Every wave touches only
+    // its own chunks, so no barrier is involved.  The slot is written back at a launch boundary (flush).
+    static constexpr bool LRING = LEAN && W == 4 && NV <= 12;
+    __device__ __forceinline__ NPHIP_LDS double2* lring(const LeanRs& rs, int vec, int k) const {
+        return (NPHIP_LDS double2*)((NPHIP_LDS char*)sig_lds + (uint32_t)(1 + vec) * (uint32_t)(ld * 8) + (uint32_t)k * (uint32_t)(W * NPHIP_CHUNK * 8) +
+                                    rs.wave_off + rs.voff);
+    }
+    __device__ __forceinline__ void lean_ring_flush(const LeanRs& rs, RegsT& X) {
+        if (!LRING || X.ring_leaf1 < 0) return;
+        const int64_t slot = slot_last(__builtin_ctzll((unsigned long long)X.ring_leaf1), A.cap);
+#pragma unroll
+        for (int k = 0; k < NVX; ++k) { bst2(rs.p, rs.voff, soff(rs, slot, 0, k), *lring(rs, 0, k)); bst2(rs.p, rs.voff, soff(rs, slot, 1, k), *lring(rs, 1, k)); }
+        X.ring_leaf1 = -1;
+    }
+
     // gradient of the resident position (after a reload: only q is kept in HBM) — two sweeps, edges through LDS
     __device__ __forceinline__ void lean_grad(const LeanRs& rs, RegsT& X) {
 #pragma unroll
@@ -1380,17 +1401,21 @@ struct Machine {
         return (v[0] < 0.0) || (v[1] < 0.0);
     }
     // (A.first, resident) || (A.last, resident)
+    // (RING: A.last comes from the LDS slot)
+    template <bool RING>
     __device__ __forceinline__ bool lean_pass2(const LeanRs& rs, const RegsT& X, int64_t sAf, int64_t sAl) {
         double2 acc[4];
 #pragma unroll
         for (int n = 0; n < 4; ++n) { acc[n].x = 0.0; acc[n].y = 0.0; }
         SlotChunk an[PF], bn[PF];
 #pragma unroll
-        for (int u = 0; u < PF; ++u) if (u < NVX) { an[u] = ldslot(rs, sAf, u); bn[u] = ldslot(rs, sAl, u); }
+        for (int u = 0; u < PF; ++u) if (u < NVX) { an[u] = ldslot(rs, sAf, u); if (!RING) bn[u] = ldslot(rs, sAl, u); }
 #pragma unroll
         for (int k = 0; k < NVX; ++k) {
-            const SlotChunk a = an[k % PF], b = bn[k % PF];
-            if (k + PF < NVX) { an[k % PF] = ldslot(rs, sAf, k + PF); bn[k % PF] = ldslot(rs, sAl, k + PF); }
+            const SlotChunk a = an[k % PF];
+            SlotChunk b;
+            if (RING) { b.p = *lring(rs, 0, k); b.r = *lring(rs, 1, k); } else { b = bn[k % PF]; }
+            if (k + PF < NVX) { an[k % PF] = ldslot(rs, sAf, k + PF); if (!RING) bn[k % PF] = ldslot(rs, sAl, k + PF); }
             const double2 s2 = sigl(rs, k);
             span_acc(a.p.x, a.r.x, X.p[k].x, X.r[k].x, s2.x, acc[0].x, acc[1].x);
             span_acc(a.p.y, a.r.y, X.p[k].y, X.r[k].y, s2.y, acc[0].y, acc[1].y);
@@ -1592,6 +1617,7 @@ struct Machine {
 #ifdef NPHIP_PROFILE
         const int64_t tp0 = (int64_t)__builtin_readcyclecounter();
 #endif
+        if (LRING && j == 1) X.ring_leaf1 = -1;
         // ---- source state (already resident unless the cursor moved or a rare path ran)
         if (X.reg_q != srcq) {
 #pragma unroll
@@ -1685,7 +1711,10 @@ struct Machine {
                 } else {
                     const int64_t a = j - (2ll << k) + 1, al = j - (1ll << k);
                     const int64_t sAf = first_slot_of(a, d), sAl = slot_last(__builtin_ctzll((unsigned long long)al), A.cap);
-                    if (k == 1) turn = (c->pre_turn != 0) | lean_pass2(rs, X, sAf, sAl);
+                    if (k == 1) {
+                        if (LRING && X.ring_leaf1 == al) turn = (c->pre_turn != 0) | lean_pass2<true>(rs, X, sAf, sAl);
+                        else turn = (c->pre_turn != 0) | lean_pass2<false>(rs, X, sAf, sAl);
+                    }
                     else turn = lean_pass3(rs, X, sAf, sAl, first_slot_of(al + 1, d));
                 }
                 if (turn) { X.dirty_qg = X.dirty_pr = false; return 2; }
@@ -1720,7 +1749,14 @@ struct Machine {
 #endif
             // ---- stores, last: q when the leaf is referenced as a candidate; (p, rho) unless the leaf is only ever the
             // source of the next leapfrog (leaf % 4 == 3)
-            lean_store(rs, X, T_q == newq, (j & 3) != 3);
+            if (LRING && (j & 3) == 2) {
+#pragma unroll
+                for (int k_ = 0; k_ < NVX; ++k_) { *lring(rs, 0, k_) = X.p[k_]; *lring(rs, 1, k_) = X.r[k_]; }
+                X.ring_leaf1 = j;
+                lean_store(rs, X, T_q == newq, false);
+            } else {
+                lean_store(rs, X, T_q == newq, (j & 3) != 3);
+            }
             issue_leaf();
 #ifdef NPHIP_PROFILE
             c->prof[7] += (int64_t)__builtin_readcyclecounter() - tp4;
@@ -2324,8 +2360,8 @@ struct Machine {
                     break;
                 }
             }
+            if (!rare) flush(X);  // launch boundary: registers (and the LDS slot) that hold the only copy of tree state go back to HBM
             sig_lds = nullptr;
-            if (!rare) flush(X);  // launch boundary: registers that hold the only copy of the cursor state go back to HBM
             if (LEAN && lean_end != 0) rare_end_draw(A, c, red, chain, lean_end == 1, lean_end == 3, false, false, true);
             if (out_of_budget) break;
         }
@@ -2459,7 +2495,7 @@ static hipError_t launch_w(const Args& a, const Args* d_args, int W, hipStream_t
     if (FUSED && a.lean && a.reg_nv > 0) {
         // lean register-resident kernels (4096 < D <= 10240): one workgroup of 8 waves = one chain, sigma^2 in dynamic LDS
         const dim3 g(n), b(64 * W);
-        const size_t dyn = (size_t)a.ld * 8;
+        const size_t dyn = (size_t)a.ld * 8 * ((W == 4 && a.reg_nv <= 12) ? 3 : 1);   // sigma^2 (+ one (p, rho) summary: Machine::LRING)
 #define NPHIP_LAUNCH_LEAN(WW, NN) hipLaunchKernelGGL((k_advance<true, WW, NN, true>), g, b, dyn, st, d_args, me, hr, sl)
 #ifndef NPHIP_DEV_LEAN
         if (W == 4) {   // 4 waves per chain, state spread over VGPRs + AGPRs (one wave per SIMD): 9..20 chunks per wave
