@@ -1319,20 +1319,27 @@ struct Machine {
         return *(const NPHIP_LDS double2*)((const NPHIP_LDS char*)sig_lds + ((uint32_t)k * (uint32_t)(W * NPHIP_CHUNK * 8) + rs.wave_off + rs.voff));
     }
 
-    // One (p, rho) summary on chip where it fits beside sigma^2 (ld <= 6144: 3 x 48 KB): the leaf = 2 mod 4 of a level-1 merge —
-    // A.last, which nothing else ever reads — goes to LDS instead of HBM and is read back from there two leaves later: one slot
-    // write and one slot read less per four leaves (16 % of the traffic of these HBM-bound kernels).  Every wave touches only
-    // its own chunks, so no barrier is involved.  The slot is written back at a launch boundary (flush).
-    static constexpr bool LRING = LEAN && W == 4 && NV <= 12;
+    // One (p, rho) summary on chip, as far as it fits beside sigma^2: the leaf = 2 mod 4 of a level-1 merge — A.last, which
+    // nothing else ever reads — goes to LDS instead of HBM and is read back from there two leaves later.  Up to ld = 6144 the
+    // whole summary fits (3 x 48 KB); above, the first KP chunks of p and KR chunks of rho of every wave do (D = 10 000: 18 of
+    // the 20 chunks of p) and the rest goes through its P-slot as before.  Every wave touches only its own chunks: no barrier.
+    // The LDS part is written back at a launch boundary (flush).
+    static constexpr int LR_FREE = (LEAN && W == 4) ? (163840 - 8192 - NVX * W * (NPHIP_CHUNK * 8)) / (W * (NPHIP_CHUNK * 8)) : 0;   // chunks per wave
+    static constexpr int KP = LR_FREE < 0 ? 0 : (LR_FREE < NVX ? LR_FREE : NVX);
+    static constexpr int KR = (LR_FREE - KP) < 0 ? 0 : ((LR_FREE - KP) < NVX ? (LR_FREE - KP) : NVX);
+    static constexpr bool LRING = KP > 0;
     __device__ __forceinline__ NPHIP_LDS double2* lring(const LeanRs& rs, int vec, int k) const {
-        return (NPHIP_LDS double2*)((NPHIP_LDS char*)sig_lds + (uint32_t)(1 + vec) * (uint32_t)(ld * 8) + (uint32_t)k * (uint32_t)(W * NPHIP_CHUNK * 8) +
+        return (NPHIP_LDS double2*)((NPHIP_LDS char*)sig_lds + (uint32_t)(ld * 8) + (uint32_t)((vec == 0 ? 0 : KP) + k) * (uint32_t)(W * NPHIP_CHUNK * 8) +
                                     rs.wave_off + rs.voff);
     }
     __device__ __forceinline__ void lean_ring_flush(const LeanRs& rs, RegsT& X) {
         if (!LRING || X.ring_leaf1 < 0) return;
         const int64_t slot = slot_last(__builtin_ctzll((unsigned long long)X.ring_leaf1), A.cap);
 #pragma unroll
-        for (int k = 0; k < NVX; ++k) { bst2(rs.p, rs.voff, soff(rs, slot, 0, k), *lring(rs, 0, k)); bst2(rs.p, rs.voff, soff(rs, slot, 1, k), *lring(rs, 1, k)); }
+        for (int k = 0; k < NVX; ++k) {
+            if (k < KP) bst2(rs.p, rs.voff, soff(rs, slot, 0, k), *lring(rs, 0, k));
+            if (k < KR) bst2(rs.p, rs.voff, soff(rs, slot, 1, k), *lring(rs, 1, k));
+        }
         X.ring_leaf1 = -1;
     }
 
@@ -1407,15 +1414,25 @@ struct Machine {
         double2 acc[4];
 #pragma unroll
         for (int n = 0; n < 4; ++n) { acc[n].x = 0.0; acc[n].y = 0.0; }
+        constexpr int kp = RING ? KP : 0, kr = RING ? KR : 0;   // chunks of A.last's p / rho that live in LDS
         SlotChunk an[PF], bn[PF];
 #pragma unroll
-        for (int u = 0; u < PF; ++u) if (u < NVX) { an[u] = ldslot(rs, sAf, u); if (!RING) bn[u] = ldslot(rs, sAl, u); }
+        for (int u = 0; u < PF; ++u) if (u < NVX) {
+            an[u] = ldslot(rs, sAf, u);
+            if (u >= kp) bn[u].p = bld2(rs.p, rs.voff, soff(rs, sAl, 0, u));
+            if (u >= kr) bn[u].r = bld2(rs.p, rs.voff, soff(rs, sAl, 1, u));
+        }
 #pragma unroll
         for (int k = 0; k < NVX; ++k) {
             const SlotChunk a = an[k % PF];
             SlotChunk b;
-            if (RING) { b.p = *lring(rs, 0, k); b.r = *lring(rs, 1, k); } else { b = bn[k % PF]; }
-            if (k + PF < NVX) { an[k % PF] = ldslot(rs, sAf, k + PF); if (!RING) bn[k % PF] = ldslot(rs, sAl, k + PF); }
+            if (k < kp) b.p = *lring(rs, 0, k); else b.p = bn[k % PF].p;
+            if (k < kr) b.r = *lring(rs, 1, k); else b.r = bn[k % PF].r;
+            if (k + PF < NVX) {
+                an[k % PF] = ldslot(rs, sAf, k + PF);
+                if (k + PF >= kp) bn[k % PF].p = bld2(rs.p, rs.voff, soff(rs, sAl, 0, k + PF));
+                if (k + PF >= kr) bn[k % PF].r = bld2(rs.p, rs.voff, soff(rs, sAl, 1, k + PF));
+            }
             const double2 s2 = sigl(rs, k);
             span_acc(a.p.x, a.r.x, X.p[k].x, X.r[k].x, s2.x, acc[0].x, acc[1].x);
             span_acc(a.p.y, a.r.y, X.p[k].y, X.r[k].y, s2.y, acc[0].y, acc[1].y);
@@ -1751,7 +1768,10 @@ struct Machine {
             // source of the next leapfrog (leaf % 4 == 3)
             if (LRING && (j & 3) == 2) {
 #pragma unroll
-                for (int k_ = 0; k_ < NVX; ++k_) { *lring(rs, 0, k_) = X.p[k_]; *lring(rs, 1, k_) = X.r[k_]; }
+                for (int k_ = 0; k_ < NVX; ++k_) {
+                    if (k_ < KP) *lring(rs, 0, k_) = X.p[k_]; else bst2(rs.p, rs.voff, soff(rs, X.reg_p, 0, k_), X.p[k_]);
+                    if (k_ < KR) *lring(rs, 1, k_) = X.r[k_]; else bst2(rs.p, rs.voff, soff(rs, X.reg_p, 1, k_), X.r[k_]);
+                }
                 X.ring_leaf1 = j;
                 lean_store(rs, X, T_q == newq, false);
             } else {
@@ -2495,7 +2515,12 @@ static hipError_t launch_w(const Args& a, const Args* d_args, int W, hipStream_t
     if (FUSED && a.lean && a.reg_nv > 0) {
         // lean register-resident kernels (4096 < D <= 10240): one workgroup of 8 waves = one chain, sigma^2 in dynamic LDS
         const dim3 g(n), b(64 * W);
-        const size_t dyn = (size_t)a.ld * 8 * ((W == 4 && a.reg_nv <= 12) ? 3 : 1);   // sigma^2 (+ one (p, rho) summary: Machine::LRING)
+        // sigma^2, and (4 waves per chain) as much of one (p, rho) summary as fits beside it: Machine::LR_FREE
+        size_t dyn = (size_t)a.ld * 8;
+        if (W == 4) {
+            const long chunk_bytes = 4 * 1024, free_chunks = (163840 - 8192 - (long)a.reg_nv * chunk_bytes) / chunk_bytes;
+            dyn += (size_t)std::max(0l, std::min(free_chunks, 2l * a.reg_nv)) * chunk_bytes;
+        }
 #define NPHIP_LAUNCH_LEAN(WW, NN) hipLaunchKernelGGL((k_advance<true, WW, NN, true>), g, b, dyn, st, d_args, me, hr, sl)
 #ifndef NPHIP_DEV_LEAN
         if (W == 4) {   // 4 waves per chain, state spread over VGPRs + AGPRs (one wave per SIMD): 9..20 chunks per wave
