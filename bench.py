@@ -56,7 +56,7 @@ def parse():
     p.add_argument("--warmup", type=int, default=30)
     p.add_argument("--dim", type=int, default=1000)
     p.add_argument("--chains", type=int, default=1024, help="chains PER GPU")
-    p.add_argument("--evals-per-launch", type=int, default=0, help="leapfrogs per chain per launch; 0 = 256 (D <= 2048) or 32")
+    p.add_argument("--evals-per-launch", type=int, default=0, help="leapfrogs per chain per launch; 0 = 512, the engine's default")
     p.add_argument("--waves", type=int, default=0)
     p.add_argument("--seed", type=int, default=20260926)
     p.add_argument("--phase", choices=("sampling", "tuning"), default="sampling",
@@ -208,13 +208,17 @@ def main():
 
     hip.lib()
     model = ar1_gaussian(args.dim)
-    E = args.evals_per_launch or (256 if args.dim <= 2048 else 32)
+    # 512 leapfrogs per chain per launch is what the engine runs by default (host.hip: launch_kernel).  A launch boundary costs
+    # every chain a flush and a reload of its register state and the device the tail of the slowest chain — measured at
+    # D = 10 000: 10.6 (32 per launch), 12.2 (128), 13.2 M leapfrogs/s (512); at D = 1000: 201 (256) and 207 (512).
+    E = args.evals_per_launch or 512
     # default number of timed launches: about 1.2 s of kernel time (178 M leapfrogs/s at D = 1000 scales like 1 / D)
     K = args.steps or max(20, int(1.2 * 1.7e11 / args.dim / (args.chains * E)))
     num_tune = 400
     # Draws to allocate: the timed region must end before any chain runs out of draws.  After warm-up a draw of these targets
     # takes ~200 (D = 1000) to ~500 (D = 10 000) leapfrogs; 1 / 64 of the leapfrogs is a 3x margin, checked below.
-    n_draws = max(64, (args.warmup + K + 2) * E // 64) if args.phase == "sampling" else (args.warmup + K + 2) * E
+    # (+ 12 launches: the warm-up below is advanced 10 launches at a time and may overshoot the end of tuning by that much)
+    n_draws = max(64, (args.warmup + K + 2 + 12) * E // 64) if args.phase == "sampling" else (args.warmup + K + 2) * E
     s = hip.PyNutsSettings.Diag(args.seed)
     s.update(num_tune=num_tune, num_draws=n_draws, num_chains=args.chains * world)
     m = hip.TridiagGaussianModel(model.diag, model.offdiag)
@@ -237,7 +241,7 @@ def main():
         launches = 0
         kms = 0.0
         while True:
-            done, l, ms = smp.step(50)
+            done, l, ms = smp.step(10)
             launches += l
             kms += ms
             if done:

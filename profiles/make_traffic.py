@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = {
     "1000:1": ("r1_v4_pmc.txt", 1024 * 256, "k_advance<fused,W=1,NV=8>"),
     "2000:2": ("r1_d2000_multiwave_kernel_pmc.txt", 1024 * 128, "k_advance<fused,W=2,NV=8>"),
-    "10000:4": ("r2_d10000_lean_lds_slot_pmc.txt", 1024 * 32, "k_advance<fused,W=4,NV=20,lean>"),
+    "10000:4": ("r2_d10000_lean_lds_slot_e128_pmc.txt", 1024 * 128, "k_advance<fused,W=4,NV=20,lean>"),
 }
 out = {}
 for key, (fn, lpl, kernel) in SOURCES.items():
