@@ -1380,7 +1380,10 @@ struct Machine {
     // ---- streamed criteria.  PF chunks of look-ahead: the operands of chunk k + PF are requested before chunk k is used.  A
     // pass is a pure memory phase of the whole CU (one chain per CU: every wave is in it at once), so what bounds it is the
     // number of bytes in flight: 4 waves with the state parked in AGPRs have VGPRs for 4 chunks x 3 slots, 8 waves for one.
-    static constexpr int PF = (W <= 4) ? 4 : 1;
+    // (18+ chunks per wave: with four chunks in flight the passes spill 32-64 VGPRs, and a lone wave waits out every reload;
+    //  measured, same box, 512 leapfrogs per launch: D = 9000 16.2 -> 16.9, 9700 13.8 -> 15.0, 10 000 12.5 -> 14.1 M leapfrogs/s with two;
+    //  one or three in flight at 20 chunks: 12.4 / 12.2)
+    static constexpr int PF = (W <= 4) ? (NV >= 18 ? 2 : 4) : 1;
     struct SlotChunk { double2 p, r; };
     __device__ __forceinline__ SlotChunk ldslot(const LeanRs& rs, int64_t slot, int k) const {
         SlotChunk c_;
