@@ -56,7 +56,7 @@ def parse():
     p.add_argument("--warmup", type=int, default=30)
     p.add_argument("--dim", type=int, default=1000)
     p.add_argument("--chains", type=int, default=1024, help="chains PER GPU")
-    p.add_argument("--evals-per-launch", type=int, default=0, help="leapfrogs per chain per launch; 0 = 512, the engine's default")
+    p.add_argument("--evals-per-launch", type=int, default=0, help="leapfrogs per chain per launch; 0 = the engine's default for this dimension")
     p.add_argument("--waves", type=int, default=0)
     p.add_argument("--seed", type=int, default=20260926)
     p.add_argument("--phase", choices=("sampling", "tuning"), default="sampling",
@@ -134,8 +134,7 @@ def run_job(hip, model, args, device, chain_offset, dims_for_ess):
     s.update(num_tune=400, num_draws=1000, num_chains=args.chains * args.gpus)
     m = hip.TridiagGaussianModel(model.diag, model.offdiag)
     t0 = time.perf_counter()
-    smp = hip.PySampler(s, m, device=device, waves_per_chain=args.waves, chain_offset=chain_offset, n_local_chains=args.chains,
-                        evals_per_launch=512)
+    smp = hip.PySampler(s, m, device=device, waves_per_chain=args.waves, chain_offset=chain_offset, n_local_chains=args.chains)
     t_alloc = time.perf_counter() - t0
     smp.wait()
     secs = smp.seconds
@@ -208,10 +207,10 @@ def main():
 
     hip.lib()
     model = ar1_gaussian(args.dim)
-    # 512 leapfrogs per chain per launch is what the engine runs by default (host.hip: launch_kernel).  A launch boundary costs
-    # every chain a flush and a reload of its register state and the device the tail of the slowest chain — measured at
-    # D = 10 000: 10.6 (32 per launch), 12.2 (128), 13.2 M leapfrogs/s (512); at D = 1000: 201 (256) and 207 (512).
-    E = args.evals_per_launch or 512
+    # The launch length the engine runs by default (host.hip: default_evals_per_launch — about 10 ms of kernel: 2048 leapfrogs per
+    # chain at D = 1000, 512 at D = 10 000).  A launch boundary costs every chain a flush and a reload of its register state and the
+    # device the tail of the slowest chain.
+    E = args.evals_per_launch or hip.default_evals_per_launch(args.dim)
     # default number of timed launches: about 1.2 s of kernel time (178 M leapfrogs/s at D = 1000 scales like 1 / D)
     K = args.steps or max(20, int(1.2 * 1.7e11 / args.dim / (args.chains * E)))
     num_tune = 400

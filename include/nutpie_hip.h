@@ -148,7 +148,7 @@ typedef struct {
     uint64_t n_local_chains;   /* 0 = settings.num_chains                                          */
     void* stream;              /* hipStream_t to run on; NULL = engine-owned stream                 */
     int32_t store_draws;       /* keep [chain][draw][dim] positions in HBM (default 1)             */
-    int32_t evals_per_launch;  /* fused models: leapfrogs per chain per kernel launch (0 = default) */
+    int32_t evals_per_launch;  /* fused models: leapfrogs per chain per kernel launch (0 = nphip_default_evals_per_launch(dim)) */
     int32_t start_paused;
     int32_t manual;            /* 1: no driver thread; the caller advances with nphip_sampler_step  */
     /* Device-callback models: caller-owned staging buffers q[n][dim], grad[n][dim], logp[n] (device,
@@ -173,6 +173,8 @@ typedef struct {
 } nphip_launch_t;
 
 void nphip_launch_defaults(nphip_launch_t*);
+/* leapfrogs per chain per launch a fused model of this dimension runs by default (about 10 ms of kernel; results do not depend on it) */
+int nphip_default_evals_per_launch(uint64_t dim);
 /* sizeof(nphip_launch_t) / sizeof(nphip_chain_progress_t) as the library was built: lets a binding check its struct layouts */
 uint64_t nphip_abi_struct_size(int which /* 0: nphip_launch_t, 1: nphip_chain_progress_t */);
 

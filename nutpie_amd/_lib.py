@@ -158,6 +158,7 @@ def lib():
             L.nphip_sampler_waiting.restype = C.c_int64
             L.nphip_sampler_resume_at.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int]
             L.nphip_launch_defaults.argtypes = [C.POINTER(_Launch)]
+            L.nphip_default_evals_per_launch.argtypes = [C.c_uint64]
             L.nphip_abi_struct_size.restype = C.c_uint64
             L.nphip_abi_struct_size.argtypes = [C.c_int]
             if L.nphip_abi_struct_size(0) != C.sizeof(_Launch) or L.nphip_abi_struct_size(1) != C.sizeof(_Progress):
@@ -800,6 +801,11 @@ class PySampler:
             self.close()
         except Exception:
             pass
+
+
+def default_evals_per_launch(dim: int) -> int:
+    """Leapfrogs per chain per kernel launch a fused model of this dimension runs by default."""
+    return int(lib().nphip_default_evals_per_launch(C.c_uint64(int(dim))))
 
 
 # --------------------------------------------------------------------------- test hooks

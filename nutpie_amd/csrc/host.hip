@@ -638,6 +638,12 @@ struct nphip_sampler {
 // it, and a chain's result must not depend on how many other chains run with it or on how they are sharded.  (Measured:
 // with 64..256 chains at D = 1000, waves_per_chain = 4 is 20 % faster — available through nphip_launch_t, not chosen
 // behind the user's back; 2 waves per chain are slower than 1.)
+// Leapfrogs per chain per launch of a fused model: about 10 ms of kernel.  A launch boundary costs every chain a flush and a
+// reload of its on-chip state, and the device the tail of the chain that met the most draw ends (measured, bench.py: D = 1000
+// 201 / 208 / 210 / 213 M leapfrogs/s with 256 / 512 / 1024 / 2048 per launch; D = 10 000 10.6 / 12.2 / 13.0 with 32 / 128 / 512
+// and nothing beyond).  Results do not depend on it.
+static int default_evals_per_launch(uint64_t dim) { return dim <= 1024 ? 2048 : (dim <= 4096 ? 1024 : 512); }
+
 static int choose_waves(uint64_t dim) {
     if (dim <= 1024) return 1;
     if (dim <= 2048) return 2;
@@ -876,7 +882,7 @@ std::string nphip_sampler::chain_error_message() {
 }
 
 bool nphip_sampler::launch_kernel(bool fused_, int have) {
-    args.max_evals = fused_ ? (launch.evals_per_launch > 0 ? launch.evals_per_launch : 512) : 0;
+    args.max_evals = fused_ ? (launch.evals_per_launch > 0 ? launch.evals_per_launch : default_evals_per_launch(dim)) : 0;
     args.have_result = have;
     if (kernel_ms_acc) {
         while (tev.size() < 2 * (timed_launches + 1)) {
@@ -1442,6 +1448,7 @@ int nphip_sampler_is_finished(nphip_sampler_t* s) {
     return s->thread_done ? 1 : 0;
 }
 int nphip_sampler_waves_per_chain(const nphip_sampler_t* s) { return s->W; }
+int nphip_default_evals_per_launch(uint64_t dim) { return default_evals_per_launch(dim); }
 uint64_t nphip_sampler_num_chains(const nphip_sampler_t* s) { return s->n; }
 uint64_t nphip_sampler_dim(const nphip_sampler_t* s) { return s->dim; }
 uint64_t nphip_sampler_total_draws(const nphip_sampler_t* s) { return s->T; }
