@@ -597,12 +597,17 @@ class PySampler:
     # constructors named as the reference's (wrapper.rs:1189-1250)
     @classmethod
     def from_pyfunc(cls, settings, cores, model, progress_type=None, extra_callback=None, extra_callback_rate=None, store=None, **kw):
+        # (the reference's constructors, wrapper.rs:1189-1250; progress reporting is done one layer up — nutpie_amd.sample's
+        #  background sampler polls progress() and calls the callback — and the engine has no storage back-ends: neither is
+        #  dropped silently)
+        if store is not None:
+            raise NotImplementedError("storage back-ends (zarr / arrow) are outside the scope of the HIP engine: the trace lives in HBM")
+        if progress_type is not None or extra_callback is not None:
+            raise NotImplementedError("progress templates / callbacks are handled by nutpie_amd.sample(), not by the sampler handle")
         return cls(settings, model, **kw)
 
     from_pymc = from_pyfunc
     from_stan = from_pyfunc
-    # (progress_type / extra_callback / store of the reference's constructors, wrapper.rs:1189-1250, are handled one layer up:
-    #  nutpie_amd.sample._BackgroundSampler polls progress() and calls the callback; the engine has no storage back-ends)
 
     def _require(self):
         if self._h is None:

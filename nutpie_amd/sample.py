@@ -88,8 +88,8 @@ class _BackgroundSampler:
         if store is not None:
             raise NotImplementedError("zarr_store is outside the scope of the HIP engine (trace lives in HBM)")
         self._sampler = compiled_model._make_sampler(
-            settings, init_mean, cores, None, progress_callback, progress_rate, None, **(engine_kwargs or {})
-        )
+            settings, init_mean, cores, None, None, progress_rate, None, **(engine_kwargs or {})
+        )   # (the progress callback is driven by the poll thread below, not by the sampler handle)
         # raw unconstrained draws only cross PCIe when somebody asked for them (device-expanding models)
         self._sampler._keep_host_draws = bool(return_raw_trace or store_unconstrained or settings.store_unconstrained)
         self._stop = threading.Event()

@@ -299,3 +299,14 @@ def test_evaluation_pool_runs_every_row_exactly_once(threads, use):
         want = (np.arange(1, rows + 1, dtype=np.uint64) * np.uint64(batches * (batches + 1) // 2))
         assert np.array_equal(got, want), (rows, batches)
     assert 1 <= cores <= os.cpu_count()
+
+
+def test_sampler_constructors_do_not_drop_arguments_silently():
+    """The reference's PySampler.from_pymc / from_stan / from_pyfunc take a progress type, a callback and a storage back-end
+    (wrapper.rs:1189-1250).  Here progress is driven one layer up and there is no storage back-end: passing either raises."""
+    from nutpie_amd import _lib
+
+    with pytest.raises(NotImplementedError, match="storage"):
+        _lib.PySampler.from_pymc(None, 1, None, None, None, None, store=object())
+    with pytest.raises(NotImplementedError, match="progress"):
+        _lib.PySampler.from_stan(None, 1, None, "template", None, None, None)
