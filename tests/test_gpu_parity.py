@@ -351,6 +351,24 @@ def test_resident_host_callback_wider_rows(hip, oracle, dim):
     assert_trace_equal(got, want)
 
 
+def test_two_resident_jobs_at_once(hip, oracle, fixture_lib):
+    """Two host-callback jobs running at the same time in one process (their resident launches share the device and possibly a
+    hardware queue): both finish, each with the oracle's trace."""
+    addr = fn_addr(fixture_lib.eight_schools_logp)
+    smps = []
+    for seed in (31, 32, 33):
+        s = hip.PyNutsSettings.Diag(seed)
+        s.update(num_tune=150, num_draws=100, num_chains=64)
+        m = hip.HostCallbackModel(10, addr)
+        m.set_init("normal")
+        smps.append((seed, hip.PySampler(s, m)))
+    for seed, smp in smps:
+        smp.wait()
+        assert smp.host_mode in ("resident", "fell-back")
+        want = oracle.sample_callback(oracle_settings(oracle, chains=64, tune=150, draws=100, seed=seed, W=1, init_kind=1), 10, addr)
+        assert_trace_equal(smp.take_results(), want)
+
+
 def test_resident_launch_that_fills_the_device(hip, oracle, fixture_lib):
     """1000 dimensions x 1024 chains through the host-callback path: 8 register chunks per chain, i.e. one workgroup per CU and
     256 workgroups — the resident launch needs the whole device.  Whether its roll call succeeds or (a CU is not available) fails
