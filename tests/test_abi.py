@@ -170,3 +170,10 @@ def test_model_validation():
     cb = _lib.RAW_LOGP_FN(lambda d, x, g, lp, u: 0)
     _lib.HostCallbackModel(3, cb)
     _lib.HostCallbackModel(3, ctypes.cast(cb, ctypes.c_void_p).value, keep_alive=cb)
+
+
+def test_default_launch_length_by_dimension():
+    """About 10 ms of kernel per launch of a fused model (host.hip: default_evals_per_launch); bench.py asks for the same number."""
+    from nutpie_amd import _lib
+
+    assert [_lib.default_evals_per_launch(d) for d in (1, 1000, 1024, 1025, 4096, 4097, 10000, 100000)] == [2048, 2048, 2048, 1024, 1024, 512, 512, 512]
