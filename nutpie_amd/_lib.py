@@ -95,7 +95,7 @@ def build(force: bool = False) -> str:
     srcs += [os.path.join(_HERE, "..", "include", f) for f in ("nutpie_hip.h", "nphip_spec.h")]
     stale = not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(s) for s in srcs)
     if force or stale:
-        r = subprocess.run(["make", "-C", _CSRC] + (["-B"] if force else []), capture_output=True, text=True)
+        r = subprocess.run(["make", "-j", str(max(1, min(8, os.cpu_count() or 1))), "-C", _CSRC] + (["-B"] if force else []), capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("building libnutpie_hip.so failed:\n" + r.stdout + r.stderr)
     return _LIB_PATH

@@ -2504,119 +2504,167 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) __attribute__((amdgpu_waves_
     }
 }
 
+// ----------------------------------------------------------------------------------------
+// launch tables.  The file is compiled as six translation units in parallel (Makefile: -DNPHIP_PART=0..5), each instantiating
+// one family of kernels; without NPHIP_PART (developer builds, see the NPHIP_DEV_* macros) everything is in one.
+// ----------------------------------------------------------------------------------------
+#ifndef NPHIP_PART
+#define NPHIP_PART -1
+#endif
+#define NPHIP_HAS(p) (NPHIP_PART == -1 || NPHIP_PART == (p))
+#if defined(NPHIP_DEV_LEAN) || defined(NPHIP_DEV_W1NV)
+#define NPHIP_DEV_BUILD 1   // one kernel instantiation only: seconds instead of minutes
+#endif
+
+hipError_t launch_fam_w1(const Args& a, const Args* d_args, hipStream_t st, const LaunchSlice sl);              // part 0
+hipError_t launch_fam_lean4(const Args& a, const Args* d_args, hipStream_t st, const LaunchSlice sl);           // part 1
+hipError_t launch_fam_lean8(const Args& a, const Args* d_args, hipStream_t st, const LaunchSlice sl);           // part 2
+hipError_t launch_fam_rw(const Args& a, const Args* d_args, int W, hipStream_t st, const LaunchSlice sl);       // part 3
+hipError_t launch_fam_mem(const Args& a, const Args* d_args, bool fused, int W, hipStream_t st, const LaunchSlice sl);   // part 4
+
+// dynamic LDS of the lean kernels: sigma^2, and (4 waves per chain) as much of one (p, rho) summary as fits beside it (Machine::LR_FREE)
+static size_t lean_dyn_lds(const Args& a, int W) {
+    size_t dyn = (size_t)a.ld * 8;
+    if (W == 4) {
+        const long chunk_bytes = 4 * 1024, free_chunks = (163840 - 8192 - (long)a.reg_nv * chunk_bytes) / chunk_bytes;
+        dyn += (size_t)std::max(0l, std::min(free_chunks, 2l * a.reg_nv)) * chunk_bytes;
+    }
+    return dyn;
+}
+#define NPHIP_LAUNCH_LEAN(WW, NN) hipLaunchKernelGGL((k_advance<true, WW, NN, true>), g, b, dyn, st, d_args, a.max_evals, a.have_result, sl)
+
+#if NPHIP_HAS(1)
+// lean register-resident kernels, 4 waves per chain (4096 < D <= 10240): state spread over VGPRs + AGPRs (one wave per SIMD), 9..20
+// chunks per wave; one workgroup = one chain
+hipError_t launch_fam_lean4(const Args& a, const Args* d_args, hipStream_t st, const LaunchSlice sl) {
+    const dim3 g((unsigned)sl.chain_n), b(256);
+    const size_t dyn = lean_dyn_lds(a, 4);
+    (void)g; (void)b; (void)dyn;
+    switch (a.reg_nv) {
+#if defined(NPHIP_DEV_LEAN) && defined(NPHIP_DEV_W) && defined(NPHIP_DEV_NC)
+#if NPHIP_DEV_W == 4
+        case NPHIP_DEV_NC: NPHIP_LAUNCH_LEAN(4, NPHIP_DEV_NC); break;
+#endif
+#elif !defined(NPHIP_DEV_BUILD)
+        case 9: NPHIP_LAUNCH_LEAN(4, 9); break;
+        case 10: NPHIP_LAUNCH_LEAN(4, 10); break;
+        case 11: NPHIP_LAUNCH_LEAN(4, 11); break;
+        case 12: NPHIP_LAUNCH_LEAN(4, 12); break;
+        case 13: NPHIP_LAUNCH_LEAN(4, 13); break;
+        case 14: NPHIP_LAUNCH_LEAN(4, 14); break;
+        case 15: NPHIP_LAUNCH_LEAN(4, 15); break;
+        case 16: NPHIP_LAUNCH_LEAN(4, 16); break;
+        case 17: NPHIP_LAUNCH_LEAN(4, 17); break;
+        case 18: NPHIP_LAUNCH_LEAN(4, 18); break;
+        case 19: NPHIP_LAUNCH_LEAN(4, 19); break;
+        case 20: NPHIP_LAUNCH_LEAN(4, 20); break;
+#endif
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+#endif
+
+#if NPHIP_HAS(2)
+// lean register-resident kernels, 8 waves per chain (on request: waves_per_chain = 8), 1..10 chunks per wave
+hipError_t launch_fam_lean8(const Args& a, const Args* d_args, hipStream_t st, const LaunchSlice sl) {
+    const dim3 g((unsigned)sl.chain_n), b(512);
+    const size_t dyn = lean_dyn_lds(a, 8);
+    (void)g; (void)b; (void)dyn;
+    switch (a.reg_nv) {
+#if defined(NPHIP_DEV_LEAN) && defined(NPHIP_DEV_NC)
+#if !defined(NPHIP_DEV_W) || NPHIP_DEV_W == 8
+        case NPHIP_DEV_NC: NPHIP_LAUNCH_LEAN(8, NPHIP_DEV_NC); break;
+#endif
+#elif !defined(NPHIP_DEV_BUILD)
+        case 1: NPHIP_LAUNCH_LEAN(8, 1); break;
+        case 2: NPHIP_LAUNCH_LEAN(8, 2); break;
+        case 3: NPHIP_LAUNCH_LEAN(8, 3); break;
+        case 4: NPHIP_LAUNCH_LEAN(8, 4); break;
+        case 5: NPHIP_LAUNCH_LEAN(8, 5); break;
+        case 6: NPHIP_LAUNCH_LEAN(8, 6); break;
+        case 7: NPHIP_LAUNCH_LEAN(8, 7); break;
+        case 8: NPHIP_LAUNCH_LEAN(8, 8); break;
+        case 9: NPHIP_LAUNCH_LEAN(8, 9); break;
+        case 10: NPHIP_LAUNCH_LEAN(8, 10); break;
+#endif
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+#endif
+#undef NPHIP_LAUNCH_LEAN
+
+#if NPHIP_HAS(3)
+// register-resident, several waves per chain (1024 < D <= 4096, or fewer chains than SIMDs): one workgroup = one chain
+hipError_t launch_fam_rw(const Args& a, const Args* d_args, int W, hipStream_t st, const LaunchSlice sl) {
+#ifdef NPHIP_DEV_BUILD
+    return hipErrorInvalidValue;
+#else
+    const dim3 g((unsigned)sl.chain_n), b(64 * W);
+#define NPHIP_LAUNCH_RW(WW, NN) hipLaunchKernelGGL((k_advance<true, WW, NN>), g, b, 0, st, d_args, a.max_evals, a.have_result, sl)
+    if (W == 2) switch (a.reg_nv) {
+        case 1: NPHIP_LAUNCH_RW(2, 1); break;
+        case 2: NPHIP_LAUNCH_RW(2, 2); break;
+        case 3: NPHIP_LAUNCH_RW(2, 3); break;
+        case 4: NPHIP_LAUNCH_RW(2, 4); break;
+        case 5: NPHIP_LAUNCH_RW(2, 5); break;
+        case 6: NPHIP_LAUNCH_RW(2, 6); break;
+        case 7: NPHIP_LAUNCH_RW(2, 7); break;
+        case 8: NPHIP_LAUNCH_RW(2, 8); break;
+        default: return hipErrorInvalidValue;
+    } else switch (a.reg_nv) {
+        case 1: NPHIP_LAUNCH_RW(4, 1); break;
+        case 2: NPHIP_LAUNCH_RW(4, 2); break;
+        case 3: NPHIP_LAUNCH_RW(4, 3); break;
+        case 4: NPHIP_LAUNCH_RW(4, 4); break;
+        case 5: NPHIP_LAUNCH_RW(4, 5); break;
+        case 6: NPHIP_LAUNCH_RW(4, 6); break;
+        case 7: NPHIP_LAUNCH_RW(4, 7); break;
+        case 8: NPHIP_LAUNCH_RW(4, 8); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef NPHIP_LAUNCH_RW
+    return hipGetLastError();
+#endif
+}
+#endif
+
+#if NPHIP_HAS(0)
+// register-resident, one wave per chain (D <= 1024): four chains per workgroup, one instantiation per exact chunk count
+hipError_t launch_fam_w1(const Args& a, const Args* d_args, hipStream_t st, const LaunchSlice sl) {
+    const dim3 g(((unsigned)sl.chain_n + 3) / 4), b(256);
+    const int me = a.max_evals, hr = a.have_result;
+    (void)g; (void)b; (void)me; (void)hr;
+    switch (a.reg_nv) {
+#if defined(NPHIP_DEV_W1NV)
+        case NPHIP_DEV_W1NV: hipLaunchKernelGGL((k_advance<true, 1, NPHIP_DEV_W1NV>), g, b, 0, st, d_args, me, hr, sl); break;
+#elif !defined(NPHIP_DEV_BUILD)
+        case 1: hipLaunchKernelGGL((k_advance<true, 1, 1>), g, b, 0, st, d_args, me, hr, sl); break;
+        case 2: hipLaunchKernelGGL((k_advance<true, 1, 2>), g, b, 0, st, d_args, me, hr, sl); break;
+        case 3: hipLaunchKernelGGL((k_advance<true, 1, 3>), g, b, 0, st, d_args, me, hr, sl); break;
+        case 4: hipLaunchKernelGGL((k_advance<true, 1, 4>), g, b, 0, st, d_args, me, hr, sl); break;
+        case 5: hipLaunchKernelGGL((k_advance<true, 1, 5>), g, b, 0, st, d_args, me, hr, sl); break;
+        case 6: hipLaunchKernelGGL((k_advance<true, 1, 6>), g, b, 0, st, d_args, me, hr, sl); break;
+        case 7: hipLaunchKernelGGL((k_advance<true, 1, 7>), g, b, 0, st, d_args, me, hr, sl); break;
+        case 8: hipLaunchKernelGGL((k_advance<true, 1, 8>), g, b, 0, st, d_args, me, hr, sl); break;
+#endif
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+#endif
+
+#if NPHIP_HAS(4)
+// memory-resident kernels: fused models of any D and W (D > 10 240, store_divergences, no_register_kernel) and the two-phase
+// callback kernels
 template <bool FUSED>
-static hipError_t launch_w(const Args& a, const Args* d_args, int W, hipStream_t st, const LaunchSlice sl) {
+static hipError_t launch_mem_t(const Args& a, const Args* d_args, int W, hipStream_t st, const LaunchSlice sl) {
+#ifdef NPHIP_DEV_BUILD
+    return hipErrorInvalidValue;
+#else
     const unsigned n = (unsigned)sl.chain_n;
     const int me = a.max_evals, hr = a.have_result;
-#ifdef NPHIP_DEV_W1NV   // developer build: only k_advance<true, 1, NPHIP_DEV_W1NV>
-    if (FUSED && W == 1 && a.reg_nv == NPHIP_DEV_W1NV) {
-        hipLaunchKernelGGL((k_advance<true, 1, NPHIP_DEV_W1NV>), dim3((n + 3) / 4), dim3(256), 0, st, d_args, me, hr, sl);
-        return hipGetLastError();
-    }
-    return hipErrorInvalidValue;
-#else
-    if (FUSED && a.lean && a.reg_nv > 0) {
-        // lean register-resident kernels (4096 < D <= 10240): one workgroup of 8 waves = one chain, sigma^2 in dynamic LDS
-        const dim3 g(n), b(64 * W);
-        // sigma^2, and (4 waves per chain) as much of one (p, rho) summary as fits beside it: Machine::LR_FREE
-        size_t dyn = (size_t)a.ld * 8;
-        if (W == 4) {
-            const long chunk_bytes = 4 * 1024, free_chunks = (163840 - 8192 - (long)a.reg_nv * chunk_bytes) / chunk_bytes;
-            dyn += (size_t)std::max(0l, std::min(free_chunks, 2l * a.reg_nv)) * chunk_bytes;
-        }
-#define NPHIP_LAUNCH_LEAN(WW, NN) hipLaunchKernelGGL((k_advance<true, WW, NN, true>), g, b, dyn, st, d_args, me, hr, sl)
-#ifndef NPHIP_DEV_LEAN
-        if (W == 4) {   // 4 waves per chain, state spread over VGPRs + AGPRs (one wave per SIMD): 9..20 chunks per wave
-            switch (a.reg_nv) {
-                case 9: NPHIP_LAUNCH_LEAN(4, 9); break;
-                case 10: NPHIP_LAUNCH_LEAN(4, 10); break;
-                case 11: NPHIP_LAUNCH_LEAN(4, 11); break;
-                case 12: NPHIP_LAUNCH_LEAN(4, 12); break;
-                case 13: NPHIP_LAUNCH_LEAN(4, 13); break;
-                case 14: NPHIP_LAUNCH_LEAN(4, 14); break;
-                case 15: NPHIP_LAUNCH_LEAN(4, 15); break;
-                case 16: NPHIP_LAUNCH_LEAN(4, 16); break;
-                case 17: NPHIP_LAUNCH_LEAN(4, 17); break;
-                case 18: NPHIP_LAUNCH_LEAN(4, 18); break;
-                case 19: NPHIP_LAUNCH_LEAN(4, 19); break;
-                case 20: NPHIP_LAUNCH_LEAN(4, 20); break;
-                default: return hipErrorInvalidValue;
-            }
-            return hipGetLastError();
-        }
-        if (W != 8) return hipErrorInvalidValue;
-#endif
-        switch (a.reg_nv) {
-#ifndef NPHIP_DEV_LEAN   // (developer builds instantiate one kernel only: seconds instead of minutes)
-            case 1: NPHIP_LAUNCH_LEAN(8, 1); break;
-            case 2: NPHIP_LAUNCH_LEAN(8, 2); break;
-            case 3: NPHIP_LAUNCH_LEAN(8, 3); break;
-            case 4: NPHIP_LAUNCH_LEAN(8, 4); break;
-            case 5: NPHIP_LAUNCH_LEAN(8, 5); break;
-            case 6: NPHIP_LAUNCH_LEAN(8, 6); break;
-            case 7: NPHIP_LAUNCH_LEAN(8, 7); break;
-            case 8: NPHIP_LAUNCH_LEAN(8, 8); break;
-            case 9: NPHIP_LAUNCH_LEAN(8, 9); break;
-#endif
-#ifdef NPHIP_DEV_NC
-#ifndef NPHIP_DEV_W
-#define NPHIP_DEV_W 8
-#endif
-            case NPHIP_DEV_NC: NPHIP_LAUNCH_LEAN(NPHIP_DEV_W, NPHIP_DEV_NC); break;
-#else
-            case 10: NPHIP_LAUNCH_LEAN(8, 10); break;
-#endif
-            default: return hipErrorInvalidValue;
-        }
-#undef NPHIP_LAUNCH_LEAN
-        return hipGetLastError();
-    }
-#ifdef NPHIP_DEV_LEAN
-    return hipErrorInvalidValue;
-#else
-    if (FUSED && (W == 2 || W == 4) && a.reg_nv > 0) {
-        // register-resident, several waves per chain (1024 < D <= 4096, or fewer chains than SIMDs): one workgroup = one chain
-        const dim3 g(n), b(64 * W);
-#define NPHIP_LAUNCH_RW(WW, NN) hipLaunchKernelGGL((k_advance<true, WW, NN>), g, b, 0, st, d_args, me, hr, sl)
-        if (W == 2) switch (a.reg_nv) {
-            case 1: NPHIP_LAUNCH_RW(2, 1); break;
-            case 2: NPHIP_LAUNCH_RW(2, 2); break;
-            case 3: NPHIP_LAUNCH_RW(2, 3); break;
-            case 4: NPHIP_LAUNCH_RW(2, 4); break;
-            case 5: NPHIP_LAUNCH_RW(2, 5); break;
-            case 6: NPHIP_LAUNCH_RW(2, 6); break;
-            case 7: NPHIP_LAUNCH_RW(2, 7); break;
-            case 8: NPHIP_LAUNCH_RW(2, 8); break;
-            default: return hipErrorInvalidValue;
-        } else switch (a.reg_nv) {
-            case 1: NPHIP_LAUNCH_RW(4, 1); break;
-            case 2: NPHIP_LAUNCH_RW(4, 2); break;
-            case 3: NPHIP_LAUNCH_RW(4, 3); break;
-            case 4: NPHIP_LAUNCH_RW(4, 4); break;
-            case 5: NPHIP_LAUNCH_RW(4, 5); break;
-            case 6: NPHIP_LAUNCH_RW(4, 6); break;
-            case 7: NPHIP_LAUNCH_RW(4, 7); break;
-            case 8: NPHIP_LAUNCH_RW(4, 8); break;
-            default: return hipErrorInvalidValue;
-        }
-#undef NPHIP_LAUNCH_RW
-        return hipGetLastError();
-    }
-    if (FUSED && W == 1 && a.reg_nv > 0) {
-        const dim3 g((n + 3) / 4), b(256);
-        switch (a.reg_nv) {
-            case 1: hipLaunchKernelGGL((k_advance<true, 1, 1>), g, b, 0, st, d_args, me, hr, sl); break;
-            case 2: hipLaunchKernelGGL((k_advance<true, 1, 2>), g, b, 0, st, d_args, me, hr, sl); break;
-            case 3: hipLaunchKernelGGL((k_advance<true, 1, 3>), g, b, 0, st, d_args, me, hr, sl); break;
-            case 4: hipLaunchKernelGGL((k_advance<true, 1, 4>), g, b, 0, st, d_args, me, hr, sl); break;
-            case 5: hipLaunchKernelGGL((k_advance<true, 1, 5>), g, b, 0, st, d_args, me, hr, sl); break;
-            case 6: hipLaunchKernelGGL((k_advance<true, 1, 6>), g, b, 0, st, d_args, me, hr, sl); break;
-            case 7: hipLaunchKernelGGL((k_advance<true, 1, 7>), g, b, 0, st, d_args, me, hr, sl); break;
-            case 8: hipLaunchKernelGGL((k_advance<true, 1, 8>), g, b, 0, st, d_args, me, hr, sl); break;
-            default: return hipErrorInvalidValue;
-        }
-        return hipGetLastError();
-    }
     if (FUSED && a.stream_cache && W == 1) {
         // memory-resident kernel with the cursor's (sigma^2, grad, p, rho) cached in VGPRs between leaves.  Measured
         // with more waves per chain (D > 1024) the cache costs occupancy or spills and does not pay; W == 1 only.
@@ -2633,9 +2681,13 @@ static hipError_t launch_w(const Args& a, const Args* d_args, int W, hipStream_t
     }
     return hipGetLastError();
 #endif
-#endif
 }
+hipError_t launch_fam_mem(const Args& a, const Args* d_args, bool fused, int W, hipStream_t st, const LaunchSlice sl) {
+    return fused ? launch_mem_t<true>(a, d_args, W, st, sl) : launch_mem_t<false>(a, d_args, W, st, sl);
+}
+#endif
 
+#if NPHIP_HAS(0)
 // Resume chains stopped in PH_WAIT_HOST at new positions (host-driven re-parametrisation): the position goes to Q-pool buffer 0
 // (and the callback staging row), the chain re-enters the initial-point sequence — evaluate, mass matrix from the gradient,
 // step-size search — and continues with its next draw.  One block per resumed chain.
@@ -2669,13 +2721,19 @@ hipError_t launch_advance(const Args& a, const Args* d_args, bool fused, int W, 
     if (slice) sl = *slice;
     else { sl.chain_lo = 0; sl.chain_n = (int)a.n_chains; sl.grp = -1; sl.seq = 0u; sl.materialise = 0; }
     sl.n_grp = 0;
-    return fused ? launch_w<true>(a, d_args, W, st, sl) : launch_w<false>(a, d_args, W, st, sl);
+    if (fused && a.lean && a.reg_nv > 0) return W == 4 ? launch_fam_lean4(a, d_args, st, sl) : (W == 8 ? launch_fam_lean8(a, d_args, st, sl) : hipErrorInvalidValue);
+    if (fused && (W == 2 || W == 4) && a.reg_nv > 0) return launch_fam_rw(a, d_args, W, st, sl);
+    if (fused && W == 1 && a.reg_nv > 0) return launch_fam_w1(a, d_args, st, sl);
+    return launch_fam_mem(a, d_args, fused, W, st, sl);
 }
+#endif   // part 0
+
+#if NPHIP_HAS(5)
 
 // Resident launch of a host-callback group (k_advance<..., REMOTE>): one wave per chain, `nv` chunks of 128 elements in
 // registers (dim <= 128 nv <= 1024).  The slice names the group and the sequence number of the launch's first evaluation.
 hipError_t launch_remote(const Args* d_args, int nv, hipStream_t st, const LaunchSlice& sl) {
-#if defined(NPHIP_DEV_LEAN) || defined(NPHIP_DEV_W1NV)
+#ifdef NPHIP_DEV_BUILD
     return hipErrorInvalidValue;
 #else
     const dim3 g(((unsigned)sl.chain_n + 3) / 4), b(256);
@@ -2696,6 +2754,9 @@ hipError_t launch_remote(const Args* d_args, int nv, hipStream_t st, const Launc
 #endif
 }
 
+#endif   // part 5
+
+#if NPHIP_HAS(0)
 // ----------------------------------------------------------------------------------------
 // test hooks: device implementations of the nphip_spec.h contract
 // ----------------------------------------------------------------------------------------
@@ -2760,5 +2821,6 @@ hipError_t launch_test_dot(int W, uint64_t n, const double* x, const double* y, 
     }
     return hipGetLastError();
 }
+#endif   // part 0
 
 }  // namespace nphip
