@@ -164,7 +164,7 @@ typedef struct {
     int32_t host_groups;        /* host-callback models with zero-copy staging: 0 = default (two groups of chains in flight: the
                                  * kernel of one runs while the host evaluates the rows of the other), 1 = no pipelining,
                                  * 2..8 = that many groups */
-    int32_t host_persist;       /* the same models, dim <= 1024, <= 1024 chains: evaluations one kernel launch serves.  0 = default
+    int32_t host_persist;       /* the same models, dim <= 4096, <= 1024 waves: evaluations one kernel launch serves.  0 = default
                                  * (256: the group's kernel stays on the device with the chain state in registers, publishes its
                                  * positions, waits for the host's word in pinned memory and goes on), N > 1 = that many,
                                  * 1 = one launch per evaluation; -N (tests) = leave the resident mode after N evaluations, the

@@ -86,7 +86,7 @@ struct Ctl {
     int64_t pre_turn;
     // resident host-callback launches (k_advance<..., REMOTE>): the evaluation this chain publishes next, whether the host
     // has asked the launch to end at the next boundary, and the group it reports to (set at kernel start; transient)
-    int64_t hs_seq, hs_last, hs_grp, hs_n, hs_wgn;
+    int64_t hs_seq, hs_last, hs_grp, hs_n, hs_wgn, hs_box;
     // cycle counters per section (only advanced when built with -DNPHIP_PROFILE): leapfrog, tree, rare, count
     int64_t prof[16];
     // sub-tree stack

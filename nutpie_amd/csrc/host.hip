@@ -28,7 +28,7 @@
 namespace nphip {
 hipError_t launch_advance(const Args& a, const Args* d_args, bool fused, int W, hipStream_t st, const LaunchSlice* slice = nullptr);
 hipError_t launch_resume(const Args* d_args, int n, const int64_t* d_chains, const double* d_pos, bool fused, hipStream_t st);
-hipError_t launch_remote(const Args* d_args, int nv, hipStream_t st, const LaunchSlice& sl);
+hipError_t launch_remote(const Args* d_args, int W, int nv, hipStream_t st, const LaunchSlice& sl);
 hipError_t launch_test_detmath(int fn, uint64_t n, const double* x, double* y, hipStream_t st);
 hipError_t launch_test_dot(int W, uint64_t n, const double* x, const double* y, double* out, hipStream_t st);
 }  // namespace nphip
@@ -720,6 +720,12 @@ bool nphip_sampler::setup() {
         // (experimental geometry: 4 waves per chain with the state spread over VGPRs + AGPRs, one wave per SIMD)
         if (W == 4 && per_wave > 8 && per_wave <= 20) { lean_nc = (int)per_wave; args.ld = per_wave * W * 128; }
     }
+    // host-callback models with several waves per chain (1024 < D <= 4096): the same padding, so that resident launches can
+    // run them on the register-resident leaf (8 chunks per wave at most)
+    if (model.kind == 1 && (W == 2 || W == 4)) {
+        const int64_t per_wave = ((int64_t)((dim + 127) / 128) + W - 1) / W;
+        if (per_wave >= 1 && per_wave <= 8) args.ld = per_wave * W * 128;
+    }
     args.cap = (int32_t)set.maxdepth;
     args.npslots = num_pslots(args.cap);
     args.nqpool = num_qpool(args.cap);
@@ -803,10 +809,11 @@ bool nphip_sampler::setup() {
                 if (!palloc(&go, 8 * kMaxGroups) || !dalloc(&args.grp_go_dev, 16 * kMaxGroups)) return false;
                 h_grp_go = go;
                 args.grp_go = go;
-                remote_nv = (int)(args.ld / 128);
+                remote_nv = (int)(args.ld / 128 / W);
                 // (above 4 MB of positions per step the job is bound by PCIe traffic either way, and launches per evaluation were 15 %
                 //  faster at 1024 chains x 1000 dimensions: resident only when asked for)
-                remote = W == 1 && remote_nv <= 8 && n <= 1024 && launch.host_persist != 1 && !launch.no_register_kernel &&
+                remote = (W == 1 || W == 2 || W == 4) && remote_nv <= 8 && (int64_t)remote_nv * W * 128 == args.ld && n * (uint64_t)W <= 1024 &&
+                         launch.host_persist != 1 && !launch.no_register_kernel &&
                          !set.store_divergences && set.pause_draws.empty() && (n * dim * 8 <= (4u << 20) || launch.host_persist > 1);
                 persist_evals = launch.host_persist > 1 ? launch.host_persist : 256;
                 if (launch.host_persist < 0) { fall_back_after = -(int64_t)launch.host_persist; persist_evals = 7; }
@@ -832,9 +839,11 @@ bool nphip_sampler::setup() {
                     // (a step of a resident group is ~20 us of device latency — PCIe round trips and one L2 write-back — and ~3 us of
                     //  host work per 64 rows: eight groups keep the driver thread busy while seven of them are in flight)
                     if (launch.host_groups == 0) n_groups = (int)std::max<uint64_t>(1, std::min<uint64_t>(8, n / 8));
-                    // a workgroup holds four chains, and they rendezvous as one (kernels.hip: remote_sync): group bounds on multiples of 4
-                    n_groups = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)n_groups, (n + 3) / 4));
-                    for (int g = 1; g < n_groups; ++g) grp_lo[g] = (((n + 3) / 4) * (uint64_t)g / (uint64_t)n_groups) * 4;
+                    // one wave per chain: a workgroup holds four chains, and they rendezvous as one (kernels.hip: remote_sync) — group
+                    // bounds on multiples of 4
+                    const uint64_t per_wg = (W == 1) ? 4 : 1, wgs = (n + per_wg - 1) / per_wg;
+                    n_groups = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)n_groups, wgs));
+                    for (int g = 1; g < n_groups; ++g) grp_lo[g] = (wgs * (uint64_t)g / (uint64_t)n_groups) * per_wg;
                     grp_lo[n_groups] = n;
                 }
                 for (int g = 0; g < n_groups; ++g) HIP_TRY(hipStreamCreateWithFlags(&grp_stream[g], hipStreamNonBlocking));
@@ -1109,7 +1118,7 @@ bool nphip_sampler::launch_remote_all() {
     }
     for (int g = 0; g <= kMaxGroups; ++g) sl.grp_lo[g] = (int)grp_lo[std::min(g, n_groups)];
     for (int g = 0; g < kMaxGroups; ++g) sl.grp_seq[g] = grp_seq[g];   // a group's first evaluation carries the number the host waits for
-    if (!hip_ok(launch_remote(d_args, remote_nv, grp_stream[0], sl), "launch k_advance (resident)")) return false;
+    if (!hip_ok(launch_remote(d_args, W, remote_nv, grp_stream[0], sl), "launch k_advance (resident)")) return false;
     for (int g = 0; g < n_groups; ++g) { grp_running[g] = true; grp_evals[g] = 0; }
     remote_fresh = true;
     return true;

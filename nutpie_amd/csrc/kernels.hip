@@ -460,7 +460,8 @@ struct Machine {
     __device__ __forceinline__ void remote_sync() {
         const int grp = (int)c->hs_grp;
         const unsigned seq = (unsigned)c->hs_seq;
-        NPHIP_LDS unsigned long long* box = (NPHIP_LDS unsigned long long*)red;   // (W == 1: the reductions never touch LDS)
+        // (the word wave 0 hands to the other waves of the workgroup lives in wave 0's control block)
+        NPHIP_LDS unsigned long long* box = (NPHIP_LDS unsigned long long*)&(c - (int)(threadIdx.x >> 6))->hs_box;
         wait_vm0();
         __syncthreads();
         if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0) {
@@ -2430,7 +2431,7 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) __attribute__((amdgpu_waves_
         unsigned* cnt = (unsigned*)(A.grp_go_dev + 2);
         const unsigned long long mine = (unsigned long long)sl.seq << 8;
         unsigned state = 0;
-        if (lane == 0) {
+        if (lane == 0 && (W == 1 || wib == 0)) {   // (one arrival per chain)
             unsigned long long v = __hip_atomic_load(verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if ((v >> 8) == (unsigned long long)sl.seq) {
                 state = (unsigned)(v & 0xff);
@@ -2457,6 +2458,13 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) __attribute__((amdgpu_waves_
             }
         }
         state = (unsigned)__builtin_amdgcn_readfirstlane((int)state);
+        if (W > 1) {   // the chain's other waves take wave 0's verdict
+            NPHIP_LDS unsigned* sh = (NPHIP_LDS unsigned*)s_red;
+            if (threadIdx.x == 0) sh[0] = state;
+            __syncthreads();
+            state = sh[0];
+            __syncthreads();
+        }
         if (state != (unsigned)kRollGo) return;
     }
     if (LEAN && threadIdx.x == 0) { s_edge[0] = 0.0; s_edge[2 * W * NV + 1] = 0.0; }   // (the first barrier is in the sigma^2 staging)
@@ -2472,7 +2480,7 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) __attribute__((amdgpu_waves_
         for (int o = 1; o < sl.n_grp; ++o) g += ((int)(chain - sl.chain_lo) >= sl.grp_lo[o]) ? 1 : 0;
         c->hs_seq = (int64_t)sl.grp_seq[g]; c->hs_last = 0; c->hs_grp = g; c->hs_n = sl.grp_lo[g + 1] - sl.grp_lo[g];
         const int64_t left = (int64_t)sl.chain_n - (int64_t)blockIdx.x * 4;
-        c->hs_wgn = left < 4 ? left : 4;   // chains of this workgroup (group bounds are multiples of 4: one workgroup, one group)
+        c->hs_wgn = (W > 1) ? 1 : (left < 4 ? left : 4);   // chains of this workgroup (W == 1: four; group bounds are multiples of 4)
     }
     Machine<FUSED, W, NV, LEAN, REMOTE> m(A, c, (LdsDouble)s_red, chain, (LdsDouble)s_par, (LdsDouble)s_ring + (LEAN ? 0 : (size_t)wib * 4 * 128 * (NV > 0 ? NV : 1)),
                             (LdsDouble)s_edge);
@@ -2505,7 +2513,7 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) __attribute__((amdgpu_waves_
 }
 
 // ----------------------------------------------------------------------------------------
-// launch tables.  The file is compiled as six translation units in parallel (Makefile: -DNPHIP_PART=0..5), each instantiating
+// launch tables.  The file is compiled as seven translation units in parallel (Makefile: -DNPHIP_PART=0..6), each instantiating
 // one family of kernels; without NPHIP_PART (developer builds, see the NPHIP_DEV_* macros) everything is in one.
 // ----------------------------------------------------------------------------------------
 #ifndef NPHIP_PART
@@ -2730,31 +2738,72 @@ hipError_t launch_advance(const Args& a, const Args* d_args, bool fused, int W, 
 
 #if NPHIP_HAS(5)
 
-// Resident launch of a host-callback group (k_advance<..., REMOTE>): one wave per chain, `nv` chunks of 128 elements in
-// registers (dim <= 128 nv <= 1024).  The slice names the group and the sequence number of the launch's first evaluation.
-hipError_t launch_remote(const Args* d_args, int nv, hipStream_t st, const LaunchSlice& sl) {
+// Resident launch of a host-callback job (k_advance<..., REMOTE>): `W` waves per chain with `nv` chunks of 128 elements each in
+// registers (dim <= 128 W nv; W = 1: four chains per workgroup, W = 2 / 4: one).  The slice names the groups and their
+// sequence numbers.
+hipError_t launch_remote_w1(const Args* d_args, int nv, hipStream_t st, const LaunchSlice& sl);     // part 5
+hipError_t launch_remote_wn(const Args* d_args, int W, int nv, hipStream_t st, const LaunchSlice& sl);   // part 6
+#define NPHIP_LAUNCH_REMOTE(WW, NN) hipLaunchKernelGGL((k_advance<false, WW, NN, false, true>), g, b, 0, st, d_args, 0, 0, sl)
+hipError_t launch_remote_w1(const Args* d_args, int nv, hipStream_t st, const LaunchSlice& sl) {
 #ifdef NPHIP_DEV_BUILD
     return hipErrorInvalidValue;
 #else
     const dim3 g(((unsigned)sl.chain_n + 3) / 4), b(256);
-#define NPHIP_LAUNCH_REMOTE(NN) hipLaunchKernelGGL((k_advance<false, 1, NN, false, true>), g, b, 0, st, d_args, 0, 0, sl)
     switch (nv) {
-        case 1: NPHIP_LAUNCH_REMOTE(1); break;
-        case 2: NPHIP_LAUNCH_REMOTE(2); break;
-        case 3: NPHIP_LAUNCH_REMOTE(3); break;
-        case 4: NPHIP_LAUNCH_REMOTE(4); break;
-        case 5: NPHIP_LAUNCH_REMOTE(5); break;
-        case 6: NPHIP_LAUNCH_REMOTE(6); break;
-        case 7: NPHIP_LAUNCH_REMOTE(7); break;
-        case 8: NPHIP_LAUNCH_REMOTE(8); break;
+        case 1: NPHIP_LAUNCH_REMOTE(1, 1); break;
+        case 2: NPHIP_LAUNCH_REMOTE(1, 2); break;
+        case 3: NPHIP_LAUNCH_REMOTE(1, 3); break;
+        case 4: NPHIP_LAUNCH_REMOTE(1, 4); break;
+        case 5: NPHIP_LAUNCH_REMOTE(1, 5); break;
+        case 6: NPHIP_LAUNCH_REMOTE(1, 6); break;
+        case 7: NPHIP_LAUNCH_REMOTE(1, 7); break;
+        case 8: NPHIP_LAUNCH_REMOTE(1, 8); break;
         default: return hipErrorInvalidValue;
     }
-#undef NPHIP_LAUNCH_REMOTE
     return hipGetLastError();
 #endif
 }
+hipError_t launch_remote(const Args* d_args, int W, int nv, hipStream_t st, const LaunchSlice& sl) {
+    return W == 1 ? launch_remote_w1(d_args, nv, st, sl) : launch_remote_wn(d_args, W, nv, st, sl);
+}
+#undef NPHIP_LAUNCH_REMOTE
 
 #endif   // part 5
+
+#if NPHIP_HAS(6)
+#define NPHIP_LAUNCH_REMOTE(WW, NN) hipLaunchKernelGGL((k_advance<false, WW, NN, false, true>), g, b, 0, st, d_args, 0, 0, sl)
+hipError_t launch_remote_wn(const Args* d_args, int W, int nv, hipStream_t st, const LaunchSlice& sl) {
+#ifdef NPHIP_DEV_BUILD
+    return hipErrorInvalidValue;
+#else
+    const dim3 g((unsigned)sl.chain_n), b(64 * W);
+    if (W == 2) switch (nv) {
+        case 1: NPHIP_LAUNCH_REMOTE(2, 1); break;
+        case 2: NPHIP_LAUNCH_REMOTE(2, 2); break;
+        case 3: NPHIP_LAUNCH_REMOTE(2, 3); break;
+        case 4: NPHIP_LAUNCH_REMOTE(2, 4); break;
+        case 5: NPHIP_LAUNCH_REMOTE(2, 5); break;
+        case 6: NPHIP_LAUNCH_REMOTE(2, 6); break;
+        case 7: NPHIP_LAUNCH_REMOTE(2, 7); break;
+        case 8: NPHIP_LAUNCH_REMOTE(2, 8); break;
+        default: return hipErrorInvalidValue;
+    } else if (W == 4) switch (nv) {
+        case 1: NPHIP_LAUNCH_REMOTE(4, 1); break;
+        case 2: NPHIP_LAUNCH_REMOTE(4, 2); break;
+        case 3: NPHIP_LAUNCH_REMOTE(4, 3); break;
+        case 4: NPHIP_LAUNCH_REMOTE(4, 4); break;
+        case 5: NPHIP_LAUNCH_REMOTE(4, 5); break;
+        case 6: NPHIP_LAUNCH_REMOTE(4, 6); break;
+        case 7: NPHIP_LAUNCH_REMOTE(4, 7); break;
+        case 8: NPHIP_LAUNCH_REMOTE(4, 8); break;
+        default: return hipErrorInvalidValue;
+    } else return hipErrorInvalidValue;
+    return hipGetLastError();
+#endif
+}
+#undef NPHIP_LAUNCH_REMOTE
+#endif   // part 6
+
 
 #if NPHIP_HAS(0)
 // ----------------------------------------------------------------------------------------

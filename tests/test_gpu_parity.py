@@ -335,9 +335,10 @@ def test_host_callback_launch_modes_are_bit_identical(hip, oracle, fixture_lib, 
     assert np.array_equal(got.stats["gradient"], want.stats["gradient"])
 
 
-@pytest.mark.parametrize("dim", [130, 700, 1024])
+@pytest.mark.parametrize("dim", [130, 700, 1024, 1100, 2048, 2500, 4096])
 def test_resident_host_callback_wider_rows(hip, oracle, dim):
-    """Resident launches with 2, 6 and 8 chunks of registers per chain (Python callable, two groups of chains)."""
+    """Resident launches with 2, 6 and 8 chunks of registers per chain, and — above 1024 dimensions — with two and four waves
+    per chain (Python callable, two groups of chains)."""
     sd = np.exp(np.random.default_rng(dim).normal(size=dim) * 0.7)
 
     def logp(x):
@@ -424,6 +425,24 @@ def test_resident_job_survives_progress_pause_and_partial_reads(hip, oracle, fix
     assert (fin <= kw["tune"] + kw["draws"]).all()
     for c in range(kw["chains"]):
         assert np.array_equal(part.draws[c, : fin[c]], want.draws[c, : fin[c]])
+
+
+@pytest.mark.parametrize("persist,mode", [(256, "resident"), (-20, "fell-back"), (1, "groups")])
+def test_multi_wave_host_callback_launch_modes(hip, oracle, persist, mode):
+    """1500 dimensions = two waves per chain: resident launches, a resident job that falls back after 20 evaluations (the first
+    launch per evaluation performs the deferred first half of the leapfrog), and launches per evaluation from the start."""
+    dim = 1500
+    sd = np.exp(np.random.default_rng(7).normal(size=dim) * 0.5)
+
+    def logp(x):
+        z = x / sd
+        return -0.5 * float(z @ z), -z / sd
+
+    info = {}
+    got, W = run_engine(hip, hip.HostCallbackModel(dim, logp), chains=5, tune=40, draws=20, seed=11, launch=dict(host_groups=2, host_persist=persist), info=info)
+    assert W == 2 and info["host_mode"] == mode
+    want = oracle.sample_callback(oracle_settings(oracle, chains=5, tune=40, draws=20, seed=11, W=W), dim, logp)
+    assert_trace_equal(got, want)
 
 
 def test_bridgestan_adapter_matches_raw_callback(hip, oracle, fixture_lib):
