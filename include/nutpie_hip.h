@@ -78,7 +78,8 @@ typedef struct nphip_model nphip_model_t;
 
 /* The reference's raw C logp callback, verbatim: src/pymc.rs:23-29 /
  * python/nutpie/compile_pymc.py:975-981.  0 ok, >0 recoverable (=> divergence), <0 fatal
- * (src/pymc.rs:166-180).  Must be re-entrant: called concurrently from n_threads host threads. */
+ * (src/pymc.rs:166-180).  Must be re-entrant: called concurrently from up to n_threads host threads (n_threads is an upper bound, 0 = the
+ * usable cores: the engine evaluates a batch of rows on as many threads as its measured cost is worth, one for cheap rows). */
 typedef int (*nphip_raw_logp_fn)(uint64_t dim, const double* x, double* grad_out, double* logp_out, void* user_data);
 /* (The return type is the reference's `std::os::raw::c_int`.  A numba cfunc declared `int64(...)`, compile_pymc.py:975-981,
  * leaves its code in the full return register; like the reference, the engine reads the low 32 bits.) */

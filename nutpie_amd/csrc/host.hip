@@ -939,8 +939,8 @@ void nphip_sampler::eval_rows(uint64_t lo, uint64_t cnt) {
 }
 
 // The rows of several ranges as ONE batch (resident launches: every group that has published by now).  Threads: the model's
-// n_threads when given; otherwise from the measured cost of a row — batches evaluated on this thread are timed — so that every
-// thread gets >= 10 us of rows (a batch of 256 rows of 40 ns is faster on one thread than handed out; 32 rows of 1.6 us are not).
+// from the measured cost of a row — batches evaluated on this thread are timed — so that every thread gets >= 10 us of rows, at
+// most the model's n_threads when given (a batch of 256 rows of 40 ns is faster on one thread than handed out; 32 rows of 1.6 us are not).
 void nphip_sampler::eval_ranges(const RowRange* rg, int nr) {
     const uint64_t d = dim;
     uint64_t total = 0;
@@ -953,12 +953,14 @@ void nphip_sampler::eval_ranges(const RowRange* rg, int nr) {
         h_code[row] = (int64_t)model.host_fn(d, h_q + row * d, h_g + row * d, &lp, model.user);   // c_int, sign-extended
         h_u[row] = lp;
     };
+    // (the model's n_threads is an upper bound: eight schools with n_threads = 16 forced onto 16 threads ran at 6.7 M leapfrogs/s
+    //  against 11.7 on one)
+    const int cap = model.n_threads > 0 ? model.n_threads : std::max(1, host_cores - 1);
     int want = 1;
-    if (model.n_threads > 0) want = (int)std::min<uint64_t>((uint64_t)model.n_threads, total);
-    else if (timed_batches >= 4 && row_ns >= 150.0)   // (rows cheaper than that are faster on one thread: measured with 35 ns rows)
-        want = (int)std::min<double>((double)std::max(1, host_cores - 1), std::floor((double)total * row_ns / 10000.0));
+    if (timed_batches >= 4 && row_ns >= 150.0)   // (rows cheaper than that are faster on one thread: measured with 35 ns rows)
+        want = (int)std::max(1.0, std::min<double>((double)cap, std::floor((double)total * row_ns / 10000.0)));
     if (want >= 2) {
-        if (!pool) pool.reset(new RowPool(model.n_threads > 0 ? model.n_threads : std::max(2, host_cores - 1)));
+        if (!pool) pool.reset(new RowPool(std::max(2, cap)));
         eval_threads = std::max(eval_threads, want);
         pool->run(total, f, want);
         return;
