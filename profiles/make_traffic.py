@@ -11,7 +11,7 @@ import re
 HERE = os.path.dirname(os.path.abspath(__file__))
 # (dim, waves) -> (summary file, leapfrogs per launch of the profiled run, kernel)
 SOURCES = {
-    "1000:1": ("r1_v4_pmc.txt", 1024 * 256, "k_advance<fused,W=1,NV=8>"),
+    "1000:1": ("r2_d1000_kernel_pmc.txt", 1024 * 256, "k_advance<fused,W=1,NV=8>"),
     "2000:2": ("r1_d2000_multiwave_kernel_pmc.txt", 1024 * 128, "k_advance<fused,W=2,NV=8>"),
     "10000:4": ("r2_d10000_lean_lds_slot_e128_pmc.txt", 1024 * 128, "k_advance<fused,W=4,NV=20,lean>"),
 }
