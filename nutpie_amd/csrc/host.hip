@@ -396,6 +396,23 @@ static int usable_cores() {
     return std::max(1, n);
 }
 
+// Is [p, p + bytes) mapped readable and writable in THIS process (/proc/self/maps)?  Fine-grained device memory is, on a large-BAR
+// system whose runtime maps it for the CPU; asking first means a box where it is not gets host-memory staging instead of a fault.
+static bool cpu_writable(const void* p, size_t bytes) {
+    FILE* f = fopen("/proc/self/maps", "r");
+    if (!f) return false;
+    const unsigned long long lo = (unsigned long long)(uintptr_t)p, hi = lo + bytes;
+    char line[512];
+    bool ok = false;
+    while (fgets(line, sizeof(line), f)) {
+        unsigned long long a = 0, b = 0;
+        char perms[8] = {0};
+        if (sscanf(line, "%llx-%llx %7s", &a, &b, perms) == 3 && a <= lo && hi <= b) { ok = perms[0] == 'r' && perms[1] == 'w'; break; }
+    }
+    fclose(f);
+    return ok;
+}
+
 // Evaluates the rows of a batch on `n` threads: the caller and n - 1 workers (the reference: one rayon worker per chain,
 // src/pymc.rs:197-215).  A batch of a cheap model is a few microseconds of work, so the workers do not sleep between batches:
 // they spin on a generation counter (a dispatch costs a cache-line transfer, not a futex wake-up of tens of microseconds) and
@@ -593,6 +610,7 @@ struct nphip_sampler {
     bool materialise = false;   // the next callback launches follow resident ones (LaunchSlice::materialise)
     int64_t fall_back_after = 0; // tests (launch.host_persist = -N): leave the resident mode after N evaluations, as a failed roll call would
     int64_t remote_evals = 0;
+    bool bar_used = false;   // (diagnostics: the BAR copy was in use at some point of the job)
     double t_wait_ns = 0.0, t_eval_ns = 0.0;   // NPHIP_TIMING=1: where the driver thread's time goes (printed at the end of the job)
     unsigned remote_launch_id = 0;
     bool remote_fresh = false;  // the running launch has not published anything yet (its roll call may still fail)
@@ -825,8 +843,11 @@ bool nphip_sampler::setup() {
                     if (large_bar && hipExtMallocWithFlags(&pg, std::max<size_t>(8, n * dim * 8), hipDeviceMallocFinegrained) == hipSuccess &&
                         hipExtMallocWithFlags(&pu, n * 8, hipDeviceMallocFinegrained) == hipSuccess &&
                         hipExtMallocWithFlags(&pc, n * 8, hipDeviceMallocFinegrained) == hipSuccess &&
-                        hipExtMallocWithFlags(&po, 8 * kMaxGroups * 8, hipDeviceMallocFinegrained) == hipSuccess) {
+                        hipExtMallocWithFlags(&po, 8 * kMaxGroups * 8, hipDeviceMallocFinegrained) == hipSuccess &&
+                        cpu_writable(pg, std::max<size_t>(8, n * dim * 8)) && cpu_writable(pu, n * 8) && cpu_writable(pc, n * 8) &&
+                        cpu_writable(po, 8 * kMaxGroups * 8)) {
                         bar = true;
+                        bar_used = true;
                         b_g = (double*)pg; b_u = (double*)pu; b_code = (int64_t*)pc; b_go = (volatile unsigned long long*)po;
                         for (int i = 0; i < 8 * kMaxGroups; ++i) b_go[i] = 0ull;
                         args.geval = b_g; args.ueval = b_u; args.ecode = b_code; args.grp_go = b_go;
@@ -1336,8 +1357,9 @@ void nphip_sampler::run() {
         (void)sync_all();
     }
     if (remote_evals > 0 && getenv("NPHIP_TIMING"))
-        fprintf(stderr, "[nutpie-hip] resident launches: %lld evaluations of a group, driver thread: %.2f us waiting for the device + %.2f us evaluating per evaluation, %d evaluation threads (%.0f ns per row)\n",
-                (long long)remote_evals, t_wait_ns / remote_evals * 1e-3, t_eval_ns / remote_evals * 1e-3, eval_threads, row_ns);
+        fprintf(stderr, "[nutpie-hip] resident launches: %lld evaluations of a group, driver thread: %.2f us waiting for the device + %.2f us evaluating per evaluation, %d evaluation threads (%.0f ns per row), results through the BAR: %s\n",
+                (long long)remote_evals, t_wait_ns / remote_evals * 1e-3, t_eval_ns / remote_evals * 1e-3, eval_threads, row_ns,
+                bar ? "yes" : (bar_used ? "at first" : "no"));
     {
         std::lock_guard<std::mutex> lk(mu);
         finished = all_done && !failed;
