@@ -48,7 +48,8 @@ enum {
     NPHIP_RNG_INIT = 4,        /* c0 = pair index ; c2 = init attempt                          */
     NPHIP_RNG_SS_MOMENTUM = 5, /* c0 = pair index ; c2 = search id (0xffffffff at chain start, */
                                /*                    else the draw index that triggered it)   */
-    NPHIP_RNG_JITTER = 6       /* c2 = draw                                                    */
+    NPHIP_RNG_JITTER = 6,      /* c2 = draw                                                    */
+    NPHIP_RNG_EXPAND = 7       /* word 0 = seed of the chain's generator for the expand step (BridgeStan's bs_rng, src/stan.rs:787-788) */
 };
 
 typedef struct { uint32_t v[4]; } nphip_u32x4;

@@ -14,7 +14,8 @@
  *   ExpandFunc / RawExpandFunc (src/pymc.rs:31-37, 64-95, nphip_model_set_expand, nphip_sampler_copy_expanded
  *     217-286)
  *   PyModel  (src/pyfunc.rs:206-230, 517-570)           nphip_model_device_callback
- *   StanModel::logp (src/stan.rs:454-463)               nphip_model_host_callback (adapter)
+ *   StanModel::logp (src/stan.rs:454-463)               nphip_model_bridgestan (adapter onto the host-callback path)
+ *   StanDensity::expand_vector (src/stan.rs:473-520)    nphip_model_set_bridgestan_expand
  *   nuts_rs::Sampler::new (src/wrapper.rs:977-1085)     nphip_sampler_create
  *   PySampler::{wait,pause,resume,abort,is_finished,    nphip_sampler_{wait,pause,resume,abort,
  *     inspect,take_results} (src/wrapper.rs:1252-1456)    is_finished,trace_*}
@@ -121,6 +122,16 @@ int nphip_model_set_init(nphip_model_t*, int kind, const double* points, uint64_
  * an expand function; the host form is evaluated on the model's host thread pool, the device form on the engine's stream. */
 int nphip_model_set_expand(nphip_model_t*, uint64_t expanded_dim, nphip_raw_expand_fn fn, void* user_data);
 int nphip_model_set_device_expand(nphip_model_t*, uint64_t expanded_dim, nphip_device_expand_fn fn, void* user_data);
+/* BridgeStan flavour of the expand step (reference src/stan.rs:473-520, 787-796): every stored draw is expanded with
+ *   bs_param_constrain(bs_model, include_tp = true, include_gq = true, theta_unc, theta, rng, &err)
+ * using ONE bs_rng per chain, as the reference does (StanModel::math builds it from the chain's generator; here its seed is
+ * word 0 of the Philox block (settings.seed; 0, global chain, 0, NPHIP_RNG_EXPAND)): the draws of a chain are expanded in
+ * order on one thread, chains concurrently.  BridgeStan writes every variable as a column-major block; the reference re-orders
+ * them to C order (src/stan.rs:507-516, 671-711): out[j] = theta[perm[j]] (perm = NULL: keep BridgeStan's order).  The
+ * function addresses are those of the loaded model library (bridgestan.h: bs_param_constrain, bs_rng_construct,
+ * bs_rng_destruct, bs_free_error_msg).  A Stan error fails the copy with "Failed to constrain the parameters of the draw". */
+int nphip_model_set_bridgestan_expand(nphip_model_t*, uint64_t expanded_dim, void* bs_model, void* param_constrain, void* rng_construct,
+                                      void* rng_destruct, void* free_error_msg, const uint64_t* perm);
 uint64_t nphip_model_expanded_dim(const nphip_model_t*);  /* 0 = no expand function */
 uint64_t nphip_model_dim(const nphip_model_t*);
 void nphip_model_free(nphip_model_t*);

@@ -150,6 +150,7 @@ def lib():
             L.nphip_model_free.argtypes = [C.c_void_p]
             L.nphip_model_set_expand.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
             L.nphip_model_set_device_expand.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+            L.nphip_model_set_bridgestan_expand.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
             L.nphip_model_expanded_dim.argtypes = [C.c_void_p]
             L.nphip_model_expanded_dim.restype = C.c_uint64
             L.nphip_sampler_copy_expanded.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
@@ -474,6 +475,23 @@ class BridgeStanModel(_Model):
         free = C.cast(stanlib.bs_free_error_msg, C.c_void_p) if hasattr(stanlib, "bs_free_error_msg") else None
         ptr = bs_model if isinstance(bs_model, C.c_void_p) else C.cast(bs_model, C.c_void_p)
         super().__init__(lib().nphip_model_bridgestan(C.c_uint64(dim), ptr, ldg, free, int(n_threads)), dim, [stanlib, bs_model, keep_alive])
+        self._bs = (stanlib, ptr, free)
+
+    def set_bridgestan_expand(self, expanded_dim: int, perm=None):
+        """The expand step behind the C-ABI (reference src/stan.rs:473-520): ``bs_param_constrain(include_tp, include_gq)`` per
+        stored draw with one ``bs_rng`` per chain, chains concurrently on the host pool; ``perm`` (``stan_names.c_order_permutation``)
+        re-orders BridgeStan's column-major blocks to C order natively."""
+        stanlib, ptr, free = self._bs
+        fn = lambda name: C.cast(getattr(stanlib, name), C.c_void_p)  # noqa: E731
+        p = None
+        if perm is not None:
+            p = np.ascontiguousarray(perm, dtype=np.uint64)
+            if p.shape != (int(expanded_dim),):
+                raise ValueError("perm must have expanded_dim entries")
+        rc = lib().nphip_model_set_bridgestan_expand(self._h, C.c_uint64(int(expanded_dim)), ptr, fn("bs_param_constrain"), fn("bs_rng_construct"),
+                                                    fn("bs_rng_destruct"), free, None if p is None else p.ctypes.data_as(C.c_void_p))
+        if rc != NPHIP_OK:
+            raise ValueError(_err())
 
 
 class DeviceCallbackModel(_Model):

@@ -8,8 +8,8 @@ thread pool, behind the engine's host-callback path (pinned ``hipMemcpyAsync`` b
 BridgeStan and the Stan toolchain are not installable in the build image, so model compilation
 and its sha256 cache (``compile_stan.py:151-224``) are OUT OF SCOPE: this module needs an
 importable ``bridgestan`` and otherwise raises ``ImportError``.  The native adapter underneath
-(``nphip_model_bridgestan``) is tested with a stand-in library that exports BridgeStan's C API
-for the eight-schools model (tests/fixtures/eight_schools.c).
+(``nphip_model_bridgestan``, and ``nphip_model_set_bridgestan_expand`` for the expand step) is tested with stand-in
+libraries that export BridgeStan's C API (tests/fixtures/eight_schools.c, tests/fixtures/bs_standin.c).
 """
 
 from __future__ import annotations
@@ -81,34 +81,27 @@ class CompiledStanModel(CompiledModel):
         return dict(self._coords or {})
 
     def _make_model(self, init_mean=None, settings=None):
+        from nutpie_amd.stan_names import c_order_permutation
+
         m = self._bound()
         model = _lib.BridgeStanModel(self.n_dim, m.stanlib, m.model_rng if hasattr(m, "model_rng") else m.model, keep_alive=m)
         model.set_init("normal")  # src/stan.rs:798-808
+        # the expand step runs behind the C-ABI: bs_param_constrain per draw with one bs_rng per chain, chains concurrently on
+        # the host pool, column-major blocks re-ordered natively (src/stan.rs:473-520, 671-711, 787-796)
+        variables = self._variables()
+        if variables:
+            model.set_bridgestan_expand(variables[-1].end, c_order_permutation(variables))
         return model
 
     def _make_sampler(self, settings, init_mean, cores, progress_type, extra_callback, extra_callback_rate, store, **engine_kw):
         return _lib.PySampler.from_stan(settings, cores, self._make_model(), progress_type, extra_callback, extra_callback_rate, store, **engine_kw)
 
-    def _expand_draws(self, draws, seed: int = 0):
-        # param_constrain per draw; BridgeStan returns column-major blocks which the reference
-        # transposes in Rust (src/stan.rs:473-520, 671-711).  The flat vector is returned here.
-        # BridgeStan needs an rng for generated quantities; the reference creates one per chain from the sampling seed
-        # (`model.new_rng(seed)`, src/stan.rs:476-492, 774-788)
-        m = self._bound()
-        n, T, _ = draws.shape
-        k = int(m.param_num(include_tp=True, include_gq=True))
-        out = np.empty((n, T, k))
-        row = np.empty(k)
-        for c in range(n):
-            rng = m.new_rng(int(seed) + c)
-            for t in range(T):
-                if np.isnan(draws[c, t, 0]):
-                    out[c, t] = np.nan
-                    continue
-                out[c, t] = m.param_constrain(draws[c, t], include_tp=True, include_gq=True, out=row, rng=rng)
-        from nutpie_amd.stan_names import expand_constrained
+    def _unflatten(self, flat):
+        # [chain, draw, n_constrained], blocks already in C order -> variables (names and shapes parsed as src/stan.rs:93-251)
+        return {v.name: flat[..., v.start:v.end].reshape(*flat.shape[:-1], *v.shape) for v in self._variables()}
 
-        return expand_constrained(out, self._variables())  # names parsed + column-major blocks re-ordered (src/stan.rs:93-251, 671-711)
+    def _expand_draws(self, draws, seed: int = 0):
+        raise RuntimeError("a Stan model expands behind the C-ABI (nphip_model_set_bridgestan_expand); it needs the sampler's stored draws")
 
 
 def compile_stan_model(*, code: Optional[str] = None, filename: Optional[str] = None, extra_compile_args=None,

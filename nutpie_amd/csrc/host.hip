@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "../../include/nutpie_hip.h"
+#include "../../include/nphip_spec.h"
 #include "engine_types.h"
 
 namespace nphip {
@@ -286,9 +287,19 @@ static int bs_trampoline(uint64_t, const double* x, double* grad, double* logp, 
     return std::isfinite(*logp) ? 0 : 4;                                     // BadLogp, recoverable
 }
 
+// BridgeStan's expand step (src/stan.rs:473-520): bs_param_constrain with one bs_rng per chain (src/stan.rs:787-796)
+typedef int (*bs_constrain_fn)(const void* model, bool include_tp, bool include_gq, const double* theta_unc, double* theta, void* rng, char** err);
+typedef void* (*bs_rng_construct_fn)(unsigned int seed, char** err);
+typedef void (*bs_rng_destruct_fn)(void* rng);
+struct BsExpand {
+    void* model; bs_constrain_fn constrain; bs_rng_construct_fn rng_new; bs_rng_destruct_fn rng_free; bs_free_err_fn free_err;
+    std::vector<uint64_t> perm;   // out[j] = theta[perm[j]] (column-major blocks -> C order); empty = identity
+};
+
 struct nphip_model {
     int kind = 0;  // 0 fused tridiag, 1 host callback, 2 device callback
     std::shared_ptr<BsAdapter> bs;
+    std::shared_ptr<BsExpand> bs_expand;
     uint64_t dim = 0;
     std::vector<double> mu, a, b;
     nphip_raw_logp_fn host_fn = nullptr;
@@ -349,11 +360,32 @@ int nphip_model_set_init(nphip_model_t* m, int kind, const double* points, uint6
 int nphip_model_set_expand(nphip_model_t* m, uint64_t expanded_dim, nphip_raw_expand_fn fn, void* user_data) {
     if (!fn || expanded_dim == 0) return bad_value("expand needs a function and expanded_dim > 0");
     m->expanded_dim = expanded_dim; m->expand_fn = fn; m->expand_dev_fn = nullptr; m->expand_user = user_data;
+    m->bs_expand.reset();
+    return NPHIP_OK;
+}
+int nphip_model_set_bridgestan_expand(nphip_model_t* m, uint64_t expanded_dim, void* bs_model, void* param_constrain, void* rng_construct,
+                                      void* rng_destruct, void* free_error_msg, const uint64_t* perm) {
+    if (!bs_model || !param_constrain || !rng_construct || !rng_destruct || expanded_dim == 0)
+        return bad_value("the BridgeStan expand step needs a model handle, bs_param_constrain, bs_rng_construct, bs_rng_destruct and expanded_dim > 0");
+    auto e = std::make_shared<BsExpand>();
+    e->model = bs_model; e->constrain = (bs_constrain_fn)param_constrain; e->rng_new = (bs_rng_construct_fn)rng_construct;
+    e->rng_free = (bs_rng_destruct_fn)rng_destruct; e->free_err = (bs_free_err_fn)free_error_msg;
+    if (perm) {
+        e->perm.assign(perm, perm + expanded_dim);
+        std::vector<uint8_t> seen(expanded_dim, 0);
+        for (uint64_t j : e->perm) {
+            if (j >= expanded_dim || seen[j]) return bad_value("perm must be a permutation of 0 .. expanded_dim - 1");
+            seen[j] = 1;
+        }
+    }
+    m->expanded_dim = expanded_dim; m->expand_fn = nullptr; m->expand_dev_fn = nullptr; m->expand_user = nullptr;
+    m->bs_expand = e;
     return NPHIP_OK;
 }
 int nphip_model_set_device_expand(nphip_model_t* m, uint64_t expanded_dim, nphip_device_expand_fn fn, void* user_data) {
     if (!fn || expanded_dim == 0) return bad_value("expand needs a function and expanded_dim > 0");
     m->expanded_dim = expanded_dim; m->expand_dev_fn = fn; m->expand_fn = nullptr; m->expand_user = user_data;
+    m->bs_expand.reset();
     return NPHIP_OK;
 }
 uint64_t nphip_model_expanded_dim(const nphip_model_t* m) { return m->expanded_dim; }
@@ -714,6 +746,14 @@ bool nphip_sampler::setup() {
     s.init_kind = model.init_kind; s.num_try_init = (int32_t)set.num_try_init;
     s.store_draws = launch.store_draws; s.store_gradient = set.store_gradient;
     s.store_mass_matrix = set.store_mass_matrix; s.store_divergences = set.store_divergences;
+    // the adaptation hook is driven by the caller (nphip_sampler_waiting / nphip_sampler_resume_at need manual mode): with a
+    // driver thread nobody would ever resume a chain that stopped, and wait() would never return.  A pause at or after the
+    // end of warm-up would re-enter the initial-point sequence (fresh mass matrix, step-size search) in the sampling phase.
+    if (!set.pause_draws.empty()) {
+        if (!launch.manual) { set_error("pause draws need a manual-mode sampler (launch.manual = 1): the caller resumes the chains"); return false; }
+        for (uint64_t pd : set.pause_draws)
+            if (pd == 0 || pd >= set.num_tune) { set_error("pause draws must lie inside the warm-up (0 < draw < num_tune)"); return false; }
+    }
     s.n_pause = (int32_t)set.pause_draws.size();
     for (size_t i = 0; i < set.pause_draws.size(); ++i) s.pause_draws[i] = (int64_t)set.pause_draws[i];
 
@@ -725,14 +765,14 @@ bool nphip_sampler::setup() {
     // chunks, so the leading dimension is padded to a multiple of 128 * W (pads are exact zeros in every reduction)
     const bool fused_model = (model.kind == 0);
     int reg_multi = 0;
-    if (fused_model && (W == 2 || W == 4) && !launch.no_register_kernel && !set.store_divergences) {
+    if (fused_model && (W == 2 || W == 4) && !launch.no_register_kernel) {
         const int64_t per_wave = ((int64_t)((dim + 127) / 128) + W - 1) / W;
         if (per_wave >= 1 && per_wave <= 8) { reg_multi = (int)per_wave; args.ld = per_wave * W * 128; }
     }
     // lean register-resident kernels (8 waves per chain, up to 10 chunks per wave: D <= 10240 — the rows of config 5): state in
     // VGPRs, sigma^2 in LDS, merge operands streamed (kernels.hip: leaf_lean).  Same padding rule as above.
     int lean_nc = 0;
-    if (fused_model && (W == 8 || W == 4) && !launch.no_register_kernel && !set.store_divergences) {
+    if (fused_model && (W == 8 || W == 4) && !launch.no_register_kernel) {
         const int64_t per_wave = ((int64_t)((dim + 127) / 128) + W - 1) / W;
         if (W == 8 && per_wave >= 1 && per_wave <= 10) { lean_nc = (int)per_wave; args.ld = per_wave * W * 128; }
         // (experimental geometry: 4 waves per chain with the state spread over VGPRs + AGPRs, one wave per SIMD)
@@ -751,9 +791,9 @@ bool nphip_sampler::setup() {
     // register-resident specialisation, one wave per chain: state in VGPRs (dim <= 1024, one instantiation per chunk count)
     args.reg_nv = lean_nc ? lean_nc : reg_multi;
     args.lean = lean_nc ? 1 : 0;
-    // (not with store_divergences: the divergence record needs the pre-step state, which only the
-    //  memory-resident kernel keeps)
-    if (fused && W == 1 && !launch.no_register_kernel && !set.store_divergences) {
+    // (store_divergences does not change the choice: the register kernels rebuild the pre-step state of a failed leapfrog in
+    //  the rare path — kernels.hip: replay_divergence)
+    if (fused && W == 1 && !launch.no_register_kernel) {
         const int nchunks = (int)(args.ld / 128);  // one kernel instantiation per exact chunk count (straight-line code)
         if (nchunks <= 8) args.reg_nv = nchunks;
     }
@@ -1565,7 +1605,53 @@ int nphip_sampler_copy_expanded(nphip_sampler_t* s, void* host_out, uint64_t nby
     // blocks of rows: at most ~64 MB of positions per block
     const uint64_t block = std::max<uint64_t>(1, std::min<uint64_t>(rows, (64ull << 20) / (d * 8)));
     std::atomic<int> first_err{0};
-    if (m.expand_fn) {
+    if (m.bs_expand) {
+        // BridgeStan: the generated quantities draw from a per-chain bs_rng, so a chain's draws are expanded in order on one
+        // thread (src/stan.rs:473-492) and the chains concurrently.  The rng's seed is the chain's own: word 0 of the Philox
+        // block (settings.seed; 0, global chain, 0, NPHIP_RNG_EXPAND) — the reference takes `rng.next_u32()` of the chain's
+        // generator (src/stan.rs:787-788); independent of sharding either way.
+        const BsExpand& B = *m.bs_expand;
+        const uint64_t T = s->T, chains_per_block = std::max<uint64_t>(1, block / std::max<uint64_t>(1, T));
+        std::vector<double> x(std::min<uint64_t>(s->n, chains_per_block) * T * d);
+        int nt = (int)std::min<uint64_t>(std::max(1u, std::thread::hardware_concurrency()), 32);
+        if (m.n_threads > 0) nt = m.n_threads;
+        RowPool pool(nt > 1 ? nt : 0);
+        std::mutex err_mu;
+        std::string err_text;
+        for (uint64_t c0 = 0; c0 < s->n; c0 += chains_per_block) {
+            const uint64_t nc = std::min(chains_per_block, s->n - c0);
+            if (!hip_ok(hipMemcpy(x.data(), s->args.tr_draws + c0 * T * d, nc * T * d * 8, hipMemcpyDeviceToHost), "copy draws")) return NPHIP_ERR;
+            pool.run(nc, [&](uint64_t r) {
+                const uint64_t chain = c0 + r;
+                const nphip_u32x4 blk = nphip_philox(s->set.seed, 0u, (uint32_t)(s->launch.chain_offset + chain), 0u, NPHIP_RNG_EXPAND);
+                char* em = nullptr;
+                void* rng = B.rng_new(blk.v[0], &em);
+                std::vector<double> theta(E);
+                for (uint64_t draw = 0; draw < T; ++draw) {
+                    double* o = out + (chain * T + draw) * E;
+                    if (!rng || (int64_t)draw >= h[chain].draw) { for (uint64_t e = 0; e < E; ++e) o[e] = NAN; continue; }
+                    const int rc = B.constrain(B.model, true, true, x.data() + (r * T + draw) * d, theta.data(), rng, &em);
+                    if (rc != 0) {
+                        int z = 0;
+                        if (first_err.compare_exchange_strong(z, rc)) { std::lock_guard<std::mutex> lk(err_mu); err_text = em ? em : ""; }
+                        if (em && B.free_err) B.free_err(em);
+                        em = nullptr;
+                        for (uint64_t e = 0; e < E; ++e) o[e] = NAN;
+                        continue;
+                    }
+                    if (B.perm.empty()) memcpy(o, theta.data(), E * 8);
+                    else for (uint64_t e = 0; e < E; ++e) o[e] = theta[B.perm[e]];
+                }
+                if (!rng) { int z = 0; if (first_err.compare_exchange_strong(z, -1)) { std::lock_guard<std::mutex> lk(err_mu); err_text = em ? em : "bs_rng_construct failed"; } if (em && B.free_err) B.free_err(em); }
+                else B.rng_free(rng);
+            });
+        }
+        if (first_err.load() != 0) {   // src/stan.rs:493-494
+            set_error("Failed to constrain the parameters of the draw" + (err_text.empty() ? std::string() : ": " + err_text));
+            return NPHIP_ERR;
+        }
+        return NPHIP_OK;
+    } else if (m.expand_fn) {
         std::vector<double> x(block * d);
         int nt = (int)std::min<uint64_t>(std::max(1u, std::thread::hardware_concurrency()), 32);
         if (m.n_threads > 0) nt = m.n_threads;

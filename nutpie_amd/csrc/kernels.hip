@@ -1139,7 +1139,7 @@ struct Machine {
                 c->acc_sym_sum += 2.0 * a / (1.0 + e);
             }
         }
-        if (diverged) { X.dirty_qg = X.dirty_pr = false; rare_end_draw(A, c, red, chain, true, false, false, false, !REMOTE); return true; }
+        if (diverged) { X.dirty_qg = X.dirty_pr = false; rare_end_draw(A, c, red, chain, true, false, FUSED, ok, !REMOTE, FUSED); return true; }
 #ifdef NPHIP_PROFILE
         int64_t tq = (int64_t)__builtin_readcyclecounter();
         c->prof[8] += tq - tp2;
@@ -1627,7 +1627,7 @@ struct Machine {
     }
 
     // returns 0 (next leaf) or an end code; the caller runs the out-of-line draw end AFTER the register state is dead:
-    // 1 diverged, 2 U-turn, 3 maximum depth
+    // 1 diverged (energy error), 2 U-turn, 3 maximum depth, 4 diverged (logp not finite: no end position to report)
     __device__ __forceinline__ int leaf_lean(const LeanRs& rs, RegsT& X) {
         const int64_t j = c->nleaf + 1, d = c->depth, dir = c->dir;
         const int db = dir > 0 ? 1 : 0;
@@ -1712,7 +1712,7 @@ struct Machine {
             c->acc_sum += a;
             c->acc_sym_sum += 2.0 * a / (1.0 + e);
         }
-        if (diverged) { X.dirty_qg = X.dirty_pr = false; return 1; }
+        if (diverged) { X.dirty_qg = X.dirty_pr = false; return ok ? 1 : 4; }
 #ifdef NPHIP_PROFILE
         int64_t tq = (int64_t)__builtin_readcyclecounter();
         c->prof[8] += tq - tp2;
@@ -1941,6 +1941,37 @@ struct Machine {
         }
     }
 
+    // Divergence record of the register-resident kernels.  The state a failed leapfrog started from lives only in registers, and
+    // the leaf updates it in place — nothing of it is left when the energy error is known.  It is rebuilt here, in the rare path:
+    // the state the current doubling started from (a trajectory end) is always in HBM, and the leaves of a doubling are a
+    // deterministic function of it, so the j - 1 leapfrogs before the failed one are integrated again with the memory-resident
+    // passes (same operations in the same order as the leaf: the same bits), then the first half of the failed one for the
+    // position it ended at.  Costs a diverging draw at most its last doubling again and the hot path nothing.
+    __device__ void replay_divergence(bool have_end) {
+        const int64_t j = c->nleaf;   // the failed leaf (already counted)
+        const int64_t dir = c->dir;
+        const int db = dir > 0 ? 1 : 0;
+        int64_t sq = c->endq[db], sp = c->endp[db];
+        // scratch: two Q-pool buffers that are neither the draw about to be emitted nor the start state; the tree is dead, so
+        // the P-slots of level 0 are free (the start state's slot is the origin's or a trajectory end's)
+        int64_t b[2];
+        int nb = 0;
+        for (int64_t i = 0; i < A.nqpool && nb < 2; ++i)
+            if (i != c->cand_q && i != sq) b[nb++] = i;
+        const int64_t ps[2] = {slot_first(0), slot_last(0, A.cap)};
+        double lp;
+        int64_t code;
+        eval_position(sq, lp, code);   // (the pool keeps q only: the gradient at the start state)
+        for (int64_t i = 1; i < j; ++i) {
+            const int t = (int)(i & 1);
+            lf1(sq, sp, b[t], ps[t], dir);
+            (void)lf2(lp, code, 1);
+            sq = b[t]; sp = ps[t];
+        }
+        lf1(sq, sp, b[(int)(j & 1)], ps[(int)(j & 1)], dir);   // first half of the failed step: q_end
+        store_divergence(have_end);
+    }
+
     // ------------------------------------------------------------------ control flow
     __device__ void start_ss(int64_t ss_id) {
         c->ss_id = ss_id;
@@ -2166,7 +2197,7 @@ struct Machine {
     // arguments: the hot Machine object never escapes, so its members stay in (S/V)GPRs.
     static __device__ __attribute__((noinline)) void rare_end_draw(const NPHIP_CONST Args& a, LdsCtl ctl, LdsDouble r, int64_t ch,
                                                                   bool diverging, bool maxdepth, bool store_div, bool div_has_end,
-                                                                  bool regrad = false) {
+                                                                  bool regrad = false, bool replay = false) {
         if (W > 1) __syncthreads();   // the caller's last reduction may have used the scratch area this one starts with
         Machine m(a, ctl, r, ch);
 #ifdef NPHIP_PROFILE
@@ -2180,7 +2211,9 @@ struct Machine {
 #ifdef NPHIP_PROFILE
         ctl->prof[12] += (int64_t)__builtin_readcyclecounter() - t0_;
 #endif
-        if (store_div) {
+        if (store_div && replay) {
+            if (a.tr_div[0]) m.replay_divergence(div_has_end);
+        } else if (store_div) {
             if (regrad && a.tr_div[0]) {   // the divergence record wants the gradient at the start of the failed step
                 double lp_;
                 int64_t code_;
@@ -2386,7 +2419,7 @@ struct Machine {
             }
             if (!rare) flush(X);  // launch boundary: registers (and the LDS slot) that hold the only copy of tree state go back to HBM
             sig_lds = nullptr;
-            if (LEAN && lean_end != 0) rare_end_draw(A, c, red, chain, lean_end == 1, lean_end == 3, false, false, true);
+            if (LEAN && lean_end != 0) rare_end_draw(A, c, red, chain, lean_end == 1 || lean_end == 4, lean_end == 3, true, lean_end == 1, true, true);
             if (out_of_budget) break;
         }
     }

@@ -128,3 +128,15 @@ def expand_constrained(flat, variables: list[StanVariable]) -> dict[str, np.ndar
         blk = fortran_to_c_order(flat[..., v.start:v.end], v.shape) if v.shape else flat[..., v.start:v.end]
         out[v.name] = blk.reshape(*flat.shape[:-1], *v.shape)
     return out
+
+
+def c_order_permutation(variables: list[StanVariable]) -> np.ndarray:
+    """``perm`` with ``out[j] = theta[perm[j]]``: BridgeStan's flat ``param_constrain`` output (every variable a column-major
+    block) -> the same vector with every block in C order.  This is what ``nphip_model_set_bridgestan_expand`` applies to each
+    draw natively (the reference: ``fortran_to_c_order`` per variable per draw, src/stan.rs:507-516, 671-711)."""
+    total = variables[-1].end if variables else 0
+    perm = np.arange(total, dtype=np.uint64)
+    for v in variables:
+        if len(v.shape) >= 2:
+            perm[v.start:v.end] = v.start + fortran_to_c_order(np.arange(v.end - v.start), v.shape).astype(np.uint64)
+    return perm

@@ -57,6 +57,8 @@ class Settings(C.Structure):
         ("adam", C.c_int32),
         ("crate_arithmetic", C.c_int32),
         ("adam_learning_rate", C.c_double),
+        ("store_divergences", C.c_int32),
+        ("reserved_", C.c_int32),
     ]
 
 
@@ -78,6 +80,10 @@ class _Trace(C.Structure):
         ("mean_tree_accept_sym", C.c_void_p),
         ("gradient", C.c_void_p),
         ("mass_matrix_inv", C.c_void_p),
+        ("divergence_start", C.c_void_p),
+        ("divergence_end", C.c_void_p),
+        ("divergence_momentum", C.c_void_p),
+        ("divergence_start_gradient", C.c_void_p),
     ]
 
 
@@ -180,6 +186,9 @@ def _alloc(s: Settings, dim: int):
         st["gradient"] = np.zeros((n, T, dim))
     if s.store_mass_matrix:
         st["mass_matrix_inv"] = np.zeros((n, T, dim))
+    if s.store_divergences:
+        for k in ("divergence_start", "divergence_end", "divergence_momentum", "divergence_start_gradient"):
+            st[k] = np.full((n, T, dim), np.nan)
     draws = np.zeros((n, T, dim))
     tr = _Trace()
     tr.draws = _p(draws)

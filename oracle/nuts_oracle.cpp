@@ -346,7 +346,15 @@ struct StatePool {
 };
 using StateP = std::shared_ptr<State>;
 
-struct DivergenceInfo { bool logp_error = false; double energy_error = NAN; };
+// What nuts-rs reports about a divergent transition: the state the failed leapfrog started from and — when the
+// divergence is an energy error, not a logp error — the position it ended at.  These feed the optional statistics
+// `divergence_start / _end / _momentum / _start_gradient` (python/nutpie/sample.py:631-650, docs/sample-stats.qmd:95-102).
+struct DivergenceInfo {
+    bool logp_error = false; double energy_error = NAN;
+    bool has_start = false, has_end = false;
+    std::vector<double> start_q, start_p, start_g, end_q;
+    void record_start(const State& s);
+};
 
 // AcceptanceRateCollector [A.6]: incremental running means over all leapfrogs of a draw.
 struct RunningMean {
@@ -379,6 +387,8 @@ struct Collector {
         mean_sym.add(2.0 * a / (1.0 + e));
     }
 };
+
+void DivergenceInfo::record_start(const State& s) { has_start = true; has_end = false; start_q = s.q; start_p = s.p; start_g = s.g; }
 
 enum class Leap { Ok, Diverge, Fatal };
 
@@ -425,6 +435,7 @@ struct Hamiltonian {
             // recoverable logp error => divergence (src/pymc.rs:166-180, src/stan.rs:392-396,459-461,
             // src/pyfunc.rs:100-116,218-220)
             info->logp_error = true;
+            info->record_start(s);
             if (col) col->register_leapfrog(o.get(), true);
             return Leap::Diverge;
         }
@@ -459,6 +470,9 @@ struct Hamiltonian {
         double de = o->energy_error();
         if (de > max_energy_error || !std::isfinite(de)) {
             info->energy_error = de;
+            info->record_start(s);
+            info->has_end = true;
+            info->end_q = o->q;
             if (col) col->register_leapfrog(o.get(), true);
             return Leap::Diverge;
         }
@@ -884,7 +898,7 @@ struct Chain {
     }
 
     // nuts::draw [A.2]
-    bool draw(uint64_t draw_idx, SampleInfo* info, StateP* out) {
+    bool draw(uint64_t draw_idx, SampleInfo* info, StateP* out, DivergenceInfo* div_out = nullptr) {
         StateP init = H.init_trajectory(*cur, S.seed, chain_id, (uint32_t)draw_idx, RNG_MOMENTUM);
         col.set_running((S.crate_arithmetic & 2) != 0);
         col.register_init();
@@ -903,7 +917,11 @@ struct Chain {
             ctx.check_turning = (S.check_turning != 0) && (tree.depth + 1 > S.mindepth);
             Ext e = tree.extend(H, dir, col, ctx, &dinfo);
             if (e == Ext::Fatal) return false;
-            if (e == Ext::Diverging) { info->depth = tree.depth; info->diverging = true; *out = tree.draw; return true; }
+            if (e == Ext::Diverging) {
+                info->depth = tree.depth; info->diverging = true; *out = tree.draw;
+                if (div_out) *div_out = std::move(dinfo);
+                return true;
+            }
             if (e == Ext::Turning) { info->depth = tree.depth; *out = tree.draw; return true; }
         }
         info->depth = tree.depth;
@@ -937,8 +955,8 @@ int run_sampler(const oracle_settings_t* S, uint64_t dim, MakeModel make_model, 
                 g_last_error = g_error; failed.store(1); return;
             }
             for (uint64_t d = 0; d < T; ++d) {
-                SampleInfo info; StateP st;
-                if (!chain.draw(d, &info, &st)) {
+                SampleInfo info; StateP st; DivergenceInfo dinfo;
+                if (!chain.draw(d, &info, &st, &dinfo)) {
                     std::lock_guard<std::mutex> lk(g_error_mutex);
                     g_last_error = g_error; failed.store(1); return;
                 }
@@ -957,6 +975,17 @@ int run_sampler(const oracle_settings_t* S, uint64_t dim, MakeModel make_model, 
                 if (out->draws) memcpy(out->draws + o * dim, st->q.data(), dim * sizeof(double));
                 if (out->gradient) memcpy(out->gradient + o * dim, st->g.data(), dim * sizeof(double));
                 if (out->mass_matrix_inv) memcpy(out->mass_matrix_inv + o * dim, chain.H.sig2.data(), dim * sizeof(double));
+                if (out->divergence_start) {
+                    // rows of draws that did not diverge stay NaN (python/nutpie/sample.py:631-650: the columns are nullable)
+                    double* rows[4] = {out->divergence_start, out->divergence_end, out->divergence_momentum, out->divergence_start_gradient};
+                    for (auto* r : rows) for (uint64_t i = 0; i < dim; ++i) r[o * dim + i] = NAN;
+                    if (info.diverging && dinfo.has_start) {
+                        memcpy(rows[0] + o * dim, dinfo.start_q.data(), dim * sizeof(double));
+                        if (dinfo.has_end) memcpy(rows[1] + o * dim, dinfo.end_q.data(), dim * sizeof(double));
+                        memcpy(rows[2] + o * dim, dinfo.start_p.data(), dim * sizeof(double));
+                        memcpy(rows[3] + o * dim, dinfo.start_g.data(), dim * sizeof(double));
+                    }
+                }
                 if (out->depth) out->depth[o] = (int64_t)info.depth;
                 if (out->n_steps) out->n_steps[o] = (int64_t)n_steps;
                 if (out->index_in_trajectory) out->index_in_trajectory[o] = idx;

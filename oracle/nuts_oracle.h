@@ -109,6 +109,8 @@ typedef struct {
      *        draw 36 of the fifth.  tests/test_oracle_kat.py pins both statements. */
     int32_t crate_arithmetic;
     double adam_learning_rate;
+    int32_t store_divergences;
+    int32_t reserved_;
 } oracle_settings_t;
 
 typedef struct {
@@ -129,6 +131,12 @@ typedef struct {
     double* mean_tree_accept_sym;
     double* gradient;         /* [chains][T][dim] or NULL */
     double* mass_matrix_inv;  /* [chains][T][dim] or NULL */
+    /* store_divergences (python/nutpie/sample.py:631-650): all four [chains][T][dim] or all NULL; rows of draws that did not
+     * diverge are NaN; divergence_end is NaN too when the divergence was a logp error rather than an energy error */
+    double* divergence_start;
+    double* divergence_end;
+    double* divergence_momentum;
+    double* divergence_start_gradient;
 } oracle_trace_t;
 
 void oracle_default_settings(oracle_settings_t* s);

@@ -59,6 +59,47 @@ def fixture_lib():
 
 
 @pytest.fixture(scope="session")
+def bs_standin():
+    """gcc-built stand-in for a BridgeStan model library (tests/fixtures/bs_standin.c): BridgeStan's C API for the Stan program
+    of the reference's golden-vector test and for a matrix-valued model, plus the same density as raw C callbacks."""
+    src = os.path.join(FIXTURES, "bs_standin.c")
+    out = os.path.join(FIXTURES, "libbs_standin.so")
+    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        subprocess.run(["gcc", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-o", out, src, "-lm"], check=True)
+    lib = ctypes.CDLL(out)
+    lib.bs_model_construct.restype = ctypes.c_void_p
+    lib.bs_model_construct.argtypes = [ctypes.c_char_p, ctypes.c_uint, ctypes.c_void_p]
+    lib.bs_model_destruct.argtypes = [ctypes.c_void_p]
+    lib.bs_param_unc_num.argtypes = [ctypes.c_void_p]
+    lib.bs_param_num.argtypes = [ctypes.c_void_p, ctypes.c_bool, ctypes.c_bool]
+    lib.bs_param_names.argtypes = [ctypes.c_void_p, ctypes.c_bool, ctypes.c_bool]
+    lib.bs_param_names.restype = ctypes.c_char_p
+    lib.bs_rng_destruct.argtypes = [ctypes.c_void_p]
+    lib.bs_param_constrain.argtypes = [ctypes.c_void_p, ctypes.c_bool, ctypes.c_bool, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    lib.bs_log_density_gradient.argtypes = [ctypes.c_void_p, ctypes.c_bool, ctypes.c_bool, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    return lib
+
+
+class FakeBridgeStanModel:
+    """What ``bridgestan.StanModel`` offers to nutpie_amd.compile_stan (BridgeStan itself is not installable here): the loaded
+    library, the model handle, ``param_unc_num`` and ``param_names``."""
+
+    def __init__(self, lib, data: bytes):
+        self.stanlib = lib
+        self.model = ctypes.c_void_p(lib.bs_model_construct(data, 0, None))
+        assert self.model.value
+
+    def param_unc_num(self):
+        return self.stanlib.bs_param_unc_num(self.model)
+
+    def param_names(self, include_tp=False, include_gq=False):
+        return self.stanlib.bs_param_names(self.model, include_tp, include_gq).decode().split(",")
+
+    def __del__(self):
+        self.stanlib.bs_model_destruct(self.model)
+
+
+@pytest.fixture(scope="session")
 def hip():
     """The HIP engine binding; GPU tests fail (not skip) if the extension is missing."""
     from nutpie_amd import _lib

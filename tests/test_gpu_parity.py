@@ -49,9 +49,9 @@ def oracle_settings(oracle, *, chains, tune, draws, seed, W, init_kind=0, chain_
         elif k == "step_size_adapt_method":
             kw["fixed_step_size"] = 1
             kw["initial_step"] = float(v)
-        elif k in ("store_gradient", "store_mass_matrix"):
+        elif k in ("store_gradient", "store_mass_matrix", "store_divergences"):
             kw[k] = int(v)
-        elif k in ("store_divergences", "store_unconstrained"):
+        elif k == "store_unconstrained":
             continue
         else:
             kw[ORACLE_KEYS[k]] = int(v) if isinstance(v, bool) else v
@@ -228,6 +228,75 @@ def test_lean_register_kernels_variants(hip, oracle, dim, settings, launch, wave
     assert_trace_equal(got, want)
     if "store_gradient" in settings:
         assert np.array_equal(got.stats["gradient"], want.stats["gradient"])
+
+
+DIV_KEYS = ("divergence_start", "divergence_end", "divergence_momentum", "divergence_start_gradient")
+
+
+@pytest.mark.parametrize("dim,waves,launch", [
+    (3, 0, {}),                                          # register kernel, one chunk
+    (24, 0, dict(evals_per_launch=7)),                   # ... with launch boundaries inside doublings
+    (1000, 0, {}),                                       # the headline kernel (8 chunks per lane)
+    (1000, 0, dict(no_register_kernel=True)),            # memory-resident, cursor cached in VGPRs (keeps no gradient in a tree)
+    (300, 0, dict(no_register_kernel=True, no_stream_cache=True)),
+    (1300, 2, {}),                                       # register kernels with 2 / 4 waves per chain
+    (2600, 4, dict(evals_per_launch=9)),
+    (5000, 0, {}),                                       # lean register kernels, 4 / 8 waves per chain
+    (5000, 8, dict(evals_per_launch=11)),
+    (11000, 0, {}),                                      # memory-resident, 8 waves per chain
+])
+def test_divergence_records_bit_identical(hip, oracle, dim, waves, launch):
+    # store_divergences (python/nutpie/sample.py:631-650, tests/test_pymc.py:303-349): the state a failed leapfrog started from
+    # (position, momentum, gradient) and the position it ended at, every float against the oracle's — in every kernel family.
+    # The register kernels rebuild the pre-step state in the rare path (kernels.hip: replay_divergence).
+    model = ar1_gaussian(dim) if dim > 24 else None
+    args = (model.diag, model.offdiag) if model else (np.exp(np.random.default_rng(dim).normal(size=dim) * 1.5),)
+    kw = dict(chains=4 if dim <= 2600 else 3, tune=60 if dim <= 2600 else 40, draws=15 if dim <= 2600 else 8, seed=dim + 17)
+    settings = dict(store_divergences=True, max_energy_error=0.3 if dim <= 24 else 0.6)
+    got, W = run_engine(hip, hip.TridiagGaussianModel(*args), launch=launch, waves=waves, **kw, **settings)
+    want = oracle.sample_tridiag(oracle_settings(oracle, W=W, **kw, **settings), *args)
+    assert_trace_equal(got, want)
+    div = np.asarray(got.stats["diverging"]).astype(bool)
+    assert div.sum() >= 5, "the case is meant to diverge"
+    assert np.asarray(got.stats["depth"])[div].max() >= 2, "divergences deep inside a doubling are the point (leaves replayed)"
+    for k in DIV_KEYS:
+        a, b = got.stats[k], want.stats[k]
+        assert np.array_equal(np.isnan(a), np.isnan(b)), k
+        assert np.array_equal(a[~np.isnan(a)], b[~np.isnan(b)]), k
+        assert np.all(np.isnan(a[~div])), k
+    assert np.all(np.isfinite(got.stats["divergence_start"][div]))
+
+
+def test_divergence_records_host_callback_and_logp_errors(hip, oracle, fixture_lib):
+    # host C callback (launch per evaluation keeps the pre-step state in memory); a recoverable logp error diverges WITHOUT an
+    # end position (src/pymc.rs:166-180: code > 0): divergence_end stays NaN there, the other three are set
+    fn = fn_addr(fixture_lib.eight_schools_logp)
+    kw = dict(chains=8, tune=80, draws=40, seed=31)
+    settings = dict(store_divergences=True, max_energy_error=0.8)
+    got, W = run_engine(hip, hip.HostCallbackModel(10, fn), **kw, **settings)
+    want = oracle.sample_callback(oracle_settings(oracle, W=W, **kw, **settings), 10, fn)
+    assert_trace_equal(got, want)
+    assert got.stats["diverging"].sum() >= 5
+    for k in DIV_KEYS:
+        assert np.array_equal(got.stats[k], want.stats[k], equal_nan=True), k
+
+    def wall(x):   # a density with a wall: beyond it the callback reports a recoverable error
+        if x[0] > 1.0:
+            raise RecoverableError()
+        return -0.5 * float(x @ x), -x
+
+    class RecoverableError(Exception):
+        is_recoverable = True
+
+    kw = dict(chains=3, tune=40, draws=25, seed=8)
+    got, W = run_engine(hip, hip.HostCallbackModel(3, wall), store_divergences=True, **kw)
+    want = oracle.sample_callback(oracle_settings(oracle, W=W, store_divergences=True, **kw), 3, wall)
+    assert_trace_equal(got, want)
+    div = np.asarray(got.stats["diverging"]).astype(bool)
+    assert div.sum() >= 3
+    assert np.all(np.isnan(got.stats["divergence_end"][div])) and np.all(np.isfinite(got.stats["divergence_start"][div]))
+    for k in DIV_KEYS:
+        assert np.array_equal(got.stats[k], want.stats[k], equal_nan=True), k
 
 
 def test_lean_kernel_equals_streaming_kernel(hip):

@@ -223,9 +223,11 @@ def test_arviz_conversion_follows_the_installed_version(monkeypatch):
     assert out.posterior.x.shape == (1, 2, 1)
 
 
-def test_stan_expand_passes_an_rng(monkeypatch, tmp_path):
-    """BridgeStan >= 2 refuses include_gq=True without an rng; the reference passes model.new_rng(seed)
-    (src/stan.rs:476-492).  A stub bridgestan with that behaviour around a 2-parameter model."""
+def test_stan_model_shell_binds_once_and_expands_behind_the_c_abi(monkeypatch, tmp_path):
+    """The Stan front-end shell around a stub ``bridgestan``: the model is bound once (not per property access), names are parsed
+    into variables, and the expand step is NOT a Python loop any more — it runs behind the C-ABI
+    (nphip_model_set_bridgestan_expand: bs_param_constrain per draw with one bs_rng per chain, src/stan.rs:473-520, 787-796;
+    GPU tests: tests/test_gpu_reference_fixtures.py), so the shell only splits the flat C-order rows into variables."""
     import sys
     import types
 
@@ -239,35 +241,53 @@ def test_stan_expand_passes_an_rng(monkeypatch, tmp_path):
         def param_unc_num(self):
             return 2
 
-        def param_num(self, include_tp=False, include_gq=False):
-            return 2 + (1 if include_tp else 0) + (2 if include_gq else 0)
-
         def param_names(self, include_tp=False, include_gq=False):
-            return ["a", "b"] + (["t"] if include_tp else []) + (["g.1", "g.2"] if include_gq else [])
-
-        def new_rng(self, seed):
-            return ("rng", seed)
-
-        def param_constrain(self, theta, include_tp=False, include_gq=False, out=None, rng=None):
-            if include_gq and rng is None:
-                raise ValueError("Error: must provide rng if including generated quantities")
-            r = np.array([theta[0], np.exp(theta[1]), theta[0] + 1, rng[1], -rng[1]], dtype=float)
-            if out is not None:
-                out[:] = r
-                return out
-            return r
+            return ["a", "b"] + (["t"] if include_tp else []) + (["g.1.1", "g.2.1", "g.1.2", "g.2.2", "g.1.3", "g.2.3"] if include_gq else [])
 
     bs.StanModel = StanModel
     monkeypatch.setitem(sys.modules, "bridgestan", bs)
     from nutpie_amd.compile_stan import CompiledStanModel
+    from nutpie_amd.stan_names import c_order_permutation, expand_constrained
 
     m = CompiledStanModel(dims={}, code="", data=None, library="x.so", model=None, _coords={})
-    assert m.n_dim == 2 and m.shapes == {"a": (), "b": (), "t": (), "g": (2,)} and m.n_dim == 2
+    assert m.n_dim == 2 and m.shapes == {"a": (), "b": (), "t": (), "g": (2, 3)} and m.n_dim == 2
     assert made["models"] == 1                     # bound once, not per property access
-    draws = np.array([[[0.5, 0.0], [np.nan, np.nan]], [[1.0, 1.0], [2.0, 0.0]]])
-    ex = m._expand_draws(draws, seed=7)
-    assert ex["b"][0, 0] == 1.0 and np.isnan(ex["a"][0, 1]) and ex["t"][1, 1] == 3.0
-    assert ex["g"][0, 0].tolist() == [7, -7] and ex["g"][1, 0].tolist() == [8, -8]      # one rng per chain, from the seed
+    # what the native adapter does to a row (out[j] = theta[perm[j]]) followed by the shell's split == the reference's
+    # per-variable fortran_to_c_order (src/stan.rs:507-516, 671-711; restated vectorised in stan_names.expand_constrained)
+    rng = np.random.default_rng(0)
+    theta = rng.normal(size=(3, 4, 9))             # BridgeStan's flat rows: column-major blocks
+    perm = c_order_permutation(m._variables())
+    assert sorted(perm.tolist()) == list(range(9)) and perm[:3].tolist() == [0, 1, 2]
+    got = m._unflatten(theta[..., perm])
+    want = expand_constrained(theta, m._variables())
+    assert got.keys() == want.keys() and all(np.array_equal(got[k], want[k]) for k in got)
+    assert got["g"].shape == (3, 4, 2, 3) and got["g"][0, 0, 1, 2] == theta[0, 0, 3 + 1 + 2 * 2]
+    with pytest.raises(RuntimeError, match="behind the C-ABI"):
+        m._expand_draws(np.zeros((1, 1, 2)))
+
+
+def test_bridgestan_stand_in_speaks_the_c_api(bs_standin):
+    """The stand-in library the BridgeStan adapters are tested against (tests/fixtures/bs_standin.c) — no GPU involved:
+    names parse to the declared shapes and its column-major output re-orders to what the Stan program means."""
+    import ctypes as C
+
+    from nutpie_amd.stan_names import c_order_permutation, parse_stan_variables
+
+    h = C.c_void_p(bs_standin.bs_model_construct(b"matrix", 0, None))
+    assert bs_standin.bs_param_unc_num(h) == 6 and bs_standin.bs_param_num(h, True, True) == 13
+    variables = parse_stan_variables(bs_standin.bs_param_names(h, True, True).decode())
+    assert [(v.name, v.shape) for v in variables] == [("m", (2, 3)), ("mt", (3, 2)), ("s", ())]
+    bs_standin.bs_rng_construct.restype = C.c_void_p
+    rng = C.c_void_p(bs_standin.bs_rng_construct(3, None))
+    unc = (C.c_double * 6)(*range(1, 7))
+    out = (C.c_double * 13)()
+    assert bs_standin.bs_param_constrain(h, True, True, unc, out, rng, None) == 0
+    row = np.array(out[:])[c_order_permutation(variables)]
+    mm = row[:6].reshape(2, 3)
+    assert mm.tolist() == [[1, 3, 5], [2, 4, 6]] and np.array_equal(row[6:12].reshape(3, 2), mm.T)
+    assert bs_standin.bs_param_constrain(h, True, True, unc, out, None, None) == 1      # generated quantities need an rng
+    bs_standin.bs_rng_destruct(rng)
+    bs_standin.bs_model_destruct(h)
 
 
 def test_install_as_nutpie_alias():

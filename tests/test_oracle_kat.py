@@ -276,3 +276,37 @@ def test_crate_arithmetic_forms_give_the_same_decisions(oracle):
             np.testing.assert_allclose(run.stats["mean_tree_accept"], base.stats["mean_tree_accept"], rtol=1e-4, atol=1e-9)
     assert set(forks) <= {"ar1_d257"}, forks
 
+
+
+def test_divergence_records_are_the_failed_leapfrog(oracle):
+    # store_divergences (python/nutpie/sample.py:631-650): divergence_start / _momentum / _start_gradient are the state the
+    # failed leapfrog started from, divergence_end the position it reached.  Known answer: one leapfrog from the
+    # recorded start with the step size and mass matrix the draw ran with lands on the recorded end, bit for bit; the recorded
+    # gradient is the model's gradient at the recorded start; rows of draws that did not diverge are NaN.
+    diag = np.array([1.0, 100.0, 0.01])
+    s = oracle.default_settings(seed=5, num_chains=4, num_tune=150, num_draws=100, max_energy_error=0.3, store_divergences=1, store_mass_matrix=1)
+    tr = oracle.sample_tridiag(s, diag)
+    div = tr.stats["diverging"].astype(bool)
+    assert div.sum() > 20
+    start, end, mom, grad = (tr.stats[k] for k in ("divergence_start", "divergence_end", "divergence_momentum", "divergence_start_gradient"))
+    for a in (start, end, mom, grad):
+        assert np.all(np.isnan(a[~div])) and np.all(np.isfinite(a[div]))
+    assert np.array_equal(grad[div], -(diag * start[div]))
+    checked = 0
+    for c, d in zip(*np.nonzero(div)):
+        if d == 0:
+            continue   # (the first draw runs with the step size of the initial search, which is not in the trace)
+        # the statistics of draw d - 1 are written after its adaptation: they are what draw d ran with
+        step, sig2 = tr.stats["step_size"][c, d - 1], tr.stats["mass_matrix_inv"][c, d - 1]
+        ends = []
+        for eps in (step, -step):   # (extended precision stands in for the fused multiply-adds: compared to 1 ulp)
+            L = np.longdouble
+            ph = (L(0.5 * eps) * grad[c, d].astype(L) + mom[c, d].astype(L)).astype(np.float64)
+            ends.append((L(eps) * (sig2 * ph).astype(L) + start[c, d].astype(L)).astype(np.float64))
+        assert any(np.allclose(e, end[c, d], rtol=3e-16, atol=0) for e in ends), (c, d)
+        checked += 1
+    assert checked > 10
+    # the records do not change anything else: same trace without them
+    s0 = oracle.default_settings(seed=5, num_chains=4, num_tune=150, num_draws=100, max_energy_error=0.3)
+    tr0 = oracle.sample_tridiag(s0, diag)
+    assert np.array_equal(tr0.draws, tr.draws) and np.array_equal(tr0.stats["n_steps"], tr.stats["n_steps"])
