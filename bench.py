@@ -18,9 +18,17 @@ before the timed region.  Multi-GPU is weak scaling: 1024 chains per GPU, chain 
 no collective in the data path (only the timing all-reduce).
 
 Extra objects in the JSON line:
-  roofline      — algorithmic bytes (40 * D per leapfrog per chain: read q, p, sigma^2; write q', p';
-                  SURVEY.md §8d, fused analytic gradient) / mean k_advance duration from HIP events on the
-                  engine's stream, against the 8 TB/s HBM peak.
+  roofline      — what bounds the dominant kernel and how close it runs to that bound, with `frac` <= 1:
+                  * register-resident kernels (D <= 4096: the chain state stays in VGPRs / LDS, so the kernel moves LESS than the
+                    SURVEY.md §8d "algorithmic" 40 * D bytes per leapfrog and HBM is not its limit): `bound` = "issue" — one wave
+                    per SIMD issues at most one instruction every four cycles; `achieved` = wave-instructions per second
+                    (instructions per leapfrog from the committed PMC passes x leapfrogs per launch / mean k_advance duration
+                    from HIP events on the engine's stream), `peak` = resident waves x 2.4 GHz / 4;
+                  * the lean / memory-resident kernels (D > 4096): `bound` = "hbm", `achieved` = measured HBM bytes per launch
+                    (PMC) / the same duration, `peak` = 8 TB/s;
+                  in both cases `hbm_measured` is the PMC traffic against the 8 TB/s peak, `stream_equivalent` the §8d figure
+                  (40 * D bytes per leapfrog / kernel time: what a stream-everything kernel would have to move to keep up —
+                  it can exceed the peak and is NOT a fraction of anything), `traffic` the PMC bytes per launch.
   cpu_baseline  — the CPU oracle (oracle/, "port": the real nuts-rs cannot be built here) timed on this
                   box's host cores on a bounded sample of the same workload (rank 0, N=1 only);
   cpu_baseline_tuned — the same C++ sampler built for speed (AVX2 + FMA, free summation order): the honest
@@ -28,6 +36,8 @@ Extra objects in the JSON line:
   tuning_phase  — leapfrogs and kernel-time rate of the (untimed) warm-up that precedes the timed region.
   job           — the complete sampling job (tune 400 + draws 1000) wall time, total leapfrogs, min bulk
                   ESS over a subset of dimensions and ESS/s (the second half of BASELINE.json's metric).
+  ranks         — world size, backend, and per rank: device, leapfrogs and kernel time of the timed region (N > 1: what a
+                  scaling record is checked against).
 """
 from __future__ import annotations
 
@@ -43,9 +53,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
-# measured HBM bytes per leapfrog per kernel / dimension: profiles/traffic.json, written by profiles/make_traffic.py from the
-# committed rocprofv3 PMC summaries ((2 x FETCH_SIZE + WRITE_SIZE) KB per launch / leapfrogs per launch; gfx950 FETCH_SIZE
-# correction of MI355X_MICROARCH.md)
+CLOCK_HZ = 2.4e9       # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs at 2.4 GHz
+N_SIMD = 1024
+# One wave per SIMD (the register-resident kernels: the whole register file is one wave's) issues at most one instruction, of
+# any kind, per four cycles (MI355X_MICROARCH.md, "one wave per SIMD (512-register kernel)": issue slots of ~4 cycles).
+CYCLES_PER_ISSUE = 4.0
+# measured per-leapfrog HBM bytes and instruction counts per kernel / dimension: profiles/traffic.json, written by
+# profiles/make_traffic.py from the committed rocprofv3 PMC summaries of THIS command (timed configuration: sampling phase,
+# positions stored, the engine's default launch length; (2 x FETCH_SIZE + WRITE_SIZE) KB per launch / leapfrogs per launch —
+# gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md)
 TRAFFIC_JSON = os.path.join(ROOT, "profiles", "traffic.json")
 
 
@@ -163,14 +179,58 @@ def run_job(hip, model, args, device, chain_offset, dims_for_ess):
     }
 
 
-def measured_traffic(dim, W, lean):
-    """HBM bytes per leapfrog of the kernel that runs at this (dim, waves) from the committed PMC summaries, or None."""
+def pmc_entry(dim, W):
     try:
         table = json.load(open(TRAFFIC_JSON))
     except OSError:
-        return None, None
-    e = table.get(f"{dim}:{W}")
+        return None
+    return table.get(f"{dim}:{W}")
+
+
+def measured_traffic(dim, W, lean):
+    """HBM bytes per leapfrog of the kernel that runs at this (dim, waves) from the committed PMC summaries, or None."""
+    e = pmc_entry(dim, W)
     return (e["bytes_per_leapfrog"], e["source"]) if e else (None, None)
+
+
+def roofline(dim, W, chains, leap_per_launch, avg_kernel_s):
+    """The `roofline` object of the JSON line (module docstring).  Live: the kernel duration.  From profiles/: bytes and
+    instructions per leapfrog of this kernel at the timed configuration."""
+    e = pmc_entry(dim, W)
+    kname = kernel_name(dim, W)
+    stream_bpl = 40.0 * dim
+    stream = {"bytes_per_leapfrog": stream_bpl, "GB/s": stream_bpl * leap_per_launch / avg_kernel_s / 1e9,
+              "note": "SURVEY.md 8d 'algorithmic' bytes (read q, p, sigma^2; write q', p' every leapfrog) / kernel time: the rate a "
+                      "stream-everything kernel would need to keep up.  Not a fraction of a peak: a kernel that keeps the state on chip moves less"}
+    stream["over_hbm_peak"] = stream["GB/s"] / HBM_PEAK_GBS
+    out = {"kernel": kname, "avg_kernel_ms": 1000.0 * avg_kernel_s, "stream_equivalent": stream}
+    hbm = None
+    if e:
+        gbs = e["bytes_per_leapfrog"] * leap_per_launch / avg_kernel_s / 1e9
+        hbm = {"GB/s": gbs, "frac_of_peak": gbs / HBM_PEAK_GBS, "bytes_per_leapfrog": e["bytes_per_leapfrog"],
+               "over_algorithmic": e["bytes_per_leapfrog"] / stream_bpl, "source": e["source"], "pmc_config": e.get("config")}
+        out["traffic"] = e["bytes_per_leapfrog"] * leap_per_launch
+    else:
+        out["traffic"] = None
+    out["hbm_measured"] = hbm
+    register_resident = "lean" not in kname and "NV=0" not in kname
+    if register_resident and e and e.get("insts_per_leapfrog"):
+        ipl = e["insts_per_leapfrog"]["total"]
+        waves = min(chains * W, N_SIMD * 8)
+        peak = waves * CLOCK_HZ / CYCLES_PER_ISSUE / 1e9
+        ach = ipl * leap_per_launch / avg_kernel_s / 1e9
+        out.update({"bound": "issue", "achieved": ach, "peak": peak, "unit": "G wave-instructions/s", "frac": ach / peak,
+                    "issue": {"insts_per_leapfrog": e["insts_per_leapfrog"], "pmc_issuing_fraction_of_wave_cycles": e.get("issuing_fraction"),
+                              "pmc_waiting_fraction_of_wave_cycles": e.get("waiting_fraction"), "resident_waves": waves,
+                              "note": "one wave per SIMD: at most one instruction per 4 cycles per wave; achieved = PMC instructions per leapfrog x "
+                                      "leapfrogs per launch / kernel time (HIP events)"}})
+    elif hbm:
+        out.update({"bound": "hbm", "achieved": hbm["GB/s"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm["frac_of_peak"]})
+    else:
+        # no PMC summary committed for this (dim, waves): only the stream-equivalent rate is known; capped, and labelled as such
+        out.update({"bound": "hbm", "achieved": min(stream["GB/s"], HBM_PEAK_GBS), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": min(1.0, stream["over_hbm_peak"]), "note": "no PMC summary for this kernel in profiles/traffic.json: stream-equivalent rate, capped at the peak"})
+    return out
 
 
 def kernel_name(dim, W):
@@ -268,7 +328,12 @@ def main():
         raise SystemExit("bench.py: a chain ran out of draws inside the timed region — the measurement is invalid; use fewer --steps")
     elapsed = t1 - t0
     leap = float(n1 - n0)
+    per_rank = [{"rank": rank, "device": device, "leapfrogs": leap, "kernel_ms": kernel_ms, "elapsed_s": elapsed}]
     if dist is not None:
+        mine = torch.tensor([rank, device, leap, kernel_ms, elapsed], dtype=torch.float64, device="cuda")
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [{"rank": int(t[0]), "device": int(t[1]), "leapfrogs": float(t[2]), "kernel_ms": float(t[3]), "elapsed_s": float(t[4])} for t in allr]
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -279,11 +344,8 @@ def main():
     draws_stored = int(sum(p.finished_draws for p in prog)) if store else 0
     smp.close()
 
-    bytes_per_leapfrog = 40.0 * args.dim
     avg_kernel_s = kernel_ms / 1000.0 / K
     leap_per_launch = leap / world / K
-    achieved = bytes_per_leapfrog * leap_per_launch / avg_kernel_s / 1e9
-    traffic_bpl, traffic_src = measured_traffic(args.dim, W, None)
     out = {
         "metric": "leapfrog steps/sec (all chains)", "value": leap / elapsed, "unit": "leapfrog steps/s", "n_gpus": world,
         "steps": K, "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / K, "higher_is_better": True,
@@ -293,14 +355,11 @@ def main():
                    "evals_per_launch": E, "leapfrogs_per_step": leap / K, "phase": args.phase, "positions_stored": store,
                    "draws_finished_all_chains": draws_stored, "timed_region_s": elapsed,
                    "chains_tuning_at_start": int(tuning0), "chains_tuning_at_end": int(tuning1), "parallelism": f"chains{world}"},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": (traffic_bpl * leap_per_launch if traffic_bpl else None),
-                     "traffic_source": traffic_src, "traffic_bytes_per_leapfrog": traffic_bpl,
-                     "kernel": kernel_name(args.dim, W), "avg_kernel_ms": 1000.0 * avg_kernel_s,
-                     "algorithmic_bytes_per_leapfrog": bytes_per_leapfrog,
-                     "note": ("achieved = algorithmic bytes (40 B x dim per leapfrog: what a stream-everything kernel moves) / kernel time; "
-                              "traffic = HBM bytes actually moved (PMC).  A kernel that keeps the state on chip moves less than the "
-                              "algorithmic bytes, so frac can pass 1: it is then bound by instruction issue, not by HBM (DESIGN.md 4)")},
+        "roofline": roofline(args.dim, W, args.chains, leap_per_launch, avg_kernel_s),
+        "ranks": {"world": world, "backend": (dist.get_backend() if dist is not None else None),
+                  "collective_ranks": (dist.get_world_size() if dist is not None else 1), "per_rank": per_rank,
+                  "note": "chains sharded by global chain id (rank r owns chains [r * chains_per_gpu, (r + 1) * chains_per_gpu)); no data-path "
+                          "collective, only this report's gather and the timing all-reduce"},
     }
     if tuning_phase is not None:
         out["tuning_phase"] = tuning_phase

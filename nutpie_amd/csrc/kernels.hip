@@ -988,15 +988,95 @@ struct Machine {
         for (int k = 0; k < NVX; ++k) if (k < nk) { st2(pn, ridx(k), tp[k]); st2(rn, ridx(k), tr[k]); }
     }
 
+    // ---- control state of a run of tree leaves, in registers.
+    // With one wave per SIMD a dependent LDS round trip costs that wave ~100 cycles, and the control block lives in LDS: the leaf
+    // loop used to read and write some forty of its words per leaf (leaf counter, cursor, pending leapfrog, collector sums ...),
+    // and the Q-pool allocation walked the open sub-trees in a loop of dependent LDS reads.  During a run of leaves the words
+    // every leaf touches live here instead — uniform values, i.e. SGPRs — together with two bit masks that make the allocation
+    // three scalar instructions: the buffers pinned for the whole doubling (draw candidate, trajectory ends) and the buffers
+    // held by open sub-trees (maintained as sub-trees are merged and opened).  What only changes when a doubling completes
+    // (trajectory ends, candidate, main-tree weight, depth) stays in the control block.  Loaded when a run starts, written back
+    // before anything else looks at the control block (rare paths, launch boundary).  Same arithmetic in the same order.
+    struct Hot {
+        int32_t nleaf, depth, dir, idx_cur;
+        int32_t srcq, srcp, newq, newp;       // the pending leapfrog (in a tree: source = cursor, sign = dir)
+        int32_t n_steps, n_steps0;            // (n_steps0: the value loaded; total_steps advances by the difference)
+        int32_t end_newp;                     // P-slot of the leaf that completes the doubling
+        uint32_t used_base, sub_used, draw;
+        bool check;                           // U-turn criteria apply in this doubling
+        double step, H0, acc, acc_sym, max_ee;
+    };
+    static __device__ __forceinline__ int32_t rfl(int64_t v) { return __builtin_amdgcn_readfirstlane((int)v); }
+    static __device__ __forceinline__ double rfl_f64(double v) {
+        return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+    }
+    // what is fixed for the duration of a doubling (read from the control block when a run or a doubling starts)
+    __device__ __forceinline__ void hot_doubling(Hot& H) const {
+        const int db = H.dir > 0 ? 1 : 0;
+        H.used_base = (1u << rfl(c->cand_q)) | (1u << rfl(c->endq[0])) | (1u << rfl(c->endq[1]));
+        H.end_newp = slot_end(db, (int)(rfl(c->endpar[db]) ^ 1));
+        H.check = A.s.check_turning && ((int64_t)H.depth + 1 > A.s.mindepth);
+    }
+    __device__ __forceinline__ void hot_load(Hot& H) const {
+        H.nleaf = rfl(c->nleaf); H.depth = rfl(c->depth); H.dir = rfl(c->dir); H.idx_cur = rfl(c->idx_cur);
+        H.srcq = rfl(c->lf_srcq); H.srcp = rfl(c->lf_srcp); H.newq = rfl(c->lf_newq); H.newp = rfl(c->lf_newp);
+        H.n_steps = H.n_steps0 = rfl(c->n_steps); H.draw = (uint32_t)rfl(c->draw);
+        H.step = rfl_f64(c->step_size); H.H0 = rfl_f64(c->H0); H.acc = rfl_f64(c->acc_sum); H.acc_sym = rfl_f64(c->acc_sym_sum);
+        H.max_ee = A.s.max_energy_error;
+        hot_doubling(H);
+        H.sub_used = 0u;
+        for (uint32_t m = (uint32_t)H.nleaf & ((1u << kMaxDepthCap) - 1u); m != 0; m &= m - 1) H.sub_used |= 1u << rfl(c->sub_q[__builtin_ctz(m)]);
+    }
+    __device__ __forceinline__ void hot_save(Hot& H) {
+        c->nleaf = H.nleaf; c->dir = H.dir; c->idx_cur = H.idx_cur;
+        c->lf_srcq = H.srcq; c->lf_srcp = H.srcp; c->lf_newq = H.newq; c->lf_newp = H.newp; c->lf_sign = H.dir; c->eval_buf = H.newq;
+        c->curq = H.srcq; c->curp = H.srcp;
+        c->n_steps = H.n_steps; c->total_steps += (int64_t)(H.n_steps - H.n_steps0);
+        H.n_steps0 = H.n_steps;
+        c->acc_sum = H.acc; c->acc_sym_sum = H.acc_sym;
+    }
+    // the next leaf of the doubling (issue_leaf): P-slot by leaf number; Q-pool buffer = the first one that is neither pinned
+    // for the doubling, held by an open sub-tree nor the cursor
+    __device__ __forceinline__ void issue_leaf_hot(Hot& H) const {
+        const int32_t j = H.nleaf + 1, d = H.depth;
+        int32_t newp;
+        if (j == (1 << d)) newp = H.end_newp;
+        else if (j & 1) newp = (j == 1) ? slot_first(d) : slot_first(__builtin_ctz((unsigned)(j - 1)));
+        else newp = slot_last(__builtin_ctz((unsigned)j), A.cap);
+        H.newq = (int32_t)__builtin_ctz(~(H.used_base | H.sub_used | (1u << H.srcq)));
+        H.newp = newp;
+    }
+    // (the trajectory ends / depth of the finished doubling are in the control block by now)
+    __device__ __forceinline__ void start_doubling_hot(Hot& H) const {
+        nphip_u32x4 r = nphip_philox(A.s.seed, (uint32_t)H.depth, gchain, H.draw, NPHIP_RNG_DIRECTION);
+        H.dir = (r.v[0] & 1u) ? 1 : -1;
+        const int db = H.dir > 0 ? 1 : 0;
+        H.nleaf = 0;
+        H.srcq = rfl(c->endq[db]);
+        H.srcp = rfl(c->endp[db]);
+        H.idx_cur = rfl(H.dir > 0 ? c->idx_right : c->idx_left);
+        H.sub_used = 0u;
+        hot_doubling(H);
+        issue_leaf_hot(H);
+    }
+    __device__ __forceinline__ double merge_uniform_hot(const Hot& H, int32_t j, int32_t d, int32_t k, nphip_u32x4& blk, int32_t& blk_id) const {
+        const int32_t id = k >> 1;
+        if (blk_id != id) {
+            const uint32_t c3 = (uint32_t)NPHIP_RNG_MERGE | ((uint32_t)d << 8) | ((uint32_t)id << 16);
+            blk = nphip_philox(A.s.seed, (uint32_t)j, gchain, H.draw, c3);
+            blk_id = id;
+        }
+        return (k & 1) ? nphip_u01(blk.v[2], blk.v[3]) : nphip_u01(blk.v[0], blk.v[1]);
+    }
+
     // returns true when an out-of-line (rare) path ran
-    __device__ __forceinline__ bool leaf_reg(RegsT& X) {
+    __device__ __forceinline__ bool leaf_reg(RegsT& X, Hot& H) {
         constexpr int nk = NVX;  // the register kernels are instantiated per exact chunk count
-        const int64_t j = c->nleaf + 1, d = c->depth, dir = c->dir;
+        const int32_t j = H.nleaf + 1, d = H.depth, dir = H.dir;
         const int db = dir > 0 ? 1 : 0;
-        const int64_t near_idx = dir > 0 ? c->idx_right : c->idx_left;
-        const int64_t idx_new = c->idx_cur + dir;
-        const int64_t srcq = c->lf_srcq, srcp = c->lf_srcp, newq = c->lf_newq, newp = c->lf_newp;
-        const bool check = A.s.check_turning && (d + 1 > A.s.mindepth);
+        const int32_t idx_new = H.idx_cur + dir;
+        const int32_t srcq = H.srcq, srcp = H.srcp, newq = H.newq, newp = H.newp;
+        const bool check = H.check;
 #ifdef NPHIP_PROFILE
         const int64_t tp0 = (int64_t)__builtin_readcyclecounter();
 #endif
@@ -1022,7 +1102,7 @@ struct Machine {
         if (j == 1) { X.ring_leaf0 = -1; X.ring_leaf1 = -1; }
         NPHIP_PHASE_FENCE();
         // ---- leapfrog (model parameters from LDS, neighbours by DPP, level-0 criterion in the same pass)
-        const double eps = (double)c->lf_sign * c->step_size;
+        const double eps = (double)dir * H.step;
         const double h = 0.5 * eps;
         if (idx_new == -1) {  // first backward step: rho' = p'  (-0.0 + p == p exactly, also for signed zeros)
 #pragma unroll
@@ -1116,14 +1196,13 @@ struct Machine {
 #endif
         const double K = 0.5 * v4[0], lp = REMOTE ? lp_remote : 0.5 * v4[1];
         const bool turn0 = (v4[2] < 0.0) || (v4[3] < 0.0);
-        if (REMOTE && code_remote < 0) { X.dirty_qg = X.dirty_pr = false; finish_chain(PH_ERROR, CE_FATAL_LOGP); return true; }
+        if (REMOTE && code_remote < 0) { X.dirty_qg = X.dirty_pr = false; hot_save(H); finish_chain(PH_ERROR, CE_FATAL_LOGP); return true; }
         // ---- NutsTree::extend / merge_into, unrolled (same decisions as cont_tree)
-        c->nleaf += 1;
-        c->n_steps += 1;
-        c->total_steps += 1;
+        H.nleaf += 1;
+        H.n_steps += 1;
         const bool ok = isfinite(lp) && (!REMOTE || code_remote == 0);
-        const double Unew = -lp, E = K + Unew, dE = E - c->H0;
-        const bool diverged = !ok || (dE > A.s.max_energy_error) || !isfinite(dE);
+        const double Unew = -lp, E = K + Unew, dE = E - H.H0;
+        const bool diverged = !ok || (dE > H.max_ee) || !isfinite(dE);
         double T_wm = 1.0;
         int64_t T_we = 0;
         {
@@ -1135,11 +1214,11 @@ struct Machine {
                 T_we = (int64_t)kk;
                 const double e = nphip_exp_scale(x, T_wm, kk);
                 const double a = e < 1.0 ? e : 1.0;
-                c->acc_sum += a;
-                c->acc_sym_sum += 2.0 * a / (1.0 + e);
+                H.acc += a;
+                H.acc_sym += 2.0 * a / (1.0 + e);
             }
         }
-        if (diverged) { X.dirty_qg = X.dirty_pr = false; rare_end_draw(A, c, red, chain, true, false, FUSED, ok, !REMOTE, FUSED); return true; }
+        if (diverged) { X.dirty_qg = X.dirty_pr = false; hot_save(H); rare_end_draw(A, c, red, chain, true, false, FUSED, ok, !REMOTE, FUSED); return true; }
 #ifdef NPHIP_PROFILE
         int64_t tq = (int64_t)__builtin_readcyclecounter();
         c->prof[8] += tq - tp2;
@@ -1148,18 +1227,18 @@ struct Machine {
         NPHIP_PHASE_FENCE();
         double T_U = Unew, T_E = E;
         nphip_u32x4 mrg_blk = {{0u, 0u, 0u, 0u}};
-        int64_t mrg_id = -1;
-        int64_t T_q = newq, T_idx = idx_new;
-        c->curq = newq; c->curp = newp; c->idx_cur = idx_new;
+        int32_t mrg_id = -1;
+        int32_t T_q = newq, T_idx = idx_new;
+        H.srcq = newq; H.srcp = newp; H.idx_cur = idx_new;   // the cursor moves to the new leaf
         double2 obp[NVX], obr[NVX];  // one operand buffer (A.first, then A.last of the merge being checked)
-        int64_t k = 0;
+        int32_t k = 0;
         while (k < d && (((j - 1) >> k) & 1)) {
             if (check) {
                 bool turn;
                 if (k == 0) {
                     turn = turn0;
                 } else {
-                    const int64_t a = j - (2ll << k) + 1, al = j - (1ll << k);
+                    const int32_t a = j - (2 << k) + 1, al = j - (1 << k);
                     // A.first
                     if (k == 1 && X.ring_leaf0 == a) ring_read(0, obp, obr);
                     else load_slot(first_slot_of(a, d), obp, obr);
@@ -1176,11 +1255,11 @@ struct Machine {
                     }
                     if (!turn) {
                         if (k == 1 && X.ring_leaf1 == al) ring_read(1, obp, obr);
-                        else load_slot(slot_last(__builtin_ctzll((unsigned long long)al), A.cap), obp, obr);
+                        else load_slot(slot_last(__builtin_ctz((unsigned)al), A.cap), obp, obr);
                         turn = sub_b(X, obp, obr);
                     }
                 }
-                if (turn) { X.dirty_qg = X.dirty_pr = false; rare_end_draw(A, c, red, chain, false, false, false, false, !REMOTE); return true; }
+                if (turn) { X.dirty_qg = X.dirty_pr = false; hot_save(H); rare_end_draw(A, c, red, chain, false, false, false, false, !REMOTE); return true; }
             }
 #ifdef NPHIP_PROFILE
             { const int64_t t_ = (int64_t)__builtin_readcyclecounter(); c->prof[k == 0 ? 9 : 10] += t_ - tq; tq = t_; }
@@ -1188,9 +1267,12 @@ struct Machine {
             NPHIP_PHASE_FENCE();
             {   // multinomial merge: keep T's draw w.p. w_T / (w_A + w_T)
                 double sm; int64_t se;
+                // (the merged sub-tree's buffer is free again unless its draw survives as T's: set below)
+                const int32_t A_q = rfl(c->sub_q[k]);
+                H.sub_used &= ~(1u << A_q);
                 nphip_w_add(c->sub_wm[k], c->sub_we[k], T_wm, T_we, &sm, &se);
-                const bool take = merge_uniform(j, d, k, mrg_blk, mrg_id) * sm < nphip_w_rel(T_wm, T_we, se);
-                if (!take) { T_q = c->sub_q[k]; T_U = c->sub_U[k]; T_E = c->sub_E[k]; T_idx = c->sub_idx[k]; }
+                const bool take = merge_uniform_hot(H, j, d, k, mrg_blk, mrg_id) * sm < nphip_w_rel(T_wm, T_we, se);
+                if (!take) { T_q = A_q; T_U = c->sub_U[k]; T_E = c->sub_E[k]; T_idx = rfl(c->sub_idx[k]); }
                 T_wm = sm; T_we = se;
             }
             NPHIP_PHASE_FENCE();
@@ -1201,13 +1283,14 @@ struct Machine {
         }
         if (k < d) {
             c->sub_wm[k] = T_wm; c->sub_we[k] = T_we; c->sub_q[k] = T_q; c->sub_U[k] = T_U; c->sub_E[k] = T_E; c->sub_idx[k] = T_idx;
+            H.sub_used |= 1u << T_q;
             // ---- stores, last: q when the leaf is referenced as a candidate; (p, rho) only for leaves a level >= 2
             // merge reads back from HBM (leaf % 4 == 0: A.last, leaf % 8 == 1: A.first)
 #ifdef NPHIP_PROFILE
             const int64_t tp3 = (int64_t)__builtin_readcyclecounter();
 #endif
             store_state(X, T_q == newq, ((j & 3) == 0) || ((j & 7) == 1));
-            issue_leaf();
+            issue_leaf_hot(H);
 #ifdef NPHIP_PROFILE
             c->prof[7] += (int64_t)__builtin_readcyclecounter() - tp3;
 #endif
@@ -1216,7 +1299,8 @@ struct Machine {
         // ---- the new sub-tree of depth d is complete (j == 2^d): merge into the main tree (general index modes)
         bool turn = false;
         if (check) {
-            const int64_t far_slot = c->endp[1 - db], far_idx = dir > 0 ? c->idx_left : c->idx_right;
+            const int32_t far_slot = rfl(c->endp[1 - db]), far_idx = rfl(dir > 0 ? c->idx_left : c->idx_right);
+            const int32_t near_idx = rfl(dir > 0 ? c->idx_right : c->idx_left);
             if (d == 0) {
                 // both ends are the origin = the source of this leapfrog, and rho_0 == p_0
                 turn = check1(X, pold, pold, far_idx, idx_new);
@@ -1229,7 +1313,7 @@ struct Machine {
                 load_slot(far_slot, obp, obr);
                 turn = check_a(X, obp, obr, pold, rold, far_idx, near_idx + dir, idx_new);   // (far, TL) || (far, TF)
                 if (!turn) {
-                    load_slot(c->endp[db], obp, obr);
+                    load_slot(rfl(c->endp[db]), obp, obr);
                     turn = check1(X, obp, obr, near_idx, idx_new);                           // (near, TL)
                 }
             }
@@ -1244,15 +1328,16 @@ struct Machine {
             nphip_w_add(c->main_wm, c->main_we, T_wm, T_we, &sm, &se);
             const double ref = nphip_w_rel(c->main_wm, c->main_we, se), oth = nphip_w_rel(T_wm, T_we, se);
             bool take = oth >= ref;
-            if (!take) take = merge_uniform(j, d, d, mrg_blk, mrg_id) * ref < oth;
+            if (!take) take = merge_uniform_hot(H, j, d, d, mrg_blk, mrg_id) * ref < oth;
             if (take) { c->cand_q = T_q; c->cand_U = T_U; c->cand_E = T_E; c->cand_idx = T_idx; }
             c->main_wm = sm; c->main_we = se;
+            H.depth = d + 1;
             c->depth = d + 1;
         }
         store_state(X, true, true);  // a new trajectory end is always written back
-        if (turn) { rare_end_draw(A, c, red, chain, false, false, false, false, !REMOTE); return true; }
-        if (c->depth >= A.s.maxdepth) { rare_end_draw(A, c, red, chain, false, true, false, false, !REMOTE); return true; }
-        start_doubling();
+        if (turn) { hot_save(H); rare_end_draw(A, c, red, chain, false, false, false, false, !REMOTE); return true; }
+        if (H.depth >= A.s.maxdepth) { hot_save(H); rare_end_draw(A, c, red, chain, false, true, false, false, !REMOTE); return true; }
+        start_doubling_hot(H);
         return false;
     }
 
@@ -2370,6 +2455,9 @@ struct Machine {
             // the run: a rare (non-inlined) path ends it, so nothing has to be kept alive across those calls.
             RegsT X;
             SCacheT Y;
+            Hot H;        // register-resident kernels (leaf_reg): the control words of the leaf loop
+            constexpr bool HOT = NV > 0 && !LEAN;
+            if (HOT) hot_load(H);
             bool rare = false, out_of_budget = false;
             int lean_end = 0;
             const LeanRs lrs = lean_rs();
@@ -2386,7 +2474,7 @@ struct Machine {
 #endif
                 if (NV > 0) {
                     if (LEAN) { lean_end = leaf_lean(lrs, X); rare = lean_end != 0; }
-                    else rare = leaf_reg(X);
+                    else rare = leaf_reg(X, H);
                 } else {
                     double lp = 0.0;
                     int64_t code = 0;
@@ -2417,9 +2505,12 @@ struct Machine {
                     break;
                 }
             }
-            if (!rare) flush(X);  // launch boundary: registers (and the LDS slot) that hold the only copy of tree state go back to HBM
+            if (!rare) {   // launch boundary: registers (and the LDS slot) that hold the only copy of tree state go back to memory
+                if (HOT) hot_save(H);
+                flush(X);
+            }
             sig_lds = nullptr;
-            if (LEAN && lean_end != 0) rare_end_draw(A, c, red, chain, lean_end == 1 || lean_end == 4, lean_end == 3, true, lean_end == 1, true, true);
+            if (LEAN && lean_end != 0) rare_end_draw(A, c, red, chain, lean_end == 1 || lean_end == 4, lean_end == 3, lean_end == 1 || lean_end == 4, lean_end == 1, true, true);
             if (out_of_budget) break;
         }
     }

@@ -1,12 +1,15 @@
 """Summarise rocprofv3 --pmc passes (rocpd sqlite files) for the k_advance kernel: mean per dispatch.
-usage: python profiles/pmc_summary.py gpurun_out/pmc_<tag>/ [skip_first_n_dispatches]"""
+usage: python profiles/pmc_summary.py gpurun_out/pmc_<tag>/ [skip_first_n_dispatches | -last_n_dispatches]
+A negative second argument keeps only the LAST n dispatches of the kernel — the timed region of bench.py (its K timed launches
+come last: warm-up of the chains, W warm launches, K timed launches)."""
 import glob
 import sqlite3
 import sys
 
 d = sys.argv[1]
 skip = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-print(f"# PMC counters for k_advance dispatches in {d} (mean per dispatch, first {skip} dispatches skipped)")
+which = f"the last {-skip} dispatches" if skip < 0 else f"first {skip} dispatches skipped"
+print(f"# PMC counters for k_advance dispatches in {d} (mean per dispatch, {which})")
 for f in sorted(glob.glob(d + "/*_results.db")):
     db = sqlite3.connect(f)
     cur = db.cursor()
@@ -20,7 +23,7 @@ for f in sorted(glob.glob(d + "/*_results.db")):
         agg.setdefault(r[ic], {}).setdefault(r[idp], 0.0)
         agg[r[ic]][r[idp]] += r[iv]
     for name, per in agg.items():
-        ids = sorted(per)[skip:]
+        ids = sorted(per)[skip:] if skip >= 0 else sorted(per)[skip:]
         vals = [per[i] for i in ids]
         if vals:
             print(f"{name:28s} n={len(vals):4d} mean={sum(vals)/len(vals):.6g}")

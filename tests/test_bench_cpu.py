@@ -50,6 +50,27 @@ def test_traffic_table_matches_the_committed_pmc_summaries():
     assert bench.kernel_name(1000, 1) == "k_advance<fused,W=1,NV=8>" and "lean" in bench.kernel_name(10000, 4)
 
 
+def test_roofline_object_is_a_fraction_of_the_binding_resource():
+    """`frac` must be a fraction of something.  The register-resident kernel keeps the state on chip (it moves
+    about half of the 40 * D "stream everything" bytes) and is bound by instruction issue with one wave per SIMD; the lean kernel
+    at D = 10 000 is bound by HBM.  Recomputed here from the committed PMC summaries at round 2's measured kernel times."""
+    import bench
+
+    r = bench.roofline(1000, 1, 1024, 1024 * 2048, 9.866e-3)       # BENCH_r02: 9.866 ms per launch of 2 097 152 leapfrogs
+    assert r["bound"] == "issue" and r["unit"] == "G wave-instructions/s"
+    assert 0.3 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["peak"] == 1024 * 2.4e9 / 4 / 1e9
+    assert 0.3 < r["hbm_measured"]["frac_of_peak"] < 1.0 and r["hbm_measured"]["over_algorithmic"] < 1.0
+    assert r["stream_equivalent"]["over_hbm_peak"] > 1.0          # the figure round 2 reported as `frac`: not a fraction
+    assert r["traffic"] == r["hbm_measured"]["bytes_per_leapfrog"] * 1024 * 2048
+    assert abs(r["issue"]["insts_per_leapfrog"]["total"] - sum(v for k, v in r["issue"]["insts_per_leapfrog"].items() if k != "total")) < 1e-6
+    h = bench.roofline(10000, 4, 1024, 1024 * 512, 37.02e-3)       # r2_bench_d10000_final: 37.02 ms per launch of 524 288 leapfrogs
+    assert h["bound"] == "hbm" and h["unit"] == "GB/s" and 0.5 < h["frac"] <= 1.0
+    assert h["frac"] == h["hbm_measured"]["frac_of_peak"] and h["hbm_measured"]["over_algorithmic"] > 1.0
+    u = bench.roofline(777, 1, 1024, 1024 * 2048, 5e-3)            # no PMC summary for this kernel: labelled, and capped
+    assert u["frac"] <= 1.0 and u["traffic"] is None and "no PMC summary" in u["note"]
+
+
 def test_bench_refuses_to_run_without_a_gpu():
     import subprocess
 
