@@ -1069,6 +1069,19 @@ struct Machine {
         return (k & 1) ? nphip_u01(blk.v[2], blk.v[3]) : nphip_u01(blk.v[0], blk.v[1]);
     }
 
+    // multinomial merge of the waiting sub-tree of level k into T: keep T's draw w.p. w_T / (w_A + w_T)
+    __device__ __forceinline__ void merge_level(Hot& H, int32_t j, int32_t d, int32_t k, nphip_u32x4& blk, int32_t& blk_id, double& T_wm, int64_t& T_we,
+                                                int32_t& T_q, double& T_U, double& T_E, int32_t& T_idx) {
+        double sm; int64_t se;
+        // (the merged sub-tree's buffer is free again unless its draw survives as T's: the caller sets T's bit when it stores T)
+        const int32_t A_q = rfl(c->sub_q[k]);
+        H.sub_used &= ~(1u << A_q);
+        nphip_w_add(c->sub_wm[k], c->sub_we[k], T_wm, T_we, &sm, &se);
+        const bool take = merge_uniform_hot(H, j, d, k, blk, blk_id) * sm < nphip_w_rel(T_wm, T_we, se);
+        if (!take) { T_q = A_q; T_U = c->sub_U[k]; T_E = c->sub_E[k]; T_idx = rfl(c->sub_idx[k]); }
+        T_wm = sm; T_we = se;
+    }
+
     // returns true when an out-of-line (rare) path ran
     __device__ __forceinline__ bool leaf_reg(RegsT& X, Hot& H) {
         constexpr int nk = NVX;  // the register kernels are instantiated per exact chunk count
@@ -1205,6 +1218,8 @@ struct Machine {
         const bool diverged = !ok || (dE > H.max_ee) || !isfinite(dE);
         double T_wm = 1.0;
         int64_t T_we = 0;
+        nphip_u32x4 mrg_blk = {{0u, 0u, 0u, 0u}};
+        int32_t mrg_id = -1;
         {
             if (!diverged) {
                 // one exp serves the collector and the leaf's multinomial weight (its (p, k) parts)
@@ -1226,8 +1241,6 @@ struct Machine {
 
         NPHIP_PHASE_FENCE();
         double T_U = Unew, T_E = E;
-        nphip_u32x4 mrg_blk = {{0u, 0u, 0u, 0u}};
-        int32_t mrg_id = -1;
         int32_t T_q = newq, T_idx = idx_new;
         H.srcq = newq; H.srcp = newp; H.idx_cur = idx_new;   // the cursor moves to the new leaf
         double2 obp[NVX], obr[NVX];  // one operand buffer (A.first, then A.last of the merge being checked)
@@ -1265,16 +1278,7 @@ struct Machine {
             { const int64_t t_ = (int64_t)__builtin_readcyclecounter(); c->prof[k == 0 ? 9 : 10] += t_ - tq; tq = t_; }
 #endif
             NPHIP_PHASE_FENCE();
-            {   // multinomial merge: keep T's draw w.p. w_T / (w_A + w_T)
-                double sm; int64_t se;
-                // (the merged sub-tree's buffer is free again unless its draw survives as T's: set below)
-                const int32_t A_q = rfl(c->sub_q[k]);
-                H.sub_used &= ~(1u << A_q);
-                nphip_w_add(c->sub_wm[k], c->sub_we[k], T_wm, T_we, &sm, &se);
-                const bool take = merge_uniform_hot(H, j, d, k, mrg_blk, mrg_id) * sm < nphip_w_rel(T_wm, T_we, se);
-                if (!take) { T_q = A_q; T_U = c->sub_U[k]; T_E = c->sub_E[k]; T_idx = rfl(c->sub_idx[k]); }
-                T_wm = sm; T_we = se;
-            }
+            merge_level(H, j, d, k, mrg_blk, mrg_id, T_wm, T_we, T_q, T_U, T_E, T_idx);
             NPHIP_PHASE_FENCE();
 #ifdef NPHIP_PROFILE
             { const int64_t t_ = (int64_t)__builtin_readcyclecounter(); c->prof[11] += t_ - tq; tq = t_; }
@@ -1713,13 +1717,12 @@ struct Machine {
 
     // returns 0 (next leaf) or an end code; the caller runs the out-of-line draw end AFTER the register state is dead:
     // 1 diverged (energy error), 2 U-turn, 3 maximum depth, 4 diverged (logp not finite: no end position to report)
-    __device__ __forceinline__ int leaf_lean(const LeanRs& rs, RegsT& X) {
-        const int64_t j = c->nleaf + 1, d = c->depth, dir = c->dir;
+    __device__ __forceinline__ int leaf_lean(const LeanRs& rs, RegsT& X, Hot& H) {
+        const int32_t j = H.nleaf + 1, d = H.depth, dir = H.dir;
         const int db = dir > 0 ? 1 : 0;
-        const int64_t near_idx = dir > 0 ? c->idx_right : c->idx_left;
-        const int64_t idx_new = c->idx_cur + dir;
-        const int64_t srcq = c->lf_srcq, srcp = c->lf_srcp, newq = c->lf_newq, newp = c->lf_newp;
-        const bool check = A.s.check_turning && (d + 1 > A.s.mindepth);
+        const int32_t idx_new = H.idx_cur + dir;
+        const int32_t srcq = H.srcq, srcp = H.srcp, newq = H.newq, newp = H.newp;
+        const bool check = H.check;
 #ifdef NPHIP_PROFILE
         const int64_t tp0 = (int64_t)__builtin_readcyclecounter();
 #endif
@@ -1736,7 +1739,7 @@ struct Machine {
         }
         NPHIP_PHASE_FENCE();
         // ---- leapfrog, sweep 1: q' = q + eps sigma^2 (p + eps/2 g); publish the chunk-edge z'
-        const double eps = (double)c->lf_sign * c->step_size;
+        const double eps = (double)dir * H.step;
         const double h = 0.5 * eps;
         const bool first_back = (idx_new == -1);   // first backward step: rho' = p'  (-0.0 + p == p exactly, also for signed zeros)
         // (software pipeline: the L2 loads of chunk k + PFM are issued before chunk k is computed; the fence at the end of every
@@ -1779,12 +1782,11 @@ struct Machine {
         const double K = 0.5 * v4[0], lp = 0.5 * v4[1];
         const bool turn0 = (v4[2] < 0.0) || (v4[3] < 0.0);
         // ---- NutsTree::extend / merge_into, unrolled (same decisions as leaf_reg / cont_tree)
-        c->nleaf += 1;
-        c->n_steps += 1;
-        c->total_steps += 1;
+        H.nleaf += 1;
+        H.n_steps += 1;
         const bool ok = isfinite(lp);
-        const double Unew = -lp, E = K + Unew, dE = E - c->H0;
-        const bool diverged = !ok || (dE > A.s.max_energy_error) || !isfinite(dE);
+        const double Unew = -lp, E = K + Unew, dE = E - H.H0;
+        const bool diverged = !ok || (dE > H.max_ee) || !isfinite(dE);
         double T_wm = 1.0;
         int64_t T_we = 0;
         if (!diverged) {
@@ -1794,10 +1796,10 @@ struct Machine {
             T_we = (int64_t)kk;
             const double e = nphip_exp_scale(x, T_wm, kk);
             const double a = e < 1.0 ? e : 1.0;
-            c->acc_sum += a;
-            c->acc_sym_sum += 2.0 * a / (1.0 + e);
+            H.acc += a;
+            H.acc_sym += 2.0 * a / (1.0 + e);
         }
-        if (diverged) { X.dirty_qg = X.dirty_pr = false; return ok ? 1 : 4; }
+        if (diverged) { X.dirty_qg = X.dirty_pr = false; hot_save(H); return ok ? 1 : 4; }
 #ifdef NPHIP_PROFILE
         int64_t tq = (int64_t)__builtin_readcyclecounter();
         c->prof[8] += tq - tp2;
@@ -1805,37 +1807,31 @@ struct Machine {
         NPHIP_PHASE_FENCE();
         double T_U = Unew, T_E = E;
         nphip_u32x4 mrg_blk = {{0u, 0u, 0u, 0u}};
-        int64_t mrg_id = -1;
-        int64_t T_q = newq, T_idx = idx_new;
-        c->curq = newq; c->curp = newp; c->idx_cur = idx_new;
-        int64_t k = 0;
+        int32_t mrg_id = -1;
+        int32_t T_q = newq, T_idx = idx_new;
+        H.srcq = newq; H.srcp = newp; H.idx_cur = idx_new;   // the cursor moves to the new leaf
+        int32_t k = 0;
         while (k < d && (((j - 1) >> k) & 1)) {
             if (check) {
                 bool turn;
                 if (k == 0) {
                     turn = turn0;
                 } else {
-                    const int64_t a = j - (2ll << k) + 1, al = j - (1ll << k);
-                    const int64_t sAf = first_slot_of(a, d), sAl = slot_last(__builtin_ctzll((unsigned long long)al), A.cap);
+                    const int32_t a = j - (2 << k) + 1, al = j - (1 << k);
+                    const int64_t sAf = first_slot_of(a, d), sAl = slot_last(__builtin_ctz((unsigned)al), A.cap);
                     if (k == 1) {
                         if (LRING && X.ring_leaf1 == al) turn = (c->pre_turn != 0) | lean_pass2<true>(rs, X, sAf, sAl);
                         else turn = (c->pre_turn != 0) | lean_pass2<false>(rs, X, sAf, sAl);
                     }
                     else turn = lean_pass3(rs, X, sAf, sAl, first_slot_of(al + 1, d));
                 }
-                if (turn) { X.dirty_qg = X.dirty_pr = false; return 2; }
+                if (turn) { X.dirty_qg = X.dirty_pr = false; hot_save(H); return 2; }
             }
 #ifdef NPHIP_PROFILE
             { const int64_t t_ = (int64_t)__builtin_readcyclecounter(); c->prof[k == 0 ? 9 : 10] += t_ - tq; tq = t_; }
 #endif
             NPHIP_PHASE_FENCE();
-            {   // multinomial merge: keep T's draw w.p. w_T / (w_A + w_T)
-                double sm; int64_t se;
-                nphip_w_add(c->sub_wm[k], c->sub_we[k], T_wm, T_we, &sm, &se);
-                const bool take = merge_uniform(j, d, k, mrg_blk, mrg_id) * sm < nphip_w_rel(T_wm, T_we, se);
-                if (!take) { T_q = c->sub_q[k]; T_U = c->sub_U[k]; T_E = c->sub_E[k]; T_idx = c->sub_idx[k]; }
-                T_wm = sm; T_we = se;
-            }
+            merge_level(H, j, d, k, mrg_blk, mrg_id, T_wm, T_we, T_q, T_U, T_E, T_idx);
             NPHIP_PHASE_FENCE();
 #ifdef NPHIP_PROFILE
             { const int64_t t_ = (int64_t)__builtin_readcyclecounter(); c->prof[11] += t_ - tq; tq = t_; }
@@ -1844,6 +1840,7 @@ struct Machine {
         }
         if (k < d) {
             c->sub_wm[k] = T_wm; c->sub_we[k] = T_we; c->sub_q[k] = T_q; c->sub_U[k] = T_U; c->sub_E[k] = T_E; c->sub_idx[k] = T_idx;
+            H.sub_used |= 1u << T_q;
             // (A.first, T.first) of the level-1 merge the next leaf will check: this leaf IS that T.first
 #ifdef NPHIP_PROFILE
             const int64_t tp3 = (int64_t)__builtin_readcyclecounter();
@@ -1866,7 +1863,7 @@ struct Machine {
             } else {
                 lean_store(rs, X, T_q == newq, (j & 3) != 3);
             }
-            issue_leaf();
+            issue_leaf_hot(H);
 #ifdef NPHIP_PROFILE
             c->prof[7] += (int64_t)__builtin_readcyclecounter() - tp4;
 #endif
@@ -1875,8 +1872,9 @@ struct Machine {
         // ---- the new sub-tree of depth d is complete (j == 2^d): merge into the main tree (general index modes)
         bool turn = false;
         if (check) {
-            const int64_t far_slot = c->endp[1 - db], far_idx = dir > 0 ? c->idx_left : c->idx_right;
-            turn = lean_top(rs, X, d != 0, far_slot, c->endp[db], slot_first((int)d), pair_of(far_idx, idx_new), pair_of(far_idx, near_idx + dir),
+            const int32_t far_slot = rfl(c->endp[1 - db]), far_idx = rfl(dir > 0 ? c->idx_left : c->idx_right);
+            const int32_t near_idx = rfl(dir > 0 ? c->idx_right : c->idx_left);
+            turn = lean_top(rs, X, d != 0, far_slot, rfl(c->endp[db]), slot_first((int)d), pair_of(far_idx, idx_new), pair_of(far_idx, near_idx + dir),
                             pair_of(near_idx, idx_new));
         }
         c->endq[db] = newq;
@@ -1888,15 +1886,16 @@ struct Machine {
             nphip_w_add(c->main_wm, c->main_we, T_wm, T_we, &sm, &se);
             const double ref = nphip_w_rel(c->main_wm, c->main_we, se), oth = nphip_w_rel(T_wm, T_we, se);
             bool take = oth >= ref;
-            if (!take) take = merge_uniform(j, d, d, mrg_blk, mrg_id) * ref < oth;
+            if (!take) take = merge_uniform_hot(H, j, d, d, mrg_blk, mrg_id) * ref < oth;
             if (take) { c->cand_q = T_q; c->cand_U = T_U; c->cand_E = T_E; c->cand_idx = T_idx; }
             c->main_wm = sm; c->main_we = se;
+            H.depth = d + 1;
             c->depth = d + 1;
         }
         lean_store(rs, X, true, true);  // a new trajectory end is always written back
-        if (turn) return 2;
-        if (c->depth >= A.s.maxdepth) return 3;
-        start_doubling();
+        if (turn) { hot_save(H); return 2; }
+        if (H.depth >= A.s.maxdepth) { hot_save(H); return 3; }
+        start_doubling_hot(H);
         return 0;
     }
 
@@ -2456,7 +2455,7 @@ struct Machine {
             RegsT X;
             SCacheT Y;
             Hot H;        // register-resident kernels (leaf_reg): the control words of the leaf loop
-            constexpr bool HOT = NV > 0 && !LEAN;
+            constexpr bool HOT = NV > 0;
             if (HOT) hot_load(H);
             bool rare = false, out_of_budget = false;
             int lean_end = 0;
@@ -2473,7 +2472,7 @@ struct Machine {
                 const int64_t t0 = (int64_t)__builtin_readcyclecounter();
 #endif
                 if (NV > 0) {
-                    if (LEAN) { lean_end = leaf_lean(lrs, X); rare = lean_end != 0; }
+                    if (LEAN) { lean_end = leaf_lean(lrs, X, H); rare = lean_end != 0; }
                     else rare = leaf_reg(X, H);
                 } else {
                     double lp = 0.0;
@@ -2493,7 +2492,7 @@ struct Machine {
                 c->prof[3] += 1;
                 if (rare) { c->prof[2] += t2 - t0; c->prof[5] += 1; } else { c->prof[1] += t2 - t0; c->prof[4] += 1; }
 #endif
-                if (rare || c->phase != PH_TREE) break;
+                if (rare || (!HOT && c->phase != PH_TREE)) break;   // (leaf_reg leaves the tree only through a rare path)
                 // the next leaf of the run: same admission test as at the top of the outer loop
                 if (REMOTE) {
                     if (c->hs_last != 0) { out_of_budget = true; break; }
