@@ -13,7 +13,7 @@
  *   LogpFunc / RawLogpFunc  (src/pymc.rs:21-62)         nphip_model_host_callback
  *   ExpandFunc / RawExpandFunc (src/pymc.rs:31-37, 64-95, nphip_model_set_expand, nphip_sampler_copy_expanded
  *     217-286)
- *   PyModel  (src/pyfunc.rs:206-230, 517-570)           nphip_model_device_callback
+ *   PyModel  (src/pyfunc.rs:206-230, 517-570)           nphip_model_device_callback, nphip_model_jit_density
  *   StanModel::logp (src/stan.rs:454-463)               nphip_model_bridgestan (adapter onto the host-callback path)
  *   StanDensity::expand_vector (src/stan.rs:473-520)    nphip_model_set_bridgestan_expand
  *   nuts_rs::Sampler::new (src/wrapper.rs:977-1085)     nphip_sampler_create
@@ -114,6 +114,14 @@ nphip_model_t* nphip_model_device_callback(uint64_t dim, nphip_device_logp_fn fn
  * 459-461).  `log_density_gradient` / `free_error_msg` are the addresses of the BridgeStan C API
  * functions of the loaded model library (bridgestan.h), `bs_model` the model handle. */
 nphip_model_t* nphip_model_bridgestan(uint64_t dim, void* bs_model, void* log_density_gradient, void* free_error_msg, int n_threads);
+/* Runtime-compiled device density (the GPU form of a compiled model's logp function: compile_pymc.py:668-871 builds one per
+ * model; here the model is HIP source compiled at run time into its own instantiation of the engine's resident kernel —
+ * nutpie_amd/density.py).  `launch_fn` = address of `nphip_jit_launch` of the model's library, `nv` = its `nphip_jit_nv()`
+ * (chunks of 128 dimensions: dim <= 1024), `data_device` = the model's data block in device memory (borrowed),
+ * `lds_bytes_per_wave` = LDS scratch the density uses per chain.  The evaluation is a call in the middle of the
+ * register-resident leaf: no launch, no memory round trip for the chain state.  The same library exports the density as a
+ * batched device callback (`nphip_jit_logp`, an nphip_device_logp_fn) for everything the resident kernel does not cover. */
+nphip_model_t* nphip_model_jit_density(uint64_t dim, void* launch_fn, int nv, const void* data_device, uint64_t lds_bytes_per_wave);
 /* Initial positions: kind 0 = U(-2,2) (src/pyfunc.rs:540-544), 1 = N(0,1) (src/stan.rs:798-808),
  * 2 = explicit host array points[n_chains_total][dim] indexed by GLOBAL chain id
  * (src/pymc.rs:505-534 evaluates the user's init function per chain on the host). */

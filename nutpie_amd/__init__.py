@@ -11,6 +11,7 @@ from nutpie_amd._lib import __version__
 from nutpie_amd.compile_pymc import compile_pymc_model
 from nutpie_amd.compile_stan import compile_stan_model, prune_stan_cache
 from nutpie_amd.compiled_pyfunc import from_pyfunc, from_torch_density, from_torchfunc
+from nutpie_amd.density import from_density_source
 from nutpie_amd.gaussian import ar1_gaussian, dense_gaussian, diag_gaussian, std_normal
 from nutpie_amd.sample import CompiledModel, sample
 
@@ -52,6 +53,7 @@ __all__ = [
     "from_pyfunc",
     "from_torchfunc",
     "from_torch_density",
+    "from_density_source",
     "std_normal",
     "diag_gaussian",
     "ar1_gaussian",

@@ -171,6 +171,11 @@ struct Args {
     volatile unsigned long long* grp_go;    // pinned host [groups][8]: sequence number whose results are ready | kGoLast
     unsigned long long* grp_go_dev;         // device [groups][16] (a cache line each): [0] the same word, republished by the
                                             // group's last arriver; of group 0 also [1] roll-call verdict, [2] roll-call count
+    // runtime-compiled device densities (nphip_model_jit_density): the density is a device function compiled into its own
+    // instantiation of k_advance; an evaluation is a call in the middle of the register-resident leaf (kernels.hip: density_eval)
+    const void* dens_data;       // the model's data block (device memory; layout defined by the generated prelude of the density source)
+    int32_t dens_lds_doubles;    // LDS scratch per wave the density asked for, in doubles (dynamic LDS of the launch)
+    int32_t dens_pad_;
 };
 constexpr unsigned long long kGoLast = 1ull << 32;      // finish this evaluation's step, then leave the kernel at the boundary
 constexpr unsigned long long kGoSeqMask = 0xffffffffull;

@@ -296,8 +296,15 @@ struct BsExpand {
     std::vector<uint64_t> perm;   // out[j] = theta[perm[j]] (column-major blocks -> C order); empty = identity
 };
 
+// launcher of a runtime-compiled density's resident kernel (kernels.hip part 7: nphip_jit_launch)
+typedef int (*nphip_jit_launch_fn)(const Args* d_args, int max_evals, void* stream, const LaunchSlice* sl, uint64_t dyn_lds_bytes);
+
 struct nphip_model {
-    int kind = 0;  // 0 fused tridiag, 1 host callback, 2 device callback
+    int kind = 0;  // 0 fused tridiag, 1 host callback, 2 device callback, 3 runtime-compiled device density (resident kernel)
+    nphip_jit_launch_fn jit_launch = nullptr;
+    const void* jit_data = nullptr;
+    uint64_t jit_lds_bytes = 0;   // LDS scratch per wave
+    int jit_nv = 0;
     std::shared_ptr<BsAdapter> bs;
     std::shared_ptr<BsExpand> bs_expand;
     uint64_t dim = 0;
@@ -346,6 +353,27 @@ nphip_model_t* nphip_model_device_callback(uint64_t dim, nphip_device_logp_fn fn
     if (dim == 0 || !fn) { set_error("device callback model needs dim > 0 and a function"); return nullptr; }
     auto* m = new nphip_model();
     m->kind = 2; m->dim = dim; m->dev_fn = fn; m->user = user_data;
+    return m;
+}
+nphip_model_t* nphip_model_jit_density(uint64_t dim, void* launch_fn, int nv, const void* data_device, uint64_t lds_bytes_per_wave) {
+    if (dim == 0 || !launch_fn) { set_error("a runtime-compiled density needs dim > 0 and its launcher"); return nullptr; }
+    if (dim > 1024 || nv < 1 || nv > 8 || (uint64_t)nv * 128 < dim) {
+        set_error("the resident kernel of a runtime-compiled density holds up to 1024 dimensions (nv chunks of 128, nv = ceil(dim / 128)); "
+                  "larger models run through the batched device callback of the same library");
+        return nullptr;
+    }
+    if (lds_bytes_per_wave % 8 != 0) { set_error("LDS scratch per wave must be a multiple of 8 bytes"); return nullptr; }
+    // LDS of the launch: four chains per workgroup — control blocks, reduction scratch, the four rings (4 x 4 KB x nv each) and
+    // the density's scratch — must fit the CU's 160 KB
+    const uint64_t fixed = 4 * 1200 + 1024 + 4 * (uint64_t)nv * 4096 + 64;
+    if (fixed + 4 * lds_bytes_per_wave > 160 * 1024) {
+        set_error("LDS scratch of the density does not fit beside the kernel's own (" + std::to_string(fixed) + " bytes fixed, " +
+                  std::to_string(4 * lds_bytes_per_wave) + " requested for four chains, 163840 per CU)");
+        return nullptr;
+    }
+    auto* m = new nphip_model();
+    m->kind = 3; m->dim = dim; m->jit_launch = (nphip_jit_launch_fn)launch_fn; m->jit_nv = nv; m->jit_data = data_device;
+    m->jit_lds_bytes = lds_bytes_per_wave;
     return m;
 }
 int nphip_model_set_init(nphip_model_t* m, int kind, const double* points, uint64_t n_points) {
@@ -540,6 +568,7 @@ struct nphip_sampler {
     Args* d_args = nullptr;  // device copy, read by the kernels through the constant address space
     int W = 1;
     bool fused = true;
+    bool dens = false;   // runtime-compiled device density: the resident kernel of the model's own library, driven like a fused model
     bool zero_copy = false;  // host callbacks: staging buffers in pinned host memory, no copies
     uint64_t n = 0, T = 0, dim = 0;
     std::vector<void*> allocs;
@@ -712,7 +741,12 @@ bool nphip_sampler::setup() {
     n = launch.n_local_chains ? launch.n_local_chains : set.num_chains;
     T = set.num_tune + set.num_draws;
     fused = model.kind == 0;
-    W = launch.waves_per_chain ? launch.waves_per_chain : choose_waves(dim);
+    dens = model.kind == 3;
+    W = dens ? 1 : (launch.waves_per_chain ? launch.waves_per_chain : choose_waves(dim));
+    if (dens && set.store_divergences) {
+        set_error("store_divergences needs the pre-step state in memory: use the batched device callback of the density's library (launch per evaluation)");
+        return false;
+    }
     if (!(W == 1 || W == 2 || W == 4 || W == 8 || W == 16)) { set_error("waves_per_chain must be 1, 2, 4, 8 or 16"); return false; }
     if (n == 0 || dim == 0) { set_error("need at least one chain and one dimension"); return false; }
     if (launch.chain_offset + n > set.num_chains) {
@@ -838,6 +872,12 @@ bool nphip_sampler::setup() {
         if (launch.staging_q && launch.staging_grad && launch.staging_logp) {
             args.qeval = (double*)launch.staging_q; args.geval = (double*)launch.staging_grad; args.ueval = (double*)launch.staging_logp;
         } else if (!zero_copy && (!dalloc(&args.qeval, n * dim) || !dalloc(&args.geval, n * dim) || !dalloc(&args.ueval, n))) return false;
+        if (dens) {
+            args.dens_data = model.jit_data;
+            args.dens_lds_doubles = (int32_t)(model.jit_lds_bytes / 8);
+            args.reg_nv = model.jit_nv;
+            if ((int64_t)model.jit_nv * 128 != args.ld) { set_error("the density's library was compiled for another dimension (nv chunks)"); return false; }
+        }
         if (model.kind == 1) {
             if (!zero_copy && !dalloc(&args.ecode, n)) return false;
             if (!palloc(&h_q, n * dim) || !palloc(&h_g, n * dim) || !palloc(&h_u, n) || !palloc(&h_code, n)) return false;
@@ -952,7 +992,7 @@ std::string nphip_sampler::chain_error_message() {
 }
 
 bool nphip_sampler::launch_kernel(bool fused_, int have) {
-    args.max_evals = fused_ ? (launch.evals_per_launch > 0 ? launch.evals_per_launch : default_evals_per_launch(dim)) : 0;
+    args.max_evals = (fused_ || dens) ? (launch.evals_per_launch > 0 ? launch.evals_per_launch : default_evals_per_launch(dim)) : 0;
     args.have_result = have;
     if (kernel_ms_acc) {
         while (tev.size() < 2 * (timed_launches + 1)) {
@@ -962,7 +1002,13 @@ bool nphip_sampler::launch_kernel(bool fused_, int have) {
         }
         if (!hip_ok(hipEventRecord(tev[2 * timed_launches], stream), "hipEventRecord")) return false;
     }
-    if (!hip_ok(launch_advance(args, d_args, fused_, W, stream), "launch k_advance")) return false;
+    if (dens) {
+        LaunchSlice sl;
+        memset(&sl, 0, sizeof(sl));
+        sl.chain_lo = 0; sl.chain_n = (int)n; sl.grp = -1;
+        const int rc = model.jit_launch(d_args, args.max_evals, (void*)stream, &sl, 4 * model.jit_lds_bytes);
+        if (rc != 0) { set_error(std::string("launch of the runtime-compiled density kernel: ") + hipGetErrorString((hipError_t)rc)); return false; }
+    } else if (!hip_ok(launch_advance(args, d_args, fused_, W, stream), "launch k_advance")) return false;
     if (kernel_ms_acc) {
         if (!hip_ok(hipEventRecord(tev[2 * timed_launches + 1], stream), "hipEventRecord")) return false;
         timed_launches += 1;
@@ -982,7 +1028,7 @@ bool nphip_sampler::iteration_fused(bool& all_done) {
     const int slot = (int)(fused_k & 1);
     if (!ev_f[0] && (!hip_ok(hipEventCreateWithFlags(&ev_f[0], hipEventDisableTiming), "hipEventCreate") ||
                      !hip_ok(hipEventCreateWithFlags(&ev_f[1], hipEventDisableTiming), "hipEventCreate"))) return false;
-    if (!launch_kernel(true, 0)) return false;
+    if (!launch_kernel(!dens, 0)) return false;
     if (!hip_ok(hipMemcpyAsync(h_counters + 2 * slot, args.counters, 16, hipMemcpyDeviceToHost, stream), "copy counters")) return false;
     if (!hip_ok(hipEventRecord(ev_f[slot], stream), "hipEventRecord")) return false;
     fused_k += 1;
@@ -1386,7 +1432,7 @@ void nphip_sampler::run() {
         bool ok;
         {
             std::lock_guard<std::mutex> run_lk(mu_run);
-            ok = fused ? iteration_fused(all_done) : (remote ? iteration_remote(all_done) : (n_groups > 0 ? iteration_pipelined(all_done) : iteration_callback(all_done, have)));
+            ok = (fused || dens) ? iteration_fused(all_done) : (remote ? iteration_remote(all_done) : (n_groups > 0 ? iteration_pipelined(all_done) : iteration_callback(all_done, have)));
         }
         seconds.store(std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count());
         if (!ok) { fail(t_error); break; }
@@ -1459,13 +1505,13 @@ int nphip_sampler_step(nphip_sampler_t* s, uint64_t n_launches, double* kernel_m
     bool all_done = false, ok = true;
     auto t0 = std::chrono::steady_clock::now();
     for (uint64_t i = 0; i < n_launches && !all_done; ++i) {
-        ok = s->fused ? s->iteration_fused(all_done) : s->iteration_callback(all_done, s->manual_have);
+        ok = (s->fused || s->dens) ? s->iteration_fused(all_done) : s->iteration_callback(all_done, s->manual_have);
         if (!ok) break;
         if (launches_done) *launches_done += 1;
     }
     s->kernel_ms_acc = nullptr;
     if (ok) ok = hip_ok(hipStreamSynchronize(s->stream), "hipStreamSynchronize");
-    if (ok && s->fused && s->fused_k > 0 && !all_done) ok = s->check_counters((int)((s->fused_k - 1) & 1), all_done);   // (the last launch, too)
+    if (ok && (s->fused || s->dens) && s->fused_k > 0 && !all_done) ok = s->check_counters((int)((s->fused_k - 1) & 1), all_done);   // (the last launch, too)
     if (ok && kernel_ms) {
         for (size_t i = 0; i < s->timed_launches && ok; ++i) {
             float ms = 0.f;

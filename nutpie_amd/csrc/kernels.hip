@@ -32,6 +32,19 @@
 #define NPHIP_CONST
 #endif
 
+// Runtime-compiled device densities (nutpie_amd/density.py -> nphip_model_jit_density): this file is compiled once more, per
+// model, with -DNPHIP_JIT_DENSITY -DNPHIP_PART=7 behind a generated prelude that defines `struct NphipData` and
+//     __device__ double nphip_density(const NphipData& data, int dim, const double* x, double* grad, double* lds, int lane)
+// — evaluated by ONE converged wavefront: x[dim] is the position row (global memory), grad[dim] receives the gradient, `lds`
+// is the wave's private LDS scratch, the return value the log-density (the same in every lane; non-finite = a recoverable
+// error, src/pyfunc.rs:218-220).  The kernel built from it is the REMOTE machine — the register-resident leaf with the
+// evaluation as a call in its middle — with the host rendezvous replaced by that call.
+#ifdef NPHIP_JIT_DENSITY
+#define NPHIP_JIT 1
+#else
+#define NPHIP_JIT 0
+#endif
+
 namespace nphip {
 
 // ----------------------------------------------------------------------------------------
@@ -212,6 +225,8 @@ struct SCache {
 template <bool FUSED, int W, int NV = 0, bool LEAN = false, bool REMOTE = false>
 struct Machine {
     static constexpr bool INK = FUSED || REMOTE;   // evaluations happen inside the kernel: a launch runs many steps
+    static constexpr bool DENS = REMOTE && (NPHIP_JIT != 0);   // ... by calling the model's own device function (runtime-compiled density)
+    LdsDouble dens_lds = nullptr;   // DENS: this wave's LDS scratch for the density
     static constexpr int NVX = NV > 0 ? NV : 1;
     static constexpr int NSX = NV < 0 ? -NV : 1;   // NV = -NS: cache (sigma^2, grad, p, rho) of NS chunks per wave
     // kernel arguments, read through the constant address space: s_load into SGPRs (uniform), never flat
@@ -246,6 +261,10 @@ struct Machine {
         sig2 = a.sig2 + (size_t)ch * ld;
         est = a.est + (size_t)ch * 8 * ld;
         T = a.s.num_tune + a.s.num_draws;
+        if (DENS) {   // (also in the machines the rare paths rebuild: the density is evaluated there too — initial point, step-size search)
+            extern __shared__ __attribute__((aligned(16))) double s_dyn_dens[];
+            dens_lds = (LdsDouble)s_dyn_dens + (size_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * a.dens_lds_doubles;
+        }
     }
 
     __device__ __forceinline__ double* Q(int64_t b) const { return qp + (size_t)b * 2 * ld; }
@@ -436,9 +455,8 @@ struct Machine {
             lp = 0.5 * a;
             code = 0;
         } else {
-            if (REMOTE) remote_sync();
-            lp = A.ueval[chain];
-            code = A.ecode ? A.ecode[chain] : 0;
+            if (REMOTE) remote_eval(lp, code);
+            else { lp = A.ueval[chain]; code = A.ecode ? A.ecode[chain] : 0; }
             NPHIP_FOR_CHUNKS(i) st2(g, i, ld2_dense(A.geval + (size_t)chain * D, i, D));
         }
     }
@@ -498,6 +516,24 @@ struct Machine {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // system scope: no stale line of the staging rows survives
         c->hs_seq = (int64_t)(seq + 1u);
         if (go & kGoLast) c->hs_last = 1;
+    }
+
+    // One evaluation of a REMOTE machine at the position in this chain's staging row: (logp, code), gradient in the gradient row.
+    // Host callbacks: the rendezvous with the host.  Runtime-compiled densities: a call of the model's device function — the
+    // wave's own stores of the position are made visible to all of its lanes first, the density's stores of the gradient after.
+    __device__ __forceinline__ void remote_eval(double& lp, int64_t& code) {
+#if NPHIP_JIT
+        if (DENS) {
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            lp = nphip_density(*(const NphipData*)A.dens_data, (int)D, A.qeval + (size_t)chain * D, A.geval + (size_t)chain * D, (double*)dens_lds, lane);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            code = 0;
+            return;
+        }
+#endif
+        remote_sync();
+        lp = A.ueval[chain];
+        code = A.ecode ? A.ecode[chain] : 0;
     }
 
     // ---- criteria of a sub-tree merge INSIDE a doubling (all leaves on one side of the origin): for an
@@ -712,9 +748,8 @@ struct Machine {
         const bool copy_rho = (idx_new == -1);
         double2 accK = {0.0, 0.0}, accL = {0.0, 0.0};
         if (!FUSED) {
-            if (REMOTE) remote_sync();
-            lp = A.ueval[chain];
-            code = A.ecode ? A.ecode[chain] : 0;
+            if (REMOTE) remote_eval(lp, code);
+            else { lp = A.ueval[chain]; code = A.ecode ? A.ecode[chain] : 0; }
             if (code != 0 || !isfinite(lp)) return 0.0;
         }
         const double* q = Q(newq);
@@ -1074,11 +1109,13 @@ struct Machine {
                                                 int32_t& T_q, double& T_U, double& T_E, int32_t& T_idx) {
         double sm; int64_t se;
         // (the merged sub-tree's buffer is free again unless its draw survives as T's: the caller sets T's bit when it stores T)
-        const int32_t A_q = rfl(c->sub_q[k]);
+        // (everything about the waiting sub-tree is read up front: one LDS round trip, not a second one behind the comparison)
+        const int32_t A_q = rfl(c->sub_q[k]), A_idx = rfl(c->sub_idx[k]);
+        const double A_U = c->sub_U[k], A_E = c->sub_E[k];
         H.sub_used &= ~(1u << A_q);
         nphip_w_add(c->sub_wm[k], c->sub_we[k], T_wm, T_we, &sm, &se);
         const bool take = merge_uniform_hot(H, j, d, k, blk, blk_id) * sm < nphip_w_rel(T_wm, T_we, se);
-        if (!take) { T_q = A_q; T_U = c->sub_U[k]; T_E = c->sub_E[k]; T_idx = rfl(c->sub_idx[k]); }
+        if (!take) { T_q = A_q; T_U = A_U; T_E = A_E; T_idx = A_idx; }
         T_wm = sm; T_we = se;
     }
 
@@ -1143,9 +1180,7 @@ struct Machine {
             double* qe = A.qeval + (size_t)chain * D;
 #pragma unroll
             for (int k = 0; k < NVX; ++k) if (k < nk) st2_dense(qe, ridx(k), D, X.q[k]);
-            remote_sync();
-            lp_remote = A.ueval[chain];
-            code_remote = A.ecode ? A.ecode[chain] : 0;
+            remote_eval(lp_remote, code_remote);
         } else {
             publish_edges(z);
         }
@@ -2432,13 +2467,13 @@ struct Machine {
             const int64_t ph = c->phase;
             if (ph == PH_DONE || ph == PH_ERROR || ph == PH_WAIT_HOST) {
                 // a resident launch: the group's rendezvous counts every chain, so a finished one keeps answering the roll
-                if (REMOTE) { while (c->hs_last == 0) remote_sync(); }
+                if (REMOTE && !DENS) { while (c->hs_last == 0) remote_sync(); }
                 break;
             }
             if (ph != PH_START) {
-                if (REMOTE) {
+                if (REMOTE && !DENS) {
                     if (c->hs_last != 0) break;   // the host asked the launch to end at this boundary
-                } else if (FUSED) {
+                } else if (FUSED || DENS) {
                     if (budget <= 0) break;
                     --budget;
                 } else {
@@ -2494,9 +2529,9 @@ struct Machine {
 #endif
                 if (rare || (!HOT && c->phase != PH_TREE)) break;   // (leaf_reg leaves the tree only through a rare path)
                 // the next leaf of the run: same admission test as at the top of the outer loop
-                if (REMOTE) {
+                if (REMOTE && !DENS) {
                     if (c->hs_last != 0) { out_of_budget = true; break; }
-                } else if (FUSED) {
+                } else if (FUSED || DENS) {
                     if (budget <= 0) { out_of_budget = true; break; }
                     --budget;
                 } else {
@@ -2544,7 +2579,7 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) __attribute__((amdgpu_waves_
         __syncthreads();
     }
     if (chain >= (int64_t)sl.chain_lo + sl.chain_n) return;
-    if (REMOTE) {
+    if (REMOTE && !NPHIP_JIT) {
         // Roll call: chains of a resident launch wait for each other inside the kernel, so all of them must be on the device
         // before any starts.  Each arrives once; the last one sets the verdict GO.  A chain that has waited 5 ms sets it to FAIL
         // (the device is busy with something that does not end: e.g. another sampler's resident launch) and everybody — also
@@ -2598,7 +2633,7 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) __attribute__((amdgpu_waves_
         for (int w = lane; w < kCtlWords; w += 64) dst[w] = src[w];
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    if (REMOTE) {
+    if (REMOTE && !NPHIP_JIT) {
         int g = 0;
         for (int o = 1; o < sl.n_grp; ++o) g += ((int)(chain - sl.chain_lo) >= sl.grp_lo[o]) ? 1 : 0;
         c->hs_seq = (int64_t)sl.grp_seq[g]; c->hs_last = 0; c->hs_grp = g; c->hs_n = sl.grp_lo[g + 1] - sl.grp_lo[g];
@@ -2927,6 +2962,47 @@ hipError_t launch_remote_wn(const Args* d_args, int W, int nv, hipStream_t st, c
 #undef NPHIP_LAUNCH_REMOTE
 #endif   // part 6
 
+
+#if NPHIP_PART == 7
+// ----------------------------------------------------------------------------------------
+// The runtime-compiled part (one model's density; nutpie_amd/density.py builds it with -DNPHIP_JIT_DENSITY -DNPHIP_PART=7
+// -DNPHIP_JIT_NV=<chunks of 128 dimensions>): the resident kernel with the density called inside the leaf, and the same density
+// as a plain batched kernel (the launch-per-evaluation form, nphip_device_logp_fn: any dimension, store_divergences, the
+// low-rank wrapper ...).  Both evaluate nphip_density with one wavefront per chain.
+// ----------------------------------------------------------------------------------------
+#if !NPHIP_JIT || !defined(NPHIP_JIT_NV)
+#error "part 7 is the runtime-compiled density: -DNPHIP_JIT_DENSITY -DNPHIP_JIT_NV=n behind a prelude that defines NphipData / nphip_density"
+#endif
+__global__ __launch_bounds__(256) void k_density_batch(const NphipData* __restrict__ data, uint64_t n_chains, int dim, const double* __restrict__ q,
+                                                       double* __restrict__ grad, double* __restrict__ logp, int lds_doubles) {
+    extern __shared__ __attribute__((aligned(16))) double s_scratch[];
+    const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint64_t chain = (uint64_t)blockIdx.x * 4 + wib;
+    if (chain >= n_chains) return;
+    const double lp = nphip_density(*data, dim, q + chain * (uint64_t)dim, grad + chain * (uint64_t)dim, s_scratch + (size_t)wib * lds_doubles, lane);
+    if (lane == 0) logp[chain] = lp;
+}
+}  // namespace nphip
+extern "C" {
+// nphip_jit_launch_fn (host.hip): one launch of the resident kernel over the slice's chains
+int nphip_jit_launch(const nphip::Args* d_args, int max_evals, void* stream, const nphip::LaunchSlice* sl, uint64_t dyn_lds_bytes) {
+    const dim3 g(((unsigned)sl->chain_n + 3) / 4), b(256);
+    hipLaunchKernelGGL((nphip::k_advance<false, 1, NPHIP_JIT_NV, false, true>), g, b, (size_t)dyn_lds_bytes, (hipStream_t)stream, d_args, max_evals, 0, *sl);
+    return (int)hipGetLastError();
+}
+int nphip_jit_nv(void) { return NPHIP_JIT_NV; }
+// nphip_device_logp_fn; user_data -> { device pointer of the data block, LDS doubles per wave }
+struct nphip_jit_batch_t { const void* data; int32_t lds_doubles, pad_; };
+int nphip_jit_logp(uint64_t n_chains, uint64_t dim, const double* q, double* grad, double* logp, void* stream, void* user_data) {
+    const nphip_jit_batch_t* u = (const nphip_jit_batch_t*)user_data;
+    if (!u) return -1;
+    hipLaunchKernelGGL(nphip::k_density_batch, dim3((unsigned)((n_chains + 3) / 4)), dim3(256), (size_t)4 * u->lds_doubles * sizeof(double), (hipStream_t)stream,
+                       (const NphipData*)u->data, n_chains, (int)dim, q, grad, logp, (int)u->lds_doubles);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+}  // extern "C"
+namespace nphip {
+#endif   // part 7
 
 #if NPHIP_HAS(0)
 // ----------------------------------------------------------------------------------------

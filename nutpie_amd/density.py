@@ -1,0 +1,292 @@
+"""Device densities compiled at run time: a model as HIP source -> its own resident NUTS kernel.
+
+The reference turns a PyMC model into ONE compiled log-density function (``compile_pymc.py:668-871``: logp + gradient joined
+into a single vector function, numba- or JAX-compiled) plus the shared data it reads (``:239-269``), and swaps that data
+with ``with_data`` without recompiling (``:140-166``).  The GPU form of that is this module: the model is a HIP device function
+
+    __device__ double nphip_density(const NphipData& data, int dim, const double* x, double* grad, double* lds, int lane);
+
+evaluated by one wavefront per chain — ``x[dim]`` the unconstrained position, ``grad[dim]`` receives the gradient, the return
+value is the log-density (the same in every lane), ``lds`` is per-chain scratch, ``data`` the model's arrays and scalars.  It is
+compiled with the ROCm compiler driver into the model's own instantiation of the engine's kernel (``kernels.hip`` part 7):
+the register-resident leaf of the fused models with the evaluation as a CALL in its middle — no kernel launch and no memory
+round trip of the chain state per gradient evaluation (``nphip_model_jit_density``).  The same library also exports the density
+as a plain batched device callback (``nphip_jit_logp``), used where the resident kernel does not apply (``dim > 1024``,
+``store_divergences``, ``adaptation="low_rank"``) — identical arithmetic, so identical draws.
+
+``NphipData`` is generated from the ``data`` dict: a float64 array ``y`` becomes ``const double* y; int n_y;``, an integer
+array ``const int* idx; int n_idx;``, a Python float / int a ``double`` / ``int`` field.  ``with_data(**updates)`` replaces
+arrays and scalars (same names and kinds) and re-uses the compiled library.
+
+Helpers available to the density source: everything in ``include/nphip_spec.h`` (``nphip_exp``, ``nphip_log`` ... — the engine's
+reproducible elementary functions; ``exp`` / ``log`` of the HIP device library work too) and ``nphip_wave_sum(double)``, the sum
+over the 64 lanes in the engine's fixed order.
+
+hiprtc is not used: the contract header includes the C standard headers, which hiprtc's built-in include set lacks; the
+compiler driver is the same one that builds the engine, with the same flags (``-ffp-contract=off``).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import dataclasses
+import hashlib
+import os
+import struct
+import subprocess
+import tempfile
+from dataclasses import dataclass
+from typing import Any, Callable
+
+import numpy as np
+
+from nutpie_amd import _lib
+from nutpie_amd.sample import CompiledModel
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+_INCLUDE = os.path.join(_HERE, "..", "include")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-unused-function"]
+
+
+def cache_dir() -> str:
+    """Where compiled densities are kept: ``$NUTPIE_AMD_CACHE``, else ``nutpie_amd/_density_cache`` beside the engine's library
+    (so that libraries built ahead of time travel with the tree), else ``~/.cache/nutpie_amd``."""
+    d = os.environ.get("NUTPIE_AMD_CACHE")
+    if not d:
+        d = os.path.join(_HERE, "_density_cache")
+        try:
+            os.makedirs(d, exist_ok=True)
+            if not os.access(d, os.W_OK):
+                raise OSError
+        except OSError:
+            d = os.path.join(os.path.expanduser("~"), ".cache", "nutpie_amd")
+    os.makedirs(d, exist_ok=True)
+    return d
+
+
+# --------------------------------------------------------------------------- the data block
+def _kind(v):
+    if isinstance(v, (bool, np.bool_)):
+        raise TypeError("boolean data is not supported: pass 0 / 1 integers")
+    if isinstance(v, (int, np.integer)):
+        return "int"
+    if isinstance(v, (float, np.floating)):
+        return "double"
+    a = np.asarray(v)
+    if a.dtype.kind == "f":
+        return "double*"
+    if a.dtype.kind in "iu":
+        return "int*"
+    raise TypeError(f"unsupported data type {a.dtype}")
+
+
+def data_layout(data: dict[str, Any]):
+    """Field order of ``NphipData``: pointers, then doubles, then ints (no padding anywhere).  Returns [(name, kind)]."""
+    kinds = {k: _kind(v) for k, v in data.items()}
+    ptrs = [(k, kinds[k]) for k in data if kinds[k].endswith("*")]
+    dbls = [(k, "double") for k in data if kinds[k] == "double"]
+    ints = [("n_" + k, "int") for k, _ in ptrs] + [(k, "int") for k in data if kinds[k] == "int"]
+    names = [n for n, _ in ptrs + dbls + ints]
+    dup = next((n for n in names if names.count(n) > 1), None)
+    if dup is not None:
+        raise ValueError(f"data field {dup!r} is defined twice (an array `y` brings its length as `n_y`)")
+    return ptrs + dbls + ints
+
+
+def struct_source(layout) -> str:
+    lines = ["struct NphipData {"]
+    for name, kind in layout:
+        lines.append(f"    const {kind[:-1]}* {name};" if kind.endswith("*") else f"    {kind} {name};")
+    if not layout:
+        lines.append("    int unused_;")
+    lines.append("};")
+    return "\n".join(lines)
+
+
+def generated_source(user_source: str, layout) -> str:
+    return "\n".join([
+        "// generated by nutpie_amd.density: one model's density compiled into the engine's resident kernel",
+        "#include <hip/hip_runtime.h>",
+        '#include "nphip_spec.h"',
+        struct_source(layout),
+        "__device__ double nphip_density(const NphipData& data, int dim, const double* x, double* grad, double* lds, int lane);",
+        '#include "kernels.hip"',
+        "// the engine's wave reduction (sum over the 64 lanes in the contract's order; the same value in every lane)",
+        "static __device__ __forceinline__ double nphip_wave_sum(double v) { return nphip::wave_sum(v); }",
+        "#line 1 \"density source\"",
+        user_source,
+        "",
+    ])
+
+
+def compile_density(user_source: str, layout, ndim: int, *, verbose: bool = False) -> str:
+    """Build (or find in the cache) the model's library; returns its path."""
+    nv = (int(ndim) + 127) // 128
+    src = generated_source(user_source, layout)
+    deps = [os.path.join(_CSRC, f) for f in ("kernels.hip", "engine_types.h")] + [os.path.join(_INCLUDE, "nphip_spec.h")]
+    h = hashlib.sha256()
+    h.update(src.encode())
+    for d in deps:
+        h.update(open(d, "rb").read())
+    flags = _FLAGS + ["-DNPHIP_JIT_DENSITY=1", "-DNPHIP_PART=7", f"-DNPHIP_JIT_NV={max(1, nv)}"]
+    h.update(" ".join(flags).encode())
+    out = os.path.join(cache_dir(), f"density_{h.hexdigest()[:24]}.so")
+    if os.path.exists(out):
+        return out
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "density.hip")
+        with open(path, "w") as f:
+            f.write(src)
+        tmp_out = os.path.join(tmp, "density.so")
+        r = subprocess.run([HIPCC, *flags, "-I", _CSRC, "-I", _INCLUDE, "-o", tmp_out, path], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("compiling the density failed:\n" + r.stderr[-4000:])
+        if verbose and r.stderr:
+            print(r.stderr)
+        os.replace(tmp_out, out)   # atomic: concurrent ranks may compile the same model
+    return out
+
+
+class _Batch(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("lds_doubles", C.c_int32), ("pad_", C.c_int32)]
+
+
+class DensityLibrary:
+    """The loaded library of one compiled density."""
+
+    def __init__(self, path: str):
+        _lib.lib()   # the engine (and torch's HIP runtime) first: one runtime per process
+        self.path = path
+        self.lib = C.CDLL(path)
+        self.lib.nphip_jit_nv.restype = C.c_int
+        self.nv = int(self.lib.nphip_jit_nv())
+        self.launch_addr = C.cast(self.lib.nphip_jit_launch, C.c_void_p).value
+        self.logp_addr = C.cast(self.lib.nphip_jit_logp, C.c_void_p).value
+
+
+class DeviceData:
+    """``NphipData`` in device memory: the arrays as torch tensors on the GPU, the block itself as a byte tensor."""
+
+    def __init__(self, data: dict[str, Any], layout, device: int):
+        import torch
+
+        dev = torch.device("cuda", device)
+        self.tensors = {}
+        blob = b""
+        for name, kind in layout:
+            if kind.endswith("*"):
+                a = np.ascontiguousarray(data[name], dtype=np.float64 if kind == "double*" else np.int32)
+                t = torch.as_tensor(a).to(dev) if a.size else torch.zeros(1, dtype=torch.float64 if kind == "double*" else torch.int32, device=dev)
+                self.tensors[name] = t
+                blob += struct.pack("<Q", t.data_ptr())
+            elif kind == "double":
+                blob += struct.pack("<d", float(data[name]))
+            elif name in data:
+                blob += struct.pack("<i", int(data[name]))
+            else:   # n_<array>
+                blob += struct.pack("<i", int(np.asarray(data[name[2:]]).size))
+        blob += b"\0" * ((-len(blob)) % 8 + 8)
+        self.block = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
+        torch.cuda.synchronize(dev)
+        self.ptr = self.block.data_ptr()
+
+
+# --------------------------------------------------------------------------- the model front-end
+@dataclass(frozen=True)
+class DensitySourceModel(CompiledModel):
+    """A model given as HIP source (module docstring).  Same contract as the other front-ends: ``n_dim``, ``shapes``, ``coords``,
+    ``with_data``, ``_make_sampler``."""
+
+    _source: str
+    _n_dim: int
+    _data: dict[str, Any]
+    _lds_bytes: int
+    _names: list[str]
+    _shapes: list[tuple[int, ...]]
+    _coords: dict[str, Any]
+    _expand_func: Callable | None = None     # (x[N, D] numpy, **data) -> dict name -> [N, *shape]
+    _init: Any = "uniform"
+    _resident: bool = True                   # False: always the batched callback (launch per evaluation)
+
+    @property
+    def n_dim(self):
+        return self._n_dim
+
+    @property
+    def shapes(self):
+        return {n: tuple(int(v) for v in s) for n, s in zip(self._names, self._shapes)}
+
+    @property
+    def coords(self):
+        return self._coords
+
+    @property
+    def data(self):
+        return dict(self._data)
+
+    def with_data(self, **updates):
+        """New data, same compiled library (reference compile_pymc.py:140-166: shared variables are swapped, nothing is
+        recompiled).  Names and kinds (float array / integer array / float / int) must match."""
+        for k, v in updates.items():
+            if k not in self._data:
+                raise ValueError(f"Unknown data variable: {k}")
+            if _kind(v) != _kind(self._data[k]):
+                raise ValueError(f"Data variable {k} must stay a {_kind(self._data[k])}")
+        return dataclasses.replace(self, _data={**self._data, **updates})
+
+    def library(self) -> DensityLibrary:
+        return DensityLibrary(compile_density(self._source, data_layout(self._data), self._n_dim))
+
+    def _make_model(self, init_mean=None, settings=None, device: int = 0, resident: bool | None = None):
+        lib = self.library()
+        dd = DeviceData(self._data, data_layout(self._data), device)
+        use_resident = self._resident if resident is None else resident
+        if settings is not None and (bool(getattr(settings, "store_divergences", False)) or getattr(settings, "_adaptation", "diag") == "low_rank"):
+            use_resident = False   # the divergence record needs the pre-step state in memory
+        if self._n_dim > 1024:
+            use_resident = False
+        if use_resident:
+            model = _lib.JitDensityModel(self._n_dim, lib.launch_addr, lib.nv, dd.ptr, self._lds_bytes, keep_alive=(lib, dd))
+        else:
+            batch = _Batch(dd.ptr, self._lds_bytes // 8, 0)
+            model = _lib.NativeDeviceCallbackModel(self._n_dim, lib.logp_addr, C.addressof(batch), keep_alive=(lib, dd, batch))
+        if isinstance(self._init, str):
+            model.set_init(self._init)
+        else:
+            model.set_init("explicit", np.asarray(self._init, dtype=np.float64))
+        return model
+
+    def _make_sampler(self, settings, init_mean, cores, progress_type, extra_callback, extra_callback_rate, store, **engine_kw):
+        import torch
+
+        if not torch.cuda.is_available():
+            raise RuntimeError("a device density needs a GPU: the nutpie-hip engine has no CPU fallback")
+        device = int(engine_kw.get("device", 0) or 0)
+        model = self._make_model(settings=settings, device=device)
+        return _lib.PySampler.from_pyfunc(settings, cores, model, progress_type, extra_callback, extra_callback_rate, store, **engine_kw)
+
+    def _expand_draws(self, draws):
+        n, T, D = draws.shape
+        if self._expand_func is None:
+            return {self._names[0]: draws.reshape(n, T, *self._shapes[0])}
+        flat = self._expand_func(draws.reshape(n * T, D), **self._data)
+        return {name: np.asarray(flat[name]).reshape(n, T, *shape) for name, shape in zip(self._names, self._shapes)}
+
+
+def from_density_source(ndim: int, source: str, data: dict[str, Any] | None = None, *, lds_doubles_per_chain: int = 0,
+                        expand_fn: Callable | None = None, expanded_names: list[str] | None = None, expanded_shapes=None,
+                        coords=None, dims=None, init="uniform", resident: bool = True, reparameterized_names=None) -> DensitySourceModel:
+    """A model from the HIP source of its log-density (module docstring): ``source`` defines ``nphip_density``; ``data`` are the
+    arrays / scalars it reads through ``NphipData``; ``lds_doubles_per_chain`` the LDS scratch it uses.  ``expand_fn`` (optional)
+    maps a numpy block ``[N, ndim]`` of draws to the dict of expanded variables, as :func:`nutpie_amd.from_torchfunc` does."""
+    if expanded_names is None:
+        if expand_fn is not None:
+            raise ValueError("expand_fn needs expanded_names and expanded_shapes")
+        expanded_names, expanded_shapes = ["x"], [(ndim,)]
+    if "nphip_density" not in source:
+        raise ValueError("the source must define `__device__ double nphip_density(const NphipData& data, int dim, const double* x, double* grad, double* lds, int lane)`")
+    return DensitySourceModel(dims=dict(dims or {}), _source=source, _n_dim=int(ndim), _data=dict(data or {}), _lds_bytes=8 * int(lds_doubles_per_chain),
+                              _names=list(expanded_names), _shapes=[tuple(s) for s in expanded_shapes], _coords=dict(coords or {}),
+                              _expand_func=expand_fn, _init=init, _resident=bool(resident), reparameterized_names=reparameterized_names)

@@ -169,3 +169,138 @@ def radon_model(data=None, device=0, use_graph=False, expand_on_device=True):
     model = from_torchfunc(D, make_logp, expand, shapes, names, coords={"county": np.arange(n)}, dims=dims, use_graph=use_graph,
                            expand_device_fn=expand_device if expand_on_device else None)
     return model
+
+
+# --------------------------------------------------------------------------------------------------------------------------
+# The same density as HIP source (nutpie_amd/density.py): compiled at run time into the model's own resident kernel.
+# One wavefront per chain; LDS scratch per chain: county effects [128] | county floor effects [128] | d lp / d mu per observation.
+# Arithmetic and summation order are those of the native callback kernel tests/fixtures/radon_device.hip (the round-2 form of
+# this model), so that the two produce the same floats.
+# --------------------------------------------------------------------------------------------------------------------------
+RADON_MAX_COUNTIES = 128
+
+RADON_DENSITY_SOURCE = r"""
+static __device__ __forceinline__ double radon_wave_sum(double v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__device__ double nphip_density(const NphipData& d, int dim, const double* x, double* g, double* lds, int lane) {
+    const int n = d.n_counties, n_obs = d.n_y;
+    double* eff = lds;              // [ce(n) | cfe(n)] then w[n_obs]
+    double* cfe = eff + 128;
+    double* w = eff + 256;
+    const int o_raw = 1, o_lsd = n, o_floor = n + 1, o_craw = n + 2, o_lcsd = 2 * n + 1, o_lsig = 2 * n + 2;
+    const double intercept = x[0], fe = x[o_floor], lsd = x[o_lsd], lcsd = x[o_lcsd], lsig = x[o_lsig];
+    const double sd = exp(lsd), csd = exp(lcsd), sig = exp(lsig), inv_sig = 1.0 / sig;
+    const double c1 = 1.0 / (sqrt((double)n) + n), c2 = 1.0 / sqrt((double)n);
+    // zero-sum extension of the two raw vectors (PyMC ZeroSumTransform.backward)
+    double s_raw = 0.0, s_craw = 0.0, ss = 0.0;
+    for (int j = lane; j < n - 1; j += 64) {
+        const double a = x[o_raw + j], b = x[o_craw + j];
+        s_raw += a; s_craw += b; ss += a * a + b * b;
+    }
+    s_raw = radon_wave_sum(s_raw); s_craw = radon_wave_sum(s_craw); ss = radon_wave_sum(ss);
+    for (int j = lane; j < n; j += 64) {
+        const double e = (j < n - 1) ? x[o_raw + j] - s_raw * c1 : -s_raw * c2;
+        const double ce = (j < n - 1) ? x[o_craw + j] - s_craw * c1 : -s_craw * c2;
+        eff[j] = e * sd;
+        cfe[j] = ce * csd;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // observations: residuals, d lp / d mu
+    double rr = 0.0, sw = 0.0, swf = 0.0;
+    for (int o = lane; o < n_obs; o += 64) {
+        const int cty = d.county[o];
+        const double fl = d.floor[o];
+        const double mu = intercept + eff[cty] + fl * (fe + cfe[cty]);
+        const double r = (d.y[o] - mu) * inv_sig;
+        const double wo = r * inv_sig;
+        w[o] = wo;
+        rr += r * r; sw += wo; swf += wo * fl;
+    }
+    rr = radon_wave_sum(rr); sw = radon_wave_sum(sw); swf = radon_wave_sum(swf);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // per-county sums of w (county effect) and w * floor (county floor effect): one lane per county, fixed order
+    double dot_e = 0.0, dot_c = 0.0, su_e = 0.0, su_c = 0.0;
+    double ge_[2] = {0.0, 0.0}, gc_[2] = {0.0, 0.0};
+    for (int t = 0, j = lane; j < n; j += 64, ++t) {
+        double a = 0.0, b = 0.0;
+        for (int k = d.row_start[j]; k < d.row_start[j + 1]; ++k) {
+            const int o = d.row_obs[k];
+            a += w[o];
+            b += w[o] * d.floor[o];
+        }
+        ge_[t] = a; gc_[t] = b;
+        const double ext = eff[j] / sd, cext = cfe[j] / csd;
+        dot_e += ext * a; dot_c += cext * b;
+        if (j < n - 1) { su_e += a * sd; su_c += b * csd; }
+    }
+    dot_e = radon_wave_sum(dot_e); dot_c = radon_wave_sum(dot_c); su_e = radon_wave_sum(su_e); su_c = radon_wave_sum(su_c);
+    // last county's (scaled) gradient, needed by the transpose of the extension
+    const int last_lane = (n - 1) & 63, last_t = (n - 1) >> 6;
+    const double gl_e = __shfl(last_t == 0 ? ge_[0] : ge_[1], last_lane, 64) * sd;
+    const double gl_c = __shfl(last_t == 0 ? gc_[0] : gc_[1], last_lane, 64) * csd;
+    for (int t = 0, j = lane; j < n - 1; j += 64, ++t) {
+        g[o_raw + j] = (ge_[t] * sd - (c1 * su_e + c2 * gl_e)) - x[o_raw + j];
+        g[o_craw + j] = (gc_[t] * csd - (c1 * su_c + c2 * gl_c)) - x[o_craw + j];
+    }
+    if (lane == 0) {
+        g[0] = -0.01 * intercept + sw;
+        g[o_floor] = -0.25 * fe + swf;
+        g[o_lsd] = 1.0 - sd * sd + sd * dot_e;
+        g[o_lcsd] = 1.0 - csd * csd + csd * dot_c;
+        g[o_lsig] = 1.0 - sig * sig / 2.25 + rr - n_obs;
+    }
+    return -0.005 * intercept * intercept - 0.125 * fe * fe - 0.5 * ss - 0.5 * sd * sd + lsd - 0.5 * csd * csd + lcsd
+           - (0.5 / 2.25) * sig * sig + lsig - 0.5 * rr - n_obs * lsig;
+}
+"""
+
+
+def radon_density_data(data=None):
+    """The ``data`` dict of the HIP-source radon model: the observations plus a CSR list of each county's observations (the
+    per-county gradient sums are taken by one lane per county, in a fixed order)."""
+    data = data or synthetic_radon_data()
+    county = np.asarray(data["county_idx"], dtype=np.int32)
+    n = int(county.max()) + 1
+    if n > RADON_MAX_COUNTIES:
+        raise ValueError(f"the radon density source holds up to {RADON_MAX_COUNTIES} counties in its LDS scratch")
+    counts = np.bincount(county, minlength=n)
+    row_start = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    row_obs = np.argsort(county, kind="stable").astype(np.int32)
+    return {"county": county, "floor": np.asarray(data["floor"], dtype=np.float64), "y": np.asarray(data["log_radon"], dtype=np.float64),
+            "row_start": row_start, "row_obs": row_obs, "n_counties": n}
+
+
+def radon_density_model(data=None, resident=True):
+    """Config 3's model as a runtime-compiled device density (:func:`nutpie_amd.from_density_source`): the same variables as
+    :func:`radon_model`; ``with_data`` swaps the observations without recompiling."""
+    from nutpie_amd.density import from_density_source
+
+    dd = radon_density_data(data)
+    n = dd["n_counties"]
+    D = 2 * n + 3
+    o_raw, o_lsd, o_floor, o_craw, o_lcsd, o_lsig = 1, n, n + 1, n + 2, 2 * n + 1, 2 * n + 2
+
+    def expand(x, **_data):
+        x = np.asarray(x)
+
+        def ext(v):
+            m = v.shape[-1] + 1
+            s = v.sum(-1, keepdims=True)
+            norm = s / (np.sqrt(m) + m)
+            return np.concatenate([v, norm - s / np.sqrt(m)], -1) - norm
+
+        raw, craw = ext(x[:, o_raw:o_raw + n - 1]), ext(x[:, o_craw:o_craw + n - 1])
+        sd, csd = np.exp(x[:, o_lsd]), np.exp(x[:, o_lcsd])
+        return {"intercept": x[:, 0], "county_raw": raw, "county_sd": sd, "county_effect": raw * sd[:, None], "floor_effect": x[:, o_floor],
+                "county_floor_raw": craw, "county_floor_sd": csd, "county_floor_effect": craw * csd[:, None], "sigma": np.exp(x[:, o_lsig])}
+
+    names = ["intercept", "county_raw", "county_sd", "county_effect", "floor_effect", "county_floor_raw", "county_floor_sd", "county_floor_effect", "sigma"]
+    shapes = [(), (n,), (), (n,), (), (n,), (), (n,), ()]
+    dims = {k: ("county",) for k in ("county_raw", "county_effect", "county_floor_raw", "county_floor_effect")}
+    return from_density_source(D, RADON_DENSITY_SOURCE, dd, lds_doubles_per_chain=2 * RADON_MAX_COUNTIES + len(dd["y"]), expand_fn=expand,
+                               expanded_names=names, expanded_shapes=shapes, coords={"county": np.arange(n)}, dims=dims, resident=resident)

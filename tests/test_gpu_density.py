@@ -1,0 +1,145 @@
+"""Runtime-compiled device densities (nutpie_amd/density.py, nphip_model_jit_density): a model given as HIP source runs in its
+own resident kernel — the register-resident leaf with the density called in its middle — and produces exactly what the
+launch-per-evaluation device-callback path produces with the same density (BASELINE.json config 3: radon)."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+from scipy import stats
+
+import nutpie_amd
+from nutpie_amd.radon import radon_density_model, synthetic_radon_data
+from tests.conftest import assert_trace_equal  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+HALFNORMAL_SOURCE = r"""
+// HalfNormal(1) on the log scale (the density of the reference's golden-vector tests): D = 1
+__device__ double nphip_density(const NphipData& d, int dim, const double* x, double* grad, double* lds, int lane) {
+    const double e = exp(2.0 * x[0]);
+    if (lane == 0) grad[0] = d.scale * (1.0 - e);
+    return d.scale * (x[0] - 0.5 * e);
+}
+"""
+
+STD_NORMAL_SOURCE = r"""
+// N(0, diag(sd^2)): uses the engine's wave reduction and per-chain LDS scratch
+__device__ double nphip_density(const NphipData& d, int dim, const double* x, double* grad, double* lds, int lane) {
+    double acc = 0.0;
+    for (int i = lane; i < dim; i += 64) {
+        const double z = x[i] / d.sd[i];
+        lds[i] = z;
+        acc = fma(z, z, acc);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < dim; i += 64) grad[i] = -lds[i] / d.sd[i];
+    return -0.5 * nphip_wave_sum(acc);
+}
+"""
+
+
+def run(model, *, chains, tune, draws, seed, **kw):
+    s = nutpie_amd._lib.PyNutsSettings.Diag(seed)
+    s.update(num_tune=tune, num_draws=draws, num_chains=chains, **kw)
+    smp = model._make_sampler(s, None, 1, None, None, None, None)
+    smp.wait()
+    return smp.take_results()
+
+
+def test_radon_resident_kernel_equals_the_device_callback_path(hip):
+    # the same compiled density driven two ways: called inside the resident kernel, and as one kernel launch per evaluation
+    # behind the batched device callback (the round-2 path) — every float and every tree identical
+    kw = dict(chains=64, tune=150, draws=60, seed=11)
+    a = run(radon_density_model(), **kw)
+    b = run(radon_density_model(resident=False), **kw)
+    for k in ("depth", "n_steps", "index_in_trajectory", "diverging", "maxdepth_reached", "tuning"):
+        assert np.array_equal(np.asarray(a.stats[k]), np.asarray(b.stats[k])), k
+    for k in ("energy", "energy_error", "logp", "step_size", "step_size_bar", "mean_tree_accept", "mean_tree_accept_sym"):
+        assert np.array_equal(a.stats[k], b.stats[k]), k
+    assert np.array_equal(a.draws, b.draws)
+    assert a.finished.tolist() == [210] * 64
+    # launch slicing does not matter either
+    s = hip.PyNutsSettings.Diag(11)
+    s.update(num_tune=150, num_draws=60, num_chains=64)
+    smp = hip.PySampler(s, radon_density_model()._make_model(), evals_per_launch=7)
+    smp.wait()
+    c = smp.take_results()
+    assert np.array_equal(a.draws, c.draws) and np.array_equal(a.stats["n_steps"], c.stats["n_steps"])
+    # gradients and mass matrices are stored from the resident kernel too
+    d1 = run(radon_density_model(), chains=8, tune=60, draws=20, seed=3, store_gradient=True, store_mass_matrix=True)
+    d2 = run(radon_density_model(resident=False), chains=8, tune=60, draws=20, seed=3, store_gradient=True, store_mass_matrix=True)
+    assert np.array_equal(d1.stats["gradient"], d2.stats["gradient"]) and np.array_equal(d1.stats["mass_matrix_inv"], d2.stats["mass_matrix_inv"])
+
+
+def test_radon_density_against_the_torch_density_and_posterior(hip):
+    import torch
+
+    from nutpie_amd import density
+    from nutpie_amd.radon import radon_model
+
+    m = radon_density_model()
+    lib = m.library()
+    dd = density.DeviceData(m._data, density.data_layout(m._data), 0)
+    D = m.n_dim
+    x = torch.randn(41, D, dtype=torch.float64, device="cuda") * 0.4
+    g = torch.empty_like(x)
+    lp = torch.empty(41, dtype=torch.float64, device="cuda")
+    batch = density._Batch(dd.ptr, m._lds_bytes // 8, 0)
+    call = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p)(lib.logp_addr)
+    assert call(41, D, x.data_ptr(), g.data_ptr(), lp.data_ptr(), 0, ctypes.addressof(batch)) == 0
+    torch.cuda.synchronize()
+    lp_ref, g_ref = radon_model(synthetic_radon_data())._make_logp_func()(x)
+    assert torch.allclose(lp, lp_ref, rtol=1e-12, atol=1e-9) and torch.allclose(g, g_ref, rtol=1e-10, atol=1e-9)
+    # the whole front-end: sample(), expanded variables, config-3 sizes
+    tr = nutpie_amd.sample(m, chains=512, tune=300, draws=200, seed=7, progress_bar=False)
+    n = m._data["n_counties"]
+    assert tr.posterior.county_effect.shape == (512, 200, n) and tr.posterior.sigma.shape == (512, 200)
+    assert abs(tr.posterior.intercept.values.mean() - 1.3) < 0.15 and abs(tr.posterior.floor_effect.values.mean() + 0.6) < 0.2
+    assert abs(tr.posterior.sigma.values.mean() - 0.75) < 0.08
+    assert np.abs(tr.posterior.county_effect.values.sum(-1)).max() < 1e-9        # zero-sum
+    assert tr.sample_stats.diverging.values.mean() < 0.02
+
+
+def test_with_data_reuses_the_compiled_library(hip):
+    m = radon_density_model()
+    other = synthetic_radon_data(seed=99)
+    from nutpie_amd.radon import radon_density_data
+
+    m2 = m.with_data(**{k: v for k, v in radon_density_data(other).items()})
+    assert m2.library().path == m.library().path                                  # swapped data, nothing recompiled
+    a = nutpie_amd.sample(m, chains=16, tune=150, draws=100, seed=1, progress_bar=False)
+    b = nutpie_amd.sample(m2, chains=16, tune=150, draws=100, seed=1, progress_bar=False)
+    assert not np.allclose(a.posterior.county_effect.values.mean((0, 1)), b.posterior.county_effect.values.mean((0, 1)), atol=0.02)
+    with pytest.raises(ValueError, match="Unknown data variable"):
+        m.with_data(nope=1)
+    with pytest.raises(ValueError, match="must stay"):
+        m.with_data(y=3)
+
+
+def test_small_densities_scalars_lds_and_the_wave_reduction(hip):
+    m = nutpie_amd.from_density_source(1, HALFNORMAL_SOURCE, {"scale": 1.0})
+    tr = nutpie_amd.sample(m, chains=64, seed=5, draws=1000, tune=300, progress_bar=False)
+    a = np.exp(tr.posterior.x.values[..., 0])
+    assert abs(a.mean() - np.sqrt(2 / np.pi)) < 0.02 and stats.kstest(a[:, ::10].ravel(), "halfnorm").pvalue > 1e-3
+    sd = np.exp(np.random.default_rng(3).normal(size=300))
+    m = nutpie_amd.from_density_source(300, STD_NORMAL_SOURCE, {"sd": sd}, lds_doubles_per_chain=300)
+    tr = nutpie_amd.sample(m, chains=128, seed=2, draws=400, tune=300, progress_bar=False)
+    x = tr.posterior.x.values.reshape(-1, 300)
+    assert np.abs(x.mean(0) / sd).max() < 0.08 and np.abs(x.std(0) / sd - 1).max() < 0.06
+    assert tr.sample_stats.n_steps.values.mean() < 20                              # the diagonal metric finds the scales (trees of depth 4)
+
+
+def test_fallbacks_and_errors(hip):
+    m = radon_density_model()
+    # store_divergences needs the pre-step state in memory: the batched callback of the same library is used
+    tr = nutpie_amd.sample(m, chains=8, tune=60, draws=20, seed=3, progress_bar=False, store_divergences=True, max_energy_error=2.0)
+    assert "divergence_start" in tr.warmup_sample_stats
+    with pytest.raises(RuntimeError, match="compiling the density failed"):
+        nutpie_amd.from_density_source(2, "__device__ double nphip_density(const NphipData& d, int dim, const double* x, double* g, double* l, int lane) { return nope; }").library()
+    with pytest.raises(ValueError, match="nphip_density"):
+        nutpie_amd.from_density_source(2, "int x;")
+    with pytest.raises(RuntimeError, match="LDS scratch"):
+        big = nutpie_amd.from_density_source(300, STD_NORMAL_SOURCE, {"sd": np.ones(300)}, lds_doubles_per_chain=8000)
+        nutpie_amd.sample(big, chains=4, tune=10, draws=5, progress_bar=False)
