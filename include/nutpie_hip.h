@@ -118,10 +118,12 @@ nphip_model_t* nphip_model_bridgestan(uint64_t dim, void* bs_model, void* log_de
  * model; here the model is HIP source compiled at run time into its own instantiation of the engine's resident kernel —
  * nutpie_amd/density.py).  `launch_fn` = address of `nphip_jit_launch` of the model's library, `nv` = its `nphip_jit_nv()`
  * (chunks of 128 dimensions: dim <= 1024), `data_device` = the model's data block in device memory (borrowed),
- * `lds_bytes_per_wave` = LDS scratch the density uses per chain.  The evaluation is a call in the middle of the
+ * `lds_bytes_per_wave` = LDS scratch the density uses per chain, `lds_bytes_shared` = LDS common to the four chains of a
+ * workgroup, filled once per launch by the library's staging function (the model's data).  The evaluation is a call in the middle of the
  * register-resident leaf: no launch, no memory round trip for the chain state.  The same library exports the density as a
  * batched device callback (`nphip_jit_logp`, an nphip_device_logp_fn) for everything the resident kernel does not cover. */
-nphip_model_t* nphip_model_jit_density(uint64_t dim, void* launch_fn, int nv, const void* data_device, uint64_t lds_bytes_per_wave);
+nphip_model_t* nphip_model_jit_density(uint64_t dim, void* launch_fn, int nv, const void* data_device, uint64_t lds_bytes_per_wave,
+                                       uint64_t lds_bytes_shared);
 /* Initial positions: kind 0 = U(-2,2) (src/pyfunc.rs:540-544), 1 = N(0,1) (src/stan.rs:798-808),
  * 2 = explicit host array points[n_chains_total][dim] indexed by GLOBAL chain id
  * (src/pymc.rs:505-534 evaluates the user's init function per chain on the host). */

@@ -175,7 +175,7 @@ struct Args {
     // instantiation of k_advance; an evaluation is a call in the middle of the register-resident leaf (kernels.hip: density_eval)
     const void* dens_data;       // the model's data block (device memory; layout defined by the generated prelude of the density source)
     int32_t dens_lds_doubles;    // LDS scratch per wave the density asked for, in doubles (dynamic LDS of the launch)
-    int32_t dens_pad_;
+    int32_t dens_shared_doubles; // LDS shared by the chains of a workgroup (the model's data staged once per launch: nphip_density_stage)
 };
 constexpr unsigned long long kGoLast = 1ull << 32;      // finish this evaluation's step, then leave the kernel at the boundary
 constexpr unsigned long long kGoSeqMask = 0xffffffffull;

@@ -304,6 +304,7 @@ struct nphip_model {
     nphip_jit_launch_fn jit_launch = nullptr;
     const void* jit_data = nullptr;
     uint64_t jit_lds_bytes = 0;   // LDS scratch per wave
+    uint64_t jit_shared_bytes = 0; // LDS shared by the chains of a workgroup
     int jit_nv = 0;
     std::shared_ptr<BsAdapter> bs;
     std::shared_ptr<BsExpand> bs_expand;
@@ -355,25 +356,28 @@ nphip_model_t* nphip_model_device_callback(uint64_t dim, nphip_device_logp_fn fn
     m->kind = 2; m->dim = dim; m->dev_fn = fn; m->user = user_data;
     return m;
 }
-nphip_model_t* nphip_model_jit_density(uint64_t dim, void* launch_fn, int nv, const void* data_device, uint64_t lds_bytes_per_wave) {
+nphip_model_t* nphip_model_jit_density(uint64_t dim, void* launch_fn, int nv, const void* data_device, uint64_t lds_bytes_per_wave,
+                                       uint64_t lds_bytes_shared) {
     if (dim == 0 || !launch_fn) { set_error("a runtime-compiled density needs dim > 0 and its launcher"); return nullptr; }
     if (dim > 1024 || nv < 1 || nv > 8 || (uint64_t)nv * 128 < dim) {
         set_error("the resident kernel of a runtime-compiled density holds up to 1024 dimensions (nv chunks of 128, nv = ceil(dim / 128)); "
                   "larger models run through the batched device callback of the same library");
         return nullptr;
     }
-    if (lds_bytes_per_wave % 8 != 0) { set_error("LDS scratch per wave must be a multiple of 8 bytes"); return nullptr; }
+    if (lds_bytes_per_wave % 8 != 0 || lds_bytes_shared % 8 != 0) { set_error("LDS scratch sizes must be multiples of 8 bytes"); return nullptr; }
     // LDS of the launch: four chains per workgroup — control blocks, reduction scratch, the four rings (4 x 4 KB x nv each) and
     // the density's scratch — must fit the CU's 160 KB
-    const uint64_t fixed = 4 * 1200 + 1024 + 4 * (uint64_t)nv * 4096 + 64;
-    if (fixed + 4 * lds_bytes_per_wave > 160 * 1024) {
+    // (+ the leaf's position and gradient rows in LDS: 2 x 1 KB x nv per chain)
+    const uint64_t fixed = 4 * 1200 + 1024 + 4 * (uint64_t)nv * 4096 + 64 + 4 * 2 * (uint64_t)nv * 1024;
+    if (fixed + 4 * lds_bytes_per_wave + lds_bytes_shared > 160 * 1024) {
         set_error("LDS scratch of the density does not fit beside the kernel's own (" + std::to_string(fixed) + " bytes fixed, " +
-                  std::to_string(4 * lds_bytes_per_wave) + " requested for four chains, 163840 per CU)");
+                  std::to_string(4 * lds_bytes_per_wave) + " requested for four chains + " + std::to_string(lds_bytes_shared) + " shared, 163840 per CU)");
         return nullptr;
     }
     auto* m = new nphip_model();
     m->kind = 3; m->dim = dim; m->jit_launch = (nphip_jit_launch_fn)launch_fn; m->jit_nv = nv; m->jit_data = data_device;
     m->jit_lds_bytes = lds_bytes_per_wave;
+    m->jit_shared_bytes = lds_bytes_shared;
     return m;
 }
 int nphip_model_set_init(nphip_model_t* m, int kind, const double* points, uint64_t n_points) {
@@ -875,6 +879,7 @@ bool nphip_sampler::setup() {
         if (dens) {
             args.dens_data = model.jit_data;
             args.dens_lds_doubles = (int32_t)(model.jit_lds_bytes / 8);
+            args.dens_shared_doubles = (int32_t)(model.jit_shared_bytes / 8);
             args.reg_nv = model.jit_nv;
             if ((int64_t)model.jit_nv * 128 != args.ld) { set_error("the density's library was compiled for another dimension (nv chunks)"); return false; }
         }
@@ -992,7 +997,9 @@ std::string nphip_sampler::chain_error_message() {
 }
 
 bool nphip_sampler::launch_kernel(bool fused_, int have) {
-    args.max_evals = (fused_ || dens) ? (launch.evals_per_launch > 0 ? launch.evals_per_launch : default_evals_per_launch(dim)) : 0;
+    // (a runtime-compiled density costs microseconds per evaluation: 512 per launch is milliseconds of kernel already, and the
+    //  job's tail — chains that are done wait for the launch to end — shrinks with the launch)
+    args.max_evals = (fused_ || dens) ? (launch.evals_per_launch > 0 ? launch.evals_per_launch : (dens ? 512 : default_evals_per_launch(dim))) : 0;
     args.have_result = have;
     if (kernel_ms_acc) {
         while (tev.size() < 2 * (timed_launches + 1)) {
@@ -1006,7 +1013,8 @@ bool nphip_sampler::launch_kernel(bool fused_, int have) {
         LaunchSlice sl;
         memset(&sl, 0, sizeof(sl));
         sl.chain_lo = 0; sl.chain_n = (int)n; sl.grp = -1;
-        const int rc = model.jit_launch(d_args, args.max_evals, (void*)stream, &sl, 4 * model.jit_lds_bytes);
+        const int rc = model.jit_launch(d_args, args.max_evals, (void*)stream, &sl,
+                                        4 * model.jit_lds_bytes + model.jit_shared_bytes + 4 * 2 * (uint64_t)args.ld * 8);
         if (rc != 0) { set_error(std::string("launch of the runtime-compiled density kernel: ") + hipGetErrorString((hipError_t)rc)); return false; }
     } else if (!hip_ok(launch_advance(args, d_args, fused_, W, stream), "launch k_advance")) return false;
     if (kernel_ms_acc) {

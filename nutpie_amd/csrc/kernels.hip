@@ -34,11 +34,15 @@
 
 // Runtime-compiled device densities (nutpie_amd/density.py -> nphip_model_jit_density): this file is compiled once more, per
 // model, with -DNPHIP_JIT_DENSITY -DNPHIP_PART=7 behind a generated prelude that defines `struct NphipData` and
-//     __device__ double nphip_density(const NphipData& data, int dim, const double* x, double* grad, double* lds, int lane)
+//     __device__ double nphip_density(const NphipData& data, int dim, const double* x, double* grad, double* lds, const double* shared, int lane)
 // — evaluated by ONE converged wavefront: x[dim] is the position row (global memory), grad[dim] receives the gradient, `lds`
-// is the wave's private LDS scratch, the return value the log-density (the same in every lane; non-finite = a recoverable
-// error, src/pyfunc.rs:218-220).  The kernel built from it is the REMOTE machine — the register-resident leaf with the
-// evaluation as a call in its middle — with the host rendezvous replaced by that call.
+// is the wave's private LDS scratch, `shared` LDS common to the chains of the workgroup, the return value the log-density
+// (the same in every lane; non-finite = a recoverable error, src/pyfunc.rs:218-220) — and
+//     __device__ void nphip_density_stage(const NphipData& data, double* shared, int thread, int n_threads)
+// called once per workgroup and launch by all of its threads to fill `shared` (typically: the model's data, so that the
+// density reads LDS instead of waiting out an L2 latency per access on a lone wave).  The kernel built from it is the REMOTE
+// machine — the register-resident leaf with the evaluation as a call in its middle — with the host rendezvous replaced by
+// that call.
 #ifdef NPHIP_JIT_DENSITY
 #define NPHIP_JIT 1
 #else
@@ -227,6 +231,8 @@ struct Machine {
     static constexpr bool INK = FUSED || REMOTE;   // evaluations happen inside the kernel: a launch runs many steps
     static constexpr bool DENS = REMOTE && (NPHIP_JIT != 0);   // ... by calling the model's own device function (runtime-compiled density)
     LdsDouble dens_lds = nullptr;   // DENS: this wave's LDS scratch for the density
+    LdsDouble dens_shared = nullptr;   // DENS: the workgroup's shared LDS (staged by nphip_density_stage at kernel start)
+    LdsDouble dens_rows = nullptr;     // DENS: this wave's position row [ld] and gradient row [ld] in LDS (the leaf's evaluations)
     static constexpr int NVX = NV > 0 ? NV : 1;
     static constexpr int NSX = NV < 0 ? -NV : 1;   // NV = -NS: cache (sigma^2, grad, p, rho) of NS chunks per wave
     // kernel arguments, read through the constant address space: s_load into SGPRs (uniform), never flat
@@ -264,6 +270,8 @@ struct Machine {
         if (DENS) {   // (also in the machines the rare paths rebuild: the density is evaluated there too — initial point, step-size search)
             extern __shared__ __attribute__((aligned(16))) double s_dyn_dens[];
             dens_lds = (LdsDouble)s_dyn_dens + (size_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * a.dens_lds_doubles;
+            dens_shared = (LdsDouble)s_dyn_dens + (size_t)4 * a.dens_lds_doubles;
+            dens_rows = dens_shared + a.dens_shared_doubles + (size_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * 2 * ld;
         }
     }
 
@@ -521,11 +529,15 @@ struct Machine {
     // One evaluation of a REMOTE machine at the position in this chain's staging row: (logp, code), gradient in the gradient row.
     // Host callbacks: the rendezvous with the host.  Runtime-compiled densities: a call of the model's device function — the
     // wave's own stores of the position are made visible to all of its lanes first, the density's stores of the gradient after.
-    __device__ __forceinline__ void remote_eval(double& lp, int64_t& code) {
+    // (DENS, rows_in_lds: the leaf keeps the position and gradient rows of its evaluations in LDS — the density's accesses to
+    //  them are LDS accesses instead of L2 round trips; the rare paths use the staging rows in memory, as the callbacks do)
+    __device__ __forceinline__ void remote_eval(double& lp, int64_t& code, bool rows_in_lds = false) {
 #if NPHIP_JIT
         if (DENS) {
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-            lp = nphip_density(*(const NphipData*)A.dens_data, (int)D, A.qeval + (size_t)chain * D, A.geval + (size_t)chain * D, (double*)dens_lds, lane);
+            const double* xr = rows_in_lds ? (const double*)dens_rows : A.qeval + (size_t)chain * D;
+            double* gr = rows_in_lds ? (double*)(dens_rows + ld) : A.geval + (size_t)chain * D;
+            lp = nphip_density(*(const NphipData*)A.dens_data, (int)D, xr, gr, (double*)dens_lds, (const double*)dens_shared, lane);
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
             code = 0;
             return;
@@ -1177,10 +1189,16 @@ struct Machine {
         int64_t code_remote = 0;
         if (REMOTE) {
             // the evaluation is a remote call: position to the host's staging row, rendezvous, results back (remote_sync)
-            double* qe = A.qeval + (size_t)chain * D;
+            if (DENS) {
 #pragma unroll
-            for (int k = 0; k < NVX; ++k) if (k < nk) st2_dense(qe, ridx(k), D, X.q[k]);
-            remote_eval(lp_remote, code_remote);
+                for (int k = 0; k < NVX; ++k) if (k < nk) *(NPHIP_LDS double2*)(dens_rows + ridx(k)) = X.q[k];
+                remote_eval(lp_remote, code_remote, true);
+            } else {
+                double* qe = A.qeval + (size_t)chain * D;
+#pragma unroll
+                for (int k = 0; k < NVX; ++k) if (k < nk) st2_dense(qe, ridx(k), D, X.q[k]);
+                remote_eval(lp_remote, code_remote);
+            }
         } else {
             publish_edges(z);
         }
@@ -1188,7 +1206,11 @@ struct Machine {
 #pragma unroll
         for (int k = 0; k < NVX; ++k) if (k < nk) {
             double2 gg;
-            if (REMOTE) {
+            if (DENS) {
+                gg = *(const NPHIP_LDS double2*)(dens_rows + ld + ridx(k));
+                if (ridx(k) >= D) gg.x = 0.0;         // (the density writes grad[0 .. dim) only)
+                if (ridx(k) + 1 >= D) gg.y = 0.0;
+            } else if (REMOTE) {
                 gg = ld2_dense(A.geval + (size_t)chain * D, ridx(k), D);
             } else {
                 double2 a, b01;          // b01 = b_{i-1}, b_i ; b2 = b_{i+1}
@@ -2578,6 +2600,12 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) __attribute__((amdgpu_waves_
         if (threadIdx.x < 8) sp[3 * ld + threadIdx.x] = -0.0;
         __syncthreads();
     }
+#if NPHIP_JIT
+    if (REMOTE) {   // the model's shared LDS block: filled once per workgroup and launch, by all of its threads
+        nphip_density_stage(*(const NphipData*)A.dens_data, (double*)s_dyn + (size_t)4 * A.dens_lds_doubles, (int)threadIdx.x, (int)blockDim.x);
+        __syncthreads();
+    }
+#endif
     if (chain >= (int64_t)sl.chain_lo + sl.chain_n) return;
     if (REMOTE && !NPHIP_JIT) {
         // Roll call: chains of a resident launch wait for each other inside the kernel, so all of them must be on the device
@@ -2978,8 +3006,11 @@ __global__ __launch_bounds__(256) void k_density_batch(const NphipData* __restri
     extern __shared__ __attribute__((aligned(16))) double s_scratch[];
     const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint64_t chain = (uint64_t)blockIdx.x * 4 + wib;
+    nphip_density_stage(*data, s_scratch + (size_t)4 * lds_doubles, (int)threadIdx.x, (int)blockDim.x);
+    __syncthreads();
     if (chain >= n_chains) return;
-    const double lp = nphip_density(*data, dim, q + chain * (uint64_t)dim, grad + chain * (uint64_t)dim, s_scratch + (size_t)wib * lds_doubles, lane);
+    const double lp = nphip_density(*data, dim, q + chain * (uint64_t)dim, grad + chain * (uint64_t)dim, s_scratch + (size_t)wib * lds_doubles,
+                                    s_scratch + (size_t)4 * lds_doubles, lane);
     if (lane == 0) logp[chain] = lp;
 }
 }  // namespace nphip
@@ -2992,11 +3023,11 @@ int nphip_jit_launch(const nphip::Args* d_args, int max_evals, void* stream, con
 }
 int nphip_jit_nv(void) { return NPHIP_JIT_NV; }
 // nphip_device_logp_fn; user_data -> { device pointer of the data block, LDS doubles per wave }
-struct nphip_jit_batch_t { const void* data; int32_t lds_doubles, pad_; };
+struct nphip_jit_batch_t { const void* data; int32_t lds_doubles, shared_doubles; };
 int nphip_jit_logp(uint64_t n_chains, uint64_t dim, const double* q, double* grad, double* logp, void* stream, void* user_data) {
     const nphip_jit_batch_t* u = (const nphip_jit_batch_t*)user_data;
     if (!u) return -1;
-    hipLaunchKernelGGL(nphip::k_density_batch, dim3((unsigned)((n_chains + 3) / 4)), dim3(256), (size_t)4 * u->lds_doubles * sizeof(double), (hipStream_t)stream,
+    hipLaunchKernelGGL(nphip::k_density_batch, dim3((unsigned)((n_chains + 3) / 4)), dim3(256), ((size_t)4 * u->lds_doubles + u->shared_doubles) * sizeof(double), (hipStream_t)stream,
                        (const NphipData*)u->data, n_chains, (int)dim, q, grad, logp, (int)u->lds_doubles);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

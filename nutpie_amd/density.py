@@ -4,10 +4,16 @@ The reference turns a PyMC model into ONE compiled log-density function (``compi
 into a single vector function, numba- or JAX-compiled) plus the shared data it reads (``:239-269``), and swaps that data
 with ``with_data`` without recompiling (``:140-166``).  The GPU form of that is this module: the model is a HIP device function
 
-    __device__ double nphip_density(const NphipData& data, int dim, const double* x, double* grad, double* lds, int lane);
+    __device__ double nphip_density(const NphipData& data, int dim, const double* x, double* grad, double* lds, const double* shared, int lane);
 
 evaluated by one wavefront per chain — ``x[dim]`` the unconstrained position, ``grad[dim]`` receives the gradient, the return
-value is the log-density (the same in every lane), ``lds`` is per-chain scratch, ``data`` the model's arrays and scalars.  It is
+value is the log-density (the same in every lane), ``lds`` is per-chain scratch, ``data`` the model's arrays and scalars.
+Optionally (``lds_doubles_shared > 0``) the source also defines
+
+    __device__ void nphip_density_stage(const NphipData& data, double* shared, int thread, int n_threads);
+
+which all threads of a workgroup run once per launch to fill ``shared`` — LDS common to the workgroup's chains, typically the
+model's data: a lone wave waits out every L2 access of its density, LDS is ten times closer.  It is
 compiled with the ROCm compiler driver into the model's own instantiation of the engine's kernel (``kernels.hip`` part 7):
 the register-resident leaf of the fused models with the evaluation as a CALL in its middle — no kernel launch and no memory
 round trip of the chain state per gradient evaluation (``nphip_model_jit_density``).  The same library also exports the density
@@ -20,7 +26,8 @@ arrays and scalars (same names and kinds) and re-uses the compiled library.
 
 Helpers available to the density source: everything in ``include/nphip_spec.h`` (``nphip_exp``, ``nphip_log`` ... — the engine's
 reproducible elementary functions; ``exp`` / ``log`` of the HIP device library work too) and ``nphip_wave_sum(double)``, the sum
-over the 64 lanes in the engine's fixed order.
+over the 64 lanes in the engine's fixed order (``nphip_wave_sum3`` / ``nphip_wave_sum4``: several sums in one pass), and ``NPHIP_LDS_PTR(type, p)`` /
+``NPHIP_LDS_CPTR(type, p)`` to address ``lds`` / ``shared`` as LDS (``ds_read`` instead of flat loads).
 
 hiprtc is not used: the contract header includes the C standard headers, which hiprtc's built-in include set lacks; the
 compiler driver is the same one that builds the engine, with the same flags (``-ffp-contract=off``).
@@ -111,12 +118,20 @@ def generated_source(user_source: str, layout) -> str:
         "#include <hip/hip_runtime.h>",
         '#include "nphip_spec.h"',
         struct_source(layout),
-        "__device__ double nphip_density(const NphipData& data, int dim, const double* x, double* grad, double* lds, int lane);",
+        "__device__ double nphip_density(const NphipData& data, int dim, const double* x, double* grad, double* lds, const double* shared, int lane);",
+        "__device__ void nphip_density_stage(const NphipData& data, double* shared, int thread, int n_threads);",
         '#include "kernels.hip"',
         "// the engine's wave reduction (sum over the 64 lanes in the contract's order; the same value in every lane)",
+        "// `lds` and `shared` are LDS: through these casts the compiler emits ds_read / ds_write instead of flat accesses",
+        "#define NPHIP_LDS_PTR(type, p) ((__attribute__((address_space(3))) type*)(p))",
+        "#define NPHIP_LDS_CPTR(type, p) ((const __attribute__((address_space(3))) type*)(p))",
         "static __device__ __forceinline__ double nphip_wave_sum(double v) { return nphip::wave_sum(v); }",
+        "// several sums at once (the same bits as one nphip_wave_sum each, issued stage by stage: a lone wave otherwise waits out every step)",
+        "static __device__ __forceinline__ void nphip_wave_sum3(double& a, double& b, double& c) { double v[3] = {a, b, c}; nphip::wave_sumN(v); a = v[0]; b = v[1]; c = v[2]; }",
+        "static __device__ __forceinline__ void nphip_wave_sum4(double& a, double& b, double& c, double& d) { double v[4] = {a, b, c, d}; nphip::wave_sumN(v); a = v[0]; b = v[1]; c = v[2]; d = v[3]; }",
         "#line 1 \"density source\"",
         user_source,
+        "" if "nphip_density_stage" in user_source else "__device__ void nphip_density_stage(const NphipData&, double*, int, int) {}",
         "",
     ])
 
@@ -130,7 +145,7 @@ def compile_density(user_source: str, layout, ndim: int, *, verbose: bool = Fals
     h.update(src.encode())
     for d in deps:
         h.update(open(d, "rb").read())
-    flags = _FLAGS + ["-DNPHIP_JIT_DENSITY=1", "-DNPHIP_PART=7", f"-DNPHIP_JIT_NV={max(1, nv)}"]
+    flags = _FLAGS + ["-DNPHIP_JIT_DENSITY=1", "-DNPHIP_PART=7", f"-DNPHIP_JIT_NV={max(1, nv)}"] + os.environ.get("NUTPIE_AMD_JIT_FLAGS", "").split()
     h.update(" ".join(flags).encode())
     out = os.path.join(cache_dir(), f"density_{h.hexdigest()[:24]}.so")
     if os.path.exists(out):
@@ -150,7 +165,7 @@ def compile_density(user_source: str, layout, ndim: int, *, verbose: bool = Fals
 
 
 class _Batch(C.Structure):
-    _fields_ = [("data", C.c_void_p), ("lds_doubles", C.c_int32), ("pad_", C.c_int32)]
+    _fields_ = [("data", C.c_void_p), ("lds_doubles", C.c_int32), ("shared_doubles", C.c_int32)]
 
 
 class DensityLibrary:
@@ -202,7 +217,8 @@ class DensitySourceModel(CompiledModel):
     _source: str
     _n_dim: int
     _data: dict[str, Any]
-    _lds_bytes: int
+    _lds_bytes: Any      # bytes of LDS scratch per chain: an int, or a function of the data dict
+    _shared_bytes: Any   # bytes of LDS shared by a workgroup's chains: likewise
     _names: list[str]
     _shapes: list[tuple[int, ...]]
     _coords: dict[str, Any]
@@ -236,6 +252,10 @@ class DensitySourceModel(CompiledModel):
                 raise ValueError(f"Data variable {k} must stay a {_kind(self._data[k])}")
         return dataclasses.replace(self, _data={**self._data, **updates})
 
+    def _lds(self):
+        r = lambda v: int(v(self._data)) if callable(v) else int(v)  # noqa: E731
+        return r(self._lds_bytes), r(self._shared_bytes)
+
     def library(self) -> DensityLibrary:
         return DensityLibrary(compile_density(self._source, data_layout(self._data), self._n_dim))
 
@@ -247,10 +267,11 @@ class DensitySourceModel(CompiledModel):
             use_resident = False   # the divergence record needs the pre-step state in memory
         if self._n_dim > 1024:
             use_resident = False
+        lds_bytes, shared_bytes = self._lds()
         if use_resident:
-            model = _lib.JitDensityModel(self._n_dim, lib.launch_addr, lib.nv, dd.ptr, self._lds_bytes, keep_alive=(lib, dd))
+            model = _lib.JitDensityModel(self._n_dim, lib.launch_addr, lib.nv, dd.ptr, lds_bytes, shared_bytes, keep_alive=(lib, dd))
         else:
-            batch = _Batch(dd.ptr, self._lds_bytes // 8, 0)
+            batch = _Batch(dd.ptr, lds_bytes // 8, shared_bytes // 8)
             model = _lib.NativeDeviceCallbackModel(self._n_dim, lib.logp_addr, C.addressof(batch), keep_alive=(lib, dd, batch))
         if isinstance(self._init, str):
             model.set_init(self._init)
@@ -275,18 +296,27 @@ class DensitySourceModel(CompiledModel):
         return {name: np.asarray(flat[name]).reshape(n, T, *shape) for name, shape in zip(self._names, self._shapes)}
 
 
-def from_density_source(ndim: int, source: str, data: dict[str, Any] | None = None, *, lds_doubles_per_chain: int = 0,
+def _times8(v):
+    return (lambda data: 8 * int(v(data))) if callable(v) else 8 * int(v)
+
+
+def from_density_source(ndim: int, source: str, data: dict[str, Any] | None = None, *, lds_doubles_per_chain: int = 0, lds_doubles_shared: int = 0,
                         expand_fn: Callable | None = None, expanded_names: list[str] | None = None, expanded_shapes=None,
                         coords=None, dims=None, init="uniform", resident: bool = True, reparameterized_names=None) -> DensitySourceModel:
     """A model from the HIP source of its log-density (module docstring): ``source`` defines ``nphip_density``; ``data`` are the
-    arrays / scalars it reads through ``NphipData``; ``lds_doubles_per_chain`` the LDS scratch it uses.  ``expand_fn`` (optional)
+    arrays / scalars it reads through ``NphipData``; ``lds_doubles_per_chain`` the LDS scratch it uses per chain, ``lds_doubles_shared``
+    the LDS its ``nphip_density_stage`` fills once per workgroup (each an int or a function of the data dict: ``with_data`` may
+    change the sizes).  ``expand_fn`` (optional)
     maps a numpy block ``[N, ndim]`` of draws to the dict of expanded variables, as :func:`nutpie_amd.from_torchfunc` does."""
     if expanded_names is None:
         if expand_fn is not None:
             raise ValueError("expand_fn needs expanded_names and expanded_shapes")
         expanded_names, expanded_shapes = ["x"], [(ndim,)]
     if "nphip_density" not in source:
-        raise ValueError("the source must define `__device__ double nphip_density(const NphipData& data, int dim, const double* x, double* grad, double* lds, int lane)`")
-    return DensitySourceModel(dims=dict(dims or {}), _source=source, _n_dim=int(ndim), _data=dict(data or {}), _lds_bytes=8 * int(lds_doubles_per_chain),
+        raise ValueError("the source must define `__device__ double nphip_density(const NphipData& data, int dim, const double* x, double* grad, double* lds, "
+                         "const double* shared, int lane)`")
+    if lds_doubles_shared and "nphip_density_stage" not in source:
+        raise ValueError("lds_doubles_shared needs `__device__ void nphip_density_stage(const NphipData& data, double* shared, int thread, int n_threads)` in the source")
+    return DensitySourceModel(dims=dict(dims or {}), _source=source, _n_dim=int(ndim), _data=dict(data or {}), _lds_bytes=_times8(lds_doubles_per_chain), _shared_bytes=_times8(lds_doubles_shared),
                               _names=list(expanded_names), _shapes=[tuple(s) for s in expanded_shapes], _coords=dict(coords or {}),
                               _expand_func=expand_fn, _init=init, _resident=bool(resident), reparameterized_names=reparameterized_names)

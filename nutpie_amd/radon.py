@@ -173,79 +173,129 @@ def radon_model(data=None, device=0, use_graph=False, expand_on_device=True):
 
 # --------------------------------------------------------------------------------------------------------------------------
 # The same density as HIP source (nutpie_amd/density.py): compiled at run time into the model's own resident kernel.
-# One wavefront per chain; LDS scratch per chain: county effects [128] | county floor effects [128] | d lp / d mu per observation.
-# Arithmetic and summation order are those of the native callback kernel tests/fixtures/radon_device.hip (the round-2 form of
-# this model), so that the two produce the same floats.
+# One wavefront per chain; LDS scratch per chain: county effects [128] | county floor effects [128] | d lp / d mu per observation, twice;
+# the observations themselves are staged once per workgroup in LDS shared by its four chains (a lone wave waits out every L2 access).
+# The formulas are those of the native callback kernel tests/fixtures/radon_device.hip (the round-2 form of this model); the wave
+# sums use the engine's DPP reduction.
 # --------------------------------------------------------------------------------------------------------------------------
 RADON_MAX_COUNTIES = 128
 
 RADON_DENSITY_SOURCE = r"""
-static __device__ __forceinline__ double radon_wave_sum(double v) {
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+// the workgroup's shared LDS block: y[n_obs] | floor[n_obs] | county[n_obs], pos[n_obs], row_start[n + 1] as 32-bit integers
+// (pos[o] = where observation o sits when the observations are grouped by county: the per-county sums then read contiguous
+//  ranges instead of chasing an index per term)
+__device__ void nphip_density_stage(const NphipData& d, double* shared, int thread, int n_threads) {
+    const int n_obs = d.n_y, n = d.n_counties;
+    int* ints = (int*)(shared + 2 * n_obs);
+    for (int o = thread; o < n_obs; o += n_threads) {
+        shared[o] = d.y[o];
+        shared[n_obs + o] = d.floor[o];
+        ints[o] = d.county[o];
+        ints[n_obs + o] = d.pos[o];
+    }
+    for (int j = thread; j <= n; j += n_threads) ints[2 * n_obs + j] = d.row_start[j];
 }
 
-__device__ double nphip_density(const NphipData& d, int dim, const double* x, double* g, double* lds, int lane) {
+// A lone wave pays the full latency of every access it has to wait for (~100 cycles in LDS, several hundred in L2), so the loops
+// below first issue the independent reads of a few iterations and then compute.
+__device__ double nphip_density(const NphipData& d, int dim, const double* x, double* g, double* lds, const double* shared, int lane) {
     const int n = d.n_counties, n_obs = d.n_y;
-    double* eff = lds;              // [ce(n) | cfe(n)] then w[n_obs]
-    double* cfe = eff + 128;
-    double* w = eff + 256;
+    const auto y_ = NPHIP_LDS_CPTR(double, shared);
+    const auto floor_ = y_ + n_obs;
+    const auto county_ = NPHIP_LDS_CPTR(int, shared + 2 * n_obs);
+    const auto pos_ = county_ + n_obs;
+    const auto row_start_ = county_ + 2 * n_obs;
+    const auto eff = NPHIP_LDS_PTR(double, lds);   // [ce(n) | cfe(n)] then, grouped by county, w[n_obs] and (w * floor)[n_obs]
+    const auto cfe = eff + 128;
+    const auto ws = eff + 256;
+    const auto wfs = ws + n_obs;
     const int o_raw = 1, o_lsd = n, o_floor = n + 1, o_craw = n + 2, o_lcsd = 2 * n + 1, o_lsig = 2 * n + 2;
     const double intercept = x[0], fe = x[o_floor], lsd = x[o_lsd], lcsd = x[o_lcsd], lsig = x[o_lsig];
+    // the raw county vectors of this lane (n <= 128: at most two per lane)
+    double xa[2] = {0.0, 0.0}, xb[2] = {0.0, 0.0};
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int j = lane + 64 * t;
+        if (j < n - 1) { xa[t] = x[o_raw + j]; xb[t] = x[o_craw + j]; }
+    }
     const double sd = exp(lsd), csd = exp(lcsd), sig = exp(lsig), inv_sig = 1.0 / sig;
     const double c1 = 1.0 / (sqrt((double)n) + n), c2 = 1.0 / sqrt((double)n);
     // zero-sum extension of the two raw vectors (PyMC ZeroSumTransform.backward)
     double s_raw = 0.0, s_craw = 0.0, ss = 0.0;
-    for (int j = lane; j < n - 1; j += 64) {
-        const double a = x[o_raw + j], b = x[o_craw + j];
-        s_raw += a; s_craw += b; ss += a * a + b * b;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        if (lane + 64 * t < n - 1) { s_raw += xa[t]; s_craw += xb[t]; ss += xa[t] * xa[t] + xb[t] * xb[t]; }
     }
-    s_raw = radon_wave_sum(s_raw); s_craw = radon_wave_sum(s_craw); ss = radon_wave_sum(ss);
-    for (int j = lane; j < n; j += 64) {
-        const double e = (j < n - 1) ? x[o_raw + j] - s_raw * c1 : -s_raw * c2;
-        const double ce = (j < n - 1) ? x[o_craw + j] - s_craw * c1 : -s_craw * c2;
-        eff[j] = e * sd;
-        cfe[j] = ce * csd;
+    nphip_wave_sum3(s_raw, s_craw, ss);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int j = lane + 64 * t;
+        if (j < n) {
+            const double e = (j < n - 1) ? xa[t] - s_raw * c1 : -s_raw * c2;
+            const double ce = (j < n - 1) ? xb[t] - s_craw * c1 : -s_craw * c2;
+            eff[j] = e * sd;
+            cfe[j] = ce * csd;
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    // observations: residuals, d lp / d mu
+    // observations: residuals, d lp / d mu — four iterations' reads in flight at a time
     double rr = 0.0, sw = 0.0, swf = 0.0;
-    for (int o = lane; o < n_obs; o += 64) {
-        const int cty = d.county[o];
-        const double fl = d.floor[o];
-        const double mu = intercept + eff[cty] + fl * (fe + cfe[cty]);
-        const double r = (d.y[o] - mu) * inv_sig;
-        const double wo = r * inv_sig;
-        w[o] = wo;
-        rr += r * r; sw += wo; swf += wo * fl;
+    constexpr int U = 4;
+    for (int o0 = lane; o0 < n_obs; o0 += 64 * U) {
+        int cty[U], ps[U];
+        double fl[U], yy[U], e1[U], e2[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int o = o0 + 64 * u, oo = o < n_obs ? o : 0;
+            cty[u] = county_[oo]; ps[u] = pos_[oo]; fl[u] = floor_[oo]; yy[u] = y_[oo];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) { e1[u] = eff[cty[u]]; e2[u] = cfe[cty[u]]; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (o0 + 64 * u < n_obs) {
+                const double mu = intercept + e1[u] + fl[u] * (fe + e2[u]);
+                const double r = (yy[u] - mu) * inv_sig;
+                const double wo = r * inv_sig;
+                ws[ps[u]] = wo;
+                wfs[ps[u]] = wo * fl[u];
+                rr += r * r; sw += wo; swf += wo * fl[u];
+            }
+        }
     }
-    rr = radon_wave_sum(rr); sw = radon_wave_sum(sw); swf = radon_wave_sum(swf);
+    nphip_wave_sum3(rr, sw, swf);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    // per-county sums of w (county effect) and w * floor (county floor effect): one lane per county, fixed order
+    // per-county sums of w (county effect) and w * floor (county floor effect): one lane per county, contiguous ranges, fixed order
     double dot_e = 0.0, dot_c = 0.0, su_e = 0.0, su_c = 0.0;
     double ge_[2] = {0.0, 0.0}, gc_[2] = {0.0, 0.0};
-    for (int t = 0, j = lane; j < n; j += 64, ++t) {
-        double a = 0.0, b = 0.0;
-        for (int k = d.row_start[j]; k < d.row_start[j + 1]; ++k) {
-            const int o = d.row_obs[k];
-            a += w[o];
-            b += w[o] * d.floor[o];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int j = lane + 64 * t;
+        if (j < n) {
+            double a = 0.0, b = 0.0;
+            const int k0 = row_start_[j], k1 = row_start_[j + 1];
+#pragma unroll 4
+            for (int k = k0; k < k1; ++k) { a += ws[k]; b += wfs[k]; }
+            ge_[t] = a; gc_[t] = b;
+            const double ext = eff[j] / sd, cext = cfe[j] / csd;
+            dot_e += ext * a; dot_c += cext * b;
+            if (j < n - 1) { su_e += a * sd; su_c += b * csd; }
         }
-        ge_[t] = a; gc_[t] = b;
-        const double ext = eff[j] / sd, cext = cfe[j] / csd;
-        dot_e += ext * a; dot_c += cext * b;
-        if (j < n - 1) { su_e += a * sd; su_c += b * csd; }
     }
-    dot_e = radon_wave_sum(dot_e); dot_c = radon_wave_sum(dot_c); su_e = radon_wave_sum(su_e); su_c = radon_wave_sum(su_c);
+    nphip_wave_sum4(dot_e, dot_c, su_e, su_c);
     // last county's (scaled) gradient, needed by the transpose of the extension
     const int last_lane = (n - 1) & 63, last_t = (n - 1) >> 6;
     const double gl_e = __shfl(last_t == 0 ? ge_[0] : ge_[1], last_lane, 64) * sd;
     const double gl_c = __shfl(last_t == 0 ? gc_[0] : gc_[1], last_lane, 64) * csd;
-    for (int t = 0, j = lane; j < n - 1; j += 64, ++t) {
-        g[o_raw + j] = (ge_[t] * sd - (c1 * su_e + c2 * gl_e)) - x[o_raw + j];
-        g[o_craw + j] = (gc_[t] * csd - (c1 * su_c + c2 * gl_c)) - x[o_craw + j];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int j = lane + 64 * t;
+        if (j < n - 1) {
+            g[o_raw + j] = (ge_[t] * sd - (c1 * su_e + c2 * gl_e)) - xa[t];
+            g[o_craw + j] = (gc_[t] * csd - (c1 * su_c + c2 * gl_c)) - xb[t];
+        }
     }
     if (lane == 0) {
         g[0] = -0.01 * intercept + sw;
@@ -261,8 +311,8 @@ __device__ double nphip_density(const NphipData& d, int dim, const double* x, do
 
 
 def radon_density_data(data=None):
-    """The ``data`` dict of the HIP-source radon model: the observations plus a CSR list of each county's observations (the
-    per-county gradient sums are taken by one lane per county, in a fixed order)."""
+    """The ``data`` dict of the HIP-source radon model: the observations, and their grouping by county (the per-county gradient
+    sums are taken by one lane per county over a contiguous range, in a fixed order)."""
     data = data or synthetic_radon_data()
     county = np.asarray(data["county_idx"], dtype=np.int32)
     n = int(county.max()) + 1
@@ -270,9 +320,10 @@ def radon_density_data(data=None):
         raise ValueError(f"the radon density source holds up to {RADON_MAX_COUNTIES} counties in its LDS scratch")
     counts = np.bincount(county, minlength=n)
     row_start = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
-    row_obs = np.argsort(county, kind="stable").astype(np.int32)
+    pos = np.empty(len(county), dtype=np.int32)
+    pos[np.argsort(county, kind="stable")] = np.arange(len(county), dtype=np.int32)   # where observation o sits, grouped by county
     return {"county": county, "floor": np.asarray(data["floor"], dtype=np.float64), "y": np.asarray(data["log_radon"], dtype=np.float64),
-            "row_start": row_start, "row_obs": row_obs, "n_counties": n}
+            "row_start": row_start, "pos": pos, "n_counties": n}
 
 
 def radon_density_model(data=None, resident=True):
@@ -302,5 +353,10 @@ def radon_density_model(data=None, resident=True):
     names = ["intercept", "county_raw", "county_sd", "county_effect", "floor_effect", "county_floor_raw", "county_floor_sd", "county_floor_effect", "sigma"]
     shapes = [(), (n,), (), (n,), (), (n,), (), (n,), ()]
     dims = {k: ("county",) for k in ("county_raw", "county_effect", "county_floor_raw", "county_floor_effect")}
-    return from_density_source(D, RADON_DENSITY_SOURCE, dd, lds_doubles_per_chain=2 * RADON_MAX_COUNTIES + len(dd["y"]), expand_fn=expand,
+    def shared_doubles(d):   # y | floor | (county, pos, row_start) as 32-bit integers
+        n_obs = len(d["y"])
+        return 2 * n_obs + (2 * n_obs + int(d["n_counties"]) + 1 + 1) // 2
+
+    return from_density_source(D, RADON_DENSITY_SOURCE, dd, lds_doubles_per_chain=lambda d: 2 * RADON_MAX_COUNTIES + 2 * len(d["y"]),
+                               lds_doubles_shared=shared_doubles, expand_fn=expand,
                                expanded_names=names, expanded_shapes=shapes, coords={"county": np.arange(n)}, dims=dims, resident=resident)

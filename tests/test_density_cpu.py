@@ -54,4 +54,4 @@ def test_density_library_cross_compiles_and_exports_its_entry_points(tmp_path, m
         assert hasattr(lib, sym), sym
     assert lib.nphip_jit_nv() == 2            # 173 dimensions: two chunks of 128
     with pytest.raises(RuntimeError, match="compiling the density failed"):
-        density.compile_density("__device__ double nphip_density(const NphipData& d, int dim, const double* x, double* g, double* l, int lane) { return nope; }", [], 2)
+        density.compile_density("__device__ double nphip_density(const NphipData& d, int dim, const double* x, double* g, double* l, const double* sh, int lane) { return nope; }", [], 2)

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 HALFNORMAL_SOURCE = r"""
 // HalfNormal(1) on the log scale (the density of the reference's golden-vector tests): D = 1
-__device__ double nphip_density(const NphipData& d, int dim, const double* x, double* grad, double* lds, int lane) {
+__device__ double nphip_density(const NphipData& d, int dim, const double* x, double* grad, double* lds, const double* shared, int lane) {
     const double e = exp(2.0 * x[0]);
     if (lane == 0) grad[0] = d.scale * (1.0 - e);
     return d.scale * (x[0] - 0.5 * e);
@@ -25,7 +25,7 @@ __device__ double nphip_density(const NphipData& d, int dim, const double* x, do
 
 STD_NORMAL_SOURCE = r"""
 // N(0, diag(sd^2)): uses the engine's wave reduction and per-chain LDS scratch
-__device__ double nphip_density(const NphipData& d, int dim, const double* x, double* grad, double* lds, int lane) {
+__device__ double nphip_density(const NphipData& d, int dim, const double* x, double* grad, double* lds, const double* shared, int lane) {
     double acc = 0.0;
     for (int i = lane; i < dim; i += 64) {
         const double z = x[i] / d.sd[i];
@@ -86,7 +86,7 @@ def test_radon_density_against_the_torch_density_and_posterior(hip):
     x = torch.randn(41, D, dtype=torch.float64, device="cuda") * 0.4
     g = torch.empty_like(x)
     lp = torch.empty(41, dtype=torch.float64, device="cuda")
-    batch = density._Batch(dd.ptr, m._lds_bytes // 8, 0)
+    batch = density._Batch(dd.ptr, m._lds()[0] // 8, m._lds()[1] // 8)
     call = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p)(lib.logp_addr)
     assert call(41, D, x.data_ptr(), g.data_ptr(), lp.data_ptr(), 0, ctypes.addressof(batch)) == 0
     torch.cuda.synchronize()
@@ -137,7 +137,7 @@ def test_fallbacks_and_errors(hip):
     tr = nutpie_amd.sample(m, chains=8, tune=60, draws=20, seed=3, progress_bar=False, store_divergences=True, max_energy_error=2.0)
     assert "divergence_start" in tr.warmup_sample_stats
     with pytest.raises(RuntimeError, match="compiling the density failed"):
-        nutpie_amd.from_density_source(2, "__device__ double nphip_density(const NphipData& d, int dim, const double* x, double* g, double* l, int lane) { return nope; }").library()
+        nutpie_amd.from_density_source(2, "__device__ double nphip_density(const NphipData& d, int dim, const double* x, double* g, double* l, const double* sh, int lane) { return nope; }").library()
     with pytest.raises(ValueError, match="nphip_density"):
         nutpie_amd.from_density_source(2, "int x;")
     with pytest.raises(RuntimeError, match="LDS scratch"):
