@@ -250,6 +250,16 @@ int64_t nphip_sampler_waiting(nphip_sampler_t*, uint8_t* mask);
  * on with its next draw; draw counter, trace and RNG streams continue.  What the host changed in between (e.g. the linear
  * map a wrapped model applies) is the host's business.  Manual-mode samplers only (the caller drives nphip_sampler_step). */
 int nphip_sampler_resume_at(nphip_sampler_t*, uint64_t n, const uint64_t* local_chains, const double* positions, int on_device);
+/* Low-rank metric (reference: the mass matrix of adaptation="low_rank", src/wrapper.rs:307-334, python/nutpie/sample.py:921-933,
+ * docs/sampling-options.qmd:124-144):  M^-1 = D^1/2 (I + V (Lambda - I) V') D^1/2  with D = diag(sigma^2), V = k <= 16 orthonormal
+ * columns, Lambda their eigenvalues.  With the boolean setting `low_rank_metric` the engine integrates, draws momenta and tests
+ * U-turns under such a metric (memory-resident kernels; every model flavour).  The metric of a chain is supplied by the host at
+ * the pause draws: sigma2[n][dim], V[n][k][dim] (row j = column j of V), lambda[n][k], host or device memory.  The chain keeps its
+ * position, runs a step-size search under the new metric and goes on with its next draw; its own diagonal adaptation is off
+ * from then on.  Until the first call a chain runs on the diagonal metric it adapts itself, exactly as without the setting.
+ * Manual-mode samplers only.  The window estimator that produces (sigma2, V, lambda) lives above the C-ABI (nutpie_amd/low_rank.py). */
+int nphip_sampler_set_metric(nphip_sampler_t*, uint64_t n, const uint64_t* local_chains, uint64_t k, const double* sigma2, const double* V,
+                             const double* lambda, int on_device);
 /* Developer aid: per-section cycle counters summed over chains; all zero unless the library was built
  * with -DNPHIP_PROFILE.  [0] leapfrog cycles [1] tree cycles (hot) [2] draw-end cycles [3..5] their counts. */
 int nphip_sampler_profile(nphip_sampler_t*, int64_t out[16]);

@@ -160,6 +160,7 @@ def lib():
             L.nphip_sampler_waiting.argtypes = [C.c_void_p, C.c_void_p]
             L.nphip_sampler_waiting.restype = C.c_int64
             L.nphip_sampler_resume_at.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int]
+            L.nphip_sampler_set_metric.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
             L.nphip_launch_defaults.argtypes = [C.POINTER(_Launch)]
             L.nphip_default_evals_per_launch.argtypes = [C.c_uint64]
             L.nphip_abi_struct_size.restype = C.c_uint64
@@ -207,7 +208,7 @@ def _check_setting(rc: int):
 _BOOL_KEYS = {
     "check_turning", "store_mass_matrix", "use_grad_based_mass_matrix", "store_unconstrained", "store_gradient",
     "store_transformed", "store_divergences", "train_on_orbit", "microcanonical_trajectory",
-    "exact_normal_trajectory", "adapt_mass_matrix",
+    "exact_normal_trajectory", "adapt_mass_matrix", "low_rank_metric",
 }
 _U64_KEYS = {
     "num_tune", "num_draws", "num_chains", "maxdepth", "mindepth", "window_switch_freq", "mass_matrix_switch_freq",
@@ -776,6 +777,31 @@ class PySampler:
             pos = np.ascontiguousarray(positions, dtype=np.float64)
             assert pos.shape == (len(ch), self.dim)
             rc = lib().nphip_sampler_resume_at(self._h, C.c_uint64(len(ch)), ch.ctypes.data_as(C.c_void_p), pos.ctypes.data_as(C.c_void_p), 0)
+        if rc != NPHIP_OK:
+            raise RuntimeError(_err())
+
+    def set_metric(self, chains, sig2, V=None, lam=None):
+        """A new metric ``M^-1 = D^1/2 (I + V (Lambda - I) V') D^1/2`` for chains stopped at a pause draw (settings
+        ``low_rank_metric``): ``sig2[n, dim]``, ``V[n, k, dim]`` (row j = column j of V), ``lam[n, k]`` — numpy arrays or CUDA
+        tensors.  The chains keep their positions, re-run the step-size search and go on."""
+        self._require()
+        ch = np.ascontiguousarray(chains, dtype=np.uint64)
+        n, d = len(ch), self.dim
+        on_device = hasattr(sig2, "data_ptr")
+        if on_device:
+            arrs = [sig2.contiguous(), None if V is None else V.contiguous(), None if lam is None else lam.contiguous()]
+            k = 0 if V is None else int(arrs[1].shape[1])
+            assert tuple(arrs[0].shape) == (n, d) and all(str(a.dtype) == "torch.float64" for a in arrs if a is not None)
+            ptrs = [C.c_void_p(a.data_ptr()) if a is not None else None for a in arrs]
+        else:
+            arrs = [np.ascontiguousarray(sig2, dtype=np.float64), None if V is None else np.ascontiguousarray(V, dtype=np.float64),
+                    None if lam is None else np.ascontiguousarray(lam, dtype=np.float64)]
+            k = 0 if V is None else int(arrs[1].shape[1])
+            assert arrs[0].shape == (n, d)
+            ptrs = [a.ctypes.data_as(C.c_void_p) if a is not None else None for a in arrs]
+        if k:
+            assert tuple(arrs[1].shape) == (n, k, d) and tuple(arrs[2].shape) == (n, k)
+        rc = lib().nphip_sampler_set_metric(self._h, C.c_uint64(n), ch.ctypes.data_as(C.c_void_p), C.c_uint64(k), ptrs[0], ptrs[1], ptrs[2], int(on_device))
         if rc != NPHIP_OK:
             raise RuntimeError(_err())
 

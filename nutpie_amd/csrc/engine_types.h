@@ -9,6 +9,7 @@
 namespace nphip {
 
 constexpr int kMaxDepthCap = 16;  // settings.maxdepth <= 16 (2^16 leapfrogs per draw)
+constexpr int kLrMax = 16;        // columns of the low-rank part of the metric, at most
 
 // ---- phases of the per-chain state machine (Ctl::phase) -------------------------------
 enum Phase : int64_t {
@@ -20,6 +21,7 @@ enum Phase : int64_t {
     PH_DONE = 5,
     PH_ERROR = 6,
     PH_WAIT_HOST = 7,  // stopped after a draw listed in DevSettings::pause_draws: the host re-parametrises the chain and resumes it
+    PH_RESUME_SS = 8,  // resumed by the host with a new metric at the same position: step-size search, then the next draw
 };
 
 enum ChainError : int64_t {
@@ -84,6 +86,10 @@ struct Ctl {
     double fin_eerr;
     // lean register kernels: (A.first, T.first) of the level-1 merge the next leaf will check, evaluated one leaf early
     int64_t pre_turn;
+    // low-rank metric (nphip_sampler_set_metric): 0 = the chain still runs on the diagonal metric it adapts itself; 1 = the host
+    // supplied (sigma^2, V, lambda) — M^-1 = D^1/2 (I + V (Lambda - I) V') D^1/2 with lr_k columns — and the chain's own
+    // mass-matrix adaptation is off
+    int64_t host_metric, lr_k;
     // resident host-callback launches (k_advance<..., REMOTE>): the evaluation this chain publishes next, whether the host
     // has asked the launch to end at the next boundary, and the group it reports to (set at kernel start; transient)
     int64_t hs_seq, hs_last, hs_grp, hs_n, hs_wgn, hs_box;
@@ -115,6 +121,7 @@ struct DevSettings {
     int32_t adapt_adam, pad1_;
     int32_t init_kind, num_try_init;
     int32_t store_draws, store_gradient, store_mass_matrix, store_divergences;
+    int32_t low_rank_metric, pad3_;   // the host may replace a chain's metric at the pause draws (nphip_sampler_set_metric)
     // host-driven adaptation (low-rank metric as a linear re-parametrisation, nutpie_amd/low_rank.py): a chain stops
     // (PH_WAIT_HOST) when it has finished exactly pause_draws[i] draws
     int32_t n_pause, pad2_;
@@ -173,6 +180,13 @@ struct Args {
                                             // group's last arriver; of group 0 also [1] roll-call verdict, [2] roll-call count
     // runtime-compiled device densities (nphip_model_jit_density): the density is a device function compiled into its own
     // instantiation of k_advance; an evaluation is a call in the middle of the register-resident leaf (kernels.hip: density_eval)
+    // low-rank metric (settings.low_rank_metric: memory-resident kernels only): P-slots carry a third vector, the velocity
+    // v = M^-1 p of the state, which the U-turn criteria read instead of recomputing sigma^2 p
+    int32_t pvec;          // vectors per P-slot: 2 (p, rho) or 3 (p, rho, v)
+    int32_t lr_on;         // the job may receive host metrics: lr_V / lr_lam / lr_std are allocated
+    double* lr_V;          // [n][kLrMax][ld]  orthonormal columns (rows here), zero beyond dim and beyond lr_k
+    double* lr_lam;        // [n][kLrMax]      eigenvalues
+    double* lr_std;        // [n][ld]          sqrt(sigma^2)
     const void* dens_data;       // the model's data block (device memory; layout defined by the generated prelude of the density source)
     int32_t dens_lds_doubles;    // LDS scratch per wave the density asked for, in doubles (dynamic LDS of the launch)
     int32_t dens_shared_doubles; // LDS shared by the chains of a workgroup (the model's data staged once per launch: nphip_density_stage)

@@ -29,6 +29,7 @@
 namespace nphip {
 hipError_t launch_advance(const Args& a, const Args* d_args, bool fused, int W, hipStream_t st, const LaunchSlice* slice = nullptr);
 hipError_t launch_resume(const Args* d_args, int n, const int64_t* d_chains, const double* d_pos, bool fused, hipStream_t st);
+hipError_t launch_set_metric(const Args* d_args, int n, const int64_t* d_chains, int k, const double* sig2, const double* V, const double* lam, hipStream_t st);
 hipError_t launch_remote(const Args* d_args, int W, int nv, hipStream_t st, const LaunchSlice& sl);
 hipError_t launch_test_detmath(int fn, uint64_t n, const double* x, double* y, hipStream_t st);
 hipError_t launch_test_dot(int W, uint64_t n, const double* x, const double* y, double* out, hipStream_t st);
@@ -74,6 +75,7 @@ struct nphip_settings {
     bool adapt_mass_matrix = true;
     uint64_t num_try_init = 100;
     std::vector<uint64_t> pause_draws;   // host-driven adaptation hook (nphip_settings_set_pause_draws)
+    bool low_rank_metric = false;        // the host may replace a chain's metric at the pause draws (nphip_sampler_set_metric)
 };
 
 static int unknown_attr(const char* name) {
@@ -170,6 +172,7 @@ int nphip_settings_set_bool(nphip_settings_t* s, const char* name, int v) {
         if (b) return bad_value(std::string(name) + " is not supported by the HIP engine");
     }
     else if (n == "adapt_mass_matrix") s->adapt_mass_matrix = b;
+    else if (n == "low_rank_metric") s->low_rank_metric = b;
     else return unknown_attr(name);
     return NPHIP_OK;
 }
@@ -747,6 +750,9 @@ bool nphip_sampler::setup() {
     fused = model.kind == 0;
     dens = model.kind == 3;
     W = dens ? 1 : (launch.waves_per_chain ? launch.waves_per_chain : choose_waves(dim));
+    const bool lrm = set.low_rank_metric;
+    if (lrm && dens) { set_error("the low-rank metric runs on the memory-resident kernels: use the batched device callback of the density's library"); return false; }
+    if (lrm) launch.no_register_kernel = 1;   // (P-slots carry the velocity as a third vector: memory-resident kernels only)
     if (dens && set.store_divergences) {
         set_error("store_divergences needs the pre-step state in memory: use the batched device callback of the density's library (launch per evaluation)");
         return false;
@@ -837,14 +843,18 @@ bool nphip_sampler::setup() {
     }
     // memory-resident fused kernel, one wave per chain (store_divergences, no_register_kernel): cache the cursor's
     // (sigma^2, grad, p, rho) in VGPRs between leaves.  With more waves per chain the cache costs occupancy (measured).
-    args.stream_cache = (fused && !args.reg_nv && W == 1 && !launch.no_stream_cache && args.ld / 128 <= 8) ? 1 : 0;
+    args.stream_cache = (fused && !args.reg_nv && W == 1 && !launch.no_stream_cache && args.ld / 128 <= 8 && !lrm) ? 1 : 0;
+    args.pvec = lrm ? 3 : 2;
+    args.lr_on = lrm ? 1 : 0;
+    s.low_rank_metric = lrm ? 1 : 0;
 
     // D > 4096 (one chain per CU): sigma^2 of the chain in LDS instead of one more HBM stream per pass
     args.sig_lds = (fused && !args.reg_nv && W >= 8 && args.ld * 8 <= 128 * 1024 && !launch.no_stream_cache) ? 1 : 0;
 
     if (!dalloc(&args.ctl, n)) return false;
     if (!dalloc(&args.qpool, n * args.nqpool * 2 * ld)) return false;
-    if (!dalloc(&args.pslots, n * args.npslots * 2 * ld)) return false;
+    if (!dalloc(&args.pslots, n * args.npslots * (size_t)args.pvec * ld)) return false;
+    if (lrm && (!dalloc(&args.lr_V, n * (size_t)kLrMax * ld) || !dalloc(&args.lr_lam, n * (size_t)kLrMax) || !dalloc(&args.lr_std, n * ld))) return false;
     if (!dalloc(&args.sig2, n * ld)) return false;
     if (!dalloc(&args.est, n * 8 * ld)) return false;
     if (!dalloc(&args.counters, 4)) return false;
@@ -916,7 +926,7 @@ bool nphip_sampler::setup() {
                 // (above 4 MB of positions per step the job is bound by PCIe traffic either way, and launches per evaluation were 15 %
                 //  faster at 1024 chains x 1000 dimensions: resident only when asked for)
                 remote = (W == 1 || W == 2 || W == 4) && remote_nv <= 8 && (int64_t)remote_nv * W * 128 == args.ld && n * (uint64_t)W <= 1024 &&
-                         launch.host_persist != 1 && !launch.no_register_kernel &&
+                         launch.host_persist != 1 && !launch.no_register_kernel && !lrm &&
                          !set.store_divergences && set.pause_draws.empty() && (n * dim * 8 <= (4u << 20) || launch.host_persist > 1);
                 persist_evals = launch.host_persist > 1 ? launch.host_persist : 256;
                 if (launch.host_persist < 0) { fall_back_after = -(int64_t)launch.host_persist; persist_evals = 7; }
@@ -1789,6 +1799,36 @@ int nphip_sampler_resume_at(nphip_sampler_t* s, uint64_t n, const uint64_t* chai
     if (d_pos) (void)hipFree(d_pos);
     // callback models: the staged positions changed after the last evaluation — the next launch must not consume its results
     s->manual_have = 0;
+    return ok ? NPHIP_OK : NPHIP_ERR;
+}
+
+int nphip_sampler_set_metric(nphip_sampler_t* s, uint64_t n, const uint64_t* chains, uint64_t k, const double* sig2, const double* V, const double* lam,
+                             int on_device) {
+    if (!s->manual) { set_error("nphip_sampler_set_metric needs a sampler created with launch.manual = 1"); return NPHIP_ERR; }
+    if (!s->set.low_rank_metric) { set_error("the sampler was not created for host-supplied metrics (settings: low_rank_metric)"); return NPHIP_ERR; }
+    if (k > (uint64_t)kLrMax) { set_error("at most " + std::to_string(kLrMax) + " low-rank columns"); return NPHIP_ERR; }
+    if (n == 0) return NPHIP_OK;
+    if (!sig2 || (k > 0 && (!V || !lam))) { set_error("set_metric needs sigma^2, and V and lambda when k > 0"); return NPHIP_ERR; }
+    for (uint64_t i = 0; i < n; ++i)
+        if (chains[i] >= s->n) { set_error("chain index out of range"); return NPHIP_ERR; }
+    std::lock_guard<std::mutex> run_lk(s->mu_run);
+    (void)hipSetDevice(s->device);
+    if (!s->sync_all()) return NPHIP_ERR;
+    std::vector<int64_t> ch(chains, chains + n);
+    int64_t* d_ch = nullptr;
+    double *d_s = nullptr, *d_v = nullptr, *d_l = nullptr;
+    const size_t bs = n * s->dim * 8, bv = n * k * s->dim * 8, bl = n * k * 8;
+    bool ok = hip_ok(hipMalloc((void**)&d_ch, n * 8), "hipMalloc") && hip_ok(hipMemcpy(d_ch, ch.data(), n * 8, hipMemcpyHostToDevice), "H2D chains");
+    if (ok && !on_device) {
+        ok = hip_ok(hipMalloc((void**)&d_s, bs), "hipMalloc") && hip_ok(hipMemcpy(d_s, sig2, bs, hipMemcpyHostToDevice), "H2D sigma^2");
+        if (ok && k > 0)
+            ok = hip_ok(hipMalloc((void**)&d_v, bv), "hipMalloc") && hip_ok(hipMemcpy(d_v, V, bv, hipMemcpyHostToDevice), "H2D V") &&
+                 hip_ok(hipMalloc((void**)&d_l, bl), "hipMalloc") && hip_ok(hipMemcpy(d_l, lam, bl, hipMemcpyHostToDevice), "H2D lambda");
+    }
+    if (ok) ok = hip_ok(launch_set_metric(s->d_args, (int)n, d_ch, (int)k, on_device ? sig2 : d_s, on_device ? V : d_v, on_device ? lam : d_l, s->stream),
+                        "launch k_set_metric") && hip_ok(hipStreamSynchronize(s->stream), "hipStreamSynchronize");
+    for (void* q : {(void*)d_ch, (void*)d_s, (void*)d_v, (void*)d_l}) if (q) (void)hipFree(q);
+    s->manual_have = 0;   // (callback models: the staged evaluation belongs to the state before the pause)
     return ok ? NPHIP_OK : NPHIP_ERR;
 }
 

@@ -263,7 +263,7 @@ struct Machine {
         wave = (W == 1) ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
         D = a.dim; ld = a.ld; nch = ld / NPHIP_CHUNK;
         qp = a.qpool + (size_t)ch * a.nqpool * 2 * ld;
-        pp = a.pslots + (size_t)ch * a.npslots * 2 * ld;
+        pp = a.pslots + (size_t)ch * a.npslots * (NV == 0 ? (size_t)a.pvec : (size_t)2) * ld;
         sig2 = a.sig2 + (size_t)ch * ld;
         est = a.est + (size_t)ch * 8 * ld;
         T = a.s.num_tune + a.s.num_draws;
@@ -277,8 +277,14 @@ struct Machine {
 
     __device__ __forceinline__ double* Q(int64_t b) const { return qp + (size_t)b * 2 * ld; }
     __device__ __forceinline__ double* G(int64_t b) const { return qp + (size_t)b * 2 * ld + ld; }
-    __device__ __forceinline__ double* P(int64_t s) const { return pp + (size_t)s * 2 * ld; }
-    __device__ __forceinline__ double* R(int64_t s) const { return pp + (size_t)s * 2 * ld + ld; }
+    // vectors per P-slot: (p, rho), and with the low-rank metric (memory-resident kernels only) the velocity v = M^-1 p as well
+    __device__ __forceinline__ size_t pvec() const { return NV == 0 ? (size_t)A.pvec : (size_t)2; }
+    __device__ __forceinline__ double* P(int64_t s) const { return pp + (size_t)s * pvec() * ld; }
+    __device__ __forceinline__ double* R(int64_t s) const { return pp + (size_t)s * pvec() * ld + ld; }
+    __device__ __forceinline__ double* VEL(int64_t s) const { return pp + (size_t)s * pvec() * ld + 2 * ld; }
+    static constexpr bool LRK = NV == 0;   // kernels that can run the low-rank metric
+    __device__ __forceinline__ bool lr_job() const { return LRK && A.lr_on != 0; }
+    __device__ __forceinline__ const double* LRV(int j) const { return A.lr_V + ((size_t)chain * kLrMax + j) * ld; }
     __device__ __forceinline__ double* EST(int64_t e, int k) const { return est + (size_t)(e * 4 + k) * ld; }
     __device__ __forceinline__ bool leader() const { return lane == 0 && wave == 0; }
     // chain-wide sums.  Consecutive reductions alternate between two LDS areas: by the time an area is written again
@@ -382,8 +388,99 @@ struct Machine {
         c->eval_buf = 0;
     }
 
+    // ---- low-rank metric M^-1 = D^1/2 (I + V (Lambda - I) V') D^1/2  (reference: src/wrapper.rs:307-334, the mass matrix of
+    // adaptation="low_rank"; D = diag(sigma^2), V: lr_k orthonormal columns, Lambda their eigenvalues).  The contract, shared
+    // with the oracle (Hamiltonian::velocity):
+    //     u = std * p ;  d_j = <V_j, u> (the contract's dot) ;  c_j = (lambda_j - 1) * d_j ;
+    //     w = u, then w = fma(V_j, c_j, w) for j = 0 .. k-1 ;  v = std * w
+    // and for the momentum draw  p = (z + sum_j V_j f_j) * sqrt(1 / sigma^2),  f_j = (1 / sqrt(lambda_j) - 1) * <V_j, z>.
+    // k dots of one vector: accumulate (pass over this wave's chunks), then two 8-value reductions.
+    struct LrAcc { double2 a[kLrMax]; };
+    __device__ __forceinline__ void lr_zero(LrAcc& S_) const {
+#pragma unroll
+        for (int j = 0; j < kLrMax; ++j) { S_.a[j].x = 0.0; S_.a[j].y = 0.0; }
+    }
+    __device__ __forceinline__ void lr_acc(LrAcc& S_, int k, int64_t i, const double2 u) const {
+#pragma unroll
+        for (int j = 0; j < kLrMax; ++j) if (j < k) {
+            const double2 vj = ld2(LRV(j), i);
+            S_.a[j].x = fma(vj.x, u.x, S_.a[j].x);
+            S_.a[j].y = fma(vj.y, u.y, S_.a[j].y);
+        }
+    }
+    // dots -> coefficients: which = 0: c_j = (lambda_j - 1) d_j (velocity); 1: f_j = (1 / sqrt(lambda_j) - 1) d_j (momentum draw)
+    __device__ __forceinline__ void lr_coef(const LrAcc& S_, int k, int which, double (&cf)[kLrMax]) {
+        double v0[8], v1[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { v0[j] = S_.a[j].x + S_.a[j].y; v1[j] = S_.a[j + 8].x + S_.a[j + 8].y; }
+        rsum(v0);
+        if (k > 8) rsum(v1);
+#pragma unroll
+        for (int j = 0; j < kLrMax; ++j) {
+            const double d = j < 8 ? v0[j] : v1[j - 8];
+            const double lam = j < k ? A.lr_lam[(size_t)chain * kLrMax + j] : 1.0;
+            cf[j] = j < k ? (which == 0 ? (lam - 1.0) * d : (1.0 / sqrt(lam) - 1.0) * d) : 0.0;
+        }
+    }
+    __device__ __forceinline__ double2 lr_apply(int k, int64_t i, double2 w, const double (&cf)[kLrMax]) const {
+#pragma unroll
+        for (int j = 0; j < kLrMax; ++j) if (j < k) {
+            const double2 vj = ld2(LRV(j), i);
+            w.x = fma(vj.x, cf[j], w.x);
+            w.y = fma(vj.y, cf[j], w.y);
+        }
+        return w;
+    }
+
+    // Momentum refresh with the low-rank metric; also writes the velocity of the new state.  Returns K.
+    __device__ double sample_momentum_lr(uint32_t purpose, uint32_t id) {
+        double *p = P(kSlotInit), *r = R(kSlotInit), *vv = VEL(kSlotInit);
+        const int k = (int)c->lr_k;
+        const double* sd = A.lr_std + (size_t)chain * ld;
+        LrAcc S_;
+        double cf[kLrMax];
+        lr_zero(S_);
+        NPHIP_FOR_CHUNKS(i) {   // z (parked in the p vector) and its products with the columns
+            double2 z = {0.0, 0.0};
+            if (i < D) {
+                nphip_normal_pair(nphip_philox(A.s.seed, (uint32_t)(i >> 1), gchain, id, purpose), &z.x, &z.y);
+                if (i + 1 >= D) z.y = 0.0;
+            }
+            st2(p, i, z);
+            lr_acc(S_, k, i, z);
+        }
+        lr_coef(S_, k, 1, cf);
+        lr_zero(S_);
+        NPHIP_FOR_CHUNKS(i) {   // p, rho = p, and the products of u = std p
+            const double2 z = ld2(p, i), s2 = ld2(sig2, i), s1 = ld2(sd, i);
+            double2 w = lr_apply(k, i, z, cf), pv, u;
+            pv.x = (i < D) ? w.x * sqrt(1.0 / s2.x) : 0.0;
+            pv.y = (i + 1 < D) ? w.y * sqrt(1.0 / s2.y) : 0.0;
+            st2(p, i, pv);
+            st2(r, i, pv);
+            u.x = s1.x * pv.x; u.y = s1.y * pv.y;
+            lr_acc(S_, k, i, u);
+        }
+        lr_coef(S_, k, 0, cf);
+        double2 acc = {0.0, 0.0};
+        NPHIP_FOR_CHUNKS(i) {   // v = std (u + V c), K
+            const double2 pv = ld2(p, i), s1 = ld2(sd, i);
+            double2 u, v;
+            u.x = s1.x * pv.x; u.y = s1.y * pv.y;
+            const double2 w = lr_apply(k, i, u, cf);
+            v.x = s1.x * w.x; v.y = s1.y * w.y;
+            st2(vv, i, v);
+            acc.x = fma(pv.x, v.x, acc.x);
+            acc.y = fma(pv.y, v.y, acc.y);
+        }
+        double a = acc.x + acc.y, b = 0.0;
+        rsum2(a, b);
+        return 0.5 * a;
+    }
+
     // Momentum refresh (initialize_trajectory): p = z * sqrt(1/sig2); rho = p.  Returns K.
     __device__ double sample_momentum(uint32_t purpose, uint32_t id) {
+        if (lr_job() && c->host_metric) return sample_momentum_lr(purpose, id);
         double* p = P(kSlotInit);
         double* r = R(kSlotInit);
         double2 acc = {0.0, 0.0};
@@ -398,6 +495,7 @@ struct Machine {
             }
             st2(p, i, v);
             st2(r, i, v);
+            if (lr_job()) { double2 vel; vel.x = s2.x * v.x; vel.y = s2.y * v.y; st2(VEL(kSlotInit), i, vel); }
             acc.x = fma(v.x, s2.x * v.x, acc.x);
             acc.y = fma(v.y, s2.y * v.y, acc.y);
         }
@@ -415,6 +513,36 @@ struct Machine {
         const double h = 0.5 * eps;
         const double *q = Q(srcq), *g = G(srcq), *p = P(srcp);
         double *qn = Q(newq), *pn = P(newp);
+        if (lr_job() && c->host_metric) {
+            // low-rank metric: q' = q + eps v(p_half) — the half-kicked momentum and its products with the columns, then the drift
+            const int k = (int)c->lr_k;
+            const double* sd = A.lr_std + (size_t)chain * ld;
+            LrAcc S_;
+            double cf[kLrMax];
+            lr_zero(S_);
+            NPHIP_FOR_CHUNKS(i) {
+                const double2 g2 = ld2(g, i), p2 = ld2(p, i), s1 = ld2(sd, i);
+                double2 ph, u;
+                ph.x = fma(h, g2.x, p2.x);
+                ph.y = fma(h, g2.y, p2.y);
+                st2(pn, i, ph);
+                u.x = s1.x * ph.x; u.y = s1.y * ph.y;
+                lr_acc(S_, k, i, u);
+            }
+            lr_coef(S_, k, 0, cf);
+            NPHIP_FOR_CHUNKS(i) {
+                const double2 q2 = ld2(q, i), ph = ld2(pn, i), s1 = ld2(sd, i);
+                double2 u, qq;
+                u.x = s1.x * ph.x; u.y = s1.y * ph.y;
+                const double2 w = lr_apply(k, i, u, cf);
+                qq.x = fma(eps, s1.x * w.x, q2.x);
+                qq.y = fma(eps, s1.y * w.y, q2.y);
+                st2(qn, i, qq);
+                if (!FUSED) st2_dense(A.qeval + (size_t)chain * D, i, D, qq);
+            }
+            if (FUSED) chain_sync<W>();
+            return;
+        }
         NPHIP_FOR_CHUNKS(i) {
             double2 q2 = ld2(q, i), g2 = ld2(g, i), p2 = ld2(p, i), s2 = ld2(sig2, i);
             double2 ph, qq;
@@ -765,6 +893,11 @@ struct Machine {
             if (code != 0 || !isfinite(lp)) return 0.0;
         }
         const double* q = Q(newq);
+        const bool lrm = lr_job() && c->host_metric;
+        const int lrk = lrm ? (int)c->lr_k : 0;
+        const double* sd = lrm ? A.lr_std + (size_t)chain * ld : nullptr;
+        LrAcc S_;
+        if (lrm) lr_zero(S_);
         NPHIP_FOR_CHUNKS(i) {
             double2 gg;
             if (FUSED) {
@@ -779,13 +912,37 @@ struct Machine {
             double2 pv, rr;
             pv.x = fma(h, gg.x, ph.x);
             pv.y = fma(h, gg.y, ph.y);
-            accK.x = fma(pv.x, s2.x * pv.x, accK.x);
-            accK.y = fma(pv.y, s2.y * pv.y, accK.y);
+            if (lrm) {   // the kinetic energy needs the velocity: products with the columns now, the rest in a second pass
+                const double2 s1 = ld2(sd, i);
+                double2 u;
+                u.x = s1.x * pv.x; u.y = s1.y * pv.y;
+                lr_acc(S_, lrk, i, u);
+            } else {
+                const double vx = s2.x * pv.x, vy = s2.y * pv.y;
+                accK.x = fma(pv.x, vx, accK.x);
+                accK.y = fma(pv.y, vy, accK.y);
+                if (lr_job()) { double2 vel; vel.x = vx; vel.y = vy; st2(VEL(newp), i, vel); }
+            }
             rr.x = copy_rho ? pv.x : r2.x + pv.x;
             rr.y = copy_rho ? pv.y : r2.y + pv.y;
             st2(g, i, gg);
             st2(pn, i, pv);
             st2(rn, i, rr);
+        }
+        if (lrm) {
+            double cf[kLrMax];
+            lr_coef(S_, lrk, 0, cf);
+            double* vn = VEL(newp);
+            NPHIP_FOR_CHUNKS(i) {
+                const double2 pv = ld2(pn, i), s1 = ld2(sd, i);
+                double2 u, v;
+                u.x = s1.x * pv.x; u.y = s1.y * pv.y;
+                const double2 w = lr_apply(lrk, i, u, cf);
+                v.x = s1.x * w.x; v.y = s1.y * w.y;
+                st2(vn, i, v);
+                accK.x = fma(pv.x, v.x, accK.x);
+                accK.y = fma(pv.y, v.y, accK.y);
+            }
         }
         double a = accK.x + accK.y, b = accL.x + accL.y;
         rsum2(a, b);
@@ -1975,15 +2132,21 @@ struct Machine {
         const int mode = (a >= 0 && b >= 0) ? 0 : ((b >= 0 && a < 0) ? 1 : 2);
         double2 acc1 = {0.0, 0.0}, acc2 = {0.0, 0.0};
         NPHIP_FOR_CHUNKS(i) {
-            double2 vps = ld2(ps, i), vrs = ld2(rs, i), vpe = ld2(pe, i), vre = ld2(re, i), s2 = sg2(i);
-            double2 t;
+            double2 vps = ld2(ps, i), vrs = ld2(rs, i), vpe = ld2(pe, i), vre = ld2(re, i);
+            double2 t, ve, vs;
+            if (lr_job()) {   // the velocities M^-1 p of both ends were stored with them (the metric may be low-rank)
+                ve = ld2(VEL(se), i); vs = ld2(VEL(ss), i);
+            } else {
+                const double2 s2 = sg2(i);
+                ve.x = s2.x * vpe.x; ve.y = s2.y * vpe.y; vs.x = s2.x * vps.x; vs.y = s2.y * vps.y;
+            }
             if (mode == 0) { t.x = (vre.x - vrs.x) + vps.x; t.y = (vre.y - vrs.y) + vps.y; }
             else if (mode == 1) { t.x = vre.x + vrs.x; t.y = vre.y + vrs.y; }
             else { t.x = (vrs.x - vre.x) + vpe.x; t.y = (vrs.y - vre.y) + vpe.y; }
-            acc1.x = fma(t.x, s2.x * vpe.x, acc1.x);
-            acc1.y = fma(t.y, s2.y * vpe.y, acc1.y);
-            acc2.x = fma(t.x, s2.x * vps.x, acc2.x);
-            acc2.y = fma(t.y, s2.y * vps.y, acc2.y);
+            acc1.x = fma(t.x, ve.x, acc1.x);
+            acc1.y = fma(t.y, ve.y, acc1.y);
+            acc2.x = fma(t.x, vs.x, acc2.x);
+            acc2.y = fma(t.y, vs.y, acc2.y);
         }
         double t1 = acc1.x + acc1.y, t2 = acc2.x + acc2.y;
         rsum2(t1, t2);
@@ -2124,8 +2287,10 @@ struct Machine {
         c->phase = PH_SS_FIRST;
     }
 
+    // search ids: 0xffffffff at chain start, 0x80000000 | draw when the host resumed the chain with a new metric before that draw
+    // (both go on with the next draw), else the draw whose adaptation triggered the search (which is finished afterwards)
     __device__ void after_ss() {
-        if (c->ss_id == 0xffffffffll) begin_draw();
+        if (c->ss_id >= 0x80000000ll) begin_draw();
         else finish_draw();
     }
 
@@ -2282,7 +2447,7 @@ struct Machine {
                 } else {
                     const int64_t al = j - (1ll << k);      // last leaf of A
                     const int64_t tf = j - (1ll << k) + 1;  // first leaf of T
-                    if (FUSED)
+                    if (FUSED && !lr_job())
                         turn = check3_stream(sA_first, slot_last(__builtin_ctzll((unsigned long long)al), A.cap),
                                              slot_first(__builtin_ctzll((unsigned long long)(tf - 1))), sT_last, Y);
                     else
@@ -2395,7 +2560,7 @@ struct Machine {
             const int64_t switch_freq = is_early ? A.s.early_mm_switch_freq : A.s.mm_switch_freq;
             const bool is_late = switch_freq + draw > A.s.final_window;
             bool did_change = false;
-            if (A.s.adapt_mass_matrix) {
+            if (A.s.adapt_mass_matrix && !c->host_metric) {   // (a chain whose metric the host supplies does not adapt its own)
                 const bool do_add = good;
                 const int64_t n_fg = c->fg_count + (do_add ? 1 : 0), n_bg = c->bg_count + (do_add ? 1 : 0);
                 const bool do_switch = (n_bg >= switch_freq) && !is_late;
@@ -2468,6 +2633,10 @@ struct Machine {
             gen_init(0);
             c->phase = PH_INIT_EVAL;
             if (FUSED) chain_sync<W>();
+        } else if (ph == PH_RESUME_SS) {
+            // the host replaced the metric between two draws (nphip_sampler_set_metric): same position, new step-size search
+            c->has_initial_mm = 0;
+            start_ss(0x80000000ll | c->draw);
         } else if (ph == PH_INIT_EVAL) {
             eval_position(c->eval_buf, lp, code);
             cont_init(lp, code);
@@ -2492,7 +2661,7 @@ struct Machine {
                 if (REMOTE && !DENS) { while (c->hs_last == 0) remote_sync(); }
                 break;
             }
-            if (ph != PH_START) {
+            if (ph != PH_START && ph != PH_RESUME_SS) {   // (those two consume no evaluation)
                 if (REMOTE && !DENS) {
                     if (c->hs_last != 0) break;   // the host asked the launch to end at this boundary
                 } else if (FUSED || DENS) {
@@ -2534,12 +2703,15 @@ struct Machine {
                 } else {
                     double lp = 0.0;
                     int64_t code = 0;
-                    if (FUSED) {
+                    if (FUSED && !lr_job()) {
                         bool turn0 = false;
                         const bool even_leaf = ((c->nleaf + 1) & 1) == 0;
                         const double K = lf_stream(lp, c->idx_cur + c->dir, turn0, Y);
                         rare = cont_tree(X, Y, K, lp, code, even_leaf, turn0);
                     } else {
+                        // (fused models under the low-rank metric: the two-pass leapfrog of the callback kernels, with the gradient
+                        //  evaluated in lf2; the deferred first half is performed here)
+                        if (FUSED) lf1(c->lf_srcq, c->lf_srcp, c->lf_newq, c->lf_newp, c->lf_sign);
                         const double K = lf2(lp, code, c->idx_cur + c->dir);
                         rare = cont_tree(X, Y, K, lp, code, false, false);
                     }
@@ -2903,6 +3075,36 @@ __global__ void k_resume(const Args* __restrict__ Ap, int n, const int64_t* __re
         c->eval_buf = 0;
         c->phase = PH_INIT_EVAL;
     }
+}
+
+// A new metric for chains stopped in PH_WAIT_HOST (host-driven low-rank adaptation): sigma^2 [n][dim], k rows of V [n][k][dim],
+// lambda [n][k]; the chain keeps its position and goes on through a step-size search (PH_RESUME_SS).  One block per chain.
+__global__ void k_set_metric(const Args* __restrict__ Ap, int n, const int64_t* __restrict__ chains, int k, const double* __restrict__ sig2,
+                             const double* __restrict__ V, const double* __restrict__ lam) {
+    const Args& A = *Ap;
+    if ((int)blockIdx.x >= n) return;
+    const int64_t ch = chains[blockIdx.x];
+    Ctl* c = A.ctl + ch;
+    if (c->phase != PH_WAIT_HOST) return;
+    for (int64_t i = threadIdx.x; i < A.ld; i += blockDim.x) {
+        const double s2 = i < A.dim ? sig2[(size_t)blockIdx.x * A.dim + i] : 1.0;
+        A.sig2[(size_t)ch * A.ld + i] = s2;
+        A.lr_std[(size_t)ch * A.ld + i] = sqrt(s2);
+        for (int j = 0; j < kLrMax; ++j)
+            A.lr_V[((size_t)ch * kLrMax + j) * A.ld + i] = (j < k && i < A.dim) ? V[((size_t)blockIdx.x * k + j) * A.dim + i] : 0.0;
+    }
+    if (threadIdx.x < kLrMax) A.lr_lam[(size_t)ch * kLrMax + threadIdx.x] = (int)threadIdx.x < k ? lam[(size_t)blockIdx.x * k + threadIdx.x] : 1.0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        c->host_metric = 1;
+        c->lr_k = k;
+        c->phase = PH_RESUME_SS;
+    }
+}
+
+hipError_t launch_set_metric(const Args* d_args, int n, const int64_t* d_chains, int k, const double* sig2, const double* V, const double* lam, hipStream_t st) {
+    hipLaunchKernelGGL(k_set_metric, dim3((unsigned)n), dim3(256), 0, st, d_args, n, d_chains, k, sig2, V, lam);
+    return hipGetLastError();
 }
 
 hipError_t launch_resume(const Args* d_args, int n, const int64_t* d_chains, const double* d_pos, bool fused, hipStream_t st) {

@@ -58,8 +58,34 @@ class Settings(C.Structure):
         ("crate_arithmetic", C.c_int32),
         ("adam_learning_rate", C.c_double),
         ("store_divergences", C.c_int32),
-        ("reserved_", C.c_int32),
+        ("low_rank_metric", C.c_int32),
+        ("n_metric_updates", C.c_int32),
+        ("metric_k", C.c_int32),
+        ("metric_draws", C.c_uint64 * 16),
+        ("metric_sig2", C.c_void_p),
+        ("metric_V", C.c_void_p),
+        ("metric_lam", C.c_void_p),
     ]
+
+    def set_metric_schedule(self, draws, sig2, V=None, lam=None):
+        """Metrics handed to the sampler (nuts_oracle.h: low_rank_metric): update u applies before draw ``draws[u]``;
+        ``sig2[u, chain, dim]``, ``V[u, chain, k, dim]``, ``lam[u, chain, k]``."""
+        sig2 = np.ascontiguousarray(sig2, dtype=np.float64)
+        U, n, _ = sig2.shape
+        assert U == len(draws) <= 16 and n == int(self.num_chains)
+        k = 0 if V is None else int(np.asarray(V).shape[2])
+        self._keep = [sig2]
+        self.low_rank_metric, self.n_metric_updates, self.metric_k = 1, U, k
+        for i, d in enumerate(draws):
+            self.metric_draws[i] = int(d)
+        self.metric_sig2 = sig2.ctypes.data
+        if k:
+            V = np.ascontiguousarray(V, dtype=np.float64)
+            lam = np.ascontiguousarray(lam, dtype=np.float64)
+            assert V.shape == (U, n, k, sig2.shape[2]) and lam.shape == (U, n, k)
+            self._keep += [V, lam]
+            self.metric_V, self.metric_lam = V.ctypes.data, lam.ctypes.data
+        return self
 
 
 class _Trace(C.Structure):
@@ -338,3 +364,14 @@ def is_turning(sig2, idx1, p1, psum1, idx2, p2, psum2, waves=1):
     sig2 = np.ascontiguousarray(sig2, dtype=np.float64)
     a = [np.ascontiguousarray(v, dtype=np.float64) for v in (p1, psum1, p2, psum2)]
     return bool(lib().oracle_is_turning(C.c_uint64(sig2.size), _p(sig2), C.c_int(waves), C.c_int64(idx1), _p(a[0]), _p(a[1]), C.c_int64(idx2), _p(a[2]), _p(a[3])))
+
+
+def lr_velocity(sig2, V, lam, p, waves=1):
+    """v = M^-1 p, M^-1 = D^1/2 (I + V (Lambda - I) V') D^1/2 with V given as k rows."""
+    sig2 = np.ascontiguousarray(sig2, dtype=np.float64)
+    V = np.ascontiguousarray(V, dtype=np.float64).reshape(-1, sig2.size)
+    lam = np.ascontiguousarray(lam, dtype=np.float64)
+    p = np.ascontiguousarray(p, dtype=np.float64)
+    v = np.empty_like(p)
+    lib().oracle_lr_velocity(C.c_uint64(sig2.size), C.c_int(V.shape[0]), _p(sig2), _p(V), _p(lam), C.c_int(waves), _p(p), _p(v))
+    return v

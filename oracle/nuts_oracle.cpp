@@ -402,6 +402,34 @@ struct Hamiltonian {
     Hamiltonian(Model* m, Geometry g) : model(m), geo(g), sig2(m->dim, 1.0), pool(m->dim) {}
     size_t dim() const { return model->dim; }
 
+    // Low-rank metric M^-1 = D^1/2 (I + V (Lambda - I) V') D^1/2 (nuts-rs LowRankMassMatrix; reference knobs src/wrapper.rs:307-334).
+    // Inactive (lr == false): the diagonal metric, v = sig2 * p, exactly as before.
+    bool lr = false;
+    int lr_k = 0;
+    std::vector<double> lr_std, lr_V, lr_lam;   // sqrt(sig2) [n]; k rows of length n; k eigenvalues
+    void set_metric(int k, const double* s2, const double* V, const double* lam) {
+        const size_t n = dim();
+        lr = true; lr_k = k;
+        sig2.assign(s2, s2 + n);
+        lr_std.resize(n);
+        for (size_t i = 0; i < n; ++i) lr_std[i] = std::sqrt(sig2[i]);
+        lr_V.assign(V ? V : s2, (V ? V : s2) + (size_t)k * n);
+        lr_lam.assign(lam ? lam : s2, (lam ? lam : s2) + k);
+    }
+    // v = M^-1 p:  u = std p ; d_j = <V_j, u> ; c_j = (lambda_j - 1) d_j ; w = u + sum_j V_j c_j (fma chain, j ascending) ; v = std w
+    void velocity(const double* p, double* v) const {
+        const size_t n = dim();
+        if (!lr) { for (size_t i = 0; i < n; ++i) v[i] = sig2[i] * p[i]; return; }
+        std::vector<double> u(n), c(lr_k);
+        for (size_t i = 0; i < n; ++i) u[i] = lr_std[i] * p[i];
+        for (int j = 0; j < lr_k; ++j) c[j] = (lr_lam[j] - 1.0) * det_dot(lr_V.data() + (size_t)j * n, u.data(), n, geo);
+        for (size_t i = 0; i < n; ++i) {
+            double w = u[i];
+            for (int j = 0; j < lr_k; ++j) w = std::fma(lr_V[(size_t)j * n + i], c[j], w);
+            v[i] = lr_std[i] * w;
+        }
+    }
+
     // EuclideanHamiltonian::leapfrog [A.5]; operand list corroborated by
     // reference benches/run_tvm_leapfrog.rs_old:81-85 (position, momentum, grad, epsilon, mass_diag).
     Leap leapfrog(const State& s, int sign, Collector* col, StateP* out_state, DivergenceInfo* info) {
@@ -423,7 +451,7 @@ struct Hamiltonian {
         }
 #else
         for (size_t i = 0; i < n; ++i) o->p[i] = std::fma(h, s.g[i], s.p[i]);
-        for (size_t i = 0; i < n; ++i) o->v[i] = sig2[i] * o->p[i];
+        velocity(o->p.data(), o->v.data());
         for (size_t i = 0; i < n; ++i) o->q[i] = std::fma(eps, o->v[i], s.q[i]);
 #endif
         double lp = 0.0;
@@ -459,7 +487,7 @@ struct Hamiltonian {
         }
 #else
         for (size_t i = 0; i < n; ++i) o->p[i] = std::fma(h, o->g[i], o->p[i]);
-        for (size_t i = 0; i < n; ++i) o->v[i] = sig2[i] * o->p[i];
+        velocity(o->p.data(), o->v.data());
         o->K = 0.5 * det_dot(o->p.data(), o->v.data(), n, geo);
         if (o->idx == -1) {
             o->psum = o->p;
@@ -528,10 +556,22 @@ struct Hamiltonian {
         for (size_t j = 0; 2 * j < n; ++j) {
             double z0, z1;
             normal_pair(philox(seed, (uint32_t)j, chain, draw_id, purpose), &z0, &z1);
-            o->p[2 * j] = z0 * std::sqrt(1.0 / sig2[2 * j]);
-            if (2 * j + 1 < n) o->p[2 * j + 1] = z1 * std::sqrt(1.0 / sig2[2 * j + 1]);
+            o->p[2 * j] = z0;
+            if (2 * j + 1 < n) o->p[2 * j + 1] = z1;
         }
-        for (size_t i = 0; i < n; ++i) o->v[i] = sig2[i] * o->p[i];
+        if (lr) {
+            // p ~ N(0, M):  p = (z + sum_j V_j f_j) * sqrt(1 / sig2),  f_j = (1 / sqrt(lambda_j) - 1) <V_j, z>
+            std::vector<double> f(lr_k);
+            for (int j = 0; j < lr_k; ++j) f[j] = (1.0 / std::sqrt(lr_lam[j]) - 1.0) * det_dot(lr_V.data() + (size_t)j * n, o->p.data(), n, geo);
+            for (size_t i = 0; i < n; ++i) {
+                double w = o->p[i];
+                for (int j = 0; j < lr_k; ++j) w = std::fma(lr_V[(size_t)j * n + i], f[j], w);
+                o->p[i] = w * std::sqrt(1.0 / sig2[i]);
+            }
+        } else {
+            for (size_t i = 0; i < n; ++i) o->p[i] = o->p[i] * std::sqrt(1.0 / sig2[i]);
+        }
+        velocity(o->p.data(), o->v.data());
         o->K = 0.5 * det_dot(o->p.data(), o->v.data(), n, geo);
         o->psum = o->p;
         o->idx = 0;
@@ -728,6 +768,7 @@ struct Chain {
     DualAverage da;
     RunningVariance fg_q, fg_g, bg_q, bg_g;
     bool has_initial_mm = true;
+    bool host_metric = false;   // the metric was handed in (low_rank_metric): the chain's own mass-matrix adaptation is off
     uint64_t last_update = 0;
     double last_accept = 0.0, last_accept_sym = 0.0;
     uint64_t early_end, final_window;
@@ -867,7 +908,7 @@ struct Chain {
             uint64_t switch_freq = is_early ? S.early_mass_matrix_switch_freq : S.mass_matrix_switch_freq;
             bool did_change = false;
             bool is_late = switch_freq + draw > final_window;
-            if (S.adapt_mass_matrix) {
+            if (S.adapt_mass_matrix && !host_metric) {
                 if (draw_is_good) {
                     fg_q.add(cur->q.data()); fg_g.add(cur->g.data());
                     bg_q.add(cur->q.data()); bg_g.add(cur->g.data());
@@ -894,6 +935,21 @@ struct Chain {
         }
         da.advance(last_accept_sym, S.target_accept);
         update_stepsize((uint32_t)draw, draw == S.num_tune - 1);
+        return true;
+    }
+
+    // metrics handed in from outside (oracle_settings_t::low_rank_metric): update u applies before draw metric_draws[u]
+    bool maybe_set_metric(uint64_t draw_idx, uint64_t local_chain) {
+        if (!S.low_rank_metric) return true;
+        const size_t n = model->dim, k = (size_t)S.metric_k, nc = (size_t)S.num_chains;
+        for (int u = 0; u < S.n_metric_updates; ++u) {
+            if (S.metric_draws[u] != draw_idx) continue;
+            H.set_metric((int)k, S.metric_sig2 + ((size_t)u * nc + local_chain) * n,
+                         k ? S.metric_V + (((size_t)u * nc + local_chain) * k) * n : nullptr, k ? S.metric_lam + ((size_t)u * nc + local_chain) * k : nullptr);
+            host_metric = true;
+            has_initial_mm = false;
+            return step_size_search(0x80000000u | (uint32_t)draw_idx);
+        }
         return true;
     }
 
@@ -956,7 +1012,7 @@ int run_sampler(const oracle_settings_t* S, uint64_t dim, MakeModel make_model, 
             }
             for (uint64_t d = 0; d < T; ++d) {
                 SampleInfo info; StateP st; DivergenceInfo dinfo;
-                if (!chain.draw(d, &info, &st, &dinfo)) {
+                if (!chain.maybe_set_metric(d, c) || !chain.draw(d, &info, &st, &dinfo)) {
                     std::lock_guard<std::mutex> lk(g_error_mutex);
                     g_last_error = g_error; failed.store(1); return;
                 }
@@ -1137,6 +1193,13 @@ void oracle_welford(uint64_t n, uint64_t dim, const double* samples, double* mea
     for (uint64_t i = 0; i < n; ++i) rv.add(samples + i * dim);
     memcpy(mean, rv.mean.data(), dim * 8);
     memcpy(m2, rv.m2.data(), dim * 8);
+}
+
+void oracle_lr_velocity(uint64_t dim, int k, const double* sig2, const double* V, const double* lam, int waves, const double* p, double* v) {
+    TridiagModel m; m.dim = dim;
+    Hamiltonian H(&m, Geometry{waves});
+    H.set_metric(k, sig2, V, lam);
+    H.velocity(p, v);
 }
 
 int oracle_is_turning(uint64_t dim, const double* sig2, int waves, int64_t idx1, const double* p1,

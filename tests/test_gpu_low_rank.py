@@ -1,0 +1,110 @@
+"""The low-rank metric M^-1 = D^1/2 (I + V (Lambda - I) V') D^1/2 inside the engine (reference: adaptation="low_rank",
+src/wrapper.rs:307-334, python/nutpie/sample.py:921-933): leapfrog, momentum draw, kinetic energy and U-turn criteria under
+the metric, bit for bit against the oracle, with the metrics handed in at the pause draws (nphip_sampler_set_metric)."""
+import numpy as np
+import pytest
+
+from nutpie_amd.gaussian import ar1_gaussian
+from tests.conftest import assert_trace_equal, fn_addr
+from tests.test_gpu_parity import oracle_settings
+
+pytestmark = pytest.mark.gpu
+
+
+def random_metrics(rng, updates, chains, dim, k):
+    sig2 = np.exp(rng.normal(size=(updates, chains, dim)))
+    V = np.zeros((updates, chains, k, dim))
+    for u in range(updates):
+        for c in range(chains):
+            q, _ = np.linalg.qr(rng.normal(size=(dim, k)))
+            V[u, c] = q.T
+    lam = np.exp(rng.uniform(np.log(0.15), np.log(8.0), size=(updates, chains, k)))
+    return sig2, V, lam
+
+
+def run_engine_with_metrics(hip, model, pauses, sig2, V, lam, *, chains, tune, draws, seed, waves=0, launch=None, **settings):
+    s = hip.PyNutsSettings.Diag(seed)
+    s.update(num_tune=tune, num_draws=draws, num_chains=chains, low_rank_metric=True, **settings)
+    s.set_pause_draws(pauses)
+    smp = hip.PySampler(s, model, waves_per_chain=waves, manual=True, **(launch or {}))
+    nxt = 0
+    for _ in range(100000):
+        done, _, _ = smp.step(4)
+        if done:
+            break
+        if nxt < len(pauses) and smp.waiting().all():
+            k = V.shape[2]
+            smp.set_metric(np.arange(chains), sig2[nxt], V[nxt] if k else None, lam[nxt] if k else None)
+            nxt += 1
+    assert done and nxt == len(pauses)
+    W = smp.waves_per_chain
+    return smp.take_results(), W
+
+
+@pytest.mark.parametrize("dim,waves,k,launch", [
+    (24, 0, 3, {}),
+    (24, 0, 0, {}),                                 # k = 0: a host-supplied DIAGONAL metric (v = std (std p))
+    (300, 0, 11, dict(evals_per_launch=9)),         # more than 8 columns: two reductions
+    (300, 2, 16, {}),
+    (1300, 0, 4, {}),                               # two waves per chain
+    (5003, 0, 2, dict(evals_per_launch=13)),        # four waves per chain (memory-resident kernels under the low-rank metric)
+])
+def test_fused_model_under_handed_in_metrics_bit_identical(hip, oracle, dim, waves, k, launch):
+    rng = np.random.default_rng(dim + k)
+    model = ar1_gaussian(dim) if dim > 24 else None
+    args = (model.diag, model.offdiag) if model else (np.exp(rng.normal(size=dim) * 1.5),)
+    chains, tune, draws, pauses = 3, 40, 10, [12, 27]
+    sig2, V, lam = random_metrics(rng, 2, chains, dim, k)
+    sig2 *= 0.05 if dim > 24 else 1.0
+    kw = dict(chains=chains, tune=tune, draws=draws, seed=dim + 5)
+    got, W = run_engine_with_metrics(hip, hip.TridiagGaussianModel(*args), pauses, sig2, V, lam, waves=waves, launch=launch, store_mass_matrix=True, **kw)
+    s = oracle_settings(oracle, W=W, store_mass_matrix=True, **kw)
+    s.set_metric_schedule(pauses, sig2, V if k else None, lam if k else None)
+    want = oracle.sample_tridiag(s, *args)
+    assert_trace_equal(got, want)
+    assert np.array_equal(got.stats["mass_matrix_inv"], want.stats["mass_matrix_inv"])
+    assert np.array_equal(got.stats["mass_matrix_inv"][:, 30], sig2[1])              # the diagonal part is the handed-in sigma^2, kept
+
+
+def test_job_without_updates_equals_the_diagonal_job(hip, oracle):
+    # the setting alone changes nothing: until the first metric arrives a chain runs on the diagonal metric it adapts itself
+    diag = np.exp(np.random.default_rng(1).normal(size=40))
+    kw = dict(chains=4, tune=60, draws=20, seed=8)
+    s = hip.PyNutsSettings.Diag(8)
+    s.update(num_tune=60, num_draws=20, num_chains=4, low_rank_metric=True)
+    smp = hip.PySampler(s, hip.TridiagGaussianModel(diag), manual=True)
+    while not smp.step(16)[0]:
+        pass
+    got = smp.take_results()
+    want = oracle.sample_tridiag(oracle_settings(oracle, W=1, **kw), diag)
+    assert_trace_equal(got, want)
+
+
+def test_host_callback_models_under_handed_in_metrics(hip, oracle, fixture_lib):
+    fn = fn_addr(fixture_lib.eight_schools_logp)
+    rng = np.random.default_rng(4)
+    chains, tune, draws, pauses = 8, 60, 20, [10, 35]
+    sig2, V, lam = random_metrics(rng, 2, chains, 10, 3)
+    kw = dict(chains=chains, tune=tune, draws=draws, seed=21)
+    got, W = run_engine_with_metrics(hip, hip.HostCallbackModel(10, fn), pauses, sig2, V, lam, **kw)
+    s = oracle_settings(oracle, W=W, **kw)
+    s.set_metric_schedule(pauses, sig2, V, lam)
+    want = oracle.sample_callback(s, 10, fn)
+    assert_trace_equal(got, want)
+
+
+def test_set_metric_errors(hip):
+    s = hip.PyNutsSettings.Diag(1)
+    s.update(num_tune=20, num_draws=5, num_chains=2)
+    smp = hip.PySampler(s, hip.TridiagGaussianModel(np.ones(4)), manual=True)
+    with pytest.raises(RuntimeError, match="low_rank_metric"):
+        smp.set_metric([0], np.ones((1, 4)))
+    smp.close()
+    s.update(low_rank_metric=True)
+    smp = hip.PySampler(s, hip.TridiagGaussianModel(np.ones(4)), manual=True)
+    with pytest.raises(RuntimeError, match="at most 16"):
+        smp.set_metric([0], np.ones((1, 4)), np.zeros((1, 17, 4)), np.ones((1, 17)))
+    smp.set_metric([0, 1], np.ones((2, 4)))          # nobody is waiting: no effect
+    while not smp.step(8)[0]:
+        pass
+    smp.close()

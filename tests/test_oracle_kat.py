@@ -310,3 +310,59 @@ def test_divergence_records_are_the_failed_leapfrog(oracle):
     s0 = oracle.default_settings(seed=5, num_chains=4, num_tune=150, num_draws=100, max_energy_error=0.3)
     tr0 = oracle.sample_tridiag(s0, diag)
     assert np.array_equal(tr0.draws, tr.draws) and np.array_equal(tr0.stats["n_steps"], tr.stats["n_steps"])
+
+
+def _low_rank_parts(cov, k):
+    """(sigma^2, V rows, lambda) with D^1/2 (I + V (Lambda - I) V') D^1/2 == cov, keeping the k eigenvalues of the correlation
+    matrix furthest from 1 (all of them when k == dim)."""
+    sd = np.sqrt(np.diag(cov))
+    lam, U = np.linalg.eigh(cov / np.outer(sd, sd))
+    keep = np.argsort(-np.abs(np.log(lam)))[:k]
+    return sd**2, U[:, keep].T.copy(), lam[keep]
+
+
+def test_low_rank_velocity_is_the_metric_applied(oracle):
+    # v = M^-1 p with M^-1 = D^1/2 (I + V (Lambda - I) V') D^1/2 (src/wrapper.rs:307-334) against dense numpy algebra
+    rng = np.random.default_rng(0)
+    D = 37
+    A = rng.normal(size=(D, D))
+    cov = A @ A.T / D + np.diag(np.exp(rng.normal(size=D)))
+    sig2, V, lam = _low_rank_parts(cov, D)              # all directions: M^-1 == cov
+    p = rng.normal(size=D)
+    for W in (1, 2):
+        np.testing.assert_allclose(oracle.lr_velocity(sig2, V, lam, p, W), cov @ p, rtol=1e-11)
+    sig2, V, lam = _low_rank_parts(cov, 5)
+    Minv = np.sqrt(sig2)[:, None] * (np.eye(D) + V.T @ np.diag(lam - 1) @ V) * np.sqrt(sig2)[None, :]
+    np.testing.assert_allclose(oracle.lr_velocity(sig2, V, lam, p), Minv @ p, rtol=1e-11)
+    np.testing.assert_array_equal(oracle.lr_velocity(sig2, V[:0], lam[:0], p), np.sqrt(sig2) * (np.sqrt(sig2) * p))   # k = 0: the diagonal
+
+
+def test_sampler_under_a_handed_in_low_rank_metric(oracle):
+    # A correlated Gaussian whose exact covariance is handed in as the metric before draw 20: NUTS then sees a standard normal —
+    # short trees, the right moments, momenta drawn from N(0, M) (kinetic energy ~ D / 2) — while the diagonal run needs long ones.
+    rng = np.random.default_rng(3)
+    D, chains, tune, draws = 12, 6, 150, 400
+    B = rng.normal(size=(D, 2))
+    cov = np.diag(np.exp(rng.normal(size=D))) + 60.0 * B @ B.T
+    P = np.linalg.inv(cov)
+
+    def logp(x):
+        g = -(P @ x)
+        return 0.5 * float(x @ g), g
+
+    sig2, V, lam = _low_rank_parts(cov, D)
+    kw = dict(seed=5, num_chains=chains, num_tune=tune, num_draws=draws, n_threads=6)
+    s = oracle.default_settings(**kw)
+    s.set_metric_schedule([20], np.tile(sig2, (1, chains, 1)), np.tile(V, (1, chains, 1, 1)), np.tile(lam, (1, chains, 1)))
+    lr = oracle.sample_callback(s, D, logp)
+    dg = oracle.sample_callback(oracle.default_settings(**kw), D, logp)
+    assert np.array_equal(lr.draws[:, :20], dg.draws[:, :20])            # before the update: the same chain
+    assert lr.stats["n_steps"][:, tune:].mean() < 8 < 3 * 8 < dg.stats["n_steps"][:, tune:].mean()
+    x = lr.draws[:, tune:].reshape(-1, D)
+    sd = np.sqrt(np.diag(cov))
+    assert np.abs(x.mean(0) / sd).max() < 0.12 and np.abs(np.cov(x.T) / cov - 1)[np.abs(cov) > 0.3 * np.outer(sd, sd)].max() < 0.35
+    # energy - potential at the start of a draw is the kinetic energy of the fresh momentum: p' M^-1 p / 2 ~ chi^2_D / 2
+    K0 = (lr.stats["energy"] - lr.stats["energy_error"] + lr.stats["logp"] * 0)[:, tune:]   # H0 of each draw
+    U0 = -np.concatenate([lr.stats["logp"][:, tune - 1:tune], lr.stats["logp"][:, tune:-1]], 1)
+    assert abs((K0 - U0).mean() - D / 2) < 0.4
+    assert lr.stats["diverging"][:, 25:].sum() == 0
