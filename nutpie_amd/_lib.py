@@ -237,8 +237,8 @@ class PyNutsSettings:
 
     @staticmethod
     def LowRank(seed=None):
-        """``PyNutsSettings::LowRank`` (wrapper.rs:725-729).  The engine's diag-NUTS kernels run on linearly transformed
-        coordinates (nutpie_amd/low_rank.py); ``mass_matrix_eigval_cutoff`` (> 1) and ``mass_matrix_gamma`` (> 0) as in
+        """``PyNutsSettings::LowRank`` (wrapper.rs:725-729).  The engine integrates under the low-rank metric (setting
+        ``low_rank_metric``); the window estimator that supplies it lives in nutpie_amd/low_rank.py; ``mass_matrix_eigval_cutoff`` (> 1) and ``mass_matrix_gamma`` (> 0) as in
         python/nutpie/sample.py:921-933 — defaults 2.0 and 1e-5 (the docstring there says 100, its own example uses 3)."""
         s = PyNutsSettings.Diag(seed)
         object.__setattr__(s, "_adaptation", "low_rank")

@@ -202,8 +202,6 @@ def from_pyfunc(
 class TorchFuncModel(CompiledModel):
     """Batched device model: all chains evaluated by one torch call per leapfrog."""
 
-    _supports_low_rank = True   # adaptation="low_rank": the metric is a linear map around this density (nutpie_amd/low_rank.py)
-
     _make_logp_func: Callable           # () -> f(x[chains, D]) -> (logp[chains], grad[chains, D])
     _expand_func: Callable | None       # (x[N, D] numpy) -> dict name -> [N, *shape]; None = identity variable "x"
     _n_dim: int
@@ -248,25 +246,6 @@ class TorchFuncModel(CompiledModel):
         logp_fn = partial(self._make_logp_func(), **self._shared_data)
         streams = {}
         graph = None
-        low_rank = getattr(settings, "_adaptation", "diag") == "low_rank"
-        lr_state = None
-        if low_rank:
-            # adaptation="low_rank": the engine samples linearly transformed coordinates y; the metric is applied here, around
-            # the user's density (nutpie_amd/low_rank.py)
-            from nutpie_amd import low_rank as lr
-
-            if self._use_graph:
-                raise NotImplementedError("use_graph and adaptation='low_rank' cannot be combined (the transform changes during warm-up)")
-            lr_state = {"T": lr.Transform.identity(n, D, dev), "identity": True}
-            user_fn = logp_fn
-
-            def logp_fn(y):
-                if lr_state["identity"]:
-                    return user_fn(y)
-                T = lr_state["T"]
-                val, grad = user_fn(T.forward(y))
-                return val, T.grad_to_y(grad.reshape(n, D).to(torch.float64))
-
         if self._use_graph:
             # launch-bound models (dozens of small torch kernels per evaluation): capture once, replay per leapfrog
             side = torch.cuda.Stream(device=dev)
@@ -303,19 +282,6 @@ class TorchFuncModel(CompiledModel):
             model.set_init(self._init)
         else:
             model.set_init("explicit", np.asarray(self._init, dtype=np.float64))
-        if low_rank:
-            pauses = lr.pause_draws(int(settings.num_tune))
-            settings = settings.clone()
-            settings.set_pause_draws(pauses)
-            settings.store_gradient = True          # the estimator needs the gradients of the window's draws
-            engine_kw = {**engine_kw, "manual": True}
-            inner = _lib.PySampler.from_pyfunc(settings, cores, model, progress_type, extra_callback, extra_callback_rate, store,
-                                               staging=(q.data_ptr(), g.data_ptr(), lp.data_ptr()), **engine_kw)
-            inner._keep_tensors = (q, g, lp, graph)
-            if self._expand_device_func is not None:
-                inner._device_expand = partial(self._expand_on_device, device=device)
-            return lr.LowRankSampler(inner, lr_state, device, settings._low_rank["mass_matrix_gamma"],
-                                     settings._low_rank["mass_matrix_eigval_cutoff"], pauses)
         sampler = _lib.PySampler.from_pyfunc(
             settings, cores, model, progress_type, extra_callback, extra_callback_rate, store,
             staging=(q.data_ptr(), g.data_ptr(), lp.data_ptr()), **engine_kw,

@@ -4,22 +4,22 @@ What the reference does (``PyNutsSettings::LowRank``, src/wrapper.rs:307-334, 72
 docs/sampling-options.qmd:124-144): nuts-rs adapts a mass matrix ``M^-1 = D^1/2 (I + V (Lambda - I) V') D^1/2`` — a diagonal
 scaling plus a rank-k correction whose eigenvalues are those of the geometric mean of the draw covariance and the inverse
 gradient covariance that lie outside ``[1/cutoff, cutoff]`` (``mass_matrix_eigval_cutoff``), regularised by
-``mass_matrix_gamma``.  The crate is not in the tree; the estimator below follows that published description (Seyboldt et al.,
-"Preconditioning Hamiltonian Monte Carlo by minimizing Fisher divergence") — PARITY UNPINNED, like the rest of the sampler.
+``mass_matrix_gamma`` — and integrates, draws momenta and tests U-turns under it.
 
-How it is built here — MI355X-first, not a translation: HMC with metric ``M^-1 = L L'`` on ``x`` IS HMC with the identity metric
-on ``y = L^-1 (x - m)`` (same trajectories, same energies, same U-turn products), so the engine keeps running its diag-NUTS
-kernels unchanged, on ``y``, and the metric lives in the batched model evaluation:
+Here (round 3) the metric lives where the reference has it, INSIDE the sampler: with the setting ``low_rank_metric`` the engine's
+memory-resident kernels apply ``v = M^-1 p`` in the leapfrog, draw ``p ~ N(0, M)`` and carry the velocity with every tree state
+(``kernels.hip``: ``lf1`` / ``lf2`` / ``sample_momentum_lr`` / ``turning``; the oracle restates the same arithmetic and the two are
+compared bit for bit, tests/test_gpu_low_rank.py) — for EVERY model flavour: fused, raw C callbacks, BridgeStan, device
+callbacks, runtime-compiled densities.  What stays above the C-ABI is the window ESTIMATOR, below: chains stop between two
+draws at the window boundaries (``nphip_settings_set_pause_draws``), the host estimates every chain's ``(sigma^2, V, lambda)``
+from the window's draws and gradients — batched ``eigh`` on the GPU, all chains at once — hands it to the engine
+(``nphip_sampler_set_metric``) and the chains go on from where they are, through a new step-size search, as nuts-rs does when
+the mass matrix changes.  The estimator follows the published description (Seyboldt et al., "Preconditioning Hamiltonian Monte
+Carlo by minimizing Fisher divergence"); the crate is not in the tree — PARITY UNPINNED, like the rest of the sampler.
 
-    x = m + s * (y + V ((sqrt(lambda) - 1) * (V' y)))          one [chains, D] x [chains, D, k] contraction each way,
-    grad_y = L' grad_x                                         on the GPU, inside the callback the engine already calls
-
-The engine contributes one generic hook (include/nutpie_hip.h: ``nphip_settings_set_pause_draws`` / ``nphip_sampler_waiting`` /
-``nphip_sampler_resume_at``): chains stop between two draws at the window boundaries; the host estimates every chain's new
-``(m, s, V, lambda)`` from the window's draws and gradients — batched ``eigh`` on the GPU, all chains at once — rewrites the
-finished part of the trace into model space, maps every chain's position into its new coordinates and resumes.  Inside a
-window the engine's own diagonal adaptation keeps running in ``y`` (it mops up what rank k cannot express), and its step-size
-search restarts after every switch, as nuts-rs does when the mass matrix changes.
+(Round 2 obtained the same sampler as a linear re-parametrisation around the density — ``y = L^-1 (x - m)`` with the engine's
+diag-NUTS on ``y``; that needed a batched torch density, two contractions per evaluation and a rewrite of the trace at every
+switch.  The :class:`Transform` below is what is left of it: the algebra the estimator's tests are written against.)
 """
 
 from __future__ import annotations
@@ -153,20 +153,27 @@ def pause_draws(num_tune: int):
     return [d for d in out if d < num_tune]
 
 
-class LowRankSampler:
-    """A ``PySampler`` in manual mode plus the host thread that drives it and adapts the metric at the window boundaries.
-    Same handle surface as ``PySampler`` (wait / pause / resume / abort / is_finished / progress / inspect / take_results)."""
+def metric_of(T: Transform):
+    """(sigma^2 [n, D], V rows [n, k, D], lambda [n, k]) of a :class:`Transform`: ``M^-1 = L L'`` with ``L = D^1/2 (I + V d V')``,
+    i.e. eigenvalues ``(1 + d)^2`` on the columns of V (unused columns: V = 0, lambda = 1)."""
+    return T.stds * T.stds, T.V.transpose(1, 2).contiguous(), ((1.0 + T.d) ** 2).contiguous()
 
-    def __init__(self, inner, state, device, gamma, cutoff, pauses):
+
+class LowRankSampler:
+    """A ``PySampler`` in manual mode (settings ``low_rank_metric``, pause draws at the window boundaries, gradients stored) plus
+    the host thread that drives it and hands the engine a new metric at every boundary.  Same handle surface as ``PySampler``
+    (wait / pause / resume / abort / is_finished / progress / inspect / take_results); the trace is in model space throughout."""
+
+    def __init__(self, inner, device, gamma, cutoff, pauses):
         self._inner = inner
-        self._state = state           # dict shared with the model callback: {"T": Transform, "identity": bool}
         self._device = device
         self._gamma, self._cutoff = float(gamma), float(cutoff)
         self._pauses = list(pauses)
         self._next = 0                # index of the next pause
-        self._seg_lo = 0              # first draw of the segment still held in y coordinates
+        self._lo = 0                  # first draw of the current window
         self._lock = threading.Lock()
         self._cv = threading.Condition(self._lock)
+        self._step_lock = threading.Lock()   # held while the engine steps or a metric is being installed: readers take it
         self._paused = False
         self._abort = False
         self._done = False
@@ -184,14 +191,14 @@ class LowRankSampler:
                         self._cv.wait()
                     if self._abort:
                         break
-                done, _, _ = self._inner.step(64)
-                if done:
-                    break
-                if self._next < len(self._pauses):
-                    code = self._inner.waiting_codes()
-                    if (code == 1).any() and not (code == 0).any():
-                        self._adapt(np.nonzero(code == 1)[0])
-            self._convert_tail_in_place()
+                with self._step_lock:
+                    done, _, _ = self._inner.step(16)
+                    if done:
+                        break
+                    if self._next < len(self._pauses):
+                        code = self._inner.waiting_codes()
+                        if (code == 1).any() and not (code == 0).any():
+                            self._adapt(np.nonzero(code == 1)[0])
         except BaseException as e:  # noqa: BLE001 - reported by wait()
             self._error = e
         finally:
@@ -204,48 +211,27 @@ class LowRankSampler:
 
         n, T, D = self._inner.num_chains, self._inner.total_draws, self._inner.dim
         draws = device_tensor(self._inner.device_ptr("draws"), (n, T, D), "float64", self._device)
-        gp = self._inner.device_ptr("gradient")
-        grads = device_tensor(gp, (n, T, D), "float64", self._device) if gp else None
+        grads = device_tensor(self._inner.device_ptr("gradient"), (n, T, D), "float64", self._device)
         return draws, grads
 
     def _adapt(self, chains):
         import torch
 
         t0 = time.perf_counter()
-        hi = self._pauses[self._next]
-        lo = self._seg_lo
+        hi, lo = self._pauses[self._next], self._lo
         draws, grads = self._views()
-        T_old = self._state["T"]
         with torch.no_grad():
-            if not self._state["identity"]:
-                draws[:, lo:hi] = T_old.forward(draws[:, lo:hi])
-                grads[:, lo:hi] = T_old.grad_to_x(grads[:, lo:hi])
             m = min(WINDOW_MAX, max(4, (hi - lo) * 2 // 3))
-            x, gx = draws[:, hi - m:hi], grads[:, hi - m:hi]
-            T_new = estimate(x, gx, self._gamma, self._cutoff)
-            y_new = T_new.inverse(draws[:, hi - 1])
+            T_new = estimate(draws[:, hi - m:hi], grads[:, hi - m:hi], self._gamma, self._cutoff)
+            sig2, V, lam = metric_of(T_new)
+            idx = torch.as_tensor(chains, device=sig2.device)
+            if len(chains) != sig2.shape[0]:
+                sig2, V, lam = sig2[idx].contiguous(), V[idx].contiguous(), lam[idx].contiguous()
             torch.cuda.synchronize(self._device)
-        self._state["T"], self._state["identity"] = T_new, False
-        self._seg_lo = hi
+            self._inner.set_metric(chains, sig2, V, lam)
+        self._lo = hi
         self._next += 1
-        self._inner.resume_at(chains, y_new[torch.as_tensor(chains, device=y_new.device)] if len(chains) != y_new.shape[0] else y_new)
         self.switch_log.append((hi, float((T_new.d != 0).sum(1).double().mean()), time.perf_counter() - t0))
-
-    def _convert_tail_in_place(self):
-        """After the last draw: the segment since the last switch goes to model space too (per chain up to its finished draw)."""
-        import torch
-
-        if self._state["identity"]:
-            return
-        draws, grads = self._views()
-        with torch.no_grad():
-            lo = self._seg_lo
-            draws[:, lo:] = self._state["T"].forward(draws[:, lo:])
-            if grads is not None:
-                grads[:, lo:] = self._state["T"].grad_to_x(grads[:, lo:])
-            torch.cuda.synchronize(self._device)
-        self._seg_lo = self._inner.total_draws
-        self._state["identity"] = True   # the trace is in model space now; nothing is evaluated any more
 
     # ------------------------------------------------------------------ handle surface
     def wait(self, timeout_seconds=None):
@@ -284,46 +270,24 @@ class LowRankSampler:
     def is_empty(self, ignore_error=False):
         return self._inner.is_empty(ignore_error)
 
-    def _snapshot_patched(self, res):
-        # a trace read before the end still holds the current segment in y coordinates: patch the host copy
-        import torch
-
-        if self._state["identity"] or res.draws is None:
-            return res
-        lo = self._seg_lo
-        draws, grads = self._views()
-        with torch.no_grad():
-            res.draws[:, lo:] = self._state["T"].forward(draws[:, lo:]).cpu().numpy()
-            if grads is not None and "gradient" in res.stats:
-                res.stats["gradient"][:, lo:] = self._state["T"].grad_to_x(grads[:, lo:]).cpu().numpy()
-        return res
-
     def inspect(self):
-        with self._cv:
-            was = self._paused
-            self._paused = True
-        try:
-            time.sleep(0.05)
-            dev_expand = self._inner.__dict__.pop("_device_expand", None) if not self._done else None
-            res = self._snapshot_patched(self._inner.inspect())
-            if dev_expand is not None:
-                self._inner._device_expand = dev_expand
-            return res
-        finally:
-            with self._cv:
-                self._paused = was
-                self._cv.notify_all()
+        with self._step_lock:   # (between two engine steps, never inside an adaptation)
+            return self._inner.inspect()
+
+    def progress(self):
+        with self._step_lock:
+            return self._inner.progress()
 
     def take_results(self):
         self._thread.join()
-        return self._snapshot_patched(self._inner.take_results())
+        return self._inner.take_results()
 
     def close(self):
         if not self._done:
             self.abort()
         self._inner.close()
 
-    def __getattr__(self, name):   # num_chains, dim, progress(), device_ptr(), seconds, ...
+    def __getattr__(self, name):   # num_chains, dim, device_ptr(), seconds, ...
         return getattr(self._inner, name)
 
     def __setattr__(self, name, value):
@@ -331,3 +295,21 @@ class LowRankSampler:
             setattr(self._inner, name, value)
         else:
             object.__setattr__(self, name, value)
+
+
+def make_sampler(compiled_model, settings, init_mean, cores, progress_type, extra_callback, extra_callback_rate, store, **engine_kw):
+    """``compiled_model._make_sampler`` for ``adaptation="low_rank"``: any model flavour."""
+    import torch
+
+    if not torch.cuda.is_available():
+        raise RuntimeError("adaptation='low_rank' needs a GPU: the nutpie-hip engine has no CPU fallback")
+    if not engine_kw.get("store_draws", True):
+        raise ValueError("adaptation='low_rank' estimates the metric from the stored draws: store_draws=False cannot be combined with it")
+    pauses = pause_draws(int(settings.num_tune))
+    inner_settings = settings.clone()
+    inner_settings.update(low_rank_metric=True, store_gradient=True)   # the estimator needs the gradients of the window's draws
+    inner_settings.set_pause_draws(pauses)
+    device = int(engine_kw.get("device", 0) or 0)
+    inner = compiled_model._make_sampler(inner_settings, init_mean, cores, progress_type, extra_callback, extra_callback_rate, store,
+                                         **{**engine_kw, "manual": True})
+    return LowRankSampler(inner, device, settings._low_rank["mass_matrix_gamma"], settings._low_rank["mass_matrix_eigval_cutoff"], pauses)

@@ -87,9 +87,16 @@ class _BackgroundSampler:
         self._html = None
         if store is not None:
             raise NotImplementedError("zarr_store is outside the scope of the HIP engine (trace lives in HBM)")
-        self._sampler = compiled_model._make_sampler(
-            settings, init_mean, cores, None, None, progress_rate, None, **(engine_kwargs or {})
-        )   # (the progress callback is driven by the poll thread below, not by the sampler handle)
+        make = compiled_model._make_sampler
+        if getattr(settings, "_adaptation", "diag") == "low_rank":
+            # the low-rank metric lives in the engine; its window estimator drives the sampler from the host (nutpie_amd/low_rank.py)
+            from functools import partial
+
+            from nutpie_amd import low_rank
+
+            make = partial(low_rank.make_sampler, compiled_model)
+        self._sampler = make(settings, init_mean, cores, None, None, progress_rate, None, **(engine_kwargs or {}))
+        # (the progress callback is driven by the poll thread below, not by the sampler handle)
         # raw unconstrained draws only cross PCIe when somebody asked for them (device-expanding models)
         self._sampler._keep_host_draws = bool(return_raw_trace or store_unconstrained or settings.store_unconstrained)
         self._stop = threading.Event()
@@ -281,7 +288,7 @@ def sample(
 
     Keyword arguments, defaults and error behaviour follow ``nutpie.sample``
     (reference sample.py:823-1102).  ``adaptation`` accepts ``"diag"`` (default, draw+gradient
-    variance), ``"draw_diag"`` and — for batched device models (``from_torchfunc``) — ``"low_rank"`` with
+    variance), ``"draw_diag"`` and ``"low_rank"`` (every model flavour: the metric is applied inside the engine) with
     ``mass_matrix_eigval_cutoff`` / ``mass_matrix_gamma``; ``"flow"`` and ``sampler="mclmc"`` raise
     ``NotImplementedError`` (out of scope for the HIP engine).  ``cores`` is accepted and ignored:
     all chains run concurrently on the GPU.
@@ -293,10 +300,6 @@ def sample(
     # behaviour (accepted keywords, warnings, error texts) documented at reference sample.py:979-1070; written independently
     adaptation, grad_based = _legacy_adaptation(adaptation, kwargs)
     settings = _settings_for(sampler, adaptation, seed)
-    if adaptation == "low_rank" and not getattr(compiled_model, "_supports_low_rank", False):
-        raise NotImplementedError(
-            "adaptation='low_rank' needs a batched device model (nutpie_amd.from_torchfunc / from_torch_density): the metric is "
-            "applied around the density on the GPU (nutpie_amd/low_rank.py)")
     if adaptation == "draw_diag" or grad_based is False:
         settings.use_grad_based_mass_matrix = False
     overrides = {"num_tune": tune, "num_draws": draws, "num_chains": chains}

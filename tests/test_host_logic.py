@@ -69,8 +69,11 @@ def test_sample_argument_handling():
         nutpie_amd.sample(m, adaptation="foo")
     with pytest.raises(ValueError, match="Unknown sampler 'hmc'"):                 # sample.py:1044-1047
         nutpie_amd.sample(m, sampler="hmc")
-    with pytest.raises(NotImplementedError, match="batched device model"):          # low-rank lives around torch densities
-        nutpie_amd.sample(m, adaptation="low_rank")
+    import torch
+
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="needs a GPU"):                          # every model flavour takes the low-rank metric — on a GPU
+            nutpie_amd.sample(m, adaptation="low_rank")
     with pytest.raises(NotImplementedError):
         nutpie_amd.sample(m, adaptation="flow")
     with pytest.raises(NotImplementedError):
@@ -81,8 +84,11 @@ def test_sample_argument_handling():
         nutpie_amd.sample(m, mass_matrix_gamma=1e-5)
     with warnings.catch_warnings(record=True) as w:                                # deprecated aliases, sample.py:979-1013
         warnings.simplefilter("always")
-        with pytest.raises(NotImplementedError):
-            nutpie_amd.sample(m, low_rank_modified_mass_matrix=True)
+        if not torch.cuda.is_available():
+            with pytest.raises(RuntimeError, match="needs a GPU"):
+                nutpie_amd.sample(m, low_rank_modified_mass_matrix=True)
+        else:
+            nutpie_amd.sample(m, low_rank_modified_mass_matrix=True, chains=2, tune=50, draws=10, progress_bar=False)
         assert any(issubclass(x.category, FutureWarning) for x in w)
     with pytest.raises(ValueError, match="cannot be combined"):
         with warnings.catch_warnings():
