@@ -45,7 +45,7 @@ def test_traffic_table_matches_the_committed_pmc_summaries():
         w = float(re.search(r"WRITE_SIZE\s+n=\s*\d+\s+mean=([0-9.e+]+)", txt).group(1))
         assert abs((2 * f + w) * 1024 / e["leapfrogs_per_launch"] - e["bytes_per_leapfrog"]) < 1.0, key
     bpl, src = bench.measured_traffic(10000, 4, None)
-    assert 1.0 < bpl / (40 * 10000) < 1.3 and src.startswith("profiles/")          # <= 1.3x algorithmic
+    assert 0.9 < bpl / (40 * 10000) < 1.3 and src.startswith("profiles/")          # <= 1.3x algorithmic
     assert bench.measured_traffic(777, 1, None) == (None, None)
     assert bench.kernel_name(1000, 1) == "k_advance<fused,W=1,NV=8>" and "lean" in bench.kernel_name(10000, 4)
 
@@ -66,7 +66,7 @@ def test_roofline_object_is_a_fraction_of_the_binding_resource():
     assert abs(r["issue"]["insts_per_leapfrog"]["total"] - sum(v for k, v in r["issue"]["insts_per_leapfrog"].items() if k != "total")) < 1e-6
     h = bench.roofline(10000, 4, 1024, 1024 * 512, 37.02e-3)       # r2_bench_d10000_final: 37.02 ms per launch of 524 288 leapfrogs
     assert h["bound"] == "hbm" and h["unit"] == "GB/s" and 0.5 < h["frac"] <= 1.0
-    assert h["frac"] == h["hbm_measured"]["frac_of_peak"] and h["hbm_measured"]["over_algorithmic"] > 1.0
+    assert h["frac"] == h["hbm_measured"]["frac_of_peak"] and 0.9 < h["hbm_measured"]["over_algorithmic"] < 1.3
     u = bench.roofline(777, 1, 1024, 1024 * 2048, 5e-3)            # no PMC summary for this kernel: labelled, and capped
     assert u["frac"] <= 1.0 and u["traffic"] is None and "no PMC summary" in u["note"]
 
