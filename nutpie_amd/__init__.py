@@ -12,6 +12,7 @@ from nutpie_amd.compile_pymc import compile_pymc_model
 from nutpie_amd.compile_stan import compile_stan_model, prune_stan_cache
 from nutpie_amd.compiled_pyfunc import from_pyfunc, from_torch_density, from_torchfunc
 from nutpie_amd.density import from_density_source
+from nutpie_amd import symbolic
 from nutpie_amd.gaussian import ar1_gaussian, dense_gaussian, diag_gaussian, std_normal
 from nutpie_amd.sample import CompiledModel, sample
 
@@ -54,6 +55,7 @@ __all__ = [
     "from_torchfunc",
     "from_torch_density",
     "from_density_source",
+    "symbolic",
     "std_normal",
     "diag_gaussian",
     "ar1_gaussian",

@@ -79,13 +79,15 @@ def compile_pymc_model(model, *, backend="numba", gradient_backend="pytensor", i
     """Same keyword signature as the reference (compile_pymc.py:523-537)."""
     if find_spec("pymc") is None:
         raise ImportError(
-            "pymc is not installed in this environment.  PyMC graph compilation is outside the scope of the HIP "
-            "engine; use nutpie_amd.from_torchfunc (batched torch logp), nutpie_amd.from_pyfunc, or "
-            "nutpie_amd.compile_pymc.from_raw_callback with the numba cfunc address the reference produces."
+            "pymc is not installed in this environment.  Write the model with nutpie_amd.symbolic (expressions -> generated "
+            "HIP density -> resident kernel), or use nutpie_amd.from_density_source (HIP source), nutpie_amd.from_torchfunc "
+            "(batched torch logp), nutpie_amd.from_pyfunc, or nutpie_amd.compile_pymc.from_raw_callback with the numba cfunc "
+            "address the reference produces."
         )
     raise NotImplementedError(
-        "PyMC graph compilation is outside the scope of the HIP engine (no PyTensor backend was built or tested here). "
-        "Compile the model with the reference and pass its numba cfunc addresses to "
-        "nutpie_amd.compile_pymc.from_raw_callback(n_dim, logp_address, expand_address=..., expanded_shapes=...), or "
-        "write the density for nutpie_amd.from_torchfunc."
+        "No PyTensor graph translator was built or tested here (PyTensor is not installable on the target image).  The "
+        "back half of that pipeline exists: nutpie_amd.symbolic turns an expression graph into a HIP density with its "
+        "gradient and compiles it into the resident kernel.  Otherwise compile the model with the reference and pass its "
+        "numba cfunc addresses to nutpie_amd.compile_pymc.from_raw_callback(n_dim, logp_address, expand_address=..., "
+        "expanded_shapes=...), or write the density for nutpie_amd.from_torchfunc / from_density_source."
     )

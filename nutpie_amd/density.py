@@ -259,6 +259,30 @@ class DensitySourceModel(CompiledModel):
     def library(self) -> DensityLibrary:
         return DensityLibrary(compile_density(self._source, data_layout(self._data), self._n_dim))
 
+    def logp_and_grad(self, x, device: int = 0):
+        """The compiled density on a block of positions ``x[N, n_dim]`` (one launch of the batched form, ``nphip_jit_logp``):
+        ``(logp[N], grad[N, n_dim])`` as numpy arrays.  For checking a model; sampling never goes through the host."""
+        import torch
+
+        lib = self.library()
+        dd = DeviceData(self._data, data_layout(self._data), device)
+        dev = torch.device("cuda", device)
+        xt = torch.as_tensor(np.atleast_2d(np.asarray(x, dtype=np.float64))).to(dev).contiguous()
+        N, D = xt.shape
+        if D != self._n_dim:
+            raise ValueError(f"positions have {D} columns, the model {self._n_dim} dimensions")
+        g = torch.empty_like(xt)
+        lp = torch.empty(N, dtype=torch.float64, device=dev)
+        lds_bytes, shared_bytes = self._lds()
+        batch = _Batch(dd.ptr, lds_bytes // 8, shared_bytes // 8)
+        call = C.CFUNCTYPE(C.c_int, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)(lib.logp_addr)
+        with torch.cuda.device(dev):
+            rc = call(N, D, xt.data_ptr(), g.data_ptr(), lp.data_ptr(), torch.cuda.current_stream().cuda_stream, C.addressof(batch))
+            torch.cuda.synchronize()
+        if rc != 0:
+            raise RuntimeError(f"launching the density failed ({rc}): too much LDS?")
+        return lp.cpu().numpy(), g.cpu().numpy()
+
     def _make_model(self, init_mean=None, settings=None, device: int = 0, resident: bool | None = None):
         lib = self.library()
         dd = DeviceData(self._data, data_layout(self._data), device)

@@ -203,7 +203,8 @@ class _BackgroundSampler:
 
     def cancel(self):
         """Abort sampling and discard progress."""
-        self._sampler.abort()
+        if not self._sampler.is_empty():   # (an error after the results were taken — in the expand step, say — must stay visible)
+            self._sampler.abort()
         self._finish_progress()
         self._sampler.close()
 

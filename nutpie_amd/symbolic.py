@@ -1,0 +1,1016 @@
+"""A model front-end that PRODUCES a device density: expressions -> reverse-mode gradient -> HIP source -> resident kernel.
+
+The reference compiles a PyMC model by asking PyTensor for the graph of ``logp`` and its gradient, joining them into one
+function of the flat unconstrained vector and handing that to a compiler (``python/nutpie/compile_pymc.py:523-871``); the
+model's observed data stay *shared variables* that ``with_data`` swaps (``:140-166``, ``:239-269``).  PyMC and PyTensor are
+not available on the target image, so this module is the part of that pipeline that does not need them, built for the GPU:
+
+    m = Model()
+    mu    = m.param("mu")                           # scalar
+    sigma = m.param("sigma", lower=0.0)             # log-transformed, Jacobian added  (PyMC's LogTransform)
+    a     = m.param("a", dim="county", size=85, zero_sum=True)     # PyMC's ZeroSumTransform
+    y     = m.data("y", y_values, dim="obs")
+    idx   = m.index("county_idx", county_values, dim="obs", into="county")
+    m.add_logp(normal_lpdf(a, 0.0, 1.0).sum())
+    m.add_logp(normal_lpdf(y, mu + a[idx], sigma).sum())
+    m.deterministic("a", a)
+    compiled = m.compile()                          # -> nutpie_amd.density.DensitySourceModel
+
+``compile`` differentiates the expression graph symbolically (reverse mode, the gradient is a graph in the same IR),
+schedules logp and gradient together into wave-wide loops — one wavefront evaluates one chain's density, lanes stride over
+the elements of a *dimension* (a coordinate of the model: counties, observations) —, and prints the HIP device function
+``nphip_density`` that :func:`nutpie_amd.from_density_source` compiles into the engine's resident NUTS kernel.
+
+The IR has five kinds of nodes: scalars; element-wise values over a dimension; ``Sum`` (dimension -> scalar);
+``Gather`` (``v[idx]``: dimension A -> dimension B through an integer data array); ``SegSum`` (its transpose: for every
+element of A the sum over the elements of B that point to it).  The transpose of a gather is evaluated without atomics and
+in a fixed order: the adjoints are stored in LDS *grouped by target* (the host computes the grouping permutation once per
+data set) and every lane sums a contiguous range.  Values a later loop needs from an earlier one (gather sources, adjoints)
+live in per-chain LDS; the model's data are staged into the workgroup's shared LDS once per launch.  Everything else is
+recomputed where it is used.
+
+Only the log-density is generated code.  ``deterministic`` values (the reference's expand step: ``compile_pymc.py:601-666``)
+are evaluated on the host with numpy from the drawn positions.
+"""
+
+from __future__ import annotations
+
+import math
+from typing import Any
+
+import numpy as np
+
+__all__ = ["Model", "Expr", "exp", "log", "log1p", "sqrt", "softplus", "sigmoid", "where_lt", "normal_lpdf", "halfnormal_lpdf",
+           "student_t_lpdf", "bernoulli_logit_lpmf", "poisson_log_lpmf"]
+
+_WAVE = 64
+_UNROLL = 4   # iterations of a loop whose reads are issued together (a lone wave waits out every access otherwise)
+
+
+# --------------------------------------------------------------------------- IR
+class Dim:
+    """A named coordinate of the model: the range one wave-wide loop runs over."""
+
+    def __init__(self, name: str, size, runtime_len: str | None = None):
+        self.name = name
+        self.size = size                  # int, or None for a data dimension whose length comes from the data block
+        self.runtime_len = runtime_len    # C expression of the length for data dimensions ("data.n_y")
+
+    def __repr__(self):
+        return f"Dim({self.name})"
+
+
+class Index:
+    """Integer data: for every element of ``dim`` the element of ``into`` it refers to."""
+
+    def __init__(self, name: str, dim: Dim, into: Dim):
+        self.name, self.dim, self.into = name, dim, into
+
+
+class Expr:
+    """A node of the expression graph.  ``dim`` is None for scalars.  Nodes are hash-consed by ``Model``-independent structural
+    keys, so that the gradient graph shares its sub-expressions with the forward graph."""
+
+    _table: dict[tuple, "Expr"] = {}
+    _count = 0
+    __array_ufunc__ = None     # numpy scalars defer to the operators below
+
+    def __new__(cls, op: str, args: tuple = (), dim: Dim | None = None, payload: Any = None):
+        key = (op, tuple(id(a) for a in args), id(dim) if dim is not None else None, payload if not isinstance(payload, (Index, Dim)) else id(payload))
+        hit = Expr._table.get(key)
+        if hit is not None:
+            return hit
+        self = object.__new__(cls)
+        self.op, self.args, self.dim, self.payload = op, tuple(args), dim, payload
+        self.id = Expr._count
+        Expr._count += 1
+        Expr._table[key] = self
+        return self
+
+    # ---- construction helpers
+    @staticmethod
+    def const(v) -> "Expr":
+        return Expr("const", (), None, float(v))
+
+    @staticmethod
+    def wrap(v) -> "Expr":
+        return v if isinstance(v, Expr) else Expr.const(v)
+
+    def is_const(self, v=None):
+        return self.op == "const" and (v is None or self.payload == v)
+
+    def _bin(self, op, other, swap=False):
+        a, b = Expr.wrap(self), Expr.wrap(other)
+        if swap:
+            a, b = b, a
+        return _binary(op, a, b)
+
+    __add__ = lambda s, o: s._bin("add", o)           # noqa: E731
+    __radd__ = lambda s, o: s._bin("add", o, True)    # noqa: E731
+    __sub__ = lambda s, o: s._bin("sub", o)           # noqa: E731
+    __rsub__ = lambda s, o: s._bin("sub", o, True)    # noqa: E731
+    __mul__ = lambda s, o: s._bin("mul", o)           # noqa: E731
+    __rmul__ = lambda s, o: s._bin("mul", o, True)    # noqa: E731
+    __truediv__ = lambda s, o: s._bin("div", o)       # noqa: E731
+    __rtruediv__ = lambda s, o: s._bin("div", o, True)  # noqa: E731
+
+    def __neg__(self):
+        return _unary("neg", self)
+
+    def __pow__(self, k):
+        if k == 2:
+            return self * self
+        raise TypeError("only `** 2` is supported: write other powers with exp / log")
+
+    def __getitem__(self, index: Index) -> "Expr":
+        if not isinstance(index, Index):
+            raise TypeError("an expression is indexed with a Model.index(...) array")
+        if self.dim is not index.into:
+            raise ValueError(f"index {index.name!r} points into dimension {index.into.name!r}, the expression lives on {self.dim.name if self.dim else 'no dimension'!r}")
+        return Expr("gather", (self,), index.dim, index)
+
+    def sum(self) -> "Expr":
+        if self.dim is None:
+            raise ValueError("sum() of a scalar")
+        return Expr("sum", (self,), None, None)
+
+    def __repr__(self):
+        return f"<{self.op}#{self.id}{'@' + self.dim.name if self.dim else ''}>"
+
+
+def _join(a: Expr, b: Expr) -> Dim | None:
+    if a.dim is None:
+        return b.dim
+    if b.dim is None or a.dim is b.dim:
+        return a.dim
+    raise ValueError(f"operands live on different dimensions ({a.dim.name!r}, {b.dim.name!r}): index one into the other")
+
+
+def _binary(op: str, a: Expr, b: Expr) -> Expr:
+    # constant folding and the identities the gradient graph is full of
+    if a.op == "const" and b.op == "const":
+        x, y = a.payload, b.payload
+        return Expr.const({"add": x + y, "sub": x - y, "mul": x * y, "div": x / y if y != 0.0 else math.copysign(math.inf, x)}[op])
+    if op == "add":
+        if a.is_const(0.0):
+            return b
+        if b.is_const(0.0):
+            return a
+    elif op == "sub":
+        if b.is_const(0.0):
+            return a
+        if a.is_const(0.0):
+            return _unary("neg", b)
+    elif op == "mul":
+        if a.is_const(1.0):
+            return b
+        if b.is_const(1.0):
+            return a
+        if a.is_const(0.0) or b.is_const(0.0):
+            return Expr.const(0.0)
+        if a.is_const(-1.0):
+            return _unary("neg", b)
+        if b.is_const(-1.0):
+            return _unary("neg", a)
+    elif op == "div":
+        if b.is_const(1.0):
+            return a
+        if a.is_const(0.0):
+            return a
+        if a.dim is not None and b.dim is None:
+            # one division per evaluation instead of one per element (the numpy evaluation follows the same graph)
+            return _binary("mul", a, _binary("div", Expr.const(1.0), b))
+    return Expr(op, (a, b), _join(a, b))
+
+
+_UNARY_FOLD = {"neg": lambda v: -v, "exp": math.exp, "log": math.log, "log1p": math.log1p, "sqrt": math.sqrt,
+               "softplus": lambda v: max(v, 0.0) + math.log1p(math.exp(-abs(v))), "sigmoid": lambda v: 1.0 / (1.0 + math.exp(-v))}
+
+
+def _unary(op: str, a) -> Expr:
+    a = Expr.wrap(a)
+    if a.op == "const":
+        return Expr.const(_UNARY_FOLD[op](a.payload))
+    if op == "neg" and a.op == "neg":
+        return a.args[0]
+    return Expr(op, (a,), a.dim)
+
+
+def exp(a):
+    return _unary("exp", a)
+
+
+def log(a):
+    return _unary("log", a)
+
+
+def log1p(a):
+    return _unary("log1p", a)
+
+
+def sqrt(a):
+    return _unary("sqrt", a)
+
+
+def softplus(a):
+    """log(1 + e^a), evaluated as max(a, 0) + log1p(e^-|a|)."""
+    return _unary("softplus", a)
+
+
+def sigmoid(a):
+    return _unary("sigmoid", a)
+
+
+def where_lt(dim: Dim, k: int, a, b) -> Expr:
+    """``a`` on the first ``k`` elements of ``dim``, ``b`` on the rest."""
+    a, b = Expr.wrap(a), Expr.wrap(b)
+    for v in (a, b):
+        if v.dim is not None and v.dim is not dim:
+            raise ValueError("where_lt: operands must be scalars or live on `dim`")
+    return Expr("where_lt", (a, b), dim, int(k))
+
+
+def _bcast(a: Expr, dim: Dim) -> Expr:
+    return a if a.dim is dim else Expr("bcast", (a,), dim, None)
+
+
+def _dim_len(dim: Dim) -> Expr:
+    return Expr.const(dim.size) if dim.size is not None else Expr("dimlen", (), None, dim)
+
+
+def _segsum(e: Expr, index: Index) -> Expr:
+    if e.is_const(0.0):
+        return e
+    return Expr("segsum", (_bcast(e, index.dim),), index.into, index)
+
+
+# --------------------------------------------------------------------------- densities
+_HALF_LOG_2PI = 0.5 * math.log(2.0 * math.pi)
+
+
+def normal_lpdf(x, mu, sigma) -> Expr:
+    x, mu, sigma = Expr.wrap(x), Expr.wrap(mu), Expr.wrap(sigma)
+    z = (x - mu) / sigma
+    return -0.5 * (z * z) - log(sigma) - _HALF_LOG_2PI
+
+
+def halfnormal_lpdf(x, sigma) -> Expr:
+    """x >= 0 (a ``lower=0`` parameter)."""
+    x, sigma = Expr.wrap(x), Expr.wrap(sigma)
+    z = x / sigma
+    return -0.5 * (z * z) - log(sigma) + 0.5 * math.log(2.0 / math.pi)
+
+
+def student_t_lpdf(x, nu: float, mu, sigma) -> Expr:
+    """``nu`` is a Python number (its log-gamma terms are folded on the host)."""
+    x, mu, sigma = Expr.wrap(x), Expr.wrap(mu), Expr.wrap(sigma)
+    nu = float(nu)
+    z = (x - mu) / sigma
+    c = math.lgamma(0.5 * (nu + 1.0)) - math.lgamma(0.5 * nu) - 0.5 * math.log(nu * math.pi)
+    return c - log(sigma) - (0.5 * (nu + 1.0)) * log1p((z * z) / nu)
+
+
+def bernoulli_logit_lpmf(y, eta) -> Expr:
+    """y in {0, 1} (data), eta the logit."""
+    y, eta = Expr.wrap(y), Expr.wrap(eta)
+    return y * eta - softplus(eta)
+
+
+def poisson_log_lpmf(y, eta, log_factorial) -> Expr:
+    """y counts (data), eta = log rate, ``log_factorial`` = data holding lgamma(y + 1) (``Model.data`` of ``scipy.special.gammaln``)."""
+    y, eta = Expr.wrap(y), Expr.wrap(eta)
+    return y * eta - exp(eta) - Expr.wrap(log_factorial)
+
+
+# --------------------------------------------------------------------------- reverse mode
+def _topo(roots) -> list[Expr]:
+    seen, order = set(), []
+    stack = [(r, False) for r in roots]
+    while stack:
+        n, done = stack.pop()
+        if done:
+            order.append(n)
+            continue
+        if n.id in seen:
+            continue
+        seen.add(n.id)
+        stack.append((n, True))
+        for a in n.args:
+            if a.id not in seen:
+                stack.append((a, False))
+    return order
+
+
+def gradient(out: Expr, wrt: list[Expr]) -> list[Expr]:
+    """d out / d wrt[k] as expressions (``out`` a scalar; every ``wrt[k]`` a parameter node).  The adjoint of a node lives on the
+    node's dimension; a scalar-valued adjoint of a dimensioned node means the same value for every element."""
+    if out.dim is not None:
+        raise ValueError("the log-density must be a scalar: sum() the element-wise terms")
+    order = _topo([out])
+    adj: dict[int, Expr] = {out.id: Expr.const(1.0)}
+
+    def reduce_to(e: Expr, from_dim, target: Expr) -> Expr:
+        """the adjoint contribution ``e`` — one value per element of ``from_dim`` — folded onto ``target``'s dimension"""
+        if target.dim is from_dim:
+            return e
+        if target.dim is None:
+            return e.sum() if e.dim is not None else _dim_len(from_dim) * e
+        raise AssertionError("dimension mismatch in the gradient")
+
+    def acc(target: Expr, e: Expr):
+        if e.is_const(0.0) or target.op in ("const", "data", "dimlen"):
+            return
+        adj[target.id] = adj[target.id] + e if target.id in adj else e
+
+    for n in reversed(order):
+        g = adj.get(n.id)
+        if g is None or not n.args:
+            continue
+        d = n.dim
+        a = n.args[0]
+        b = n.args[1] if len(n.args) > 1 else None
+        if n.op == "add":
+            acc(a, reduce_to(g, d, a)); acc(b, reduce_to(g, d, b))
+        elif n.op == "sub":
+            acc(a, reduce_to(g, d, a)); acc(b, reduce_to(-g, d, b))
+        elif n.op == "mul":
+            acc(a, reduce_to(g * b, d, a)); acc(b, reduce_to(g * a, d, b))
+        elif n.op == "div":
+            acc(a, reduce_to(g / b, d, a)); acc(b, reduce_to(-(g * n) / b, d, b))
+        elif n.op == "neg":
+            acc(a, -g)
+        elif n.op == "exp":
+            acc(a, g * n)
+        elif n.op == "log":
+            acc(a, g / a)
+        elif n.op == "log1p":
+            acc(a, g / (1.0 + a))
+        elif n.op == "sqrt":
+            acc(a, g / (2.0 * n))
+        elif n.op == "softplus":
+            acc(a, g * sigmoid(a))
+        elif n.op == "sigmoid":
+            acc(a, g * (n * (1.0 - n)))
+        elif n.op == "where_lt":
+            acc(a, reduce_to(where_lt(d, n.payload, g, 0.0), d, a)); acc(b, reduce_to(where_lt(d, n.payload, 0.0, g), d, b))
+        elif n.op == "bcast":
+            acc(a, reduce_to(g, d, a))
+        elif n.op == "sum":
+            acc(a, g)                      # the same scalar for every element
+        elif n.op == "gather":
+            acc(a, _segsum(g, n.payload))
+        elif n.op == "segsum":
+            acc(a, _bcast(g, n.payload.into)[n.payload])
+        else:
+            raise AssertionError(n.op)
+    return [adj.get(w.id, Expr.const(0.0)) for w in wrt]
+
+
+# --------------------------------------------------------------------------- numpy evaluation (expand step; the tests' checker)
+def evaluate(nodes: list[Expr], x: np.ndarray, data: dict[str, Any]) -> list[np.ndarray]:
+    """Values of ``nodes`` for a block of positions ``x[N, D]``: scalars as ``[N]``, dimensioned nodes as ``[N, len]``."""
+    x = np.atleast_2d(np.asarray(x, dtype=np.float64))
+    N = x.shape[0]
+    val: dict[int, np.ndarray] = {}
+
+    def dim_len(dim: Dim) -> int:
+        return dim.size if dim.size is not None else int(np.asarray(data[dim.runtime_len]).size)
+
+    def up(v, n):     # align a scalar [N] with a dimensioned operand [N, len]
+        return v[:, None] if (n.dim is not None and v.ndim == 1) else v
+
+    for n in _topo(nodes):
+        a = val[n.args[0].id] if n.args else None
+        b = val[n.args[1].id] if len(n.args) > 1 else None
+        if n.op in ("add", "sub", "mul", "div", "where_lt"):
+            a, b = up(a, n), up(b, n)
+        with np.errstate(all="ignore"):
+            if n.op == "const":
+                v = np.full(N, n.payload)
+            elif n.op == "sparam":
+                v = x[:, n.payload]
+            elif n.op == "vparam":
+                off, nv = n.payload
+                v = np.zeros((N, dim_len(n.dim)))
+                v[:, :nv] = x[:, off:off + nv]
+            elif n.op == "data":
+                v = np.broadcast_to(np.asarray(data[n.payload], dtype=np.float64), (N, dim_len(n.dim)))
+            elif n.op == "sdata":
+                v = np.full(N, float(data[n.payload]))
+            elif n.op == "dimlen":
+                v = np.full(N, float(dim_len(n.payload)))
+            elif n.op == "add":
+                v = a + b
+            elif n.op == "sub":
+                v = a - b
+            elif n.op == "mul":
+                v = a * b
+            elif n.op == "div":
+                v = a / b
+            elif n.op == "neg":
+                v = -a
+            elif n.op == "exp":
+                v = np.exp(a)
+            elif n.op == "log":
+                v = np.log(a)
+            elif n.op == "log1p":
+                v = np.log1p(a)
+            elif n.op == "sqrt":
+                v = np.sqrt(a)
+            elif n.op == "softplus":
+                v = np.maximum(a, 0.0) + np.log1p(np.exp(-np.abs(a)))
+            elif n.op == "sigmoid":
+                v = 1.0 / (1.0 + np.exp(-a))
+            elif n.op == "where_lt":
+                L = dim_len(n.dim)
+                v = np.where((np.arange(L) < n.payload)[None, :], np.broadcast_to(a, (N, L)), np.broadcast_to(b, (N, L)))
+            elif n.op == "bcast":
+                v = np.broadcast_to(a[:, None] if a.ndim == 1 else a, (N, dim_len(n.dim)))
+            elif n.op == "sum":
+                v = a.sum(axis=1)
+            elif n.op == "gather":
+                v = a[:, np.asarray(data[n.payload.name], dtype=np.int64)]
+            elif n.op == "segsum":
+                idx = np.asarray(data[n.payload.name], dtype=np.int64)
+                v = np.zeros((N, dim_len(n.dim)))
+                np.add.at(v, (slice(None), idx), a)
+            else:
+                raise AssertionError(n.op)
+        val[n.id] = np.asarray(v, dtype=np.float64)
+    return [val[n.id] for n in nodes]
+
+
+# --------------------------------------------------------------------------- code generation
+class _Gen:
+    """logp + gradient -> the source of ``nphip_density``."""
+
+    def __init__(self, model: "Model", logp: Expr, grads: list[Expr]):
+        self.m = model
+        self.logp = logp
+        self.params = model._params
+        # gradient outputs: scalars by lane 0 at the end; vectors in a loop over their dimension
+        self.out_scalar = [(p, g) for p, g in zip(self.params, grads) if p.dim is None]
+        self.out_vector = [(p, _bcast(g, p.dim) if g.dim is None else g) for p, g in zip(self.params, grads) if p.dim is not None]
+        roots = [logp] + [g for _, g in self.out_scalar] + [g for _, g in self.out_vector]
+        self.order = _topo(roots)
+        self.level: dict[int, int] = {}
+        for n in self.order:
+            lv = max([self.level[a.id] for a in n.args], default=0)
+            if n.op in ("sum", "gather", "segsum"):
+                lv += 1
+            self.level[n.id] = lv
+        # where every dimensioned node is USED (the loop levels that read it): a node is read in the loop of its consumer
+        uses: dict[int, set[int]] = {}
+        for n in self.order:
+            for a in n.args:
+                if a.dim is None:
+                    continue
+                # sum / gather / segsum read their argument in the loop that produces the argument (sum: accumulate there;
+                # gather, segsum: the argument is stored there for the later loop)
+                at = self.level[a.id] if n.op in ("sum", "gather", "segsum") else self.level[n.id]
+                uses.setdefault(a.id, set()).add(at)
+        for _, g in self.out_vector:
+            uses.setdefault(g.id, set()).add(self.level[g.id])
+        # what lives in per-chain LDS: sources of gathers (unless they are parameters or data, read in place), arguments of
+        # segment sums (stored grouped by target), and segment sums that more than one loop reads
+        self.stored: dict[int, tuple[str, Dim]] = {}
+        for n in self.order:
+            if n.op == "gather" and n.args[0].op not in ("vparam", "data"):
+                self.stored[n.args[0].id] = ("plain", n.args[0].dim)
+            elif n.op == "segsum":
+                self.stored[("seg", n.args[0].id, n.payload.name)] = ("grouped", n.args[0].dim)
+                if len(uses.get(n.id, ())) > 1 or any(u > self.level[n.id] for u in uses.get(n.id, ())):
+                    self.stored[n.id] = ("plain", n.dim)
+        self.uses = uses
+
+    # ---- LDS layout
+    def lds_layout(self):
+        """[(key, dim)] in the order of allocation; the size of each entry is its dimension's length."""
+        return list(self.stored.items())
+
+    def source(self) -> tuple[str, list]:
+        m = self.m
+        L: list[str] = []
+        emit = L.append
+        stage_src, shared_fields = m._stage_source()
+        emit(stage_src)
+        emit("__device__ double nphip_density(const NphipData& data, int dim, const double* x, double* g, double* lds, const double* shared, int lane) {")
+        # dimension lengths, data pointers (shared LDS where staged, else global), LDS scratch
+        for d in m._dims.values():
+            emit(f"    const int n_{d.name} = {d.size if d.size is not None else 'data.n_' + d.runtime_len};")
+        off_expr = "0"
+        for name, kind, dim in shared_fields:
+            n_c = _field_len_c(name, dim)
+            if not m._staged:
+                emit(f"    const {'double' if kind == 'double' else 'int'}* __restrict__ D_{name} = data.{name};")
+            elif kind == "double":
+                emit(f"    const auto D_{name} = NPHIP_LDS_CPTR(double, shared + ({off_expr}));")
+                off_expr += f" + {n_c}"
+            else:
+                emit(f"    const auto D_{name} = NPHIP_LDS_CPTR(int, shared + ({off_expr}));")
+                off_expr += f" + ({n_c} + 1) / 2"
+        lds_off = "0"
+        self.store_name: dict[Any, str] = {}
+        for k, (key, (_, dim)) in enumerate(self.stored.items()):
+            self.store_name[key] = f"M{k}"
+            emit(f"    const auto M{k} = NPHIP_LDS_PTR(double, lds + ({lds_off}));")
+            lds_off += f" + n_{dim.name}"
+        max_level = max(self.level.values(), default=0)
+        done_scalar: set[int] = set()
+        self.L = L
+
+        def scalar_ready(n: Expr) -> bool:
+            return all(a.dim is not None or a.id in done_scalar for a in n.args)
+
+        for lv in range(max_level + 2):
+            # scalars of this level (sums were produced by the loops of the level below)
+            for n in self.order:
+                if n.dim is None and n.op != "sum" and self.level[n.id] == lv and n.id not in done_scalar:
+                    assert scalar_ready(n), n
+                    if n.op != "const":
+                        emit(f"    const double s{n.id} = {self.scalar_rhs(n)};")
+                    done_scalar.add(n.id)
+            # loops of this level, one per dimension that has something to produce here
+            for d in m._dims.values():
+                sums = [n for n in self.order if n.op == "sum" and n.args[0].dim is d and self.level[n.args[0].id] == lv]
+                stores = []
+                for key, (how, sd) in self.stored.items():
+                    if sd is not d:
+                        continue
+                    node_id = key[1] if isinstance(key, tuple) else key
+                    if self.level[node_id] == lv:
+                        stores.append((key, how))
+                outs = [(p, g) for p, g in self.out_vector if p.dim is d and self.level[g.id] == lv]
+                if not (sums or stores or outs):
+                    continue
+                self.loop(d, lv, sums, stores, outs)
+                for n in sums:
+                    done_scalar.add(n.id)
+        emit("    if (lane == 0) {")
+        for p, g in self.out_scalar:
+            emit(f"        g[{p.payload}] = {self.sref(g)};")
+        emit("    }")
+        emit(f"    return {self.sref(self.logp)};")
+        emit("}")
+        return "\n".join(L), shared_fields
+
+    # ---- scalars
+    def sref(self, n: Expr) -> str:
+        if n.op == "const":
+            return _lit(n.payload)
+        return f"s{n.id}"
+
+    def scalar_rhs(self, n: Expr) -> str:
+        if n.op == "sparam":
+            return f"x[{n.payload}]"
+        if n.op == "sdata":
+            return f"data.{n.payload}"
+        if n.op == "dimlen":
+            return f"(double)n_{n.payload.name}"
+        return _op_c(n.op, [self.sref(a) for a in n.args])
+
+    # ---- one wave-wide loop
+    def loop(self, d: Dim, lv: int, sums, stores, outs):
+        emit = self.L.append
+        U = _UNROLL if d.size is None else max(1, min(_UNROLL, -(-d.size // _WAVE)))
+        by_id = {n.id: n for n in self.order}
+        emit(f"    // level {lv}, over {d.name}")
+        for n in sums:
+            emit(f"    double s{n.id} = 0.0;")
+        emit(f"    for (int i0 = lane; i0 < n_{d.name}; i0 += {_WAVE * U}) {{")
+        stages: list[list[str]] = [[], [], [], [], []]   # 0 direct reads, 1 dependent reads, 2 segment sums, 3 arithmetic, 4 stores / sums
+        seg: dict[tuple, list[tuple[str, str]]] = {}     # (iteration, index) -> [(accumulator, array)]: one inner loop for all of them
+        for u in range(U):
+            memo: dict[int, str] = {}
+            stages[0].append(f"        const int i_{u} = i0 + {_WAVE * u}, j_{u} = i_{u} < n_{d.name} ? i_{u} : 0;")
+
+            def val(n: Expr, u=u, memo=memo) -> str:
+                if n.dim is None:
+                    return self.sref(n)
+                if n.id in memo:
+                    return memo[n.id]
+                name = f"v{n.id}_{u}"
+                if n.id in self.stored and self.level[n.id] < lv:
+                    stages[0].append(f"        const double {name} = {self.store_name[n.id]}[j_{u}];")
+                elif n.op == "vparam":
+                    off, nv = n.payload
+                    full = d.size is not None and nv == d.size
+                    stages[0].append(f"        const double {name} = " + (f"x[{off} + j_{u}];" if full else f"(j_{u} < {nv}) ? x[{off} + j_{u}] : 0.0;"))
+                elif n.op == "data":
+                    stages[0].append(f"        const double {name} = D_{n.payload}[j_{u}];")
+                elif n.op == "gather":
+                    src, index = n.args[0], n.payload
+                    iname = f"k{index.name}_{u}"
+                    if ("idx", index.name) not in memo:
+                        stages[0].append(f"        const int {iname} = D_{index.name}[j_{u}];")
+                        memo[("idx", index.name)] = iname
+                    if src.op == "vparam":
+                        off, nv = src.payload
+                        full = src.dim.size is not None and nv == src.dim.size
+                        stages[1].append(f"        const double {name} = " + (f"x[{off} + {iname}];" if full else f"({iname} < {nv}) ? x[{off} + {iname}] : 0.0;"))
+                    elif src.op == "data":
+                        stages[1].append(f"        const double {name} = D_{src.payload}[{iname}];")
+                    else:
+                        stages[1].append(f"        const double {name} = {self.store_name[src.id]}[{iname}];")
+                elif n.op == "segsum":
+                    index = n.payload
+                    arr = self.store_name[("seg", n.args[0].id, index.name)]
+                    if (u, index.name) not in seg:
+                        seg[(u, index.name)] = []
+                        stages[0].append(f"        const int r0{index.name}_{u} = D_{index.name}__rows[j_{u}], "
+                                         f"r1{index.name}_{u} = (i_{u} < n_{d.name}) ? D_{index.name}__rows[j_{u} + 1] : r0{index.name}_{u};")
+                    seg[(u, index.name)].append((name, arr))
+                elif n.op == "bcast":
+                    name = self.sref(n.args[0])
+                elif n.op == "where_lt":
+                    a, b = val(n.args[0]), val(n.args[1])
+                    stages[3].append(f"        const double {name} = (j_{u} < {n.payload}) ? {a} : {b};")
+                else:
+                    args = [val(a) for a in n.args]
+                    stages[3].append(f"        const double {name} = {_op_c(n.op, args)};")
+                memo[n.id] = name
+                return name
+
+            guard = f"if (i_{u} < n_{d.name}) "
+            for key, how in stores:
+                node = by_id[key[1] if isinstance(key, tuple) else key]
+                v = val(node)
+                if how == "grouped":
+                    index_name = key[2]
+                    pname = f"p{index_name}_{u}"
+                    if ("pos", index_name) not in memo:
+                        stages[0].append(f"        const int {pname} = D_{index_name}__pos[j_{u}];")
+                        memo[("pos", index_name)] = pname
+                    stages[4].append(f"        {guard}{self.store_name[key]}[{pname}] = {v};")
+                else:
+                    stages[4].append(f"        {guard}{self.store_name[key]}[i_{u}] = {v};")
+            for n in sums:
+                stages[4].append(f"        {guard}s{n.id} += {val(n.args[0])};")
+            for p, gexpr in outs:
+                off, nv = p.payload
+                stages[4].append(f"        if (i_{u} < {nv}) g[{off} + i_{u}] = {val(gexpr)};")
+        for (u, iname), accs in seg.items():
+            stages[2].append("        double " + ", ".join(f"{a} = 0.0" for a, _ in accs) + ";")
+            stages[2].append("#pragma unroll 4")
+            stages[2].append(f"        for (int k = r0{iname}_{u}; k < r1{iname}_{u}; ++k) {{ " + " ".join(f"{a} += {arr}[k];" for a, arr in accs) + " }")
+        for st in stages:
+            for line in st:
+                emit(line)
+        emit("    }")
+        # the loop's sums over the wave, several at a time
+        ids = [f"s{n.id}" for n in sums]
+        for k in range(0, len(ids), 4):
+            grp = ids[k:k + 4]
+            if len(grp) == 1:
+                emit(f"    {grp[0]} = nphip_wave_sum({grp[0]});")
+            elif len(grp) == 2:
+                emit(f"    {{ double z_ = 0.0; nphip_wave_sum3({grp[0]}, {grp[1]}, z_); }}")
+            else:
+                emit(f"    nphip_wave_sum{len(grp)}({', '.join(grp)});")
+        if stores:
+            emit('    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");')
+            emit("    __builtin_amdgcn_wave_barrier();")
+
+
+def _field_len_c(name: str, dim: Dim) -> str:
+    """C expression of the length of a data field (the ranges of a grouping have one more entry than the target dimension)"""
+    return f"(n_{dim.name} + 1)" if name.endswith("__rows") else f"n_{dim.name}"
+
+
+def _lit(v: float) -> str:
+    if math.isinf(v):
+        return "INFINITY" if v > 0 else "-INFINITY"
+    if math.isnan(v):
+        return "NAN"
+    return f"({float(v).hex()})" if v < 0 else float(v).hex()
+
+
+def _op_c(op: str, a: list[str]) -> str:
+    if op == "add":
+        return f"{a[0]} + {a[1]}"
+    if op == "sub":
+        return f"{a[0]} - {a[1]}"
+    if op == "mul":
+        return f"{a[0]} * {a[1]}"
+    if op == "div":
+        return f"{a[0]} / {a[1]}"
+    if op == "neg":
+        return f"-{a[0]}"
+    if op in ("exp", "log", "log1p", "sqrt"):
+        return f"{op}({a[0]})"
+    if op == "softplus":
+        return f"(fmax({a[0]}, 0.0) + log1p(exp(-fabs({a[0]}))))"
+    if op == "sigmoid":
+        return f"(1.0 / (1.0 + exp(-{a[0]})))"
+    raise AssertionError(op)
+
+
+# --------------------------------------------------------------------------- the model
+class Model:
+    """Collects parameters, data and log-density terms; ``compile()`` returns the sampler-ready model."""
+
+    #: LDS a workgroup may spend on staged data (bytes); beyond it the density reads its data from global memory (L2)
+    STAGE_LIMIT = 48 * 1024
+
+    def __init__(self):
+        self._dims: dict[str, Dim] = {}
+        self._params: list[Expr] = []          # sparam / vparam nodes in the order of the flat vector
+        self._param_names: list[str] = []
+        self._n_dim = 0
+        self._data: dict[str, Any] = {}
+        self._data_fields: list[tuple[str, str, Dim | None]] = []   # (name, "double" | "int", dim) in declaration order
+        self._indices: dict[str, Index] = {}
+        self._terms: list[Expr] = []
+        self._det: list[tuple[str, Expr]] = []
+        self._staged = True
+
+    # ---- declarations
+    def dim(self, name: str, size: int | None = None) -> Dim:
+        d = self._dims.get(name)
+        if d is None:
+            if size is None:
+                raise ValueError(f"dimension {name!r} is not known yet: give its size")
+            d = self._dims[name] = Dim(name, int(size))
+        elif size is not None and d.size is not None and d.size != int(size):
+            raise ValueError(f"dimension {name!r} has size {d.size}, not {size}")
+        return d
+
+    def _data_dim(self, name: str, array_name: str, n: int) -> Dim:
+        d = self._dims.get(name)
+        if d is None:
+            d = self._dims[name] = Dim(name, None, runtime_len=array_name)   # its length is that of its first data array
+        elif d.size is not None and d.size != n:
+            raise ValueError(f"data on dimension {name!r} must have length {d.size}")
+        elif d.size is None and len(self._data[d.runtime_len]) != n:
+            raise ValueError(f"data on dimension {name!r} must have length {len(self._data[d.runtime_len])}")
+        return d
+
+    def param(self, name: str, dim: str | None = None, size: int | None = None, lower: float | None = None, zero_sum: bool = False) -> Expr:
+        """A free parameter.  Scalar, or a vector over ``dim``.  ``lower``: the log transform ``value = lower + exp(raw)`` with its
+        Jacobian added to the density (PyMC's default transform of positive variables); ``zero_sum``: the vector sums to zero
+        (``size - 1`` free values, PyMC's isometric ZeroSumTransform — no Jacobian term)."""
+        if name in self._param_names:
+            raise ValueError(f"parameter {name!r} is defined twice")
+        self._param_names.append(name)
+        if dim is None:
+            raw = Expr("sparam", (), None, self._n_dim)
+            self._params.append(raw)
+            self._n_dim += 1
+            if zero_sum:
+                raise ValueError("zero_sum needs a vector parameter")
+            value = raw
+            if lower is not None:
+                self._terms.append(raw)
+                value = exp(raw) + lower if lower != 0.0 else exp(raw)
+            self._det.append((name, value))
+            return value
+        d = self.dim(dim, size)
+        if d.size is None:
+            raise ValueError("a parameter's dimension needs a fixed size")
+        n_free = d.size - 1 if zero_sum else d.size
+        raw = Expr("vparam", (), d, (self._n_dim, n_free))
+        self._params.append(raw)
+        self._n_dim += n_free
+        if zero_sum:
+            if lower is not None:
+                raise ValueError("zero_sum and lower exclude each other")
+            n = d.size
+            s = raw.sum()            # (the padding element reads as 0)
+            value = where_lt(d, n - 1, raw - s * (1.0 / (math.sqrt(n) + n)), -s * (1.0 / math.sqrt(n)))
+        elif lower is not None:
+            self._terms.append(raw.sum())
+            value = exp(raw) + lower if lower != 0.0 else exp(raw)
+        else:
+            value = raw
+        self._det.append((name, value))
+        return value
+
+    def data(self, name: str, values, dim: str | None = None) -> Expr:
+        """Observed / shared data: a float array over ``dim`` or (``dim=None``) one float.  ``with_data`` can replace it."""
+        self._check_new_data(name)
+        if dim is None:
+            self._data[name] = float(values)
+            self._data_fields.append((name, "sdouble", None))
+            return Expr("sdata", (), None, name)
+        a = np.ascontiguousarray(values, dtype=np.float64)
+        if a.ndim != 1:
+            raise ValueError("data arrays are one-dimensional")
+        self._data[name] = a
+        d = self._data_dim(dim, name, a.size)
+        self._data_fields.append((name, "double", d))
+        return Expr("data", (), d, name)
+
+    def index(self, name: str, values, dim: str, into: str) -> Index:
+        """Integer data: ``values[i]`` is the element of dimension ``into`` that element ``i`` of ``dim`` belongs to."""
+        self._check_new_data(name)
+        a = np.ascontiguousarray(values, dtype=np.int32)
+        into_d = self.dim(into)
+        if into_d.size is None:
+            raise ValueError("the target of an index needs a fixed size")
+        self._data[name] = a
+        d = self._data_dim(dim, name, a.size)
+        ix = Index(name, d, into_d)
+        self._indices[name] = ix
+        self._data_fields.append((name, "int", d))
+        self._data_fields.append((name + "__pos", "int", d))
+        self._data_fields.append((name + "__rows", "int", into_d))
+        self._derive(name)
+        return ix
+
+    def _check_new_data(self, name):
+        if not name.isidentifier() or "__" in name:
+            raise ValueError(f"data name {name!r} must be an identifier without double underscores")
+        if name in self._data:
+            raise ValueError(f"data {name!r} is defined twice")
+
+    def _derive(self, name, data=None):
+        """the grouping of an index array: where each element sits when the elements are grouped by target, and the groups' ranges"""
+        data = self._data if data is None else data
+        ix = self._indices[name]
+        a = np.asarray(data[name], dtype=np.int64)
+        n = ix.into.size
+        if a.size and (a.min() < 0 or a.max() >= n):
+            raise ValueError(f"index {name!r} must lie in [0, {n})")
+        counts = np.bincount(a, minlength=n)
+        rows = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+        order = np.argsort(a, kind="stable")
+        pos = np.empty(a.size, dtype=np.int32)
+        pos[order] = np.arange(a.size, dtype=np.int32)
+        data[name + "__pos"] = pos
+        data[name + "__rows"] = rows
+
+    def add_logp(self, term) -> None:
+        term = Expr.wrap(term)
+        if term.dim is not None:
+            raise ValueError("a log-density term must be a scalar: sum() it")
+        self._terms.append(term)
+
+    def deterministic(self, name: str, expr) -> None:
+        """A value to report in the trace besides the parameters (the reference's expanded variables)."""
+        if any(n == name for n, _ in self._det):
+            raise ValueError(f"{name!r} is reported already")
+        self._det.append((name, Expr.wrap(expr)))
+
+    # ---- compilation
+    @property
+    def n_dim(self):
+        return self._n_dim
+
+    def logp_expr(self) -> Expr:
+        if not self._terms:
+            raise ValueError("the model has no log-density terms")
+        total = self._terms[0]
+        for t in self._terms[1:]:
+            total = total + t
+        return total
+
+    def _stage_source(self):
+        """``nphip_density_stage`` + the order of the staged fields: doubles first, then the 32-bit integers (each rounded up to a
+        whole double)."""
+        fields = [f for f in self._data_fields if f[1] == "double"] + [f for f in self._data_fields if f[1] == "int"]
+        if not self._staged or not fields:
+            return "", fields
+        L = ["__device__ void nphip_density_stage(const NphipData& data, double* shared, int thread, int n_threads) {"]
+        for d in self._dims.values():
+            L.append(f"    const int n_{d.name} = {d.size if d.size is not None else 'data.n_' + d.runtime_len};")
+        L.append("    double* at = shared;")
+        for name, kind, dim in fields:
+            n = _field_len_c(name, dim)
+            if kind == "double":
+                L.append(f"    for (int i = thread; i < {n}; i += n_threads) at[i] = data.{name}[i];")
+                L.append(f"    at += {n};")
+            else:
+                L.append(f"    for (int i = thread; i < {n}; i += n_threads) ((int*)at)[i] = data.{name}[i];")
+                L.append(f"    at += ({n} + 1) / 2;")
+        L.append("}")
+        return "\n".join(L), fields
+
+    def _shared_doubles(self, data) -> int:
+        if not self._staged:
+            return 0
+        total = 0
+        for name, kind, _ in self._data_fields:
+            if kind == "double":
+                total += len(data[name])
+            elif kind == "int":
+                total += (len(data[name]) + 1) // 2
+        return total
+
+    def generate(self):
+        """-> (source, generator): the HIP source of the density and the object that knows its LDS layout."""
+        logp = self.logp_expr()
+        grads = gradient(logp, self._params)
+        self._staged = 8 * self._shared_doubles_unconditional(self._data) <= self.STAGE_LIMIT
+        gen = _Gen(self, logp, grads)
+        src, _ = gen.source()
+        return src, gen
+
+    def _shared_doubles_unconditional(self, data):
+        was, self._staged = self._staged, True
+        try:
+            return self._shared_doubles(data)
+        finally:
+            self._staged = was
+
+    def compile(self, *, init="uniform", resident: bool = True, coords=None, dims=None):
+        """-> :class:`SymbolicModel` (a :class:`nutpie_amd.density.DensitySourceModel`)."""
+        from nutpie_amd.density import from_density_source
+
+        src, gen = self.generate()
+        dim_of = {k: d for k, d in self._dims.items()}
+        stored_dims = [d for _, (_, d) in gen.stored.items()]
+
+        def dim_len(d: Dim, data):
+            return d.size if d.size is not None else len(data[d.runtime_len])
+
+        def lds_per_chain(data):
+            return sum(dim_len(d, data) for d in stored_dims)
+
+        fields = list(self._data_fields)
+        staged = self._staged and any(k in ("double", "int") for _, k, _ in fields)
+
+        def lds_shared(data):
+            if not staged:
+                return 0
+            return sum(len(data[n]) if k == "double" else (len(data[n]) + 1) // 2 for n, k, _ in fields if k in ("double", "int"))
+
+        det = list(self._det)
+        names = [n for n, _ in det]
+        nodes = [e for _, e in det]
+        shapes = [() if e.dim is None else (e.dim.size if e.dim.size is not None else len(self._data[e.dim.runtime_len]),) for e in nodes]
+        auto_dims = {n: (e.dim.name,) for n, e in det if e.dim is not None}
+        auto_coords = {d.name: np.arange(d.size) for d in dim_of.values() if d.size is not None and any(e.dim is d for e in nodes)}
+
+        def expand(positions, /, **data):   # (positional-only: a data array may be called `x`)
+            vals = evaluate(nodes, positions, data)
+            return {n: v for n, v in zip(names, vals)}
+
+        base = from_density_source(self._n_dim, src, dict(self._data), lds_doubles_per_chain=lds_per_chain, lds_doubles_shared=lds_shared if staged else 0,
+                                   expand_fn=expand, expanded_names=names, expanded_shapes=shapes, coords={**auto_coords, **(coords or {})},
+                                   dims={**auto_dims, **(dims or {})}, init=init, resident=resident)
+        import dataclasses
+
+        return _symbolic_model_class()(**{f.name: getattr(base, f.name) for f in dataclasses.fields(base)}, _front=self)
+
+
+_SYMBOLIC_MODEL = None
+
+
+def _symbolic_model_class():
+    global _SYMBOLIC_MODEL
+    if _SYMBOLIC_MODEL is not None:
+        return _SYMBOLIC_MODEL
+    import dataclasses
+
+    from nutpie_amd.density import DensitySourceModel
+
+    @dataclasses.dataclass(frozen=True)
+    class SymbolicModel(DensitySourceModel):
+        """The compiled form of a :class:`Model`: a :class:`~nutpie_amd.density.DensitySourceModel` that also knows how the
+        index arrays' groupings are derived, so that ``with_data`` can replace them."""
+
+        _front: Any = None
+
+        def with_data(self, **updates):
+            f = self._front
+            for k in updates:
+                if k not in f._data or "__" in k:
+                    raise ValueError(f"Unknown data variable: {k}")
+            new = {**self._data}
+            for k, v in updates.items():
+                kind = next(kd for n, kd, _ in f._data_fields if n == k)
+                new[k] = float(v) if kind == "sdouble" else np.ascontiguousarray(v, dtype=np.int32 if kind == "int" else np.float64)
+            for name in f._indices:
+                f._derive(name, new)
+            # arrays of one dimension must keep a common length
+            for d in f._dims.values():
+                if d.size is None:
+                    n = len(new[d.runtime_len])
+                    for name, kind, dd in f._data_fields:
+                        if dd is d and kind in ("double", "int") and not name.endswith("__rows") and len(new[name]) != n:
+                            raise ValueError(f"data on dimension {d.name!r} must share one length ({name!r} has {len(new[name])}, {d.runtime_len!r} has {n})")
+            return dataclasses.replace(self, _data=new)
+
+        def logp_and_grad_numpy(self, x):
+            """The same graph evaluated with numpy (host; for checking a model, not for sampling)."""
+            logp = f_logp = self._front.logp_expr()
+            grads = gradient(f_logp, self._front._params)
+            vals = evaluate([logp] + grads, x, self._data)
+            N = vals[0].shape[0]
+            g = np.zeros((N, self._front._n_dim))
+            for p, v in zip(self._front._params, vals[1:]):
+                if p.dim is None:
+                    g[:, p.payload] = v
+                else:
+                    off, nv = p.payload
+                    g[:, off:off + nv] = (v if v.ndim == 2 else np.broadcast_to(v[:, None], (N, nv)))[:, :nv]
+            return vals[0], g
+
+    _SYMBOLIC_MODEL = SymbolicModel
+    return SymbolicModel
+
+
+def __getattr__(name):
+    if name == "SymbolicModel":
+        return _symbolic_model_class()
+    raise AttributeError(name)

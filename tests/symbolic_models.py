@@ -1,0 +1,104 @@
+"""Small models written with nutpie_amd.symbolic, shared by the CPU and the GPU tests of the front-end."""
+
+import numpy as np
+
+from nutpie_amd import symbolic as S
+
+
+def radon(data=None):
+    """Config 3's varying-intercept / varying-slope model (nutpie_amd/radon.py) written with the front-end."""
+    from nutpie_amd.radon import synthetic_radon_data
+
+    d = data or synthetic_radon_data()
+    n = int(np.max(d["county_idx"])) + 1
+    m = S.Model()
+    m.dim("county", n)
+    intercept = m.param("intercept")
+    raw = m.param("county_raw", dim="county", zero_sum=True)
+    sd = m.param("county_sd", lower=0.0)
+    fe = m.param("floor_effect")
+    craw = m.param("county_floor_raw", dim="county", zero_sum=True)
+    csd = m.param("county_floor_sd", lower=0.0)
+    sig = m.param("sigma", lower=0.0)
+    y = m.data("y", d["log_radon"], dim="obs")
+    fl = m.data("floor", d["floor"], dim="obs")
+    ci = m.index("county", d["county_idx"], dim="obs", into="county")
+    eff, cfe = raw * sd, craw * csd
+    m.deterministic("county_effect", eff)
+    m.deterministic("county_floor_effect", cfe)
+    # the priors of nutpie_amd/radon.py, constants dropped as there (the hand-written density is the comparison)
+    m.add_logp(-0.005 * (intercept * intercept) - 0.125 * (fe * fe))
+    m.add_logp((-0.5 * (raw * raw)).sum() + (-0.5 * (craw * craw)).sum())
+    m.add_logp(-0.5 * (sd * sd) - 0.5 * (csd * csd) - (0.5 / 2.25) * (sig * sig))
+    mu = intercept + eff[ci] + fl * (fe + cfe[ci])
+    z = (y - mu) / sig
+    m.add_logp((-0.5 * (z * z) - S.log(sig)).sum())
+    return m
+
+
+def logistic(seed=3, n_obs=500, n_group=7, n_item=11):
+    """Two crossed random effects (two different groupings of the observations), Bernoulli likelihood, one covariate."""
+    rng = np.random.default_rng(seed)
+    group = rng.integers(0, n_group, n_obs)
+    item = rng.integers(0, n_item, n_obs)
+    xcov = rng.normal(size=n_obs)
+    eta = 0.3 + 0.8 * xcov + 0.5 * rng.normal(size=n_group)[group] + 0.7 * rng.normal(size=n_item)[item]
+    yy = (rng.uniform(size=n_obs) < 1.0 / (1.0 + np.exp(-eta))).astype(np.float64)
+    m = S.Model()
+    m.dim("group", n_group)
+    m.dim("item", n_item)
+    b0 = m.param("b0")
+    b1 = m.param("b1")
+    sg = m.param("sigma_group", lower=0.0)
+    si = m.param("sigma_item", lower=0.0)
+    g = m.param("group_raw", dim="group")
+    it = m.param("item_effect", dim="item")
+    y = m.data("y", yy, dim="obs")
+    xc = m.data("x", xcov, dim="obs")
+    gi = m.index("group_idx", group, dim="obs", into="group")
+    ii = m.index("item_idx", item, dim="obs", into="item")
+    m.add_logp(S.normal_lpdf(b0, 0.0, 2.0) + S.normal_lpdf(b1, 0.0, 2.0))
+    m.add_logp(S.halfnormal_lpdf(sg, 1.0) + S.halfnormal_lpdf(si, 1.0))
+    m.add_logp(S.normal_lpdf(g, 0.0, 1.0).sum())              # non-centred
+    m.add_logp(S.normal_lpdf(it, 0.0, si).sum())              # centred
+    m.add_logp(S.bernoulli_logit_lpmf(y, b0 + b1 * xc + (g * sg)[gi] + it[ii]).sum())
+    m.deterministic("group_effect", g * sg)
+    return m
+
+
+def poisson_offsets(seed=5, n_obs=300, n_site=40):
+    """Poisson counts with a site effect read straight from the parameter vector, a per-site data column gathered to the
+    observations, a Student-t prior and a scalar data value that ``with_data`` can change."""
+    from scipy.special import gammaln
+
+    rng = np.random.default_rng(seed)
+    site = rng.integers(0, n_site, n_obs)
+    expo = rng.uniform(0.5, 2.0, size=n_site)
+    counts = rng.poisson(expo[site] * np.exp(0.4 + 0.3 * rng.normal(size=n_site)[site])).astype(np.float64)
+    m = S.Model()
+    m.dim("site", n_site)
+    a = m.param("a")
+    tau = m.param("tau", lower=0.0)
+    u = m.param("u", dim="site")
+    y = m.data("y", counts, dim="obs")
+    lf = m.data("log_fact", gammaln(counts + 1.0), dim="obs")
+    le = m.data("log_exposure", np.log(expo), dim="site")
+    prior_scale = m.data("prior_scale", 1.5)
+    si = m.index("site_idx", site, dim="obs", into="site")
+    m.add_logp(S.normal_lpdf(a, 0.0, prior_scale))
+    m.add_logp(S.halfnormal_lpdf(tau, 1.0))
+    m.add_logp(S.student_t_lpdf(u, 4.0, 0.0, tau).sum())
+    m.add_logp(S.poisson_log_lpmf(y, a + u[si] + le[si], lf).sum())
+    return m
+
+
+def scalar_only():
+    """No dimension at all: a banana in two scalars."""
+    m = S.Model()
+    a = m.param("a")
+    b = m.param("b", lower=1.0)
+    m.add_logp(S.normal_lpdf(a, 0.0, 1.0) + S.normal_lpdf(b, 1.0 + a * a, 0.5) + S.log1p(S.sqrt(b)) - S.softplus(a))
+    return m
+
+
+ALL = {"radon": radon, "logistic": logistic, "poisson_offsets": poisson_offsets, "scalar_only": scalar_only}

@@ -1,0 +1,79 @@
+"""The expression front-end on the GPU (nutpie_amd/symbolic.py): generated densities against the numpy evaluation of the same
+graph, the generated radon model against the hand-written HIP density of nutpie_amd/radon.py, sampling and data swapping."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(__file__))
+import symbolic_models as zoo  # noqa: E402
+
+import nutpie_amd  # noqa: E402
+from nutpie_amd.radon import radon_density_model, synthetic_radon_data  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", list(zoo.ALL))
+def test_generated_density_equals_the_numpy_evaluation_of_its_graph(hip, name):
+    m = zoo.ALL[name]().compile()
+    rng = np.random.default_rng(7)
+    x = 0.4 * rng.normal(size=(37, m.n_dim))
+    lp, g = m.logp_and_grad(x)
+    lp_ref, g_ref = m.logp_and_grad_numpy(x)
+    # same operations in the same order (-ffp-contract=off); exp / log / log1p differ from numpy's in the last place,
+    # and the sums run in the wave's order
+    np.testing.assert_allclose(lp, lp_ref, rtol=1e-11, atol=1e-10)
+    np.testing.assert_allclose(g, g_ref, rtol=1e-9, atol=1e-9)
+
+
+def test_generated_radon_equals_the_hand_written_density(hip):
+    d = synthetic_radon_data()
+    gen = zoo.radon(d).compile()
+    hand = radon_density_model(d)
+    assert gen.n_dim == hand.n_dim
+    x = 0.4 * np.random.default_rng(1).normal(size=(64, gen.n_dim))
+    lp_a, g_a = gen.logp_and_grad(x)
+    lp_b, g_b = hand.logp_and_grad(x)
+    np.testing.assert_allclose(lp_a, lp_b, rtol=1e-12, atol=1e-9)
+    np.testing.assert_allclose(g_a, g_b, rtol=1e-9, atol=1e-9)
+    # and the same posterior through the resident kernel
+    a = nutpie_amd.sample(gen, chains=128, tune=300, draws=200, seed=3, progress_bar=False)
+    b = nutpie_amd.sample(hand, chains=128, tune=300, draws=200, seed=3, progress_bar=False)
+    for k in ("intercept", "floor_effect", "sigma", "county_sd", "county_floor_sd"):
+        va, vb = a.posterior[k].values, b.posterior[k].values
+        assert abs(va.mean() - vb.mean()) < 4 * vb.std() / np.sqrt(2000), k
+    ea, eb = a.posterior.county_effect.values, b.posterior.county_effect.values
+    assert np.abs(ea.mean((0, 1)) - eb.mean((0, 1))).max() < 0.03
+    assert np.abs(ea.sum(-1)).max() < 1e-9 and a.sample_stats.diverging.values.mean() < 0.02
+
+
+def test_resident_and_batched_forms_draw_the_same(hip):
+    m = zoo.logistic()
+    a = nutpie_amd.sample(m.compile(), chains=32, tune=120, draws=50, seed=5, progress_bar=False)
+    b = nutpie_amd.sample(m.compile(resident=False), chains=32, tune=120, draws=50, seed=5, progress_bar=False)
+    assert np.array_equal(a.posterior.b0.values, b.posterior.b0.values)
+    assert np.array_equal(a.sample_stats.n_steps.values, b.sample_stats.n_steps.values)
+    # the posterior recovers the generating coefficients (0.3, 0.8) within its own spread
+    assert abs(a.posterior.b0.values.mean() - 0.3) < 0.6 and abs(a.posterior.b1.values.mean() - 0.8) < 0.4
+    assert a.posterior.group_effect.shape == (32, 50, 7)
+
+
+def test_with_data_on_a_generated_model(hip):
+    from scipy.special import gammaln
+
+    compiled = zoo.poisson_offsets().compile()
+    rng = np.random.default_rng(11)
+    site = rng.integers(0, 40, 777)
+    y2 = rng.poisson(3.0, 777).astype(np.float64)
+    swapped = compiled.with_data(y=y2, log_fact=gammaln(y2 + 1.0), site_idx=site, prior_scale=0.7)
+    assert swapped.library().path == compiled.library().path
+    x = 0.3 * rng.normal(size=(9, compiled.n_dim))
+    for mm in (compiled, swapped):
+        lp, g = mm.logp_and_grad(x)
+        lp_ref, g_ref = mm.logp_and_grad_numpy(x)
+        np.testing.assert_allclose(lp, lp_ref, rtol=1e-11, atol=1e-10)
+        np.testing.assert_allclose(g, g_ref, rtol=1e-9, atol=1e-9)
+    tr = nutpie_amd.sample(swapped, chains=16, tune=150, draws=80, seed=2, progress_bar=False)
+    assert tr.posterior.u.shape == (16, 80, 40) and np.all(tr.posterior.tau.values > 0)

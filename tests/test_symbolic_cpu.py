@@ -1,0 +1,122 @@
+"""The expression front-end on the host: the symbolic gradient against finite differences, the generated source against the
+compiler (hipcc cross-compiles without a GPU), data swapping."""
+
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(__file__))
+import symbolic_models as zoo  # noqa: E402
+
+from nutpie_amd import symbolic as S  # noqa: E402
+
+
+def _numeric_grad(f, x, h=1e-6):
+    g = np.zeros_like(x)
+    for i in range(x.size):
+        e = np.zeros_like(x)
+        e[i] = h
+        g[i] = (f(x + e) - f(x - e)) / (2 * h)
+    return g
+
+
+@pytest.mark.parametrize("name", list(zoo.ALL))
+def test_symbolic_gradient_matches_finite_differences(name):
+    m = zoo.ALL[name]()
+    logp = m.logp_expr()
+    grads = S.gradient(logp, m._params)
+    rng = np.random.default_rng(1)
+    x = 0.3 * rng.normal(size=(3, m.n_dim))
+    vals = S.evaluate([logp] + grads, x, m._data)
+    assert np.all(np.isfinite(vals[0]))
+    for r in range(x.shape[0]):
+        f = lambda v: float(S.evaluate([logp], v[None, :], m._data)[0][0])  # noqa: E731
+        num = _numeric_grad(f, x[r])
+        ana = np.zeros(m.n_dim)
+        for p, v in zip(m._params, vals[1:]):
+            if p.dim is None:
+                ana[p.payload] = v[r]
+            else:
+                off, nv = p.payload
+                ana[off:off + nv] = (v[r] if v.ndim == 2 else np.full(nv, v[r]))[:nv]
+        np.testing.assert_allclose(ana, num, rtol=2e-5, atol=2e-6)
+
+
+def test_radon_graph_is_the_hand_written_density():
+    """same value as the closed form of nutpie_amd/radon.py's density (restated here with numpy)"""
+    from nutpie_amd.radon import synthetic_radon_data
+
+    d = synthetic_radon_data()
+    m = zoo.radon(d)
+    n = int(d["county_idx"].max()) + 1
+    rng = np.random.default_rng(2)
+    x = 0.2 * rng.normal(size=m.n_dim)
+
+    def ext(v):
+        k = v.size + 1
+        s = v.sum()
+        return np.concatenate([v - s / (np.sqrt(k) + k), [-s / np.sqrt(k)]])
+
+    icpt, raw, lsd, fe, craw, lcsd, lsig = x[0], x[1:n], x[n], x[n + 1], x[n + 2:2 * n + 1], x[2 * n + 1], x[2 * n + 2]
+    sd, csd, sig = np.exp(lsd), np.exp(lcsd), np.exp(lsig)
+    mu = icpt + (ext(raw) * sd)[d["county_idx"]] + d["floor"] * (fe + (ext(craw) * csd)[d["county_idx"]])
+    r = (d["log_radon"] - mu) / sig
+    want = (-0.005 * icpt ** 2 - 0.125 * fe ** 2 - 0.5 * (raw ** 2).sum() - 0.5 * (craw ** 2).sum() - 0.5 * sd ** 2 + lsd - 0.5 * csd ** 2 + lcsd
+            - (0.5 / 2.25) * sig ** 2 + lsig - 0.5 * (r ** 2).sum() - r.size * lsig)
+    got = S.evaluate([m.logp_expr()], x[None, :], m._data)[0][0]
+    np.testing.assert_allclose(got, want, rtol=1e-12)
+
+
+def test_generated_source_layout_and_errors():
+    m = zoo.logistic()
+    src, gen = m.generate()
+    assert "nphip_density_stage" in src and "nphip_wave_sum" in src
+    # two groupings of the observations -> two arrays of adjoints stored grouped by target, and the non-centred effect as a gather source
+    kinds = sorted(how for how, _ in gen.stored.values())
+    assert kinds.count("grouped") == 2 and kinds.count("plain") >= 1
+    with pytest.raises(ValueError, match="different dimensions"):
+        _ = m._params[4] + m._params[5]
+    with pytest.raises(ValueError, match="scalar"):
+        m.add_logp(m._params[4])
+    bad = S.Model()
+    bad.dim("g", 2)
+    with pytest.raises(ValueError, match="must lie in"):
+        bad.index("i", [0, 5], dim="obs", into="g")
+
+
+def test_compiles_for_gfx950_and_swaps_data_without_recompiling(tmp_path, monkeypatch):
+    monkeypatch.setenv("NUTPIE_AMD_CACHE", str(tmp_path))
+    from nutpie_amd.density import compile_density, data_layout
+
+    m = zoo.poisson_offsets()
+    compiled = m.compile()
+    path = compile_density(compiled._source, data_layout(compiled._data), compiled.n_dim)
+    assert os.path.exists(path)
+    rng = np.random.default_rng(0)
+    # new observations of a different length: same layout, same source -> same library
+    n2 = 123
+    site = rng.integers(0, 40, n2)
+    y2 = rng.poisson(2.0, n2).astype(np.float64)
+    from scipy.special import gammaln
+
+    swapped = compiled.with_data(y=y2, log_fact=gammaln(y2 + 1.0), site_idx=site, prior_scale=3.0)
+    assert compile_density(swapped._source, data_layout(swapped._data), swapped.n_dim) == path
+    assert len(swapped._data["site_idx__pos"]) == n2 and swapped._data["site_idx__rows"][-1] == n2
+    lds, shared = swapped._lds()
+    lds0, shared0 = compiled._lds()
+    assert shared < shared0 and lds < lds0
+    with pytest.raises(ValueError, match="share one length"):
+        compiled.with_data(y=y2)
+    with pytest.raises(ValueError, match="Unknown data variable"):
+        compiled.with_data(nope=1.0)
+    # the host restatement follows the data
+    x = 0.1 * rng.normal(size=(2, compiled.n_dim))
+    a, _ = compiled.logp_and_grad_numpy(x)
+    b, _ = swapped.logp_and_grad_numpy(x)
+    assert np.all(np.isfinite(a)) and np.all(np.isfinite(b)) and not np.allclose(a, b)
+    # expanded variables: the constrained values of the parameters
+    out = compiled._expand_draws(x.reshape(1, 2, -1))
+    np.testing.assert_allclose(out["tau"][0], np.exp(x[:, 1]))
+    assert out["u"].shape == (1, 2, 40)
