@@ -63,6 +63,10 @@ template <int W>
 // lean kernels: the unrolled chunk sweeps must stay sweeps — without a fence per chunk the scheduler issues the loads of
 // all chunks first and the allocator spills the resident state to make room for them
 #define NPHIP_CHUNK_FENCE(k) __builtin_amdgcn_sched_barrier(0)
+// register kernels with several waves per chain: up to this many chunks per wave run two waves per SIMD (256 registers each)
+#ifndef NPHIP_RW_OCC2_MAX
+#define NPHIP_RW_OCC2_MAX 4
+#endif
 #ifndef NPHIP_LEAN_OCC
 // waves per SIMD of the lean kernels: 8 waves = one chain per CU at 256 VGPRs per wave (4 waves: 512 = VGPRs + AGPRs)
 #define NPHIP_LEAN_OCC(W) ((W) <= 4 ? 1 : ((W) <= 8 ? 2 : 4))
@@ -2748,7 +2752,7 @@ struct Machine {
 // `Ap` points to the engine's argument block in device memory (written once at set-up); it is read through
 // the constant address space, i.e. with scalar loads into SGPRs.  Per-launch scalars are kernel parameters.
 template <bool FUSED, int W, int NV, bool LEAN = false, bool REMOTE = false>
-__global__ __launch_bounds__(W == 1 ? 256 : 64 * W) __attribute__((amdgpu_waves_per_eu(LEAN ? NPHIP_LEAN_OCC(W) : ((NV > 0 && NV <= (W == 1 ? 3 : 4)) ? 2 : 1), LEAN ? NPHIP_LEAN_OCC(W) : ((NV > 0 && NV <= (W == 1 ? 3 : 4)) ? 2 : 8)))) void k_advance(const Args* __restrict__ Ap, int max_evals, int have_result, const LaunchSlice sl) {
+__global__ __launch_bounds__(W == 1 ? 256 : 64 * W) __attribute__((amdgpu_waves_per_eu(LEAN ? NPHIP_LEAN_OCC(W) : ((NV > 0 && NV <= (W == 1 ? 3 : NPHIP_RW_OCC2_MAX)) ? 2 : 1), LEAN ? NPHIP_LEAN_OCC(W) : ((NV > 0 && NV <= (W == 1 ? 3 : NPHIP_RW_OCC2_MAX)) ? 2 : 8)))) void k_advance(const Args* __restrict__ Ap, int max_evals, int have_result, const LaunchSlice sl) {
     const NPHIP_CONST Args& A = *(const NPHIP_CONST Args*)Ap;
     constexpr int WAVES = (W == 1) ? 4 : W;
     __shared__ Ctl s_ctl[WAVES];
@@ -2964,11 +2968,16 @@ hipError_t launch_fam_lean8(const Args& a, const Args* d_args, hipStream_t st, c
 #if NPHIP_HAS(3)
 // register-resident, several waves per chain (1024 < D <= 4096, or fewer chains than SIMDs): one workgroup = one chain
 hipError_t launch_fam_rw(const Args& a, const Args* d_args, int W, hipStream_t st, const LaunchSlice sl) {
-#ifdef NPHIP_DEV_BUILD
+#define NPHIP_LAUNCH_RW(WW, NN) hipLaunchKernelGGL((k_advance<true, WW, NN>), g, b, 0, st, d_args, a.max_evals, a.have_result, sl)
+#if defined(NPHIP_DEV_RW_W) && defined(NPHIP_DEV_RW_NV)
+    const dim3 g((unsigned)sl.chain_n), b(64 * W);
+    if (W != NPHIP_DEV_RW_W || a.reg_nv != NPHIP_DEV_RW_NV) return hipErrorInvalidValue;
+    NPHIP_LAUNCH_RW(NPHIP_DEV_RW_W, NPHIP_DEV_RW_NV);
+    return hipGetLastError();
+#elif defined(NPHIP_DEV_BUILD)
     return hipErrorInvalidValue;
 #else
     const dim3 g((unsigned)sl.chain_n), b(64 * W);
-#define NPHIP_LAUNCH_RW(WW, NN) hipLaunchKernelGGL((k_advance<true, WW, NN>), g, b, 0, st, d_args, a.max_evals, a.have_result, sl)
     if (W == 2) switch (a.reg_nv) {
         case 1: NPHIP_LAUNCH_RW(2, 1); break;
         case 2: NPHIP_LAUNCH_RW(2, 2); break;
@@ -2990,9 +2999,9 @@ hipError_t launch_fam_rw(const Args& a, const Args* d_args, int W, hipStream_t s
         case 8: NPHIP_LAUNCH_RW(4, 8); break;
         default: return hipErrorInvalidValue;
     }
-#undef NPHIP_LAUNCH_RW
     return hipGetLastError();
 #endif
+#undef NPHIP_LAUNCH_RW
 }
 #endif
 
