@@ -117,13 +117,15 @@ nphip_model_t* nphip_model_bridgestan(uint64_t dim, void* bs_model, void* log_de
 /* Runtime-compiled device density (the GPU form of a compiled model's logp function: compile_pymc.py:668-871 builds one per
  * model; here the model is HIP source compiled at run time into its own instantiation of the engine's resident kernel —
  * nutpie_amd/density.py).  `launch_fn` = address of `nphip_jit_launch` of the model's library, `nv` = its `nphip_jit_nv()`
- * (chunks of 128 dimensions: dim <= 1024), `data_device` = the model's data block in device memory (borrowed),
- * `lds_bytes_per_wave` = LDS scratch the density uses per chain, `lds_bytes_shared` = LDS common to the four chains of a
- * workgroup, filled once per launch by the library's staging function (the model's data).  The evaluation is a call in the middle of the
- * register-resident leaf: no launch, no memory round trip for the chain state.  The same library exports the density as a
- * batched device callback (`nphip_jit_logp`, an nphip_device_logp_fn) for everything the resident kernel does not cover. */
-nphip_model_t* nphip_model_jit_density(uint64_t dim, void* launch_fn, int nv, const void* data_device, uint64_t lds_bytes_per_wave,
-                                       uint64_t lds_bytes_shared);
+ * (chunks of 128 dimensions per wave: dim <= 1024), `waves_per_chain` = its `nphip_jit_w()` (1, 2 or 4 wavefronts evaluate one
+ * chain's density together; 0 = 1), `data_device` = the model's data block in device memory (borrowed),
+ * `lds_bytes_per_chain` = LDS scratch the density uses per chain, `lds_bytes_shared` = LDS common to the chains of a
+ * workgroup (four with one wave per chain, else one), filled once per launch by the library's staging function (the model's
+ * data).  The evaluation is a call in the middle of the register-resident leaf: no launch, no memory round trip for the chain
+ * state.  The same library exports the density as a batched device callback (`nphip_jit_logp`, an nphip_device_logp_fn) for
+ * everything the resident kernel does not cover. */
+nphip_model_t* nphip_model_jit_density(uint64_t dim, void* launch_fn, int nv, const void* data_device, uint64_t lds_bytes_per_chain,
+                                       uint64_t lds_bytes_shared, int waves_per_chain);
 /* Initial positions: kind 0 = U(-2,2) (src/pyfunc.rs:540-544), 1 = N(0,1) (src/stan.rs:798-808),
  * 2 = explicit host array points[n_chains_total][dim] indexed by GLOBAL chain id
  * (src/pymc.rs:505-534 evaluates the user's init function per chain on the host). */

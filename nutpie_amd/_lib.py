@@ -147,7 +147,7 @@ def lib():
             L.nphip_model_bridgestan.restype = C.c_void_p
             L.nphip_model_bridgestan.argtypes = [C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
             L.nphip_model_jit_density.restype = C.c_void_p
-            L.nphip_model_jit_density.argtypes = [C.c_uint64, C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_uint64]
+            L.nphip_model_jit_density.argtypes = [C.c_uint64, C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int]
             L.nphip_model_set_init.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64]
             L.nphip_model_free.argtypes = [C.c_void_p]
             L.nphip_model_set_expand.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
@@ -527,9 +527,9 @@ class JitDensityModel(_Model):
     """A device density compiled at run time into its own resident kernel (``nphip_model_jit_density``; nutpie_amd/density.py):
     ``launch_addr`` / ``nv`` come from the model's library, ``data_ptr`` is its data block in device memory."""
 
-    def __init__(self, dim, launch_addr: int, nv: int, data_ptr: int, lds_bytes_per_chain: int = 0, lds_bytes_shared: int = 0, keep_alive=None):
+    def __init__(self, dim, launch_addr: int, nv: int, data_ptr: int, lds_bytes_per_chain: int = 0, lds_bytes_shared: int = 0, keep_alive=None, waves_per_chain: int = 1):
         super().__init__(lib().nphip_model_jit_density(C.c_uint64(dim), C.c_void_p(launch_addr), int(nv), C.c_void_p(data_ptr), C.c_uint64(int(lds_bytes_per_chain)),
-                                                      C.c_uint64(int(lds_bytes_shared))), dim, [keep_alive])
+                                                      C.c_uint64(int(lds_bytes_shared)), int(waves_per_chain)), dim, [keep_alive])
         self.exception = None
 
 

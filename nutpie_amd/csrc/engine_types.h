@@ -28,6 +28,7 @@ enum ChainError : int64_t {
     CE_NONE = 0,
     CE_INIT_FAILED = 1,  // no finite initial point after num_try_init attempts
     CE_FATAL_LOGP = 2,   // logp callback returned a negative code
+    CE_RESUME_FAILED = 3,   // the position given to nphip_sampler_resume_at does not evaluate (logp or gradient not finite)
 };
 
 // ---- P-slots: (p, rho) pairs.  Assignment is a pure function of the leaf index ---------

@@ -308,7 +308,8 @@ struct nphip_model {
     const void* jit_data = nullptr;
     uint64_t jit_lds_bytes = 0;   // LDS scratch per wave
     uint64_t jit_shared_bytes = 0; // LDS shared by the chains of a workgroup
-    int jit_nv = 0;
+    int jit_nv = 0;   // chunks of 128 dimensions per wave
+    int jit_w = 1;    // waves per chain
     std::shared_ptr<BsAdapter> bs;
     std::shared_ptr<BsExpand> bs_expand;
     uint64_t dim = 0;
@@ -359,27 +360,30 @@ nphip_model_t* nphip_model_device_callback(uint64_t dim, nphip_device_logp_fn fn
     m->kind = 2; m->dim = dim; m->dev_fn = fn; m->user = user_data;
     return m;
 }
-nphip_model_t* nphip_model_jit_density(uint64_t dim, void* launch_fn, int nv, const void* data_device, uint64_t lds_bytes_per_wave,
-                                       uint64_t lds_bytes_shared) {
+nphip_model_t* nphip_model_jit_density(uint64_t dim, void* launch_fn, int nv, const void* data_device, uint64_t lds_bytes_per_chain,
+                                       uint64_t lds_bytes_shared, int waves_per_chain) {
+    const int w = waves_per_chain > 0 ? waves_per_chain : 1;
     if (dim == 0 || !launch_fn) { set_error("a runtime-compiled density needs dim > 0 and its launcher"); return nullptr; }
-    if (dim > 1024 || nv < 1 || nv > 8 || (uint64_t)nv * 128 < dim) {
-        set_error("the resident kernel of a runtime-compiled density holds up to 1024 dimensions (nv chunks of 128, nv = ceil(dim / 128)); "
-                  "larger models run through the batched device callback of the same library");
+    if (!(w == 1 || w == 2 || w == 4)) { set_error("a runtime-compiled density runs with 1, 2 or 4 waves per chain"); return nullptr; }
+    if (dim > 1024 || nv < 1 || nv > 8 || (uint64_t)nv * 128 * w < dim || (uint64_t)nv != ((dim + 127) / 128 + w - 1) / w) {
+        set_error("the resident kernel of a runtime-compiled density holds up to 1024 dimensions (nv chunks of 128 per wave, nv = "
+                  "ceil(ceil(dim / 128) / waves)); larger models run through the batched device callback of the same library");
         return nullptr;
     }
-    if (lds_bytes_per_wave % 8 != 0 || lds_bytes_shared % 8 != 0) { set_error("LDS scratch sizes must be multiples of 8 bytes"); return nullptr; }
-    // LDS of the launch: four chains per workgroup — control blocks, reduction scratch, the four rings (4 x 4 KB x nv each) and
-    // the density's scratch — must fit the CU's 160 KB
-    // (+ the leaf's position and gradient rows in LDS: 2 x 1 KB x nv per chain)
-    const uint64_t fixed = 4 * 1200 + 1024 + 4 * (uint64_t)nv * 4096 + 64 + 4 * 2 * (uint64_t)nv * 1024;
-    if (fixed + 4 * lds_bytes_per_wave + lds_bytes_shared > 160 * 1024) {
+    if (lds_bytes_per_chain % 8 != 0 || lds_bytes_shared % 8 != 0) { set_error("LDS scratch sizes must be multiples of 8 bytes"); return nullptr; }
+    // LDS of the launch must fit the CU's 160 KB.  One wave per chain: four chains per workgroup — control blocks, reduction
+    // scratch, the four rings (4 x 4 KB x nv each), the leaf's position and gradient rows (2 x 1 KB x nv per chain) and the
+    // density's scratch.  Several waves per chain: one chain per workgroup, a ring per wave.
+    const uint64_t cpb = w == 1 ? 4 : 1, waves = w == 1 ? 4 : (uint64_t)w, ld = (uint64_t)nv * 128 * w;
+    const uint64_t fixed = waves * 1200 + 1024 + waves * (uint64_t)nv * 4096 + 64 + 16 * (uint64_t)w * nv + cpb * 2 * ld * 8;
+    if (fixed + cpb * lds_bytes_per_chain + lds_bytes_shared > 160 * 1024) {
         set_error("LDS scratch of the density does not fit beside the kernel's own (" + std::to_string(fixed) + " bytes fixed, " +
-                  std::to_string(4 * lds_bytes_per_wave) + " requested for four chains + " + std::to_string(lds_bytes_shared) + " shared, 163840 per CU)");
+                  std::to_string(cpb * lds_bytes_per_chain) + " requested for the chains of a workgroup + " + std::to_string(lds_bytes_shared) + " shared, 163840 per CU)");
         return nullptr;
     }
     auto* m = new nphip_model();
-    m->kind = 3; m->dim = dim; m->jit_launch = (nphip_jit_launch_fn)launch_fn; m->jit_nv = nv; m->jit_data = data_device;
-    m->jit_lds_bytes = lds_bytes_per_wave;
+    m->kind = 3; m->dim = dim; m->jit_launch = (nphip_jit_launch_fn)launch_fn; m->jit_nv = nv; m->jit_w = w; m->jit_data = data_device;
+    m->jit_lds_bytes = lds_bytes_per_chain;
     m->jit_shared_bytes = lds_bytes_shared;
     return m;
 }
@@ -749,7 +753,7 @@ bool nphip_sampler::setup() {
     T = set.num_tune + set.num_draws;
     fused = model.kind == 0;
     dens = model.kind == 3;
-    W = dens ? 1 : (launch.waves_per_chain ? launch.waves_per_chain : choose_waves(dim));
+    W = dens ? model.jit_w : (launch.waves_per_chain ? launch.waves_per_chain : choose_waves(dim));
     const bool lrm = set.low_rank_metric;
     if (lrm && dens) { set_error("the low-rank metric runs on the memory-resident kernels: use the batched device callback of the density's library"); return false; }
     if (lrm) launch.no_register_kernel = 1;   // (P-slots carry the velocity as a third vector: memory-resident kernels only)
@@ -824,7 +828,7 @@ bool nphip_sampler::setup() {
     }
     // host-callback models with several waves per chain (1024 < D <= 4096): the same padding, so that resident launches can
     // run them on the register-resident leaf (8 chunks per wave at most)
-    if (model.kind == 1 && (W == 2 || W == 4)) {
+    if ((model.kind == 1 || model.kind == 3) && (W == 2 || W == 4)) {
         const int64_t per_wave = ((int64_t)((dim + 127) / 128) + W - 1) / W;
         if (per_wave >= 1 && per_wave <= 8) args.ld = per_wave * W * 128;
     }
@@ -891,7 +895,7 @@ bool nphip_sampler::setup() {
             args.dens_lds_doubles = (int32_t)(model.jit_lds_bytes / 8);
             args.dens_shared_doubles = (int32_t)(model.jit_shared_bytes / 8);
             args.reg_nv = model.jit_nv;
-            if ((int64_t)model.jit_nv * 128 != args.ld) { set_error("the density's library was compiled for another dimension (nv chunks)"); return false; }
+            if ((int64_t)model.jit_nv * 128 * W != args.ld) { set_error("the density's library was compiled for another dimension (nv chunks)"); return false; }
         }
         if (model.kind == 1) {
             if (!zero_copy && !dalloc(&args.ecode, n)) return false;
@@ -1000,6 +1004,7 @@ std::string nphip_sampler::chain_error_message() {
             std::string c = "chain " + std::to_string(launch.chain_offset + i) + ": ";
             if (h[i].err == CE_INIT_FAILED) return c + "could not find a finite initial point (logp or gradient not finite)";
             if (h[i].err == CE_FATAL_LOGP) return c + "logp function returned a fatal error";
+            if (h[i].err == CE_RESUME_FAILED) return c + "the position given to resume_at does not evaluate (logp or gradient not finite)";
             return c + "unknown error";
         }
     }
@@ -1023,8 +1028,9 @@ bool nphip_sampler::launch_kernel(bool fused_, int have) {
         LaunchSlice sl;
         memset(&sl, 0, sizeof(sl));
         sl.chain_lo = 0; sl.chain_n = (int)n; sl.grp = -1;
+        const uint64_t cpb = W == 1 ? 4 : 1;   // chains per workgroup
         const int rc = model.jit_launch(d_args, args.max_evals, (void*)stream, &sl,
-                                        4 * model.jit_lds_bytes + model.jit_shared_bytes + 4 * 2 * (uint64_t)args.ld * 8);
+                                        cpb * model.jit_lds_bytes + model.jit_shared_bytes + cpb * 2 * (uint64_t)args.ld * 8);
         if (rc != 0) { set_error(std::string("launch of the runtime-compiled density kernel: ") + hipGetErrorString((hipError_t)rc)); return false; }
     } else if (!hip_ok(launch_advance(args, d_args, fused_, W, stream), "launch k_advance")) return false;
     if (kernel_ms_acc) {
@@ -1085,7 +1091,9 @@ void nphip_sampler::eval_ranges(const RowRange* rg, int nr) {
     if (timed_batches >= 4 && row_ns >= 150.0)   // (rows cheaper than that are faster on one thread: measured with 35 ns rows)
         want = (int)std::max(1.0, std::min<double>((double)cap, std::floor((double)total * row_ns / 10000.0)));
     if (want >= 2) {
-        if (!pool) pool.reset(new RowPool(std::max(2, cap)));
+        // sized to the largest batch width asked for so far (every worker of a pool acknowledges every batch: idle workers of a
+        // pool sized to the core count would spin through each of the steady batches of a resident job); growing it is rare
+        if (!pool || pool->size() < want) pool.reset(new RowPool(want));
         eval_threads = std::max(eval_threads, want);
         pool->run(total, f, want);
         return;

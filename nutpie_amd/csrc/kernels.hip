@@ -273,9 +273,11 @@ struct Machine {
         T = a.s.num_tune + a.s.num_draws;
         if (DENS) {   // (also in the machines the rare paths rebuild: the density is evaluated there too — initial point, step-size search)
             extern __shared__ __attribute__((aligned(16))) double s_dyn_dens[];
-            dens_lds = (LdsDouble)s_dyn_dens + (size_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * a.dens_lds_doubles;
-            dens_shared = (LdsDouble)s_dyn_dens + (size_t)4 * a.dens_lds_doubles;
-            dens_rows = dens_shared + a.dens_shared_doubles + (size_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * 2 * ld;
+            // one wave per chain: four chains per workgroup, each with its own scratch and rows; several waves per chain: one chain
+            const int slot = (W == 1) ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+            dens_lds = (LdsDouble)s_dyn_dens + (size_t)slot * a.dens_lds_doubles;
+            dens_shared = (LdsDouble)s_dyn_dens + (size_t)(W == 1 ? 4 : 1) * a.dens_lds_doubles;
+            dens_rows = dens_shared + a.dens_shared_doubles + (size_t)slot * 2 * ld;
         }
     }
 
@@ -666,11 +668,12 @@ struct Machine {
     __device__ __forceinline__ void remote_eval(double& lp, int64_t& code, bool rows_in_lds = false) {
 #if NPHIP_JIT
         if (DENS) {
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            chain_sync<W>();   // (several waves per chain: every wave has written its chunks of the position)
             const double* xr = rows_in_lds ? (const double*)dens_rows : A.qeval + (size_t)chain * D;
             double* gr = rows_in_lds ? (double*)(dens_rows + ld) : A.geval + (size_t)chain * D;
-            lp = nphip_density(*(const NphipData*)A.dens_data, (int)D, xr, gr, (double*)dens_lds, (const double*)dens_shared, lane);
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            // `lane` of the density = the thread's index within the chain (0 .. 64 W - 1)
+            lp = nphip_density(*(const NphipData*)A.dens_data, (int)D, xr, gr, (double*)dens_lds, (const double*)dens_shared, (W == 1) ? lane : (int)threadIdx.x);
+            chain_sync<W>();
             code = 0;
             return;
         }
@@ -2337,6 +2340,8 @@ struct Machine {
     __device__ __forceinline__ void cont_init(double lp, int64_t code) {
         if (code < 0) { finish_chain(PH_ERROR, CE_FATAL_LOGP); return; }
         if (code != 0 || !isfinite(lp)) {
+            // a chain resumed at a host-given position (k_resume) is never restarted from a random point behind the host's back
+            if (c->init_attempt < 0) { finish_chain(PH_ERROR, CE_RESUME_FAILED); return; }
             c->init_attempt += 1;
             if (c->init_attempt >= A.s.num_try_init) { finish_chain(PH_ERROR, CE_INIT_FAILED); return; }
             gen_init(c->init_attempt);
@@ -2778,7 +2783,7 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) __attribute__((amdgpu_waves_
     }
 #if NPHIP_JIT
     if (REMOTE) {   // the model's shared LDS block: filled once per workgroup and launch, by all of its threads
-        nphip_density_stage(*(const NphipData*)A.dens_data, (double*)s_dyn + (size_t)4 * A.dens_lds_doubles, (int)threadIdx.x, (int)blockDim.x);
+        nphip_density_stage(*(const NphipData*)A.dens_data, (double*)s_dyn + (size_t)(W == 1 ? 4 : 1) * A.dens_lds_doubles, (int)threadIdx.x, (int)blockDim.x);
         __syncthreads();
     }
 #endif
@@ -3080,7 +3085,7 @@ __global__ void k_resume(const Args* __restrict__ Ap, int n, const int64_t* __re
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        c->init_attempt = 0;
+        c->init_attempt = -1;   // (cont_init: fail instead of retrying elsewhere)
         c->eval_buf = 0;
         c->phase = PH_INIT_EVAL;
     }
@@ -3212,34 +3217,57 @@ hipError_t launch_remote_wn(const Args* d_args, int W, int nv, hipStream_t st, c
 #if !NPHIP_JIT || !defined(NPHIP_JIT_NV)
 #error "part 7 is the runtime-compiled density: -DNPHIP_JIT_DENSITY -DNPHIP_JIT_NV=n behind a prelude that defines NphipData / nphip_density"
 #endif
-__global__ __launch_bounds__(256) void k_density_batch(const NphipData* __restrict__ data, uint64_t n_chains, int dim, const double* __restrict__ q,
-                                                       double* __restrict__ grad, double* __restrict__ logp, int lds_doubles) {
+#ifndef NPHIP_JIT_W
+#define NPHIP_JIT_W 1
+#endif
+// one wave per chain: four chains per workgroup; NPHIP_JIT_W waves per chain: one chain per workgroup of 64 W threads
+__global__ __launch_bounds__(NPHIP_JIT_W == 1 ? 256 : 64 * NPHIP_JIT_W) void k_density_batch(const NphipData* __restrict__ data, uint64_t n_chains, int dim, const double* __restrict__ q,
+                                                       double* __restrict__ grad, double* __restrict__ logp, int lds_doubles, int shared_doubles, int rows_in_lds) {
     extern __shared__ __attribute__((aligned(16))) double s_scratch[];
-    const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint64_t chain = (uint64_t)blockIdx.x * 4 + wib;
-    nphip_density_stage(*data, s_scratch + (size_t)4 * lds_doubles, (int)threadIdx.x, (int)blockDim.x);
+    constexpr int CPB = NPHIP_JIT_W == 1 ? 4 : 1;   // chains per block
+    constexpr int TPC = 64 * NPHIP_JIT_W;           // threads per chain
+    const int slot = NPHIP_JIT_W == 1 ? (int)(threadIdx.x >> 6) : 0, tid = NPHIP_JIT_W == 1 ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
+    const uint64_t chain = (uint64_t)blockIdx.x * CPB + slot;
+    double* shared = s_scratch + (size_t)CPB * lds_doubles;
+    // the chain's position and gradient rows in LDS, as in the resident kernel (the density reads x[] several times)
+    const int ldp = (dim + 1) & ~1;
+    double* rows = shared + shared_doubles + (size_t)slot * 2 * ldp;
+    nphip_density_stage(*data, shared, (int)threadIdx.x, (int)blockDim.x);
+    if (rows_in_lds && chain < n_chains) for (int i = tid; i < dim; i += TPC) rows[i] = q[chain * (uint64_t)dim + i];
     __syncthreads();
     if (chain >= n_chains) return;
-    const double lp = nphip_density(*data, dim, q + chain * (uint64_t)dim, grad + chain * (uint64_t)dim, s_scratch + (size_t)wib * lds_doubles,
-                                    s_scratch + (size_t)4 * lds_doubles, lane);
-    if (lane == 0) logp[chain] = lp;
+    if (!rows_in_lds) {   // (rows too long for LDS: the density works on the rows in memory)
+        const double lp = nphip_density(*data, dim, q + chain * (uint64_t)dim, grad + chain * (uint64_t)dim, s_scratch + (size_t)slot * lds_doubles, shared, tid);
+        if (tid == 0) logp[chain] = lp;
+        return;
+    }
+    const double lp = nphip_density(*data, dim, rows, rows + ldp, s_scratch + (size_t)slot * lds_doubles, shared, tid);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    if (NPHIP_JIT_W == 1) __builtin_amdgcn_wave_barrier(); else __syncthreads();
+    for (int i = tid; i < dim; i += TPC) grad[chain * (uint64_t)dim + i] = rows[ldp + i];
+    if (tid == 0) logp[chain] = lp;
 }
 }  // namespace nphip
 extern "C" {
 // nphip_jit_launch_fn (host.hip): one launch of the resident kernel over the slice's chains
 int nphip_jit_launch(const nphip::Args* d_args, int max_evals, void* stream, const nphip::LaunchSlice* sl, uint64_t dyn_lds_bytes) {
-    const dim3 g(((unsigned)sl->chain_n + 3) / 4), b(256);
-    hipLaunchKernelGGL((nphip::k_advance<false, 1, NPHIP_JIT_NV, false, true>), g, b, (size_t)dyn_lds_bytes, (hipStream_t)stream, d_args, max_evals, 0, *sl);
+    const dim3 g(NPHIP_JIT_W == 1 ? ((unsigned)sl->chain_n + 3) / 4 : (unsigned)sl->chain_n), b(NPHIP_JIT_W == 1 ? 256 : 64 * NPHIP_JIT_W);
+    hipLaunchKernelGGL((nphip::k_advance<false, NPHIP_JIT_W, NPHIP_JIT_NV, false, true>), g, b, (size_t)dyn_lds_bytes, (hipStream_t)stream, d_args, max_evals, 0, *sl);
     return (int)hipGetLastError();
 }
+int nphip_jit_w(void) { return NPHIP_JIT_W; }
 int nphip_jit_nv(void) { return NPHIP_JIT_NV; }
 // nphip_device_logp_fn; user_data -> { device pointer of the data block, LDS doubles per wave }
 struct nphip_jit_batch_t { const void* data; int32_t lds_doubles, shared_doubles; };
 int nphip_jit_logp(uint64_t n_chains, uint64_t dim, const double* q, double* grad, double* logp, void* stream, void* user_data) {
     const nphip_jit_batch_t* u = (const nphip_jit_batch_t*)user_data;
     if (!u) return -1;
-    hipLaunchKernelGGL(nphip::k_density_batch, dim3((unsigned)((n_chains + 3) / 4)), dim3(256), ((size_t)4 * u->lds_doubles + u->shared_doubles) * sizeof(double), (hipStream_t)stream,
-                       (const NphipData*)u->data, n_chains, (int)dim, q, grad, logp, (int)u->lds_doubles);
+    constexpr int CPB = NPHIP_JIT_W == 1 ? 4 : 1;
+    const size_t own = (size_t)CPB * u->lds_doubles + u->shared_doubles, rows = (size_t)CPB * 2 * (((size_t)dim + 1) & ~(size_t)1);
+    const int rows_in_lds = (own + rows) * sizeof(double) <= 144 * 1024;
+    hipLaunchKernelGGL(nphip::k_density_batch, dim3((unsigned)((n_chains + CPB - 1) / CPB)), dim3(NPHIP_JIT_W == 1 ? 256 : 64 * NPHIP_JIT_W),
+                       (own + (rows_in_lds ? rows : 0)) * sizeof(double), (hipStream_t)stream,
+                       (const NphipData*)u->data, n_chains, (int)dim, q, grad, logp, (int)u->lds_doubles, (int)u->shared_doubles, rows_in_lds);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 }  // extern "C"

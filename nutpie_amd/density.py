@@ -126,6 +126,22 @@ def generated_source(user_source: str, layout) -> str:
         "#define NPHIP_LDS_PTR(type, p) ((__attribute__((address_space(3))) type*)(p))",
         "#define NPHIP_LDS_CPTR(type, p) ((const __attribute__((address_space(3))) type*)(p))",
         "static __device__ __forceinline__ double nphip_wave_sum(double v) { return nphip::wave_sum(v); }",
+        "// the same over ALL threads of the chain (waves_per_chain > 1: wave totals added in wave order through LDS; every thread gets the",
+        "// same value), the number of threads that evaluate one chain's density, and the barrier between its phases",
+        "#define NPHIP_CHAIN_THREADS (64 * NPHIP_JIT_W)",
+        "template <int N> static __device__ __forceinline__ void nphip_chain_sumN(double (&v)[N]) {",
+        "    if (NPHIP_JIT_W == 1) { nphip::wave_sumN(v); return; }",
+        "    __shared__ double red_[8 * NPHIP_JIT_W];",
+        "    nphip::reduceN<NPHIP_JIT_W, N>(v, (NPHIP_LDS double*)red_);",
+        "}",
+        "static __device__ __forceinline__ double nphip_chain_sum(double a) { double v[1] = {a}; nphip_chain_sumN(v); return v[0]; }",
+        "static __device__ __forceinline__ void nphip_chain_sum2(double& a, double& b) { double v[2] = {a, b}; nphip_chain_sumN(v); a = v[0]; b = v[1]; }",
+        "static __device__ __forceinline__ void nphip_chain_sum3(double& a, double& b, double& c) { double v[3] = {a, b, c}; nphip_chain_sumN(v); a = v[0]; b = v[1]; c = v[2]; }",
+        "static __device__ __forceinline__ void nphip_chain_sum4(double& a, double& b, double& c, double& d) { double v[4] = {a, b, c, d}; nphip_chain_sumN(v); a = v[0]; b = v[1]; c = v[2]; d = v[3]; }",
+        "static __device__ __forceinline__ void nphip_chain_barrier() {",
+        '    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");',
+        "    if (NPHIP_JIT_W == 1) __builtin_amdgcn_wave_barrier(); else __syncthreads();",
+        "}",
         "// several sums at once (the same bits as one nphip_wave_sum each, issued stage by stage: a lone wave otherwise waits out every step)",
         "static __device__ __forceinline__ void nphip_wave_sum3(double& a, double& b, double& c) { double v[3] = {a, b, c}; nphip::wave_sumN(v); a = v[0]; b = v[1]; c = v[2]; }",
         "static __device__ __forceinline__ void nphip_wave_sum4(double& a, double& b, double& c, double& d) { double v[4] = {a, b, c, d}; nphip::wave_sumN(v); a = v[0]; b = v[1]; c = v[2]; d = v[3]; }",
@@ -136,16 +152,18 @@ def generated_source(user_source: str, layout) -> str:
     ])
 
 
-def compile_density(user_source: str, layout, ndim: int, *, verbose: bool = False) -> str:
-    """Build (or find in the cache) the model's library; returns its path."""
-    nv = (int(ndim) + 127) // 128
+def compile_density(user_source: str, layout, ndim: int, *, waves: int = 1, verbose: bool = False) -> str:
+    """Build (or find in the cache) the model's library; returns its path.  ``waves`` wavefronts evaluate one chain's density."""
+    if waves not in (1, 2, 4):
+        raise ValueError("waves_per_chain must be 1, 2 or 4")
+    nv = ((int(ndim) + 127) // 128 + waves - 1) // waves   # chunks of 128 dimensions per wave
     src = generated_source(user_source, layout)
     deps = [os.path.join(_CSRC, f) for f in ("kernels.hip", "engine_types.h")] + [os.path.join(_INCLUDE, "nphip_spec.h")]
     h = hashlib.sha256()
     h.update(src.encode())
     for d in deps:
         h.update(open(d, "rb").read())
-    flags = _FLAGS + ["-DNPHIP_JIT_DENSITY=1", "-DNPHIP_PART=7", f"-DNPHIP_JIT_NV={max(1, nv)}"] + os.environ.get("NUTPIE_AMD_JIT_FLAGS", "").split()
+    flags = _FLAGS + ["-DNPHIP_JIT_DENSITY=1", "-DNPHIP_PART=7", f"-DNPHIP_JIT_NV={max(1, nv)}", f"-DNPHIP_JIT_W={waves}"] + os.environ.get("NUTPIE_AMD_JIT_FLAGS", "").split()
     h.update(" ".join(flags).encode())
     out = os.path.join(cache_dir(), f"density_{h.hexdigest()[:24]}.so")
     if os.path.exists(out):
@@ -177,6 +195,8 @@ class DensityLibrary:
         self.lib = C.CDLL(path)
         self.lib.nphip_jit_nv.restype = C.c_int
         self.nv = int(self.lib.nphip_jit_nv())
+        self.lib.nphip_jit_w.restype = C.c_int
+        self.waves = int(self.lib.nphip_jit_w())
         self.launch_addr = C.cast(self.lib.nphip_jit_launch, C.c_void_p).value
         self.logp_addr = C.cast(self.lib.nphip_jit_logp, C.c_void_p).value
 
@@ -225,6 +245,7 @@ class DensitySourceModel(CompiledModel):
     _expand_func: Callable | None = None     # (x[N, D] numpy, **data) -> dict name -> [N, *shape]
     _init: Any = "uniform"
     _resident: bool = True                   # False: always the batched callback (launch per evaluation)
+    _waves: int = 1                          # wavefronts that evaluate one chain's density together
 
     @property
     def n_dim(self):
@@ -257,9 +278,9 @@ class DensitySourceModel(CompiledModel):
         return r(self._lds_bytes), r(self._shared_bytes)
 
     def library(self) -> DensityLibrary:
-        return DensityLibrary(compile_density(self._source, data_layout(self._data), self._n_dim))
+        return DensityLibrary(compile_density(self._source, data_layout(self._data), self._n_dim, waves=self._waves))
 
-    def logp_and_grad(self, x, device: int = 0):
+    def logp_and_grad(self, x, device: int = 0, return_data: bool = False):
         """The compiled density on a block of positions ``x[N, n_dim]`` (one launch of the batched form, ``nphip_jit_logp``):
         ``(logp[N], grad[N, n_dim])`` as numpy arrays.  For checking a model; sampling never goes through the host."""
         import torch
@@ -281,6 +302,8 @@ class DensitySourceModel(CompiledModel):
             torch.cuda.synchronize()
         if rc != 0:
             raise RuntimeError(f"launching the density failed ({rc}): too much LDS?")
+        if return_data:   # (the data block as it is after the call: sources that write into their data — cycle counters — are read back)
+            return lp.cpu().numpy(), g.cpu().numpy(), {k: t.cpu().numpy() for k, t in dd.tensors.items()}
         return lp.cpu().numpy(), g.cpu().numpy()
 
     def _make_model(self, init_mean=None, settings=None, device: int = 0, resident: bool | None = None):
@@ -293,7 +316,7 @@ class DensitySourceModel(CompiledModel):
             use_resident = False
         lds_bytes, shared_bytes = self._lds()
         if use_resident:
-            model = _lib.JitDensityModel(self._n_dim, lib.launch_addr, lib.nv, dd.ptr, lds_bytes, shared_bytes, keep_alive=(lib, dd))
+            model = _lib.JitDensityModel(self._n_dim, lib.launch_addr, lib.nv, dd.ptr, lds_bytes, shared_bytes, keep_alive=(lib, dd), waves_per_chain=lib.waves)
         else:
             batch = _Batch(dd.ptr, lds_bytes // 8, shared_bytes // 8)
             model = _lib.NativeDeviceCallbackModel(self._n_dim, lib.logp_addr, C.addressof(batch), keep_alive=(lib, dd, batch))
@@ -310,6 +333,10 @@ class DensitySourceModel(CompiledModel):
             raise RuntimeError("a device density needs a GPU: the nutpie-hip engine has no CPU fallback")
         device = int(engine_kw.get("device", 0) or 0)
         model = self._make_model(settings=settings, device=device)
+        if not engine_kw.get("waves_per_chain") and (self._waves > 1 or self._n_dim <= 1024):
+            # the batched form runs the engine with as many waves per chain as the resident kernel has: a chain's sums are taken
+            # in the same order either way, so both forms of one library draw identically
+            engine_kw = {**engine_kw, "waves_per_chain": self._waves}
         return _lib.PySampler.from_pyfunc(settings, cores, model, progress_type, extra_callback, extra_callback_rate, store, **engine_kw)
 
     def _expand_draws(self, draws):
@@ -326,12 +353,17 @@ def _times8(v):
 
 def from_density_source(ndim: int, source: str, data: dict[str, Any] | None = None, *, lds_doubles_per_chain: int = 0, lds_doubles_shared: int = 0,
                         expand_fn: Callable | None = None, expanded_names: list[str] | None = None, expanded_shapes=None,
-                        coords=None, dims=None, init="uniform", resident: bool = True, reparameterized_names=None) -> DensitySourceModel:
+                        coords=None, dims=None, init="uniform", resident: bool = True, reparameterized_names=None, waves_per_chain: int = 1) -> DensitySourceModel:
     """A model from the HIP source of its log-density (module docstring): ``source`` defines ``nphip_density``; ``data`` are the
     arrays / scalars it reads through ``NphipData``; ``lds_doubles_per_chain`` the LDS scratch it uses per chain, ``lds_doubles_shared``
     the LDS its ``nphip_density_stage`` fills once per workgroup (each an int or a function of the data dict: ``with_data`` may
     change the sizes).  ``expand_fn`` (optional)
-    maps a numpy block ``[N, ndim]`` of draws to the dict of expanded variables, as :func:`nutpie_amd.from_torchfunc` does."""
+    maps a numpy block ``[N, ndim]`` of draws to the dict of expanded variables, as :func:`nutpie_amd.from_torchfunc` does.
+    ``waves_per_chain`` (1, 2 or 4): that many wavefronts evaluate one chain's density together — the source then strides its loops
+    by ``NPHIP_CHAIN_THREADS`` (``lane`` runs over ``0 .. NPHIP_CHAIN_THREADS - 1``), sums with ``nphip_chain_sum*`` and separates
+    its phases with ``nphip_chain_barrier()``; with fewer chains than the device has SIMDs (1024) this is what fills it."""
+    if waves_per_chain not in (1, 2, 4):
+        raise ValueError("waves_per_chain must be 1, 2 or 4")
     if expanded_names is None:
         if expand_fn is not None:
             raise ValueError("expand_fn needs expanded_names and expanded_shapes")
@@ -343,4 +375,4 @@ def from_density_source(ndim: int, source: str, data: dict[str, Any] | None = No
         raise ValueError("lds_doubles_shared needs `__device__ void nphip_density_stage(const NphipData& data, double* shared, int thread, int n_threads)` in the source")
     return DensitySourceModel(dims=dict(dims or {}), _source=source, _n_dim=int(ndim), _data=dict(data or {}), _lds_bytes=_times8(lds_doubles_per_chain), _shared_bytes=_times8(lds_doubles_shared),
                               _names=list(expanded_names), _shapes=[tuple(s) for s in expanded_shapes], _coords=dict(coords or {}),
-                              _expand_func=expand_fn, _init=init, _resident=bool(resident), reparameterized_names=reparameterized_names)
+                              _expand_func=expand_fn, _init=init, _resident=bool(resident), _waves=int(waves_per_chain), reparameterized_names=reparameterized_names)

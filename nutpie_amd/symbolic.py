@@ -151,11 +151,15 @@ def _binary(op: str, a: Expr, b: Expr) -> Expr:
     if a.op == "const" and b.op == "const":
         x, y = a.payload, b.payload
         return Expr.const({"add": x + y, "sub": x - y, "mul": x * y, "div": x / y if y != 0.0 else math.copysign(math.inf, x)}[op])
+    if op == "mul" and b.op == "const" and a.op != "const":
+        a, b = b, a                                   # constants first
     if op == "add":
         if a.is_const(0.0):
             return b
         if b.is_const(0.0):
             return a
+        if a is b:
+            return _binary("mul", Expr.const(2.0), a)
     elif op == "sub":
         if b.is_const(0.0):
             return a
@@ -170,15 +174,19 @@ def _binary(op: str, a: Expr, b: Expr) -> Expr:
             return Expr.const(0.0)
         if a.is_const(-1.0):
             return _unary("neg", b)
-        if b.is_const(-1.0):
-            return _unary("neg", a)
+        if a.op == "const" and b.op == "mul" and b.args[0].op == "const":
+            return _binary("mul", Expr.const(a.payload * b.args[0].payload), b.args[1])     # c1 (c2 x) = (c1 c2) x
+        if a.op == "const" and b.op == "neg":
+            return _binary("mul", Expr.const(-a.payload), b.args[0])
     elif op == "div":
         if b.is_const(1.0):
             return a
         if a.is_const(0.0):
             return a
+        if b.op == "const" and b.payload != 0.0:
+            return _binary("mul", a, Expr.const(1.0 / b.payload))     # (the numpy evaluation follows the same graph)
         if a.dim is not None and b.dim is None:
-            # one division per evaluation instead of one per element (the numpy evaluation follows the same graph)
+            # one division per evaluation instead of one per element
             return _binary("mul", a, _binary("div", Expr.const(1.0), b))
     return Expr(op, (a, b), _join(a, b))
 
@@ -192,6 +200,10 @@ def _unary(op: str, a) -> Expr:
     if a.op == "const":
         return Expr.const(_UNARY_FOLD[op](a.payload))
     if op == "neg" and a.op == "neg":
+        return a.args[0]
+    if op == "neg" and a.op == "mul" and a.args[0].op == "const":
+        return _binary("mul", Expr.const(-a.args[0].payload), a.args[1])
+    if op == "log" and a.op == "exp":      # log sigma of a log-transformed sigma: the raw parameter
         return a.args[0]
     return Expr(op, (a,), a.dim)
 
@@ -444,8 +456,11 @@ def evaluate(nodes: list[Expr], x: np.ndarray, data: dict[str, Any]) -> list[np.
 class _Gen:
     """logp + gradient -> the source of ``nphip_density``."""
 
-    def __init__(self, model: "Model", logp: Expr, grads: list[Expr]):
+    def __init__(self, model: "Model", logp: Expr, grads: list[Expr], waves: int = 1, profile: bool = False):
         self.m = model
+        self.threads = _WAVE * waves
+        self.profile = profile      # cycle counters per section, added into data.prof__ (Model.profile)
+        self.sections: list[str] = []
         self.logp = logp
         self.params = model._params
         # gradient outputs: scalars by lane 0 at the end; vectors in a loop over their dimension
@@ -459,29 +474,52 @@ class _Gen:
             if n.op in ("sum", "gather", "segsum"):
                 lv += 1
             self.level[n.id] = lv
-        # where every dimensioned node is USED (the loop levels that read it): a node is read in the loop of its consumer
-        uses: dict[int, set[int]] = {}
-        for n in self.order:
-            for a in n.args:
-                if a.dim is None:
-                    continue
-                # sum / gather / segsum read their argument in the loop that produces the argument (sum: accumulate there;
-                # gather, segsum: the argument is stored there for the later loop)
-                at = self.level[a.id] if n.op in ("sum", "gather", "segsum") else self.level[n.id]
-                uses.setdefault(a.id, set()).add(at)
-        for _, g in self.out_vector:
-            uses.setdefault(g.id, set()).add(self.level[g.id])
         # what lives in per-chain LDS: sources of gathers (unless they are parameters or data, read in place), arguments of
-        # segment sums (stored grouped by target), and segment sums that more than one loop reads
-        self.stored: dict[int, tuple[str, Dim]] = {}
+        # segment sums (stored grouped by target) ...
+        self.stored: dict[Any, tuple[str, Dim]] = {}
         for n in self.order:
             if n.op == "gather" and n.args[0].op not in ("vparam", "data"):
                 self.stored[n.args[0].id] = ("plain", n.args[0].dim)
             elif n.op == "segsum":
                 self.stored[("seg", n.args[0].id, n.payload.name)] = ("grouped", n.args[0].dim)
-                if len(uses.get(n.id, ())) > 1 or any(u > self.level[n.id] for u in uses.get(n.id, ())):
-                    self.stored[n.id] = ("plain", n.dim)
-        self.uses = uses
+        # ... and segment sums that more than one loop needs.  Element-wise values are recomputed in every loop that needs them
+        # (a few operations on values that are read anyway); a segment sum is an inner loop over its range.
+        evaluated: dict[int, set[int]] = {}     # segment sum -> the levels of the loops that evaluate it
+        by_id = {n.id: n for n in self.order}
+        for lv, roots in self.loop_roots().items():
+            seen: set[int] = set()
+            stack = list(roots)
+            while stack:
+                n = stack.pop()
+                if n.dim is None or n.id in seen:
+                    continue
+                seen.add(n.id)
+                if n.id in self.stored and self.level[n.id] < lv[1]:
+                    continue               # read from LDS
+                if n.op == "segsum":
+                    evaluated.setdefault(n.id, set()).add(lv[1])
+                    continue               # (its argument was stored by an earlier loop)
+                if n.op == "gather":
+                    continue
+                stack.extend(n.args)
+        for nid, levels in evaluated.items():
+            if len(levels) > 1:
+                self.stored[nid] = ("plain", by_id[nid].dim)
+
+    def loop_roots(self) -> dict[tuple[int, int], list[Expr]]:
+        """(id of the dimension, level) -> the nodes the loop has to produce: arguments of sums, stored values, gradient rows"""
+        roots: dict[tuple[int, int], list[Expr]] = {}
+        by_id = {n.id: n for n in self.order}
+        for n in self.order:
+            if n.op == "sum":
+                a = n.args[0]
+                roots.setdefault((id(a.dim), self.level[a.id]), []).append(a)
+        for key in self.stored:
+            node = by_id[key[1] if isinstance(key, tuple) else key]
+            roots.setdefault((id(node.dim), self.level[node.id]), []).append(node)
+        for _, g in self.out_vector:
+            roots.setdefault((id(g.dim), self.level[g.id]), []).append(g)
+        return roots
 
     # ---- LDS layout
     def lds_layout(self):
@@ -518,6 +556,18 @@ class _Gen:
         max_level = max(self.level.values(), default=0)
         done_scalar: set[int] = set()
         self.L = L
+        if self.profile:   # eight evaluations, the last one timed: the first pays for instruction and data cache misses
+            emit("    double result_ = 0.0;")
+            emit("    for (int rep_ = 0; rep_ < 8; ++rep_) {")
+            emit("    long long t_ = (long long)__builtin_readcyclecounter();")
+
+        def mark(label: str):
+            if self.profile:
+                # (kept in registers until the evaluation is over: 1024 chains adding into one counter would be what is measured)
+                emit('    __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");')
+                emit(f"    const long long m{len(self.sections)}_ = (long long)__builtin_readcyclecounter();")
+                emit("    __builtin_amdgcn_sched_barrier(0);")
+                self.sections.append(label)
 
         def scalar_ready(n: Expr) -> bool:
             return all(a.dim is not None or a.id in done_scalar for a in n.args)
@@ -530,6 +580,7 @@ class _Gen:
                     if n.op != "const":
                         emit(f"    const double s{n.id} = {self.scalar_rhs(n)};")
                     done_scalar.add(n.id)
+            mark(f"scalars of level {lv}")
             # loops of this level, one per dimension that has something to produce here
             for d in m._dims.values():
                 sums = [n for n in self.order if n.op == "sum" and n.args[0].dim is d and self.level[n.args[0].id] == lv]
@@ -543,14 +594,25 @@ class _Gen:
                 outs = [(p, g) for p, g in self.out_vector if p.dim is d and self.level[g.id] == lv]
                 if not (sums or stores or outs):
                     continue
-                self.loop(d, lv, sums, stores, outs)
+                self.loop(d, lv, sums, stores, outs, mark)
                 for n in sums:
                     done_scalar.add(n.id)
+        mark("tail scalars")
         emit("    if (lane == 0) {")
         for p, g in self.out_scalar:
             emit(f"        g[{p.payload}] = {self.sref(g)};")
         emit("    }")
-        emit(f"    return {self.sref(self.logp)};")
+        if self.profile:
+            emit(f"    result_ = {self.sref(self.logp)};")
+            emit("    if (lane == 0 && rep_ == 7) {")
+            for k in range(len(self.sections)):
+                emit(f"        atomicAdd((double*)data.prof__ + {k}, (double)(m{k}_ - {'t_' if k == 0 else f'm{k - 1}_'}));")
+            emit("    }")
+            emit("    nphip_chain_barrier();")
+            emit("    }")
+            emit("    return result_;")
+        else:
+            emit(f"    return {self.sref(self.logp)};")
         emit("}")
         return "\n".join(L), shared_fields
 
@@ -570,19 +632,20 @@ class _Gen:
         return _op_c(n.op, [self.sref(a) for a in n.args])
 
     # ---- one wave-wide loop
-    def loop(self, d: Dim, lv: int, sums, stores, outs):
+    def loop(self, d: Dim, lv: int, sums, stores, outs, mark=lambda label: None):
         emit = self.L.append
-        U = _UNROLL if d.size is None else max(1, min(_UNROLL, -(-d.size // _WAVE)))
+        T = self.threads
+        U = _UNROLL if d.size is None else max(1, min(_UNROLL, -(-d.size // T)))
         by_id = {n.id: n for n in self.order}
         emit(f"    // level {lv}, over {d.name}")
         for n in sums:
             emit(f"    double s{n.id} = 0.0;")
-        emit(f"    for (int i0 = lane; i0 < n_{d.name}; i0 += {_WAVE * U}) {{")
+        emit(f"    for (int i0 = lane; i0 < n_{d.name}; i0 += {T * U}) {{")
         stages: list[list[str]] = [[], [], [], [], []]   # 0 direct reads, 1 dependent reads, 2 segment sums, 3 arithmetic, 4 stores / sums
         seg: dict[tuple, list[tuple[str, str]]] = {}     # (iteration, index) -> [(accumulator, array)]: one inner loop for all of them
         for u in range(U):
             memo: dict[int, str] = {}
-            stages[0].append(f"        const int i_{u} = i0 + {_WAVE * u}, j_{u} = i_{u} < n_{d.name} ? i_{u} : 0;")
+            stages[0].append(f"        const int i_{u} = i0 + {T * u}, j_{u} = i_{u} < n_{d.name} ? i_{u} : 0;")
 
             def val(n: Expr, u=u, memo=memo) -> str:
                 if n.dim is None:
@@ -649,6 +712,8 @@ class _Gen:
             for p, gexpr in outs:
                 off, nv = p.payload
                 stages[4].append(f"        if (i_{u} < {nv}) g[{off} + i_{u}] = {val(gexpr)};")
+        # all segment sums of one index in one inner loop per unrolled iteration (walking the ranges of several iterations side by
+        # side was measured: the extra compares cost more than the overlapped reads save — config 3: 44.7 -> 40.7 M leapfrogs/s)
         for (u, iname), accs in seg.items():
             stages[2].append("        double " + ", ".join(f"{a} = 0.0" for a, _ in accs) + ";")
             stages[2].append("#pragma unroll 4")
@@ -657,19 +722,19 @@ class _Gen:
             for line in st:
                 emit(line)
         emit("    }")
+        mark(f"loop over {d.name}, level {lv}")
         # the loop's sums over the wave, several at a time
         ids = [f"s{n.id}" for n in sums]
         for k in range(0, len(ids), 4):
             grp = ids[k:k + 4]
             if len(grp) == 1:
-                emit(f"    {grp[0]} = nphip_wave_sum({grp[0]});")
-            elif len(grp) == 2:
-                emit(f"    {{ double z_ = 0.0; nphip_wave_sum3({grp[0]}, {grp[1]}, z_); }}")
+                emit(f"    {grp[0]} = nphip_chain_sum({grp[0]});")
             else:
-                emit(f"    nphip_wave_sum{len(grp)}({', '.join(grp)});")
+                emit(f"    nphip_chain_sum{len(grp)}({', '.join(grp)});")
         if stores:
-            emit('    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");')
-            emit("    __builtin_amdgcn_wave_barrier();")
+            emit("    nphip_chain_barrier();")
+        if ids or stores:
+            mark(f"{len(ids)} sums" + (" + barrier" if stores else "") + f" after {d.name}, level {lv}")
 
 
 def _field_len_c(name: str, dim: Dim) -> str:
@@ -896,12 +961,12 @@ class Model:
                 total += (len(data[name]) + 1) // 2
         return total
 
-    def generate(self):
+    def generate(self, waves_per_chain: int = 1):
         """-> (source, generator): the HIP source of the density and the object that knows its LDS layout."""
         logp = self.logp_expr()
         grads = gradient(logp, self._params)
         self._staged = 8 * self._shared_doubles_unconditional(self._data) <= self.STAGE_LIMIT
-        gen = _Gen(self, logp, grads)
+        gen = _Gen(self, logp, grads, waves_per_chain)
         src, _ = gen.source()
         return src, gen
 
@@ -912,11 +977,42 @@ class Model:
         finally:
             self._staged = was
 
-    def compile(self, *, init="uniform", resident: bool = True, coords=None, dims=None):
-        """-> :class:`SymbolicModel` (a :class:`nutpie_amd.density.DensitySourceModel`)."""
+    def profile(self, n_chains: int = 1024, waves_per_chain: int = 1, scale: float = 0.3, seed: int = 0):
+        """Where an evaluation spends its cycles: the density is generated with a cycle counter (``s_memtime``) after every
+        section, compiled, and run once for ``n_chains`` positions (1024 single-wave chains = one wave per SIMD, the situation
+        of the sampler).  Returns ``[(section, mean cycles per evaluation)]``."""
+        logp = self.logp_expr()
+        grads = gradient(logp, self._params)
+        had = "prof__" in self._data
+        if not had:
+            self._data["prof__"] = np.zeros(64)
+            self._data_fields.append(("prof__", "raw", None))
+        try:
+            self._staged = 8 * self._shared_doubles_unconditional(self._data) <= self.STAGE_LIMIT
+            gen = _Gen(self, logp, grads, waves_per_chain, profile=True)
+            src, _ = gen.source()
+            compiled = self._finish(src, gen, waves_per_chain=waves_per_chain)
+            x = scale * np.random.default_rng(seed).normal(size=(n_chains, self._n_dim))
+            compiled.logp_and_grad(x)                      # (first call: loads the library, pages in)
+            _, _, data = compiled.logp_and_grad(x, return_data=True)
+            cycles = data["prof__"][:len(gen.sections)] / n_chains
+            return list(zip(gen.sections, cycles.tolist()))
+        finally:
+            if not had:
+                del self._data["prof__"]
+                self._data_fields.pop()
+
+    def compile(self, *, init="uniform", resident: bool = True, coords=None, dims=None, waves_per_chain: int = 1):
+        """-> :class:`SymbolicModel` (a :class:`nutpie_amd.density.DensitySourceModel`).  ``waves_per_chain`` (1, 2, 4): wavefronts
+        that evaluate one chain's density together — more than one pays with fewer chains than the device has SIMDs (1024)."""
         from nutpie_amd.density import from_density_source
 
-        src, gen = self.generate()
+        src, gen = self.generate(waves_per_chain)
+        return self._finish(src, gen, init=init, resident=resident, coords=coords, dims=dims, waves_per_chain=waves_per_chain)
+
+    def _finish(self, src, gen, *, init="uniform", resident=True, coords=None, dims=None, waves_per_chain=1):
+        from nutpie_amd.density import from_density_source
+
         dim_of = {k: d for k, d in self._dims.items()}
         stored_dims = [d for _, (_, d) in gen.stored.items()]
 
@@ -947,7 +1043,7 @@ class Model:
 
         base = from_density_source(self._n_dim, src, dict(self._data), lds_doubles_per_chain=lds_per_chain, lds_doubles_shared=lds_shared if staged else 0,
                                    expand_fn=expand, expanded_names=names, expanded_shapes=shapes, coords={**auto_coords, **(coords or {})},
-                                   dims={**auto_dims, **(dims or {})}, init=init, resident=resident)
+                                   dims={**auto_dims, **(dims or {})}, init=init, resident=resident, waves_per_chain=waves_per_chain)
         import dataclasses
 
         return _symbolic_model_class()(**{f.name: getattr(base, f.name) for f in dataclasses.fields(base)}, _front=self)

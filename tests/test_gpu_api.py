@@ -599,6 +599,27 @@ def test_pause_and_resume_hook(hip):
         auto.resume_at([0], pos[:1])
 
 
+def test_resume_at_a_position_that_does_not_evaluate_fails_the_chain(hip):
+    """a chain resumed by the host is never restarted from a random point behind the host's back: the position either evaluates
+    or the chain ends with an error that names the cause"""
+    s = hip.PyNutsSettings.Diag(5)
+    s.update(num_tune=40, num_draws=20, num_chains=4)
+    s.set_pause_draws([10])
+    smp = hip.PySampler(s, hip.TridiagGaussianModel(np.ones(5)), manual=True, evals_per_launch=50)
+    for _ in range(200):
+        smp.step(1)
+        if smp.waiting().all():
+            break
+    pos = np.zeros((4, 5))
+    pos[2, 3] = np.nan
+    smp.resume_at(np.arange(4), pos)
+    with pytest.raises(RuntimeError, match="resume_at does not evaluate"):
+        for _ in range(400):
+            if smp.step(10)[0]:
+                break
+        smp.take_results()
+
+
 def test_low_rank_adaptation_on_a_correlated_gaussian():
     """adaptation="low_rank" (reference docs/sampling-options.qmd:124-144): a 60-dimensional Gaussian with three strong
     correlated directions on top of heterogeneous scales.  A diagonal metric cannot undo the rotation and needs long

@@ -72,7 +72,7 @@ def test_radon_graph_is_the_hand_written_density():
 def test_generated_source_layout_and_errors():
     m = zoo.logistic()
     src, gen = m.generate()
-    assert "nphip_density_stage" in src and "nphip_wave_sum" in src
+    assert "nphip_density_stage" in src and "nphip_chain_sum" in src and "nphip_chain_barrier" in src
     # two groupings of the observations -> two arrays of adjoints stored grouped by target, and the non-centred effect as a gather source
     kinds = sorted(how for how, _ in gen.stored.values())
     assert kinds.count("grouped") == 2 and kinds.count("plain") >= 1
