@@ -15,4 +15,5 @@ timeout 900 bash scratch/pmc_bench.sh ${T}_d1000 "" > /dev/null
 python profiles/pmc_summary.py $(dirname $(ls $O/pmc_${T}_d1000/*/*_results.db $O/pmc_${T}_d1000/*_results.db 2>/dev/null | head -1)) -97 > $O/${T}_d1000_timed_config_pmc.txt 2>&1; cat $O/${T}_d1000_timed_config_pmc.txt
 timeout 1200 bash scratch/pmc_bench.sh ${T}_d10000 "--dim 10000" > /dev/null
 python profiles/pmc_summary.py $(dirname $(ls $O/pmc_${T}_d10000/*/*_results.db $O/pmc_${T}_d10000/*_results.db 2>/dev/null | head -1)) -38 > $O/${T}_d10000_timed_config_pmc.txt 2>&1; cat $O/${T}_d10000_timed_config_pmc.txt
+timeout 300 python scratch/c3gen.py 512 2>&1 | grep -v amdgpu.ids > $O/${T}_config3.txt; cat $O/${T}_config3.txt
 rm -rf $O/pmc_${T}_d1000 $O/pmc_${T}_d10000 $O/${T}_kt $O/${T}_kt10k
