@@ -51,10 +51,19 @@ _UNROLL = 4   # iterations of a loop whose reads are issued together (a lone wav
 class Dim:
     """A named coordinate of the model: the range one wave-wide loop runs over."""
 
-    def __init__(self, name: str, size, runtime_len: str | None = None):
+    def __init__(self, name: str, size, runtime_len: str | None = None, runtime_div: int = 1):
         self.name = name
         self.size = size                  # int, or None for a data dimension whose length comes from the data block
-        self.runtime_len = runtime_len    # C expression of the length for data dimensions ("data.n_y")
+        self.runtime_len = runtime_len    # the data array whose length is the dimension's (times runtime_div: a matrix's rows)
+        self.runtime_div = runtime_div
+
+    def len_c(self) -> str:
+        if self.size is not None:
+            return str(self.size)
+        return f"data.n_{self.runtime_len}" + (f" / {self.runtime_div}" if self.runtime_div != 1 else "")
+
+    def len_py(self, data) -> int:
+        return self.size if self.size is not None else int(np.asarray(data[self.runtime_len]).size) // self.runtime_div
 
     def __repr__(self):
         return f"Dim({self.name})"
@@ -65,6 +74,27 @@ class Index:
 
     def __init__(self, name: str, dim: Dim, into: Dim):
         self.name, self.dim, self.into = name, dim, into
+
+
+class Matrix:
+    """Float data with one row per element of ``dim`` and one column per element of ``cols`` (a design matrix).  ``X @ v`` with ``v``
+    on ``cols`` is the linear predictor on ``dim``: a sum over the columns of (column x element of v), so that its transpose —
+    the gradient with respect to ``v`` — is one wave-wide sum per column."""
+
+    def __init__(self, name: str, dim: Dim, cols: Dim):
+        self.name, self.dim, self.cols = name, dim, cols
+
+    def column(self, c: int) -> "Expr":
+        return Expr("datacol", (), self.dim, (self.name, int(c), self.cols.size))
+
+    def __matmul__(self, v) -> "Expr":
+        if not isinstance(v, Expr) or v.dim is not self.cols:
+            raise ValueError(f"matrix {self.name!r} multiplies a vector on dimension {self.cols.name!r}")
+        total = None
+        for c in range(self.cols.size):
+            term = self.column(c) * elem(v, c)
+            total = term if total is None else total + term
+        return total
 
 
 class Expr:
@@ -256,6 +286,31 @@ def _segsum(e: Expr, index: Index) -> Expr:
     return Expr("segsum", (_bcast(e, index.dim),), index.into, index)
 
 
+def elem(v: Expr, c: int) -> Expr:
+    """Element ``c`` of a vector on a fixed-size dimension, as a scalar."""
+    if v.dim is None:
+        return v
+    if v.dim.size is None or not 0 <= c < v.dim.size:
+        raise ValueError("elem() needs a vector on a fixed-size dimension and an index inside it")
+    if v.op == "vparam" and c >= v.payload[1]:
+        return Expr.const(0.0)            # the padding element of a zero-sum parameter
+    if v.op == "stack":
+        return v.args[c]
+    if v.op == "bcast":
+        return v.args[0]
+    return Expr("elem", (v,), None, int(c))
+
+
+def stack(scalars, dim: Dim) -> Expr:
+    """The vector on ``dim`` whose elements are the given scalars."""
+    scalars = [Expr.wrap(v) for v in scalars]
+    if dim.size is None or len(scalars) != dim.size or any(v.dim is not None for v in scalars):
+        raise ValueError("stack() needs one scalar per element of a fixed-size dimension")
+    if all(v.is_const(0.0) for v in scalars):
+        return Expr.const(0.0)
+    return Expr("stack", tuple(scalars), dim, None)
+
+
 # --------------------------------------------------------------------------- densities
 _HALF_LOG_2PI = 0.5 * math.log(2.0 * math.pi)
 
@@ -330,13 +385,25 @@ def gradient(out: Expr, wrt: list[Expr]) -> list[Expr]:
         raise AssertionError("dimension mismatch in the gradient")
 
     def acc(target: Expr, e: Expr):
-        if e.is_const(0.0) or target.op in ("const", "data", "dimlen"):
+        if e.is_const(0.0) or target.op in ("const", "data", "dimlen", "datacol"):
             return
         adj[target.id] = adj[target.id] + e if target.id in adj else e
 
+    elem_adj: dict[int, dict[int, Expr]] = {}     # vector -> {element: adjoint of elem(vector, element)}
     for n in reversed(order):
+        if n.id in elem_adj:      # every consumer of n has been visited: the adjoints of its extracted elements as one vector
+            parts = elem_adj.pop(n.id)
+            acc(n, stack([parts.get(c, Expr.const(0.0)) for c in range(n.dim.size)], n.dim))
         g = adj.get(n.id)
         if g is None or not n.args:
+            continue
+        if n.op == "elem":
+            slot = elem_adj.setdefault(n.args[0].id, {})
+            slot[n.payload] = slot[n.payload] + g if n.payload in slot else g
+            continue
+        if n.op == "stack":
+            for c, a_ in enumerate(n.args):
+                acc(a_, elem(g, c))
             continue
         d = n.dim
         a = n.args[0]
@@ -386,7 +453,7 @@ def evaluate(nodes: list[Expr], x: np.ndarray, data: dict[str, Any]) -> list[np.
     val: dict[int, np.ndarray] = {}
 
     def dim_len(dim: Dim) -> int:
-        return dim.size if dim.size is not None else int(np.asarray(data[dim.runtime_len]).size)
+        return dim.len_py(data)
 
     def up(v, n):     # align a scalar [N] with a dimensioned operand [N, len]
         return v[:, None] if (n.dim is not None and v.ndim == 1) else v
@@ -407,6 +474,13 @@ def evaluate(nodes: list[Expr], x: np.ndarray, data: dict[str, Any]) -> list[np.
                 v[:, :nv] = x[:, off:off + nv]
             elif n.op == "data":
                 v = np.broadcast_to(np.asarray(data[n.payload], dtype=np.float64), (N, dim_len(n.dim)))
+            elif n.op == "datacol":
+                name, c, K = n.payload
+                v = np.broadcast_to(np.asarray(data[name], dtype=np.float64).reshape(-1, K)[:, c], (N, dim_len(n.dim)))
+            elif n.op == "elem":
+                v = a[:, n.payload] if a.ndim == 2 else a
+            elif n.op == "stack":
+                v = np.stack([np.broadcast_to(val[x_.id], (N,)) for x_ in n.args], axis=1)
             elif n.op == "sdata":
                 v = np.full(N, float(data[n.payload]))
             elif n.op == "dimlen":
@@ -471,7 +545,7 @@ class _Gen:
         self.level: dict[int, int] = {}
         for n in self.order:
             lv = max([self.level[a.id] for a in n.args], default=0)
-            if n.op in ("sum", "gather", "segsum"):
+            if n.op in ("sum", "gather", "segsum") or (n.op == "elem" and n.args[0].op not in ("vparam", "data")):
                 lv += 1
             self.level[n.id] = lv
         # what lives in per-chain LDS: sources of gathers (unless they are parameters or data, read in place), arguments of
@@ -482,6 +556,10 @@ class _Gen:
                 self.stored[n.args[0].id] = ("plain", n.args[0].dim)
             elif n.op == "segsum":
                 self.stored[("seg", n.args[0].id, n.payload.name)] = ("grouped", n.args[0].dim)
+            elif n.op == "elem" and n.args[0].op not in ("vparam", "data", "stack"):
+                self.stored[n.args[0].id] = ("plain", n.args[0].dim)     # a scalar read of one element of a computed vector
+            elif n.op == "stack":
+                self.stored[n.id] = ("scalars", n.dim)                   # written by the scalar code, element by element
         # ... and segment sums that more than one loop needs.  Element-wise values are recomputed in every loop that needs them
         # (a few operations on values that are read anyway); a segment sum is an inner loop over its range.
         evaluated: dict[int, set[int]] = {}     # segment sum -> the levels of the loops that evaluate it
@@ -494,7 +572,7 @@ class _Gen:
                 if n.dim is None or n.id in seen:
                     continue
                 seen.add(n.id)
-                if n.id in self.stored and self.level[n.id] < lv[1]:
+                if n.op == "stack" or (n.id in self.stored and self.level[n.id] < lv[1]):
                     continue               # read from LDS
                 if n.op == "segsum":
                     evaluated.setdefault(n.id, set()).add(lv[1])
@@ -514,7 +592,9 @@ class _Gen:
             if n.op == "sum":
                 a = n.args[0]
                 roots.setdefault((id(a.dim), self.level[a.id]), []).append(a)
-        for key in self.stored:
+        for key, (how, _) in self.stored.items():
+            if how == "scalars":
+                continue
             node = by_id[key[1] if isinstance(key, tuple) else key]
             roots.setdefault((id(node.dim), self.level[node.id]), []).append(node)
         for _, g in self.out_vector:
@@ -535,10 +615,10 @@ class _Gen:
         emit("__device__ double nphip_density(const NphipData& data, int dim, const double* x, double* g, double* lds, const double* shared, int lane) {")
         # dimension lengths, data pointers (shared LDS where staged, else global), LDS scratch
         for d in m._dims.values():
-            emit(f"    const int n_{d.name} = {d.size if d.size is not None else 'data.n_' + d.runtime_len};")
+            emit(f"    const int n_{d.name} = {d.len_c()};")
         off_expr = "0"
         for name, kind, dim in shared_fields:
-            n_c = _field_len_c(name, dim)
+            n_c = _field_len_c(name, dim, m._matrix_cols.get(name, 1))
             if not m._staged:
                 emit(f"    const {'double' if kind == 'double' else 'int'}* __restrict__ D_{name} = data.{name};")
             elif kind == "double":
@@ -580,13 +660,21 @@ class _Gen:
                     if n.op != "const":
                         emit(f"    const double s{n.id} = {self.scalar_rhs(n)};")
                     done_scalar.add(n.id)
+            stacks = [n for n in self.order if n.op == "stack" and self.level[n.id] == lv]
+            if stacks:
+                emit("    if (lane == 0) {")
+                for n in stacks:
+                    for c, a_ in enumerate(n.args):
+                        emit(f"        {self.store_name[n.id]}[{c}] = {self.sref(a_)};")
+                emit("    }")
+                emit("    nphip_chain_barrier();")
             mark(f"scalars of level {lv}")
             # loops of this level, one per dimension that has something to produce here
             for d in m._dims.values():
                 sums = [n for n in self.order if n.op == "sum" and n.args[0].dim is d and self.level[n.args[0].id] == lv]
                 stores = []
                 for key, (how, sd) in self.stored.items():
-                    if sd is not d:
+                    if sd is not d or how == "scalars":
                         continue
                     node_id = key[1] if isinstance(key, tuple) else key
                     if self.level[node_id] == lv:
@@ -629,6 +717,13 @@ class _Gen:
             return f"data.{n.payload}"
         if n.op == "dimlen":
             return f"(double)n_{n.payload.name}"
+        if n.op == "elem":
+            v, c = n.args[0], n.payload
+            if v.op == "vparam":
+                return f"x[{v.payload[0] + c}]"
+            if v.op == "data":
+                return f"D_{v.payload}[{c}]"
+            return f"{self.store_name[v.id]}[{c}]"
         return _op_c(n.op, [self.sref(a) for a in n.args])
 
     # ---- one wave-wide loop
@@ -661,6 +756,11 @@ class _Gen:
                     stages[0].append(f"        const double {name} = " + (f"x[{off} + j_{u}];" if full else f"(j_{u} < {nv}) ? x[{off} + j_{u}] : 0.0;"))
                 elif n.op == "data":
                     stages[0].append(f"        const double {name} = D_{n.payload}[j_{u}];")
+                elif n.op == "datacol":
+                    mname, c, K = n.payload
+                    stages[0].append(f"        const double {name} = D_{mname}[j_{u} * {K} + {c}];")
+                elif n.op == "stack":
+                    stages[0].append(f"        const double {name} = {self.store_name[n.id]}[j_{u}];")
                 elif n.op == "gather":
                     src, index = n.args[0], n.payload
                     iname = f"k{index.name}_{u}"
@@ -737,8 +837,11 @@ class _Gen:
             mark(f"{len(ids)} sums" + (" + barrier" if stores else "") + f" after {d.name}, level {lv}")
 
 
-def _field_len_c(name: str, dim: Dim) -> str:
-    """C expression of the length of a data field (the ranges of a grouping have one more entry than the target dimension)"""
+def _field_len_c(name: str, dim: Dim, cols: int = 1) -> str:
+    """C expression of the length of a data field (the ranges of a grouping have one more entry than the target dimension; a
+    matrix has ``cols`` values per element)"""
+    if cols != 1:
+        return f"(n_{dim.name} * {cols})"
     return f"(n_{dim.name} + 1)" if name.endswith("__rows") else f"n_{dim.name}"
 
 
@@ -785,6 +888,7 @@ class Model:
         self._data: dict[str, Any] = {}
         self._data_fields: list[tuple[str, str, Dim | None]] = []   # (name, "double" | "int", dim) in declaration order
         self._indices: dict[str, Index] = {}
+        self._matrix_cols: dict[str, int] = {}       # matrix data: values per row
         self._terms: list[Expr] = []
         self._det: list[tuple[str, Expr]] = []
         self._staged = True
@@ -800,15 +904,31 @@ class Model:
             raise ValueError(f"dimension {name!r} has size {d.size}, not {size}")
         return d
 
-    def _data_dim(self, name: str, array_name: str, n: int) -> Dim:
+    def _data_dim(self, name: str, array_name: str, n: int, div: int = 1) -> Dim:
         d = self._dims.get(name)
         if d is None:
-            d = self._dims[name] = Dim(name, None, runtime_len=array_name)   # its length is that of its first data array
+            d = self._dims[name] = Dim(name, None, runtime_len=array_name, runtime_div=div)   # its length is that of its first data array
         elif d.size is not None and d.size != n:
             raise ValueError(f"data on dimension {name!r} must have length {d.size}")
-        elif d.size is None and len(self._data[d.runtime_len]) != n:
-            raise ValueError(f"data on dimension {name!r} must have length {len(self._data[d.runtime_len])}")
+        elif d.size is None and d.len_py(self._data) != n:
+            raise ValueError(f"data on dimension {name!r} must have length {d.len_py(self._data)}")
         return d
+
+    def matrix(self, name: str, values, dim: str, cols: str) -> Matrix:
+        """A float data matrix with one row per element of ``dim`` and one column per element of ``cols`` (a fixed-size dimension:
+        the coefficients'): ``X @ beta`` is the linear predictor.  ``with_data`` can replace it (same number of columns)."""
+        self._check_new_data(name)
+        a = np.ascontiguousarray(values, dtype=np.float64)
+        if a.ndim != 2:
+            raise ValueError("a matrix is two-dimensional")
+        cd = self.dim(cols, a.shape[1])
+        if cd.size is None or cd.size != a.shape[1]:
+            raise ValueError(f"matrix {name!r} needs {cd.size} columns")
+        self._data[name] = a.reshape(-1)
+        self._matrix_cols[name] = int(a.shape[1])
+        d = self._data_dim(dim, name, a.shape[0], div=int(a.shape[1]))
+        self._data_fields.append((name, "double", d))
+        return Matrix(name, d, cd)
 
     def param(self, name: str, dim: str | None = None, size: int | None = None, lower: float | None = None, zero_sum: bool = False) -> Expr:
         """A free parameter.  Scalar, or a vector over ``dim``.  ``lower``: the log transform ``value = lower + exp(raw)`` with its
@@ -937,10 +1057,10 @@ class Model:
             return "", fields
         L = ["__device__ void nphip_density_stage(const NphipData& data, double* shared, int thread, int n_threads) {"]
         for d in self._dims.values():
-            L.append(f"    const int n_{d.name} = {d.size if d.size is not None else 'data.n_' + d.runtime_len};")
+            L.append(f"    const int n_{d.name} = {d.len_c()};")
         L.append("    double* at = shared;")
         for name, kind, dim in fields:
-            n = _field_len_c(name, dim)
+            n = _field_len_c(name, dim, self._matrix_cols.get(name, 1))
             if kind == "double":
                 L.append(f"    for (int i = thread; i < {n}; i += n_threads) at[i] = data.{name}[i];")
                 L.append(f"    at += {n};")
@@ -1017,7 +1137,7 @@ class Model:
         stored_dims = [d for _, (_, d) in gen.stored.items()]
 
         def dim_len(d: Dim, data):
-            return d.size if d.size is not None else len(data[d.runtime_len])
+            return d.len_py(data)
 
         def lds_per_chain(data):
             return sum(dim_len(d, data) for d in stored_dims)
@@ -1033,7 +1153,7 @@ class Model:
         det = list(self._det)
         names = [n for n, _ in det]
         nodes = [e for _, e in det]
-        shapes = [() if e.dim is None else (e.dim.size if e.dim.size is not None else len(self._data[e.dim.runtime_len]),) for e in nodes]
+        shapes = [() if e.dim is None else (e.dim.len_py(self._data),) for e in nodes]
         auto_dims = {n: (e.dim.name,) for n, e in det if e.dim is not None}
         auto_coords = {d.name: np.arange(d.size) for d in dim_of.values() if d.size is not None and any(e.dim is d for e in nodes)}
 
@@ -1075,16 +1195,23 @@ def _symbolic_model_class():
             new = {**self._data}
             for k, v in updates.items():
                 kind = next(kd for n, kd, _ in f._data_fields if n == k)
+                if k in f._matrix_cols:
+                    a = np.ascontiguousarray(v, dtype=np.float64)
+                    if a.ndim != 2 or a.shape[1] != f._matrix_cols[k]:
+                        raise ValueError(f"matrix {k!r} must keep its {f._matrix_cols[k]} columns")
+                    new[k] = a.reshape(-1)
+                    continue
                 new[k] = float(v) if kind == "sdouble" else np.ascontiguousarray(v, dtype=np.int32 if kind == "int" else np.float64)
             for name in f._indices:
                 f._derive(name, new)
             # arrays of one dimension must keep a common length
             for d in f._dims.values():
                 if d.size is None:
-                    n = len(new[d.runtime_len])
+                    n = d.len_py(new)
                     for name, kind, dd in f._data_fields:
-                        if dd is d and kind in ("double", "int") and not name.endswith("__rows") and len(new[name]) != n:
-                            raise ValueError(f"data on dimension {d.name!r} must share one length ({name!r} has {len(new[name])}, {d.runtime_len!r} has {n})")
+                        rows = len(new[name]) // f._matrix_cols.get(name, 1) if kind in ("double", "int") else 0
+                        if dd is d and kind in ("double", "int") and not name.endswith("__rows") and rows != n:
+                            raise ValueError(f"data on dimension {d.name!r} must share one length ({name!r} has {rows}, {d.runtime_len!r} has {n})")
             return dataclasses.replace(self, _data=new)
 
         def logp_and_grad_numpy(self, x):

@@ -92,6 +92,47 @@ def poisson_offsets(seed=5, n_obs=300, n_site=40):
     return m
 
 
+def regression(seed=9, n_obs=400, n_coef=6, n_group=9):
+    """A design matrix: ``X @ beta`` with shrunken coefficients ``beta = raw * tau`` (the elements of a COMPUTED vector feed the
+    predictor), a group intercept, Normal likelihood."""
+    rng = np.random.default_rng(seed)
+    X = rng.normal(size=(n_obs, n_coef))
+    group = rng.integers(0, n_group, n_obs)
+    beta_true = np.array([1.0, -0.5, 0.0, 0.25, 0.0, 2.0])[:n_coef]
+    yy = X @ beta_true + 0.3 * rng.normal(size=n_group)[group] + 0.5 * rng.normal(size=n_obs)
+    m = S.Model()
+    m.dim("group", n_group)
+    tau = m.param("tau", lower=0.0)
+    raw = m.param("beta_raw", dim="coef", size=n_coef)
+    sg = m.param("sigma_group", lower=0.0)
+    a = m.param("a", dim="group")
+    sig = m.param("sigma", lower=0.0)
+    Xm = m.matrix("X", X, dim="obs", cols="coef")
+    y = m.data("y", yy, dim="obs")
+    gi = m.index("group_idx", group, dim="obs", into="group")
+    beta = raw * tau
+    m.deterministic("beta", beta)
+    m.add_logp(S.halfnormal_lpdf(tau, 1.0) + S.halfnormal_lpdf(sg, 1.0) + S.halfnormal_lpdf(sig, 1.0))
+    m.add_logp(S.normal_lpdf(raw, 0.0, 1.0).sum() + S.normal_lpdf(a, 0.0, sg).sum())
+    m.add_logp(S.normal_lpdf(y, Xm @ beta + a[gi], sig).sum())
+    return m
+
+
+def plain_regression(seed=4, n_obs=250, n_coef=3):
+    """``X @ beta`` with the coefficients read straight from the parameter vector."""
+    rng = np.random.default_rng(seed)
+    X = np.column_stack([np.ones(n_obs), rng.normal(size=(n_obs, n_coef - 1))])
+    yy = X @ np.array([0.5, 1.5, -1.0])[:n_coef] + 0.7 * rng.normal(size=n_obs)
+    m = S.Model()
+    beta = m.param("beta", dim="coef", size=n_coef)
+    sig = m.param("sigma", lower=0.0)
+    Xm = m.matrix("X", X, dim="obs", cols="coef")
+    y = m.data("y", yy, dim="obs")
+    m.add_logp(S.normal_lpdf(beta, 0.0, 5.0).sum() + S.halfnormal_lpdf(sig, 2.0))
+    m.add_logp(S.normal_lpdf(y, Xm @ beta, sig).sum())
+    return m
+
+
 def scalar_only():
     """No dimension at all: a banana in two scalars."""
     m = S.Model()
@@ -101,4 +142,5 @@ def scalar_only():
     return m
 
 
-ALL = {"radon": radon, "logistic": logistic, "poisson_offsets": poisson_offsets, "scalar_only": scalar_only}
+ALL = {"radon": radon, "logistic": logistic, "poisson_offsets": poisson_offsets, "scalar_only": scalar_only, "regression": regression,
+       "plain_regression": plain_regression}

@@ -101,3 +101,22 @@ def test_several_waves_per_chain(hip, waves):
     one = nutpie_amd.sample(front.compile(), chains=48, tune=150, draws=60, seed=9, progress_bar=False)
     # same model, same seed: the first draws agree to rounding (the trajectories drift apart later, as any two summation orders do)
     np.testing.assert_allclose(a.warmup_posterior.sigma.values[:, :3], one.warmup_posterior.sigma.values[:, :3], rtol=1e-6)
+
+
+def test_design_matrix_regression_recovers_its_coefficients(hip):
+    """``X @ beta`` (nutpie_amd.symbolic.Matrix): the predictor is a sum over the matrix's columns, the gradient with respect to the
+    coefficients one wave-wide sum per column; here the coefficients are a computed vector (raw * tau)."""
+    m = zoo.regression().compile()
+    tr = nutpie_amd.sample(m, chains=64, tune=300, draws=200, seed=4, progress_bar=False)
+    beta = tr.posterior.beta.values.reshape(-1, 6)
+    want = np.array([1.0, -0.5, 0.0, 0.25, 0.0, 2.0])
+    assert np.abs(beta.mean(0) - want).max() < 0.12, beta.mean(0)
+    assert abs(tr.posterior.sigma.values.mean() - 0.5) < 0.08 and tr.sample_stats.diverging.values.mean() < 0.03
+    # new rows, same library
+    rng = np.random.default_rng(8)
+    X2 = rng.normal(size=(150, 6))
+    y2 = X2 @ np.array([0.0, 0.0, 3.0, 0.0, 0.0, 0.0]) + 0.5 * rng.normal(size=150)
+    m2 = m.with_data(X=X2, y=y2, group_idx=rng.integers(0, 9, 150))
+    assert m2.library().path == m.library().path
+    tr2 = nutpie_amd.sample(m2, chains=64, tune=300, draws=200, seed=4, progress_bar=False)
+    assert abs(tr2.posterior.beta.values[..., 2].mean() - 3.0) < 0.2

@@ -120,3 +120,22 @@ def test_compiles_for_gfx950_and_swaps_data_without_recompiling(tmp_path, monkey
     out = compiled._expand_draws(x.reshape(1, 2, -1))
     np.testing.assert_allclose(out["tau"][0], np.exp(x[:, 1]))
     assert out["u"].shape == (1, 2, 40)
+
+
+def test_design_matrix_lowering():
+    """``X @ v``: one data column and one extracted element per term; the gradient with respect to a computed ``v`` comes back as
+    one vector written by the scalar code (stack), the one with respect to a parameter vector likewise"""
+    m = zoo.regression()
+    src, gen = m.generate()
+    kinds = [how for how, _ in gen.stored.values()]
+    assert kinds.count("scalars") == 1 and "D_X[j_0 * 6 + 5]" in src
+    compiled = m.compile()
+    X2 = np.random.default_rng(0).normal(size=(77, 6))
+    swapped = compiled.with_data(X=X2, y=np.zeros(77), group_idx=np.zeros(77, dtype=int))
+    assert swapped._lds()[1] < compiled._lds()[1] and len(swapped._data["X"]) == 77 * 6
+    with pytest.raises(ValueError, match="keep its 6 columns"):
+        compiled.with_data(X=X2[:, :3], y=np.zeros(77), group_idx=np.zeros(77, dtype=int))
+    with pytest.raises(ValueError, match="share one length"):
+        compiled.with_data(X=X2)
+    with pytest.raises(ValueError, match="multiplies a vector on dimension"):
+        _ = S.Matrix("X", m._dims["obs"], m._dims["coef"]) @ m._params[3]
