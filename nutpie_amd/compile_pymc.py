@@ -76,7 +76,14 @@ def from_raw_callback(n_dim: int, logp_address: int, user_data: int = 0, *, name
 
 def compile_pymc_model(model, *, backend="numba", gradient_backend="pytensor", initial_points=None, jitter_rvs=None,
                        default_initialization_strategy="support_point", var_names=None, freeze_model=None, **kwargs):
-    """Same keyword signature as the reference (compile_pymc.py:523-537)."""
+    """Same keyword signature as the reference (compile_pymc.py:523-537).  A :class:`nutpie_amd.symbolic.Model` — this package's own
+    model front-end — is compiled to its generated device density (``initial_points``: explicit start positions, ``[chains, n_dim]``);
+    a PyMC model needs PyMC and PyTensor, which the target image does not have."""
+    from nutpie_amd import symbolic
+
+    if isinstance(model, symbolic.Model):
+        extra = {k: kwargs[k] for k in ("resident", "waves_per_chain", "coords", "dims") if k in kwargs}
+        return model.compile(init="uniform" if initial_points is None else initial_points, **extra)
     if find_spec("pymc") is None:
         raise ImportError(
             "pymc is not installed in this environment.  Write the model with nutpie_amd.symbolic (expressions -> generated "

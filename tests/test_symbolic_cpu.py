@@ -139,3 +139,13 @@ def test_design_matrix_lowering():
         compiled.with_data(X=X2)
     with pytest.raises(ValueError, match="multiplies a vector on dimension"):
         _ = S.Matrix("X", m._dims["obs"], m._dims["coef"]) @ m._params[3]
+
+
+def test_compile_pymc_model_accepts_the_front_end(tmp_path, monkeypatch):
+    import nutpie_amd
+
+    m = zoo.scalar_only()
+    compiled = nutpie_amd.compile_pymc_model(m)
+    assert compiled.n_dim == 2 and list(compiled.shapes) == ["a", "b"]
+    with pytest.raises((ImportError, NotImplementedError)):
+        nutpie_amd.compile_pymc_model(object())
