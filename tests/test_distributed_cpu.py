@@ -117,3 +117,18 @@ def test_more_ranks_than_chains(tmp_path):
     full = oracle.sample_tridiag(oracle.default_settings(seed=5, num_chains=2, num_tune=20, num_draws=10), np.ones(4))
     assert np.array_equal(got["draws"], full.draws) and np.array_equal(got["n_steps"], full.stats["n_steps"])
     assert got["draw_mean"].shape == (2, 4)
+
+
+def test_eight_rank_layout_of_config_5(tmp_path):
+    """BASELINE.json config 5's layout at toy size: 8 ranks, contiguous blocks of chains (8192 = 8 x 1024 there, 24 = 8 x 3 here),
+    RNG streams keyed by the GLOBAL chain id, one gather of the thinned draws + statistics to rank 0, leapfrogs summed by an
+    all-reduce: the result is the single-process job, bit for bit."""
+    import oracle
+
+    out = str(tmp_path / "gathered8.npz")
+    mp.spawn(_worker, args=(8, _free_port(), 24, out), nprocs=8, join=True)
+    got = np.load(out)
+    full = oracle.sample_tridiag(oracle.default_settings(seed=77, num_chains=24, num_tune=40, num_draws=30), np.linspace(0.5, 2.0, 6))
+    assert np.array_equal(got["draws"], full.draws[:, ::2])
+    assert np.array_equal(got["n_steps"], full.stats["n_steps"]) and np.array_equal(got["diverging"], full.stats["diverging"])
+    assert got["total"][0] == full.stats["n_steps"].sum()
