@@ -40,8 +40,9 @@ from typing import Any
 
 import numpy as np
 
-__all__ = ["Model", "Expr", "exp", "log", "log1p", "sqrt", "softplus", "sigmoid", "where_lt", "normal_lpdf", "halfnormal_lpdf",
-           "student_t_lpdf", "bernoulli_logit_lpmf", "poisson_log_lpmf"]
+__all__ = ["Model", "Expr", "Matrix", "exp", "log", "log1p", "sqrt", "softplus", "sigmoid", "where_lt", "elem", "stack", "normal_lpdf",
+           "halfnormal_lpdf", "student_t_lpdf", "cauchy_lpdf", "halfcauchy_lpdf", "exponential_lpdf", "lognormal_lpdf", "gamma_lpdf",
+           "bernoulli_logit_lpmf", "poisson_log_lpmf"]
 
 _WAVE = 64
 _UNROLL = 4   # iterations of a loop whose reads are issued together (a lone wave waits out every access otherwise)
@@ -335,6 +336,40 @@ def student_t_lpdf(x, nu: float, mu, sigma) -> Expr:
     z = (x - mu) / sigma
     c = math.lgamma(0.5 * (nu + 1.0)) - math.lgamma(0.5 * nu) - 0.5 * math.log(nu * math.pi)
     return c - log(sigma) - (0.5 * (nu + 1.0)) * log1p((z * z) / nu)
+
+
+def cauchy_lpdf(x, mu, gamma) -> Expr:
+    x, mu, gamma = Expr.wrap(x), Expr.wrap(mu), Expr.wrap(gamma)
+    z = (x - mu) / gamma
+    return -math.log(math.pi) - log(gamma) - log1p(z * z)
+
+
+def halfcauchy_lpdf(x, gamma) -> Expr:
+    """x >= 0 (a ``lower=0`` parameter)."""
+    x, gamma = Expr.wrap(x), Expr.wrap(gamma)
+    z = x / gamma
+    return math.log(2.0 / math.pi) - log(gamma) - log1p(z * z)
+
+
+def exponential_lpdf(x, rate) -> Expr:
+    """x >= 0."""
+    x, rate = Expr.wrap(x), Expr.wrap(rate)
+    return log(rate) - rate * x
+
+
+def lognormal_lpdf(x, mu, sigma) -> Expr:
+    """x > 0."""
+    x, mu, sigma = Expr.wrap(x), Expr.wrap(mu), Expr.wrap(sigma)
+    lx = log(x)
+    z = (lx - mu) / sigma
+    return -0.5 * (z * z) - log(sigma) - lx - _HALF_LOG_2PI
+
+
+def gamma_lpdf(x, alpha: float, beta) -> Expr:
+    """x > 0; the shape ``alpha`` is a Python number (its log-gamma is folded on the host), the rate ``beta`` an expression."""
+    x, beta = Expr.wrap(x), Expr.wrap(beta)
+    alpha = float(alpha)
+    return alpha * log(beta) - math.lgamma(alpha) + (alpha - 1.0) * log(x) - beta * x
 
 
 def bernoulli_logit_lpmf(y, eta) -> Expr:
@@ -930,10 +965,25 @@ class Model:
         self._data_fields.append((name, "double", d))
         return Matrix(name, d, cd)
 
-    def param(self, name: str, dim: str | None = None, size: int | None = None, lower: float | None = None, zero_sum: bool = False) -> Expr:
-        """A free parameter.  Scalar, or a vector over ``dim``.  ``lower``: the log transform ``value = lower + exp(raw)`` with its
-        Jacobian added to the density (PyMC's default transform of positive variables); ``zero_sum``: the vector sums to zero
-        (``size - 1`` free values, PyMC's isometric ZeroSumTransform — no Jacobian term)."""
+    def _constrain(self, raw: Expr, lower, upper) -> tuple[Expr, Expr | None]:
+        """(value, log-Jacobian) of the default transforms: log (``lower`` only), logit-interval (both bounds)"""
+        if lower is None and upper is None:
+            return raw, None
+        if upper is None:
+            return (exp(raw) + lower if lower != 0.0 else exp(raw)), raw
+        if lower is None:
+            return upper - exp(raw), raw
+        if not upper > lower:
+            raise ValueError("upper must exceed lower")
+        width = float(upper) - float(lower)
+        # value = lower + width sigmoid(raw);  log |d value / d raw| = log width - softplus(raw) - softplus(-raw)
+        return sigmoid(raw) * width + lower, math.log(width) - softplus(raw) - softplus(-raw)
+
+    def param(self, name: str, dim: str | None = None, size: int | None = None, lower: float | None = None, upper: float | None = None,
+              zero_sum: bool = False) -> Expr:
+        """A free parameter.  Scalar, or a vector over ``dim``.  ``lower`` / ``upper``: PyMC's default transforms — ``lower + exp(raw)``,
+        ``upper - exp(raw)``, or ``lower + (upper - lower) sigmoid(raw)`` with both — with the log-Jacobian added to the density;
+        ``zero_sum``: the vector sums to zero (``size - 1`` free values, PyMC's isometric ZeroSumTransform — no Jacobian term)."""
         if name in self._param_names:
             raise ValueError(f"parameter {name!r} is defined twice")
         self._param_names.append(name)
@@ -943,10 +993,9 @@ class Model:
             self._n_dim += 1
             if zero_sum:
                 raise ValueError("zero_sum needs a vector parameter")
-            value = raw
-            if lower is not None:
-                self._terms.append(raw)
-                value = exp(raw) + lower if lower != 0.0 else exp(raw)
+            value, jac = self._constrain(raw, lower, upper)
+            if jac is not None:
+                self._terms.append(jac)
             self._det.append((name, value))
             return value
         d = self.dim(dim, size)
@@ -957,16 +1006,15 @@ class Model:
         self._params.append(raw)
         self._n_dim += n_free
         if zero_sum:
-            if lower is not None:
-                raise ValueError("zero_sum and lower exclude each other")
+            if lower is not None or upper is not None:
+                raise ValueError("zero_sum and bounds exclude each other")
             n = d.size
             s = raw.sum()            # (the padding element reads as 0)
             value = where_lt(d, n - 1, raw - s * (1.0 / (math.sqrt(n) + n)), -s * (1.0 / math.sqrt(n)))
-        elif lower is not None:
-            self._terms.append(raw.sum())
-            value = exp(raw) + lower if lower != 0.0 else exp(raw)
         else:
-            value = raw
+            value, jac = self._constrain(raw, lower, upper)
+            if jac is not None:
+                self._terms.append(jac.sum())
         self._det.append((name, value))
         return value
 

@@ -133,6 +133,27 @@ def plain_regression(seed=4, n_obs=250, n_coef=3):
     return m
 
 
+def eight_schools():
+    """The classic, non-centred: data on a parameter's own dimension, a HalfCauchy scale, an interval-bounded and an upper-bounded
+    nuisance parameter with their Jacobians, Cauchy / Gamma / Exponential / LogNormal terms."""
+    y = np.array([28.0, 8.0, -3.0, 7.0, -1.0, 1.0, 18.0, 12.0])
+    sd = np.array([15.0, 10.0, 16.0, 11.0, 9.0, 11.0, 10.0, 18.0])
+    m = S.Model()
+    mu = m.param("mu")
+    tau = m.param("tau", lower=0.0)
+    th = m.param("theta_raw", dim="school", size=8)
+    w = m.param("w", lower=-1.0, upper=3.0)
+    u = m.param("u", upper=2.0)
+    r = m.param("rates", dim="school", lower=0.5, upper=4.0)
+    yy = m.data("y", y, dim="school")
+    ss = m.data("sd", sd, dim="school")
+    m.add_logp(S.normal_lpdf(mu, 0.0, 5.0) + S.halfcauchy_lpdf(tau, 5.0) + S.normal_lpdf(th, 0.0, 1.0).sum())
+    m.add_logp(S.normal_lpdf(yy, mu + tau * th, ss).sum())
+    m.add_logp(S.cauchy_lpdf(w, 0.5, 1.5) + S.exponential_lpdf(2.0 - u, 0.7) + S.gamma_lpdf(r, 2.5, 1.3).sum() + S.lognormal_lpdf(r, 0.1 * w, 0.8).sum())
+    m.deterministic("theta", mu + tau * th)
+    return m
+
+
 def scalar_only():
     """No dimension at all: a banana in two scalars."""
     m = S.Model()
@@ -143,4 +164,4 @@ def scalar_only():
 
 
 ALL = {"radon": radon, "logistic": logistic, "poisson_offsets": poisson_offsets, "scalar_only": scalar_only, "regression": regression,
-       "plain_regression": plain_regression}
+       "plain_regression": plain_regression, "eight_schools": eight_schools}

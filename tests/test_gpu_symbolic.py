@@ -120,3 +120,15 @@ def test_design_matrix_regression_recovers_its_coefficients(hip):
     assert m2.library().path == m.library().path
     tr2 = nutpie_amd.sample(m2, chains=64, tune=300, draws=200, seed=4, progress_bar=False)
     assert abs(tr2.posterior.beta.values[..., 2].mean() - 3.0) < 0.2
+
+
+def test_eight_schools_through_the_front_end(hip):
+    """the classic (non-centred), with bounded nuisance parameters riding along: the known posterior of (mu, tau) and the bounds"""
+    m = zoo.eight_schools().compile()
+    tr = nutpie_amd.sample(m, chains=256, tune=400, draws=400, seed=12, progress_bar=False, target_accept=0.9)
+    mu, tau = tr.posterior.mu.values, tr.posterior.tau.values
+    assert 3.3 < mu.mean() < 5.5 and 2.6 < tau.mean() < 4.6, (mu.mean(), tau.mean())       # Gelman et al.: E mu ~ 4.4, E tau ~ 3.6
+    assert tr.posterior.theta.shape == (256, 400, 8) and abs(tr.posterior.theta.values[..., 0].mean() - 6.2) < 1.0
+    w, u, r = tr.posterior.w.values, tr.posterior.u.values, tr.posterior.rates.values
+    assert w.min() > -1.0 and w.max() < 3.0 and u.max() < 2.0 and r.min() > 0.5 and r.max() < 4.0
+    assert tr.sample_stats.diverging.values.mean() < 0.02
