@@ -238,7 +238,7 @@ struct Machine {
     LdsDouble dens_shared = nullptr;   // DENS: the workgroup's shared LDS (staged by nphip_density_stage at kernel start)
     LdsDouble dens_rows = nullptr;     // DENS: this wave's position row [ld] and gradient row [ld] in LDS (the leaf's evaluations)
     static constexpr int NVX = NV > 0 ? NV : 1;
-    static constexpr int NSX = NV < 0 ? -NV : 1;   // NV = -NS: cache (sigma^2, grad, p, rho) of NS chunks per wave
+    static constexpr int NSX = NV < -1 ? -NV : 1;   // NV = -NS (NS >= 2): cache (sigma^2, grad, p, rho) of NS chunks per wave
     // kernel arguments, read through the constant address space: s_load into SGPRs (uniform), never flat
     const NPHIP_CONST Args& A;
     LdsCtl c;        // this wave's private LDS copy
@@ -267,7 +267,7 @@ struct Machine {
         wave = (W == 1) ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
         D = a.dim; ld = a.ld; nch = ld / NPHIP_CHUNK;
         qp = a.qpool + (size_t)ch * a.nqpool * 2 * ld;
-        pp = a.pslots + (size_t)ch * a.npslots * (NV == 0 ? (size_t)a.pvec : (size_t)2) * ld;
+        pp = a.pslots + (size_t)ch * a.npslots * (NV == -1 ? (size_t)a.pvec : (size_t)2) * ld;
         sig2 = a.sig2 + (size_t)ch * ld;
         est = a.est + (size_t)ch * 8 * ld;
         T = a.s.num_tune + a.s.num_draws;
@@ -284,11 +284,15 @@ struct Machine {
     __device__ __forceinline__ double* Q(int64_t b) const { return qp + (size_t)b * 2 * ld; }
     __device__ __forceinline__ double* G(int64_t b) const { return qp + (size_t)b * 2 * ld + ld; }
     // vectors per P-slot: (p, rho), and with the low-rank metric (memory-resident kernels only) the velocity v = M^-1 p as well
-    __device__ __forceinline__ size_t pvec() const { return NV == 0 ? (size_t)A.pvec : (size_t)2; }
+    __device__ __forceinline__ size_t pvec() const { return NV == -1 ? (size_t)A.pvec : (size_t)2; }
     __device__ __forceinline__ double* P(int64_t s) const { return pp + (size_t)s * pvec() * ld; }
     __device__ __forceinline__ double* R(int64_t s) const { return pp + (size_t)s * pvec() * ld + ld; }
     __device__ __forceinline__ double* VEL(int64_t s) const { return pp + (size_t)s * pvec() * ld + 2 * ld; }
-    static constexpr bool LRK = NV == 0;   // kernels that can run the low-rank metric
+    // NV == -1: the memory-resident kernels WITH the low-rank metric — their own instantiations, so that the plain memory-resident
+    // kernels (NV == 0: every launch-per-evaluation callback job runs each of their paths once per launch) do not carry the code
+    // (measured: config 3 behind the device callback 13.7 -> 10.4 M leapfrogs/s with the low-rank branches compiled in, 29 against
+    // 18 us per launch)
+    static constexpr bool LRK = NV == -1;
     __device__ __forceinline__ bool lr_job() const { return LRK && A.lr_on != 0; }
     __device__ __forceinline__ const double* LRV(int j) const { return A.lr_V + ((size_t)chain * kLrMax + j) * ld; }
     __device__ __forceinline__ double* EST(int64_t e, int k) const { return est + (size_t)(e * 4 + k) * ld; }
@@ -313,6 +317,38 @@ struct Machine {
     __device__ __forceinline__ double sg1(int64_t i) const { return sig_lds ? sig_lds[i] : ld1(sig2, i); }
 
 #define NPHIP_FOR_CHUNKS(i) for (int64_t cc_ = wave, i = cc_ * NPHIP_CHUNK + 2 * lane; cc_ < nch; cc_ += W, i = cc_ * NPHIP_CHUNK + 2 * lane)
+    // The same walk U chunks at a time with the reads of all U issued before anything is computed or stored.  The plain loop above
+    // serialises on memory: the compiler cannot move the loads of chunk k+1 above the stores of chunk k (all vectors of a chain live
+    // in one pool), so a wave waits out one L2 / HBM round trip per chunk and pass — with one wave per chain at D = 1000 that was
+    // 148 us per launch of the callback kernel, four times the time its traffic takes.  Chunks are visited in the same order, so
+    // every (lane, component) accumulator sums in the same order: the same bits.
+    template <int U, class LoadT, class BodyT>
+    __device__ __forceinline__ void chunks_pf(LoadT load, BodyT body) const {
+        for (int64_t c0 = wave; c0 < nch; c0 += (int64_t)W * U) {
+            decltype(load((int64_t)0)) v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                int64_t cc = c0 + (int64_t)u * W;
+                cc = cc < nch ? cc : nch - 1;          // (past the end: the last chunk again, never used — unconditional reads stay in registers)
+                v[u] = load(cc * NPHIP_CHUNK + 2 * lane);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t cc = c0 + (int64_t)u * W;
+                if (cc < nch) body(cc * NPHIP_CHUNK + 2 * lane, v[u]);
+            }
+        }
+    }
+    // Used where one wave owns the whole row (W == 1: callbacks up to D = 1024, the launch-per-evaluation kernels); with several
+    // waves per chain the waves of a chain overlap each other's round trips and the extra code costs more than it saves (these
+    // kernels run every path once per launch: measured at D = 1000, 8 waves per chain, 84 -> 137 us per launch).
+    static constexpr bool BATCHED = (W == 1);
+    template <class LoadT, class BodyT>
+    __device__ __forceinline__ void chunks(LoadT load, BodyT body) const {
+        if (nch > 2) chunks_pf<4>(load, body);
+        else chunks_pf<2>(load, body);
+    }
+    struct V4 { double2 a, b, c, d; };
 
     // ------------------------------------------------------------------ scalar helpers
     __device__ void da_init(double step) {
@@ -549,17 +585,31 @@ struct Machine {
             if (FUSED) chain_sync<W>();
             return;
         }
-        NPHIP_FOR_CHUNKS(i) {
-            double2 q2 = ld2(q, i), g2 = ld2(g, i), p2 = ld2(p, i), s2 = ld2(sig2, i);
-            double2 ph, qq;
-            ph.x = fma(h, g2.x, p2.x);
-            ph.y = fma(h, g2.y, p2.y);
-            qq.x = fma(eps, s2.x * ph.x, q2.x);
-            qq.y = fma(eps, s2.y * ph.y, q2.y);
-            st2(qn, i, qq);
-            st2(pn, i, ph);
-            if (!FUSED) st2_dense(A.qeval + (size_t)chain * D, i, D, qq);
-        }
+        if (!BATCHED) {
+            NPHIP_FOR_CHUNKS(i) {
+                double2 q2 = ld2(q, i), g2 = ld2(g, i), p2 = ld2(p, i), s2 = ld2(sig2, i);
+                double2 ph, qq;
+                ph.x = fma(h, g2.x, p2.x);
+                ph.y = fma(h, g2.y, p2.y);
+                qq.x = fma(eps, s2.x * ph.x, q2.x);
+                qq.y = fma(eps, s2.y * ph.y, q2.y);
+                st2(qn, i, qq);
+                st2(pn, i, ph);
+                if (!FUSED) st2_dense(A.qeval + (size_t)chain * D, i, D, qq);
+            }
+        } else
+        chunks(
+            [&](int64_t i) { V4 v; v.a = ld2(q, i); v.b = ld2(g, i); v.c = ld2(p, i); v.d = ld2(sig2, i); return v; },
+            [&](int64_t i, const V4& v) {
+                double2 ph, qq;
+                ph.x = fma(h, v.b.x, v.c.x);
+                ph.y = fma(h, v.b.y, v.c.y);
+                qq.x = fma(eps, v.d.x * ph.x, v.a.x);
+                qq.y = fma(eps, v.d.y * ph.y, v.a.y);
+                st2(qn, i, qq);
+                st2(pn, i, ph);
+                if (!FUSED) st2_dense(A.qeval + (size_t)chain * D, i, D, qq);
+            });
         if (FUSED) chain_sync<W>();  // the fused model reads neighbouring elements of q'
     }
 
@@ -698,7 +748,7 @@ struct Machine {
     // z' = q' - mu of ONE element e (a chunk-edge neighbour owned by another lane / wave), from that element's own inputs.
     // The cached streaming kernel keeps no gradient in memory inside a tree (NOG): it is rebuilt from q (bit-identical to
     // the value computed when q was produced: same operations in the same order).
-    static constexpr bool NOG = FUSED && NV < 0;   // measured: pays with the VGPR cache (W = 1), costs 4-8 % at W = 8
+    static constexpr bool NOG = FUSED && NV < -1;   // measured: pays with the VGPR cache (W = 1), costs 4-8 % at W = 8
     __device__ __forceinline__ double elem_grad(const double* q, int64_t e) const {
         const double ze = ld1(q, e) - ld1(A.m_mu, e);
         double t = ld1(A.m_a, e) * ze;
@@ -742,7 +792,7 @@ struct Machine {
         const double *q = Q(srcq), *g = G(srcq), *p = P(srcp), *r = R(srcp);
         double *qn = Q(newq), *gn = G(newq), *pn = P(newp), *rn = R(newp);
         double2 accK = {0.0, 0.0}, accL = {0.0, 0.0}, accE = {0.0, 0.0}, accS = {0.0, 0.0};
-        if (NV < 0) {
+        if (NV < -1) {
             // fill the cache where the cursor moved (new doubling, rare path) — normally nothing to do
             if (!Y.sig_ok) {
 #pragma unroll
@@ -806,7 +856,7 @@ struct Machine {
             st2(qn, i, qq); st2(pn, i, pv); st2(rn, i, rr);
             if (!NOG) st2(gn, i, gg);
         };
-        if (NV < 0) {
+        if (NV < -1) {
             // the only state loads left: q of every chunk, issued back to back so
             // that they are all in flight together (chunks past the end re-read the last one; never used)
             double2 qv[NSX];
@@ -857,7 +907,7 @@ struct Machine {
             span_acc(xa.x, xra.x, xf.x, xrf.x, s2.x, acc[4].x, acc[5].x);
             span_acc(xa.y, xra.y, xf.y, xrf.y, s2.y, acc[4].y, acc[5].y);
         };
-        if (NV < 0 && Y.tag_p == sTL && Y.sig_ok) {   // T.last is the leaf just integrated: still in the cache
+        if (NV < -1 && Y.tag_p == sTL && Y.sig_ok) {   // T.last is the leaf just integrated: still in the cache
             // operands of two chunks (12 vectors) in flight at a time
 #pragma unroll
             for (int k0 = 0; k0 < NSX; k0 += 2) {
@@ -905,6 +955,24 @@ struct Machine {
         const double* sd = lrm ? A.lr_std + (size_t)chain * ld : nullptr;
         LrAcc S_;
         if (lrm) lr_zero(S_);
+        if (BATCHED && !FUSED && !lr_job()) {
+            const double* ge = A.geval + (size_t)chain * D;
+            chunks(
+                [&](int64_t i) { V4 v; v.a = ld2_dense(ge, i, D); v.b = ld2(pn, i); v.c = ld2(sig2, i); v.d = ld2(rp, i); return v; },
+                [&](int64_t i, const V4& v) {
+                    double2 pv, rr;
+                    pv.x = fma(h, v.a.x, v.b.x);
+                    pv.y = fma(h, v.a.y, v.b.y);
+                    const double vx = v.c.x * pv.x, vy = v.c.y * pv.y;
+                    accK.x = fma(pv.x, vx, accK.x);
+                    accK.y = fma(pv.y, vy, accK.y);
+                    rr.x = copy_rho ? pv.x : v.d.x + pv.x;
+                    rr.y = copy_rho ? pv.y : v.d.y + pv.y;
+                    st2(g, i, v.a);
+                    st2(pn, i, pv);
+                    st2(rn, i, rr);
+                });
+        } else
         NPHIP_FOR_CHUNKS(i) {
             double2 gg;
             if (FUSED) {
@@ -2138,6 +2206,22 @@ struct Machine {
         const double *ps = P(ss), *rs = R(ss), *pe = P(se), *re = R(se);
         const int mode = (a >= 0 && b >= 0) ? 0 : ((b >= 0 && a < 0) ? 1 : 2);
         double2 acc1 = {0.0, 0.0}, acc2 = {0.0, 0.0};
+        if (BATCHED && !lr_job()) {
+            struct V5 { double2 ps, rs, pe, re, s; };
+            chunks(
+                [&](int64_t i) { V5 v; v.ps = ld2(ps, i); v.rs = ld2(rs, i); v.pe = ld2(pe, i); v.re = ld2(re, i); v.s = sg2(i); return v; },
+                [&](int64_t, const V5& v) {
+                    double2 t, ve, vs;
+                    ve.x = v.s.x * v.pe.x; ve.y = v.s.y * v.pe.y; vs.x = v.s.x * v.ps.x; vs.y = v.s.y * v.ps.y;
+                    if (mode == 0) { t.x = (v.re.x - v.rs.x) + v.ps.x; t.y = (v.re.y - v.rs.y) + v.ps.y; }
+                    else if (mode == 1) { t.x = v.re.x + v.rs.x; t.y = v.re.y + v.rs.y; }
+                    else { t.x = (v.rs.x - v.re.x) + v.pe.x; t.y = (v.rs.y - v.re.y) + v.pe.y; }
+                    acc1.x = fma(t.x, ve.x, acc1.x);
+                    acc1.y = fma(t.y, ve.y, acc1.y);
+                    acc2.x = fma(t.x, vs.x, acc2.x);
+                    acc2.y = fma(t.y, vs.y, acc2.y);
+                });
+        } else
         NPHIP_FOR_CHUNKS(i) {
             double2 vps = ld2(ps, i), vrs = ld2(rs, i), vpe = ld2(pe, i), vre = ld2(re, i);
             double2 t, ve, vs;
@@ -2695,7 +2779,7 @@ struct Machine {
             bool rare = false, out_of_budget = false;
             int lean_end = 0;
             const LeanRs lrs = lean_rs();
-            if ((NV == 0 || LEAN) && sig_copy != nullptr) {
+            if ((NV == 0 || NV == -1 || LEAN) && sig_copy != nullptr) {
                 // stage sigma^2 in LDS: it only changes in the rare draw-end path
                 for (int64_t i = 2 * (int64_t)threadIdx.x; i < ld; i += 2 * (int64_t)blockDim.x)
                     *(NPHIP_LDS double2*)(sig_copy + i) = ld2(sig2, i);
@@ -2851,7 +2935,7 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) __attribute__((amdgpu_waves_
     }
     Machine<FUSED, W, NV, LEAN, REMOTE> m(A, c, (LdsDouble)s_red, chain, (LdsDouble)s_par, (LdsDouble)s_ring + (LEAN ? 0 : (size_t)wib * 4 * 128 * (NV > 0 ? NV : 1)),
                             (LdsDouble)s_edge);
-    m.run(max_evals, have_result != 0, (LEAN || (NV == 0 && W >= 8 && A.sig_lds)) ? (LdsDouble)s_dyn : nullptr, sl.materialise != 0);
+    m.run(max_evals, have_result != 0, (LEAN || ((NV == 0 || NV == -1) && W >= 8 && A.sig_lds)) ? (LdsDouble)s_dyn : nullptr, sl.materialise != 0);
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     if (W == 1 || wib == 0) {
         NPHIP_GLOBAL uint64_t* dst = (NPHIP_GLOBAL uint64_t*)(A.ctl + chain);
@@ -3050,6 +3134,14 @@ static hipError_t launch_mem_t(const Args& a, const Args* d_args, int W, hipStre
         // with more waves per chain (D > 1024) the cache costs occupancy or spills and does not pay; W == 1 only.
         hipLaunchKernelGGL((k_advance<true, 1, -8>), dim3((n + 3) / 4), dim3(256), 0, st, d_args, me, hr, sl);
         return hipGetLastError();
+    }
+    if (a.lr_on) switch (W) {   // the low-rank metric: the NV = -1 instantiations
+        case 1: hipLaunchKernelGGL((k_advance<FUSED, 1, -1>), dim3((n + 3) / 4), dim3(256), 0, st, d_args, me, hr, sl); return hipGetLastError();
+        case 2: hipLaunchKernelGGL((k_advance<FUSED, 2, -1>), dim3(n), dim3(128), 0, st, d_args, me, hr, sl); return hipGetLastError();
+        case 4: hipLaunchKernelGGL((k_advance<FUSED, 4, -1>), dim3(n), dim3(256), 0, st, d_args, me, hr, sl); return hipGetLastError();
+        case 8: hipLaunchKernelGGL((k_advance<FUSED, 8, -1>), dim3(n), dim3(512), a.sig_lds ? (size_t)a.ld * 8 : 0, st, d_args, me, hr, sl); return hipGetLastError();
+        case 16: hipLaunchKernelGGL((k_advance<FUSED, 16, -1>), dim3(n), dim3(1024), a.sig_lds ? (size_t)a.ld * 8 : 0, st, d_args, me, hr, sl); return hipGetLastError();
+        default: return hipErrorInvalidValue;
     }
     switch (W) {
         case 1: hipLaunchKernelGGL((k_advance<FUSED, 1, 0>), dim3((n + 3) / 4), dim3(256), 0, st, d_args, me, hr, sl); break;
@@ -3264,7 +3356,8 @@ int nphip_jit_logp(uint64_t n_chains, uint64_t dim, const double* q, double* gra
     if (!u) return -1;
     constexpr int CPB = NPHIP_JIT_W == 1 ? 4 : 1;
     const size_t own = (size_t)CPB * u->lds_doubles + u->shared_doubles, rows = (size_t)CPB * 2 * (((size_t)dim + 1) & ~(size_t)1);
-    const int rows_in_lds = (own + rows) * sizeof(double) <= 144 * 1024;
+    static const bool rows_global = getenv("NUTPIE_AMD_BATCH_ROWS_GLOBAL") != nullptr;   // (measurement switch)
+    const int rows_in_lds = !rows_global && (own + rows) * sizeof(double) <= 144 * 1024;
     hipLaunchKernelGGL(nphip::k_density_batch, dim3((unsigned)((n_chains + CPB - 1) / CPB)), dim3(NPHIP_JIT_W == 1 ? 256 : 64 * NPHIP_JIT_W),
                        (own + (rows_in_lds ? rows : 0)) * sizeof(double), (hipStream_t)stream,
                        (const NphipData*)u->data, n_chains, (int)dim, q, grad, logp, (int)u->lds_doubles, (int)u->shared_doubles, rows_in_lds);
