@@ -1170,11 +1170,36 @@ class Model:
                 del self._data["prof__"]
                 self._data_fields.pop()
 
-    def compile(self, *, init="uniform", resident: bool = True, coords=None, dims=None, waves_per_chain: int = 1):
+    #: LDS of a CU (bytes) and what the resident kernel itself takes of it: per wave of a workgroup a control block and a ring of
+    #: (p, rho) summaries (4 KB per chunk of 128 dimensions), per chain the position and gradient rows — nphip_model_jit_density
+    LDS_BYTES = 160 * 1024
+
+    def _lds_fits(self, gen, waves: int) -> bool:
+        nch = (self._n_dim + 127) // 128
+        nv = (nch + waves - 1) // waves
+        cpb, nwaves, ld = (4, 4, nv * 128) if waves == 1 else (1, waves, nv * 128 * waves)
+        fixed = nwaves * 1200 + 1024 + nwaves * nv * 4096 + 64 + 16 * waves * nv + cpb * 2 * ld * 8
+        per_chain = 8 * sum(d.len_py(self._data) for _, (_, d) in gen.stored.items())
+        shared = 8 * self._shared_doubles(self._data)
+        return fixed + cpb * per_chain + shared <= self.LDS_BYTES - 2048
+
+    def compile(self, *, init="uniform", resident: bool = True, coords=None, dims=None, waves_per_chain: int | None = None):
         """-> :class:`SymbolicModel` (a :class:`nutpie_amd.density.DensitySourceModel`).  ``waves_per_chain`` (1, 2, 4): wavefronts
-        that evaluate one chain's density together — more than one pays with fewer chains than the device has SIMDs (1024)."""
+        that evaluate one chain's density together — more than one pays with fewer chains than the device has SIMDs (1024), and a
+        workgroup then holds ONE chain instead of four, i.e. a quarter of the per-chain LDS: the default (None) is one wave per
+        chain unless the model's scratch (one double per observation and gathered value) only fits with more."""
         from nutpie_amd.density import from_density_source
 
+        if waves_per_chain is None:
+            for waves_per_chain in (1, 2, 4):
+                src, gen = self.generate(waves_per_chain)
+                if self._lds_fits(gen, waves_per_chain):
+                    break
+            else:
+                need = 8 * sum(d.len_py(self._data) for _, (_, d) in gen.stored.items())
+                raise ValueError(f"the model keeps {need} bytes of intermediate values per chain (one double per observation for every gathered "
+                                 f"term): more than a CU's LDS holds even with one chain per workgroup.  Fewer observations per model, "
+                                 f"or nutpie_amd.from_density_source with a density that keeps its scratch elsewhere")
         src, gen = self.generate(waves_per_chain)
         return self._finish(src, gen, init=init, resident=resident, coords=coords, dims=dims, waves_per_chain=waves_per_chain)
 

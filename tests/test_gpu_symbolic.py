@@ -132,3 +132,19 @@ def test_eight_schools_through_the_front_end(hip):
     w, u, r = tr.posterior.w.values, tr.posterior.u.values, tr.posterior.rates.values
     assert w.min() > -1.0 and w.max() < 3.0 and u.max() < 2.0 and r.min() > 0.5 and r.max() < 4.0
     assert tr.sample_stats.diverging.values.mean() < 0.02
+
+
+def test_a_model_too_large_for_four_chains_per_workgroup(hip):
+    """3000 observations: the per-chain scratch only fits with one chain per workgroup — compile() picks two waves per chain, the
+    data stay in global memory (too much to stage); same checks as the small model"""
+    from nutpie_amd.radon import synthetic_radon_data
+
+    m = zoo.radon(synthetic_radon_data(n_obs=3000)).compile()
+    assert m._waves == 2
+    x = 0.3 * np.random.default_rng(5).normal(size=(11, m.n_dim))
+    lp, g = m.logp_and_grad(x)
+    lp_ref, g_ref = m.logp_and_grad_numpy(x)
+    np.testing.assert_allclose(lp, lp_ref, rtol=1e-11, atol=1e-9)
+    np.testing.assert_allclose(g, g_ref, rtol=1e-9, atol=1e-8)
+    tr = nutpie_amd.sample(m, chains=64, tune=200, draws=100, seed=6, progress_bar=False)
+    assert abs(tr.posterior.sigma.values.mean() - 0.75) < 0.05 and tr.sample_stats.diverging.values.mean() < 0.02

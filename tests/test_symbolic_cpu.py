@@ -149,3 +149,16 @@ def test_compile_pymc_model_accepts_the_front_end(tmp_path, monkeypatch):
     assert compiled.n_dim == 2 and list(compiled.shapes) == ["a", "b"]
     with pytest.raises((ImportError, NotImplementedError)):
         nutpie_amd.compile_pymc_model(object())
+
+
+def test_waves_per_chain_follow_the_lds_the_model_needs():
+    """one wave per chain = four chains per workgroup = a quarter of the LDS each: a model with more observations gets one chain per
+    workgroup (two waves) by itself, and one that cannot fit says why"""
+    from nutpie_amd.radon import synthetic_radon_data
+
+    assert zoo.radon().compile()._waves == 1
+    big = zoo.radon(synthetic_radon_data(n_obs=3000)).compile()
+    assert big._waves == 2 and big._lds()[1] == 0            # (and its data are read through L2: too much to stage)
+    assert zoo.radon(synthetic_radon_data(n_obs=3000)).compile(waves_per_chain=4)._waves == 4
+    with pytest.raises(ValueError, match="more than a CU's LDS holds"):
+        zoo.radon(synthetic_radon_data(n_obs=40000)).compile()
