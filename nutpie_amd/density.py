@@ -129,6 +129,9 @@ def generated_source(user_source: str, layout) -> str:
         "// the same over ALL threads of the chain (waves_per_chain > 1: wave totals added in wave order through LDS; every thread gets the",
         "// same value), the number of threads that evaluate one chain's density, and the barrier between its phases",
         "#define NPHIP_CHAIN_THREADS (64 * NPHIP_JIT_W)",
+        "// which of the launch's resident chains this is (one wave per chain: four per workgroup) — the index of its block of",
+        "// data.scratch__ when the model asked for scratch in device memory (scratch_doubles_per_chain)",
+        "#define NPHIP_CHAIN_SLOT (NPHIP_JIT_W == 1 ? (int)(blockIdx.x * 4 + (threadIdx.x >> 6)) : (int)blockIdx.x)",
         "template <int N> static __device__ __forceinline__ void nphip_chain_sumN(double (&v)[N]) {",
         "    if (NPHIP_JIT_W == 1) { nphip::wave_sumN(v); return; }",
         "    __shared__ double red_[8 * NPHIP_JIT_W];",
@@ -204,14 +207,19 @@ class DensityLibrary:
 class DeviceData:
     """``NphipData`` in device memory: the arrays as torch tensors on the GPU, the block itself as a byte tensor."""
 
-    def __init__(self, data: dict[str, Any], layout, device: int):
+    def __init__(self, data: dict[str, Any], layout, device: int, device_arrays: dict[str, Any] | None = None):
         import torch
 
         dev = torch.device("cuda", device)
         self.tensors = {}
+        device_arrays = device_arrays or {}
         blob = b""
         for name, kind in layout:
-            if kind.endswith("*"):
+            if kind.endswith("*") and name in device_arrays:      # allocated on the device by the caller (scratch)
+                t = device_arrays[name]
+                self.tensors[name] = t
+                blob += struct.pack("<Q", t.data_ptr())
+            elif kind.endswith("*"):
                 a = np.ascontiguousarray(data[name], dtype=np.float64 if kind == "double*" else np.int32)
                 t = torch.as_tensor(a).to(dev) if a.size else torch.zeros(1, dtype=torch.float64 if kind == "double*" else torch.int32, device=dev)
                 self.tensors[name] = t
@@ -220,6 +228,8 @@ class DeviceData:
                 blob += struct.pack("<d", float(data[name]))
             elif name in data:
                 blob += struct.pack("<i", int(data[name]))
+            elif name[2:] in device_arrays:
+                blob += struct.pack("<i", int(min(device_arrays[name[2:]].numel(), 2**31 - 1)))
             else:   # n_<array>
                 blob += struct.pack("<i", int(np.asarray(data[name[2:]]).size))
         blob += b"\0" * ((-len(blob)) % 8 + 8)
@@ -246,6 +256,7 @@ class DensitySourceModel(CompiledModel):
     _init: Any = "uniform"
     _resident: bool = True                   # False: always the batched callback (launch per evaluation)
     _waves: int = 1                          # wavefronts that evaluate one chain's density together
+    _scratch: Any = 0                        # doubles of device-memory scratch per chain (int or function of the data): data.scratch__
 
     @property
     def n_dim(self):
@@ -277,6 +288,18 @@ class DensitySourceModel(CompiledModel):
         r = lambda v: int(v(self._data)) if callable(v) else int(v)  # noqa: E731
         return r(self._lds_bytes), r(self._shared_bytes)
 
+    def _device_data(self, n_chains: int, device: int) -> "DeviceData":
+        """the data block, with ``scratch__`` — one block per resident chain of a launch — allocated on the device when asked for"""
+        per = int(self._scratch(self._data)) if callable(self._scratch) else int(self._scratch)
+        if per <= 0:
+            return DeviceData(self._data, data_layout(self._data), device)
+        import torch
+
+        cpb = 4 if self._waves == 1 else 1
+        slots = (max(1, int(n_chains)) + cpb - 1) // cpb * cpb
+        scratch = torch.empty(slots * per, dtype=torch.float64, device=torch.device("cuda", device))
+        return DeviceData(self._data, data_layout(self._data), device, device_arrays={"scratch__": scratch})
+
     def library(self) -> DensityLibrary:
         return DensityLibrary(compile_density(self._source, data_layout(self._data), self._n_dim, waves=self._waves))
 
@@ -286,10 +309,10 @@ class DensitySourceModel(CompiledModel):
         import torch
 
         lib = self.library()
-        dd = DeviceData(self._data, data_layout(self._data), device)
         dev = torch.device("cuda", device)
         xt = torch.as_tensor(np.atleast_2d(np.asarray(x, dtype=np.float64))).to(dev).contiguous()
         N, D = xt.shape
+        dd = self._device_data(N, device)
         if D != self._n_dim:
             raise ValueError(f"positions have {D} columns, the model {self._n_dim} dimensions")
         g = torch.empty_like(xt)
@@ -308,7 +331,10 @@ class DensitySourceModel(CompiledModel):
 
     def _make_model(self, init_mean=None, settings=None, device: int = 0, resident: bool | None = None):
         lib = self.library()
-        dd = DeviceData(self._data, data_layout(self._data), device)
+        n_chains = int(getattr(settings, "num_chains", 0) or 0) if settings is not None else 0
+        if (callable(self._scratch) or self._scratch) and n_chains <= 0:
+            raise ValueError("a density with device-memory scratch needs the settings (num_chains) to size it")
+        dd = self._device_data(n_chains, device)
         use_resident = self._resident if resident is None else resident
         if settings is not None and (bool(getattr(settings, "store_divergences", False)) or getattr(settings, "_adaptation", "diag") == "low_rank"):
             use_resident = False   # the divergence record needs the pre-step state in memory
@@ -353,7 +379,8 @@ def _times8(v):
 
 def from_density_source(ndim: int, source: str, data: dict[str, Any] | None = None, *, lds_doubles_per_chain: int = 0, lds_doubles_shared: int = 0,
                         expand_fn: Callable | None = None, expanded_names: list[str] | None = None, expanded_shapes=None,
-                        coords=None, dims=None, init="uniform", resident: bool = True, reparameterized_names=None, waves_per_chain: int = 1) -> DensitySourceModel:
+                        coords=None, dims=None, init="uniform", resident: bool = True, reparameterized_names=None, waves_per_chain: int = 1,
+                        scratch_doubles_per_chain=0) -> DensitySourceModel:
     """A model from the HIP source of its log-density (module docstring): ``source`` defines ``nphip_density``; ``data`` are the
     arrays / scalars it reads through ``NphipData``; ``lds_doubles_per_chain`` the LDS scratch it uses per chain, ``lds_doubles_shared``
     the LDS its ``nphip_density_stage`` fills once per workgroup (each an int or a function of the data dict: ``with_data`` may
@@ -373,6 +400,14 @@ def from_density_source(ndim: int, source: str, data: dict[str, Any] | None = No
                          "const double* shared, int lane)`")
     if lds_doubles_shared and "nphip_density_stage" not in source:
         raise ValueError("lds_doubles_shared needs `__device__ void nphip_density_stage(const NphipData& data, double* shared, int thread, int n_threads)` in the source")
-    return DensitySourceModel(dims=dict(dims or {}), _source=source, _n_dim=int(ndim), _data=dict(data or {}), _lds_bytes=_times8(lds_doubles_per_chain), _shared_bytes=_times8(lds_doubles_shared),
+    data = dict(data or {})
+    if callable(scratch_doubles_per_chain) or scratch_doubles_per_chain:
+        # ``scratch_doubles_per_chain`` (int or function of the data): scratch in DEVICE memory for what does not fit the LDS — the
+        # source finds its block at ``(double*)data.scratch__ + (size_t)NPHIP_CHAIN_SLOT * <doubles per chain>``
+        if "scratch__" in data:
+            raise ValueError("the data field `scratch__` is reserved for the device-memory scratch")
+        data["scratch__"] = np.zeros(1)
+    return DensitySourceModel(dims=dict(dims or {}), _source=source, _n_dim=int(ndim), _data=data, _lds_bytes=_times8(lds_doubles_per_chain), _shared_bytes=_times8(lds_doubles_shared),
                               _names=list(expanded_names), _shapes=[tuple(s) for s in expanded_shapes], _coords=dict(coords or {}),
-                              _expand_func=expand_fn, _init=init, _resident=bool(resident), _waves=int(waves_per_chain), reparameterized_names=reparameterized_names)
+                              _expand_func=expand_fn, _init=init, _resident=bool(resident), _waves=int(waves_per_chain), _scratch=scratch_doubles_per_chain,
+                              reparameterized_names=reparameterized_names)

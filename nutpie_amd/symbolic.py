@@ -570,6 +570,7 @@ class _Gen:
         self.threads = _WAVE * waves
         self.profile = profile      # cycle counters per section, added into data.prof__ (Model.profile)
         self.sections: list[str] = []
+        self.spilled: list[Any] = []   # keys of `stored` that live in device memory (data.scratch__) instead of LDS: Model.compile decides
         self.logp = logp
         self.params = model._params
         # gradient outputs: scalars by lane 0 at the end; vectors in a loop over their dimension
@@ -664,10 +665,18 @@ class _Gen:
                 off_expr += f" + ({n_c} + 1) / 2"
         lds_off = "0"
         self.store_name: dict[Any, str] = {}
+        if self.spilled:   # this chain's block of the device-memory scratch: the arrays that do not fit the LDS
+            stride = " + ".join(f"(size_t)n_{self.stored[key][1].name}" for key in self.spilled)
+            emit(f"    double* const scratch_ = (double*)data.scratch__ + (size_t)NPHIP_CHAIN_SLOT * ({stride});")
+        g_off = "0"
         for k, (key, (_, dim)) in enumerate(self.stored.items()):
             self.store_name[key] = f"M{k}"
-            emit(f"    const auto M{k} = NPHIP_LDS_PTR(double, lds + ({lds_off}));")
-            lds_off += f" + n_{dim.name}"
+            if key in self.spilled:
+                emit(f"    double* const M{k} = scratch_ + ({g_off});")
+                g_off += f" + (size_t)n_{dim.name}"
+            else:
+                emit(f"    const auto M{k} = NPHIP_LDS_PTR(double, lds + ({lds_off}));")
+                lds_off += f" + n_{dim.name}"
         max_level = max(self.level.values(), default=0)
         done_scalar: set[int] = set()
         self.L = L
@@ -1174,14 +1183,27 @@ class Model:
     #: (p, rho) summaries (4 KB per chunk of 128 dimensions), per chain the position and gradient rows — nphip_model_jit_density
     LDS_BYTES = 160 * 1024
 
-    def _lds_fits(self, gen, waves: int) -> bool:
+    def _lds_budget(self, waves: int) -> int:
+        """bytes of LDS one chain may use for its scratch with ``waves`` waves per chain"""
         nch = (self._n_dim + 127) // 128
         nv = (nch + waves - 1) // waves
         cpb, nwaves, ld = (4, 4, nv * 128) if waves == 1 else (1, waves, nv * 128 * waves)
         fixed = nwaves * 1200 + 1024 + nwaves * nv * 4096 + 64 + 16 * waves * nv + cpb * 2 * ld * 8
-        per_chain = 8 * sum(d.len_py(self._data) for _, (_, d) in gen.stored.items())
         shared = 8 * self._shared_doubles(self._data)
-        return fixed + cpb * per_chain + shared <= self.LDS_BYTES - 2048
+        return (self.LDS_BYTES - 2048 - fixed - shared) // cpb
+
+    def _lds_fits(self, gen, waves: int) -> bool:
+        per_chain = 8 * sum(d.len_py(self._data) for key, (_, d) in gen.stored.items() if key not in gen.spilled)
+        return per_chain <= self._lds_budget(waves)
+
+    def _spill(self, gen, waves: int) -> None:
+        """move the largest stored arrays to device memory until the rest fits the LDS"""
+        by_size = sorted(gen.stored.items(), key=lambda kv: -kv[1][1].len_py(self._data))
+        for key, (how, d) in by_size:
+            if self._lds_fits(gen, waves):
+                return
+            if how != "scalars":       # (vectors assembled by the scalar code are tiny and written by one lane: they stay)
+                gen.spilled.append(key)
 
     def compile(self, *, init="uniform", resident: bool = True, coords=None, dims=None, waves_per_chain: int | None = None):
         """-> :class:`SymbolicModel` (a :class:`nutpie_amd.density.DensitySourceModel`).  ``waves_per_chain`` (1, 2, 4): wavefronts
@@ -1190,24 +1212,30 @@ class Model:
         chain unless the model's scratch (one double per observation and gathered value) only fits with more."""
         from nutpie_amd.density import from_density_source
 
+        logp = self.logp_expr()
+        grads = gradient(logp, self._params)
+        self._staged = 8 * self._shared_doubles_unconditional(self._data) <= self.STAGE_LIMIT
         if waves_per_chain is None:
             for waves_per_chain in (1, 2, 4):
-                src, gen = self.generate(waves_per_chain)
+                gen = _Gen(self, logp, grads, waves_per_chain)
                 if self._lds_fits(gen, waves_per_chain):
                     break
             else:
-                need = 8 * sum(d.len_py(self._data) for _, (_, d) in gen.stored.items())
-                raise ValueError(f"the model keeps {need} bytes of intermediate values per chain (one double per observation for every gathered "
-                                 f"term): more than a CU's LDS holds even with one chain per workgroup.  Fewer observations per model, "
-                                 f"or nutpie_amd.from_density_source with a density that keeps its scratch elsewhere")
-        src, gen = self.generate(waves_per_chain)
+                # not even one chain per workgroup holds it: four chains per workgroup again, the large arrays in device memory
+                waves_per_chain = 1
+                gen = _Gen(self, logp, grads, 1)
+        else:
+            gen = _Gen(self, logp, grads, waves_per_chain)
+        self._spill(gen, waves_per_chain)
+        src, _ = gen.source()
         return self._finish(src, gen, init=init, resident=resident, coords=coords, dims=dims, waves_per_chain=waves_per_chain)
 
     def _finish(self, src, gen, *, init="uniform", resident=True, coords=None, dims=None, waves_per_chain=1):
         from nutpie_amd.density import from_density_source
 
         dim_of = {k: d for k, d in self._dims.items()}
-        stored_dims = [d for _, (_, d) in gen.stored.items()]
+        stored_dims = [d for key, (_, d) in gen.stored.items() if key not in gen.spilled]
+        spilled_dims = [gen.stored[key][1] for key in gen.spilled]
 
         def dim_len(d: Dim, data):
             return d.len_py(data)
@@ -1234,7 +1262,12 @@ class Model:
             vals = evaluate(nodes, positions, data)
             return {n: v for n, v in zip(names, vals)}
 
-        base = from_density_source(self._n_dim, src, dict(self._data), lds_doubles_per_chain=lds_per_chain, lds_doubles_shared=lds_shared if staged else 0,
+        def scratch_per_chain(data):
+            return sum(dim_len(d, data) for d in spilled_dims)
+
+        data0 = {k: v for k, v in self._data.items() if k != "scratch__"}
+        base = from_density_source(self._n_dim, src, data0, lds_doubles_per_chain=lds_per_chain, lds_doubles_shared=lds_shared if staged else 0,
+                                   scratch_doubles_per_chain=scratch_per_chain if spilled_dims else 0,
                                    expand_fn=expand, expanded_names=names, expanded_shapes=shapes, coords={**auto_coords, **(coords or {})},
                                    dims={**auto_dims, **(dims or {})}, init=init, resident=resident, waves_per_chain=waves_per_chain)
         import dataclasses

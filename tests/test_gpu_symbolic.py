@@ -148,3 +148,22 @@ def test_a_model_too_large_for_four_chains_per_workgroup(hip):
     np.testing.assert_allclose(g, g_ref, rtol=1e-9, atol=1e-8)
     tr = nutpie_amd.sample(m, chains=64, tune=200, draws=100, seed=6, progress_bar=False)
     assert abs(tr.posterior.sigma.values.mean() - 0.75) < 0.05 and tr.sample_stats.diverging.values.mean() < 0.02
+
+
+def test_intermediate_arrays_in_device_memory(hip):
+    """40 000 observations: 640 KB of adjoints per chain — the generated density keeps them in device memory (one block per resident
+    chain, data.scratch__), everything else as before; resident and batched forms of the library draw the same"""
+    from nutpie_amd.radon import synthetic_radon_data
+
+    front = zoo.radon(synthetic_radon_data(n_obs=40000))
+    m = front.compile()
+    assert m._waves == 1 and m._scratch(m._data) == 80000
+    x = 0.2 * np.random.default_rng(5).normal(size=(9, m.n_dim))
+    lp, g = m.logp_and_grad(x)
+    lp_ref, g_ref = m.logp_and_grad_numpy(x)
+    np.testing.assert_allclose(lp, lp_ref, rtol=1e-11, atol=1e-8)
+    np.testing.assert_allclose(g, g_ref, rtol=1e-9, atol=1e-7)
+    a = nutpie_amd.sample(m, chains=24, tune=100, draws=40, seed=6, progress_bar=False)
+    b = nutpie_amd.sample(front.compile(resident=False), chains=24, tune=100, draws=40, seed=6, progress_bar=False)
+    assert np.array_equal(a.posterior.sigma.values, b.posterior.sigma.values)
+    assert abs(a.posterior.sigma.values.mean() - 0.75) < 0.03

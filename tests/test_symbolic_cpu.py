@@ -153,12 +153,15 @@ def test_compile_pymc_model_accepts_the_front_end(tmp_path, monkeypatch):
 
 def test_waves_per_chain_follow_the_lds_the_model_needs():
     """one wave per chain = four chains per workgroup = a quarter of the LDS each: a model with more observations gets one chain per
-    workgroup (two waves) by itself, and one that cannot fit says why"""
+    workgroup (two waves) by itself, and one that cannot fit even so keeps its large arrays in device memory"""
     from nutpie_amd.radon import synthetic_radon_data
 
     assert zoo.radon().compile()._waves == 1
     big = zoo.radon(synthetic_radon_data(n_obs=3000)).compile()
     assert big._waves == 2 and big._lds()[1] == 0            # (and its data are read through L2: too much to stage)
     assert zoo.radon(synthetic_radon_data(n_obs=3000)).compile(waves_per_chain=4)._waves == 4
-    with pytest.raises(ValueError, match="more than a CU's LDS holds"):
-        zoo.radon(synthetic_radon_data(n_obs=40000)).compile()
+    # nothing fits: four chains per workgroup again, the two observation-sized arrays of adjoints in device memory (data.scratch__)
+    huge = zoo.radon(synthetic_radon_data(n_obs=40000)).compile()
+    assert huge._waves == 1 and huge._scratch(huge._data) == 80000 and "NPHIP_CHAIN_SLOT" in huge._source
+    assert huge._lds()[0] < 4096 and huge.with_data(y=np.zeros(10), floor=np.zeros(10), county=np.zeros(10, dtype=int))._scratch(
+        {"y": np.zeros(10)}) == 20
