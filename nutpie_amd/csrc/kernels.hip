@@ -3356,8 +3356,7 @@ int nphip_jit_logp(uint64_t n_chains, uint64_t dim, const double* q, double* gra
     if (!u) return -1;
     constexpr int CPB = NPHIP_JIT_W == 1 ? 4 : 1;
     const size_t own = (size_t)CPB * u->lds_doubles + u->shared_doubles, rows = (size_t)CPB * 2 * (((size_t)dim + 1) & ~(size_t)1);
-    static const bool rows_global = getenv("NUTPIE_AMD_BATCH_ROWS_GLOBAL") != nullptr;   // (measurement switch)
-    const int rows_in_lds = !rows_global && (own + rows) * sizeof(double) <= 144 * 1024;
+    const int rows_in_lds = (own + rows) * sizeof(double) <= 144 * 1024;
     hipLaunchKernelGGL(nphip::k_density_batch, dim3((unsigned)((n_chains + CPB - 1) / CPB)), dim3(NPHIP_JIT_W == 1 ? 256 : 64 * NPHIP_JIT_W),
                        (own + (rows_in_lds ? rows : 0)) * sizeof(double), (hipStream_t)stream,
                        (const NphipData*)u->data, n_chains, (int)dim, q, grad, logp, (int)u->lds_doubles, (int)u->shared_doubles, rows_in_lds);
