@@ -154,6 +154,35 @@ def eight_schools():
     return m
 
 
+def nested(seed=21, n_obs=350, n_group=12, n_region=4):
+    """Three levels: observations in groups in regions.  The region effect reaches the observations through TWO gathers
+    (region -> group -> observation), so its gradient is a segment sum of a segment sum; one parameter is used both directly and
+    through a gather."""
+    rng = np.random.default_rng(seed)
+    region_of_group = rng.integers(0, n_region, n_group)
+    group = rng.integers(0, n_group, n_obs)
+    yy = 0.5 + 0.8 * rng.normal(size=n_region)[region_of_group][group] + 0.4 * rng.normal(size=n_group)[group] + 0.6 * rng.normal(size=n_obs)
+    m = S.Model()
+    m.dim("region", n_region)
+    m.dim("group", n_group)
+    mu = m.param("mu")
+    sr = m.param("sigma_region", lower=0.0)
+    sg = m.param("sigma_group", lower=0.0)
+    sig = m.param("sigma", lower=0.0)
+    r = m.param("region_raw", dim="region")
+    g = m.param("group_raw", dim="group")
+    y = m.data("y", yy, dim="obs")
+    rg = m.index("region_of_group", region_of_group, dim="group", into="region")
+    gi = m.index("group_idx", group, dim="obs", into="group")
+    group_effect = (r * sr)[rg] + g * sg            # on "group"
+    m.deterministic("group_effect", group_effect)
+    m.add_logp(S.normal_lpdf(mu, 0.0, 3.0) + S.halfnormal_lpdf(sr, 1.0) + S.halfnormal_lpdf(sg, 1.0) + S.halfnormal_lpdf(sig, 1.0))
+    m.add_logp(S.normal_lpdf(r, 0.0, 1.0).sum() + S.normal_lpdf(g, 0.0, 1.0).sum())
+    m.add_logp(S.normal_lpdf(y, mu + group_effect[gi], sig).sum())
+    m.add_logp((-0.01 * (g * g)).sum())             # (the same parameter once more, directly)
+    return m
+
+
 def scalar_only():
     """No dimension at all: a banana in two scalars."""
     m = S.Model()
@@ -164,4 +193,4 @@ def scalar_only():
 
 
 ALL = {"radon": radon, "logistic": logistic, "poisson_offsets": poisson_offsets, "scalar_only": scalar_only, "regression": regression,
-       "plain_regression": plain_regression, "eight_schools": eight_schools}
+       "plain_regression": plain_regression, "eight_schools": eight_schools, "nested": nested}
