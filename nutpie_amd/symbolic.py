@@ -619,6 +619,28 @@ class _Gen:
         for nid, levels in evaluated.items():
             if len(levels) > 1:
                 self.stored[nid] = ("plain", by_id[nid].dim)
+        # Parameter vectors on a dimension short enough for ONE trip of its loops (size <= threads x unroll): every loop over the
+        # dimension reads the same elements in the same lanes, so they are read once, before the first loop (a read of x[] at the
+        # head of a loop is a round trip nothing else hides).
+        self.hoisted: set[int] = set()
+        reads: dict[int, set[tuple[int, int]]] = {}
+        for key, roots in self.loop_roots().items():
+            seen: set[int] = set()
+            stack = list(roots)
+            while stack:
+                n = stack.pop()
+                if n.dim is None or n.id in seen:
+                    continue
+                seen.add(n.id)
+                if n.op == "vparam":
+                    reads.setdefault(n.id, set()).add(key)
+                if n.op in ("stack", "gather", "segsum") or (n.id in self.stored and self.level[n.id] < key[1]):
+                    continue
+                stack.extend(n.args)
+        for nid, loops in reads.items():
+            d = by_id[nid].dim
+            if len(loops) > 1 and d.size is not None and d.size <= self.threads * _UNROLL:
+                self.hoisted.add(nid)
 
     def loop_roots(self) -> dict[tuple[int, int], list[Expr]]:
         """(id of the dimension, level) -> the nodes the loop has to produce: arguments of sums, stored values, gradient rows"""
@@ -677,6 +699,14 @@ class _Gen:
             else:
                 emit(f"    const auto M{k} = NPHIP_LDS_PTR(double, lds + ({lds_off}));")
                 lds_off += f" + n_{dim.name}"
+        by_id_ = {n.id: n for n in self.order}
+        for nid in sorted(self.hoisted):
+            n = by_id_[nid]
+            off, nv = n.payload
+            U = max(1, min(_UNROLL, -(-n.dim.size // self.threads)))
+            for u in range(U):
+                idx = f"(lane + {self.threads * u})"
+                emit(f"    const double H{nid}_{u} = ({idx} < {nv}) ? x[{off} + {idx}] : 0.0;")
         max_level = max(self.level.values(), default=0)
         done_scalar: set[int] = set()
         self.L = L
@@ -794,6 +824,8 @@ class _Gen:
                 name = f"v{n.id}_{u}"
                 if n.id in self.stored and self.level[n.id] < lv:
                     stages[0].append(f"        const double {name} = {self.store_name[n.id]}[j_{u}];")
+                elif n.op == "vparam" and n.id in self.hoisted:
+                    name = f"H{n.id}_{u}"       # (read before the first loop; lanes past the end hold 0 and are never used)
                 elif n.op == "vparam":
                     off, nv = n.payload
                     full = d.size is not None and nv == d.size
