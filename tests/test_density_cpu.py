@@ -55,3 +55,19 @@ def test_density_library_cross_compiles_and_exports_its_entry_points(tmp_path, m
     assert lib.nphip_jit_nv() == 2            # 173 dimensions: two chunks of 128
     with pytest.raises(RuntimeError, match="compiling the density failed"):
         density.compile_density("__device__ double nphip_density(const NphipData& d, int dim, const double* x, double* g, double* l, const double* sh, int lane) { return nope; }", [], 2)
+
+
+def test_device_memory_scratch_is_a_field_of_the_data_block():
+    """``scratch_doubles_per_chain``: the data block carries ``scratch__`` (allocated on the device when a sampler is created, one block
+    per resident chain of a launch); the name is reserved"""
+    from nutpie_amd import density
+
+    src = "__device__ double nphip_density(const NphipData& d, int dim, const double* x, double* g, double* l, const double* sh, int lane) { return 0.0; }"
+    m = density.from_density_source(3, src, {"y": np.zeros(5)}, scratch_doubles_per_chain=lambda d: 2 * len(d["y"]))
+    layout = density.data_layout(m._data)
+    assert ("scratch__", "double*") in layout and ("n_scratch__", "int") in layout
+    assert "const double* scratch__;" in density.struct_source(layout) and "NPHIP_CHAIN_SLOT" in density.generated_source(src, layout)
+    assert m._scratch(m.with_data(y=np.zeros(9))._data) == 18
+    with pytest.raises(ValueError, match="reserved"):
+        density.from_density_source(3, src, {"scratch__": np.zeros(2)}, scratch_doubles_per_chain=4)
+    assert "scratch__" not in density.from_density_source(3, src, {"y": np.zeros(5)})._data
