@@ -21,12 +21,19 @@ schedules logp and gradient together into wave-wide loops — one wavefront eval
 the elements of a *dimension* (a coordinate of the model: counties, observations) —, and prints the HIP device function
 ``nphip_density`` that :func:`nutpie_amd.from_density_source` compiles into the engine's resident NUTS kernel.
 
+Also: ``m.matrix("X", values, dim="obs", cols="coef")`` and ``X @ beta`` (a design matrix: lowered to a sum over its columns, the
+transposed product to one wave-wide sum per column); ``lower=`` / ``upper=`` / both (log and logit-interval transforms with their
+Jacobians); densities ``normal``, ``halfnormal``, ``student_t``, ``cauchy``, ``halfcauchy``, ``exponential``, ``lognormal``, ``gamma``,
+``bernoulli_logit``, ``poisson_log``; ``compile(waves_per_chain=...)`` (default: from the LDS the model needs); ``Model.profile()``
+(cycle attribution of the generated code on the GPU).
+
 The IR has five kinds of nodes: scalars; element-wise values over a dimension; ``Sum`` (dimension -> scalar);
 ``Gather`` (``v[idx]``: dimension A -> dimension B through an integer data array); ``SegSum`` (its transpose: for every
 element of A the sum over the elements of B that point to it).  The transpose of a gather is evaluated without atomics and
 in a fixed order: the adjoints are stored in LDS *grouped by target* (the host computes the grouping permutation once per
 data set) and every lane sums a contiguous range.  Values a later loop needs from an earlier one (gather sources, adjoints)
-live in per-chain LDS; the model's data are staged into the workgroup's shared LDS once per launch.  Everything else is
+live in per-chain LDS (the largest of them in device memory when the LDS is too small: models with tens of thousands of
+observations); the model's data are staged into the workgroup's shared LDS once per launch while they fit.  Everything else is
 recomputed where it is used.
 
 Only the log-density is generated code.  ``deterministic`` values (the reference's expand step: ``compile_pymc.py:601-666``)
