@@ -165,3 +165,13 @@ def test_waves_per_chain_follow_the_lds_the_model_needs():
     assert huge._waves == 1 and huge._scratch(huge._data) == 80000 and "NPHIP_CHAIN_SLOT" in huge._source
     assert huge._lds()[0] < 4096 and huge.with_data(y=np.zeros(10), floor=np.zeros(10), county=np.zeros(10, dtype=int))._scratch(
         {"y": np.zeros(10)}) == 20
+
+
+@pytest.mark.parametrize("name,waves", [("nested", 2), ("regression", 4)])
+def test_multi_wave_sources_cross_compile(name, waves):
+    """the generated source with several waves per chain (chain-wide sums and barriers) builds for gfx950"""
+    from nutpie_amd.density import compile_density, data_layout
+
+    m = zoo.ALL[name]().compile(waves_per_chain=waves)
+    assert m._waves == waves and "nphip_chain_barrier" in m._source
+    assert os.path.exists(compile_density(m._source, data_layout(m._data), m.n_dim, waves=waves))
