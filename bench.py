@@ -38,6 +38,17 @@ Extra objects in the JSON line:
                   ESS over a subset of dimensions and ESS/s (the second half of BASELINE.json's metric).
   ranks         — world size, backend, and per rank: device, leapfrogs and kernel time of the timed region (N > 1: what a
                   scaling record is checked against).
+  config5_shard — BASELINE.json configs[4]'s per-GPU shard on every rank (10 000 dimensions x 1024 chains, lean kernel): a
+                  timed region of >= 10 launches in the sampling phase with its own `roofline` (bound "hbm"), then the
+                  job runs to its end and its trace goes to rank 0 in ONE gather (nutpie_amd.distributed.gather_trace:
+                  draws thinned on the device + per-chain moments + statistics) — seconds, bytes, ranks of the collective.
+  other_configs — (N = 1) bounded runs of the remaining BASELINE.json configs on this GPU: config 3 (radon, 512 chains) with
+                  the generated density and with the torch density, config 4 (eight schools, 256 chains, host C callback),
+                  config 2 (ii) (dense Gaussian, gradient = fp64 GEMM behind the device callback).
+
+Launching: under torch.distributed.run (RANK in the environment) this process is one rank.  WITHOUT it, `--gpus N` with
+N > 1 re-executes itself under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`,
+one rank per GPU, and fails loudly when fewer than N GPUs are visible.
 """
 from __future__ import annotations
 
@@ -65,7 +76,7 @@ CYCLES_PER_ISSUE = 4.0
 TRAFFIC_JSON = os.path.join(ROOT, "profiles", "traffic.json")
 
 
-def parse():
+def parse(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=0, help="timed launches; 0 = enough for a timed region of about 1.2 s")
@@ -80,7 +91,13 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-job", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
-    return p.parse_args()
+    p.add_argument("--no-other-configs", action="store_true", help="skip the bounded runs of configs 3, 4, 2 (ii) (N = 1)")
+    p.add_argument("--no-config5", action="store_true", help="skip the config-5 shard leg (10 000 dimensions, roofline + trace gather)")
+    p.add_argument("--config5-dim", type=int, default=10000)
+    p.add_argument("--config5-launches", type=int, default=10)
+    p.add_argument("--engine-stub", default="", help="TEST PLUMBING ONLY: path of a module that stands in for nutpie_amd._lib (no GPU, gloo); "
+                   "the line it prints is marked stub and measures nothing")
+    return p.parse_args(argv)
 
 
 def total_leapfrogs(smp):
@@ -142,12 +159,12 @@ def cpu_baseline(model, seed, target_seconds):
     }
 
 
-def run_job(hip, model, args, device, chain_offset, dims_for_ess):
+def run_job(hip, model, args, device, chain_offset, dims_for_ess, world=1):
     """The complete job: tune 400 + draws 1000 on this GPU's chains; returns wall seconds, leapfrogs, ESS."""
     from nutpie_amd.ess import ess_bulk
 
     s = hip.PyNutsSettings.Diag(args.seed)
-    s.update(num_tune=400, num_draws=1000, num_chains=args.chains * args.gpus)
+    s.update(num_tune=400, num_draws=1000, num_chains=args.chains * world)
     m = hip.TridiagGaussianModel(model.diag, model.offdiag)
     t0 = time.perf_counter()
     smp = hip.PySampler(s, m, device=device, waves_per_chain=args.waves, chain_offset=chain_offset, n_local_chains=args.chains)
@@ -244,28 +261,308 @@ def kernel_name(dim, W):
     return f"k_advance<fused,W={W},NV=0>"
 
 
-def main():
-    args = parse()
-    import torch
+def free_port():
+    import socket
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if "RANK" in os.environ:  # launched by torch.distributed.run (also with a single rank: same code path)
-        import torch.distributed as dist
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
 
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
-    device = local_rank if dist is not None else 0
-    torch.cuda.set_device(device)
 
-    from nutpie_amd import _lib as hip
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks ourselves, one per GPU of this node."""
+    import subprocess
+
+    if not args.engine_stub:
+        import torch
+
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible on this node — refusing to run fewer ranks than asked for")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__), *argv]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.run(cmd, env=env).returncode
+
+
+class Env:
+    """What differs between a real run (GPU, RCCL) and the stub used by the CPU plumbing test (no device, gloo)."""
+
+    def __init__(self, args):
+        import torch
+
+        self.torch = torch
+        self.stub = bool(args.engine_stub)
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.dist = None
+        if "RANK" in os.environ and self.world != args.gpus:
+            raise SystemExit(f"bench.py: launched with WORLD_SIZE={self.world} but --gpus {args.gpus}: they must agree")
+        if not self.stub:
+            if not torch.cuda.is_available():
+                raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
+            if torch.cuda.device_count() <= self.local_rank:
+                raise SystemExit(f"bench.py: rank {self.rank} wants GPU {self.local_rank}, but only {torch.cuda.device_count()} are visible")
+            torch.cuda.set_device(self.local_rank)
+        self.device = self.local_rank if "RANK" in os.environ else 0
+        if "RANK" in os.environ:  # launched by torch.distributed.run (also with a single rank: same code path)
+            import torch.distributed as dist
+
+            if self.stub:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+            self.dist = dist
+        if self.stub:
+            import importlib.util
+
+            spec = importlib.util.spec_from_file_location("bench_engine_stub", args.engine_stub)
+            self.hip = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(self.hip)
+        else:
+            from nutpie_amd import _lib as hip
+
+            hip.lib()
+            self.hip = hip
+
+    def ensure_group(self):
+        """A process group for the gather leg also when bench.py runs as a plain single process (one-rank RCCL)."""
+        if self.dist is None:
+            import torch.distributed as dist
+
+            if self.stub:
+                dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{free_port()}", rank=0, world_size=1)
+            else:
+                dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{free_port()}", rank=0, world_size=1,
+                                        device_id=self.torch.device("cuda", self.device))
+            self.dist = dist
+        return self.dist
+
+    def sync(self):
+        if not self.stub:
+            self.torch.cuda.synchronize()
+
+    def barrier(self):
+        self.sync()
+        if self.dist is not None:
+            self.dist.barrier()
+            self.sync()
+
+    def tensor(self, values):
+        return self.torch.tensor(values, dtype=self.torch.float64, device="cpu" if self.stub else "cuda")
+
+    def all_max(self, x):
+        if self.dist is None:
+            return float(x)
+        t = self.tensor([x])
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def all_sum(self, values):
+        if self.dist is None:
+            return [float(v) for v in values]
+        t = self.tensor(list(values))
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return [float(v) for v in t.tolist()]
+
+    def all_rows(self, row):
+        """Every rank's row (a list of floats), in rank order."""
+        if self.dist is None:
+            return [list(map(float, row))]
+        mine = self.tensor(list(row))
+        allr = [self.torch.zeros_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(allr, mine)
+        return [t.tolist() for t in allr]
+
+
+class InvalidRegion(RuntimeError):
+    pass
+
+
+def warm_up_to_sampling(smp, batch=10):
+    """Advance every chain through its warm-up (manual mode).  Returns (leapfrogs, launches, kernel ms, wall s)."""
+    t0 = time.perf_counter()
+    n0 = total_leapfrogs(smp)
+    launches, kms = 0, 0.0
+    while True:
+        done, l, ms = smp.step(batch)
+        launches += l
+        kms += ms
+        if done:
+            raise InvalidRegion("bench.py: chains finished during warm-up; increase the number of draws")
+        if not any(p.tuning for p in smp.progress()):
+            break
+    return total_leapfrogs(smp) - n0, launches, kms, time.perf_counter() - t0
+
+
+def timed_launches(env, smp, K, total_draws):
+    """EXACTLY K launches between barrier + synchronize on both sides.  Returns (elapsed s of this rank, leapfrogs, kernel ms)."""
+    env.barrier()
+    n0 = total_leapfrogs(smp)
+    env.barrier()
+    t0 = time.perf_counter()
+    done, launches, kernel_ms = smp.step(K)
+    env.barrier()
+    t1 = time.perf_counter()
+    prog = smp.progress()
+    if launches != K or done or max(p.finished_draws for p in prog) >= total_draws:
+        raise InvalidRegion("bench.py: a chain ran out of draws inside the timed region — the measurement is invalid; use fewer --steps")
+    return t1 - t0, float(total_leapfrogs(smp) - n0), kernel_ms, prog
+
+
+def config5_shard(env, args):
+    """BASELINE.json configs[4] on every rank: this GPU's shard (1024 chains x 10 000 dimensions, lean register kernel) — a
+    timed region in the sampling phase with the `hbm` roofline, then the job to its end and ONE gather of the thinned trace
+    + on-device moments + statistics to rank 0 (nutpie_amd.distributed.gather_trace; RCCL over xGMI for N > 1).
+    Bounded: a SHORT warm-up (tune = 60) and 64 draws — the kernel's rate per leapfrog does not depend on how well adapted the chain is."""
+    from nutpie_amd.distributed import gather_trace
     from nutpie_amd.gaussian import ar1_gaussian
 
-    hip.lib()
+    hip, dim, chains = env.hip, args.config5_dim, args.chains
+    model = ar1_gaussian(dim)
+    E = hip.default_evals_per_launch(dim)
+    K, tune = max(1, args.config5_launches), 60
+    n_draws = max(64, (K + 6) * E // 96)   # (a 10 000-dimensional draw takes 250 .. 1000 leapfrogs; checked by timed_launches)
+    s = hip.PyNutsSettings.Diag(args.seed)
+    s.update(num_tune=tune, num_draws=n_draws, num_chains=chains * env.world)
+    smp = hip.PySampler(s, hip.TridiagGaussianModel(model.diag, model.offdiag), device=env.device, chain_offset=env.rank * chains,
+                        n_local_chains=chains, store_draws=True, evals_per_launch=E, manual=True)
+    W = smp.waves_per_chain
+    t_all = time.perf_counter()
+    warm = warm_up_to_sampling(smp, batch=4)
+    smp.step(2)
+    elapsed, leap, kernel_ms, _ = timed_launches(env, smp, K, tune + n_draws)
+    elapsed_max = env.all_max(elapsed)
+    leap_sum, kms_sum = env.all_sum([leap, kernel_ms])
+    t0 = time.perf_counter()
+    while True:   # the rest of the job: the trace that is gathered is a finished one
+        done, _, _ = smp.step(8)
+        if done:
+            break
+    env.sync()
+    finish_s = time.perf_counter() - t0
+    dist = env.ensure_group()
+    timing = {}
+    thin = 8
+    g = gather_trace(smp, chains, chains * env.world, thin=thin, moments_after=tune, timing=timing,
+                     device=None if env.stub else env.device)
+    check = None
+    if g is not None:
+        mean = g["draw_mean"]
+        check = {"chains_gathered": int(mean.shape[0]), "draws_shape": list(g["draws"].shape), "moments_shape": list(mean.shape),
+                 "posterior_mean_abs_max": float(mean.mean(0).abs().max())}
+    smp.close()
+    avg_kernel_s = kms_sum / env.world / 1000.0 / K
+    out = {
+        "workload": f"{dim}-dim correlated Gaussian (AR(1) rho=0.9, fused), {chains} chains per GPU x {env.world} GPU(s) (BASELINE.json configs[4] "
+                    f"per-GPU shard); short warm-up (tune {tune}), timed region in the sampling phase with positions stored",
+        "value": leap_sum / elapsed_max, "unit": "leapfrog steps/s", "steps": K, "ms_per_step": 1000.0 * elapsed_max / K,
+        "waves_per_chain": W, "evals_per_launch": E, "warmup": {"leapfrogs": warm[0], "launches": warm[1], "kernel_ms": warm[2], "wall_s": warm[3]},
+        "roofline": roofline(dim, W, chains, leap_sum / env.world / K, avg_kernel_s),
+        "gather": {"backend": dist.get_backend(), "thin": thin, "finish_job_s": finish_s,
+                   "note": "one torch.distributed.gather per array to rank 0 (RCCL: direct sends over xGMI); draws thinned and moments reduced on the device first",
+                   **timing, "check": check},
+        "leg_wall_s": time.perf_counter() - t_all,
+    }
+    if timing.get("gather_s") and timing.get("bytes_gathered") and env.world > 1:
+        out["gather"]["GB_per_s_into_root"] = timing["bytes_gathered"] * (env.world - 1) / env.world / timing["gather_s"] / 1e9
+    return out
+
+
+def job_rate(smp, t_create):
+    """Wait for a sampler and describe the job it ran."""
+    smp.wait()
+    secs = smp.seconds
+    n = smp._copy("n_steps", np.int64)
+    div = smp._copy("diverging", np.bool_)
+    tun = smp._copy("tuning", np.bool_)
+    out = {"leapfrogs_per_s": float(n.sum() / secs), "job_s": secs, "wall_incl_setup_s": time.perf_counter() - t_create, "leapfrogs": int(n.sum()),
+           "mean_leapfrogs_per_draw_sampling": float(n[~tun].mean()) if (~tun).any() else None, "divergences_sampling": int(div[~tun].sum()),
+           "launches": smp.launches}
+    smp.close()
+    return out
+
+
+def other_configs(env, args):
+    """Bounded runs of the BASELINE.json configs the headline does not cover, on this GPU (rank 0, N = 1).  Each entry is a
+    whole `sample`-shaped job (its wall time from sampler creation to the last draw, leapfrogs from the trace)."""
+    hip = env.hip
+    out = {}
+
+    def leg(name, fn):
+        t0 = time.perf_counter()
+        try:
+            out[name] = fn()
+        except Exception as e:   # evidence legs: a failure is reported in the line, it does not lose the headline
+            out[name] = {"error": repr(e)}
+        out[name]["leg_wall_s"] = time.perf_counter() - t0
+
+    def settings(chains, tune, draws, seed=20260926):
+        s = hip.PyNutsSettings.Diag(seed)
+        s.update(num_tune=tune, num_draws=draws, num_chains=chains)
+        return s
+
+    def c3_generated():
+        from nutpie_amd.radon import radon_symbolic_model
+
+        m = radon_symbolic_model().compile()
+        t0 = time.perf_counter()
+        r = job_rate(m._make_sampler(settings(512, 400, 1000), None, 1, None, None, None, None), t0)
+        r["workload"] = "radon (D = 173, 85 counties, 919 observations), 512 chains, tune 400 + draws 1000; density generated by nutpie_amd.symbolic, compiled into its own resident kernel"
+        return r
+
+    def c3_torch():
+        from nutpie_amd.radon import radon_model
+
+        m = radon_model(device=env.device, use_graph=True)
+        t0 = time.perf_counter()
+        r = job_rate(m._make_sampler(settings(512, 100, 50), None, 1, None, None, None, None, store_draws=False), t0)
+        r["workload"] = "radon, 512 chains, torch log-density (HIP-graph replay) behind the batched device callback; bounded sample: tune 100 + draws 50"
+        return r
+
+    def c4():
+        import ctypes
+
+        fix = ctypes.CDLL(os.path.join(ROOT, "tests", "fixtures", "libeight_schools.so"))
+        m = hip.HostCallbackModel(10, ctypes.cast(fix.eight_schools_logp, ctypes.c_void_p).value)
+        m.set_init("normal")
+        t0 = time.perf_counter()
+        smp = hip.PySampler(settings(256, 400, 1000, seed=21), m, device=env.device)
+        mode = smp.host_mode
+        r = job_rate(smp, t0)
+        r["host_mode"] = mode
+        r["workload"] = "eight schools (D = 10, non-centred), 256 chains, tune 400 + draws 1000; raw C logp callback on the host (the reference's signature), PCIe inclusive"
+        return r
+
+    def c2_dense():
+        import nutpie_amd
+
+        m = nutpie_amd.dense_gaussian(1000, device=env.device)
+        t0 = time.perf_counter()
+        r = job_rate(m._make_sampler(settings(1024, 60, 20, seed=1), None, 1, None, None, None, None, store_draws=False), t0)
+        r["workload"] = "dense 1000-dim Gaussian (condition 1e4), 1024 chains, gradient = fp64 GEMM (rocBLAS via torch) behind the batched device callback; bounded sample: tune 60 + draws 20"
+        return r
+
+    leg("config3_radon_generated_density", c3_generated)
+    leg("config3_radon_torch_density", c3_torch)
+    leg("config4_eight_schools_host_callback", c4)
+    leg("config2ii_dense_gaussian_gemm_callback", c2_dense)
+    return out
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse(argv)
+    if "RANK" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args, argv))
+    env = Env(args)
+    hip, world, rank, device, dist = env.hip, env.world, env.rank, env.device, env.dist
+
+    from nutpie_amd.gaussian import ar1_gaussian
+
     model = ar1_gaussian(args.dim)
     # The launch length the engine runs by default (host.hip: default_evals_per_launch — about 10 ms of kernel: 2048 leapfrogs per
     # chain at D = 1000, 512 at D = 10 000).  A launch boundary costs every chain a flush and a reload of its register state and the
@@ -286,61 +583,29 @@ def main():
                         store_draws=store, evals_per_launch=E, manual=True)
     W = smp.waves_per_chain
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
-
     # ---- set-up, untimed: the whole warm-up (tune = 400 draws per chain); its rate is reported as `tuning_phase`
     tuning_phase = None
     if args.phase == "sampling":
-        t0 = time.perf_counter()
-        n0 = total_leapfrogs(smp)
-        launches = 0
-        kms = 0.0
-        while True:
-            done, l, ms = smp.step(10)
-            launches += l
-            kms += ms
-            if done:
-                raise SystemExit("bench.py: chains finished during warm-up; increase the number of draws")
-            if not any(p.tuning for p in smp.progress()):
-                break
-        torch.cuda.synchronize()
-        n1 = total_leapfrogs(smp)
-        tuning_phase = {"leapfrogs": int(n1 - n0), "launches": launches, "wall_s": time.perf_counter() - t0,
-                        "leapfrogs_per_s_kernel_time": (n1 - n0) / (kms / 1e3), "note": "all chains through tune = 400 draws (untimed set-up of the "
+        try:
+            leapfrogs, launches, kms, wall = warm_up_to_sampling(smp)
+        except InvalidRegion as e:
+            raise SystemExit(str(e))
+        env.sync()
+        tuning_phase = {"leapfrogs": int(leapfrogs), "launches": launches, "wall_s": wall,
+                        "leapfrogs_per_s_kernel_time": leapfrogs / (kms / 1e3), "note": "all chains through tune = 400 draws (untimed set-up of the "
                         "bench; includes initial points, step-size search, mass-matrix adaptation; wall time includes progress polling)"}
     smp.step(args.warmup)
-    barrier()
-    n0 = total_leapfrogs(smp)
     tuning0 = sum(p.tuning for p in smp.progress())
-    barrier()
-    t0 = time.perf_counter()
-    done, launches, kernel_ms = smp.step(K)
-    barrier()
-    t1 = time.perf_counter()
-    n1 = total_leapfrogs(smp)
-    prog = smp.progress()
+    try:
+        elapsed, leap, kernel_ms, prog = timed_launches(env, smp, K, num_tune + n_draws)
+    except InvalidRegion as e:
+        raise SystemExit(str(e))
     tuning1 = sum(p.tuning for p in prog)
-    if launches != K or done or max(p.finished_draws for p in prog) >= num_tune + n_draws:
-        raise SystemExit("bench.py: a chain ran out of draws inside the timed region — the measurement is invalid; use fewer --steps")
-    elapsed = t1 - t0
-    leap = float(n1 - n0)
-    per_rank = [{"rank": rank, "device": device, "leapfrogs": leap, "kernel_ms": kernel_ms, "elapsed_s": elapsed}]
-    if dist is not None:
-        mine = torch.tensor([rank, device, leap, kernel_ms, elapsed], dtype=torch.float64, device="cuda")
-        allr = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(allr, mine)
-        per_rank = [{"rank": int(t[0]), "device": int(t[1]), "leapfrogs": float(t[2]), "kernel_ms": float(t[3]), "elapsed_s": float(t[4])} for t in allr]
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        c = torch.tensor([leap, kernel_ms], dtype=torch.float64, device="cuda")
-        dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        leap, kernel_ms_sum = float(c[0].item()), float(c[1].item())
-        kernel_ms = kernel_ms_sum / world
+    rows = env.all_rows([rank, device, leap, kernel_ms, elapsed])
+    per_rank = [{"rank": int(t[0]), "device": int(t[1]), "leapfrogs": float(t[2]), "kernel_ms": float(t[3]), "elapsed_s": float(t[4])} for t in rows]
+    elapsed = env.all_max(elapsed)
+    leap, kernel_ms_sum = env.all_sum([leap, kernel_ms])
+    kernel_ms = kernel_ms_sum / world
     draws_stored = int(sum(p.finished_draws for p in prog)) if store else 0
     smp.close()
 
@@ -358,15 +623,28 @@ def main():
         "roofline": roofline(args.dim, W, args.chains, leap_per_launch, avg_kernel_s),
         "ranks": {"world": world, "backend": (dist.get_backend() if dist is not None else None),
                   "collective_ranks": (dist.get_world_size() if dist is not None else 1), "per_rank": per_rank,
+                  "launched_by": "torch.distributed.run" if "RANK" in os.environ else "single process",
                   "note": "chains sharded by global chain id (rank r owns chains [r * chains_per_gpu, (r + 1) * chains_per_gpu)); no data-path "
                           "collective, only this report's gather and the timing all-reduce"},
     }
+    if env.stub:
+        out["data"] = "stub"
+        out["stub"] = "engine replaced by a test stand-in: this line exercises bench.py's multi-rank plumbing and measures nothing"
     if tuning_phase is not None:
         out["tuning_phase"] = tuning_phase
-    if rank == 0 and world == 1 and not args.no_job and args.dim <= 2048:
+    if not args.no_config5 and args.dim != args.config5_dim:
+        try:
+            out["config5_shard"] = config5_shard(env, args)   # (collective: every rank takes part)
+        except Exception as e:
+            if world > 1:
+                raise   # a rank that drops out of a collective must not leave the others waiting
+            out["config5_shard"] = {"error": repr(e)}
+    if rank == 0 and world == 1 and not args.no_job and args.dim <= 2048 and not env.stub:
         dims = sorted(set(np.linspace(0, args.dim - 1, 12).astype(int).tolist() + [int(np.argmax(model.diag)), int(np.argmin(model.diag))]))
-        out["job"] = run_job(hip, model, args, device, 0, dims)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["job"] = run_job(hip, model, args, device, 0, dims, world)
+    if rank == 0 and world == 1 and not args.no_other_configs and not env.stub:
+        out["other_configs"] = other_configs(env, args)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not env.stub:
         tuned, port = cpu_baseline(model, args.seed, args.cpu_seconds)
         out["cpu_baseline"] = port
         out["gpu_over_cpu"] = out["value"] / port["value"]
@@ -375,10 +653,10 @@ def main():
             if "value" in tuned:
                 out["gpu_over_cpu_tuned"] = out["value"] / tuned["value"]
     if rank == 0:
-        print(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        print(json.dumps(out), flush=True)
+    if env.dist is not None:
+        env.dist.barrier()
+        env.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -171,7 +171,8 @@ def compile_density(user_source: str, layout, ndim: int, *, waves: int = 1, verb
     out = os.path.join(cache_dir(), f"density_{h.hexdigest()[:24]}.so")
     if os.path.exists(out):
         return out
-    with tempfile.TemporaryDirectory() as tmp:
+    # (the temporary directory lives INSIDE the cache directory: os.replace below must not cross a filesystem — /tmp often is a tmpfs)
+    with tempfile.TemporaryDirectory(dir=cache_dir(), prefix=".build_") as tmp:
         path = os.path.join(tmp, "density.hip")
         with open(path, "w") as f:
             f.write(src)
@@ -300,8 +301,12 @@ class DensitySourceModel(CompiledModel):
         scratch = torch.empty(slots * per, dtype=torch.float64, device=torch.device("cuda", device))
         return DeviceData(self._data, data_layout(self._data), device, device_arrays={"scratch__": scratch})
 
+    def library_path(self) -> str:
+        """Build (or find) this model's library without loading it — what an ahead-of-time build calls (no GPU needed)."""
+        return compile_density(self._source, data_layout(self._data), self._n_dim, waves=self._waves)
+
     def library(self) -> DensityLibrary:
-        return DensityLibrary(compile_density(self._source, data_layout(self._data), self._n_dim, waves=self._waves))
+        return DensityLibrary(self.library_path())
 
     def logp_and_grad(self, x, device: int = 0, return_data: bool = False):
         """The compiled density on a block of positions ``x[N, n_dim]`` (one launch of the batched form, ``nphip_jit_logp``):

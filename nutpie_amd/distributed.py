@@ -73,7 +73,7 @@ def chain_moments(draws, n_tune: int):
 
 def sample_sharded(make_sampler, num_chains: int, *, group=None, thin: int = 1, dims=None, gather_draws: bool = True,
                    stats=("depth", "n_steps", "diverging", "tuning", "step_size", "energy", "logp"), device=None,
-                   moments_after: int | None = None):
+                   moments_after: int | None = None, timing: dict | None = None):
     """Run this rank's shard to completion and gather the trace on rank 0.
 
     ``make_sampler(chain_offset, n_local) -> PySampler``.  Draws are thinned by ``thin`` and restricted to
@@ -81,8 +81,10 @@ def sample_sharded(make_sampler, num_chains: int, *, group=None, thin: int = 1, 
     ``moments_after=n_tune`` additionally gathers ``draw_mean`` / ``draw_var`` ``[chains, D]`` (per-chain moments of the
     post-warm-up draws, reduced on the device; megabytes instead of the trace).
     Returns ``(sampler, gathered)``; ``gathered`` is a dict of tensors on rank 0 and None elsewhere.
+    ``timing`` (optional dict) receives ``sample_s`` and what :func:`gather_trace` reports.
     """
-    import torch
+    import time
+
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
@@ -93,10 +95,38 @@ def sample_sharded(make_sampler, num_chains: int, *, group=None, thin: int = 1, 
         # takes part in the gather with empty shards of the shapes rank 0 announces
         return None, _gather_empty(group)
     sampler = make_sampler(offset, n_local)
+    t0 = time.perf_counter()
     sampler.wait()
+    if timing is not None:
+        timing["sample_s"] = time.perf_counter() - t0
+    gathered = gather_trace(sampler, n_local, num_chains, group=group, thin=thin, dims=dims, gather_draws=gather_draws, stats=stats,
+                            device=device, moments_after=moments_after, timing=timing)
+    return sampler, gathered
+
+
+def gather_trace(sampler, n_local: int, num_chains: int, *, group=None, thin: int = 1, dims=None, gather_draws: bool = True,
+                 stats=("depth", "n_steps", "diverging", "tuning", "step_size", "energy", "logp"), device=None,
+                 moments_after: int | None = None, timing: dict | None = None):
+    """The collective half of :func:`sample_sharded`: the finished sampler's trace (thinned / reduced on the device) to rank 0 in
+    ONE ``gather`` per array.  With ``timing`` the on-device reduction and the collective are timed apart (a barrier in between
+    keeps a straggling rank's sampling time out of the collective's figure) and the payload is counted:
+    ``reduce_s``, ``gather_s``, ``bytes_local`` (this rank's shard), ``bytes_gathered`` (rank 0: all shards), ``arrays``."""
+    import time
+
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
     T, D = sampler.total_draws, sampler.dim
     on_gpu = dist.get_backend(group) == "nccl"
     dev = device if device is not None else (torch.cuda.current_device() if on_gpu else None)
+
+    def sync():
+        if on_gpu:
+            torch.cuda.synchronize()
+
+    t0 = time.perf_counter()
     local = {}
     dtypes = {"depth": "int64", "n_steps": "int64", "index_in_trajectory": "int64", "diverging": "uint8", "maxdepth_reached": "uint8", "tuning": "uint8"}
     for name in stats:
@@ -120,8 +150,22 @@ def sample_sharded(make_sampler, num_chains: int, *, group=None, thin: int = 1, 
     if world > num_chains:   # some ranks are empty: tell them what is being gathered (names, trailing shapes, dtypes)
         spec = [{k: (tuple(v.shape[1:]), str(v.dtype).replace("torch.", "")) for k, v in sorted(local.items())}] if rank == 0 else [None]
         dist.broadcast_object_list(spec, src=0, group=group)
+    if timing is not None:
+        sync()
+        timing["reduce_s"] = time.perf_counter() - t0
+        timing["bytes_local"] = int(sum(int(np.prod(v.shape)) * (v.element_size() if hasattr(v, "element_size") else v.itemsize) for v in local.values()))
+        timing["arrays"] = {k: list(v.shape) for k, v in sorted(local.items())}
+        dist.barrier(group=group)
+        sync()
+        t0 = time.perf_counter()
     gathered = gather_arrays(local, n_local, group=group)
-    return sampler, gathered
+    if timing is not None:
+        sync()
+        timing["gather_s"] = time.perf_counter() - t0
+        timing["collective_ranks"] = world
+        if gathered is not None:
+            timing["bytes_gathered"] = int(sum(v.numel() * v.element_size() for v in gathered.values()))
+    return gathered
 
 
 def _gather_empty(group=None):

@@ -360,3 +360,35 @@ def radon_density_model(data=None, resident=True):
     return from_density_source(D, RADON_DENSITY_SOURCE, dd, lds_doubles_per_chain=lambda d: 2 * RADON_MAX_COUNTIES + 2 * len(d["y"]),
                                lds_doubles_shared=shared_doubles, expand_fn=expand,
                                expanded_names=names, expanded_shapes=shapes, coords={"county": np.arange(n)}, dims=dims, resident=resident)
+
+
+def radon_symbolic_model(data=None):
+    """Config 3's model written with the front-end (:mod:`nutpie_amd.symbolic`): expressions -> symbolic gradient -> generated HIP
+    density -> the model's own resident kernel (``.compile()``).  Same variables and priors as :func:`radon_model`."""
+    from nutpie_amd import symbolic as S
+
+    d = data or synthetic_radon_data()
+    n = int(np.max(d["county_idx"])) + 1
+    m = S.Model()
+    m.dim("county", n)
+    intercept = m.param("intercept")
+    raw = m.param("county_raw", dim="county", zero_sum=True)
+    sd = m.param("county_sd", lower=0.0)
+    fe = m.param("floor_effect")
+    craw = m.param("county_floor_raw", dim="county", zero_sum=True)
+    csd = m.param("county_floor_sd", lower=0.0)
+    sig = m.param("sigma", lower=0.0)
+    y = m.data("y", d["log_radon"], dim="obs")
+    fl = m.data("floor", d["floor"], dim="obs")
+    ci = m.index("county", d["county_idx"], dim="obs", into="county")
+    eff, cfe = raw * sd, craw * csd
+    m.deterministic("county_effect", eff)
+    m.deterministic("county_floor_effect", cfe)
+    # the priors of radon_model, constants dropped as there (the hand-written density is the comparison)
+    m.add_logp(-0.005 * (intercept * intercept) - 0.125 * (fe * fe))
+    m.add_logp((-0.5 * (raw * raw)).sum() + (-0.5 * (craw * craw)).sum())
+    m.add_logp(-0.5 * (sd * sd) - 0.5 * (csd * csd) - (0.5 / 2.25) * (sig * sig))
+    mu = intercept + eff[ci] + fl * (fe + cfe[ci])
+    z = (y - mu) / sig
+    m.add_logp((-0.5 * (z * z) - S.log(sig)).sum())
+    return m

@@ -6,34 +6,10 @@ from nutpie_amd import symbolic as S
 
 
 def radon(data=None):
-    """Config 3's varying-intercept / varying-slope model (nutpie_amd/radon.py) written with the front-end."""
-    from nutpie_amd.radon import synthetic_radon_data
+    """Config 3's varying-intercept / varying-slope model written with the front-end (it lives in the package: bench.py runs it)."""
+    from nutpie_amd.radon import radon_symbolic_model
 
-    d = data or synthetic_radon_data()
-    n = int(np.max(d["county_idx"])) + 1
-    m = S.Model()
-    m.dim("county", n)
-    intercept = m.param("intercept")
-    raw = m.param("county_raw", dim="county", zero_sum=True)
-    sd = m.param("county_sd", lower=0.0)
-    fe = m.param("floor_effect")
-    craw = m.param("county_floor_raw", dim="county", zero_sum=True)
-    csd = m.param("county_floor_sd", lower=0.0)
-    sig = m.param("sigma", lower=0.0)
-    y = m.data("y", d["log_radon"], dim="obs")
-    fl = m.data("floor", d["floor"], dim="obs")
-    ci = m.index("county", d["county_idx"], dim="obs", into="county")
-    eff, cfe = raw * sd, craw * csd
-    m.deterministic("county_effect", eff)
-    m.deterministic("county_floor_effect", cfe)
-    # the priors of nutpie_amd/radon.py, constants dropped as there (the hand-written density is the comparison)
-    m.add_logp(-0.005 * (intercept * intercept) - 0.125 * (fe * fe))
-    m.add_logp((-0.5 * (raw * raw)).sum() + (-0.5 * (craw * craw)).sum())
-    m.add_logp(-0.5 * (sd * sd) - 0.5 * (csd * csd) - (0.5 / 2.25) * (sig * sig))
-    mu = intercept + eff[ci] + fl * (fe + cfe[ci])
-    z = (y - mu) / sig
-    m.add_logp((-0.5 * (z * z) - S.log(sig)).sum())
-    return m
+    return radon_symbolic_model(data)
 
 
 def logistic(seed=3, n_obs=500, n_group=7, n_item=11):

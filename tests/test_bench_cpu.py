@@ -80,3 +80,67 @@ def test_bench_refuses_to_run_without_a_gpu():
         return
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1"], capture_output=True, text=True)
     assert r.returncode != 0 and "no CPU fallback" in (r.stderr + r.stdout)
+
+
+def _run_bench(*argv, env_extra=None, timeout=240):
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], capture_output=True, text=True, timeout=timeout, env=env)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None), lines
+
+
+STUB = os.path.join(ROOT, "tests", "bench_stub_engine.py")
+
+
+def test_gpus_n_spawns_its_own_ranks_and_gathers_in_global_chain_order():
+    """`python bench.py --gpus 2` with no RANK in the environment starts two ranks itself (torch.distributed.run,
+    127.0.0.1), shards the chains by global id, runs the config-5 shard leg with ONE gather to rank 0, and rank 0 prints one line.
+    The engine is a stand-in (tests/bench_stub_engine.py, gloo): this pins the plumbing, it measures nothing."""
+    r, out, lines = _run_bench("--gpus", "2", "--engine-stub", STUB, "--chains", "8", "--dim", "16", "--config5-dim", "32",
+                               "--steps", "3", "--warmup", "1", "--config5-launches", "2")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(lines) == 1                                        # ONE JSON line, from rank 0
+    assert out["n_gpus"] == 2 and out["data"] == "stub" and "stub" in out
+    ranks = out["ranks"]
+    assert ranks["world"] == 2 and ranks["collective_ranks"] == 2 and ranks["backend"] == "gloo" and ranks["launched_by"] == "torch.distributed.run"
+    assert [p["rank"] for p in ranks["per_rank"]] == [0, 1] and [p["device"] for p in ranks["per_rank"]] == [0, 1]
+    # weak scaling: every rank advanced its 8 chains by 3 launches of the stub's 8 leapfrogs; value = the sum over ranks / max time
+    assert all(p["leapfrogs"] == 8 * 3 * 8 for p in ranks["per_rank"])
+    assert out["config"]["leapfrogs_per_step"] == 2 * 8 * 8 and out["steps"] == 3
+    assert abs(out["value"] - 2 * 8 * 3 * 8 / (out["ms_per_step"] * 3 / 1000)) < 1e-6 * out["value"]
+    g = out["config5_shard"]["gather"]
+    assert g["collective_ranks"] == 2 and g["backend"] == "gloo"
+    assert g["check"]["chains_gathered"] == 16 and g["check"]["moments_shape"] == [16, 32]
+    assert g["bytes_gathered"] == 2 * g["bytes_local"] and g["gather_s"] >= 0
+    assert "job" not in out and "cpu_baseline" not in out and "other_configs" not in out      # N = 1 legs only
+
+
+def test_stub_gather_is_in_global_chain_order():
+    """The same leg in one process (no torch.distributed.run): a one-rank group is created for the gather."""
+    r, out, _ = _run_bench("--engine-stub", STUB, "--chains", "4", "--dim", "16", "--config5-dim", "32", "--steps", "2", "--warmup", "1",
+                           "--config5-launches", "1")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert out["n_gpus"] == 1 and out["ranks"]["launched_by"] == "single process"
+    c5 = out["config5_shard"]
+    assert c5["gather"]["collective_ranks"] == 1 and c5["gather"]["check"]["chains_gathered"] == 4
+    assert c5["gather"]["arrays"]["draws"][0] == 4 and c5["gather"]["arrays"]["draw_mean"] == [4, 32]
+
+
+def test_gpus_n_refuses_when_fewer_gpus_are_visible():
+    import torch
+
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        return
+    r, out, _ = _run_bench("--gpus", "2", "--steps", "1", "--warmup", "1")
+    assert r.returncode != 0 and out is None
+    assert "GPU(s) visible" in (r.stderr + r.stdout)
+
+
+def test_world_size_must_agree_with_gpus():
+    r, out, _ = _run_bench("--gpus", "2", "--engine-stub", STUB, env_extra={"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0",
+                                                                          "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29999"})
+    assert r.returncode != 0 and "must agree" in (r.stderr + r.stdout)
