@@ -45,6 +45,21 @@ def radon_device_lib():
 
 
 @pytest.fixture(scope="session")
+def scaled_normal_device_lib():
+    """hipcc-built device twin of eight_schools.c::scaled_normal_logp (tests/fixtures/scaled_normal_device.hip): the same IEEE
+    operations in the same order behind the batched DEVICE callback, so that a device-callback job can be compared with the
+    oracle bit for bit."""
+    src = os.path.join(FIXTURES, "scaled_normal_device.hip")
+    out = os.path.join(FIXTURES, "libscaled_normal_device.so")
+    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-o", out, src], check=True)
+    from nutpie_amd import _lib
+
+    _lib.lib()  # first: it loads torch's HIP runtime before any other library can pull in a second one
+    return ctypes.CDLL(out)
+
+
+@pytest.fixture(scope="session")
 def fixture_lib():
     """gcc-built shared library with the eight-schools test model (tests/fixtures/eight_schools.c)."""
     src = os.path.join(FIXTURES, "eight_schools.c")

@@ -542,6 +542,21 @@ def test_recoverable_and_fatal_callback_codes(hip, oracle, fixture_lib):
         smp.wait()
 
 
+@pytest.mark.parametrize("dim,chains,waves,graph_steps", [(10, 40, 0, 0), (10, 40, 0, 16), (200, 24, 0, 0), (700, 12, 0, 16), (1000, 9, 0, 0),
+                                                         (1000, 9, 1, 16), (1000, 9, 4, 0), (1000, 9, 8, 16), (2500, 5, 0, 16), (5003, 3, 0, 0)])
+def test_device_callback_bit_identical(hip, oracle, fixture_lib, scaled_normal_device_lib, dim, chains, waves, graph_steps):
+    """The launch-per-evaluation kernels behind a batched DEVICE callback (src/pyfunc.rs:206-230 flavour; what a torch
+    density runs on), plain and replayed from a HIP graph, against the oracle — zero tolerance: the device density
+    (tests/fixtures/scaled_normal_device.hip, one thread per chain) performs the host C function's operations in its order."""
+    fn = fn_addr(scaled_normal_device_lib.scaled_normal_device_seq)
+    got, W = run_engine(hip, hip.NativeDeviceCallbackModel(dim, fn, 0, keep_alive=scaled_normal_device_lib), chains=chains, tune=70, draws=30,
+                        seed=dim + chains, waves=waves, launch=dict(graph_steps=graph_steps), store_gradient=True)
+    want = oracle.sample_callback(oracle_settings(oracle, chains=chains, tune=70, draws=30, seed=dim + chains, W=W, store_gradient=True), dim,
+                                  fn_addr(fixture_lib.scaled_normal_logp))
+    assert_trace_equal(got, want)
+    assert np.array_equal(got.stats["gradient"], want.stats["gradient"])
+
+
 def test_python_callable_through_host_callback(hip, oracle):
     def logp(x):
         return -0.5 * float(x @ x), -x
