@@ -542,8 +542,8 @@ def other_configs(env, args):
 
         m = nutpie_amd.dense_gaussian(1000, device=env.device)
         t0 = time.perf_counter()
-        r = job_rate(m._make_sampler(settings(1024, 60, 20, seed=1), None, 1, None, None, None, None, store_draws=False), t0)
-        r["workload"] = "dense 1000-dim Gaussian (condition 1e4), 1024 chains, gradient = fp64 GEMM (rocBLAS via torch) behind the batched device callback; bounded sample: tune 60 + draws 20"
+        r = job_rate(m._make_sampler(settings(1024, 30, 10, seed=1), None, 1, None, None, None, None, store_draws=False), t0)
+        r["workload"] = "dense 1000-dim Gaussian (condition 1e4), 1024 chains, gradient = fp64 GEMM (rocBLAS via torch) behind the batched device callback; bounded sample: tune 30 + draws 10"
         return r
 
     leg("config3_radon_generated_density", c3_generated)
@@ -653,6 +653,15 @@ def main(argv=None):
             if "value" in tuned:
                 out["gpu_over_cpu_tuned"] = out["value"] / tuned["value"]
     if rank == 0:
+        # (RCCL prints a version banner through C stdio when its first communicator is created; flush it BEFORE the line, so
+        #  that the JSON line is the last thing on stdout)
+        try:
+            import ctypes
+
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
         print(json.dumps(out), flush=True)
     if env.dist is not None:
         env.dist.barrier()

@@ -22,6 +22,10 @@ enum Phase : int64_t {
     PH_ERROR = 6,
     PH_WAIT_HOST = 7,  // stopped after a draw listed in DevSettings::pause_draws: the host re-parametrises the chain and resumes it
     PH_RESUME_SS = 8,  // resumed by the host with a new metric at the same position: step-size search, then the next draw
+    // launch-per-evaluation (callback) kernels only — a launch lasts as long as its slowest chain, so the end of a draw is cut into
+    // slices that take a launch each (the chain sits out the evaluations in between; its trace does not change):
+    PH_DRAW_END = 9,    // the tree of the draw is complete (Ctl::pend_end says how): adaptation, trace row, statistics
+    PH_DRAW_BEGIN = 10, // momentum refresh and the first leapfrog of the next draw
 };
 
 enum ChainError : int64_t {
@@ -87,6 +91,8 @@ struct Ctl {
     double fin_eerr;
     // lean register kernels: (A.first, T.first) of the level-1 merge the next leaf will check, evaluated one leaf early
     int64_t pre_turn;
+    // PH_DRAW_END: how the draw ended — bit 0 diverging, bit 1 maxdepth reached, bit 2 store the divergence record, bit 3 ... with its end position
+    int64_t pend_end;
     // low-rank metric (nphip_sampler_set_metric): 0 = the chain still runs on the diagonal metric it adapts itself; 1 = the host
     // supplied (sigma^2, V, lambda) — M^-1 = D^1/2 (I + V (Lambda - I) V') D^1/2 with lr_k columns — and the chain's own
     // mass-matrix adaptation is off

@@ -744,6 +744,17 @@ static int choose_waves(uint64_t dim) {
     return 8;  // memory-resident kernels; measured at D = 10 000: W = 8 (5.5 M leapfrogs/s) beats 4 (5.0) and 16 (3.6)
 }
 
+// Device-callback models run on the launch-per-evaluation kernels, whose fused leaf holds up to two chunks of 128 dimensions per
+// wave in registers (kernels.hip: leaf_cb, NPHIP_CB_CHUNKS): the fewest waves per chain that keep a row inside it — a function of
+// the dimension alone, like choose_waves (a chain's floats depend on the number of waves that sum over its row).  Measured at
+// D = 1000 x 1024 chains (profiles/r4_callback_kernels.txt): 4 waves x 2 chunks 33.5 us per launch, 2 waves x 4 chunks 36.6.
+static int choose_waves_callback(uint64_t dim) {
+    const uint64_t nch = (dim + 127) / 128;
+    for (int w = 1; w <= 16; w *= 2)
+        if (nch <= 2u * (uint64_t)w) return w;
+    return 16;
+}
+
 bool nphip_sampler::setup() {
     HIP_TRY(hipSetDevice(device));
     if (launch.stream) { stream = (hipStream_t)launch.stream; own_stream = false; }
@@ -753,7 +764,7 @@ bool nphip_sampler::setup() {
     T = set.num_tune + set.num_draws;
     fused = model.kind == 0;
     dens = model.kind == 3;
-    W = dens ? model.jit_w : (launch.waves_per_chain ? launch.waves_per_chain : choose_waves(dim));
+    W = dens ? model.jit_w : (launch.waves_per_chain ? launch.waves_per_chain : (model.kind == 2 ? choose_waves_callback(dim) : choose_waves(dim)));
     const bool lrm = set.low_rank_metric;
     if (lrm && dens) { set_error("the low-rank metric runs on the memory-resident kernels: use the batched device callback of the density's library"); return false; }
     if (lrm) launch.no_register_kernel = 1;   // (P-slots carry the velocity as a third vector: memory-resident kernels only)
@@ -1128,8 +1139,17 @@ bool nphip_sampler::iteration_callback(bool& all_done, int& have) {
     } else {
         // device callback: counters are polled without synchronising (stale values only delay exit), and only every
         // eighth step: the 16-byte copy is a 5 us kernel in the same stream (13 % of a step with a one-kernel model)
-        if ((cb_polls++ & 7) == 0 &&
-            !hip_ok(hipMemcpyAsync(h_counters, args.counters, 16, hipMemcpyDeviceToHost, stream), "copy counters")) return false;
+        // ... and the host stays at most sixteen steps ahead of the device: without a bound it enqueues thousands of launches while
+        // the device works through the first ones, and when the last chain finishes the device still has all of them to run
+        // (measured: 11 089 launches for a job of 3 425 evaluation steps)
+        if ((cb_polls & 7) == 0) {
+            const int slot = (int)((cb_polls >> 3) & 1);
+            if (!cb_ev[slot] && !hip_ok(hipEventCreate(&cb_ev[slot]), "hipEventCreate")) return false;
+            if (cb_polls >= 16 && !hip_ok(hipEventSynchronize(cb_ev[slot]), "hipEventSynchronize")) return false;
+            if (!hip_ok(hipMemcpyAsync(h_counters, args.counters, 16, hipMemcpyDeviceToHost, stream), "copy counters")) return false;
+            if (!hip_ok(hipEventRecord(cb_ev[slot], stream), "hipEventRecord")) return false;
+        }
+        ++cb_polls;
         volatile unsigned long long* hc = h_counters;
         if (hc[1] > 0) {
             (void)hipStreamSynchronize(stream);
@@ -1173,7 +1193,8 @@ bool nphip_sampler::iteration_graph(bool& all_done) {
             int have = 1;
             return iteration_callback(all_done, have);
         }
-        if (!hip_ok(hipEventCreate(&cb_ev[0]), "hipEventCreate") || !hip_ok(hipEventCreate(&cb_ev[1]), "hipEventCreate")) return false;
+        for (auto& e : cb_ev)
+            if (!e && !hip_ok(hipEventCreate(&e), "hipEventCreate")) return false;
     }
     const int slot = (int)(cb_replays & 1);
     if (cb_replays >= 2 && !hip_ok(hipEventSynchronize(cb_ev[slot]), "hipEventSynchronize")) return false;

@@ -67,6 +67,13 @@ template <int W>
 #ifndef NPHIP_RW_OCC2_MAX
 #define NPHIP_RW_OCC2_MAX 4
 #endif
+#ifndef NPHIP_CB_OCC
+// waves per SIMD the launch-per-evaluation (callback) kernels are compiled for.  Two: 256 registers per lane, (almost) nothing
+// spilled.  Measured at four waves per SIMD (128 registers, every chain of a 1024-chain batch x 4 waves on the device at once):
+// 82 spilled VGPRs, eleven of them stored by every wave of every launch — 23 MB of scratch traffic per launch in a kernel that
+// is bound by its memory traffic — 38.4 us per launch against 33.5 (profiles/r4_callback_kernels.txt)
+#define NPHIP_CB_OCC(W) 2
+#endif
 #ifndef NPHIP_LEAN_OCC
 // waves per SIMD of the lean kernels: 8 waves = one chain per CU at 256 VGPRs per wave (4 waves: 512 = VGPRs + AGPRs)
 #define NPHIP_LEAN_OCC(W) ((W) <= 4 ? 1 : ((W) <= 8 ? 2 : 4))
@@ -172,14 +179,28 @@ __device__ __forceinline__ double2 ld2(const double* p, int64_t i) { return *(co
 __device__ __forceinline__ void st2(double* p, int64_t i, double2 v) { *(NPHIP_GLOBAL double2*)(p + i) = v; }
 __device__ __forceinline__ double ld1(const double* p, int64_t i) { return *(const NPHIP_GLOBAL double*)(p + i); }
 __device__ __forceinline__ void st1(double* p, int64_t i, double v) { *(NPHIP_GLOBAL double*)(p + i) = v; }
+// the same with a 32-bit byte offset per lane: with a uniform base the access is `global_load ... v_off, s[base:base+1]` — ONE
+// address register per lane for every vector of a pass instead of a 64-bit pair per (vector, chunk)
+__device__ __forceinline__ double2 ld2b(const double* p, uint32_t off) { return *(const NPHIP_GLOBAL double2*)((const NPHIP_GLOBAL char*)p + off); }
+__device__ __forceinline__ void st2b(double* p, uint32_t off, double2 v) { *(NPHIP_GLOBAL double2*)((NPHIP_GLOBAL char*)p + off) = v; }
 // dense rows (ld == dim, possibly odd / unaligned): guarded scalar accesses
+// (an even row length — rows start on 16-byte boundaries then, and no pair straddles the end — takes whole pairs)
 __device__ __forceinline__ double2 ld2_dense(const double* p, int64_t i, int64_t D) {
     double2 v;
+    if ((D & 1) == 0) {
+        v.x = 0.0; v.y = 0.0;
+        if (i < D) v = ld2(p, i);
+        return v;
+    }
     v.x = (i < D) ? ld1(p, i) : 0.0;
     v.y = (i + 1 < D) ? ld1(p, i + 1) : 0.0;
     return v;
 }
 __device__ __forceinline__ void st2_dense(double* p, int64_t i, int64_t D, double2 v) {
+    if ((D & 1) == 0) {
+        if (i < D) st2(p, i, v);
+        return;
+    }
     if (i < D) st1(p, i, v.x);
     if (i + 1 < D) st1(p, i + 1, v.y);
 }
@@ -233,6 +254,8 @@ struct SCache {
 template <bool FUSED, int W, int NV = 0, bool LEAN = false, bool REMOTE = false>
 struct Machine {
     static constexpr bool INK = FUSED || REMOTE;   // evaluations happen inside the kernel: a launch runs many steps
+    // launch-per-evaluation kernels: the end of a draw is cut into slices of a launch each (engine_types.h: PH_DRAW_END / PH_DRAW_BEGIN)
+    static constexpr bool SLICED = !INK && NV == 0;
     static constexpr bool DENS = REMOTE && (NPHIP_JIT != 0);   // ... by calling the model's own device function (runtime-compiled density)
     LdsDouble dens_lds = nullptr;   // DENS: this wave's LDS scratch for the density
     LdsDouble dens_shared = nullptr;   // DENS: the workgroup's shared LDS (staged by nphip_density_stage at kernel start)
@@ -242,7 +265,8 @@ struct Machine {
     // kernel arguments, read through the constant address space: s_load into SGPRs (uniform), never flat
     const NPHIP_CONST Args& A;
     LdsCtl c;        // this wave's private LDS copy
-    LdsDouble red;   // LDS reduction scratch: two areas of [8*W], used alternately (one barrier per reduction)
+    LdsDouble red;   // LDS reduction scratch: two areas of [16*W], used alternately (one barrier per reduction; up to 16 values each)
+    LdsDouble parked = nullptr;   // callback kernels, W > 1: wave totals of the fused leaf's sums, [kParkMax][W] (leaf_cb)
     int rflip = 0;
     LdsDouble par;   // NV > 0: LDS copy of the fused model: mu[ld], a[ld], then b shifted by one (par_b[i] = b_{i-1})
     LdsDouble ring;  // NV > 0: this wave's LDS ring of two (p, rho) summaries: [slot][p|rho][NV*64 double2]
@@ -301,7 +325,8 @@ struct Machine {
     // every wave has passed the barrier of the reduction in between, i.e. has finished reading it.
     template <int N>
     __device__ __forceinline__ void rsum(double (&v)[N]) {
-        reduceN<W, N, false>(v, red + (W > 1 ? rflip * 8 * W : 0));
+        static_assert(N <= 16, "a reduction area holds 16 values per wave");
+        reduceN<W, N, false>(v, red + (W > 1 ? rflip * 16 * W : 0));
         rflip ^= 1;
     }
     __device__ __forceinline__ void rsum2(double& a, double& b) {
@@ -1023,6 +1048,280 @@ struct Machine {
         rsum2(a, b);
         if (FUSED) { lp = 0.5 * b; code = 0; }
         return 0.5 * a;
+    }
+
+
+    // ======================================================================================
+    // Launch-per-evaluation kernels (callback models: NV == 0, the evaluation happens between two launches): the hot leaf.
+    //
+    // A launch of these kernels serves ONE evaluation and lasts as long as the chain with the longest dependent path — and
+    // among a thousand chains there always is one that closes a deep sub-tree or a doubling.  The plain sequence (lf2, one
+    // turning() pass per criterion and level, lf1) is a chain of up to 3 * depth + 4 dependent passes over the row.  Here
+    //   * ONE pass takes the second half of the leapfrog, the kinetic energy, the level-0 criterion AND the criteria of the first
+    //     merge level >= 1 the leaf closes (which sub-trees a leaf closes, and in which P-slots their summaries lie, follows
+    //     from the leaf number alone), and — speculatively — the FIRST half of the next leapfrog: the next leaf of a doubling
+    //     always continues from this one; when the tree ends instead, what was written is dead storage;
+    //   * deeper levels and the top-level merge take one more pass per two levels, against the new leaf kept in registers;
+    //   * the scalar cascade (cont_tree: weights, multinomial merges) then only consumes bits.
+    // Each criterion keeps its own pair of accumulators, summed per (lane, component) over the wave's chunks in increasing
+    // order and reduced in the contract's order — the bits of the plain sequence, which remains the fall-back (rows of more
+    // than CBK chunks per wave; evaluations that failed).
+    // ======================================================================================
+#ifndef NPHIP_CB_CHUNKS
+#define NPHIP_CB_CHUNKS 2
+#endif
+    static constexpr int CBK = NPHIP_CB_CHUNKS;   // chunks per wave the fused leaf holds in registers (host.hip: choose_waves_callback)
+    static constexpr int kParkMax = 3 + 6 * (kMaxDepthCap - 1) + 6;   // K, level 0, six values per level >= 1 and for the top-level merge
+    struct CbCrit {
+        uint32_t bits;        // bit k: the criteria of merge level k say "turning"  (level 0 = the pair (source, new leaf))
+        bool turn_top;        // the criteria of the top-level merge (only meaningful for the leaf that completes the doubling)
+        int64_t spec_q, spec_p;   // >= 0: the first half of the NEXT leapfrog has been taken into these buffers
+    };
+    __device__ __forceinline__ bool cb_fast_ok() const { return !INK && NV == 0 && nch <= (int64_t)CBK * W; }
+    // P-slots of A.first / A.last of the sub-tree that waits at merge level k (>= 1) when leaf j of a doubling of depth d arrives
+    __device__ __forceinline__ void level_slots(int64_t j, int64_t d, int k, int64_t& sA, int64_t& sB) const {
+        const int64_t a = j - (2ll << k) + 1, al = j - (1ll << k);
+        sA = (a == 1) ? slot_first((int)d) : slot_first(__builtin_ctzll((unsigned long long)(a - 1)));
+        sB = slot_last(__builtin_ctzll((unsigned long long)al), A.cap);
+    }
+    struct CbRegs { double2 tp[CBK], tr[CBK]; };   // T.last = the new leaf: (p, rho)
+    // the fused pass; L = merge levels >= 1 whose criteria ride along (0, 1).  out = K, level-0 pair, 6 sums per level
+    template <int L>
+    __device__ __forceinline__ void cb_pass1(int64_t newq, int64_t newp, int64_t srcp, int64_t nextq, int64_t nextp, double h, double eps, bool copy_rho,
+                                             const int64_t (&sA)[2], const int64_t (&sB)[2], CbRegs& T_, double (&out)[3 + 6 * L]) {
+        constexpr int LX = L > 0 ? L : 1;
+        double2 acc[3 + 6 * L];
+#pragma unroll
+        for (int n = 0; n < 3 + 6 * L; ++n) { acc[n].x = 0.0; acc[n].y = 0.0; }
+        const double* ge = A.geval + (size_t)chain * D;
+        double *g = G(newq), *pn = P(newp), *rn = R(newp);
+        const double *rp = R(srcp), *ps = P(srcp), *qn = Q(newq);
+        double2 gv[CBK], ph[CBK], s2[CBK], r2[CBK], p2[CBK], q2[CBK], ap[CBK][LX], ar[CBK][LX], bp[CBK][LX], br[CBK][LX];
+        // every read of the pass first (both chunks): one round trip
+#pragma unroll
+        for (int k = 0; k < CBK; ++k) {
+            int64_t cc = wave + (int64_t)k * W;
+            cc = cc < nch ? cc : nch - 1;   // (past the end: the last chunk again, never used — unconditional reads stay in registers)
+            const int64_t i = cc * NPHIP_CHUNK + 2 * lane;
+            const uint32_t ob = (uint32_t)i * 8u;
+            gv[k] = ld2_dense(ge, i, D); ph[k] = ld2b(pn, ob); s2[k] = ld2b(sig2, ob); r2[k] = ld2b(rp, ob); p2[k] = ld2b(ps, ob);
+            if (nextq >= 0) q2[k] = ld2b(qn, ob);
+#pragma unroll
+            for (int l = 0; l < L; ++l) { ap[k][l] = ld2b(P(sA[l]), ob); ar[k][l] = ld2b(R(sA[l]), ob); bp[k][l] = ld2b(P(sB[l]), ob); br[k][l] = ld2b(R(sB[l]), ob); }
+        }
+#pragma unroll
+        for (int k = 0; k < CBK; ++k) {
+            const int64_t cc = wave + (int64_t)k * W;
+            if (cc < nch) {
+                const int64_t i = cc * NPHIP_CHUNK + 2 * lane;
+                const uint32_t ob = (uint32_t)i * 8u;
+                double2 pv, rr;
+                pv.x = fma(h, gv[k].x, ph[k].x);
+                pv.y = fma(h, gv[k].y, ph[k].y);
+                const double vx = s2[k].x * pv.x, vy = s2[k].y * pv.y;
+                acc[0].x = fma(pv.x, vx, acc[0].x);
+                acc[0].y = fma(pv.y, vy, acc[0].y);
+                rr.x = copy_rho ? pv.x : r2[k].x + pv.x;
+                rr.y = copy_rho ? pv.y : r2[k].y + pv.y;
+                // level 0: the pair (source, new leaf) — turning() on the two P-slots, from the registers
+                const double tx0 = (rr.x - r2[k].x) + p2[k].x, ty0 = (rr.y - r2[k].y) + p2[k].y;
+                acc[1].x = fma(tx0, vx, acc[1].x);
+                acc[1].y = fma(ty0, vy, acc[1].y);
+                acc[2].x = fma(tx0, s2[k].x * p2[k].x, acc[2].x);
+                acc[2].y = fma(ty0, s2[k].y * p2[k].y, acc[2].y);
+#pragma unroll
+                for (int l = 0; l < L; ++l) {
+                    const double2 fpv = l == 0 ? p2[k] : ap[k][l > 0 ? l - 1 : 0], frv = l == 0 ? r2[k] : ar[k][l > 0 ? l - 1 : 0];   // T.first of this level
+                    span_acc(ap[k][l].x, ar[k][l].x, pv.x, rr.x, s2[k].x, acc[3 + 6 * l].x, acc[4 + 6 * l].x);      // (A.first, T.last)
+                    span_acc(ap[k][l].y, ar[k][l].y, pv.y, rr.y, s2[k].y, acc[3 + 6 * l].y, acc[4 + 6 * l].y);
+                    span_acc(bp[k][l].x, br[k][l].x, pv.x, rr.x, s2[k].x, acc[5 + 6 * l].x, acc[6 + 6 * l].x);      // (A.last, T.last)
+                    span_acc(bp[k][l].y, br[k][l].y, pv.y, rr.y, s2[k].y, acc[5 + 6 * l].y, acc[6 + 6 * l].y);
+                    span_acc(ap[k][l].x, ar[k][l].x, fpv.x, frv.x, s2[k].x, acc[7 + 6 * l].x, acc[8 + 6 * l].x);    // (A.first, T.first)
+                    span_acc(ap[k][l].y, ar[k][l].y, fpv.y, frv.y, s2[k].y, acc[7 + 6 * l].y, acc[8 + 6 * l].y);
+                }
+                st2b(g, ob, gv[k]);
+                st2b(pn, ob, pv);
+                st2b(rn, ob, rr);
+                if (nextq >= 0) {   // first half of the next leapfrog (lf1), continuing from this leaf
+                    double2 ph2, qq;
+                    ph2.x = fma(h, gv[k].x, pv.x);
+                    ph2.y = fma(h, gv[k].y, pv.y);
+                    qq.x = fma(eps, s2[k].x * ph2.x, q2[k].x);
+                    qq.y = fma(eps, s2[k].y * ph2.y, q2[k].y);
+                    st2b(Q(nextq), ob, qq);
+                    st2b(P(nextp), ob, ph2);
+                    st2_dense(A.qeval + (size_t)chain * D, i, D, qq);
+                }
+                T_.tp[k] = pv; T_.tr[k] = rr;
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < 3 + 6 * L; ++n) out[n] = acc[n].x + acc[n].y;
+        wave_sumN(out);   // (the wave's totals: the waves of the chain are added once, after the last pass — leaf_cb)
+    }
+    // criteria of merge level k (>= 1) against the new leaf in registers: the wave's totals.  (A.first, T.last) || (A.last, T.last) ||
+    // (A.first, T.first); T.first = the first leaf of T: the source of this leapfrog at level 1, A.first of the level below otherwise
+    __device__ __forceinline__ void cb_level(int64_t j, int64_t d, int k, int64_t srcp, const CbRegs& T_, double (&v)[6]) {
+        int64_t sA, sB, sF = srcp, unused;
+        level_slots(j, d, k, sA, sB);
+        if (k > 1) level_slots(j, d, k - 1, sF, unused);
+        double2 acc[6], ap[CBK], ar[CBK], bp[CBK], br[CBK], fp[CBK], fr[CBK], sg[CBK];
+#pragma unroll
+        for (int n = 0; n < 6; ++n) { acc[n].x = 0.0; acc[n].y = 0.0; }
+#pragma unroll
+        for (int q_ = 0; q_ < CBK; ++q_) {
+            int64_t cc = wave + (int64_t)q_ * W;
+            cc = cc < nch ? cc : nch - 1;
+            const int64_t i = cc * NPHIP_CHUNK + 2 * lane;
+            const uint32_t ob = (uint32_t)i * 8u;
+            ap[q_] = ld2b(P(sA), ob); ar[q_] = ld2b(R(sA), ob); bp[q_] = ld2b(P(sB), ob); br[q_] = ld2b(R(sB), ob);
+            fp[q_] = ld2b(P(sF), ob); fr[q_] = ld2b(R(sF), ob); sg[q_] = ld2b(sig2, ob);
+        }
+#pragma unroll
+        for (int q_ = 0; q_ < CBK; ++q_) {
+            if (wave + (int64_t)q_ * W < nch) {
+                span_acc(ap[q_].x, ar[q_].x, T_.tp[q_].x, T_.tr[q_].x, sg[q_].x, acc[0].x, acc[1].x);
+                span_acc(ap[q_].y, ar[q_].y, T_.tp[q_].y, T_.tr[q_].y, sg[q_].y, acc[0].y, acc[1].y);
+                span_acc(bp[q_].x, br[q_].x, T_.tp[q_].x, T_.tr[q_].x, sg[q_].x, acc[2].x, acc[3].x);
+                span_acc(bp[q_].y, br[q_].y, T_.tp[q_].y, T_.tr[q_].y, sg[q_].y, acc[2].y, acc[3].y);
+                span_acc(ap[q_].x, ar[q_].x, fp[q_].x, fr[q_].x, sg[q_].x, acc[4].x, acc[5].x);
+                span_acc(ap[q_].y, ar[q_].y, fp[q_].y, fr[q_].y, sg[q_].y, acc[4].y, acc[5].y);
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < 6; ++n) v[n] = acc[n].x + acc[n].y;
+        wave_sumN(v);
+    }
+    // criteria of the top-level merge (the leaf that completes the doubling), general index modes: (far, T.last) || (near, T.last) ||
+    // (far, T.first); depth 0: (far, T.last) alone — far and near end are the origin
+    __device__ __forceinline__ void cb_top(int64_t d, int64_t far_slot, int64_t far_idx, int64_t near_slot, int64_t near_idx, int64_t dir, int64_t idx_new,
+                                           const CbRegs& T_, double (&v)[6]) {
+        const Pair p1 = pair_of(far_idx, idx_new), p2 = pair_of(near_idx, idx_new), p3 = pair_of(far_idx, near_idx + dir);
+        const int64_t sF = slot_first((int)d);   // T.first = leaf 1 of the doubling
+        double2 acc[6], fa[CBK], fb[CBK], na[CBK], nb[CBK], tfp[CBK], tfr[CBK], sg[CBK];
+#pragma unroll
+        for (int n = 0; n < 6; ++n) { acc[n].x = 0.0; acc[n].y = 0.0; }
+#pragma unroll
+        for (int k = 0; k < CBK; ++k) {
+            int64_t cc = wave + (int64_t)k * W;
+            cc = cc < nch ? cc : nch - 1;
+            const int64_t i = cc * NPHIP_CHUNK + 2 * lane;
+            const uint32_t ob = (uint32_t)i * 8u;
+            fa[k] = ld2b(P(far_slot), ob); fb[k] = ld2b(R(far_slot), ob); sg[k] = ld2b(sig2, ob);
+            if (d > 0) { na[k] = ld2b(P(near_slot), ob); nb[k] = ld2b(R(near_slot), ob); tfp[k] = ld2b(P(sF), ob); tfr[k] = ld2b(R(sF), ob); }
+        }
+#pragma unroll
+        for (int k = 0; k < CBK; ++k) {
+            if (wave + (int64_t)k * W < nch) {
+                pair_acc(p1, fa[k].x, fb[k].x, T_.tp[k].x, T_.tr[k].x, sg[k].x, acc[0].x, acc[1].x);
+                pair_acc(p1, fa[k].y, fb[k].y, T_.tp[k].y, T_.tr[k].y, sg[k].y, acc[0].y, acc[1].y);
+                if (d > 0) {
+                    pair_acc(p2, na[k].x, nb[k].x, T_.tp[k].x, T_.tr[k].x, sg[k].x, acc[2].x, acc[3].x);
+                    pair_acc(p2, na[k].y, nb[k].y, T_.tp[k].y, T_.tr[k].y, sg[k].y, acc[2].y, acc[3].y);
+                    pair_acc(p3, fa[k].x, fb[k].x, tfp[k].x, tfr[k].x, sg[k].x, acc[4].x, acc[5].x);
+                    pair_acc(p3, fa[k].y, fb[k].y, tfp[k].y, tfr[k].y, sg[k].y, acc[4].y, acc[5].y);
+                }
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < 6; ++n) v[n] = acc[n].x + acc[n].y;
+        wave_sumN(v);
+    }
+    // Deferred chain-wide sums of the fused leaf: every group of values is reduced within the wave as soon as its pass is through
+    // and parked in LDS (wave totals, [value][wave]); after the LAST pass one barrier, and every wave adds the wave totals of every
+    // group in wave order — the bits of one rsum() per group, for one barrier instead of one per pass.  (One wave per chain: the
+    // wave totals are the sums.)
+    template <int N>
+    __device__ __forceinline__ void park(const double (&v)[N], int at) {
+        if (W > 1 && lane == 0) {
+#pragma unroll
+            for (int n = 0; n < N; ++n) parked[(at + n) * W + wave] = v[n];
+        }
+    }
+    __device__ __forceinline__ double parked_sum(int at) const {
+        double t = parked[at * W];
+        for (int w = 1; w < W; ++w) t = t + parked[at * W + w];
+        return t;
+    }
+    __device__ __forceinline__ bool parked_any_negative(int at, int n) const {
+        bool t = false;
+        for (int i = 0; i < n; ++i) t = t || (parked_sum(at + i) < 0.0);
+        return t;
+    }
+    template <int N>
+    static __device__ __forceinline__ bool any_negative(const double (&v)[N], int from) {
+        bool t = false;
+#pragma unroll
+        for (int n = 0; n < N; ++n) t = t || (n >= from && v[n] < 0.0);
+        return t;
+    }
+    // The evaluation of the pending tree leapfrog has arrived (finite, code 0): everything cont_tree needs, in as few dependent
+    // passes as the leaf allows.  Returns the kinetic energy.
+    __device__ __forceinline__ double leaf_cb(CbCrit& cr) {
+        // (the control words are the same in every lane: as scalars, so that slots and addresses are scalar too)
+        const int64_t j = rfl(c->nleaf) + 1, d = rfl(c->depth), dir = rfl(c->dir);
+        const int db = dir > 0 ? 1 : 0;
+        const int64_t idx_new = rfl(c->idx_cur) + dir;
+        const int64_t newq = rfl(c->lf_newq), newp = rfl(c->lf_newp), srcp = rfl(c->lf_srcp);
+        const double eps = (double)dir * rfl_f64(c->step_size), h = 0.5 * eps;
+        const bool complete = j == (1ll << d);
+        const bool check = A.s.check_turning && (d + 1 > A.s.mindepth);
+        // merge levels this leaf closes: k = 0 .. nm - 1  (bits 0 .. k of j - 1 set, k < d)
+        int nm = __builtin_ctzll(~(unsigned long long)(j - 1));
+        nm = nm < (int)d ? nm : (int)d;
+        const int nlev = check && nm > 1 ? nm - 1 : 0;   // levels >= 1 with criteria
+        // the next leaf (unless this one completes the doubling): its P-slot by its number, its Q-pool buffer = any that neither
+        // the tree nor this leaf holds (the cursor's own buffer is free once the leapfrog that started from it is done — but the
+        // divergence record reads the state a failed leapfrog started from: no speculation then)
+        cr.spec_q = -1; cr.spec_p = -1;
+        if (!complete && A.tr_div[0] == nullptr) {
+            const int64_t jn = j + 1;
+            if (jn == (1ll << d)) cr.spec_p = slot_end(db, (int)(rfl(c->endpar[db]) ^ 1));
+            else if (jn & 1) cr.spec_p = slot_first(__builtin_ctzll((unsigned long long)(jn - 1)));
+            else cr.spec_p = slot_last(__builtin_ctzll((unsigned long long)jn), A.cap);
+            uint32_t used = (1u << rfl(c->cand_q)) | (1u << rfl(c->endq[0])) | (1u << rfl(c->endq[1])) | (1u << newq);
+            for (uint64_t m = (uint64_t)(j - 1) & ((1ull << kMaxDepthCap) - 1); m != 0; m &= m - 1) used |= 1u << rfl(c->sub_q[__builtin_ctzll(m)]);
+            cr.spec_q = (int64_t)__builtin_ctz(~used);
+        }
+        int64_t sA[2] = {0, 0}, sB[2] = {0, 0};
+        CbRegs T_;
+        double K = 0.0;
+        cr.bits = 0; cr.turn_top = false;
+        const bool copy_rho = idx_new == -1;
+        // parked values: [0] K, [1, 2] level 0, then six per level >= 1, then the six of the top-level merge
+        {
+            double v[3];
+            cb_pass1<0>(newq, newp, srcp, cr.spec_q, cr.spec_p, h, eps, copy_rho, sA, sB, T_, v);
+            if (W == 1) { K = 0.5 * v[0]; cr.bits = ((v[1] < 0.0) || (v[2] < 0.0)) ? 1u : 0u; }
+            else park(v, 0);
+        }
+        // levels >= 1, one pass each (operands mostly in L2; no stores in between, so their reads overlap; ONE barrier at the end).
+        // Two levels per pass or level 1 inside the fused pass need 150+ registers per lane: two waves per SIMD instead of four,
+        // i.e. half of a 1024-chain batch waiting for the other half (measured: 44 against 37 us per step)
+        for (int k0 = 1; k0 <= nlev; ++k0) {
+            double u[6];
+            cb_level(j, d, k0, srcp, T_, u);
+            if (W == 1) cr.bits |= any_negative(u, 0) ? (1u << k0) : 0u;
+            else park(u, 3 + 6 * (k0 - 1));
+        }
+        const bool top = complete && check;
+        const int at_top = 3 + 6 * nlev;
+        if (top) {
+            const int64_t far_idx = rfl(dir > 0 ? c->idx_left : c->idx_right), near_idx = rfl(dir > 0 ? c->idx_right : c->idx_left);
+            double u[6];
+            cb_top(d, rfl(c->endp[1 - db]), far_idx, rfl(c->endp[db]), near_idx, dir, idx_new, T_, u);
+            if (W == 1) cr.turn_top = any_negative(u, 0);
+            else park(u, at_top);
+        }
+        if (W > 1) {
+            __syncthreads();
+            K = 0.5 * parked_sum(0);
+            cr.bits = ((parked_sum(1) < 0.0) || (parked_sum(2) < 0.0)) ? 1u : 0u;
+            for (int k = 1; k <= nlev; ++k) cr.bits |= parked_any_negative(3 + 6 * (k - 1), 6) ? (1u << k) : 0u;
+            if (top) cr.turn_top = parked_any_negative(at_top, 6);
+        }
+        if (!check) cr.bits = 0;
+        return K;
     }
 
     // ---- register-resident leapfrog (NV > 0): one fused pass, no loads when continuing from the cursor ----
@@ -2271,6 +2570,9 @@ struct Machine {
 
     // End-of-draw vector pass: trace row, Welford updates of both estimators, mass-matrix refresh.
     __device__ void position_pass(int64_t draw, bool do_add, bool do_switch, bool do_update, int64_t n_fg, int64_t n_bg) {
+#ifdef NPHIP_PROFILE
+        const int64_t tpp0_ = (int64_t)__builtin_readcyclecounter();
+#endif
         const int64_t cq = c->cand_q;
         const double *q = Q(cq), *g = G(cq);
         const size_t row = ((size_t)chain * T + draw) * D;
@@ -2322,6 +2624,9 @@ struct Machine {
             }
             if (A.tr_mm) st2_dense(A.tr_mm + row, i, D, s);
         }
+#ifdef NPHIP_PROFILE
+        if (!INK) c->prof[10] += (int64_t)__builtin_readcyclecounter() - tpp0_;
+#endif
     }
 
     __device__ __forceinline__ void store_divergence(bool have_end) {
@@ -2441,9 +2746,16 @@ struct Machine {
         start_ss(0xffffffffll);
     }
 
-    __device__ void begin_draw() {
+    __device__ void begin_draw(bool now = false) {
         if (c->draw >= T) { finish_chain(PH_DONE, CE_NONE); return; }
+        if (SLICED && !now) { c->phase = PH_DRAW_BEGIN; return; }   // (a slice of its own: rare_phase)
+#ifdef NPHIP_PROFILE
+        const int64_t tb0_ = (int64_t)__builtin_readcyclecounter();
+#endif
         double K0 = sample_momentum(NPHIP_RNG_MOMENTUM, (uint32_t)c->draw);
+#ifdef NPHIP_PROFILE
+        if (!INK) c->prof[8] += (int64_t)__builtin_readcyclecounter() - tb0_;
+#endif
         c->H0 = K0 + c->cand_U;
         c->depth = 0; c->main_wm = 1.0; c->main_we = 0;
         c->idx_left = 0; c->idx_right = 0;
@@ -2488,9 +2800,21 @@ struct Machine {
         return (k & 1) ? nphip_u01(blk.v[2], blk.v[3]) : nphip_u01(blk.v[0], blk.v[1]);
     }
 
+    // the tree of the draw is complete.  Fused / resident kernels finish the draw on the spot (out of line); the launch-per-evaluation
+    // kernels leave it to the next launch, which does nothing else for this chain
+    __device__ __forceinline__ void draw_complete(bool diverging, bool maxdepth, bool store_div, bool div_has_end) {
+        if (SLICED) {
+            c->pend_end = (diverging ? 1 : 0) | (maxdepth ? 2 : 0) | (store_div ? 4 : 0) | (div_has_end ? 8 : 0);
+            c->phase = PH_DRAW_END;
+        } else {
+            rare_end_draw(A, c, red, chain, diverging, maxdepth, store_div, div_has_end, NOG);
+        }
+    }
     // one leapfrog of the tree has been evaluated: NutsTree::extend / merge_into, unrolled
     // returns true when a rare, non-inlined path ran (the register mirror must then be dropped)
-    __device__ __forceinline__ bool cont_tree(RegsT& X, SCacheT& Y, double K, double lp, int64_t code, bool have_turn0, bool turn0) {
+    // `cr` (callback kernels, leaf_cb): the criteria of every merge this leaf performs were evaluated up front, and the first half
+    // of the next leapfrog may have been taken already
+    __device__ __forceinline__ bool cont_tree(RegsT& X, SCacheT& Y, double K, double lp, int64_t code, bool have_turn0, bool turn0, const CbCrit* cr = nullptr) {
         if (code < 0) { finish_chain(PH_ERROR, CE_FATAL_LOGP); return true; }
         c->nleaf += 1;
         c->n_steps += 1;
@@ -2517,7 +2841,7 @@ struct Machine {
                 c->acc_sym_sum += 2.0 * a / (1.0 + e);
             }
         }
-        if (diverged) { rare_end_draw(A, c, red, chain, true, false, true, ok, NOG); return true; }
+        if (diverged) { draw_complete(true, false, true, ok); return true; }
 
         const int64_t near_idx = dir > 0 ? c->idx_right : c->idx_left;
         const int64_t sT_last = c->lf_newp;
@@ -2535,7 +2859,9 @@ struct Machine {
                 const int64_t sA_first = (a == 1) ? slot_first((int)d) : slot_first(__builtin_ctzll((unsigned long long)(a - 1)));
                 const int64_t iA_first = near_idx + dir * a;
                 bool turn;
-                if (k == 0) {
+                if (cr != nullptr) {
+                    turn = ((cr->bits >> k) & 1u) != 0;
+                } else if (k == 0) {
                     turn = have_turn0 ? turn0 : check_merge(X, 1, sA_first, iA_first, 0, 0, 0, 0, sT_last, idx_new);
                 } else {
                     const int64_t al = j - (1ll << k);      // last leaf of A
@@ -2547,7 +2873,7 @@ struct Machine {
                         turn = check_merge(X, 3, sA_first, iA_first, slot_last(__builtin_ctzll((unsigned long long)al), A.cap), near_idx + dir * al,
                                            slot_first(__builtin_ctzll((unsigned long long)(tf - 1))), near_idx + dir * tf, sT_last, idx_new);
                 }
-                if (turn) { rare_end_draw(A, c, red, chain, false, false, false, false, NOG); return true; }
+                if (turn) { draw_complete(false, false, false, false); return true; }
             }
             {   // multinomial merge: keep T's draw w.p. w_T / (w_A + w_T)
                 double sm; int64_t se;
@@ -2560,14 +2886,22 @@ struct Machine {
         }
         if (k < d) {
             c->sub_wm[k] = T_wm; c->sub_we[k] = T_we; c->sub_q[k] = T_q; c->sub_U[k] = T_U; c->sub_E[k] = T_E; c->sub_idx[k] = T_idx;
-            issue_leaf();
+            if (cr != nullptr && cr->spec_q >= 0) {
+                // the first half of the next leapfrog was taken inside the fused pass: what issue_leaf() / lf1() would record
+                c->lf_srcq = c->curq; c->lf_srcp = c->curp; c->lf_newq = cr->spec_q; c->lf_newp = cr->spec_p; c->lf_sign = c->dir;
+                c->eval_buf = cr->spec_q;
+                c->phase = PH_TREE;
+            } else {
+                issue_leaf();
+            }
             return false;
         }
         // the new sub-tree of depth d is complete: merge into the main tree
         bool turn = false;
         if (check) {
             const int64_t far_slot = c->endp[1 - db], far_idx = dir > 0 ? c->idx_left : c->idx_right;
-            if (d == 0) turn = check_merge(X, 1, far_slot, far_idx, 0, 0, 0, 0, sT_last, idx_new);
+            if (cr != nullptr) turn = cr->turn_top;
+            else if (d == 0) turn = check_merge(X, 1, far_slot, far_idx, 0, 0, 0, 0, sT_last, idx_new);
             else turn = check_merge(X, 3, far_slot, far_idx, c->endp[db], near_idx, slot_first((int)d), near_idx + dir, sT_last, idx_new);
         }
         c->endq[db] = c->lf_newq;
@@ -2585,8 +2919,8 @@ struct Machine {
             c->main_wm = sm; c->main_we = se;
             c->depth = d + 1;
         }
-        if (turn) { rare_end_draw(A, c, red, chain, false, false, false, false, NOG); return true; }
-        if (c->depth >= A.s.maxdepth) { rare_end_draw(A, c, red, chain, false, true, false, false, NOG); return true; }
+        if (turn) { draw_complete(false, false, false, false); return true; }
+        if (c->depth >= A.s.maxdepth) { draw_complete(false, true, false, false); return true; }
         start_doubling();
         return false;
     }
@@ -2621,6 +2955,9 @@ struct Machine {
             m.store_divergence(div_has_end);
         }
         m.end_draw(diverging, maxdepth);
+#ifdef NPHIP_PROFILE
+        if (!INK) ctl->prof[7] += (int64_t)__builtin_readcyclecounter() - t0_;   // callback kernels: the whole draw end
+#endif
         if (W > 1) __syncthreads();
     }
     static __device__ __attribute__((noinline)) void rare_phase_fn(const NPHIP_CONST Args& a, LdsCtl ctl, LdsDouble r, int64_t ch, int64_t ph) {
@@ -2730,6 +3067,8 @@ struct Machine {
             // the host replaced the metric between two draws (nphip_sampler_set_metric): same position, new step-size search
             c->has_initial_mm = 0;
             start_ss(0x80000000ll | c->draw);
+        } else if (ph == PH_DRAW_BEGIN) {
+            begin_draw(true);
         } else if (ph == PH_INIT_EVAL) {
             eval_position(c->eval_buf, lp, code);
             cont_init(lp, code);
@@ -2747,11 +3086,24 @@ struct Machine {
             // this launch finds what a callback launch expects — an evaluation pending
             lf1(c->lf_srcq, c->lf_srcp, c->lf_newq, c->lf_newp, c->lf_sign);
         }
+        bool worked = false;   // SLICED: this launch has advanced the chain already
         for (;;) {
             const int64_t ph = c->phase;
             if (ph == PH_DONE || ph == PH_ERROR || ph == PH_WAIT_HOST) {
                 // a resident launch: the group's rendezvous counts every chain, so a finished one keeps answering the roll
                 if (REMOTE && !DENS) { while (c->hs_last == 0) remote_sync(); }
+                break;
+            }
+            if (SLICED && (ph == PH_DRAW_END || ph == PH_DRAW_BEGIN)) {
+                // a slice of the end of a draw: a launch's worth of work by itself, and it consumes no evaluation (whatever the
+                // callback made of this chain's stale row is ignored)
+                if (worked) break;
+                if (ph == PH_DRAW_END) {
+                    const int64_t pe = c->pend_end;
+                    rare_end_draw(A, c, red, chain, (pe & 1) != 0, (pe & 2) != 0, (pe & 4) != 0, (pe & 8) != 0, NOG);
+                } else {
+                    rare_phase_fn(A, c, red, chain, ph);
+                }
                 break;
             }
             if (ph != PH_START && ph != PH_RESUME_SS) {   // (those two consume no evaluation)
@@ -2765,6 +3117,7 @@ struct Machine {
                     have = false;
                 }
             }
+            worked = true;
             if (ph != PH_TREE) {
                 rare_phase_fn(A, c, red, chain, ph);
                 continue;
@@ -2805,8 +3158,18 @@ struct Machine {
                         // (fused models under the low-rank metric: the two-pass leapfrog of the callback kernels, with the gradient
                         //  evaluated in lf2; the deferred first half is performed here)
                         if (FUSED) lf1(c->lf_srcq, c->lf_srcp, c->lf_newq, c->lf_newp, c->lf_sign);
-                        const double K = lf2(lp, code, c->idx_cur + c->dir);
-                        rare = cont_tree(X, Y, K, lp, code, false, false);
+                        CbCrit cr;
+                        bool fast = false;
+                        if (cb_fast_ok()) {   // callback kernels, rows of up to CBK chunks per wave: the fused leaf (an evaluation that failed: the plain passes)
+                            lp = A.ueval[chain];
+                            code = A.ecode ? A.ecode[chain] : 0;
+                            fast = code == 0 && isfinite(lp);
+                        }
+                        const double K = fast ? leaf_cb(cr) : lf2(lp, code, c->idx_cur + c->dir);
+#ifdef NPHIP_PROFILE
+                        c->prof[0] += (int64_t)__builtin_readcyclecounter() - t0;
+#endif
+                        rare = cont_tree(X, Y, K, lp, code, false, false, fast ? &cr : nullptr);
                     }
                 }
 #ifdef NPHIP_PROFILE
@@ -2841,11 +3204,11 @@ struct Machine {
 // `Ap` points to the engine's argument block in device memory (written once at set-up); it is read through
 // the constant address space, i.e. with scalar loads into SGPRs.  Per-launch scalars are kernel parameters.
 template <bool FUSED, int W, int NV, bool LEAN = false, bool REMOTE = false>
-__global__ __launch_bounds__(W == 1 ? 256 : 64 * W) __attribute__((amdgpu_waves_per_eu(LEAN ? NPHIP_LEAN_OCC(W) : ((NV > 0 && NV <= (W == 1 ? 3 : NPHIP_RW_OCC2_MAX)) ? 2 : 1), LEAN ? NPHIP_LEAN_OCC(W) : ((NV > 0 && NV <= (W == 1 ? 3 : NPHIP_RW_OCC2_MAX)) ? 2 : 8)))) void k_advance(const Args* __restrict__ Ap, int max_evals, int have_result, const LaunchSlice sl) {
+__global__ __launch_bounds__(W == 1 ? 256 : 64 * W) __attribute__((amdgpu_waves_per_eu(LEAN ? NPHIP_LEAN_OCC(W) : ((NV > 0 && NV <= (W == 1 ? 3 : NPHIP_RW_OCC2_MAX)) ? 2 : ((!FUSED && NV == 0 && !REMOTE) ? NPHIP_CB_OCC(W) : 1)), LEAN ? NPHIP_LEAN_OCC(W) : ((NV > 0 && NV <= (W == 1 ? 3 : NPHIP_RW_OCC2_MAX)) ? 2 : 8)))) void k_advance(const Args* __restrict__ Ap, int max_evals, int have_result, const LaunchSlice sl) {
     const NPHIP_CONST Args& A = *(const NPHIP_CONST Args*)Ap;
     constexpr int WAVES = (W == 1) ? 4 : W;
     __shared__ Ctl s_ctl[WAVES];
-    __shared__ double s_red[16 * WAVES];   // two alternating reduction areas
+    __shared__ double s_red[W == 1 ? 8 : 32 * WAVES];   // two alternating reduction areas of 16 values per wave (one wave per chain: DPP only)
     __shared__ __attribute__((aligned(16))) double s_par[(NV > 0 && W == 1) ? 3 * 128 * NV + 8 : 2];
     __shared__ __attribute__((aligned(16))) double s_ring[(NV > 0 && !LEAN) ? WAVES * 4 * 128 * NV : 2];  // per wave: 2 slots x (p, rho)
     __shared__ double s_edge[(NV > 0 && W > 1) ? 2 * W * NV + 2 : 2];   // lean kernels: padded with one 0.0 at each end
@@ -2920,6 +3283,9 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) __attribute__((amdgpu_waves_
     }
     if (LEAN && threadIdx.x == 0) { s_edge[0] = 0.0; s_edge[2 * W * NV + 1] = 0.0; }   // (the first barrier is in the sigma^2 staging)
     LdsCtl c = (LdsCtl)&s_ctl[wib];
+#ifdef NPHIP_PROFILE
+    const int64_t tk0_ = (int64_t)__builtin_readcyclecounter();
+#endif
     {
         const NPHIP_GLOBAL uint64_t* src = (const NPHIP_GLOBAL uint64_t*)(A.ctl + chain);
         NPHIP_LDS uint64_t* dst = (NPHIP_LDS uint64_t*)c;
@@ -2935,8 +3301,13 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) __attribute__((amdgpu_waves_
     }
     Machine<FUSED, W, NV, LEAN, REMOTE> m(A, c, (LdsDouble)s_red, chain, (LdsDouble)s_par, (LdsDouble)s_ring + (LEAN ? 0 : (size_t)wib * 4 * 128 * (NV > 0 ? NV : 1)),
                             (LdsDouble)s_edge);
+    __shared__ double s_park[(!FUSED && NV == 0 && W > 1) ? Machine<FUSED, W, NV, LEAN, REMOTE>::kParkMax * W : 2];
+    m.parked = (LdsDouble)s_park;
     m.run(max_evals, have_result != 0, (LEAN || ((NV == 0 || NV == -1) && W >= 8 && A.sig_lds)) ? (LdsDouble)s_dyn : nullptr, sl.materialise != 0);
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+#ifdef NPHIP_PROFILE
+    if (!FUSED && NV == 0) c->prof[15] += (int64_t)__builtin_readcyclecounter() - tk0_;   // callback kernels: the chain's whole launch
+#endif
     if (W == 1 || wib == 0) {
         NPHIP_GLOBAL uint64_t* dst = (NPHIP_GLOBAL uint64_t*)(A.ctl + chain);
         const NPHIP_LDS uint64_t* src = (const NPHIP_LDS uint64_t*)c;
@@ -2971,7 +3342,7 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) __attribute__((amdgpu_waves_
 #define NPHIP_PART -1
 #endif
 #define NPHIP_HAS(p) (NPHIP_PART == -1 || NPHIP_PART == (p))
-#if defined(NPHIP_DEV_LEAN) || defined(NPHIP_DEV_W1NV)
+#if defined(NPHIP_DEV_LEAN) || defined(NPHIP_DEV_W1NV) || defined(NPHIP_DEV_CB_W)
 #define NPHIP_DEV_BUILD 1   // one kernel instantiation only: seconds instead of minutes
 #endif
 
@@ -3124,7 +3495,17 @@ hipError_t launch_fam_w1(const Args& a, const Args* d_args, hipStream_t st, cons
 // callback kernels
 template <bool FUSED>
 static hipError_t launch_mem_t(const Args& a, const Args* d_args, int W, hipStream_t st, const LaunchSlice sl) {
-#ifdef NPHIP_DEV_BUILD
+#if defined(NPHIP_DEV_CB_W)   // developer build: the callback kernel of ONE geometry
+    if constexpr (!FUSED) {
+        if (W == NPHIP_DEV_CB_W && !a.lr_on) {
+            const unsigned n_ = (unsigned)sl.chain_n;
+            hipLaunchKernelGGL((k_advance<false, NPHIP_DEV_CB_W, 0>), dim3(NPHIP_DEV_CB_W == 1 ? (n_ + 3) / 4 : n_), dim3(NPHIP_DEV_CB_W == 1 ? 256 : 64 * NPHIP_DEV_CB_W),
+                               (NPHIP_DEV_CB_W >= 8 && a.sig_lds) ? (size_t)a.ld * 8 : 0, st, d_args, a.max_evals, a.have_result, sl);
+            return hipGetLastError();
+        }
+    }
+    return hipErrorInvalidValue;
+#elif defined(NPHIP_DEV_BUILD)
     return hipErrorInvalidValue;
 #else
     const unsigned n = (unsigned)sl.chain_n;

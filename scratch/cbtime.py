@@ -11,9 +11,9 @@ dim, chains = int(sys.argv[1]), int(sys.argv[2])
 waves = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 graph = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 tune, draws = (int(sys.argv[5]), int(sys.argv[6])) if len(sys.argv) > 6 else (60, 20)
+hip.lib()   # first: it loads torch's HIP runtime before any other library can pull in a second one
 fix = ctypes.CDLL(os.path.join(ROOT, "tests", "fixtures", "libscaled_normal_device.so"))
 fn = ctypes.cast(fix.scaled_normal_device_fast, ctypes.c_void_p).value
-hip.lib()
 for rep in range(2):
     s = hip.PyNutsSettings.Diag(11)
     s.update(num_tune=tune, num_draws=draws, num_chains=chains)
@@ -24,5 +24,12 @@ for rep in range(2):
     secs = smp.seconds
     n = smp._copy("n_steps", np.int64)
     print(f"scaled normal D={dim} chains={chains} waves={smp.waves_per_chain} graph_steps={graph}: {n.sum() / secs / 1e6:.2f} M leapfrogs/s, job {secs:.3f} s, "
-          f"{smp.launches} launches, {secs / smp.launches * 1e6:.1f} us per step (engine kernel + callback kernel + gaps), mean depth {smp._copy('depth', np.int64).mean():.2f}", flush=True)
+          f"{smp.launches} launches, {secs / n.sum(1).max() * 1e6:.1f} us per evaluation step of the longest chain (engine kernel + callback kernel + gaps; "
+          f"{n.sum(1).max()} evaluations), mean depth {smp._copy('depth', np.int64).mean():.2f}", flush=True)
+    out = (ctypes.c_int64 * 16)(); hip.lib().nphip_sampler_profile(smp._h, out); o = list(out)
+    if o[3]:
+        print(f"   cycles: leaf pass (leaf_cb / lf2) {o[0] / o[3]:.0f} per leaf; whole leaf, no rare path {o[1] / max(o[4], 1):.0f} (n={o[4]}); leaf that ends in a rare path "
+              f"{o[2] / max(o[5], 1):.0f} (n={o[5]}): adapt / position pass {o[13] / max(o[5], 1):.0f}, begin_draw {o[14] / max(o[5], 1):.0f}; "
+              f"whole launch per chain {o[15] / max(smp.launches, 1) / chains:.0f} (sum over {smp.launches} launches)")
+        print(f"   draw end (rare_end_draw, whole) {o[7] / max(o[5], 1):.0f}: position pass alone {o[10] / max(o[5], 1):.0f}, momentum refresh {o[8] / max(o[5], 1):.0f}")
     smp.close()

@@ -9,7 +9,7 @@ SRC=kernels.hip
 if [ -n "$3" ]; then SRC=kernels_variant_$1.hip; sed "$3" kernels.hip > $SRC; cmp -s kernels.hip $SRC && { echo "sed expression changed nothing"; rm -f $SRC; exit 1; }; fi
 /opt/rocm/bin/hipcc $F -c $SRC -o /tmp/dev_$1_k.o
 [ -n "$3" ] && rm -f $SRC
-[ -f /tmp/dev_host.o ] && [ /tmp/dev_host.o -nt host.hip ] || /opt/rocm/bin/hipcc $F -c host.hip -o /tmp/dev_host.o
+[ -f /tmp/dev_host.o ] && [ /tmp/dev_host.o -nt host.hip ] && [ /tmp/dev_host.o -nt engine_types.h ] || /opt/rocm/bin/hipcc $F -c host.hip -o /tmp/dev_host.o
 mkdir -p ../../scratch/libs
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../scratch/libs/$1.so /tmp/dev_$1_k.o /tmp/dev_host.o -pthread
 ls -la ../../scratch/libs/$1.so
