@@ -3743,6 +3743,46 @@ int nphip_jit_logp(uint64_t n_chains, uint64_t dim, const double* q, double* gra
                        (const NphipData*)u->data, n_chains, (int)dim, q, grad, logp, (int)u->lds_doubles, (int)u->shared_doubles, rows_in_lds);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
+int nphip_jit_has_expand(void) {
+#ifdef NPHIP_JIT_EXPAND
+    return 1;
+#else
+    return 0;
+#endif
+}
+#ifdef NPHIP_JIT_EXPAND
+}  // extern "C"
+namespace nphip {
+// The model's expand step (nphip_expand, generated with the density: constrained parameters and deterministic values of ONE draw)
+// over a block of stored draws: one wavefront (NPHIP_JIT_W wavefronts) per row, as the density is evaluated.
+__global__ __launch_bounds__(NPHIP_JIT_W == 1 ? 256 : 64 * NPHIP_JIT_W) void k_expand_batch(const NphipData* __restrict__ data, uint64_t n_rows, int dim, uint64_t expanded,
+                                                      const double* __restrict__ x, double* __restrict__ out, int lds_doubles, int shared_doubles) {
+    extern __shared__ __attribute__((aligned(16))) double s_scratch[];
+    constexpr int CPB = NPHIP_JIT_W == 1 ? 4 : 1;
+    const int slot = NPHIP_JIT_W == 1 ? (int)(threadIdx.x >> 6) : 0, tid = NPHIP_JIT_W == 1 ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
+    const uint64_t row = (uint64_t)blockIdx.x * CPB + slot;
+    double* shared = s_scratch + (size_t)CPB * lds_doubles;
+    nphip_density_stage(*data, shared, (int)threadIdx.x, (int)blockDim.x);
+    __syncthreads();
+    if (row >= n_rows) return;
+    (void)nphip_expand(*data, dim, x + row * (uint64_t)dim, out + row * expanded, s_scratch + (size_t)slot * lds_doubles, shared, tid);
+}
+}  // namespace nphip
+extern "C" {
+// nphip_device_expand_fn (include/nutpie_hip.h); user_data -> nphip_jit_batch_t with the expand function's LDS need
+int nphip_jit_expand(uint64_t n_rows, uint64_t dim, uint64_t expanded_dim, const double* x, double* out, void* stream, void* user_data) {
+    const nphip_jit_batch_t* u = (const nphip_jit_batch_t*)user_data;
+    if (!u) return -1;
+    if (n_rows == 0) return 0;
+    constexpr int CPB = NPHIP_JIT_W == 1 ? 4 : 1;
+    const size_t own = (size_t)CPB * u->lds_doubles + u->shared_doubles;
+    hipLaunchKernelGGL(nphip::k_expand_batch, dim3((unsigned)((n_rows + CPB - 1) / CPB)), dim3(NPHIP_JIT_W == 1 ? 256 : 64 * NPHIP_JIT_W), own * sizeof(double),
+                       (hipStream_t)stream, (const NphipData*)u->data, n_rows, (int)dim, expanded_dim, x, out, (int)u->lds_doubles, (int)u->shared_doubles);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+#else
+int nphip_jit_expand(uint64_t, uint64_t, uint64_t, const double*, double*, void*, void*) { return -1; }
+#endif
 }  // extern "C"
 namespace nphip {
 #endif   // part 7

@@ -120,6 +120,9 @@ def generated_source(user_source: str, layout) -> str:
         struct_source(layout),
         "__device__ double nphip_density(const NphipData& data, int dim, const double* x, double* grad, double* lds, const double* shared, int lane);",
         "__device__ void nphip_density_stage(const NphipData& data, double* shared, int thread, int n_threads);",
+        "// the model also defines its expand step as a device function (nphip_expand: generated by nutpie_amd.symbolic)",
+        "#define NPHIP_JIT_EXPAND 1" if "nphip_expand(" in user_source else "",
+        "__device__ double nphip_expand(const NphipData& data, int dim, const double* x, double* out, double* lds, const double* shared, int lane);" if "nphip_expand(" in user_source else "",
         '#include "kernels.hip"',
         "// the engine's wave reduction (sum over the 64 lanes in the contract's order; the same value in every lane)",
         "// `lds` and `shared` are LDS: through these casts the compiler emits ds_read / ds_write instead of flat accesses",
@@ -203,6 +206,8 @@ class DensityLibrary:
         self.waves = int(self.lib.nphip_jit_w())
         self.launch_addr = C.cast(self.lib.nphip_jit_launch, C.c_void_p).value
         self.logp_addr = C.cast(self.lib.nphip_jit_logp, C.c_void_p).value
+        self.lib.nphip_jit_has_expand.restype = C.c_int
+        self.expand_addr = C.cast(self.lib.nphip_jit_expand, C.c_void_p).value if int(self.lib.nphip_jit_has_expand()) else None
 
 
 class DeviceData:
@@ -258,6 +263,7 @@ class DensitySourceModel(CompiledModel):
     _resident: bool = True                   # False: always the batched callback (launch per evaluation)
     _waves: int = 1                          # wavefronts that evaluate one chain's density together
     _scratch: Any = 0                        # doubles of device-memory scratch per chain (int or function of the data): data.scratch__
+    _expand_lds_bytes: Any = 0               # the source defines nphip_expand (the expand step as a device function): its LDS scratch per row
 
     @property
     def n_dim(self):
@@ -355,6 +361,13 @@ class DensitySourceModel(CompiledModel):
             model.set_init(self._init)
         else:
             model.set_init("explicit", np.asarray(self._init, dtype=np.float64))
+        if lib.expand_addr is not None:
+            # the expand step behind the C-ABI, batched on the device (nphip_model_set_device_expand): one launch per block of stored
+            # draws; the flat rows are split into variables by CompiledModel._unflatten
+            e_lds = int(self._expand_lds_bytes(self._data)) if callable(self._expand_lds_bytes) else int(self._expand_lds_bytes)
+            ebatch = _Batch(dd.ptr, e_lds // 8, shared_bytes // 8)
+            total = sum(int(np.prod(shp, dtype=np.int64)) if len(shp) else 1 for shp in self._shapes)
+            model.set_device_expand(total, lib.expand_addr, C.addressof(ebatch), keep_alive=(lib, dd, ebatch))
         return model
 
     def _make_sampler(self, settings, init_mean, cores, progress_type, extra_callback, extra_callback_rate, store, **engine_kw):
@@ -385,12 +398,15 @@ def _times8(v):
 def from_density_source(ndim: int, source: str, data: dict[str, Any] | None = None, *, lds_doubles_per_chain: int = 0, lds_doubles_shared: int = 0,
                         expand_fn: Callable | None = None, expanded_names: list[str] | None = None, expanded_shapes=None,
                         coords=None, dims=None, init="uniform", resident: bool = True, reparameterized_names=None, waves_per_chain: int = 1,
-                        scratch_doubles_per_chain=0) -> DensitySourceModel:
+                        scratch_doubles_per_chain=0, expand_lds_doubles=0) -> DensitySourceModel:
     """A model from the HIP source of its log-density (module docstring): ``source`` defines ``nphip_density``; ``data`` are the
     arrays / scalars it reads through ``NphipData``; ``lds_doubles_per_chain`` the LDS scratch it uses per chain, ``lds_doubles_shared``
     the LDS its ``nphip_density_stage`` fills once per workgroup (each an int or a function of the data dict: ``with_data`` may
     change the sizes).  ``expand_fn`` (optional)
-    maps a numpy block ``[N, ndim]`` of draws to the dict of expanded variables, as :func:`nutpie_amd.from_torchfunc` does.
+    maps a numpy block ``[N, ndim]`` of draws to the dict of expanded variables, as :func:`nutpie_amd.from_torchfunc` does.  A source
+    that also defines ``__device__ double nphip_expand(const NphipData&, int dim, const double* x, double* out, double* lds, const
+    double* shared, int lane)`` — one row of the flat expanded vector per draw, ``expand_lds_doubles`` of LDS scratch per row —
+    gets its expand step run on the device behind the C-ABI instead.
     ``waves_per_chain`` (1, 2 or 4): that many wavefronts evaluate one chain's density together — the source then strides its loops
     by ``NPHIP_CHAIN_THREADS`` (``lane`` runs over ``0 .. NPHIP_CHAIN_THREADS - 1``), sums with ``nphip_chain_sum*`` and separates
     its phases with ``nphip_chain_barrier()``; with fewer chains than the device has SIMDs (1024) this is what fills it."""
@@ -415,4 +431,4 @@ def from_density_source(ndim: int, source: str, data: dict[str, Any] | None = No
     return DensitySourceModel(dims=dict(dims or {}), _source=source, _n_dim=int(ndim), _data=data, _lds_bytes=_times8(lds_doubles_per_chain), _shared_bytes=_times8(lds_doubles_shared),
                               _names=list(expanded_names), _shapes=[tuple(s) for s in expanded_shapes], _coords=dict(coords or {}),
                               _expand_func=expand_fn, _init=init, _resident=bool(resident), _waves=int(waves_per_chain), _scratch=scratch_doubles_per_chain,
-                              reparameterized_names=reparameterized_names)
+                              _expand_lds_bytes=_times8(expand_lds_doubles), reparameterized_names=reparameterized_names)

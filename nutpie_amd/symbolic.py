@@ -13,7 +13,7 @@ not available on the target image, so this module is the part of that pipeline t
     idx   = m.index("county_idx", county_values, dim="obs", into="county")
     m.add_logp(normal_lpdf(a, 0.0, 1.0).sum())
     m.add_logp(normal_lpdf(y, mu + a[idx], sigma).sum())
-    m.deterministic("a", a)
+    m.deterministic("a_plus_mu", a + mu)            # (the parameters themselves are reported without asking)
     compiled = m.compile()                          # -> nutpie_amd.density.DensitySourceModel
 
 ``compile`` differentiates the expression graph symbolically (reverse mode, the gradient is a graph in the same IR),
@@ -36,8 +36,10 @@ live in per-chain LDS (the largest of them in device memory when the LDS is too 
 observations); the model's data are staged into the workgroup's shared LDS once per launch while they fit.  Everything else is
 recomputed where it is used.
 
-Only the log-density is generated code.  ``deterministic`` values (the reference's expand step: ``compile_pymc.py:601-666``)
-are evaluated on the host with numpy from the drawn positions.
+``deterministic`` values and the constrained parameters (the reference's expand step: ``compile_pymc.py:601-666``) are generated
+code too: a second device function, ``nphip_expand``, that the engine runs over the stored draws in one batched launch
+(``nphip_model_set_device_expand``); values on a data dimension — whose size changes with ``with_data`` — and ``_expand_draws`` of
+positions that did not come out of a sampler are evaluated with numpy from the same graph.
 """
 
 from __future__ import annotations
@@ -49,7 +51,7 @@ import numpy as np
 
 __all__ = ["Model", "Expr", "Matrix", "exp", "log", "log1p", "sqrt", "softplus", "sigmoid", "where_lt", "elem", "stack", "normal_lpdf",
            "halfnormal_lpdf", "student_t_lpdf", "cauchy_lpdf", "halfcauchy_lpdf", "exponential_lpdf", "lognormal_lpdf", "gamma_lpdf",
-           "bernoulli_logit_lpmf", "poisson_log_lpmf"]
+           "bernoulli_logit_lpmf", "poisson_log_lpmf", "dirichlet_lpdf", "flat_lpdf"]
 
 _WAVE = 64
 _UNROLL = 4   # iterations of a loop whose reads are issued together (a lone wave waits out every access otherwise)
@@ -379,6 +381,26 @@ def gamma_lpdf(x, alpha: float, beta) -> Expr:
     return alpha * log(beta) - math.lgamma(alpha) + (alpha - 1.0) * log(x) - beta * x
 
 
+def dirichlet_lpdf(p, a) -> Expr:
+    """Dirichlet log-density of a simplex-valued vector ``p`` (``Model.param(..., simplex=True)``): ``sum((a - 1) log p)`` plus the
+    normalising constant when the concentration ``a`` is one number; with ``a`` a data vector on ``p``'s dimension the constant
+    (which no parameter enters) is dropped."""
+    p = Expr.wrap(p)
+    if p.dim is None:
+        raise ValueError("dirichlet_lpdf needs a vector")
+    if isinstance(a, Expr):
+        return ((a - 1.0) * log(p)).sum()
+    a = float(a)
+    n = p.dim.size
+    const = math.lgamma(n * a) - n * math.lgamma(a) if n is not None else 0.0
+    return ((a - 1.0) * log(p)).sum() + const if a != 1.0 else Expr.const(const)
+
+
+def flat_lpdf(x) -> Expr:
+    """An improper flat prior (``pm.Flat``): contributes nothing to the density — here for models that want to say so."""
+    return Expr.const(0.0)
+
+
 def bernoulli_logit_lpmf(y, eta) -> Expr:
     """y in {0, 1} (data), eta the logit."""
     y, eta = Expr.wrap(y), Expr.wrap(eta)
@@ -569,20 +591,37 @@ def evaluate(nodes: list[Expr], x: np.ndarray, data: dict[str, Any]) -> list[np.
 
 
 # --------------------------------------------------------------------------- code generation
-class _Gen:
-    """logp + gradient -> the source of ``nphip_density``."""
+class _Out:
+    """Where a generated function writes one of its outputs: what ``_Gen`` reads of a parameter node (``dim``, ``payload`` = offset
+    or (offset, valid length)), for outputs that are not gradients — the rows of the generated expand function.  ``perm`` =
+    (rows, columns) of a two-dimensional value that is stored transposed."""
 
-    def __init__(self, model: "Model", logp: Expr, grads: list[Expr], waves: int = 1, profile: bool = False):
+    def __init__(self, dim, payload, perm=None):
+        self.dim, self.payload, self.perm = dim, payload, perm
+
+
+class _Gen:
+    """logp + gradient -> the source of ``nphip_density``; or (``outputs``) a list of reported values -> ``nphip_expand``."""
+
+    def __init__(self, model: "Model", logp: Expr, grads: list[Expr], waves: int = 1, profile: bool = False, outputs=None, fn_name: str = "nphip_density"):
         self.m = model
         self.threads = _WAVE * waves
         self.profile = profile      # cycle counters per section, added into data.prof__ (Model.profile)
         self.sections: list[str] = []
         self.spilled: list[Any] = []   # keys of `stored` that live in device memory (data.scratch__) instead of LDS: Model.compile decides
         self.logp = logp
+        self.fn_name = fn_name
         self.params = model._params
-        # gradient outputs: scalars by lane 0 at the end; vectors in a loop over their dimension
-        self.out_scalar = [(p, g) for p, g in zip(self.params, grads) if p.dim is None]
-        self.out_vector = [(p, _bcast(g, p.dim) if g.dim is None else g) for p, g in zip(self.params, grads) if p.dim is not None]
+        if outputs is not None:
+            # (offset, expression, transposed-as) of every reported value: a row of the expand function's output
+            self.out_scalar = [(_Out(None, off), e) for off, e, _ in outputs if e.dim is None]
+            # (a raw parameter vector reports its free values only: a zero-sum / simplex parameter has one fewer than its dimension)
+            self.out_vector = [(_Out(e.dim, (off, e.payload[1] if e.op == "vparam" else (e.dim.size if e.dim.size is not None else f"n_{e.dim.name}")), perm), e)
+                               for off, e, perm in outputs if e.dim is not None]
+        else:
+            # gradient outputs: scalars by lane 0 at the end; vectors in a loop over their dimension
+            self.out_scalar = [(p, g) for p, g in zip(self.params, grads) if p.dim is None]
+            self.out_vector = [(p, _bcast(g, p.dim) if g.dim is None else g) for p, g in zip(self.params, grads) if p.dim is not None]
         roots = [logp] + [g for _, g in self.out_scalar] + [g for _, g in self.out_vector]
         self.order = _topo(roots)
         self.level: dict[int, int] = {}
@@ -671,13 +710,14 @@ class _Gen:
         """[(key, dim)] in the order of allocation; the size of each entry is its dimension's length."""
         return list(self.stored.items())
 
-    def source(self) -> tuple[str, list]:
+    def source(self, emit_stage: bool = True) -> tuple[str, list]:
         m = self.m
         L: list[str] = []
         emit = L.append
         stage_src, shared_fields = m._stage_source()
-        emit(stage_src)
-        emit("__device__ double nphip_density(const NphipData& data, int dim, const double* x, double* g, double* lds, const double* shared, int lane) {")
+        if emit_stage:
+            emit(stage_src)
+        emit(f"__device__ double {self.fn_name}(const NphipData& data, int dim, const double* x, double* g, double* lds, const double* shared, int lane) {{")
         # dimension lengths, data pointers (shared LDS where staged, else global), LDS scratch
         for d in m._dims.values():
             emit(f"    const int n_{d.name} = {d.len_c()};")
@@ -894,7 +934,9 @@ class _Gen:
                 stages[4].append(f"        {guard}s{n.id} += {val(n.args[0])};")
             for p, gexpr in outs:
                 off, nv = p.payload
-                stages[4].append(f"        if (i_{u} < {nv}) g[{off} + i_{u}] = {val(gexpr)};")
+                perm = getattr(p, "perm", None)
+                at = f"i_{u}" if perm is None else f"((i_{u} % {perm[1]}) * {perm[0]} + i_{u} / {perm[1]})"   # (row-major [rows][cols] stored as [cols][rows])
+                stages[4].append(f"        if (i_{u} < {nv}) g[{off} + {at}] = {val(gexpr)};")
         # all segment sums of one index in one inner loop per unrolled iteration (walking the ranges of several iterations side by
         # side was measured: the extra compares cost more than the overlapped reads save — config 3: 44.7 -> 40.7 M leapfrogs/s)
         for (u, iname), accs in seg.items():
@@ -974,6 +1016,9 @@ class Model:
         self._matrix_cols: dict[str, int] = {}       # matrix data: values per row
         self._terms: list[Expr] = []
         self._det: list[tuple[str, Expr]] = []
+        self._det_dims: dict[str, tuple[str, ...]] = {}       # reported values on a product of two dimensions: the order of the axes in the trace
+        self._products: dict[str, tuple[Dim, Dim, Index, Index]] = {}   # product dimension -> (rows, columns, index to rows, index to columns)
+        self._unconstrained: dict[str, tuple[str, int, int]] = {}       # parameter -> (name of its unconstrained value, offset, free values)
         self._staged = True
 
     # ---- declarations
@@ -1027,20 +1072,69 @@ class Model:
         # value = lower + width sigmoid(raw);  log |d value / d raw| = log width - softplus(raw) - softplus(-raw)
         return sigmoid(raw) * width + lower, math.log(width) - softplus(raw) - softplus(-raw)
 
+    def product(self, rows: str, cols: str) -> Dim:
+        """The dimension of the (rows x cols) values of a two-dimensional quantity, row-major — with the two index arrays that
+        take an element to its row and to its column, so that sums along an axis and broadcasts are the IR's segment sums and
+        gathers (``reduce`` / ``broadcast``)."""
+        name = f"{rows}_x_{cols}"
+        if name in self._products:
+            return self._dims[name]
+        r, c = self.dim(rows), self.dim(cols)
+        if r.size is None or c.size is None:
+            raise ValueError("a product needs two dimensions of fixed size")
+        self.dim(name, r.size * c.size)
+        e = np.arange(r.size * c.size)
+        to_r = self.index(f"{name}_row", e // c.size, dim=name, into=rows)
+        to_c = self.index(f"{name}_col", e % c.size, dim=name, into=cols)
+        self._products[name] = (r, c, to_r, to_c)
+        return self._dims[name]
+
+    def reduce(self, expr: Expr, over: str) -> Expr:
+        """Sum of a two-dimensional value along the axis ``over``: a vector on the other axis."""
+        r, c, to_r, to_c = self._product_of(expr)
+        if over == r.name:
+            return _segsum(expr, to_c)
+        if over == c.name:
+            return _segsum(expr, to_r)
+        raise ValueError(f"{over!r} is not an axis of this value")
+
+    def broadcast(self, vec: Expr, rows: str, cols: str) -> Expr:
+        """A vector on one of the two axes, repeated along the other: a value on the product dimension."""
+        self.product(rows, cols)
+        r, c, to_r, to_c = self._products[f"{rows}_x_{cols}"]
+        if vec.dim is r:
+            return vec[to_r]
+        if vec.dim is c:
+            return vec[to_c]
+        raise ValueError("broadcast: the vector lives on neither axis")
+
+    def _product_of(self, expr: Expr):
+        if expr.dim is None or expr.dim.name not in self._products:
+            raise ValueError("not a two-dimensional value (Model.param(..., dims=(rows, cols)))")
+        return self._products[expr.dim.name]
+
     def param(self, name: str, dim: str | None = None, size: int | None = None, lower: float | None = None, upper: float | None = None,
-              zero_sum: bool = False) -> Expr:
+              zero_sum: bool = False, simplex: bool = False, dims: tuple[str, str] | None = None) -> Expr:
         """A free parameter.  Scalar, or a vector over ``dim``.  ``lower`` / ``upper``: PyMC's default transforms — ``lower + exp(raw)``,
         ``upper - exp(raw)``, or ``lower + (upper - lower) sigmoid(raw)`` with both — with the log-Jacobian added to the density;
-        ``zero_sum``: the vector sums to zero (``size - 1`` free values, PyMC's isometric ZeroSumTransform — no Jacobian term)."""
+        ``zero_sum``: the vector sums to zero (``size - 1`` free values, PyMC's isometric ZeroSumTransform — no Jacobian term);
+        ``simplex``: positive and sums to one (``size - 1`` free values: the softmax of the zero-sum extension of the free values —
+        PyMC's SimplexTransform, the default transform of ``pm.Dirichlet`` — with its log-Jacobian).
+        ``dims=(rows, cols)``: a two-dimensional parameter, a value on ``product(rows, cols)`` (row-major); with ``zero_sum`` every
+        COLUMN sums to zero along ``rows`` (``pmd.ZeroSumNormal(core_dims=(rows,), dims=(rows, cols))``: ``(rows - 1) x cols`` free values)."""
         if name in self._param_names:
             raise ValueError(f"parameter {name!r} is defined twice")
+        if dims is not None:
+            return self._param_2d(name, dims, lower, upper, zero_sum, simplex)
         self._param_names.append(name)
         if dim is None:
             raw = Expr("sparam", (), None, self._n_dim)
             self._params.append(raw)
+            self._unconstrained[name] = (name + ("_log__" if (lower is not None and upper is None) else "_interval__" if lower is not None else
+                                                 "_upper__" if upper is not None else ""), self._n_dim, 1)
             self._n_dim += 1
-            if zero_sum:
-                raise ValueError("zero_sum needs a vector parameter")
+            if zero_sum or simplex:
+                raise ValueError("zero_sum / simplex need a vector parameter")
             value, jac = self._constrain(raw, lower, upper)
             if jac is not None:
                 self._terms.append(jac)
@@ -1049,9 +1143,13 @@ class Model:
         d = self.dim(dim, size)
         if d.size is None:
             raise ValueError("a parameter's dimension needs a fixed size")
-        n_free = d.size - 1 if zero_sum else d.size
+        if zero_sum and simplex:
+            raise ValueError("zero_sum and simplex exclude each other")
+        n_free = d.size - 1 if (zero_sum or simplex) else d.size
         raw = Expr("vparam", (), d, (self._n_dim, n_free))
         self._params.append(raw)
+        self._unconstrained[name] = (name + ("_zerosum__" if zero_sum else "_simplex__" if simplex else "_log__" if (lower is not None and upper is None) else
+                                             "_interval__" if lower is not None else "_upper__" if upper is not None else ""), self._n_dim, n_free)
         self._n_dim += n_free
         if zero_sum:
             if lower is not None or upper is not None:
@@ -1059,6 +1157,43 @@ class Model:
             n = d.size
             s = raw.sum()            # (the padding element reads as 0)
             value = where_lt(d, n - 1, raw - s * (1.0 / (math.sqrt(n) + n)), -s * (1.0 / math.sqrt(n)))
+        elif simplex:
+            if lower is not None or upper is not None:
+                raise ValueError("simplex and bounds exclude each other")
+            # y = (raw, -sum raw);  value = softmax(y) = softmax(y + sum raw): z = raw + s on the free elements, 0 on the last
+            n = d.size
+            s = raw.sum()
+            e = exp(where_lt(d, n - 1, raw + s, 0.0))
+            total = e.sum()
+            value = e / total
+            self._terms.append(math.log(n) + n * s - n * log(total))     # log |det d value[:n-1] / d raw|
+        else:
+            value, jac = self._constrain(raw, lower, upper)
+            if jac is not None:
+                self._terms.append(jac.sum())
+        self._det.append((name, value))
+        return value
+
+    def _param_2d(self, name, dims, lower, upper, zero_sum, simplex):
+        rows, cols = dims
+        if simplex:
+            raise ValueError("a simplex parameter is one-dimensional")
+        prod = self.product(rows, cols)
+        r, c, to_r, to_c = self._products[prod.name]
+        self._param_names.append(name)
+        n_free = (r.size - 1) * c.size if zero_sum else r.size * c.size
+        raw = Expr("vparam", (), prod, (self._n_dim, n_free))     # (row-major: the free rows come first, the padding row reads as 0)
+        self._params.append(raw)
+        self._unconstrained[name] = (name + ("_zerosum__" if zero_sum else "_log__" if (lower is not None and upper is None) else
+                                             "_interval__" if lower is not None else "_upper__" if upper is not None else ""), self._n_dim, n_free)
+        self._n_dim += n_free
+        if zero_sum:
+            if lower is not None or upper is not None:
+                raise ValueError("zero_sum and bounds exclude each other")
+            n = r.size
+            s = _segsum(raw, to_c)                   # per column: the sum of its free values
+            sb = s[to_c]
+            value = where_lt(prod, (n - 1) * c.size, raw - sb * (1.0 / (math.sqrt(n) + n)), -sb * (1.0 / math.sqrt(n)))
         else:
             value, jac = self._constrain(raw, lower, upper)
             if jac is not None:
@@ -1126,11 +1261,18 @@ class Model:
             raise ValueError("a log-density term must be a scalar: sum() it")
         self._terms.append(term)
 
-    def deterministic(self, name: str, expr) -> None:
-        """A value to report in the trace besides the parameters (the reference's expanded variables)."""
+    def deterministic(self, name: str, expr, dims: tuple[str, ...] | None = None) -> None:
+        """A value to report in the trace besides the parameters (the reference's expanded variables).  ``dims``: for a
+        two-dimensional value, the order of its axes in the trace (``(cols, rows)`` reports it transposed)."""
         if any(n == name for n, _ in self._det):
             raise ValueError(f"{name!r} is reported already")
-        self._det.append((name, Expr.wrap(expr)))
+        expr = Expr.wrap(expr)
+        if dims is not None:
+            r, c, _, _ = self._product_of(expr)
+            if tuple(dims) not in ((r.name, c.name), (c.name, r.name)):
+                raise ValueError(f"dims must be a permutation of ({r.name!r}, {c.name!r})")
+            self._det_dims[name] = tuple(dims)
+        self._det.append((name, expr))
 
     # ---- compilation
     @property
@@ -1291,24 +1433,99 @@ class Model:
             return sum(len(data[n]) if k == "double" else (len(data[n]) + 1) // 2 for n, k, _ in fields if k in ("double", "int"))
 
         det = list(self._det)
+        # the unconstrained values of transformed parameters, under PyMC's names (b_log__, c_zerosum__, d_simplex__ ...): they go to
+        # the trace's `unconstrained_posterior` group (reference sample.py:147-160; nutpie.sample(store_unconstrained=True))
+        by_name = dict(zip(self._param_names, self._params))
+        raw_names = []
+        for pname, (uname, _, n_free) in self._unconstrained.items():
+            if uname != pname:
+                det.append((uname, by_name[pname]))
+                raw_names.append(uname)
         names = [n for n, _ in det]
         nodes = [e for _, e in det]
-        shapes = [() if e.dim is None else (e.dim.len_py(self._data),) for e in nodes]
-        auto_dims = {n: (e.dim.name,) for n, e in det if e.dim is not None}
-        auto_coords = {d.name: np.arange(d.size) for d in dim_of.values() if d.size is not None and any(e.dim is d for e in nodes)}
+
+        def shape_of(name, e):
+            if e.dim is None:
+                return ()
+            if e.op == "vparam" and name in raw_names:
+                if e.dim.name in self._products:
+                    r, c, _, _ = self._products[e.dim.name]
+                    return (e.payload[1] // c.size, c.size)
+                return (e.payload[1],)
+            if e.dim.name in self._products:
+                r, c, _, _ = self._products[e.dim.name]
+                return (c.size, r.size) if self._det_dims.get(name) == (c.name, r.name) else (r.size, c.size)
+            return (e.dim.len_py(self._data),)
+
+        def dims_of(name, e):
+            if e.op == "vparam" and name in raw_names:
+                # an unconstrained value keeps its dimension unless the transform took an element away (tests/test_pymc.py:332-346)
+                if e.dim.name in self._products:
+                    r, c, _, _ = self._products[e.dim.name]
+                    return ((r.name if e.payload[1] == r.size * c.size else name + "_dim"), c.name)
+                return (e.dim.name if e.payload[1] == e.dim.size else name + "_dim",)
+            if e.dim.name in self._products:
+                r, c, _, _ = self._products[e.dim.name]
+                return self._det_dims.get(name, (r.name, c.name))
+            return (e.dim.name,)
+
+        shapes = [shape_of(n, e) for n, e in det]
+        auto_dims = {n: dims_of(n, e) for n, e in det if e.dim is not None}
+        used_dims = {dn for ds in auto_dims.values() for dn in ds}
+        auto_coords = {d.name: np.arange(d.size) for d in dim_of.values() if d.size is not None and d.name in used_dims and d.name not in self._products}
+        transposed = {n for n, e in det if n not in raw_names and e.dim is not None and e.dim.name in self._products
+                      and self._det_dims.get(n) == tuple(reversed(dims_of("", e)))}
 
         def expand(positions, /, **data):   # (positional-only: a data array may be called `x`)
             vals = evaluate(nodes, positions, data)
-            return {n: v for n, v in zip(names, vals)}
+            out = {}
+            for (n, e), v in zip(det, vals):
+                if e.op == "vparam" and n in raw_names:
+                    v = np.asarray(v)[:, :e.payload[1]]
+                    out[n] = v.reshape(v.shape[0], *shape_of(n, e))
+                    continue
+                if e.dim is not None and e.dim.name in self._products:
+                    r, c, _, _ = self._products[e.dim.name]
+                    v = np.asarray(v).reshape(-1, r.size, c.size)
+                    v = v.transpose(0, 2, 1) if n in transposed else v
+                out[n] = v
+            return out
+
+        # the same values as a generated device function (the reference's expand step, compile_pymc.py:601-666, on the GPU): one row
+        # of the flat expanded vector per draw, variables in declaration order, each in its trace layout
+        offs, off = [], 0
+        for (n, e), shp in zip(det, shapes):
+            perm = None
+            if n in transposed:
+                r, c, _, _ = self._products[e.dim.name]
+                perm = (r.size, c.size)
+            offs.append((off, e, perm))
+            off += int(np.prod(shp, dtype=np.int64)) if shp else 1
+        fixed = all(e.dim is None or e.dim.size is not None for e in nodes)   # (values on a data dimension change size with the data: host expand)
+        egen = _Gen(self, Expr.const(0.0), [], waves_per_chain, outputs=offs, fn_name="nphip_expand") if (fixed and det) else None
+        expand_src = ""
+        if egen is not None:
+            egen.spilled = []
+            expand_src, _ = egen.source(emit_stage=False)
+            e_dims = [d for key, (_, d) in egen.stored.items()]
+
+            def expand_lds(data):
+                return sum(dim_len(d, data) for d in e_dims)
+        else:
+            def expand_lds(data):
+                return 0
 
         def scratch_per_chain(data):
             return sum(dim_len(d, data) for d in spilled_dims)
 
         data0 = {k: v for k, v in self._data.items() if k != "scratch__"}
+        src = src + ("\n" + expand_src if expand_src else "")
         base = from_density_source(self._n_dim, src, data0, lds_doubles_per_chain=lds_per_chain, lds_doubles_shared=lds_shared if staged else 0,
+                                   expand_lds_doubles=expand_lds if expand_src else 0,
                                    scratch_doubles_per_chain=scratch_per_chain if spilled_dims else 0,
                                    expand_fn=expand, expanded_names=names, expanded_shapes=shapes, coords={**auto_coords, **(coords or {})},
-                                   dims={**auto_dims, **(dims or {})}, init=init, resident=resident, waves_per_chain=waves_per_chain)
+                                   dims={**auto_dims, **(dims or {})}, init=init, resident=resident, waves_per_chain=waves_per_chain,
+                                   reparameterized_names=raw_names)
         import dataclasses
 
         return _symbolic_model_class()(**{f.name: getattr(base, f.name) for f in dataclasses.fields(base)}, _front=self)

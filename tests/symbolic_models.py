@@ -168,5 +168,62 @@ def scalar_only():
     return m
 
 
-ALL = {"radon": radon, "logistic": logistic, "poisson_offsets": poisson_offsets, "scalar_only": scalar_only, "regression": regression,
+def store_extra():
+    """The parameter kinds of the reference's test_pymc_model_store_extra (tests/test_pymc.py:303-349): a normal vector, a positive
+    vector (log transform), a zero-sum vector and a Dirichlet (simplex transform) on a second dimension."""
+    m = S.Model()
+    m.dim("foo", 5)
+    m.dim("bar", 4)
+    a = m.param("a", dim="foo")
+    b = m.param("b", dim="foo", lower=0.0)
+    c = m.param("c", dim="foo", zero_sum=True)
+    d = m.param("d", dim="bar", simplex=True)
+    m.add_logp(S.normal_lpdf(a, 0.0, 1.0).sum() + S.halfnormal_lpdf(b, 1.0).sum() + (-0.5 * (c * c)).sum() + S.dirichlet_lpdf(d, 1.0))
+    return m
+
+
+def dirichlet_counts(seed=6):
+    """A Dirichlet-multinomial: concentration 2.5, observed counts as data on the simplex's dimension (the posterior is Dirichlet
+    with concentration 2.5 + counts: a known answer for the simplex transform and its Jacobian)."""
+    counts = np.array([12.0, 3.0, 0.0, 7.0, 30.0, 1.0])
+    m = S.Model()
+    m.dim("cat", 6)
+    p = m.param("p", dim="cat", simplex=True)
+    k = m.data("counts", counts, dim="cat")
+    m.add_logp(S.dirichlet_lpdf(p, 2.5) + (k * S.log(p)).sum())
+    m.deterministic("odds_first", S.elem(p, 0) / S.elem(p, 4))
+    return m
+
+
+def dims_model():
+    """The reference's test_dims_model (tests/test_pymc.py:618-640): a zero-sum normal over the core dimension a of a value with
+    dims (a, b), and a deterministic reported with its axes the other way round."""
+    m = S.Model()
+    m.dim("a", 3)
+    m.dim("b", 5)
+    z = m.param("zero_sum", dims=("a", "b"), zero_sum=True)
+    m.add_logp((-0.5 * (z * z)).sum())
+    m.deterministic("one_sum", z + 1.0 / 3.0, dims=("b", "a"))
+    m.deterministic("col_sum", m.reduce(z, over="a"))
+    return m
+
+
+def no_prior():
+    """The reference's test_pymc_model_no_prior (tests/test_pymc.py:210-222): a flat prior, one observation."""
+    m = S.Model()
+    a = m.param("a")
+    m.add_logp(S.flat_lpdf(a) + S.normal_lpdf(0.0, a, 1.0))
+    return m
+
+
+def uniform_det():
+    """The reference's test_trafo / test_det (tests/test_pymc.py:352-380): a Uniform(0, 1) vector (interval transform) and twice it."""
+    m = S.Model()
+    a = m.param("a", dim="two", size=2, lower=0.0, upper=1.0)
+    m.deterministic("b", 2.0 * a)
+    m.add_logp(0.0 * a.sum())      # (uniform on the interval: only the transform's Jacobian remains)
+    return m
+
+
+ALL = {"store_extra": store_extra, "dirichlet_counts": dirichlet_counts, "dims_model": dims_model, "no_prior": no_prior, "uniform_det": uniform_det, "radon": radon, "logistic": logistic, "poisson_offsets": poisson_offsets, "scalar_only": scalar_only, "regression": regression,
        "plain_regression": plain_regression, "eight_schools": eight_schools, "nested": nested}

@@ -167,3 +167,52 @@ def test_intermediate_arrays_in_device_memory(hip):
     b = nutpie_amd.sample(front.compile(resident=False), chains=24, tune=100, draws=40, seed=6, progress_bar=False)
     assert np.array_equal(a.posterior.sigma.values, b.posterior.sigma.values)
     assert abs(a.posterior.sigma.values.mean() - 0.75) < 0.03
+
+
+@pytest.mark.parametrize("name", ["store_extra", "dirichlet_counts", "dims_model", "uniform_det", "eight_schools", "radon", "regression"])
+def test_generated_expand_equals_the_numpy_evaluation(hip, name):
+    """The expand step as generated device code (nphip_expand behind nphip_model_set_device_expand: SURVEY §8f N2 for models of
+    the front-end) against the numpy evaluation of the same graph: a sampled trace's expanded variables, variable by variable —
+    shapes as the reference reports them (transposed two-dimensional values included)."""
+    m = zoo.ALL[name]().compile()
+    tr = nutpie_amd.sample(m, chains=6, tune=60, draws=40, seed=9, progress_bar=False, return_raw_trace=True)
+    assert tr.expanded is not None and "__flat__" in tr.expanded          # the engine's expand ran, on the device
+    got = m._unflatten(tr.expanded["__flat__"])
+    want = m._expand_draws(tr.draws)
+    assert list(got) == list(want) == list(m.shapes)
+    for k in want:
+        assert got[k].shape == want[k].shape == (6, 100, *m.shapes[k])
+        np.testing.assert_allclose(got[k], want[k], rtol=1e-12, atol=1e-13, err_msg=k)
+
+
+def test_reference_front_end_models_sample(hip):
+    """The reference's own front-end test models (tests/test_pymc.py:303-349, 618-640, 210-222) through `nutpie_amd.sample`: what
+    the reference asserts about `trace.posterior`, and the posteriors' known answers."""
+    tr = nutpie_amd.sample(zoo.store_extra().compile(), chains=64, tune=300, draws=300, seed=3, progress_bar=False, store_unconstrained=True,
+                           store_mass_matrix=True, store_gradient=True)
+    assert tr.posterior.c.dims == ("chain", "draw", "foo") and tr.posterior.d.dims == ("chain", "draw", "bar")
+    # tests/test_pymc.py:331-346: the unconstrained values under PyMC's names; a transform that takes an element away takes the dim away
+    up = tr.unconstrained_posterior
+    assert up.b_log__.dims == ("chain", "draw", "foo") and up.c_zerosum__.dims != ("chain", "draw", "foo") and up.d_simplex__.dims != ("chain", "draw", "bar")
+    assert "b_log__" not in tr.posterior and up.c_zerosum__.shape == (64, 300, 4) and up.d_simplex__.shape == (64, 300, 3)
+    np.testing.assert_allclose(np.exp(up.b_log__.values), tr.posterior.b.values, rtol=1e-13)
+    np.testing.assert_array_equal(tr.sample_stats.unconstrained_draw.values[..., 5:10], up.b_log__.values)
+    assert tr.sample_stats.gradient.shape == tr.sample_stats.mass_matrix_inv.shape == (64, 300, 17)
+    c, d, b = tr.posterior.c.values, tr.posterior.d.values, tr.posterior.b.values
+    np.testing.assert_allclose(c.sum(-1), 0, atol=1e-12)
+    np.testing.assert_allclose(d.sum(-1), 1, atol=1e-12)
+    assert abs(d.mean() - 0.25) < 0.01 and abs(b.mean() - np.sqrt(2 / np.pi)) < 0.03
+    # Dirichlet(1, 1, 1, 1): every component is Beta(1, 3): variance 3 / 80
+    assert abs(d.var() - 3.0 / 80.0) < 0.004
+    post = nutpie_amd.sample(zoo.dims_model().compile(), chains=8, tune=200, draws=100, seed=1, progress_bar=False).posterior
+    assert post["zero_sum"].dims == ("chain", "draw", "a", "b") and post["one_sum"].dims == ("chain", "draw", "b", "a")
+    np.testing.assert_allclose(post["zero_sum"].values.sum(2), 0, atol=1e-5)       # over a
+    np.testing.assert_allclose(post["one_sum"].values.sum(3), 1, atol=1e-5)
+    tr = nutpie_amd.sample(zoo.no_prior().compile(), chains=64, tune=300, draws=300, seed=5, progress_bar=False)
+    a = tr.posterior.a.values
+    assert abs(a.mean()) < 0.05 and abs(a.std() - 1.0) < 0.05      # a | b = 0 ~ N(0, 1)
+    # Dirichlet-multinomial: the posterior is Dirichlet(2.5 + counts)
+    tr = nutpie_amd.sample(zoo.dirichlet_counts().compile(), chains=128, tune=400, draws=400, seed=8, progress_bar=False)
+    alpha = 2.5 + np.array([12.0, 3.0, 0.0, 7.0, 30.0, 1.0])
+    np.testing.assert_allclose(tr.posterior.p.values.mean((0, 1)), alpha / alpha.sum(), atol=0.004)
+    assert tr.sample_stats.diverging.values.mean() < 0.01

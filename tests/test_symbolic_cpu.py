@@ -146,7 +146,7 @@ def test_compile_pymc_model_accepts_the_front_end(tmp_path, monkeypatch):
 
     m = zoo.scalar_only()
     compiled = nutpie_amd.compile_pymc_model(m)
-    assert compiled.n_dim == 2 and list(compiled.shapes) == ["a", "b"]
+    assert compiled.n_dim == 2 and [k for k in compiled.shapes if k not in compiled.reparameterized_names] == ["a", "b"]
     with pytest.raises((ImportError, NotImplementedError)):
         nutpie_amd.compile_pymc_model(object())
 
@@ -175,3 +175,76 @@ def test_multi_wave_sources_cross_compile(name, waves):
     m = zoo.ALL[name]().compile(waves_per_chain=waves)
     assert m._waves == waves and "nphip_chain_barrier" in m._source
     assert os.path.exists(compile_density(m._source, data_layout(m._data), m.n_dim, waves=waves))
+
+
+def test_simplex_transform_and_its_jacobian():
+    """`param(simplex=True)` (PyMC's SimplexTransform, the default of pm.Dirichlet: tests/test_pymc.py:312): positive, sums to one,
+    and the log-Jacobian the model adds equals log |det d value[:n-1] / d raw| (finite differences)."""
+    m = S.Model()
+    m.dim("bar", 4)
+    d = m.param("d", dim="bar", simplex=True)
+    m.add_logp(S.flat_lpdf(d))          # nothing but the transform's Jacobian
+    cm = m.compile()
+    assert cm.n_dim == 3 and cm.shapes == {"d": (4,), "d_simplex__": (3,)}
+    rng = np.random.default_rng(1)
+    for x in rng.normal(size=(4, 3)) * np.array([[0.3], [1.0], [2.0], [4.0]]):
+        value = lambda v: cm._expand_func(v[None], **cm._data)["d"][0]  # noqa: E731
+        p = value(x)
+        assert np.all(p > 0) and abs(p.sum() - 1.0) < 1e-14
+        J = np.stack([(value(x + h)[:3] - value(x - h)[:3]) / 2e-6 for h in 1e-6 * np.eye(3)], axis=1)
+        lp, _ = cm.logp_and_grad_numpy(x[None])
+        np.testing.assert_allclose(lp[0], np.log(abs(np.linalg.det(J))), rtol=1e-6)
+
+
+def test_reference_test_models_shapes_and_constraints():
+    """The model shapes of the reference's own front-end tests, written with the front-end: what `trace.posterior` must look like
+    (tests/test_pymc.py:303-349: dims of c and d; :618-640: (a, b) / transposed (b, a), sums to 0 and to 1; :352-380; :210-222)."""
+    rng = np.random.default_rng(3)
+    se = zoo.store_extra().compile()
+    assert se.n_dim == 5 + 5 + 4 + 3
+    assert se.shapes == {"a": (5,), "b": (5,), "c": (5,), "d": (4,), "b_log__": (5,), "c_zerosum__": (4,), "d_simplex__": (3,)}
+    assert se.dims["c"] == ("foo",) and se.dims["d"] == ("bar",)
+    # the unconstrained values (the trace's unconstrained_posterior group): b_log__ keeps the dimension, c_zerosum__ and d_simplex__
+    # lose an element and with it the dimension (tests/test_pymc.py:332-346)
+    assert se.reparameterized_names == ["b_log__", "c_zerosum__", "d_simplex__"]
+    assert se.dims["b_log__"] == ("foo",) and se.dims["c_zerosum__"] != ("foo",) and se.dims["d_simplex__"] != ("bar",)
+    xs = rng.normal(size=(6, se.n_dim))
+    ex = se._expand_func(xs, **se._data)
+    assert np.array_equal(ex["b_log__"], xs[:, 5:10]) and np.array_equal(ex["c_zerosum__"], xs[:, 10:14]) and np.array_equal(ex["d_simplex__"], xs[:, 14:17])
+    assert np.all(ex["b"] > 0) and np.abs(ex["c"].sum(-1)).max() < 1e-14 and np.abs(ex["d"].sum(-1) - 1).max() < 1e-14 and np.all(ex["d"] > 0)
+    dm = zoo.dims_model().compile()
+    assert dm.n_dim == 2 * 5 and dm.shapes == {"zero_sum": (3, 5), "one_sum": (5, 3), "col_sum": (5,), "zero_sum_zerosum__": (2, 5)}
+    assert {k: dm.dims[k] for k in ("zero_sum", "one_sum", "col_sum")} == {"zero_sum": ("a", "b"), "one_sum": ("b", "a"), "col_sum": ("b",)}
+    assert set(dm.coords) == {"a", "b"}
+    x = rng.normal(size=(4, dm.n_dim))
+    ex = dm._expand_func(x, **dm._data)
+    np.testing.assert_allclose(ex["zero_sum"].sum(1), 0, atol=1e-14)          # along a, for every b
+    np.testing.assert_allclose(ex["one_sum"].sum(2), 1, atol=1e-14)
+    np.testing.assert_array_equal(ex["one_sum"], ex["zero_sum"].transpose(0, 2, 1) + 1.0 / 3.0)
+    lp, _ = dm.logp_and_grad_numpy(x)
+    np.testing.assert_allclose(lp, -0.5 * (x * x).sum(1), rtol=1e-13)         # the zero-sum extension is an isometry
+    ud = zoo.uniform_det().compile()
+    ex = ud._expand_func(3.0 * rng.normal(size=(50, 2)), **ud._data)
+    assert ex["a"].shape == (50, 2) and ex["a"].min() > 0 and ex["a"].max() < 1 and np.array_equal(ex["b"], 2.0 * ex["a"])
+    npm = zoo.no_prior().compile()
+    lp, g = npm.logp_and_grad_numpy(np.array([[0.7]]))
+    np.testing.assert_allclose(g[0, 0], -0.7)                                   # a flat prior adds nothing
+
+
+def test_expand_step_is_generated_too():
+    """`deterministic` values and the constrained parameters are a generated device function (`nphip_expand`) next to the density,
+    exported behind the C-ABI's device-expand signature; values on a data dimension stay with the host evaluation."""
+    for name in ("store_extra", "dims_model", "eight_schools", "radon"):
+        cm = zoo.ALL[name]().compile()
+        assert "__device__ double nphip_expand(const NphipData& data" in cm._source and cm._source.count("nphip_density_stage(") <= 1
+    assert "((i_0 % 5) * 3 + i_0 / 5)" in zoo.dims_model().compile()._source       # one_sum is stored transposed: (a, b) -> (b, a)
+    from nutpie_amd.density import data_layout, generated_source
+
+    cm = zoo.store_extra().compile()
+    assert "#define NPHIP_JIT_EXPAND 1" in generated_source(cm._source, data_layout(cm._data))
+    m = S.Model()
+    mu = m.param("mu")
+    y = m.data("y", np.arange(5.0), dim="obs")
+    m.add_logp(S.normal_lpdf(y, mu, 1.0).sum())
+    m.deterministic("resid", y - mu)                    # lives on a data dimension: its length changes under with_data
+    assert "nphip_expand" not in m.compile()._source
