@@ -227,8 +227,12 @@ class LowRankSampler:
             idx = torch.as_tensor(chains, device=sig2.device)
             if len(chains) != sig2.shape[0]:
                 sig2, V, lam = sig2[idx].contiguous(), V[idx].contiguous(), lam[idx].contiguous()
+            # only the columns some chain uses (estimate() puts a chain's used columns first): every column handed in costs every
+            # leapfrog of every chain a dot product and an update in both halves of the step — sixteen when two or three are live
+            k_used = int((lam != 1.0).sum(1).max().item()) if lam.numel() else 0
+            V, lam = V[:, :k_used].contiguous(), lam[:, :k_used].contiguous()
             torch.cuda.synchronize(self._device)
-            self._inner.set_metric(chains, sig2, V, lam)
+            self._inner.set_metric(chains, sig2, V if k_used else None, lam if k_used else None)
         self._lo = hi
         self._next += 1
         self.switch_log.append((hi, float((T_new.d != 0).sum(1).double().mean()), time.perf_counter() - t0))
