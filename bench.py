@@ -236,6 +236,13 @@ def roofline(dim, W, chains, leap_per_launch, avg_kernel_s):
         waves = min(chains * W, N_SIMD * 8)
         peak = waves * CLOCK_HZ / CYCLES_PER_ISSUE / 1e9
         ach = ipl * leap_per_launch / avg_kernel_s / 1e9
+        # the honest companion figure: of the instructions the kernel issues per leapfrog, how many are the fp64 operations
+        # the mathematics needs — 19 per element (leapfrog 9, gradient 5, logp 1, level-0 criterion 4), 16 elements per lane at D = 1000
+        useful = 19.0 * ((dim + 127) // 128) * 2
+        out["useful_work"] = {"useful_fp64_insts_per_leapfrog": useful, "fraction_of_issued": useful / ipl,
+                              "fraction_of_issue_slots": useful * leap_per_launch / avg_kernel_s / 1e9 / peak,
+                              "note": "19 fp64 operations per element x elements per lane; everything else the kernel issues is tree bookkeeping, reductions, "
+                                      "register traffic (AGPR moves, SGPR spill lanes) and address arithmetic"}
         out.update({"bound": "issue", "achieved": ach, "peak": peak, "unit": "G wave-instructions/s", "frac": ach / peak,
                     "issue": {"insts_per_leapfrog": e["insts_per_leapfrog"], "pmc_issuing_fraction_of_wave_cycles": e.get("issuing_fraction"),
                               "pmc_waiting_fraction_of_wave_cycles": e.get("waiting_fraction"), "resident_waves": waves,

@@ -45,6 +45,7 @@ positions that did not come out of a sampler are evaluated with numpy from the s
 from __future__ import annotations
 
 import math
+import weakref
 from typing import Any
 
 import numpy as np
@@ -111,12 +112,14 @@ class Expr:
     """A node of the expression graph.  ``dim`` is None for scalars.  Nodes are hash-consed by ``Model``-independent structural
     keys, so that the gradient graph shares its sub-expressions with the forward graph."""
 
-    _table: dict[tuple, "Expr"] = {}
+    _table: "weakref.WeakValueDictionary[tuple, Expr]" = None   # (weak: the nodes of a discarded model are collected with it)
     _count = 0
     __array_ufunc__ = None     # numpy scalars defer to the operators below
 
     def __new__(cls, op: str, args: tuple = (), dim: Dim | None = None, payload: Any = None):
         key = (op, tuple(id(a) for a in args), id(dim) if dim is not None else None, payload if not isinstance(payload, (Index, Dim)) else id(payload))
+        if Expr._table is None:
+            Expr._table = weakref.WeakValueDictionary()
         hit = Expr._table.get(key)
         if hit is not None:
             return hit
@@ -1364,14 +1367,17 @@ class Model:
     #: (p, rho) summaries (4 KB per chunk of 128 dimensions), per chain the position and gradient rows — nphip_model_jit_density
     LDS_BYTES = 160 * 1024
 
-    def _lds_budget(self, waves: int) -> int:
+    def _lds_budget(self, waves: int, data=None) -> int:
         """bytes of LDS one chain may use for its scratch with ``waves`` waves per chain"""
         nch = (self._n_dim + 127) // 128
         nv = (nch + waves - 1) // waves
         cpb, nwaves, ld = (4, 4, nv * 128) if waves == 1 else (1, waves, nv * 128 * waves)
         fixed = nwaves * 1200 + 1024 + nwaves * nv * 4096 + 64 + 16 * waves * nv + cpb * 2 * ld * 8
-        shared = 8 * self._shared_doubles(self._data)
+        shared = 8 * self._shared_doubles(self._data if data is None else data)
         return (self.LDS_BYTES - 2048 - fixed - shared) // cpb
+
+    def _lds_budget_for(self, waves: int, data) -> int:
+        return self._lds_budget(waves, data)
 
     def _lds_fits(self, gen, waves: int) -> bool:
         per_chain = 8 * sum(d.len_py(self._data) for key, (_, d) in gen.stored.items() if key not in gen.spilled)
@@ -1444,7 +1450,8 @@ class Model:
         names = [n for n, _ in det]
         nodes = [e for _, e in det]
 
-        def shape_of(name, e):
+        def shape_of(name, e, data=None):
+            data = self._data if data is None else data
             if e.dim is None:
                 return ()
             if e.op == "vparam" and name in raw_names:
@@ -1455,7 +1462,7 @@ class Model:
             if e.dim.name in self._products:
                 r, c, _, _ = self._products[e.dim.name]
                 return (c.size, r.size) if self._det_dims.get(name) == (c.name, r.name) else (r.size, c.size)
-            return (e.dim.len_py(self._data),)
+            return (e.dim.len_py(data),)
 
         def dims_of(name, e):
             if e.op == "vparam" and name in raw_names:
@@ -1470,6 +1477,10 @@ class Model:
             return (e.dim.name,)
 
         shapes = [shape_of(n, e) for n, e in det]
+        # (what with_data needs to re-derive for new data: the shapes of values on a data dimension, and whether the LDS plan —
+        #  staging, waves per chain, what was moved to device memory: decided here, from THIS data — still holds)
+        self._shapes_for = lambda data: [shape_of(n, e, data) for n, e in det]
+        self._plan_check = lambda data: (8 * lds_per_chain(data), self._lds_budget_for(waves_per_chain, data))
         auto_dims = {n: dims_of(n, e) for n, e in det if e.dim is not None}
         used_dims = {dn for ds in auto_dims.values() for dn in ds}
         auto_coords = {d.name: np.arange(d.size) for d in dim_of.values() if d.size is not None and d.name in used_dims and d.name not in self._products}
@@ -1574,7 +1585,13 @@ def _symbolic_model_class():
                         rows = len(new[name]) // f._matrix_cols.get(name, 1) if kind in ("double", "int") else 0
                         if dd is d and kind in ("double", "int") and not name.endswith("__rows") and rows != n:
                             raise ValueError(f"data on dimension {d.name!r} must share one length ({name!r} has {rows}, {d.runtime_len!r} has {n})")
-            return dataclasses.replace(self, _data=new)
+            # what compile() decided from the ORIGINAL data: re-derive the shapes of values on a data dimension, and refuse — here,
+            # not after the run — data that no longer fit the LDS plan (staging, waves per chain, spilled arrays)
+            need, budget = f._plan_check(new)
+            if need > budget:
+                raise ValueError(f"the new data do not fit the LDS plan compile() made for the original data ({need} bytes of scratch per chain needed, "
+                                 f"{max(budget, 0)} left beside the staged data): compile the model again with data of this size")
+            return dataclasses.replace(self, _data=new, _shapes=[tuple(s_) for s_ in f._shapes_for(new)])
 
         def logp_and_grad_numpy(self, x):
             """The same graph evaluated with numpy (host; for checking a model, not for sampling)."""

@@ -248,3 +248,34 @@ def test_expand_step_is_generated_too():
     m.add_logp(S.normal_lpdf(y, mu, 1.0).sum())
     m.deterministic("resid", y - mu)                    # lives on a data dimension: its length changes under with_data
     assert "nphip_expand" not in m.compile()._source
+
+
+def test_with_data_rederives_shapes_and_checks_the_plan():
+    """`with_data` may change the length of a data dimension (only the rank is fixed, as in the reference:
+    compile_pymc.py:140-166).  Shapes of reported values on that dimension follow the new data, and data that no longer fit the LDS
+    plan of compile() are refused at `with_data` — not after the run, in a reshape."""
+    m = S.Model()
+    mu = m.param("mu")
+    y = m.data("y", np.arange(5.0), dim="obs")
+    m.add_logp(S.normal_lpdf(y, mu, 1.0).sum())
+    m.deterministic("resid", y - mu)
+    cm = m.compile()
+    assert cm.shapes == {"mu": (), "resid": (5,)}
+    cm2 = cm.with_data(y=np.arange(9.0))
+    assert cm2.shapes == {"mu": (), "resid": (9,)} and cm.shapes["resid"] == (5,)
+    ex = cm2._expand_draws(np.zeros((2, 3, 1)))
+    assert ex["resid"].shape == (2, 3, 9) and np.array_equal(ex["resid"][0, 0], np.arange(9.0))
+    with pytest.raises(ValueError, match="do not fit the LDS plan"):
+        cm.with_data(y=np.zeros(200_000))
+
+
+def test_expression_table_does_not_outlive_its_models():
+    import gc
+
+    m = zoo.eight_schools()
+    _ = m.logp_expr()
+    assert len(S.Expr._table) > 50
+    before = len(S.Expr._table)
+    del m, _
+    gc.collect()
+    assert len(S.Expr._table) < before
