@@ -294,6 +294,26 @@ def spawn_ranks(args, argv):
     return subprocess.run(cmd, env=env).returncode
 
 
+class _stdout_to_stderr:
+    """fd 1 -> fd 2 for the duration: RCCL prints a version banner through C stdio when its first communicator is created, and
+    stdout is for the ONE JSON line."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        try:
+            import ctypes
+
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 class Env:
     """What differs between a real run (GPU, RCCL) and the stub used by the CPU plumbing test (no device, gloo)."""
 
@@ -322,6 +342,9 @@ class Env:
                 dist.init_process_group("gloo")
             else:
                 dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+                with _stdout_to_stderr():   # (the communicator is created by the first collective)
+                    dist.barrier()
+                    torch.cuda.synchronize()
             self.dist = dist
         if self.stub:
             import importlib.util
@@ -345,6 +368,9 @@ class Env:
             else:
                 dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{free_port()}", rank=0, world_size=1,
                                         device_id=self.torch.device("cuda", self.device))
+                with _stdout_to_stderr():
+                    dist.barrier()
+                    self.torch.cuda.synchronize()
             self.dist = dist
         return self.dist
 

@@ -75,21 +75,22 @@ def run_shape_summary(x):
 
 def test_reference_values_against_a_calibrated_ensemble(hip, bs_standin):
     """the law test, quantified.  The engine runs the reference's run shape (2 chains, tune 100, draws 100:
-    tests/test_pymc.py:533-552) 1000 times — one job of 2000 chains; a chain's stream is keyed by (seed, chain id), so chains
+    tests/test_pymc.py:533-552) 4000 times — one job of 8000 chains; a chain's stream is keyed by (seed, chain id), so chains
     (2k, 2k + 1) are run k and run 0 is the very call the reference's test makes — and the reference's 200 values are ranked inside
     that ensemble, statistic by statistic.
 
-    Measured (also with 2000 runs of the CPU oracle, which is the same sampler bit for bit): the reference's realisation lies in
-    the tails of this sampler's law — pooled mean 0.560 at rank 0.001 (ensemble median 0.797), chain means 0.477 / 0.643 at ranks
-    0.004 / 0.009, KS distance 0.211 and lag-1 autocorrelation 0.853 at rank 0.994 — the same excursion (six consecutive draws
-    below 0.13 in chain 0) seen by five correlated statistics.  One realisation cannot tell a 1-in-300 draw of the same law from
-    a sampler whose short warm-up adapts differently (the constants of nuts-rs 0.18.3's adaptation are recalled, not pinned:
-    oracle/nuts_oracle.h); what the test pins is the QUANTIFIED statement: every statistic of the reference's file lies inside the
-    0.05 % .. 99.95 % envelope of the ensemble, the ensemble itself is calibrated against HalfNormal(1), and the ranks are
-    reported.  (The previous test accepted any KS distance below 0.35 — looser than the ensemble's own 99.9th percentile, 0.23.)"""
+    Measured (the same 4000 runs of the CPU oracle, which is this sampler bit for bit): the reference's realisation lies in the
+    TAILS of this sampler's law — pooled mean 0.560 at rank 0.0010 (4 of 4000 runs below it; ensemble median 0.797), chain means
+    0.477 / 0.643 at ranks 0.005 / 0.008, KS distance to HalfNormal(1) 0.211 and lag-1 autocorrelation of log a 0.853 at rank
+    0.992 — one excursion (six consecutive draws below 0.13 in chain 0) seen by five correlated statistics.  One realisation
+    cannot tell a 1-in-1000 draw of the same law from a sampler whose short warm-up adapts differently (the constants of nuts-rs
+    0.18.3's adaptation are recalled, not pinned: oracle/nuts_oracle.h), so this stays a law test — but a quantified one: every
+    statistic of the reference's file lies INSIDE the range the ensemble spans (rank between 1 / R and 1 - 1 / R), the ensemble
+    itself is calibrated against HalfNormal(1), and the ranks are printed.  (The previous test accepted any KS distance below
+    0.35 — looser than the ensemble's own 99.9th percentile, 0.23.)"""
     from nutpie_amd.compile_pymc import from_raw_callback
 
-    R = 1000
+    R = 4000
     m = from_raw_callback(1, fn_addr(bs_standin.halfnormal_logp), expand_address=fn_addr(bs_standin.halfnormal_expand), expanded_shapes={"a": ()},
                           keep_alive=bs_standin)
     tr = nutpie_amd.sample(m, chains=2 * R, seed=123, draws=100, tune=100, progress_bar=False)
@@ -100,13 +101,13 @@ def test_reference_values_against_a_calibrated_ensemble(hip, bs_standin):
     for k, v in ref.items():
         col = np.array([e[k] for e in ens])
         ranks[k] = float(np.mean(col < v))
-        assert 0.0005 <= ranks[k] <= 0.9995, f"{k}: the reference's {v:.4f} lies outside the ensemble ({np.percentile(col, [0.1, 50, 99.9])})"
+        assert 1.0 / R <= ranks[k] <= 1.0 - 1.0 / R, f"{k}: the reference's {v:.4f} lies outside the ensemble ({np.percentile(col, [0.1, 50, 99.9])})"
     print("ranks of the reference's values in the ensemble:", {k: round(v, 4) for k, v in ranks.items()})
     # the ensemble itself: the law of this run shape against HalfNormal(1)
     pooled = np.array([e["pooled_mean"] for e in ens])
     assert abs(np.median(pooled) - MEAN) < 0.02 and abs(pooled.mean() - MEAN) < 0.01
     assert np.median([e["ks_to_halfnormal"] for e in ens]) < 0.12
-    assert abs((a**2).mean() - 1.0) < 0.02                                    # E Z^2 = 1 over 200 000 draws
+    assert abs((a**2).mean() - 1.0) < 0.02                                    # E Z^2 = 1 over 800 000 draws
     assert stats.kstest(a[:, :, ::20].ravel(), "halfnorm").pvalue > 1e-3
 
 
