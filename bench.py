@@ -441,8 +441,11 @@ def timed_launches(env, smp, K, total_draws):
     env.barrier()
     t1 = time.perf_counter()
     prog = smp.progress()
-    if launches != K or done or max(p.finished_draws for p in prog) >= total_draws:
-        raise InvalidRegion("bench.py: a chain ran out of draws inside the timed region — the measurement is invalid; use fewer --steps")
+    # (the verdict is COLLECTIVE: a rank that left alone would leave the others waiting in the next collective)
+    bad = launches != K or done or max(p.finished_draws for p in prog) >= total_draws
+    if env.all_max(1.0 if bad else 0.0) > 0.0:
+        raise InvalidRegion("bench.py: a chain ran out of draws inside the timed region" + ("" if bad else " (on another rank)") +
+                            " — the measurement is invalid; use fewer --steps")
     return t1 - t0, float(total_leapfrogs(smp) - n0), kernel_ms, prog
 
 
@@ -465,9 +468,20 @@ def config5_shard(env, args):
                         n_local_chains=chains, store_draws=True, evals_per_launch=E, manual=True)
     W = smp.waves_per_chain
     t_all = time.perf_counter()
-    warm = warm_up_to_sampling(smp, batch=4)
+    err = None
+    try:
+        warm = warm_up_to_sampling(smp, batch=4)
+    except InvalidRegion as e:
+        err = str(e)
+    if env.all_max(1.0 if err else 0.0) > 0.0:
+        smp.close()
+        raise InvalidRegion(err or "another rank's chains finished during warm-up")
     smp.step(2)
-    elapsed, leap, kernel_ms, _ = timed_launches(env, smp, K, tune + n_draws)
+    try:
+        elapsed, leap, kernel_ms, _ = timed_launches(env, smp, K, tune + n_draws)
+    except InvalidRegion:
+        smp.close()
+        raise
     elapsed_max = env.all_max(elapsed)
     leap_sum, kms_sum = env.all_sum([leap, kernel_ms])
     t0 = time.perf_counter()
@@ -619,10 +633,13 @@ def main(argv=None):
     # ---- set-up, untimed: the whole warm-up (tune = 400 draws per chain); its rate is reported as `tuning_phase`
     tuning_phase = None
     if args.phase == "sampling":
+        err = None
         try:
             leapfrogs, launches, kms, wall = warm_up_to_sampling(smp)
         except InvalidRegion as e:
-            raise SystemExit(str(e))
+            err = str(e)
+        if env.all_max(1.0 if err else 0.0) > 0.0:   # (collective: every rank leaves, or none)
+            raise SystemExit(err or "bench.py: another rank's chains finished during warm-up")
         env.sync()
         tuning_phase = {"leapfrogs": int(leapfrogs), "launches": launches, "wall_s": wall,
                         "leapfrogs_per_s_kernel_time": leapfrogs / (kms / 1e3), "note": "all chains through tune = 400 draws (untimed set-up of the "
@@ -668,6 +685,8 @@ def main(argv=None):
     if not args.no_config5 and args.dim != args.config5_dim:
         try:
             out["config5_shard"] = config5_shard(env, args)   # (collective: every rank takes part)
+        except InvalidRegion as e:    # (raised on every rank together: see timed_launches)
+            out["config5_shard"] = {"error": repr(e)}
         except Exception as e:
             if world > 1:
                 raise   # a rank that drops out of a collective must not leave the others waiting
