@@ -557,6 +557,33 @@ def test_device_callback_bit_identical(hip, oracle, fixture_lib, scaled_normal_d
     assert np.array_equal(got.stats["gradient"], want.stats["gradient"])
 
 
+@pytest.mark.parametrize("dim", [24, 333, 900])
+@pytest.mark.parametrize("settings", [
+    dict(maxdepth=12, target_accept=0.99),                  # deep trees: many merge levels per leaf, the top-level merge of deep doublings
+    dict(max_energy_error=0.2),                             # many divergences (with the speculative first half taken)
+    dict(max_energy_error=0.2, store_divergences=True),     # ... and with the divergence record (no speculation)
+    dict(maxdepth=2),
+    dict(mindepth=3),
+    dict(check_turning=False, maxdepth=4),
+], ids=["deep", "divergences", "divergence-records", "maxdepth2", "mindepth3", "no-turning"])
+def test_device_callback_settings_variants_bit_identical(hip, oracle, fixture_lib, scaled_normal_device_lib, dim, settings):
+    """The fused leaf of the launch-per-evaluation kernels (kernels.hip: leaf_cb) under the settings that change what a leaf does:
+    one (D = 24), two (D = 333, odd: element-wise dense rows) and four (D = 900) waves per chain, replayed from a HIP graph."""
+    fn = fn_addr(scaled_normal_device_lib.scaled_normal_device_seq)
+    kw = dict(chains=5, tune=60, draws=30, seed=7 + dim)
+    got, W = run_engine(hip, hip.NativeDeviceCallbackModel(dim, fn, 0, keep_alive=scaled_normal_device_lib), launch=dict(graph_steps=8), **kw, **settings)
+    assert W == {24: 1, 333: 2, 900: 4}[dim]
+    want = oracle.sample_callback(oracle_settings(oracle, W=W, **kw, **settings), dim, fn_addr(fixture_lib.scaled_normal_logp))
+    assert_trace_equal(got, want)
+    if settings.get("store_divergences"):
+        for k in DIV_KEYS:
+            assert np.array_equal(got.stats[k], want.stats[k], equal_nan=True), k
+    if "max_energy_error" in settings:
+        assert got.stats["diverging"].sum() > 10
+    if settings.get("maxdepth") == 12:
+        assert got.stats["depth"].max() >= 5
+
+
 def test_python_callable_through_host_callback(hip, oracle):
     def logp(x):
         return -0.5 * float(x @ x), -x
