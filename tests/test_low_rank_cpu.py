@@ -85,3 +85,31 @@ def test_estimator_degenerate_windows_fall_back_to_the_diagonal():
     T = lr.estimate(x, -x, gamma=1e-5, cutoff=4.0)
     assert (T.d == 0).all()
     assert lr.pause_draws(400) == [32, 80, 160, 260] and lr.pause_draws(20) == [13] and lr.pause_draws(10) == []
+
+
+@pytest.mark.parametrize("n,D,m,seed,gamma,cutoff,tol", [(4, 30, 48, 3, 1e-5, 2.0, 1e-9), (2, 60, 64, 7, 1e-3, 4.0, 1e-9), (3, 120, 40, 5, 1e-5, 2.0, 1e-4)])
+def test_estimator_against_its_cpu_oracle(n, D, m, seed, gamma, cutoff, tol):
+    """the window estimator had property tests only.  oracle/low_rank_estimator.py restates it independently
+    (numpy, one chain at a time, SVD for the subspace, scipy's matrix square root for the geometric mean); the two are compared
+    through the dense metric M^-1 = D^1/2 (I + V (Lambda - I) V') D^1/2 — invariant to the order, sign and basis of the columns —
+    and through the number of columns kept.  (Third case: a window that spans fewer directions than the model has, sixteen
+    columns kept: the cap cuts through nearly equal eigenvalues, hence the looser tolerance.)"""
+    from nutpie_amd import low_rank as lr
+    from oracle.low_rank_estimator import dense_metric, estimate_chain
+
+    g = torch.Generator().manual_seed(seed)
+    B = torch.randn(n, D, 3, generator=g, dtype=torch.float64)
+    scales = torch.exp(torch.randn(n, D, generator=g, dtype=torch.float64))
+    Sigma = torch.diag_embed(scales ** 2) + 25.0 * (scales[:, :, None] * B) @ (scales[:, :, None] * B).transpose(1, 2)
+    x = torch.einsum("nde,nme->nmd", torch.linalg.cholesky(Sigma), torch.randn(n, m, D, generator=g, dtype=torch.float64)) + 2.0
+    gx = -torch.linalg.solve(Sigma, (x - 2.0).transpose(1, 2)).transpose(1, 2)
+    sig2, V, lam = lr.metric_of(lr.estimate(x, gx, gamma=gamma, cutoff=cutoff))
+    for c in range(n):
+        s2, Vc, lc = estimate_chain(x[c].numpy(), gx[c].numpy(), gamma, cutoff)
+        assert len(lc) == int((lam[c] != 1).sum()) >= 3
+        want = dense_metric(s2, Vc, lc)
+        got = dense_metric(sig2[c].numpy(), V[c].numpy().T, lam[c].numpy())
+        assert np.abs(got - want).max() <= tol * np.abs(want).max()
+        # (and the metric does what it is for: in its coordinates the window's covariance is within the cutoff of the identity
+        #  along the directions the window spans — the property the older test checks on the engine's version alone)
+        np.testing.assert_allclose(np.sort(lc), np.sort(lam[c].numpy()[lam[c].numpy() != 1]), rtol=max(tol, 1e-9) * 100)
