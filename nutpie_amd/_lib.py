@@ -148,6 +148,7 @@ def lib():
             L.nphip_model_bridgestan.argtypes = [C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
             L.nphip_model_jit_density.restype = C.c_void_p
             L.nphip_model_jit_density.argtypes = [C.c_uint64, C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int]
+            L.nphip_model_jit_low_rank.argtypes = [C.c_void_p, C.c_int]
             L.nphip_model_set_init.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64]
             L.nphip_model_free.argtypes = [C.c_void_p]
             L.nphip_model_set_expand.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
@@ -527,10 +528,13 @@ class JitDensityModel(_Model):
     """A device density compiled at run time into its own resident kernel (``nphip_model_jit_density``; nutpie_amd/density.py):
     ``launch_addr`` / ``nv`` come from the model's library, ``data_ptr`` is its data block in device memory."""
 
-    def __init__(self, dim, launch_addr: int, nv: int, data_ptr: int, lds_bytes_per_chain: int = 0, lds_bytes_shared: int = 0, keep_alive=None, waves_per_chain: int = 1):
+    def __init__(self, dim, launch_addr: int, nv: int, data_ptr: int, lds_bytes_per_chain: int = 0, lds_bytes_shared: int = 0, keep_alive=None, waves_per_chain: int = 1,
+                 low_rank: bool = False):
         super().__init__(lib().nphip_model_jit_density(C.c_uint64(dim), C.c_void_p(launch_addr), int(nv), C.c_void_p(data_ptr), C.c_uint64(int(lds_bytes_per_chain)),
                                                       C.c_uint64(int(lds_bytes_shared)), int(waves_per_chain)), dim, [keep_alive])
         self.exception = None
+        if low_rank and lib().nphip_model_jit_low_rank(self._h, 1) != NPHIP_OK:   # (the library's resident kernel was built with -DNPHIP_JIT_LR=1)
+            raise ValueError(_err())
 
 
 # --------------------------------------------------------------------------- progress / trace

@@ -310,6 +310,7 @@ struct nphip_model {
     uint64_t jit_shared_bytes = 0; // LDS shared by the chains of a workgroup
     int jit_nv = 0;   // chunks of 128 dimensions per wave
     int jit_w = 1;    // waves per chain
+    bool jit_lr = false;   // the library's resident kernel was built for the low-rank metric (nphip_model_jit_low_rank)
     std::shared_ptr<BsAdapter> bs;
     std::shared_ptr<BsExpand> bs_expand;
     uint64_t dim = 0;
@@ -387,6 +388,13 @@ nphip_model_t* nphip_model_jit_density(uint64_t dim, void* launch_fn, int nv, co
     m->jit_shared_bytes = lds_bytes_shared;
     return m;
 }
+int nphip_model_jit_low_rank(nphip_model_t* m, int capable) {
+    if (!m || m->kind != 3) { set_error("nphip_model_jit_low_rank: not a runtime-compiled density"); return NPHIP_ERR; }
+    if (capable && m->jit_w != 1) { set_error("the low-rank metric on the resident kernel needs one wave per chain"); return NPHIP_ERR; }
+    m->jit_lr = capable != 0;
+    return NPHIP_OK;
+}
+
 int nphip_model_set_init(nphip_model_t* m, int kind, const double* points, uint64_t n_points) {
     if (kind < 0 || kind > 2) return bad_value("init kind must be 0, 1 or 2");
     if (kind == 2 && (!points || n_points == 0)) return bad_value("explicit init needs points");
@@ -766,8 +774,14 @@ bool nphip_sampler::setup() {
     dens = model.kind == 3;
     W = dens ? model.jit_w : (launch.waves_per_chain ? launch.waves_per_chain : (model.kind == 2 ? choose_waves_callback(dim) : choose_waves(dim)));
     const bool lrm = set.low_rank_metric;
-    if (lrm && dens) { set_error("the low-rank metric runs on the memory-resident kernels: use the batched device callback of the density's library"); return false; }
-    if (lrm) launch.no_register_kernel = 1;   // (P-slots carry the velocity as a third vector: memory-resident kernels only)
+    if (dens && lrm != model.jit_lr) {
+        set_error(lrm ? "this library's resident kernel was not built for the low-rank metric (compile it with -DNPHIP_JIT_LR=1 and say so with nphip_model_jit_low_rank), or use its batched device callback"
+                      : "this library's resident kernel was built for the low-rank metric: the job must set low_rank_metric");
+        return false;
+    }
+    // (P-slots carry the velocity as a third vector.  Round 4: fused models with one wave per chain — D <= 1024 — keep the register-resident
+    //  leaf under the metric (kernels.hip: Machine<..., LR>); everything else runs the memory-resident kernels)
+    if (lrm && !(model.kind == 0 && W == 1 && dim <= 1024) && !dens) launch.no_register_kernel = 1;
     if (dens && set.store_divergences) {
         set_error("store_divergences needs the pre-step state in memory: use the batched device callback of the density's library (launch per evaluation)");
         return false;

@@ -221,6 +221,7 @@ __device__ __forceinline__ double clamp_mm(double v) { return v < 1e-20 ? 1e-20 
 template <int NV>
 struct Regs {
     double2 q[NV], g[NV], p[NV], r[NV], s[NV];
+    double2 v[NV], sd[NV];   // low-rank metric (Machine<..., LR>): the cursor's velocity M^-1 p, sqrt(sigma^2)
     int64_t reg_q = -1, reg_p = -1;
     bool sig_ok = false;
     bool dirty_qg = false, dirty_pr = false;  // the registers hold the only copy (stores were elided)
@@ -251,7 +252,10 @@ struct SCache {
 // REMOTE (NV > 0, W == 1, not FUSED): a host-callback model driven like a fused one — the kernel stays resident, and an
 // evaluation is a remote call in the middle of the leaf: publish the position in the host's staging row, arrive, wait for
 // the host's word, read (logp, gradient) back (remote_sync).  The cursor state stays in registers across the call.
-template <bool FUSED, int W, int NV = 0, bool LEAN = false, bool REMOTE = false>
+// LR (NV > 0, W == 1, not LEAN; round 4): the register-resident leaf under the low-rank metric M^-1 = D^1/2 (I + V (Lambda - I) V') D^1/2 —
+// the cursor's velocity v = M^-1 p is a sixth resident vector, every P-slot carries it as a third vector (Args::pvec = 3), the k
+// columns of V are streamed from L2 against the resident momentum (k dots + k updates per half step), and the LDS ring is not used.
+template <bool FUSED, int W, int NV = 0, bool LEAN = false, bool REMOTE = false, bool LR = false>
 struct Machine {
     static constexpr bool INK = FUSED || REMOTE;   // evaluations happen inside the kernel: a launch runs many steps
     // launch-per-evaluation kernels: the end of a draw is cut into slices of a launch each (engine_types.h: PH_DRAW_END / PH_DRAW_BEGIN)
@@ -291,7 +295,7 @@ struct Machine {
         wave = (W == 1) ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
         D = a.dim; ld = a.ld; nch = ld / NPHIP_CHUNK;
         qp = a.qpool + (size_t)ch * a.nqpool * 2 * ld;
-        pp = a.pslots + (size_t)ch * a.npslots * (NV == -1 ? (size_t)a.pvec : (size_t)2) * ld;
+        pp = a.pslots + (size_t)ch * a.npslots * ((NV == -1 || LR) ? (size_t)a.pvec : (size_t)2) * ld;
         sig2 = a.sig2 + (size_t)ch * ld;
         est = a.est + (size_t)ch * 8 * ld;
         T = a.s.num_tune + a.s.num_draws;
@@ -308,7 +312,7 @@ struct Machine {
     __device__ __forceinline__ double* Q(int64_t b) const { return qp + (size_t)b * 2 * ld; }
     __device__ __forceinline__ double* G(int64_t b) const { return qp + (size_t)b * 2 * ld + ld; }
     // vectors per P-slot: (p, rho), and with the low-rank metric (memory-resident kernels only) the velocity v = M^-1 p as well
-    __device__ __forceinline__ size_t pvec() const { return NV == -1 ? (size_t)A.pvec : (size_t)2; }
+    __device__ __forceinline__ size_t pvec() const { return LRK ? (size_t)A.pvec : (size_t)2; }
     __device__ __forceinline__ double* P(int64_t s) const { return pp + (size_t)s * pvec() * ld; }
     __device__ __forceinline__ double* R(int64_t s) const { return pp + (size_t)s * pvec() * ld + ld; }
     __device__ __forceinline__ double* VEL(int64_t s) const { return pp + (size_t)s * pvec() * ld + 2 * ld; }
@@ -316,7 +320,7 @@ struct Machine {
     // kernels (NV == 0: every launch-per-evaluation callback job runs each of their paths once per launch) do not carry the code
     // (measured: config 3 behind the device callback 13.7 -> 10.4 M leapfrogs/s with the low-rank branches compiled in, 29 against
     // 18 us per launch)
-    static constexpr bool LRK = NV == -1;
+    static constexpr bool LRK = NV == -1 || LR;
     __device__ __forceinline__ bool lr_job() const { return LRK && A.lr_on != 0; }
     __device__ __forceinline__ const double* LRV(int j) const { return A.lr_V + ((size_t)chain * kLrMax + j) * ld; }
     __device__ __forceinline__ double* EST(int64_t e, int k) const { return est + (size_t)(e * 4 + k) * ld; }
@@ -764,6 +768,13 @@ struct Machine {
         const double t = (rl - re_) + pe_;
         a1 = fma(t, s2v * pl, a1);
         a2 = fma(t, s2v * pe_, a2);
+    }
+
+    // the same with the velocities v = M^-1 p of the two states given (low-rank metric: not sigma^2 p)
+    __device__ __forceinline__ void span_acc_v(double pe_, double re_, double ve_, double rl, double vl, double& a1, double& a2) const {
+        const double t = (rl - re_) + pe_;
+        a1 = fma(t, vl, a1);
+        a2 = fma(t, ve_, a2);
     }
 
     // ---- Streaming fused leapfrog (FUSED, NV == 0: any D, any W).  ONE pass per leaf: each wave streams its
@@ -1403,6 +1414,21 @@ struct Machine {
         acc_e = fma(t, s2v * pe, acc_e);
         acc_s = fma(t, s2v * ps, acc_s);
     }
+    __device__ __forceinline__ void pair_acc_v(const Pair pr, double p1, double r1, double v1, double p2, double r2, double v2, double& acc_e, double& acc_s) const {
+        const double ps = pr.first_is_start ? p1 : p2, rs = pr.first_is_start ? r1 : r2, vs = pr.first_is_start ? v1 : v2;
+        const double pe = pr.first_is_start ? p2 : p1, re = pr.first_is_start ? r2 : r1, ve = pr.first_is_start ? v2 : v1;
+        double t;
+        if (pr.mode == 0) t = (re - rs) + ps;
+        else if (pr.mode == 1) t = re + rs;
+        else t = (rs - re) + pe;
+        acc_e = fma(t, ve, acc_e);
+        acc_s = fma(t, vs, acc_s);
+    }
+    __device__ __forceinline__ void load_slot_v(int64_t slot, double2 (&v)[NVX]) const {
+        const double* gv = VEL(slot);
+#pragma unroll
+        for (int k = 0; k < NVX; ++k) v[k] = ld2(gv, ridx(k));
+    }
     __device__ __forceinline__ void load_slot(int64_t slot, double2 (&p)[NVX], double2 (&r)[NVX]) const {
         const double *gp = P(slot), *gr = R(slot);
         constexpr int nk = NVX;  // the register kernels are instantiated per exact chunk count
@@ -1478,6 +1504,67 @@ struct Machine {
         rsum(v);
         return (v[0] < 0.0) || (v[1] < 0.0);
     }
+    // ---- the same four under the low-rank metric (LR): every operand comes with its velocity
+    __device__ __forceinline__ bool check_a_v(const RegsT& X, const double2 (&ap)[NVX], const double2 (&ar)[NVX], const double2 (&av)[NVX], const double2 (&fp)[NVX],
+                                              const double2 (&fr)[NVX], const double2 (&fv)[NVX], int64_t iA, int64_t iTF, int64_t iTL) {
+        const Pair p1 = pair_of(iA, iTL), p3 = pair_of(iA, iTF);
+        double2 acc[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) { acc[n].x = 0.0; acc[n].y = 0.0; }
+#pragma unroll
+        for (int k = 0; k < NVX; ++k) {
+            pair_acc_v(p1, ap[k].x, ar[k].x, av[k].x, X.p[k].x, X.r[k].x, X.v[k].x, acc[0].x, acc[1].x);
+            pair_acc_v(p1, ap[k].y, ar[k].y, av[k].y, X.p[k].y, X.r[k].y, X.v[k].y, acc[0].y, acc[1].y);
+            pair_acc_v(p3, ap[k].x, ar[k].x, av[k].x, fp[k].x, fr[k].x, fv[k].x, acc[2].x, acc[3].x);
+            pair_acc_v(p3, ap[k].y, ar[k].y, av[k].y, fp[k].y, fr[k].y, fv[k].y, acc[2].y, acc[3].y);
+        }
+        double v[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) v[n] = acc[n].x + acc[n].y;
+        rsum(v);
+        return (v[0] < 0.0) || (v[1] < 0.0) || (v[2] < 0.0) || (v[3] < 0.0);
+    }
+    __device__ __forceinline__ bool check1_v(const RegsT& X, const double2 (&ap)[NVX], const double2 (&ar)[NVX], const double2 (&av)[NVX], int64_t iA, int64_t iTL) {
+        const Pair p1 = pair_of(iA, iTL);
+        double2 e = {0.0, 0.0}, st = {0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < NVX; ++k) {
+            pair_acc_v(p1, ap[k].x, ar[k].x, av[k].x, X.p[k].x, X.r[k].x, X.v[k].x, e.x, st.x);
+            pair_acc_v(p1, ap[k].y, ar[k].y, av[k].y, X.p[k].y, X.r[k].y, X.v[k].y, e.y, st.y);
+        }
+        double v[2] = {e.x + e.y, st.x + st.y};
+        rsum(v);
+        return (v[0] < 0.0) || (v[1] < 0.0);
+    }
+    __device__ __forceinline__ bool sub_a_v(const RegsT& X, const double2 (&ap)[NVX], const double2 (&ar)[NVX], const double2 (&av)[NVX], const double2 (&fp)[NVX],
+                                            const double2 (&fr)[NVX], const double2 (&fv)[NVX]) {
+        double2 acc[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) { acc[n].x = 0.0; acc[n].y = 0.0; }
+#pragma unroll
+        for (int k = 0; k < NVX; ++k) {
+            span_acc_v(ap[k].x, ar[k].x, av[k].x, X.r[k].x, X.v[k].x, acc[0].x, acc[1].x);
+            span_acc_v(ap[k].y, ar[k].y, av[k].y, X.r[k].y, X.v[k].y, acc[0].y, acc[1].y);
+            span_acc_v(ap[k].x, ar[k].x, av[k].x, fr[k].x, fv[k].x, acc[2].x, acc[3].x);
+            span_acc_v(ap[k].y, ar[k].y, av[k].y, fr[k].y, fv[k].y, acc[2].y, acc[3].y);
+        }
+        double v[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) v[n] = acc[n].x + acc[n].y;
+        rsum(v);
+        return (v[0] < 0.0) || (v[1] < 0.0) || (v[2] < 0.0) || (v[3] < 0.0);
+    }
+    __device__ __forceinline__ bool sub_b_v(const RegsT& X, const double2 (&ap)[NVX], const double2 (&ar)[NVX], const double2 (&av)[NVX]) {
+        double2 e = {0.0, 0.0}, st = {0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < NVX; ++k) {
+            span_acc_v(ap[k].x, ar[k].x, av[k].x, X.r[k].x, X.v[k].x, e.x, st.x);
+            span_acc_v(ap[k].y, ar[k].y, av[k].y, X.r[k].y, X.v[k].y, e.y, st.y);
+        }
+        double v[2] = {e.x + e.y, st.x + st.y};
+        rsum(v);
+        return (v[0] < 0.0) || (v[1] < 0.0);
+    }
     // ---- LDS ring of recent (p, rho) summaries
     __device__ __forceinline__ NPHIP_LDS double2* ring_ptr(int slot, int vec) const {
         return (NPHIP_LDS double2*)(ring + (size_t)(slot * 2 + vec) * NVX * 128) + lane;
@@ -1540,6 +1627,11 @@ struct Machine {
             double *pn = P(X.reg_p), *rn = R(X.reg_p);
 #pragma unroll
             for (int k = 0; k < NVX; ++k) if (k < nk) { st2(pn, ridx(k), X.p[k]); st2(rn, ridx(k), X.r[k]); }
+            if (LR) {
+                double* vn = VEL(X.reg_p);
+#pragma unroll
+                for (int k = 0; k < NVX; ++k) st2(vn, ridx(k), X.v[k]);
+            }
             X.dirty_pr = false;
         }
     }
@@ -1686,13 +1778,22 @@ struct Machine {
                 regs_grad(X);
             }
         }
-        if (X.reg_p != srcp) load_slot(srcp, X.p, X.r);
+        if (X.reg_p != srcp) { load_slot(srcp, X.p, X.r); if (LR) load_slot_v(srcp, X.v); }
         if (!X.sig_ok) {
 #pragma unroll
             for (int k = 0; k < NVX; ++k) if (k < nk) X.s[k] = ld2(sig2, ridx(k));
+            if (LR) {
+                const double* sdp = A.lr_std + (size_t)chain * ld;
+#pragma unroll
+                for (int k = 0; k < NVX; ++k) X.sd[k] = ld2(sdp, ridx(k));
+            }
             X.sig_ok = true;
         }
         if (j == 1) { X.ring_leaf0 = -1; X.ring_leaf1 = -1; }
+        // low-rank metric: does this chain integrate under a handed-in metric yet (else: the diagonal metric it adapts itself, with
+        // the velocity sigma^2 p carried along so that every P-slot of the job has one)
+        const bool lrm = LR && lr_job() && rfl(c->host_metric) != 0;
+        const int lrk = lrm ? (int)rfl(c->lr_k) : 0;
         NPHIP_PHASE_FENCE();
         // ---- leapfrog (model parameters from LDS, neighbours by DPP, level-0 criterion in the same pass)
         const double eps = (double)dir * H.step;
@@ -1701,19 +1802,45 @@ struct Machine {
 #pragma unroll
             for (int k = 0; k < NVX; ++k) if (k < nk) { X.r[k].x = -0.0; X.r[k].y = -0.0; }
         }
-        double2 z[NVX], pold[NVX], rold[NVX];
+        double2 z[NVX], pold[NVX], rold[NVX], vold[NVX];
+        LrAcc lrS;
+        double lrc[kLrMax];
+        if (LR && lrm) lr_zero(lrS);
 #pragma unroll
         for (int k = 0; k < NVX; ++k) if (k < nk) {
             pold[k] = X.p[k];
             rold[k] = X.r[k];
+            if (LR) vold[k] = X.v[k];
             X.p[k].x = fma(h, X.g[k].x, X.p[k].x);
             X.p[k].y = fma(h, X.g[k].y, X.p[k].y);
-            X.q[k].x = fma(eps, X.s[k].x * X.p[k].x, X.q[k].x);
-            X.q[k].y = fma(eps, X.s[k].y * X.p[k].y, X.q[k].y);
-            if (!REMOTE) {
+            if (LR && lrm) {   // the products of u = std p_half with the columns first; the drift follows the reduction
+                double2 u;
+                u.x = X.sd[k].x * X.p[k].x; u.y = X.sd[k].y * X.p[k].y;
+                lr_acc(lrS, lrk, ridx(k), u);
+            } else {
+                X.q[k].x = fma(eps, X.s[k].x * X.p[k].x, X.q[k].x);
+                X.q[k].y = fma(eps, X.s[k].y * X.p[k].y, X.q[k].y);
+            }
+            if (!REMOTE && !(LR && lrm)) {
                 const double2 mu = par_mu(ridx(k));
                 z[k].x = X.q[k].x - mu.x;
                 z[k].y = X.q[k].y - mu.y;
+            }
+        }
+        if (LR && lrm) {
+            lr_coef(lrS, lrk, 0, lrc);
+#pragma unroll
+            for (int k = 0; k < NVX; ++k) {
+                double2 u;
+                u.x = X.sd[k].x * X.p[k].x; u.y = X.sd[k].y * X.p[k].y;
+                const double2 w = lr_apply(lrk, ridx(k), u, lrc);
+                X.q[k].x = fma(eps, X.sd[k].x * w.x, X.q[k].x);
+                X.q[k].y = fma(eps, X.sd[k].y * w.y, X.q[k].y);
+                if (!REMOTE) {
+                    const double2 mu = par_mu(ridx(k));
+                    z[k].x = X.q[k].x - mu.x;
+                    z[k].y = X.q[k].y - mu.y;
+                }
             }
         }
         double lp_remote = 0.0;
@@ -1734,6 +1861,7 @@ struct Machine {
             publish_edges(z);
         }
         double2 accK = {0.0, 0.0}, accL = {0.0, 0.0}, accE = {0.0, 0.0}, accS = {0.0, 0.0};
+        if (LR && lrm) lr_zero(lrS);
 #pragma unroll
         for (int k = 0; k < NVX; ++k) if (k < nk) {
             double2 gg;
@@ -1765,25 +1893,56 @@ struct Machine {
             X.g[k] = gg;
             X.p[k].x = fma(h, gg.x, X.p[k].x);
             X.p[k].y = fma(h, gg.y, X.p[k].y);
+            X.r[k].x = rold[k].x + X.p[k].x;
+            X.r[k].y = rold[k].y + X.p[k].y;
+            if (LR && lrm) {   // the velocity of the new state needs the products with the columns first: second loop below
+                double2 u;
+                u.x = X.sd[k].x * X.p[k].x; u.y = X.sd[k].y * X.p[k].y;
+                lr_acc(lrS, lrk, ridx(k), u);
+                continue;
+            }
             const double vx = X.s[k].x * X.p[k].x, vy = X.s[k].y * X.p[k].y;
             accK.x = fma(X.p[k].x, vx, accK.x);
             accK.y = fma(X.p[k].y, vy, accK.y);
-            X.r[k].x = rold[k].x + X.p[k].x;
-            X.r[k].y = rold[k].y + X.p[k].y;
             // level-0 criterion between source and new leaf: span = (rho' - rho) + p
             const double tx0 = (X.r[k].x - rold[k].x) + pold[k].x, ty0 = (X.r[k].y - rold[k].y) + pold[k].y;
             accE.x = fma(tx0, vx, accE.x);
             accE.y = fma(ty0, vy, accE.y);
-            accS.x = fma(tx0, X.s[k].x * pold[k].x, accS.x);
-            accS.y = fma(ty0, X.s[k].y * pold[k].y, accS.y);
+            if (LR) {   // (a job that may receive metrics: every state carries its velocity, here sigma^2 p)
+                X.v[k].x = vx; X.v[k].y = vy;
+                accS.x = fma(tx0, vold[k].x, accS.x);
+                accS.y = fma(ty0, vold[k].y, accS.y);
+            } else {
+                accS.x = fma(tx0, X.s[k].x * pold[k].x, accS.x);
+                accS.y = fma(ty0, X.s[k].y * pold[k].y, accS.y);
+            }
+        }
+        if (LR && lrm) {
+            lr_coef(lrS, lrk, 0, lrc);
+#pragma unroll
+            for (int k = 0; k < NVX; ++k) {
+                double2 u;
+                u.x = X.sd[k].x * X.p[k].x; u.y = X.sd[k].y * X.p[k].y;
+                const double2 w = lr_apply(lrk, ridx(k), u, lrc);
+                X.v[k].x = X.sd[k].x * w.x; X.v[k].y = X.sd[k].y * w.y;
+                accK.x = fma(X.p[k].x, X.v[k].x, accK.x);
+                accK.y = fma(X.p[k].y, X.v[k].y, accK.y);
+                const double tx0 = (X.r[k].x - rold[k].x) + pold[k].x, ty0 = (X.r[k].y - rold[k].y) + pold[k].y;
+                accE.x = fma(tx0, X.v[k].x, accE.x);
+                accE.y = fma(ty0, X.v[k].y, accE.y);
+                accS.x = fma(tx0, vold[k].x, accS.x);
+                accS.y = fma(ty0, vold[k].y, accS.y);
+            }
         }
         X.reg_q = newq;
         X.reg_p = newp;
         X.dirty_qg = true;
         X.dirty_pr = true;
         // the two most recent summaries a level-1 merge needs stay on chip
-        if ((j & 3) == 1) { ring_write(0, X.p, X.r); X.ring_leaf0 = j; }
-        else if ((j & 3) == 2) { ring_write(1, X.p, X.r); X.ring_leaf1 = j; }
+        if (!LR) {
+            if ((j & 3) == 1) { ring_write(0, X.p, X.r); X.ring_leaf0 = j; }
+            else if ((j & 3) == 2) { ring_write(1, X.p, X.r); X.ring_leaf1 = j; }
+        }
 #ifdef NPHIP_PROFILE
         const int64_t tp1 = (int64_t)__builtin_readcyclecounter();
 #endif
@@ -1831,13 +1990,28 @@ struct Machine {
         double T_U = Unew, T_E = E;
         int32_t T_q = newq, T_idx = idx_new;
         H.srcq = newq; H.srcp = newp; H.idx_cur = idx_new;   // the cursor moves to the new leaf
-        double2 obp[NVX], obr[NVX];  // one operand buffer (A.first, then A.last of the merge being checked)
+        double2 obp[NVX], obr[NVX], obv[NVX];  // one operand buffer (A.first, then A.last of the merge being checked)
         int32_t k = 0;
         while (k < d && (((j - 1) >> k) & 1)) {
             if (check) {
                 bool turn;
                 if (k == 0) {
                     turn = turn0;
+                } else if (LR) {
+                    // low-rank metric: no LDS ring — every summary comes from its P-slot (p, rho, v); T.first as in the other branch
+                    const int32_t a = j - (2 << k) + 1, al = j - (1 << k);
+                    load_slot(first_slot_of(a, d), obp, obr); load_slot_v(first_slot_of(a, d), obv);
+                    if (k == 2) { load_slot(first_slot_of(al + 1, d), pold, rold); load_slot_v(first_slot_of(al + 1, d), vold); }
+                    turn = sub_a_v(X, obp, obr, obv, pold, rold, vold);
+                    if (k >= 2) {
+#pragma unroll
+                        for (int q_ = 0; q_ < NVX; ++q_) { pold[q_] = obp[q_]; rold[q_] = obr[q_]; vold[q_] = obv[q_]; }
+                    }
+                    if (!turn) {
+                        const int32_t sl_ = slot_last(__builtin_ctz((unsigned)al), A.cap);
+                        load_slot(sl_, obp, obr); load_slot_v(sl_, obv);
+                        turn = sub_b_v(X, obp, obr, obv);
+                    }
                 } else {
                     const int32_t a = j - (2 << k) + 1, al = j - (1 << k);
                     // A.first
@@ -1881,7 +2055,7 @@ struct Machine {
 #ifdef NPHIP_PROFILE
             const int64_t tp3 = (int64_t)__builtin_readcyclecounter();
 #endif
-            store_state(X, T_q == newq, ((j & 3) == 0) || ((j & 7) == 1));
+            store_state(X, T_q == newq, LR || ((j & 3) == 0) || ((j & 7) == 1));   // (low-rank: no ring, every summary goes to its slot)
             issue_leaf_hot(H);
 #ifdef NPHIP_PROFILE
             c->prof[7] += (int64_t)__builtin_readcyclecounter() - tp3;
@@ -1895,7 +2069,15 @@ struct Machine {
             const int32_t near_idx = rfl(dir > 0 ? c->idx_right : c->idx_left);
             if (d == 0) {
                 // both ends are the origin = the source of this leapfrog, and rho_0 == p_0
-                turn = check1(X, pold, pold, far_idx, idx_new);
+                turn = LR ? check1_v(X, pold, pold, vold, far_idx, idx_new) : check1(X, pold, pold, far_idx, idx_new);
+            } else if (LR) {
+                if (d == 2) { load_slot(slot_first((int)d), pold, rold); load_slot_v(slot_first((int)d), vold); }
+                load_slot(far_slot, obp, obr); load_slot_v(far_slot, obv);
+                turn = check_a_v(X, obp, obr, obv, pold, rold, vold, far_idx, near_idx + dir, idx_new);
+                if (!turn) {
+                    load_slot(rfl(c->endp[db]), obp, obr); load_slot_v(rfl(c->endp[db]), obv);
+                    turn = check1_v(X, obp, obr, obv, near_idx, idx_new);
+                }
             } else {
                 // T.first = leaf 1: d == 1 -> source registers; d == 2 -> ring slot 0; d >= 3 -> already in (pold, rold)
                 if (d == 2) {
@@ -3203,14 +3385,14 @@ struct Machine {
 
 // `Ap` points to the engine's argument block in device memory (written once at set-up); it is read through
 // the constant address space, i.e. with scalar loads into SGPRs.  Per-launch scalars are kernel parameters.
-template <bool FUSED, int W, int NV, bool LEAN = false, bool REMOTE = false>
-__global__ __launch_bounds__(W == 1 ? 256 : 64 * W) __attribute__((amdgpu_waves_per_eu(LEAN ? NPHIP_LEAN_OCC(W) : ((NV > 0 && NV <= (W == 1 ? 3 : NPHIP_RW_OCC2_MAX)) ? 2 : ((!FUSED && NV == 0 && !REMOTE) ? NPHIP_CB_OCC(W) : 1)), LEAN ? NPHIP_LEAN_OCC(W) : ((NV > 0 && NV <= (W == 1 ? 3 : NPHIP_RW_OCC2_MAX)) ? 2 : 8)))) void k_advance(const Args* __restrict__ Ap, int max_evals, int have_result, const LaunchSlice sl) {
+template <bool FUSED, int W, int NV, bool LEAN = false, bool REMOTE = false, bool LR = false>
+__global__ __launch_bounds__(W == 1 ? 256 : 64 * W) __attribute__((amdgpu_waves_per_eu(LEAN ? NPHIP_LEAN_OCC(W) : ((NV > 0 && !LR && NV <= (W == 1 ? 3 : NPHIP_RW_OCC2_MAX)) ? 2 : ((!FUSED && NV == 0 && !REMOTE) ? NPHIP_CB_OCC(W) : 1)), LEAN ? NPHIP_LEAN_OCC(W) : ((NV > 0 && !LR && NV <= (W == 1 ? 3 : NPHIP_RW_OCC2_MAX)) ? 2 : 8)))) void k_advance(const Args* __restrict__ Ap, int max_evals, int have_result, const LaunchSlice sl) {
     const NPHIP_CONST Args& A = *(const NPHIP_CONST Args*)Ap;
     constexpr int WAVES = (W == 1) ? 4 : W;
     __shared__ Ctl s_ctl[WAVES];
     __shared__ double s_red[W == 1 ? 8 : 32 * WAVES];   // two alternating reduction areas of 16 values per wave (one wave per chain: DPP only)
     __shared__ __attribute__((aligned(16))) double s_par[(NV > 0 && W == 1) ? 3 * 128 * NV + 8 : 2];
-    __shared__ __attribute__((aligned(16))) double s_ring[(NV > 0 && !LEAN) ? WAVES * 4 * 128 * NV : 2];  // per wave: 2 slots x (p, rho)
+    __shared__ __attribute__((aligned(16))) double s_ring[(NV > 0 && !LEAN && !LR) ? WAVES * 4 * 128 * NV : 2];  // per wave: 2 slots x (p, rho)
     __shared__ double s_edge[(NV > 0 && W > 1) ? 2 * W * NV + 2 : 2];   // lean kernels: padded with one 0.0 at each end
     extern __shared__ __attribute__((aligned(16))) double s_dyn[];  // a.sig_lds: sigma^2 of the chain [ld]
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
@@ -3299,9 +3481,9 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) __attribute__((amdgpu_waves_
         const int64_t left = (int64_t)sl.chain_n - (int64_t)blockIdx.x * 4;
         c->hs_wgn = (W > 1) ? 1 : (left < 4 ? left : 4);   // chains of this workgroup (W == 1: four; group bounds are multiples of 4)
     }
-    Machine<FUSED, W, NV, LEAN, REMOTE> m(A, c, (LdsDouble)s_red, chain, (LdsDouble)s_par, (LdsDouble)s_ring + (LEAN ? 0 : (size_t)wib * 4 * 128 * (NV > 0 ? NV : 1)),
+    Machine<FUSED, W, NV, LEAN, REMOTE, LR> m(A, c, (LdsDouble)s_red, chain, (LdsDouble)s_par, (LdsDouble)s_ring + ((LEAN || LR) ? 0 : (size_t)wib * 4 * 128 * (NV > 0 ? NV : 1)),
                             (LdsDouble)s_edge);
-    __shared__ double s_park[(!FUSED && NV == 0 && W > 1) ? Machine<FUSED, W, NV, LEAN, REMOTE>::kParkMax * W : 2];
+    __shared__ double s_park[(!FUSED && NV == 0 && W > 1) ? Machine<FUSED, W, NV, LEAN, REMOTE, LR>::kParkMax * W : 2];
     m.parked = (LdsDouble)s_park;
     m.run(max_evals, have_result != 0, (LEAN || ((NV == 0 || NV == -1) && W >= 8 && A.sig_lds)) ? (LdsDouble)s_dyn : nullptr, sl.materialise != 0);
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -3335,18 +3517,19 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) __attribute__((amdgpu_waves_
 }
 
 // ----------------------------------------------------------------------------------------
-// launch tables.  The file is compiled as seven translation units in parallel (Makefile: -DNPHIP_PART=0..6), each instantiating
+// launch tables.  The file is compiled as eight translation units in parallel (Makefile: -DNPHIP_PART=0..6, 8), each instantiating
 // one family of kernels; without NPHIP_PART (developer builds, see the NPHIP_DEV_* macros) everything is in one.
 // ----------------------------------------------------------------------------------------
 #ifndef NPHIP_PART
 #define NPHIP_PART -1
 #endif
 #define NPHIP_HAS(p) (NPHIP_PART == -1 || NPHIP_PART == (p))
-#if defined(NPHIP_DEV_LEAN) || defined(NPHIP_DEV_W1NV) || defined(NPHIP_DEV_CB_W)
+#if defined(NPHIP_DEV_LEAN) || defined(NPHIP_DEV_W1NV) || defined(NPHIP_DEV_CB_W) || defined(NPHIP_DEV_W1NV_LR)
 #define NPHIP_DEV_BUILD 1   // one kernel instantiation only: seconds instead of minutes
 #endif
 
 hipError_t launch_fam_w1(const Args& a, const Args* d_args, hipStream_t st, const LaunchSlice sl);              // part 0
+hipError_t launch_fam_w1_lr(const Args& a, const Args* d_args, hipStream_t st, const LaunchSlice sl);           // part 8
 hipError_t launch_fam_lean4(const Args& a, const Args* d_args, hipStream_t st, const LaunchSlice sl);           // part 1
 hipError_t launch_fam_lean8(const Args& a, const Args* d_args, hipStream_t st, const LaunchSlice sl);           // part 2
 hipError_t launch_fam_rw(const Args& a, const Args* d_args, int W, hipStream_t st, const LaunchSlice sl);       // part 3
@@ -3490,6 +3673,31 @@ hipError_t launch_fam_w1(const Args& a, const Args* d_args, hipStream_t st, cons
 }
 #endif
 
+#if NPHIP_HAS(8)
+// register-resident, one wave per chain, under the low-rank metric (settings.low_rank_metric; Machine<..., LR>): D <= 1024
+hipError_t launch_fam_w1_lr(const Args& a, const Args* d_args, hipStream_t st, const LaunchSlice sl) {
+    const dim3 g(((unsigned)sl.chain_n + 3) / 4), b(256);
+    const int me = a.max_evals, hr = a.have_result;
+    (void)g; (void)b; (void)me; (void)hr;
+    switch (a.reg_nv) {
+#if defined(NPHIP_DEV_W1NV_LR)
+        case NPHIP_DEV_W1NV_LR: hipLaunchKernelGGL((k_advance<true, 1, NPHIP_DEV_W1NV_LR, false, false, true>), g, b, 0, st, d_args, me, hr, sl); break;
+#elif !defined(NPHIP_DEV_BUILD)
+        case 1: hipLaunchKernelGGL((k_advance<true, 1, 1, false, false, true>), g, b, 0, st, d_args, me, hr, sl); break;
+        case 2: hipLaunchKernelGGL((k_advance<true, 1, 2, false, false, true>), g, b, 0, st, d_args, me, hr, sl); break;
+        case 3: hipLaunchKernelGGL((k_advance<true, 1, 3, false, false, true>), g, b, 0, st, d_args, me, hr, sl); break;
+        case 4: hipLaunchKernelGGL((k_advance<true, 1, 4, false, false, true>), g, b, 0, st, d_args, me, hr, sl); break;
+        case 5: hipLaunchKernelGGL((k_advance<true, 1, 5, false, false, true>), g, b, 0, st, d_args, me, hr, sl); break;
+        case 6: hipLaunchKernelGGL((k_advance<true, 1, 6, false, false, true>), g, b, 0, st, d_args, me, hr, sl); break;
+        case 7: hipLaunchKernelGGL((k_advance<true, 1, 7, false, false, true>), g, b, 0, st, d_args, me, hr, sl); break;
+        case 8: hipLaunchKernelGGL((k_advance<true, 1, 8, false, false, true>), g, b, 0, st, d_args, me, hr, sl); break;
+#endif
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+#endif
+
 #if NPHIP_HAS(4)
 // memory-resident kernels: fused models of any D and W (D > 10 240, store_divergences, no_register_kernel) and the two-phase
 // callback kernels
@@ -3606,7 +3814,7 @@ hipError_t launch_advance(const Args& a, const Args* d_args, bool fused, int W, 
     sl.n_grp = 0;
     if (fused && a.lean && a.reg_nv > 0) return W == 4 ? launch_fam_lean4(a, d_args, st, sl) : (W == 8 ? launch_fam_lean8(a, d_args, st, sl) : hipErrorInvalidValue);
     if (fused && (W == 2 || W == 4) && a.reg_nv > 0) return launch_fam_rw(a, d_args, W, st, sl);
-    if (fused && W == 1 && a.reg_nv > 0) return launch_fam_w1(a, d_args, st, sl);
+    if (fused && W == 1 && a.reg_nv > 0) return a.lr_on ? launch_fam_w1_lr(a, d_args, st, sl) : launch_fam_w1(a, d_args, st, sl);
     return launch_fam_mem(a, d_args, fused, W, st, sl);
 }
 #endif   // part 0
@@ -3693,6 +3901,11 @@ hipError_t launch_remote_wn(const Args* d_args, int W, int nv, hipStream_t st, c
 #ifndef NPHIP_JIT_W
 #define NPHIP_JIT_W 1
 #endif
+// -DNPHIP_JIT_LR=1: the library's resident kernel integrates under the low-rank metric (Machine<..., LR>; one wave per chain)
+#ifndef NPHIP_JIT_LR
+#define NPHIP_JIT_LR 0
+#endif
+static_assert(!(NPHIP_JIT_LR != 0 && NPHIP_JIT_W != 1), "the low-rank metric on the register-resident leaf: one wave per chain");
 // one wave per chain: four chains per workgroup; NPHIP_JIT_W waves per chain: one chain per workgroup of 64 W threads
 __global__ __launch_bounds__(NPHIP_JIT_W == 1 ? 256 : 64 * NPHIP_JIT_W) void k_density_batch(const NphipData* __restrict__ data, uint64_t n_chains, int dim, const double* __restrict__ q,
                                                        double* __restrict__ grad, double* __restrict__ logp, int lds_doubles, int shared_doubles, int rows_in_lds) {
@@ -3725,10 +3938,11 @@ extern "C" {
 // nphip_jit_launch_fn (host.hip): one launch of the resident kernel over the slice's chains
 int nphip_jit_launch(const nphip::Args* d_args, int max_evals, void* stream, const nphip::LaunchSlice* sl, uint64_t dyn_lds_bytes) {
     const dim3 g(NPHIP_JIT_W == 1 ? ((unsigned)sl->chain_n + 3) / 4 : (unsigned)sl->chain_n), b(NPHIP_JIT_W == 1 ? 256 : 64 * NPHIP_JIT_W);
-    hipLaunchKernelGGL((nphip::k_advance<false, NPHIP_JIT_W, NPHIP_JIT_NV, false, true>), g, b, (size_t)dyn_lds_bytes, (hipStream_t)stream, d_args, max_evals, 0, *sl);
+    hipLaunchKernelGGL((nphip::k_advance<false, NPHIP_JIT_W, NPHIP_JIT_NV, false, true, (NPHIP_JIT_LR != 0)>), g, b, (size_t)dyn_lds_bytes, (hipStream_t)stream, d_args, max_evals, 0, *sl);
     return (int)hipGetLastError();
 }
 int nphip_jit_w(void) { return NPHIP_JIT_W; }
+int nphip_jit_lr(void) { return NPHIP_JIT_LR; }
 int nphip_jit_nv(void) { return NPHIP_JIT_NV; }
 // nphip_device_logp_fn; user_data -> { device pointer of the data block, LDS doubles per wave }
 struct nphip_jit_batch_t { const void* data; int32_t lds_doubles, shared_doubles; };

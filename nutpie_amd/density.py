@@ -158,10 +158,13 @@ def generated_source(user_source: str, layout) -> str:
     ])
 
 
-def compile_density(user_source: str, layout, ndim: int, *, waves: int = 1, verbose: bool = False) -> str:
-    """Build (or find in the cache) the model's library; returns its path.  ``waves`` wavefronts evaluate one chain's density."""
+def compile_density(user_source: str, layout, ndim: int, *, waves: int = 1, verbose: bool = False, low_rank: bool = False) -> str:
+    """Build (or find in the cache) the model's library; returns its path.  ``waves`` wavefronts evaluate one chain's density.
+    ``low_rank``: the library's resident kernel integrates under the low-rank metric (``adaptation="low_rank"``; one wave per chain)."""
     if waves not in (1, 2, 4):
         raise ValueError("waves_per_chain must be 1, 2 or 4")
+    if low_rank and waves != 1:
+        raise ValueError("the low-rank metric on the resident kernel needs one wave per chain")
     nv = ((int(ndim) + 127) // 128 + waves - 1) // waves   # chunks of 128 dimensions per wave
     src = generated_source(user_source, layout)
     deps = [os.path.join(_CSRC, f) for f in ("kernels.hip", "engine_types.h")] + [os.path.join(_INCLUDE, "nphip_spec.h")]
@@ -169,7 +172,8 @@ def compile_density(user_source: str, layout, ndim: int, *, waves: int = 1, verb
     h.update(src.encode())
     for d in deps:
         h.update(open(d, "rb").read())
-    flags = _FLAGS + ["-DNPHIP_JIT_DENSITY=1", "-DNPHIP_PART=7", f"-DNPHIP_JIT_NV={max(1, nv)}", f"-DNPHIP_JIT_W={waves}"] + os.environ.get("NUTPIE_AMD_JIT_FLAGS", "").split()
+    flags = (_FLAGS + ["-DNPHIP_JIT_DENSITY=1", "-DNPHIP_PART=7", f"-DNPHIP_JIT_NV={max(1, nv)}", f"-DNPHIP_JIT_W={waves}"] + (["-DNPHIP_JIT_LR=1"] if low_rank else [])
+             + os.environ.get("NUTPIE_AMD_JIT_FLAGS", "").split())
     h.update(" ".join(flags).encode())
     out = os.path.join(cache_dir(), f"density_{h.hexdigest()[:24]}.so")
     if os.path.exists(out):
@@ -206,6 +210,8 @@ class DensityLibrary:
         self.waves = int(self.lib.nphip_jit_w())
         self.launch_addr = C.cast(self.lib.nphip_jit_launch, C.c_void_p).value
         self.logp_addr = C.cast(self.lib.nphip_jit_logp, C.c_void_p).value
+        self.lib.nphip_jit_lr.restype = C.c_int
+        self.low_rank = bool(self.lib.nphip_jit_lr())
         self.lib.nphip_jit_has_expand.restype = C.c_int
         self.expand_addr = C.cast(self.lib.nphip_jit_expand, C.c_void_p).value if int(self.lib.nphip_jit_has_expand()) else None
 
@@ -307,12 +313,13 @@ class DensitySourceModel(CompiledModel):
         scratch = torch.empty(slots * per, dtype=torch.float64, device=torch.device("cuda", device))
         return DeviceData(self._data, data_layout(self._data), device, device_arrays={"scratch__": scratch})
 
-    def library_path(self) -> str:
-        """Build (or find) this model's library without loading it — what an ahead-of-time build calls (no GPU needed)."""
-        return compile_density(self._source, data_layout(self._data), self._n_dim, waves=self._waves)
+    def library_path(self, low_rank: bool = False) -> str:
+        """Build (or find) this model's library without loading it — what an ahead-of-time build calls (no GPU needed).
+        ``low_rank``: the variant whose resident kernel integrates under the low-rank metric."""
+        return compile_density(self._source, data_layout(self._data), self._n_dim, waves=self._waves, low_rank=low_rank)
 
-    def library(self) -> DensityLibrary:
-        return DensityLibrary(self.library_path())
+    def library(self, low_rank: bool = False) -> DensityLibrary:
+        return DensityLibrary(self.library_path(low_rank))
 
     def logp_and_grad(self, x, device: int = 0, return_data: bool = False):
         """The compiled density on a block of positions ``x[N, n_dim]`` (one launch of the batched form, ``nphip_jit_logp``):
@@ -341,19 +348,26 @@ class DensitySourceModel(CompiledModel):
         return lp.cpu().numpy(), g.cpu().numpy()
 
     def _make_model(self, init_mean=None, settings=None, device: int = 0, resident: bool | None = None):
-        lib = self.library()
+        low_rank = settings is not None and getattr(settings, "_adaptation", "diag") == "low_rank"
+        # adaptation="low_rank": the resident kernel under the metric where the library can be built for it (one wave per chain, up
+        # to 1024 dimensions), else the batched callback on the memory-resident kernels
+        lr_resident = low_rank and self._waves == 1 and self._n_dim <= 1024
+        lib = self.library(low_rank=lr_resident)
         n_chains = int(getattr(settings, "num_chains", 0) or 0) if settings is not None else 0
         if (callable(self._scratch) or self._scratch) and n_chains <= 0:
             raise ValueError("a density with device-memory scratch needs the settings (num_chains) to size it")
         dd = self._device_data(n_chains, device)
         use_resident = self._resident if resident is None else resident
-        if settings is not None and (bool(getattr(settings, "store_divergences", False)) or getattr(settings, "_adaptation", "diag") == "low_rank"):
+        if settings is not None and (bool(getattr(settings, "store_divergences", False)) or (low_rank and not lr_resident)):
             use_resident = False   # the divergence record needs the pre-step state in memory
+        if lr_resident and not use_resident:
+            lib = self.library()   # (the batched form comes from the plain library)
         if self._n_dim > 1024:
             use_resident = False
         lds_bytes, shared_bytes = self._lds()
         if use_resident:
-            model = _lib.JitDensityModel(self._n_dim, lib.launch_addr, lib.nv, dd.ptr, lds_bytes, shared_bytes, keep_alive=(lib, dd), waves_per_chain=lib.waves)
+            model = _lib.JitDensityModel(self._n_dim, lib.launch_addr, lib.nv, dd.ptr, lds_bytes, shared_bytes, keep_alive=(lib, dd), waves_per_chain=lib.waves,
+                                         low_rank=lib.low_rank)
         else:
             batch = _Batch(dd.ptr, lds_bytes // 8, shared_bytes // 8)
             model = _lib.NativeDeviceCallbackModel(self._n_dim, lib.logp_addr, C.addressof(batch), keep_alive=(lib, dd, batch))

@@ -225,5 +225,23 @@ def uniform_det():
     return m
 
 
-ALL = {"store_extra": store_extra, "dirichlet_counts": dirichlet_counts, "dims_model": dims_model, "no_prior": no_prior, "uniform_det": uniform_det, "radon": radon, "logistic": logistic, "poisson_offsets": poisson_offsets, "scalar_only": scalar_only, "regression": regression,
+def collinear_regression(seed=2, n=400):
+    """A regression on two nearly collinear columns: a strongly correlated posterior (what adaptation="low_rank" is for)."""
+    rng = np.random.default_rng(seed)
+    x1 = rng.normal(size=n)
+    X = np.stack([x1, x1 + 0.02 * rng.normal(size=n), rng.normal(size=n)], 1)
+    y = X @ np.array([1.0, -0.5, 2.0]) + 0.5 * rng.normal(size=n)
+    m = S.Model()
+    Xm = m.matrix("X", X, dim="obs", cols="coef")
+    beta = m.param("beta", dim="coef")
+    sig = m.param("sigma", lower=0.0)
+    yy = m.data("y", y, dim="obs")
+    m.add_logp(S.normal_lpdf(beta, 0.0, 10.0).sum() + S.halfnormal_lpdf(sig, 2.0) + S.normal_lpdf(yy, Xm @ beta, sig).sum())
+    return m
+
+
+ALL = {"collinear_regression": collinear_regression, "store_extra": store_extra, "dirichlet_counts": dirichlet_counts, "dims_model": dims_model, "no_prior": no_prior, "uniform_det": uniform_det, "radon": radon, "logistic": logistic, "poisson_offsets": poisson_offsets, "scalar_only": scalar_only, "regression": regression,
        "plain_regression": plain_regression, "eight_schools": eight_schools, "nested": nested}
+
+# models whose library is also built for the low-rank metric ahead of time (tests/test_gpu_density.py; __graft_entry__.build)
+LOW_RANK = ("eight_schools", "radon", "store_extra", "collinear_regression")

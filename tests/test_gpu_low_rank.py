@@ -42,10 +42,13 @@ def run_engine_with_metrics(hip, model, pauses, sig2, V, lam, *, chains, tune, d
 
 
 @pytest.mark.parametrize("dim,waves,k,launch", [
-    (24, 0, 3, {}),
+    (24, 0, 3, {}),                                 # one wave per chain: the REGISTER-RESIDENT leaf under the metric (round 4)
     (24, 0, 0, {}),                                 # k = 0: a host-supplied DIAGONAL metric (v = std (std p))
-    (300, 0, 11, dict(evals_per_launch=9)),         # more than 8 columns: two reductions
+    (24, 0, 3, dict(no_register_kernel=True)),      # ... and the memory-resident kernels on the same job
+    (300, 0, 11, dict(evals_per_launch=9)),         # more than 8 columns: two reductions; launch boundaries every 9 leapfrogs
+    (300, 0, 11, dict(no_register_kernel=True)),
     (300, 2, 16, {}),
+    (1000, 0, 4, dict(evals_per_launch=37)),        # eight chunks per lane in registers (+ the velocity: the full register file)
     (1300, 0, 4, {}),                               # two waves per chain
     (5003, 0, 2, dict(evals_per_launch=13)),        # four waves per chain (memory-resident kernels under the low-rank metric)
 ])
