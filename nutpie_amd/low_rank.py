@@ -32,6 +32,7 @@ import numpy as np
 
 K_MAX = 16            # columns kept per chain (the reference has no such knob; windows of <= 64 draws span <= 128 directions)
 WINDOW_MAX = 64       # draws (and gradients) per estimate
+HOLD_LAUNCHES = 3     # looks (a launch, or a few ms of launches) a stopped chain waits for company before it is handed in on its own
 SWITCH_FRACTIONS = (0.08, 0.2, 0.4, 0.65)   # of num_tune: window boundaries; the last leaves 35 % of warm-up to the step size
 
 
@@ -82,6 +83,29 @@ class Transform:
         return (1.0 + self.d) ** 2
 
 
+EIGH_PAD = 128        # rocSOLVER's path for symmetric problems of order <= 64 takes 90-210 ms per batch of 512 (measured on MI355X,
+                      # scratch/eigh_time.py), the blocked path for larger ones 5-12 ms: small problems are embedded in a larger one
+
+
+def _eigh_psd(A):
+    """``torch.linalg.eigh`` of a batch of positive semi-definite matrices.  Orders <= 64 are embedded as the leading block of a
+    block-diagonal problem of order EIGH_PAD whose other block is diagonal with distinct negative entries: those come out first
+    (eigenvalues ascend) and are cut off, the block's own eigenpairs are unchanged."""
+    import torch
+
+    s = A.shape[-1]
+    if s > 64 or not A.is_cuda:
+        return torch.linalg.eigh(A)
+    n = A.shape[0]
+    P = torch.zeros(n, EIGH_PAD, EIGH_PAD, dtype=A.dtype, device=A.device)
+    P[:, :s, :s] = A
+    idx = torch.arange(s, EIGH_PAD, device=A.device)
+    scale = torch.diagonal(A, dim1=1, dim2=2).abs().amax(1).clamp_min(1e-300)                   # [n]
+    P[:, idx, idx] = -(1.0 + (idx - s).to(A.dtype))[None, :] * scale[:, None]
+    e, U = torch.linalg.eigh(P)
+    return e[:, EIGH_PAD - s:].contiguous(), U[:, :s, EIGH_PAD - s:].contiguous()
+
+
 def estimate(x, gx, gamma: float, cutoff: float, k_max: int = K_MAX) -> Transform:
     """The low-rank metric of every chain from its window: ``x``, ``gx``: [n, m, D] draws and gradients in model space.
 
@@ -103,7 +127,7 @@ def estimate(x, gx, gamma: float, cutoff: float, k_max: int = K_MAX) -> Transfor
     X = (x - mean[:, None, :]) / stds[:, None, :]
     G = (gx - gx.mean(1, keepdim=True)) * stds[:, None, :]
     Z = torch.cat([X, G], 1)                                   # [n, 2m, D]
-    ev, U = torch.linalg.eigh(Z @ Z.transpose(1, 2))           # [n, 2m], [n, 2m, 2m]
+    ev, U = _eigh_psd(Z @ Z.transpose(1, 2))           # [n, 2m], [n, 2m, 2m]
     keep = ev > (1e-10 * ev[:, -1:].clamp_min(1e-300))
     scale = torch.where(keep, ev.clamp_min(1e-300).rsqrt(), torch.zeros_like(ev))
     Q = Z.transpose(1, 2) @ (U * scale[:, None, :])            # [n, D, 2m], orthonormal columns (zero where dropped)
@@ -112,14 +136,14 @@ def estimate(x, gx, gamma: float, cutoff: float, k_max: int = K_MAX) -> Transfor
     Cx = Px.transpose(1, 2) @ Px / m + gamma * eye
     Cg = Pg.transpose(1, 2) @ Pg / m + gamma * eye
     # S = Cg^-1/2 (Cg^1/2 Cx Cg^1/2)^1/2 Cg^-1/2
-    eg, Ug = torch.linalg.eigh(Cg)
+    eg, Ug = _eigh_psd(Cg)
     eg = eg.clamp_min(1e-300)
     half = (Ug * eg.sqrt()[:, None, :]) @ Ug.transpose(1, 2)
     ihalf = (Ug * eg.rsqrt()[:, None, :]) @ Ug.transpose(1, 2)
-    em, Um = torch.linalg.eigh(half @ Cx @ half)
+    em, Um = _eigh_psd(half @ Cx @ half)
     mid = (Um * em.clamp_min(0).sqrt()[:, None, :]) @ Um.transpose(1, 2)
     S = ihalf @ mid @ ihalf
-    es, W = torch.linalg.eigh(0.5 * (S + S.transpose(1, 2)))
+    es, W = _eigh_psd(0.5 * (S + S.transpose(1, 2)))
     es = es.clamp_min(1e-300)
     # Re-centre the spectrum on its bulk.  With strong correlations sqrt(std(x) / std(g)) over-scales EVERY coordinate (std(x)
     # carries the shared directions, std(g) the conditional precisions): a few eigenvalues end up large and all the others small
@@ -169,8 +193,7 @@ class LowRankSampler:
         self._device = device
         self._gamma, self._cutoff = float(gamma), float(cutoff)
         self._pauses = list(pauses)
-        self._next = 0                # index of the next pause
-        self._lo = 0                  # first draw of the current window
+        self._chain_next = np.zeros(inner.num_chains, dtype=np.int64)   # per chain: index of the next boundary it stops at
         self._lock = threading.Lock()
         self._cv = threading.Condition(self._lock)
         self._step_lock = threading.Lock()   # held while the engine steps or a metric is being installed: readers take it
@@ -178,13 +201,20 @@ class LowRankSampler:
         self._abort = False
         self._done = False
         self._error = None
-        self.switch_log = []          # (draws finished, mean number of columns used, seconds spent estimating)
+        self.switch_log = []          # (boundary draw, mean number of columns used, seconds spent estimating, chains handed in)
         self._thread = threading.Thread(target=self._run, daemon=True)
         self._thread.start()
 
     # ------------------------------------------------------------------ driver
     def _run(self):
+        """Drive the engine one launch at a time while chains can still stop at a window boundary.  A chain that has stopped gets
+        ITS new metric without waiting for the other chains: the estimate is per chain anyway, and in lockstep a single chain
+        with a poor early metric (max-depth trees for a whole window) held 511 finished chains for most of the job (measured:
+        radon, 512 chains: 284 launches for a mean of 50 launches' worth of work per chain, profiles/r4_low_rank_driver.txt).
+        Stopped chains are handed in together: when nothing else is running, when they are a quarter of the unfinished chains,
+        or after HOLD_LAUNCHES looks — each hand-in is one batched estimate (tens of ms), the same order as a launch."""
         try:
+            held, per_check = 0, 1
             while True:
                 with self._cv:
                     while self._paused and not self._abort:
@@ -192,13 +222,24 @@ class LowRankSampler:
                     if self._abort:
                         break
                 with self._step_lock:
-                    done, _, _ = self._inner.step(16)
+                    pending = bool((self._chain_next < len(self._pauses)).any())
+                    done, cnt, ms = self._inner.step(per_check if pending else 16)
                     if done:
                         break
-                    if self._next < len(self._pauses):
+                    if pending:
+                        # a few ms of engine time between two looks at the chains: one launch of a resident kernel (hundreds of
+                        # gradient evaluations per chain), sixteen of a model whose launches are one evaluation each
+                        if cnt:
+                            per_check = int(min(16, max(1, round(4.0 * cnt / max(ms, 1e-3)))))
                         code = self._inner.waiting_codes()
-                        if (code == 1).any() and not (code == 0).any():
-                            self._adapt(np.nonzero(code == 1)[0])
+                        wait = code == 1
+                        if wait.any():
+                            n_wait, n_run = int(wait.sum()), int((code == 0).sum())
+                            if n_run == 0 or 4 * n_wait >= n_wait + n_run or held >= HOLD_LAUNCHES:
+                                self._adapt(np.nonzero(wait)[0])
+                                held = 0
+                            else:
+                                held += 1
         except BaseException as e:  # noqa: BLE001 - reported by wait()
             self._error = e
         finally:
@@ -215,27 +256,34 @@ class LowRankSampler:
         return draws, grads
 
     def _adapt(self, chains):
+        """New metric for the stopped ``chains`` (each is at ITS next window boundary; chains at the same boundary are estimated
+        as one batch)."""
         import torch
 
-        t0 = time.perf_counter()
-        hi, lo = self._pauses[self._next], self._lo
         draws, grads = self._views()
-        with torch.no_grad():
-            m = min(WINDOW_MAX, max(4, (hi - lo) * 2 // 3))
-            T_new = estimate(draws[:, hi - m:hi], grads[:, hi - m:hi], self._gamma, self._cutoff)
-            sig2, V, lam = metric_of(T_new)
-            idx = torch.as_tensor(chains, device=sig2.device)
-            if len(chains) != sig2.shape[0]:
-                sig2, V, lam = sig2[idx].contiguous(), V[idx].contiguous(), lam[idx].contiguous()
-            # only the columns some chain uses (estimate() puts a chain's used columns first): every column handed in costs every
-            # leapfrog of every chain a dot product and an update in both halves of the step — sixteen when two or three are live
-            k_used = int((lam != 1.0).sum(1).max().item()) if lam.numel() else 0
-            V, lam = V[:, :k_used].contiguous(), lam[:, :k_used].contiguous()
-            torch.cuda.synchronize(self._device)
-            self._inner.set_metric(chains, sig2, V if k_used else None, lam if k_used else None)
-        self._lo = hi
-        self._next += 1
-        self.switch_log.append((hi, float((T_new.d != 0).sum(1).double().mean()), time.perf_counter() - t0))
+        chains = np.asarray(chains)
+        at = self._chain_next[chains].copy()
+        for i in np.unique(at):
+            t0 = time.perf_counter()
+            grp = chains[at == i]
+            hi, lo = self._pauses[i], (self._pauses[i - 1] if i else 0)
+            with torch.no_grad():
+                m = min(WINDOW_MAX, max(4, (hi - lo) * 2 // 3))
+                if len(grp) == draws.shape[0]:
+                    x, g = draws[:, hi - m:hi], grads[:, hi - m:hi]
+                else:
+                    idx = torch.as_tensor(grp, device=draws.device)
+                    x, g = draws[idx, hi - m:hi], grads[idx, hi - m:hi]
+                T_new = estimate(x, g, self._gamma, self._cutoff)
+                sig2, V, lam = metric_of(T_new)
+                # only the columns some chain uses (estimate() puts a chain's used columns first): every column handed in costs
+                # every leapfrog of every chain a dot product and an update in both halves of the step
+                k_used = int((lam != 1.0).sum(1).max().item()) if lam.numel() else 0
+                V, lam = V[:, :k_used].contiguous(), lam[:, :k_used].contiguous()
+                torch.cuda.synchronize(self._device)
+                self._inner.set_metric(grp, sig2, V if k_used else None, lam if k_used else None)
+            self._chain_next[grp] = i + 1
+            self.switch_log.append((hi, float((T_new.d != 0).sum(1).double().mean()), time.perf_counter() - t0, len(grp)))
 
     # ------------------------------------------------------------------ handle surface
     def wait(self, timeout_seconds=None):
