@@ -471,12 +471,29 @@ struct Machine {
 #pragma unroll
         for (int j = 0; j < kLrMax; ++j) { S_.a[j].x = 0.0; S_.a[j].y = 0.0; }
     }
+    // The columns are taken four at a time where four are live: a load per column behind its own `j < k` branch is a round trip
+    // to L2 per column (nothing may be loaded ahead of the branch that guards it), four loads behind one branch are one round
+    // trip.  Same operations on the same values in the same order per element as a column at a time.
     __device__ __forceinline__ void lr_acc(LrAcc& S_, int k, int64_t i, const double2 u) const {
+        const int kq = k & ~3;
 #pragma unroll
-        for (int j = 0; j < kLrMax; ++j) if (j < k) {
-            const double2 vj = ld2(LRV(j), i);
-            S_.a[j].x = fma(vj.x, u.x, S_.a[j].x);
-            S_.a[j].y = fma(vj.y, u.y, S_.a[j].y);
+        for (int j0 = 0; j0 < kLrMax; j0 += 4) if (j0 < kq) {
+            double2 vj[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) vj[t] = ld2(LRV(j0 + t), i);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                S_.a[j0 + t].x = fma(vj[t].x, u.x, S_.a[j0 + t].x);
+                S_.a[j0 + t].y = fma(vj[t].y, u.y, S_.a[j0 + t].y);
+            }
+        }
+        if (kq != k) {
+#pragma unroll
+            for (int j = 0; j < kLrMax; ++j) if (j >= kq && j < k) {
+                const double2 vj = ld2(LRV(j), i);
+                S_.a[j].x = fma(vj.x, u.x, S_.a[j].x);
+                S_.a[j].y = fma(vj.y, u.y, S_.a[j].y);
+            }
         }
     }
     // dots -> coefficients: which = 0: c_j = (lambda_j - 1) d_j (velocity); 1: f_j = (1 / sqrt(lambda_j) - 1) d_j (momentum draw)
@@ -494,11 +511,66 @@ struct Machine {
         }
     }
     __device__ __forceinline__ double2 lr_apply(int k, int64_t i, double2 w, const double (&cf)[kLrMax]) const {
+        const int kq = k & ~3;
 #pragma unroll
-        for (int j = 0; j < kLrMax; ++j) if (j < k) {
-            const double2 vj = ld2(LRV(j), i);
-            w.x = fma(vj.x, cf[j], w.x);
-            w.y = fma(vj.y, cf[j], w.y);
+        for (int j0 = 0; j0 < kLrMax; j0 += 4) if (j0 < kq) {
+            double2 vj[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) vj[t] = ld2(LRV(j0 + t), i);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                w.x = fma(vj[t].x, cf[j0 + t], w.x);
+                w.y = fma(vj[t].y, cf[j0 + t], w.y);
+            }
+        }
+        if (kq != k) {
+#pragma unroll
+            for (int j = 0; j < kLrMax; ++j) if (j >= kq && j < k) {
+                const double2 vj = ld2(LRV(j), i);
+                w.x = fma(vj.x, cf[j], w.x);
+                w.y = fma(vj.y, cf[j], w.y);
+            }
+        }
+        return w;
+    }
+
+    // The register-resident leaf takes a whole pass over the columns without a branch: the number of columns rounded up to a
+    // multiple of four is a compile-time constant inside `lr_dispatch`, so every load of the pass (all chunks, all columns) can be
+    // in flight at once — one round trip to L2 per pass instead of one per chunk and group.  Columns k .. KC-1 are zero in memory
+    // (k_set_metric); their dots are dropped by lr_coef and their coefficients are 0.
+    template <int N> struct LrCols { static constexpr int value = N; };
+    template <class F> __device__ __forceinline__ void lr_dispatch(int k, F&& f) {
+        switch ((k + 3) >> 2) {
+            case 0: f(LrCols<0>{}); break;   // (a metric without columns: the passes still do their diagonal part)
+            case 1: f(LrCols<4>{}); break;
+            case 2: f(LrCols<8>{}); break;
+            case 3: f(LrCols<12>{}); break;
+            case 4: f(LrCols<16>{}); break;
+            default: break;
+        }
+    }
+    template <int KC> __device__ __forceinline__ void lr_acc_c(LrAcc& S_, int64_t i, const double2 u) const {
+        if constexpr (KC > 0) {
+            double2 vj[KC];
+#pragma unroll
+            for (int t = 0; t < KC; ++t) vj[t] = ld2(LRV(t), i);
+#pragma unroll
+            for (int t = 0; t < KC; ++t) {
+                S_.a[t].x = fma(vj[t].x, u.x, S_.a[t].x);
+                S_.a[t].y = fma(vj[t].y, u.y, S_.a[t].y);
+            }
+        }
+    }
+    template <int KC> __device__ __forceinline__ double2 lr_apply_c(int64_t i, double2 w, const double (&cf)[kLrMax]) const {
+        if constexpr (KC > 0) {
+            double2 vj[KC];
+#pragma unroll
+            for (int t = 0; t < KC; ++t) vj[t] = ld2(LRV(t), i);
+#pragma unroll
+            for (int t = 0; t < KC; ++t) {
+                w.x = fma(vj[t].x, cf[t], w.x);
+                w.y = fma(vj[t].y, cf[t], w.y);
+            }
         }
         return w;
     }
@@ -1813,10 +1885,7 @@ struct Machine {
             if (LR) vold[k] = X.v[k];
             X.p[k].x = fma(h, X.g[k].x, X.p[k].x);
             X.p[k].y = fma(h, X.g[k].y, X.p[k].y);
-            if (LR && lrm) {   // the products of u = std p_half with the columns first; the drift follows the reduction
-                double2 u;
-                u.x = X.sd[k].x * X.p[k].x; u.y = X.sd[k].y * X.p[k].y;
-                lr_acc(lrS, lrk, ridx(k), u);
+            if (LR && lrm) {   // the products of u = std p_half with the columns first (below); the drift follows the reduction
             } else {
                 X.q[k].x = fma(eps, X.s[k].x * X.p[k].x, X.q[k].x);
                 X.q[k].y = fma(eps, X.s[k].y * X.p[k].y, X.q[k].y);
@@ -1828,15 +1897,28 @@ struct Machine {
             }
         }
         if (LR && lrm) {
-            lr_coef(lrS, lrk, 0, lrc);
+            lr_dispatch(lrk, [&](auto kc) {
 #pragma unroll
-            for (int k = 0; k < NVX; ++k) {
-                double2 u;
-                u.x = X.sd[k].x * X.p[k].x; u.y = X.sd[k].y * X.p[k].y;
-                const double2 w = lr_apply(lrk, ridx(k), u, lrc);
-                X.q[k].x = fma(eps, X.sd[k].x * w.x, X.q[k].x);
-                X.q[k].y = fma(eps, X.sd[k].y * w.y, X.q[k].y);
-                if (!REMOTE) {
+                for (int k = 0; k < NVX; ++k) {
+                    double2 u;
+                    u.x = X.sd[k].x * X.p[k].x; u.y = X.sd[k].y * X.p[k].y;
+                    lr_acc_c<decltype(kc)::value>(lrS, ridx(k), u);
+                }
+            });
+            lr_coef(lrS, lrk, 0, lrc);
+            lr_dispatch(lrk, [&](auto kc) {
+#pragma unroll
+                for (int k = 0; k < NVX; ++k) {
+                    double2 u;
+                    u.x = X.sd[k].x * X.p[k].x; u.y = X.sd[k].y * X.p[k].y;
+                    const double2 w = lr_apply_c<decltype(kc)::value>(ridx(k), u, lrc);
+                    X.q[k].x = fma(eps, X.sd[k].x * w.x, X.q[k].x);
+                    X.q[k].y = fma(eps, X.sd[k].y * w.y, X.q[k].y);
+                }
+            });
+            if (!REMOTE) {
+#pragma unroll
+                for (int k = 0; k < NVX; ++k) {
                     const double2 mu = par_mu(ridx(k));
                     z[k].x = X.q[k].x - mu.x;
                     z[k].y = X.q[k].y - mu.y;
@@ -1895,12 +1977,7 @@ struct Machine {
             X.p[k].y = fma(h, gg.y, X.p[k].y);
             X.r[k].x = rold[k].x + X.p[k].x;
             X.r[k].y = rold[k].y + X.p[k].y;
-            if (LR && lrm) {   // the velocity of the new state needs the products with the columns first: second loop below
-                double2 u;
-                u.x = X.sd[k].x * X.p[k].x; u.y = X.sd[k].y * X.p[k].y;
-                lr_acc(lrS, lrk, ridx(k), u);
-                continue;
-            }
+            if (LR && lrm) continue;   // the velocity of the new state needs the products with the columns first: below
             const double vx = X.s[k].x * X.p[k].x, vy = X.s[k].y * X.p[k].y;
             accK.x = fma(X.p[k].x, vx, accK.x);
             accK.y = fma(X.p[k].y, vy, accK.y);
@@ -1918,13 +1995,26 @@ struct Machine {
             }
         }
         if (LR && lrm) {
+            lr_dispatch(lrk, [&](auto kc) {
+#pragma unroll
+                for (int k = 0; k < NVX; ++k) {
+                    double2 u;
+                    u.x = X.sd[k].x * X.p[k].x; u.y = X.sd[k].y * X.p[k].y;
+                    lr_acc_c<decltype(kc)::value>(lrS, ridx(k), u);
+                }
+            });
             lr_coef(lrS, lrk, 0, lrc);
+            lr_dispatch(lrk, [&](auto kc) {
+#pragma unroll
+                for (int k = 0; k < NVX; ++k) {
+                    double2 u;
+                    u.x = X.sd[k].x * X.p[k].x; u.y = X.sd[k].y * X.p[k].y;
+                    const double2 w = lr_apply_c<decltype(kc)::value>(ridx(k), u, lrc);
+                    X.v[k].x = X.sd[k].x * w.x; X.v[k].y = X.sd[k].y * w.y;
+                }
+            });
 #pragma unroll
             for (int k = 0; k < NVX; ++k) {
-                double2 u;
-                u.x = X.sd[k].x * X.p[k].x; u.y = X.sd[k].y * X.p[k].y;
-                const double2 w = lr_apply(lrk, ridx(k), u, lrc);
-                X.v[k].x = X.sd[k].x * w.x; X.v[k].y = X.sd[k].y * w.y;
                 accK.x = fma(X.p[k].x, X.v[k].x, accK.x);
                 accK.y = fma(X.p[k].y, X.v[k].y, accK.y);
                 const double tx0 = (X.r[k].x - rold[k].x) + pold[k].x, ty0 = (X.r[k].y - rold[k].y) + pold[k].y;
