@@ -39,13 +39,14 @@ if __name__ == "__main__":
             print(D, cm.library_path(False), cm.library_path(True))
             continue
         import nutpie_amd
-        for adaptation in ("diag", "low_rank"):
+        runs = [("diag", 500), ("low_rank", 500)] + ([("diag", 1000), ("diag", 2000), ("diag", 4000), ("low_rank", 1000)] if D == 500 else [])
+        for adaptation, tune in runs:
             for rep in range(2):   # the second run: libraries loaded, rocSOLVER initialised
                 t0 = time.perf_counter()
-                tr = nutpie_amd.sample(cm, adaptation=adaptation, chains=256, tune=500, draws=500, seed=3, progress_bar=False)
+                tr = nutpie_amd.sample(cm, adaptation=adaptation, chains=256, tune=tune, draws=500, seed=3, progress_bar=False)
                 dt = time.perf_counter() - t0
             st = tr.sample_stats
             x = tr.posterior.x.values.reshape(-1, D)
             err = np.abs(np.sqrt(np.diag(np.cov(x.T))) / np.sqrt(np.diag(Sigma)) - 1).max()
-            print(f"D={D} ({nd} strong directions) {adaptation:8s}: {st.n_steps.values.mean():7.1f} leapfrogs per draw (depth {st.depth.values.mean():.2f}), "
+            print(f"D={D} ({nd} strong directions) {adaptation:8s} tune {tune:4d}: {st.n_steps.values.mean():7.1f} leapfrogs per draw (depth {st.depth.values.mean():.2f}), "
                   f"warm-up {tr.warmup_sample_stats.n_steps.values.sum() / 1e6:.2f} M leapfrogs, job {dt:.2f} s, max rel. sd error {err:.3f}")
