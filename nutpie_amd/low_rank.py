@@ -280,7 +280,8 @@ class LowRankSampler:
                 # every leapfrog of every chain a dot product and an update in both halves of the step
                 k_used = int((lam != 1.0).sum(1).max().item()) if lam.numel() else 0
                 V, lam = V[:, :k_used].contiguous(), lam[:, :k_used].contiguous()
-                torch.cuda.synchronize(self._device)
+                if sig2.is_cuda:
+                    torch.cuda.synchronize(self._device)
                 self._inner.set_metric(grp, sig2, V if k_used else None, lam if k_used else None)
             self._chain_next[grp] = i + 1
             self.switch_log.append((hi, float((T_new.d != 0).sum(1).double().mean()), time.perf_counter() - t0, len(grp)))

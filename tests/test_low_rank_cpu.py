@@ -113,3 +113,77 @@ def test_estimator_against_its_cpu_oracle(n, D, m, seed, gamma, cutoff, tol):
         # (and the metric does what it is for: in its coordinates the window's covariance is within the cutoff of the identity
         #  along the directions the window spans — the property the older test checks on the engine's version alone)
         np.testing.assert_allclose(np.sort(lc), np.sort(lam[c].numpy()[lam[c].numpy() != 1]), rtol=max(tol, 1e-9) * 100)
+
+
+class _FakeEngine:
+    """What LowRankSampler needs of a manual-mode PySampler, on the CPU: chains that advance at their own speed, stop at the
+    pause draws, and go on when `set_metric` names them.  Draws and gradients are fixed random arrays, so the metric a chain
+    must receive at a boundary can be recomputed from its own window."""
+
+    def __init__(self, n, total, dim, pauses, speed, seed=0):
+        g = torch.Generator().manual_seed(seed)
+        self.num_chains, self.total_draws, self.dim = n, total, dim
+        self.draws = torch.randn(n, total, dim, generator=g, dtype=torch.float64)
+        self.grads = -self.draws * torch.exp(torch.randn(n, 1, dim, generator=g, dtype=torch.float64)) + 0.1 * torch.randn(n, total, dim, generator=g, dtype=torch.float64)
+        self.pauses, self.speed = list(pauses), np.asarray(speed)
+        self.at = np.zeros(n, dtype=np.int64)            # finished draws
+        self.waiting = np.zeros(n, dtype=bool)
+        self.passed = np.zeros(n, dtype=np.int64)        # boundaries this chain has been resumed at
+        self.log = []                                    # (step number, chain, boundary draw, sigma2 row, k)
+        self.steps = 0
+
+    def step(self, n_launches=1):
+        for _ in range(int(n_launches)):
+            self.steps += 1
+            for c in range(self.num_chains):
+                if self.waiting[c] or self.at[c] >= self.total_draws:
+                    continue
+                stop = self.pauses[self.passed[c]] if self.passed[c] < len(self.pauses) else self.total_draws
+                self.at[c] = min(self.at[c] + self.speed[c], stop, self.total_draws)
+                if self.at[c] == stop and stop < self.total_draws:
+                    self.waiting[c] = True
+        return bool((self.at >= self.total_draws).all()), int(n_launches), 10.0 * n_launches
+
+    def waiting_codes(self):
+        return np.where(self.at >= self.total_draws, 2, np.where(self.waiting, 1, 0)).astype(np.uint8)
+
+    def set_metric(self, chains, sig2, V, lam):
+        chains = np.asarray(chains)
+        assert self.waiting[chains].all(), "a metric for a chain that has not stopped"
+        assert sig2.shape == (len(chains), self.dim) and (V is None or V.shape[0] == len(chains))
+        for r, c in enumerate(chains):
+            self.log.append((self.steps, int(c), int(self.at[c]), sig2[r].clone(), 0 if V is None else V.shape[1]))
+            self.passed[c] += 1
+            self.waiting[c] = False
+
+
+def test_driver_hands_every_chain_its_own_windows_without_lock_step():
+    """LowRankSampler._run: every chain receives one metric per boundary, in order, estimated from ITS window of draws and
+    gradients — and a chain that crawls does not hold the others (they are handed in, and finish, long before it arrives)."""
+    from nutpie_amd import low_rank as lr
+
+    n, total, dim = 6, 150, 8
+    pauses = [30, 60, 90]
+    eng = _FakeEngine(n, total, dim, pauses, speed=[1, 20, 20, 15, 20, 10])
+
+    class Driver(lr.LowRankSampler):
+        def _views(self):
+            return self._inner.draws, self._inner.grads
+
+    smp = Driver(eng, 0, 1e-5, 2.0, pauses)
+    smp.wait(timeout_seconds=120)
+    assert smp.is_finished() and (eng.at == total).all()
+    by_chain = {c: [e for e in eng.log if e[1] == c] for c in range(n)}
+    for c, entries in by_chain.items():
+        assert [e[2] for e in entries] == pauses, f"chain {c}: boundaries {[e[2] for e in entries]}"
+        for i, (_, _, hi, sig2, _) in enumerate(entries):
+            lo = pauses[i - 1] if i else 0
+            m = min(lr.WINDOW_MAX, max(4, (hi - lo) * 2 // 3))
+            T = lr.estimate(eng.draws[c:c + 1, hi - m:hi], eng.grads[c:c + 1, hi - m:hi], 1e-5, 2.0)
+            assert torch.allclose(sig2, (T.stds * T.stds)[0], rtol=1e-12, atol=0), f"chain {c}, boundary {hi}: not its own window"
+    # the crawling chain reaches its first boundary after every other chain has passed its last one
+    first_slow = by_chain[0][0][0]
+    assert all(by_chain[c][-1][0] < first_slow for c in range(1, n))
+    # the hand-ins are batched: fewer estimates than (chain, boundary) pairs
+    assert len(smp.switch_log) < n * len(pauses)
+    assert sum(e[3] for e in smp.switch_log) == n * len(pauses)
