@@ -24,6 +24,7 @@ switch.  The :class:`Transform` below is what is left of it: the algebra the est
 
 from __future__ import annotations
 
+import contextlib
 import threading
 import time
 from dataclasses import dataclass
@@ -194,6 +195,7 @@ class LowRankSampler:
         self._gamma, self._cutoff = float(gamma), float(cutoff)
         self._pauses = list(pauses)
         self._chain_next = np.zeros(inner.num_chains, dtype=np.int64)   # per chain: index of the next boundary it stops at
+        self._stream = None           # the estimator's stream (made on its thread)
         self._lock = threading.Lock()
         self._cv = threading.Condition(self._lock)
         self._step_lock = threading.Lock()   # held while the engine steps or a metric is being installed: readers take it
@@ -210,11 +212,20 @@ class LowRankSampler:
         """Drive the engine one launch at a time while chains can still stop at a window boundary.  A chain that has stopped gets
         ITS new metric without waiting for the other chains: the estimate is per chain anyway, and in lockstep a single chain
         with a poor early metric (max-depth trees for a whole window) held 511 finished chains for most of the job (measured:
-        radon, 512 chains: 284 launches for a mean of 50 launches' worth of work per chain, profiles/r4_low_rank_driver.txt).
-        Stopped chains are handed in together: when nothing else is running, when they are a quarter of the unfinished chains,
-        or after HOLD_LAUNCHES looks — each hand-in is one batched estimate (tens of ms), the same order as a launch."""
+        radon, 512 chains: 284 launches for a mean of 50 launches' worth of work per chain,
+        profiles/r4_low_rank_register_kernel.txt §4).  The estimate runs on a worker thread and its own stream WHILE the engine
+        does its next launch for the chains that have not stopped, and is installed right after that launch — always that one,
+        so that which chains are estimated together (rocSOLVER's batched results depend on the batch in the last bits) depends
+        on the engine's state alone and a job is reproducible from its seed.  Stopped chains are handed in together: when nothing
+        else is running, when they are a quarter of the unfinished chains, or after HOLD_LAUNCHES looks."""
+        from concurrent.futures import ThreadPoolExecutor
+
+        pool = ThreadPoolExecutor(1)
         try:
-            held, per_check = 0, 1
+            held = 0
+            per_look, probe_ms, probe_n = 1, 0.0, 0                # launches between two looks: fixed after the first three
+            job = None                                             # the estimate in flight
+            busy = np.zeros(self._inner.num_chains, dtype=bool)    # chains whose estimate is in flight
             while True:
                 with self._cv:
                     while self._paused and not self._abort:
@@ -223,26 +234,37 @@ class LowRankSampler:
                         break
                 with self._step_lock:
                     pending = bool((self._chain_next < len(self._pauses)).any())
-                    done, cnt, ms = self._inner.step(per_check if pending else 16)
+                    done, cnt, ms = self._inner.step(per_look if pending else 16)
+                    if job is not None:                            # its estimate ran while the engine did that launch
+                        self._install(job.result())
+                        busy[:] = False
+                        job = None
                     if done:
                         break
                     if pending:
                         # a few ms of engine time between two looks at the chains: one launch of a resident kernel (hundreds of
-                        # gradient evaluations per chain), sixteen of a model whose launches are one evaluation each
-                        if cnt:
-                            per_check = int(min(16, max(1, round(4.0 * cnt / max(ms, 1e-3)))))
+                        # gradient evaluations per chain), sixteen of a model whose launches are one evaluation each.  Decided
+                        # once: when the looks happen decides which chains are estimated together, and a job must not depend
+                        # on the clock.
+                        if probe_n >= 0:
+                            probe_ms, probe_n = probe_ms + ms, probe_n + cnt
+                            if probe_n >= 3:
+                                per_look, probe_n = (1 if probe_ms / probe_n >= 0.5 else 16), -1
                         code = self._inner.waiting_codes()
-                        wait = code == 1
+                        wait = (code == 1) & ~busy
                         if wait.any():
                             n_wait, n_run = int(wait.sum()), int((code == 0).sum())
                             if n_run == 0 or 4 * n_wait >= n_wait + n_run or held >= HOLD_LAUNCHES:
-                                self._adapt(np.nonzero(wait)[0])
+                                grp = np.nonzero(wait)[0]
+                                busy[grp] = True
+                                job = pool.submit(self._estimate, grp, self._chain_next[grp].copy())
                                 held = 0
                             else:
                                 held += 1
         except BaseException as e:  # noqa: BLE001 - reported by wait()
             self._error = e
         finally:
+            pool.shutdown(wait=True)
             with self._cv:
                 self._done = True
                 self._cv.notify_all()
@@ -255,19 +277,23 @@ class LowRankSampler:
         grads = device_tensor(self._inner.device_ptr("gradient"), (n, T, D), "float64", self._device)
         return draws, grads
 
-    def _adapt(self, chains):
-        """New metric for the stopped ``chains`` (each is at ITS next window boundary; chains at the same boundary are estimated
-        as one batch)."""
+    def _estimate(self, chains, at):
+        """(worker thread) New metrics for the stopped ``chains``; ``at``: the index of the boundary each one is at.  Chains at the
+        same boundary are one batch.  -> [(chains, boundary index, sigma^2, V, lambda, log entry)], ready to install."""
         import torch
 
         draws, grads = self._views()
-        chains = np.asarray(chains)
-        at = self._chain_next[chains].copy()
-        for i in np.unique(at):
-            t0 = time.perf_counter()
-            grp = chains[at == i]
-            hi, lo = self._pauses[i], (self._pauses[i - 1] if i else 0)
-            with torch.no_grad():
+        out = []
+        cuda = draws.is_cuda
+        if cuda:
+            torch.cuda.set_device(self._device)
+            if self._stream is None:
+                self._stream = torch.cuda.Stream(self._device)
+        with torch.no_grad(), (torch.cuda.stream(self._stream) if cuda else contextlib.nullcontext()):
+            for i in np.unique(at):
+                t0 = time.perf_counter()
+                grp = chains[at == i]
+                hi, lo = self._pauses[i], (self._pauses[i - 1] if i else 0)
                 m = min(WINDOW_MAX, max(4, (hi - lo) * 2 // 3))
                 if len(grp) == draws.shape[0]:
                     x, g = draws[:, hi - m:hi], grads[:, hi - m:hi]
@@ -280,11 +306,23 @@ class LowRankSampler:
                 # every leapfrog of every chain a dot product and an update in both halves of the step
                 k_used = int((lam != 1.0).sum(1).max().item()) if lam.numel() else 0
                 V, lam = V[:, :k_used].contiguous(), lam[:, :k_used].contiguous()
-                if sig2.is_cuda:
-                    torch.cuda.synchronize(self._device)
-                self._inner.set_metric(grp, sig2, V if k_used else None, lam if k_used else None)
+                cols = float((T_new.d != 0).sum(1).double().mean())
+                if cuda:
+                    self._stream.synchronize()
+                out.append((grp, int(i), sig2, V if k_used else None, lam if k_used else None, (hi, cols, time.perf_counter() - t0, len(grp))))
+        return out
+
+    def _install(self, metrics):
+        """(driver thread, between two launches) hand the estimated metrics to the engine"""
+        for grp, i, sig2, V, lam, entry in metrics:
+            self._inner.set_metric(grp, sig2, V, lam)
             self._chain_next[grp] = i + 1
-            self.switch_log.append((hi, float((T_new.d != 0).sum(1).double().mean()), time.perf_counter() - t0, len(grp)))
+            self.switch_log.append(entry)
+
+    def _adapt(self, chains):
+        """Estimate and install in one go (what the driver does, without the overlap)."""
+        chains = np.asarray(chains)
+        self._install(self._estimate(chains, self._chain_next[chains].copy()))
 
     # ------------------------------------------------------------------ handle surface
     def wait(self, timeout_seconds=None):

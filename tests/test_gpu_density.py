@@ -213,3 +213,23 @@ def test_low_rank_adaptation_of_a_model_written_as_expressions(hip):
     np.testing.assert_allclose(b_lr.mean(0), b_dg.mean(0), atol=4 * b_dg.std(0).max() / np.sqrt(200))
     np.testing.assert_allclose(b_lr.std(0), b_dg.std(0), rtol=0.15)
     assert lr.sample_stats.diverging.values.mean() < 0.01
+
+
+def test_low_rank_job_is_reproducible_from_its_seed(hip):
+    """Two adaptation="low_rank" jobs with the same seed give the same trace, bit for bit: the driver hands stopped chains in
+    while the others run and estimates on a second thread and stream, but WHEN it looks and WHOM it estimates together depends
+    on the engine's state alone (nutpie_amd/low_rank.py::LowRankSampler._run)."""
+    import sys
+
+    sys.path.insert(0, os.path.dirname(__file__))
+    import symbolic_models as zoo
+
+    cm = zoo.radon().compile()
+    kw = dict(chains=96, tune=300, draws=100, seed=11, progress_bar=False, adaptation="low_rank")
+    a = nutpie_amd.sample(cm, **kw)
+    b = nutpie_amd.sample(cm, **kw)
+    for name in ("n_steps", "depth", "energy", "step_size"):
+        assert np.array_equal(a.sample_stats[name].values, b.sample_stats[name].values), name
+        assert np.array_equal(a.warmup_sample_stats[name].values, b.warmup_sample_stats[name].values), name
+    for name in a.posterior.data_vars:
+        assert np.array_equal(a.posterior[name].values, b.posterior[name].values), name

@@ -133,7 +133,10 @@ class _FakeEngine:
         self.steps = 0
 
     def step(self, n_launches=1):
+        import time
+
         for _ in range(int(n_launches)):
+            time.sleep(0.002)                            # (a launch takes a while: the estimates run meanwhile, on their thread)
             self.steps += 1
             for c in range(self.num_chains):
                 if self.waiting[c] or self.at[c] >= self.total_draws:
@@ -162,9 +165,9 @@ def test_driver_hands_every_chain_its_own_windows_without_lock_step():
     gradients — and a chain that crawls does not hold the others (they are handed in, and finish, long before it arrives)."""
     from nutpie_amd import low_rank as lr
 
-    n, total, dim = 6, 150, 8
-    pauses = [30, 60, 90]
-    eng = _FakeEngine(n, total, dim, pauses, speed=[1, 20, 20, 15, 20, 10])
+    n, total, dim = 6, 240, 8
+    pauses = [60, 120, 180]
+    eng = _FakeEngine(n, total, dim, pauses, speed=[1, 40, 40, 30, 40, 20])
 
     class Driver(lr.LowRankSampler):
         def _views(self):
