@@ -561,6 +561,23 @@ def other_configs(env, args):
         r["workload"] = "radon (D = 173, 85 counties, 919 observations), 512 chains, tune 400 + draws 1000; density generated by nutpie_amd.symbolic, compiled into its own resident kernel"
         return r
 
+    def c3_low_rank():
+        from nutpie_amd import low_rank
+        from nutpie_amd.radon import radon_symbolic_model
+
+        m = radon_symbolic_model().compile()
+        s = hip.PyNutsSettings.LowRank(20260926)
+        s.update(num_tune=400, num_draws=1000, num_chains=512)
+        t0 = time.perf_counter()
+        smp = low_rank.make_sampler(m, s, None, 1, None, None, None, None)
+        smp.wait()
+        log = list(smp.switch_log)
+        r = job_rate(smp, t0)
+        r.update(hand_ins=len(log), estimating_s=float(sum(e[2] for e in log)), mean_columns=float(np.mean([e[1] for e in log])) if log else 0.0)
+        r["workload"] = ("radon as above under adaptation='low_rank' (not a BASELINE config; SURVEY 8f N4): the metric on the register-resident leaf of the compiled "
+                         "density, window estimates (batched eigh on the device) handed to each chain as it stops; job_s is engine time, wall_incl_setup_s the job")
+        return r
+
     def c3_torch():
         from nutpie_amd.radon import radon_model
 
@@ -594,6 +611,7 @@ def other_configs(env, args):
         return r
 
     leg("config3_radon_generated_density", c3_generated)
+    leg("config3_radon_generated_density_low_rank", c3_low_rank)
     leg("config3_radon_torch_density", c3_torch)
     leg("config4_eight_schools_host_callback", c4)
     leg("config2ii_dense_gaussian_gemm_callback", c2_dense)

@@ -779,9 +779,14 @@ bool nphip_sampler::setup() {
                       : "this library's resident kernel was built for the low-rank metric: the job must set low_rank_metric");
         return false;
     }
-    // (P-slots carry the velocity as a third vector.  Round 4: fused models with one wave per chain — D <= 1024 — keep the register-resident
-    //  leaf under the metric (kernels.hip: Machine<..., LR>); everything else runs the memory-resident kernels)
-    if (lrm && !(model.kind == 0 && W == 1 && dim <= 1024) && !dens) launch.no_register_kernel = 1;
+    // (P-slots carry the velocity as a third vector.  Round 4: fused models keep the register-resident leaf under the metric
+    //  (kernels.hip: Machine<..., LR>) in the geometries choose_waves() picks up to D = 4096 — one wave per chain, or two / four
+    //  with 5..8 chunks per wave; everything else runs the memory-resident kernels)
+    if (lrm && !dens) {
+        const uint64_t per_wave = ((dim + 127) / 128 + (uint64_t)W - 1) / (uint64_t)W;
+        const bool lr_reg = model.kind == 0 && ((W == 1 && dim <= 1024) || ((W == 2 || W == 4) && per_wave >= 5 && per_wave <= 8));
+        if (!lr_reg) launch.no_register_kernel = 1;
+    }
     if (dens && set.store_divergences) {
         set_error("store_divergences needs the pre-step state in memory: use the batched device callback of the density's library (launch per evaluation)");
         return false;

@@ -3607,14 +3607,14 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) __attribute__((amdgpu_waves_
 }
 
 // ----------------------------------------------------------------------------------------
-// launch tables.  The file is compiled as eight translation units in parallel (Makefile: -DNPHIP_PART=0..6, 8), each instantiating
+// launch tables.  The file is compiled as nine translation units in parallel (Makefile: -DNPHIP_PART=0..6, 8, 9), each instantiating
 // one family of kernels; without NPHIP_PART (developer builds, see the NPHIP_DEV_* macros) everything is in one.
 // ----------------------------------------------------------------------------------------
 #ifndef NPHIP_PART
 #define NPHIP_PART -1
 #endif
 #define NPHIP_HAS(p) (NPHIP_PART == -1 || NPHIP_PART == (p))
-#if defined(NPHIP_DEV_LEAN) || defined(NPHIP_DEV_W1NV) || defined(NPHIP_DEV_CB_W) || defined(NPHIP_DEV_W1NV_LR)
+#if defined(NPHIP_DEV_LEAN) || defined(NPHIP_DEV_W1NV) || defined(NPHIP_DEV_CB_W) || defined(NPHIP_DEV_W1NV_LR) || defined(NPHIP_DEV_RW_LR_W)
 #define NPHIP_DEV_BUILD 1   // one kernel instantiation only: seconds instead of minutes
 #endif
 
@@ -3623,6 +3623,7 @@ hipError_t launch_fam_w1_lr(const Args& a, const Args* d_args, hipStream_t st, c
 hipError_t launch_fam_lean4(const Args& a, const Args* d_args, hipStream_t st, const LaunchSlice sl);           // part 1
 hipError_t launch_fam_lean8(const Args& a, const Args* d_args, hipStream_t st, const LaunchSlice sl);           // part 2
 hipError_t launch_fam_rw(const Args& a, const Args* d_args, int W, hipStream_t st, const LaunchSlice sl);       // part 3
+hipError_t launch_fam_rw_lr(const Args& a, const Args* d_args, int W, hipStream_t st, const LaunchSlice sl);    // part 9
 hipError_t launch_fam_mem(const Args& a, const Args* d_args, bool fused, int W, hipStream_t st, const LaunchSlice sl);   // part 4
 
 // dynamic LDS of the lean kernels: sigma^2, and (4 waves per chain) as much of one (p, rho) summary as fits beside it (Machine::LR_FREE)
@@ -3788,6 +3789,39 @@ hipError_t launch_fam_w1_lr(const Args& a, const Args* d_args, hipStream_t st, c
 }
 #endif
 
+#if NPHIP_HAS(9)
+// register-resident, two / four waves per chain, under the low-rank metric: the geometries choose_waves() picks (1024 < D <= 2048:
+// two waves, 2048 < D <= 4096: four; 5..8 chunks per wave)
+hipError_t launch_fam_rw_lr(const Args& a, const Args* d_args, int W, hipStream_t st, const LaunchSlice sl) {
+#define NPHIP_LAUNCH_RW_LR(WW, NN) hipLaunchKernelGGL((k_advance<true, WW, NN, false, false, true>), g, b, 0, st, d_args, a.max_evals, a.have_result, sl)
+    const dim3 g((unsigned)sl.chain_n), b(64 * W);
+    (void)g; (void)b;
+#if defined(NPHIP_DEV_RW_LR_W) && defined(NPHIP_DEV_RW_LR_NV)
+    if (W != NPHIP_DEV_RW_LR_W || a.reg_nv != NPHIP_DEV_RW_LR_NV) return hipErrorInvalidValue;
+    NPHIP_LAUNCH_RW_LR(NPHIP_DEV_RW_LR_W, NPHIP_DEV_RW_LR_NV);
+    return hipGetLastError();
+#elif defined(NPHIP_DEV_BUILD)
+    return hipErrorInvalidValue;
+#else
+    if (W == 2) switch (a.reg_nv) {
+        case 5: NPHIP_LAUNCH_RW_LR(2, 5); break;
+        case 6: NPHIP_LAUNCH_RW_LR(2, 6); break;
+        case 7: NPHIP_LAUNCH_RW_LR(2, 7); break;
+        case 8: NPHIP_LAUNCH_RW_LR(2, 8); break;
+        default: return hipErrorInvalidValue;
+    } else switch (a.reg_nv) {
+        case 5: NPHIP_LAUNCH_RW_LR(4, 5); break;
+        case 6: NPHIP_LAUNCH_RW_LR(4, 6); break;
+        case 7: NPHIP_LAUNCH_RW_LR(4, 7); break;
+        case 8: NPHIP_LAUNCH_RW_LR(4, 8); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+#endif
+#undef NPHIP_LAUNCH_RW_LR
+}
+#endif
+
 #if NPHIP_HAS(4)
 // memory-resident kernels: fused models of any D and W (D > 10 240, store_divergences, no_register_kernel) and the two-phase
 // callback kernels
@@ -3903,7 +3937,7 @@ hipError_t launch_advance(const Args& a, const Args* d_args, bool fused, int W, 
     else { sl.chain_lo = 0; sl.chain_n = (int)a.n_chains; sl.grp = -1; sl.seq = 0u; sl.materialise = 0; }
     sl.n_grp = 0;
     if (fused && a.lean && a.reg_nv > 0) return W == 4 ? launch_fam_lean4(a, d_args, st, sl) : (W == 8 ? launch_fam_lean8(a, d_args, st, sl) : hipErrorInvalidValue);
-    if (fused && (W == 2 || W == 4) && a.reg_nv > 0) return launch_fam_rw(a, d_args, W, st, sl);
+    if (fused && (W == 2 || W == 4) && a.reg_nv > 0) return a.lr_on ? launch_fam_rw_lr(a, d_args, W, st, sl) : launch_fam_rw(a, d_args, W, st, sl);
     if (fused && W == 1 && a.reg_nv > 0) return a.lr_on ? launch_fam_w1_lr(a, d_args, st, sl) : launch_fam_w1(a, d_args, st, sl);
     return launch_fam_mem(a, d_args, fused, W, st, sl);
 }

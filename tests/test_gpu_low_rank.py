@@ -49,7 +49,9 @@ def run_engine_with_metrics(hip, model, pauses, sig2, V, lam, *, chains, tune, d
     (300, 0, 11, dict(no_register_kernel=True)),
     (300, 2, 16, {}),
     (1000, 0, 4, dict(evals_per_launch=37)),        # eight chunks per lane in registers (+ the velocity: the full register file)
-    (1300, 0, 4, {}),                               # two waves per chain
+    (1300, 0, 4, {}),                               # two waves per chain, six chunks each: the register-resident leaf (launch_fam_rw_lr)
+    (1300, 0, 4, dict(no_register_kernel=True)),    # ... and the memory-resident kernels on the same job
+    (2500, 0, 9, dict(evals_per_launch=21)),        # four waves per chain, five chunks each, register-resident; two reductions
     (5003, 0, 2, dict(evals_per_launch=13)),        # four waves per chain (memory-resident kernels under the low-rank metric)
 ])
 def test_fused_model_under_handed_in_metrics_bit_identical(hip, oracle, dim, waves, k, launch):
