@@ -126,8 +126,8 @@ nphip_model_t* nphip_model_bridgestan(uint64_t dim, void* bs_model, void* log_de
  * everything the resident kernel does not cover. */
 nphip_model_t* nphip_model_jit_density(uint64_t dim, void* launch_fn, int nv, const void* data_device, uint64_t lds_bytes_per_chain,
                                        uint64_t lds_bytes_shared, int waves_per_chain);
-/* The library's resident kernel was compiled for the low-rank metric (-DNPHIP_JIT_LR=1: `nphip_jit_lr()` of the library returns 1; one
- * wave per chain): a job with `low_rank_metric` (adaptation = "low_rank", src/wrapper.rs:307-334) then keeps the register-resident leaf —
+/* The library's resident kernel was compiled for the low-rank metric (-DNPHIP_JIT_LR=1: `nphip_jit_lr()` of the library returns 1;
+ * one, two or four waves per chain): a job with `low_rank_metric` (adaptation = "low_rank", src/wrapper.rs:307-334) then keeps the register-resident leaf —
  * the cursor's velocity M^-1 p as a sixth resident vector, the columns of V streamed against it — instead of the batched callback. */
 int nphip_model_jit_low_rank(nphip_model_t*, int capable);
 /* Initial positions: kind 0 = U(-2,2) (src/pyfunc.rs:540-544), 1 = N(0,1) (src/stan.rs:798-808),

@@ -390,7 +390,6 @@ nphip_model_t* nphip_model_jit_density(uint64_t dim, void* launch_fn, int nv, co
 }
 int nphip_model_jit_low_rank(nphip_model_t* m, int capable) {
     if (!m || m->kind != 3) { set_error("nphip_model_jit_low_rank: not a runtime-compiled density"); return NPHIP_ERR; }
-    if (capable && m->jit_w != 1) { set_error("the low-rank metric on the resident kernel needs one wave per chain"); return NPHIP_ERR; }
     m->jit_lr = capable != 0;
     return NPHIP_OK;
 }

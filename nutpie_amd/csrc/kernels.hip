@@ -252,7 +252,7 @@ struct SCache {
 // REMOTE (NV > 0, W == 1, not FUSED): a host-callback model driven like a fused one — the kernel stays resident, and an
 // evaluation is a remote call in the middle of the leaf: publish the position in the host's staging row, arrive, wait for
 // the host's word, read (logp, gradient) back (remote_sync).  The cursor state stays in registers across the call.
-// LR (NV > 0, W == 1, not LEAN; round 4): the register-resident leaf under the low-rank metric M^-1 = D^1/2 (I + V (Lambda - I) V') D^1/2 —
+// LR (NV > 0, not LEAN; round 4): the register-resident leaf under the low-rank metric M^-1 = D^1/2 (I + V (Lambda - I) V') D^1/2 —
 // the cursor's velocity v = M^-1 p is a sixth resident vector, every P-slot carries it as a third vector (Args::pvec = 3), the k
 // columns of V are streamed from L2 against the resident momentum (k dots + k updates per half step), and the LDS ring is not used.
 template <bool FUSED, int W, int NV = 0, bool LEAN = false, bool REMOTE = false, bool LR = false>
@@ -4025,11 +4025,10 @@ hipError_t launch_remote_wn(const Args* d_args, int W, int nv, hipStream_t st, c
 #ifndef NPHIP_JIT_W
 #define NPHIP_JIT_W 1
 #endif
-// -DNPHIP_JIT_LR=1: the library's resident kernel integrates under the low-rank metric (Machine<..., LR>; one wave per chain)
+// -DNPHIP_JIT_LR=1: the library's resident kernel integrates under the low-rank metric (Machine<..., LR>)
 #ifndef NPHIP_JIT_LR
 #define NPHIP_JIT_LR 0
 #endif
-static_assert(!(NPHIP_JIT_LR != 0 && NPHIP_JIT_W != 1), "the low-rank metric on the register-resident leaf: one wave per chain");
 // one wave per chain: four chains per workgroup; NPHIP_JIT_W waves per chain: one chain per workgroup of 64 W threads
 __global__ __launch_bounds__(NPHIP_JIT_W == 1 ? 256 : 64 * NPHIP_JIT_W) void k_density_batch(const NphipData* __restrict__ data, uint64_t n_chains, int dim, const double* __restrict__ q,
                                                        double* __restrict__ grad, double* __restrict__ logp, int lds_doubles, int shared_doubles, int rows_in_lds) {

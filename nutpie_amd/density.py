@@ -160,11 +160,9 @@ def generated_source(user_source: str, layout) -> str:
 
 def compile_density(user_source: str, layout, ndim: int, *, waves: int = 1, verbose: bool = False, low_rank: bool = False) -> str:
     """Build (or find in the cache) the model's library; returns its path.  ``waves`` wavefronts evaluate one chain's density.
-    ``low_rank``: the library's resident kernel integrates under the low-rank metric (``adaptation="low_rank"``; one wave per chain)."""
+    ``low_rank``: the library's resident kernel integrates under the low-rank metric (``adaptation="low_rank"``)."""
     if waves not in (1, 2, 4):
         raise ValueError("waves_per_chain must be 1, 2 or 4")
-    if low_rank and waves != 1:
-        raise ValueError("the low-rank metric on the resident kernel needs one wave per chain")
     nv = ((int(ndim) + 127) // 128 + waves - 1) // waves   # chunks of 128 dimensions per wave
     src = generated_source(user_source, layout)
     deps = [os.path.join(_CSRC, f) for f in ("kernels.hip", "engine_types.h")] + [os.path.join(_INCLUDE, "nphip_spec.h")]
@@ -349,9 +347,9 @@ class DensitySourceModel(CompiledModel):
 
     def _make_model(self, init_mean=None, settings=None, device: int = 0, resident: bool | None = None):
         low_rank = settings is not None and getattr(settings, "_adaptation", "diag") == "low_rank"
-        # adaptation="low_rank": the resident kernel under the metric where the library can be built for it (one wave per chain, up
-        # to 1024 dimensions), else the batched callback on the memory-resident kernels
-        lr_resident = low_rank and self._waves == 1 and self._n_dim <= 1024
+        # adaptation="low_rank": the resident kernel under the metric where the model has a resident kernel at all (up to 1024
+        # dimensions), else the batched callback on the memory-resident kernels
+        lr_resident = low_rank and self._n_dim <= 1024
         lib = self.library(low_rank=lr_resident)
         n_chains = int(getattr(settings, "num_chains", 0) or 0) if settings is not None else 0
         if (callable(self._scratch) or self._scratch) and n_chains <= 0:

@@ -174,8 +174,8 @@ def test_low_rank_metric_on_the_resident_kernel_of_a_compiled_density(hip):
     sys.path.insert(0, os.path.dirname(__file__))
     import symbolic_models as zoo
 
-    for name, k in (("eight_schools", 3), ("radon", 5), ("store_extra", 2)):
-        m = zoo.ALL[name]().compile()
+    for name, k, waves in (("eight_schools", 3, None), ("radon", 5, None), ("store_extra", 2, None), ("radon", 9, 2)):
+        m = zoo.ALL[name]().compile(waves_per_chain=waves)
         assert m.library(low_rank=True).low_rank and not m.library().low_rank
         D, chains, pauses = m.n_dim, 12, [14, 30]
         rng = np.random.default_rng(D)
