@@ -259,11 +259,13 @@ int nphip_sampler_resume_at(nphip_sampler_t*, uint64_t n, const uint64_t* local_
 /* Low-rank metric (reference: the mass matrix of adaptation="low_rank", src/wrapper.rs:307-334, python/nutpie/sample.py:921-933,
  * docs/sampling-options.qmd:124-144):  M^-1 = D^1/2 (I + V (Lambda - I) V') D^1/2  with D = diag(sigma^2), V = k <= 16 orthonormal
  * columns, Lambda their eigenvalues.  With the boolean setting `low_rank_metric` the engine integrates, draws momenta and tests
- * U-turns under such a metric (memory-resident kernels; every model flavour).  The metric of a chain is supplied by the host at
+ * U-turns under such a metric (every model flavour; fused models up to D = 4096 and compiled densities on the register-resident leaf).  The metric of a chain is supplied by the host at
  * the pause draws: sigma2[n][dim], V[n][k][dim] (row j = column j of V), lambda[n][k], host or device memory.  The chain keeps its
  * position, runs a step-size search under the new metric and goes on with its next draw; its own diagonal adaptation is off
  * from then on.  Until the first call a chain runs on the diagonal metric it adapts itself, exactly as without the setting.
- * Manual-mode samplers only.  The window estimator that produces (sigma2, V, lambda) lives above the C-ABI (nutpie_amd/low_rank.py). */
+ * Manual-mode samplers only.  Every named chain must be stopped at a pause draw (nphip_sampler_waiting): chains that are not keep
+ * their metric and the call returns an error naming how many (the stopped ones among them have taken the new one).  The window
+ * estimator that produces (sigma2, V, lambda) lives above the C-ABI (nutpie_amd/low_rank.py). */
 int nphip_sampler_set_metric(nphip_sampler_t*, uint64_t n, const uint64_t* local_chains, uint64_t k, const double* sigma2, const double* V,
                              const double* lambda, int on_device);
 /* Developer aid: per-section cycle counters summed over chains; all zero unless the library was built

@@ -29,7 +29,7 @@
 namespace nphip {
 hipError_t launch_advance(const Args& a, const Args* d_args, bool fused, int W, hipStream_t st, const LaunchSlice* slice = nullptr);
 hipError_t launch_resume(const Args* d_args, int n, const int64_t* d_chains, const double* d_pos, bool fused, hipStream_t st);
-hipError_t launch_set_metric(const Args* d_args, int n, const int64_t* d_chains, int k, const double* sig2, const double* V, const double* lam, hipStream_t st);
+hipError_t launch_set_metric(const Args* d_args, int n, const int64_t* d_chains, int k, const double* sig2, const double* V, const double* lam, int* d_taken, hipStream_t st);
 hipError_t launch_remote(const Args* d_args, int W, int nv, hipStream_t st, const LaunchSlice& sl);
 hipError_t launch_test_detmath(int fn, uint64_t n, const double* x, double* y, hipStream_t st);
 hipError_t launch_test_dot(int W, uint64_t n, const double* x, const double* y, double* out, hipStream_t st);
@@ -1863,19 +1863,29 @@ int nphip_sampler_set_metric(nphip_sampler_t* s, uint64_t n, const uint64_t* cha
     if (!s->sync_all()) return NPHIP_ERR;
     std::vector<int64_t> ch(chains, chains + n);
     int64_t* d_ch = nullptr;
+    int* d_taken = nullptr;
+    int taken = 0;
     double *d_s = nullptr, *d_v = nullptr, *d_l = nullptr;
     const size_t bs = n * s->dim * 8, bv = n * k * s->dim * 8, bl = n * k * 8;
-    bool ok = hip_ok(hipMalloc((void**)&d_ch, n * 8), "hipMalloc") && hip_ok(hipMemcpy(d_ch, ch.data(), n * 8, hipMemcpyHostToDevice), "H2D chains");
+    bool ok = hip_ok(hipMalloc((void**)&d_ch, n * 8), "hipMalloc") && hip_ok(hipMemcpy(d_ch, ch.data(), n * 8, hipMemcpyHostToDevice), "H2D chains") &&
+              hip_ok(hipMalloc((void**)&d_taken, sizeof(int)), "hipMalloc") && hip_ok(hipMemset(d_taken, 0, sizeof(int)), "hipMemset");
     if (ok && !on_device) {
         ok = hip_ok(hipMalloc((void**)&d_s, bs), "hipMalloc") && hip_ok(hipMemcpy(d_s, sig2, bs, hipMemcpyHostToDevice), "H2D sigma^2");
         if (ok && k > 0)
             ok = hip_ok(hipMalloc((void**)&d_v, bv), "hipMalloc") && hip_ok(hipMemcpy(d_v, V, bv, hipMemcpyHostToDevice), "H2D V") &&
                  hip_ok(hipMalloc((void**)&d_l, bl), "hipMalloc") && hip_ok(hipMemcpy(d_l, lam, bl, hipMemcpyHostToDevice), "H2D lambda");
     }
-    if (ok) ok = hip_ok(launch_set_metric(s->d_args, (int)n, d_ch, (int)k, on_device ? sig2 : d_s, on_device ? V : d_v, on_device ? lam : d_l, s->stream),
-                        "launch k_set_metric") && hip_ok(hipStreamSynchronize(s->stream), "hipStreamSynchronize");
-    for (void* q : {(void*)d_ch, (void*)d_s, (void*)d_v, (void*)d_l}) if (q) (void)hipFree(q);
+    if (ok) ok = hip_ok(launch_set_metric(s->d_args, (int)n, d_ch, (int)k, on_device ? sig2 : d_s, on_device ? V : d_v, on_device ? lam : d_l, d_taken, s->stream),
+                        "launch k_set_metric") && hip_ok(hipStreamSynchronize(s->stream), "hipStreamSynchronize") &&
+                 hip_ok(hipMemcpy(&taken, d_taken, sizeof(int), hipMemcpyDeviceToHost), "D2H taken");
+    for (void* q : {(void*)d_ch, (void*)d_taken, (void*)d_s, (void*)d_v, (void*)d_l}) if (q) (void)hipFree(q);
     s->manual_have = 0;   // (callback models: the staged evaluation belongs to the state before the pause)
+    if (ok && (uint64_t)taken != n) {
+        // (a metric for a chain that is not stopped used to be dropped without a word)
+        set_error(std::to_string(n - (uint64_t)taken) + " of " + std::to_string(n) + " chains were not stopped at a pause draw (nphip_sampler_waiting): they keep their metric" +
+                  (taken ? ", the other " + std::to_string(taken) + " took the new one" : ""));
+        return NPHIP_ERR;
+    }
     return ok ? NPHIP_OK : NPHIP_ERR;
 }
 

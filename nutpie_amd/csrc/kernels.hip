@@ -3899,7 +3899,7 @@ __global__ void k_resume(const Args* __restrict__ Ap, int n, const int64_t* __re
 // A new metric for chains stopped in PH_WAIT_HOST (host-driven low-rank adaptation): sigma^2 [n][dim], k rows of V [n][k][dim],
 // lambda [n][k]; the chain keeps its position and goes on through a step-size search (PH_RESUME_SS).  One block per chain.
 __global__ void k_set_metric(const Args* __restrict__ Ap, int n, const int64_t* __restrict__ chains, int k, const double* __restrict__ sig2,
-                             const double* __restrict__ V, const double* __restrict__ lam) {
+                             const double* __restrict__ V, const double* __restrict__ lam, int* __restrict__ taken) {
     const Args& A = *Ap;
     if ((int)blockIdx.x >= n) return;
     const int64_t ch = chains[blockIdx.x];
@@ -3918,11 +3918,12 @@ __global__ void k_set_metric(const Args* __restrict__ Ap, int n, const int64_t* 
         c->host_metric = 1;
         c->lr_k = k;
         c->phase = PH_RESUME_SS;
+        atomicAdd(taken, 1);   // (the host compares with n: a chain that was not stopped keeps its metric, and the caller is told)
     }
 }
 
-hipError_t launch_set_metric(const Args* d_args, int n, const int64_t* d_chains, int k, const double* sig2, const double* V, const double* lam, hipStream_t st) {
-    hipLaunchKernelGGL(k_set_metric, dim3((unsigned)n), dim3(256), 0, st, d_args, n, d_chains, k, sig2, V, lam);
+hipError_t launch_set_metric(const Args* d_args, int n, const int64_t* d_chains, int k, const double* sig2, const double* V, const double* lam, int* d_taken, hipStream_t st) {
+    hipLaunchKernelGGL(k_set_metric, dim3((unsigned)n), dim3(256), 0, st, d_args, n, d_chains, k, sig2, V, lam, d_taken);
     return hipGetLastError();
 }
 

@@ -109,7 +109,8 @@ def test_set_metric_errors(hip):
     smp = hip.PySampler(s, hip.TridiagGaussianModel(np.ones(4)), manual=True)
     with pytest.raises(RuntimeError, match="at most 16"):
         smp.set_metric([0], np.ones((1, 4)), np.zeros((1, 17, 4)), np.ones((1, 17)))
-    smp.set_metric([0, 1], np.ones((2, 4)))          # nobody is waiting: no effect
+    with pytest.raises(RuntimeError, match="2 of 2 chains were not stopped"):
+        smp.set_metric([0, 1], np.ones((2, 4)))      # nobody is waiting: nothing changes, and the caller is told
     while not smp.step(8)[0]:
         pass
     smp.close()
