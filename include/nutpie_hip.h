@@ -268,6 +268,14 @@ int nphip_sampler_resume_at(nphip_sampler_t*, uint64_t n, const uint64_t* local_
  * estimator that produces (sigma2, V, lambda) lives above the C-ABI (nutpie_amd/low_rank.py). */
 int nphip_sampler_set_metric(nphip_sampler_t*, uint64_t n, const uint64_t* local_chains, uint64_t k, const double* sigma2, const double* V,
                              const double* lambda, int on_device);
+/* Batched symmetric eigendecomposition on the device — the dense-linear-algebra kernel of the low-rank estimator (reference:
+ * adaptation="low_rank", src/wrapper.rs:307-334; nuts-rs uses faer's self-adjoint eigendecomposition there, Cargo.lock faer 0.24).
+ * a_device: [n_batch][order][order] row-major, the LOWER triangle is the matrix; on return column j of matrix b is the eigenvector
+ * of w_device[b][j], eigenvalues ascending.  order <= 128: one workgroup per matrix, the matrix resident in LDS (Householder
+ * tridiagonalisation, Q in place, implicit QL — nutpie_amd/csrc/linalg.hip).  Runs on `stream` and returns after it has finished
+ * (the convergence status of every matrix is checked).  Used by nutpie_amd/low_rank.py::estimate for its four decompositions. */
+int nphip_batched_eigh(uint64_t n_batch, uint64_t order, double* a_device, double* w_device, void* stream);
+
 /* Developer aid: per-section cycle counters summed over chains; all zero unless the library was built
  * with -DNPHIP_PROFILE.  [0] leapfrog cycles [1] tree cycles (hot) [2] draw-end cycles [3..5] their counts. */
 int nphip_sampler_profile(nphip_sampler_t*, int64_t out[16]);
@@ -278,6 +286,9 @@ void* nphip_sampler_device_ptr(nphip_sampler_t*, const char* name);
 /* Evaluate the device implementations of include/nphip_spec.h on arrays (parity tests).
  * fn: 0 exp 1 log 2 log1p 3 sin2pi 4 cos2pi 5 sqrt 6 reciprocal 7 normals(seed=x[0],chain=x[1],draw=x[2],purpose=x[3]) */
 int nphip_test_detmath(int device, int fn, uint64_t n, const double* x, double* y);
+/* the stages of nphip_batched_eigh on their own.  mode 1: Householder tridiagonalisation only — w = the diagonal of T, row 0 of each a = its
+ * sub-diagonal (entry i couples i and i + 1); mode 2: also Q, returned in a (T = Q' A Q) */
+int nphip_test_eigh_stage(uint64_t n_batch, uint64_t order, double* a_device, double* w_device, void* stream, int mode);
 /* dot product in the engine's summation order with W waves */
 int nphip_test_dot(int device, int waves, uint64_t n, const double* x, const double* y, double* out);
 /* host-only: the evaluation pool of the host-callback path (spin-waiting workers, `use` threads per batch); row r of batch b

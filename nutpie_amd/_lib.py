@@ -162,6 +162,8 @@ def lib():
             L.nphip_sampler_waiting.restype = C.c_int64
             L.nphip_sampler_resume_at.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int]
             L.nphip_sampler_set_metric.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+            L.nphip_batched_eigh.argtypes = [C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+            L.nphip_test_eigh_stage.argtypes = [C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
             L.nphip_launch_defaults.argtypes = [C.POINTER(_Launch)]
             L.nphip_default_evals_per_launch.argtypes = [C.c_uint64]
             L.nphip_abi_struct_size.restype = C.c_uint64
@@ -866,6 +868,28 @@ class PySampler:
             self.close()
         except Exception:
             pass
+
+
+def batched_eigh(A, _stage=0):
+    """``nphip_batched_eigh`` on a CUDA float64 tensor ``A[b, n, n]`` (symmetric, the lower triangle is read; n <= 128):
+    ``(w[b, n] ascending, V[b, n, n])`` with ``A[i] @ V[i] == V[i] * w[i]`` — the shapes of ``torch.linalg.eigh``.  One workgroup per
+    matrix on torch's current stream of A's device (nutpie_amd/csrc/linalg.hip)."""
+    import torch
+
+    if not (A.is_cuda and A.dtype == torch.float64 and A.dim() == 3 and A.shape[1] == A.shape[2]):
+        raise ValueError("batched_eigh: a CUDA float64 tensor [batch, n, n]")
+    b, n = int(A.shape[0]), int(A.shape[1])
+    V = A.contiguous().clone()
+    w = torch.empty(b, n, dtype=torch.float64, device=A.device)
+    with torch.cuda.device(A.device):
+        st = C.c_void_p(torch.cuda.current_stream(A.device).cuda_stream)
+        if _stage:   # (test hook: the stages on their own, include/nutpie_hip.h: nphip_test_eigh_stage)
+            rc = lib().nphip_test_eigh_stage(C.c_uint64(b), C.c_uint64(n), C.c_void_p(V.data_ptr()), C.c_void_p(w.data_ptr()), st, int(_stage))
+        else:
+            rc = lib().nphip_batched_eigh(C.c_uint64(b), C.c_uint64(n), C.c_void_p(V.data_ptr()), C.c_void_p(w.data_ptr()), st)
+    if rc != NPHIP_OK:
+        raise RuntimeError(_err())
+    return w, V
 
 
 def default_evals_per_launch(dim: int) -> int:

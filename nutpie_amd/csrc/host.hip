@@ -1902,6 +1902,34 @@ void* nphip_sampler_device_ptr(nphip_sampler_t* s, const char* name) {
     return stat_ptr(s, name, &bytes);
 }
 
+// ---- dense linear algebra for the low-rank estimator (linalg.hip) ------------------------
+extern "C" int nphip_linalg_launch_eigh(uint64_t n_batch, uint64_t order, double* a_device, double* w_device, int* status_device, void* stream, int mode);
+
+static int batched_eigh_mode(uint64_t n_batch, uint64_t order, double* a_device, double* w_device, void* stream, int mode);
+int nphip_batched_eigh(uint64_t n_batch, uint64_t order, double* a_device, double* w_device, void* stream) {
+    return batched_eigh_mode(n_batch, order, a_device, w_device, stream, 0);
+}
+// test hook: the stages of nphip_batched_eigh on their own (mode 1: the tridiagonal form — w = diagonal, row 0 of a = sub-diagonal; 2: a = Q)
+int nphip_test_eigh_stage(uint64_t n_batch, uint64_t order, double* a_device, double* w_device, void* stream, int mode) {
+    return batched_eigh_mode(n_batch, order, a_device, w_device, stream, mode);
+}
+static int batched_eigh_mode(uint64_t n_batch, uint64_t order, double* a_device, double* w_device, void* stream, int mode) {
+    if (order == 0 || order > 128) { set_error("nphip_batched_eigh: the order must be 1..128 (the matrix lives in LDS)"); return NPHIP_ERR; }
+    if (n_batch == 0) return NPHIP_OK;
+    if (!a_device || !w_device) { set_error("nphip_batched_eigh: null device pointer"); return NPHIP_ERR; }
+    int* d_status = nullptr;
+    if (!hip_ok(hipMalloc((void**)&d_status, n_batch * sizeof(int)), "hipMalloc")) return NPHIP_ERR;
+    std::vector<int> st(n_batch, 0);
+    bool ok = hip_ok((hipError_t)nphip_linalg_launch_eigh(n_batch, order, a_device, w_device, d_status, stream, mode), "launch k_batched_eigh") &&
+              hip_ok(hipStreamSynchronize((hipStream_t)stream), "hipStreamSynchronize") &&
+              hip_ok(hipMemcpy(st.data(), d_status, n_batch * sizeof(int), hipMemcpyDeviceToHost), "D2H status");
+    (void)hipFree(d_status);
+    if (!ok) return NPHIP_ERR;
+    for (uint64_t i = 0; i < n_batch; ++i)
+        if (st[i] != 0) { set_error("nphip_batched_eigh: the QL iteration of matrix " + std::to_string(i) + " did not converge"); return NPHIP_ERR; }
+    return NPHIP_OK;
+}
+
 // ---- test hooks ------------------------------------------------------------------------
 int nphip_test_detmath(int device, int fn, uint64_t n, const double* x, double* y) {
     if (hipSetDevice(device) != hipSuccess) { set_error("no HIP device"); return NPHIP_ERR; }

@@ -84,27 +84,24 @@ class Transform:
         return (1.0 + self.d) ** 2
 
 
-EIGH_PAD = 128        # rocSOLVER's path for symmetric problems of order <= 64 takes 90-210 ms per batch of 512 (measured on MI355X,
-                      # scratch/eigh_time.py), the blocked path for larger ones 5-12 ms: small problems are embedded in a larger one
+NATIVE_EIGH_MAX = 64   # measured on MI355X, 512 problems (scratch/eigh_time.py, profiles/r4_low_rank_register_kernel.txt §5):
+                       #   order      16     42     64     66     96    128
+                       #   rocSOLVER  12.1   89.0  208.9   4.3    6.7   11.6 ms   (its small-matrix path below 65)
+                       #   engine      0.32   1.32   2.63  2.92  10.4   17.8 ms   (one workgroup per matrix; the QL sweep is one lane's work)
 
 
 def _eigh_psd(A):
-    """``torch.linalg.eigh`` of a batch of positive semi-definite matrices.  Orders <= 64 are embedded as the leading block of a
-    block-diagonal problem of order EIGH_PAD whose other block is diagonal with distinct negative entries: those come out first
-    (eigenvalues ascend) and are cut off, the block's own eigenpairs are unchanged."""
+    """Eigendecomposition of a batch of symmetric matrices ``[n, s, s]`` in the shapes of ``torch.linalg.eigh``.  On the GPU, orders
+    up to NATIVE_EIGH_MAX go to the engine's own batched routine (``nphip_batched_eigh``, nutpie_amd/csrc/linalg.hip: one workgroup
+    per matrix, the matrix in LDS; results independent of the batch), larger ones to rocSOLVER through torch; on the CPU (tests) it
+    is LAPACK through torch."""
     import torch
 
-    s = A.shape[-1]
-    if s > 64 or not A.is_cuda:
-        return torch.linalg.eigh(A)
-    n = A.shape[0]
-    P = torch.zeros(n, EIGH_PAD, EIGH_PAD, dtype=A.dtype, device=A.device)
-    P[:, :s, :s] = A
-    idx = torch.arange(s, EIGH_PAD, device=A.device)
-    scale = torch.diagonal(A, dim1=1, dim2=2).abs().amax(1).clamp_min(1e-300)                   # [n]
-    P[:, idx, idx] = -(1.0 + (idx - s).to(A.dtype))[None, :] * scale[:, None]
-    e, U = torch.linalg.eigh(P)
-    return e[:, EIGH_PAD - s:].contiguous(), U[:, :s, EIGH_PAD - s:].contiguous()
+    if A.is_cuda and A.shape[-1] <= NATIVE_EIGH_MAX:
+        from nutpie_amd import _lib
+
+        return _lib.batched_eigh(A)
+    return torch.linalg.eigh(A)
 
 
 def estimate(x, gx, gamma: float, cutoff: float, k_max: int = K_MAX) -> Transform:

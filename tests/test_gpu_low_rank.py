@@ -166,3 +166,66 @@ def test_low_rank_adaptation_on_a_fused_model_and_a_compiled_density(hip):
 
     tr = nutpie_amd.sample(radon_density_model(), adaptation="low_rank", chains=16, tune=300, draws=100, seed=2, progress_bar=False)
     assert abs(tr.posterior.intercept.values.mean() - 1.3) < 0.2 and tr.sample_stats.diverging.values.mean() < 0.02
+
+
+@pytest.mark.parametrize("order", [1, 2, 3, 8, 42, 64, 65, 96, 128])
+def test_batched_eigh_against_lapack(hip, order):
+    """nphip_batched_eigh (nutpie_amd/csrc/linalg.hip; the dense-linear-algebra kernel of the low-rank estimator): residual,
+    orthogonality and eigenvalues against numpy's LAPACK on random, rank-deficient, diagonal, repeated-eigenvalue, badly scaled
+    and zero matrices — and the lower triangle is the matrix."""
+    import torch
+
+    rng = np.random.default_rng(order)
+    mats = []
+    for _ in range(5):
+        B = rng.normal(size=(order, order))
+        mats.append(B + B.T)
+    Z = rng.normal(size=(order, max(1, order // 3)))
+    mats.append(Z @ Z.T)                                             # positive semi-definite, rank order / 3 (a Gram matrix)
+    mats.append(np.diag(rng.normal(size=order)))                    # already diagonal
+    q, _ = np.linalg.qr(rng.normal(size=(order, order)))
+    mats.append((q * np.repeat([1.0, 2.0], [order - order // 2, order // 2])) @ q.T)    # two eigenvalues, high multiplicity
+    mats.append(mats[0] * 1e-180)
+    mats.append(mats[1] * 1e150)
+    mats.append(np.zeros((order, order)))
+    mats.append(np.eye(order) + 1e-9 * mats[2])                      # a tight cluster
+    r = max(1, order // 2)                                           # gamma I + a covariance of half the rank with a wide spectrum: a cluster
+    mats.append(1e-5 * np.eye(order) + (q[:, :r] * np.exp(rng.uniform(np.log(1e-3), np.log(20.0), size=r))) @ q[:, :r].T)   # next to eigenvalues 10^6 times larger
+    A = np.stack([(m + m.T) / 2 for m in mats])
+    dirty = A.copy()
+    iu = np.triu_indices(order, 1)
+    dirty[:, iu[0], iu[1]] = 7.0                                     # the upper triangle is never read
+    w, V = hip.batched_eigh(torch.as_tensor(dirty, device="cuda"))
+    w, V = w.cpu().numpy(), V.cpu().numpy()
+    for b in range(len(A)):
+        scale = max(np.abs(A[b]).max(), 1e-300)
+        assert np.all(np.diff(w[b]) >= 0)
+        np.testing.assert_allclose(w[b], np.linalg.eigvalsh(A[b]), rtol=0, atol=2e-13 * scale * max(order, 4))
+        assert np.abs(V[b].T @ V[b] - np.eye(order)).max() < 1e-12 * max(order, 4)
+        assert np.abs(A[b] @ V[b] - V[b] * w[b][None, :]).max() < 2e-13 * scale * max(order, 4)
+
+
+def test_estimator_on_the_gpu_against_its_cpu_oracle(hip):
+    """estimate() on the device — with the engine's batched eigendecomposition — against the numpy restatement
+    (oracle/low_rank_estimator.py): the same dense metric for every chain, and independent of what else is in the batch."""
+    import torch
+
+    from nutpie_amd import low_rank as lr
+    from oracle import low_rank_estimator as ref
+
+    rng = np.random.default_rng(5)
+    n, m, D = 6, 30, 30      # (2m = 60: the engine's own eigendecomposition; larger windows go to rocSOLVER, low_rank.NATIVE_EIGH_MAX)
+    B = rng.normal(size=(n, D, 3))
+    scales = np.exp(rng.normal(size=(n, D)))
+    Sigma = np.stack([np.diag(scales[c] ** 2) + 25.0 * (scales[c][:, None] * B[c]) @ (scales[c][:, None] * B[c]).T for c in range(n)])
+    x = np.stack([rng.multivariate_normal(np.zeros(D), Sigma[c], size=m) for c in range(n)]) + 2.0
+    g = -np.stack([np.linalg.solve(Sigma[c], (x[c] - 2.0).T).T for c in range(n)])
+    xt, gt = torch.as_tensor(x, device="cuda"), torch.as_tensor(g, device="cuda")
+    T = lr.estimate(xt, gt, 1e-5, 2.0)
+    sig2, V, lam = (t.cpu().numpy() for t in lr.metric_of(T))
+    for c in range(n):
+        want = ref.dense_metric(*ref.estimate_chain(x[c], g[c], 1e-5, 2.0, lr.K_MAX))
+        got = ref.dense_metric(sig2[c], V[c].T, lam[c])
+        assert np.abs(got - want).max() <= 1e-7 * np.abs(want).max()
+    T1 = lr.estimate(xt[2:3], gt[2:3], 1e-5, 2.0)
+    assert torch.equal(T1.stds, T.stds[2:3]) and torch.equal(T1.V, T.V[2:3]) and torch.equal(T1.d, T.d[2:3])   # no dependence on the batch
