@@ -7,12 +7,14 @@ gradient covariance that lie outside ``[1/cutoff, cutoff]`` (``mass_matrix_eigva
 ``mass_matrix_gamma`` — and integrates, draws momenta and tests U-turns under it.
 
 Here (round 3) the metric lives where the reference has it, INSIDE the sampler: with the setting ``low_rank_metric`` the engine's
-memory-resident kernels apply ``v = M^-1 p`` in the leapfrog, draw ``p ~ N(0, M)`` and carry the velocity with every tree state
-(``kernels.hip``: ``lf1`` / ``lf2`` / ``sample_momentum_lr`` / ``turning``; the oracle restates the same arithmetic and the two are
+kernels apply ``v = M^-1 p`` in the leapfrog, draw ``p ~ N(0, M)`` and carry the velocity with every tree state
+(``kernels.hip``: ``lf1`` / ``lf2`` / ``sample_momentum_lr`` / ``turning``; round 4: also the register-resident leaf, ``Machine<..., LR>``
+— fused models up to D = 4096 and compiled densities; the oracle restates the same arithmetic and the two are
 compared bit for bit, tests/test_gpu_low_rank.py) — for EVERY model flavour: fused, raw C callbacks, BridgeStan, device
 callbacks, runtime-compiled densities.  What stays above the C-ABI is the window ESTIMATOR, below: chains stop between two
 draws at the window boundaries (``nphip_settings_set_pause_draws``), the host estimates every chain's ``(sigma^2, V, lambda)``
-from the window's draws and gradients — batched ``eigh`` on the GPU, all chains at once — hands it to the engine
+from the window's draws and gradients — batched eigendecompositions on the GPU (the engine's ``nphip_batched_eigh`` up to order 64,
+rocSOLVER above), the chains that have stopped at once, on a worker thread while the others run — hands it to the engine
 (``nphip_sampler_set_metric``) and the chains go on from where they are, through a new step-size search, as nuts-rs does when
 the mass matrix changes.  The estimator follows the published description (Seyboldt et al., "Preconditioning Hamiltonian Monte
 Carlo by minimizing Fisher divergence"); the crate is not in the tree — PARITY UNPINNED, like the rest of the sampler.
