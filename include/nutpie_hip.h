@@ -287,7 +287,8 @@ void* nphip_sampler_device_ptr(nphip_sampler_t*, const char* name);
  * fn: 0 exp 1 log 2 log1p 3 sin2pi 4 cos2pi 5 sqrt 6 reciprocal 7 normals(seed=x[0],chain=x[1],draw=x[2],purpose=x[3]) */
 int nphip_test_detmath(int device, int fn, uint64_t n, const double* x, double* y);
 /* the stages of nphip_batched_eigh on their own.  mode 1: Householder tridiagonalisation only — w = the diagonal of T, row 0 of each a = its
- * sub-diagonal (entry i couples i and i + 1); mode 2: also Q, returned in a (T = Q' A Q) */
+ * sub-diagonal (entry i couples i and i + 1); mode 2: also Q, returned in a (T = Q' A Q); mode 3: the decomposition, with w[0..6] of every
+ * matrix replaced by cycle counts (tridiagonalisation, Q, QL recurrence, QL application, rotations, sweeps, total) */
 int nphip_test_eigh_stage(uint64_t n_batch, uint64_t order, double* a_device, double* w_device, void* stream, int mode);
 /* dot product in the engine's summation order with W waves */
 int nphip_test_dot(int device, int waves, uint64_t n, const double* x, const double* y, double* out);

@@ -49,6 +49,15 @@ __device__ __forceinline__ double block_max(double v, double* red, int tid) {
     return fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
 }
 
+// lane `l` (uniform) of a value held across wave 0
+__device__ __forceinline__ double lane_read(double a, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a), l), __builtin_amdgcn_readlane(__double2loint(a), l));
+}
+__device__ __forceinline__ double lane_get(double a0, double a1, int i) {   // both halves are read, a scalar select picks: no branch
+    const double x0 = lane_read(a0, i & 63), x1 = lane_read(a1, i & 63);
+    return (i & 64) ? x1 : x0;
+}
+
 // status per matrix: 0 ok, 1 QL did not converge
 // mode 0: the decomposition; 1 (test hook): stop after stage 1 — W = diagonal of T, row 0 of A = its sub-diagonal; 2: stop after stage 2 — A = Q
 __global__ __launch_bounds__(kThreads) void k_batched_eigh(int n, double* __restrict__ A_all, double* __restrict__ W_all, int* __restrict__ status, int mode) {
@@ -69,6 +78,8 @@ __global__ __launch_bounds__(kThreads) void k_batched_eigh(int n, double* __rest
     int* perm = ctl + 4;             // n
     double* A = A_all + (size_t)blockIdx.x * n * n;
 
+    const long long T0 = (long long)__builtin_readcyclecounter();
+    long long tA = 0, tB = 0, nrot = 0, nsweep = 0;
     // ---- load, scaled by 1 / max |a_ij| (no over- or underflow in the squares below; the eigenvalues are scaled back)
     double amax = 0.0;
     for (int idx = tid; idx < n * n; idx += kThreads) {
@@ -117,7 +128,8 @@ __global__ __launch_bounds__(kThreads) void k_batched_eigh(int n, double* __rest
         if (row < s) {
             const double* ar = V + (size_t)(k + 1 + row) * ld + (k + 1);
             double acc = 0.0;
-            for (int j = j0; j < j1; ++j) acc = fma(ar[j], pv[j], acc);
+#pragma unroll 8
+            for (int j = j0; j < j1; ++j) acc = fma(ar[j], pv[j], acc);   // (unrolled: the LDS reads of several terms in flight)
             part[half * n + row] = acc;
         }
         __syncthreads();
@@ -129,6 +141,7 @@ __global__ __launch_bounds__(kThreads) void k_batched_eigh(int n, double* __rest
         if (row < s) {
             double* ar = V + (size_t)(k + 1 + row) * ld + (k + 1);
             const double vr = pv[row], wr = wv[row];
+#pragma unroll 8
             for (int j = j0; j < j1; ++j) ar[j] = ar[j] - (vr * wv[j] + wr * pv[j]);
         }
         __syncthreads();
@@ -140,6 +153,7 @@ __global__ __launch_bounds__(kThreads) void k_batched_eigh(int n, double* __rest
     }
     __syncthreads();
 
+    const long long T1 = (long long)__builtin_readcyclecounter();
     if (mode == 1) {
         for (int i = tid; i < n; i += kThreads) { W_all[(size_t)blockIdx.x * n + i] = d[i] * amax; A[i] = e[i] * amax; }
         if (tid == 0) status[blockIdx.x] = 0;
@@ -163,9 +177,11 @@ __global__ __launch_bounds__(kThreads) void k_batched_eigh(int n, double* __rest
         if (tid > rj && tid < n) {
             const int c = tid;
             double dot = V[(size_t)rj * ld + c];   // v[rj] = 1
+#pragma unroll 8
             for (int r = rj + 1; r < n; ++r) dot = fma(V[(size_t)r * ld + rj], V[(size_t)r * ld + c], dot);
             dot *= tj;
             V[(size_t)rj * ld + c] -= dot;
+#pragma unroll 8
             for (int r = rj + 1; r < n; ++r) V[(size_t)r * ld + c] = fma(-dot, V[(size_t)r * ld + rj], V[(size_t)r * ld + c]);
         }
         __syncthreads();
@@ -175,6 +191,7 @@ __global__ __launch_bounds__(kThreads) void k_batched_eigh(int n, double* __rest
         __syncthreads();
     }
 
+    const long long T2 = (long long)__builtin_readcyclecounter();
     if (mode == 2) {
         for (int idx = tid; idx < n * n; idx += kThreads) { const int i = idx / n, j = idx - i * n; A[idx] = V[(size_t)i * ld + j]; }
         for (int i = tid; i < n; i += kThreads) W_all[(size_t)blockIdx.x * n + i] = d[i] * amax;
@@ -182,60 +199,85 @@ __global__ __launch_bounds__(kThreads) void k_batched_eigh(int n, double* __rest
         return;
     }
 
-    // ---- 3. implicit QL on (d, e), the rotations accumulated into the columns of V
-    int failed = 0;
-    // (lane 0) a sub-diagonal below eps times the norm of T is zero.  A test relative to its two neighbours alone never ends inside
-    // a cluster that shares an unreduced block with eigenvalues a million times larger — gamma I + a low-rank covariance is exactly
-    // that, and so is a Gram matrix of low rank (a cluster of zeros): every sweep over the block commits roundings of size eps |T|
+    // ---- 3. implicit QL on (d, e), the rotations accumulated into the columns of V.  A sweep's scalar recurrence is sequential; it
+    //         runs on wave 0 with every lane computing the same values: the sweep's operands d[i], e[i] are read from a lane-resident
+    //         snapshot (v_readlane: no LDS round trip inside the dependent chain; a sweep reads each entry before it writes it), the
+    //         negligible sub-diagonal is found by one ballot instead of a walk, 1 / r and r come from one v_rsq_f64 and two Newton steps.
+    const bool w0 = tid < 64;
+    const double eps = 2.220446049250313e-16;
+    // a sub-diagonal below eps times the norm of T is zero.  A test relative to its two neighbours alone never ends inside a cluster
+    // that shares an unreduced block with eigenvalues a million times larger — gamma I + a low-rank covariance is exactly that, and
+    // so is a Gram matrix of low rank (a cluster of zeros): every sweep over the block commits roundings of size eps |T|
     double anorm = 0.0;
-    if (tid == 0)
-        for (int i = 0; i < n; ++i) anorm = fmax(anorm, fabs(d[i]) + fabs(e[i]));
+    if (w0) {
+        if (tid < n) anorm = fabs(d[tid]) + fabs(e[tid]);
+        if (tid + 64 < n) anorm = fmax(anorm, fabs(d[tid + 64]) + fabs(e[tid + 64]));
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) anorm = fmax(anorm, __shfl_xor(anorm, off, 64));
+    }
+    int failed = 0;
     for (int l = 0; l < n; ++l) {
         int iter = 0;
         while (true) {
-            if (tid == 0) {
-                int m = l;
-                for (; m < n - 1; ++m) {
-                    const double dd = fabs(d[m]) + fabs(d[m + 1]);
-                    if (fabs(e[m]) <= 2.220446049250313e-16 * fmax(dd, anorm)) break;
-                }
-                if (m == l) ctl[0] = 0;
-                else if (iter >= kMaxSweeps) ctl[0] = 2;
+            const long long ta = (long long)__builtin_readcyclecounter();
+            if (w0) {
+                const int j0 = tid, j1 = tid + 64;
+                const double d0 = j0 < n ? d[j0] : 0.0, d1 = j1 < n ? d[j1] : 0.0;
+                const double e0 = j0 < n ? e[j0] : 0.0, e1 = j1 < n ? e[j1] : 0.0;
+                const double dn0 = j0 + 1 < n ? d[j0 + 1] : 0.0, dn1 = j1 + 1 < n ? d[j1 + 1] : 0.0;
+                const bool z0 = j0 >= l && j0 < n - 1 && fabs(e0) <= eps * fmax(fabs(d0) + fabs(dn0), anorm);
+                const bool z1 = j1 >= l && j1 < n - 1 && fabs(e1) <= eps * fmax(fabs(d1) + fabs(dn1), anorm);
+                const unsigned long long b0 = __ballot(z0), b1 = __ballot(z1);
+                const int m = b0 ? __ffsll((long long)b0) - 1 : (b1 ? 63 + __ffsll((long long)b1) : n - 1);
+                int state = 1, lo = l;
+                if (m == l) state = 0;
+                else if (iter >= kMaxSweeps) state = 2;
                 else {
-                    double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
-                    double r = sqrt(fma(g, g, 1.0));
-                    g = d[m] - d[l] + e[l] / (g + copysign(r, g));
-                    double s = 1.0, c = 1.0, p = 0.0;
-                    int i = m - 1;
+                    const double dl = lane_get(d0, d1, l), el = lane_get(e0, e1, l), dm = lane_get(d0, d1, m);
+                    double g = (lane_get(d0, d1, l + 1) - dl) / (2.0 * el);
+                    const double r0 = sqrt(fma(g, g, 1.0));
+                    g = dm - dl + el / (g + copysign(r0, g));
+                    double s = 1.0, c = 1.0, p = 0.0, dup = dm;   // dup: d[i + 1] as it was before this sweep
                     bool broke = false;
-                    double di = d[i], ei = e[i], dup = d[m];   // dup: d[i + 1] as it was before this sweep
+                    int i = m - 1;
                     for (; i >= l; --i) {
-                        const double dn = (i > l) ? d[i - 1] : 0.0, en = (i > l) ? e[i - 1] : 0.0;   // next iteration's operands, ahead of the chain
+                        const double di = lane_get(d0, d1, i), ei = lane_get(e0, e1, i);
                         const double f = s * ei, b = c * ei;
-                        r = sqrt(fma(f, f, g * g));
-                        e[i + 1] = r;
-                        if (r == 0.0) { d[i + 1] = dup - p; e[m] = 0.0; broke = true; break; }
-                        const double rinv = 1.0 / r;
-                        s = f * rinv;
-                        c = g * rinv;
+                        const double x = fma(f, f, g * g);
+                        if (x == 0.0) {
+                            if (tid == 0) { e[i + 1] = 0.0; d[i + 1] = dup - p; e[m] = 0.0; }
+                            broke = true;
+                            break;
+                        }
+                        double y = __builtin_amdgcn_rsq(x);            // 1 / sqrt(x), refined to full precision
+                        const double hx = 0.5 * x;
+                        y = fma(y, fma(-hx * y, y, 0.5), y);
+                        y = fma(y, fma(-hx * y, y, 0.5), y);
+                        double rr = x * y;                             // sqrt(x)
+                        rr = fma(fma(-rr, rr, x), 0.5 * y, rr);
+                        s = f * y;
+                        c = g * y;
                         g = dup - p;
-                        r = (di - g) * s + 2.0 * c * b;
-                        p = s * r;
-                        d[i + 1] = g + p;
-                        g = c * r - b;
-                        cs[i] = c;
-                        sn[i] = s;
-                        dup = di; di = dn; ei = en;
+                        const double r2 = fma(di - g, s, 2.0 * c * b);
+                        p = s * r2;
+                        const double dnew = g + p;
+                        g = fma(c, r2, -b);
+                        if (tid == 0) { e[i + 1] = rr; d[i + 1] = dnew; cs[i] = c; sn[i] = s; }
+                        dup = di;
                     }
-                    if (!broke) { d[l] -= p; e[l] = g; e[m] = 0.0; }
-                    ctl[0] = 1; ctl[1] = m; ctl[2] = broke ? i + 1 : l;
+                    if (broke) lo = i + 1;
+                    else if (tid == 0) { d[l] = dl - p; e[l] = g; e[m] = 0.0; }
                 }
+                if (tid == 0) { ctl[0] = state; ctl[1] = m; ctl[2] = lo; }
             }
             __syncthreads();
+            const long long tb = (long long)__builtin_readcyclecounter();
             const int state = ctl[0], m = ctl[1], lo = ctl[2];
+            if (state == 1) { nrot += m - lo; ++nsweep; }
             if (state == 1 && tid < n && lo <= m - 1) {
                 double* r = V + (size_t)tid * ld;
                 double hi = r[m];            // the entry of column i + 1, carried from rotation to rotation
+#pragma unroll 8
                 for (int i = m - 1; i >= lo; --i) {
                     const double c = cs[i], s = sn[i], zi = r[i];
                     r[i + 1] = fma(s, zi, c * hi);
@@ -243,7 +285,8 @@ __global__ __launch_bounds__(kThreads) void k_batched_eigh(int n, double* __rest
                 }
                 r[lo] = hi;
             }
-            __syncthreads();   // (ctl, cs, sn are rewritten by the next sweep)
+            __syncthreads();   // (ctl, cs, sn, d, e are rewritten by the next sweep)
+            tA += tb - ta; tB += (long long)__builtin_readcyclecounter() - tb;
             if (state == 0) break;
             if (state == 2) { failed = 1; break; }
             ++iter;
@@ -269,6 +312,11 @@ __global__ __launch_bounds__(kThreads) void k_batched_eigh(int n, double* __rest
         A[idx] = V[(size_t)i * ld + perm[j]];
     }
     for (int i = tid; i < n; i += kThreads) W_all[(size_t)blockIdx.x * n + i] = d[perm[i]] * amax;
+    if (mode == 3 && tid == 0 && n >= 8) {   // (developer aid: cycles of the stages instead of the first eigenvalues)
+        double* w = W_all + (size_t)blockIdx.x * n;
+        w[0] = (double)(T1 - T0); w[1] = (double)(T2 - T1); w[2] = (double)tA; w[3] = (double)tB; w[4] = (double)nrot; w[5] = (double)nsweep;
+        w[6] = (double)((long long)__builtin_readcyclecounter() - T0);
+    }
 }
 
 size_t lds_bytes(int n) {

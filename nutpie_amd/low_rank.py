@@ -89,7 +89,8 @@ class Transform:
 NATIVE_EIGH_MAX = 64   # measured on MI355X, 512 problems (scratch/eigh_time.py, profiles/r4_low_rank_register_kernel.txt §5):
                        #   order      16     42     64     66     96    128
                        #   rocSOLVER  12.1   89.0  208.9   4.3    6.7   11.6 ms   (its small-matrix path below 65)
-                       #   engine      0.32   1.32   2.63  2.92  10.4   17.8 ms   (one workgroup per matrix; the QL sweep is one lane's work)
+                       #   engine      0.26   1.10   1.83  2.11   7.0   11.9 ms   (one workgroup per matrix; the QL sweep is one wave's sequential
+                       #                                                       work, 540 cycles per rotation: 6.1 ms for ONE order-128 problem, rocSOLVER 2.5)
 
 
 def _eigh_psd(A):
