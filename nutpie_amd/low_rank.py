@@ -145,7 +145,14 @@ def estimate(x, gx, gamma: float, cutoff: float, k_max: int = K_MAX) -> Transfor
     mid = (Um * em.clamp_min(0).sqrt()[:, None, :]) @ Um.transpose(1, 2)
     S = ihalf @ mid @ ihalf
     es, W = _eigh_psd(0.5 * (S + S.transpose(1, 2)))
-    es = es.clamp_min(1e-300)
+    # The geometric mean of A = Cx (eigenvalues in [gamma, |Cx|]) and B = Cg^-1 (in [1 / |Cg|, 1 / gamma]) has its eigenvalues in
+    # [sqrt(gamma / |Cg|), sqrt(|Cx| / gamma)]: anything outside is rounding — half Cx half has a condition number of 1 / gamma^2 and an
+    # eigensolver is accurate to eps |A|, so its smallest eigenvalues can come out zero or negative, S singular, and a column with
+    # lambda = 1e-300 would be "the most extreme direction" (measured: radon, a chain still in transit at the first boundary: every
+    # draw of the next window diverged with a NaN energy; one chain of 96 with rocSOLVER, two with the engine's solver)
+    lo = (gamma / eg[:, -1].clamp_min(gamma)).sqrt()
+    hi = (Cx.diagonal(dim1=1, dim2=2).sum(1).clamp_min(gamma) / gamma).sqrt()      # (the trace bounds the largest eigenvalue)
+    es = torch.maximum(torch.minimum(es, hi[:, None]), lo[:, None])
     # Re-centre the spectrum on its bulk.  With strong correlations sqrt(std(x) / std(g)) over-scales EVERY coordinate (std(x)
     # carries the shared directions, std(g) the conditional precisions): a few eigenvalues end up large and all the others small
     # (measured: 3 at ~500, 57 at ~0.03) — more directions than k_max columns can repair.  Dividing by the median eigenvalue

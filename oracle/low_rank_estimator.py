@@ -35,7 +35,8 @@ def estimate_chain(x, g, gamma, cutoff, k_max=16):
     ihalf = np.linalg.inv(half)
     S = ihalf @ np.real(sla.sqrtm(half @ Cx @ half)) @ ihalf
     es, W = np.linalg.eigh(0.5 * (S + S.T))
-    es = np.maximum(es, 1e-300)
+    # (the exact spectrum lies in [sqrt(gamma / |Cg|), sqrt(|Cx| / gamma)]; what rounding puts outside is clamped — as in the engine's version)
+    es = np.clip(es, np.sqrt(gamma / max(np.linalg.eigvalsh(Cg)[-1], gamma)), np.sqrt(max(np.trace(Cx), gamma) / gamma))
     # re-centre the spectrum on its bulk (the median eigenvalue goes into the diagonal scaling)
     # (the LOWER median for an even count, as torch.nanmedian takes it in the engine's version)
     centre = np.exp(np.sort(np.log(es))[(len(es) - 1) // 2])

@@ -229,7 +229,10 @@ def test_low_rank_job_is_reproducible_from_its_seed(hip):
     a = nutpie_amd.sample(cm, **kw)
     b = nutpie_amd.sample(cm, **kw)
     for name in ("n_steps", "depth", "energy", "step_size"):
-        assert np.array_equal(a.sample_stats[name].values, b.sample_stats[name].values), name
-        assert np.array_equal(a.warmup_sample_stats[name].values, b.warmup_sample_stats[name].values), name
+        assert np.array_equal(a.sample_stats[name].values, b.sample_stats[name].values, equal_nan=True), name
+        assert np.array_equal(a.warmup_sample_stats[name].values, b.warmup_sample_stats[name].values, equal_nan=True), name
     for name in a.posterior.data_vars:
         assert np.array_equal(a.posterior[name].values, b.posterior[name].values), name
+    # and no chain is handed a metric it cannot integrate under (a singular geometric mean used to give lambda = 1e-300: NaN energies
+    # and a diverging draw after draw until the next boundary — low_rank.estimate clamps the spectrum to its exact bounds)
+    assert np.isfinite(a.warmup_sample_stats["energy"].values).all()
