@@ -120,6 +120,9 @@ def estimate(x, gx, gamma: float, cutoff: float, k_max: int = K_MAX) -> Transfor
     import torch
 
     n, m, D = x.shape
+    # a window with a non-finite entry says nothing: that chain gets the identity (sigma = 1, no columns) instead of a NaN metric
+    ok = (torch.isfinite(x).flatten(1).all(1) & torch.isfinite(gx).flatten(1).all(1))[:, None, None]
+    x, gx = torch.where(ok, x, torch.zeros_like(x)), torch.where(ok, gx, torch.zeros_like(gx))
     mean = x.mean(1)
     sx = x.std(1, unbiased=True)
     sg = gx.std(1, unbiased=True)

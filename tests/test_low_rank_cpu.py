@@ -190,3 +190,21 @@ def test_driver_hands_every_chain_its_own_windows_without_lock_step():
     # the hand-ins are batched: fewer estimates than (chain, boundary) pairs
     assert len(smp.switch_log) < n * len(pauses)
     assert sum(e[3] for e in smp.switch_log) == n * len(pauses)
+
+
+def test_estimator_ignores_a_window_with_non_finite_entries():
+    """One chain's window holds an inf: that chain gets the identity (sigma = 1, no columns), the others are not touched."""
+    from nutpie_amd import low_rank as lr
+
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(3, 20, 7, generator=g, dtype=torch.float64)
+    gx = -x + 0.1 * torch.randn(3, 20, 7, generator=g, dtype=torch.float64)
+    want = lr.estimate(x, gx, 1e-5, 2.0)
+    bad = gx.clone()
+    bad[1, 4, 2] = float("inf")
+    got = lr.estimate(x, bad, 1e-5, 2.0)
+    for a, b in ((got.stds, want.stds), (got.V, want.V), (got.d, want.d)):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2])
+    assert torch.equal(got.stds[1], torch.ones(7, dtype=torch.float64)) and not got.d[1].any() and not got.V[1].any()
+    sig2, V, lam = lr.metric_of(got)
+    assert torch.isfinite(sig2).all() and torch.isfinite(V).all() and torch.isfinite(lam).all()
