@@ -578,13 +578,27 @@ def other_configs(env, args):
                          "density, window estimates (batched eigh on the device) handed to each chain as it stops; job_s is engine time, wall_incl_setup_s the job")
         return r
 
+    def c3_traced():
+        from nutpie_amd.radon import radon_traced_model
+
+        t_c = time.perf_counter()
+        m = radon_traced_model()          # torch.fx trace -> expression graph -> symbolic gradient -> HIP source (-> hipcc unless cached)
+        m.library_path()
+        compile_s = time.perf_counter() - t_c
+        t0 = time.perf_counter()
+        r = job_rate(m._make_sampler(settings(512, 400, 1000), None, 1, None, None, None, None), t0)
+        r["trace_and_compile_s"] = compile_s
+        r["workload"] = ("radon, 512 chains, tune 400 + draws 1000; the model is a TORCH log-density (forward pass only, nutpie_amd.radon.radon_torch_density) that "
+                         "nutpie_amd.from_torch_density traces (torch.fx), differentiates and compiles into its own resident kernel")
+        return r
+
     def c3_torch():
         from nutpie_amd.radon import radon_model
 
         m = radon_model(device=env.device, use_graph=True)
         t0 = time.perf_counter()
         r = job_rate(m._make_sampler(settings(512, 100, 50), None, 1, None, None, None, None, store_draws=False), t0)
-        r["workload"] = "radon, 512 chains, torch log-density (HIP-graph replay) behind the batched device callback; bounded sample: tune 100 + draws 50"
+        r["workload"] = "radon, 512 chains, torch log-density evaluated EAGERLY (hand-derived gradient, HIP-graph replay) behind the batched device callback; bounded sample: tune 100 + draws 50"
         return r
 
     def c4():
@@ -612,7 +626,8 @@ def other_configs(env, args):
 
     leg("config3_radon_generated_density", c3_generated)
     leg("config3_radon_generated_density_low_rank", c3_low_rank)
-    leg("config3_radon_torch_density", c3_torch)
+    leg("config3_radon_torch_density", c3_traced)
+    leg("config3_radon_torch_density_eager", c3_torch)
     leg("config4_eight_schools_host_callback", c4)
     leg("config2ii_dense_gaussian_gemm_callback", c2_dense)
     return out

@@ -383,10 +383,35 @@ def autograd_logp(density_fn: Callable) -> Callable:
     return logp
 
 
-def from_torch_density(ndim: int, density_fn: Callable, **kwargs):
-    """Batched device model from a log-density alone: the gradient comes from ``torch.autograd``.  Keyword arguments as
-    :func:`from_torchfunc` (``use_graph=True`` replays the whole evaluation from a HIP graph); ``shared_data`` entries
-    are passed to ``density_fn`` as keyword arguments."""
+def from_torch_density(ndim: int, density_fn: Callable, *, compile: Any = "auto", batched: bool = True, waves_per_chain: int | None = None, **kwargs):
+    """A model from a torch log-density alone: ``density_fn(x: Tensor[chains, ndim], **shared_data) -> Tensor[chains]``.
+
+    ``compile`` (default ``"auto"``): the function is TRACED once (:mod:`nutpie_amd.torch_trace`: ``torch.fx`` -> the front-end's
+    expression graph -> symbolic gradient -> generated HIP density) and runs inside the model's own resident NUTS kernel — no torch
+    call, no kernel launch and no memory round trip per gradient evaluation (the reference compiles a model's logp graph likewise,
+    ``python/nutpie/compile_pymc.py:668-871``).  ``"auto"`` falls back to the eager path below when the function uses an operation
+    the tracer cannot map (a ``UserWarning`` names it); ``True`` raises :class:`nutpie_amd.torch_trace.UnsupportedTorchOp` instead;
+    ``False`` never traces.  ``batched=False``: ``density_fn(x: Tensor[ndim]) -> scalar`` (compiled path only).
+
+    The eager path: a batched device callback, the gradient from ``torch.autograd`` (``use_graph=True`` replays the whole evaluation
+    from a HIP graph).  Keyword arguments as :func:`from_torchfunc`; ``shared_data`` entries are passed to ``density_fn`` as keyword
+    arguments (``with_data`` replaces them; a compiled model is traced again, its library is re-used when only values changed)."""
+    if compile not in (True, False, "auto"):
+        raise ValueError("compile must be True, False or 'auto'")
+    if compile:
+        from nutpie_amd.torch_trace import UnsupportedTorchOp, traced_model
+
+        try:
+            return traced_model(ndim, density_fn, batched=batched, waves_per_chain=waves_per_chain,
+                                **{k: v for k, v in kwargs.items() if k not in ("use_graph", "expand_device_fn")})
+        except UnsupportedTorchOp as e:
+            if compile is True:
+                raise
+            import warnings
+
+            warnings.warn(f"the torch log-density is evaluated eagerly (one launch per operation): {e}", UserWarning, stacklevel=2)
+    if not batched:
+        raise ValueError("batched=False needs the compiled path")
 
     def make_logp():
         def logp(x, **shared):

@@ -47,6 +47,80 @@ def _extend_zero_sum(x):
     return torch.cat([x, fill], -1) - norm
 
 
+def radon_torch_density(data=None, device="cpu"):
+    """The model's log-density as a user of ``from_torch_density`` writes it (forward pass only, batched over chains): what
+    BASELINE config 3 names as its backend.  Returns ``(D, logp)``; the data tensors live on ``device``."""
+    import torch
+
+    data = data or synthetic_radon_data()
+    n = int(np.max(data["county_idx"])) + 1
+    D = 2 * n + 3
+    o_int, o_raw, o_lsd, o_floor, o_craw, o_lcsd, o_lsig = 0, 1, n, n + 1, n + 2, 2 * n + 1, 2 * n + 2
+    dev = torch.device(device) if isinstance(device, str) else torch.device("cuda", device)
+    cidx = torch.as_tensor(data["county_idx"], device=dev, dtype=torch.long)
+    floor = torch.as_tensor(data["floor"], device=dev, dtype=torch.float64)
+    y = torch.as_tensor(data["log_radon"], device=dev, dtype=torch.float64)
+    n_obs = y.shape[0]
+
+    def logp(x):
+        intercept = x[:, o_int]
+        raw = x[:, o_raw:o_raw + n - 1]
+        lsd = x[:, o_lsd]
+        fe = x[:, o_floor]
+        craw = x[:, o_craw:o_craw + n - 1]
+        lcsd = x[:, o_lcsd]
+        lsig = x[:, o_lsig]
+        sd, csd, sig = torch.exp(lsd), torch.exp(lcsd), torch.exp(lsig)
+        ce = _extend_zero_sum(raw) * sd[:, None]
+        cfe = _extend_zero_sum(craw) * csd[:, None]
+        mu = intercept[:, None] + ce[:, cidx] + fe[:, None] * floor + cfe[:, cidx] * floor
+        r = (y - mu) / sig[:, None]
+        lp = -0.5 * (intercept / 10.0) ** 2 - 0.5 * (fe / 2.0) ** 2
+        lp = lp - 0.5 * (raw * raw).sum(-1) - 0.5 * (craw * craw).sum(-1)
+        lp = lp - 0.5 * sd * sd + lsd - 0.5 * csd * csd + lcsd - 0.5 * (sig / 1.5) ** 2 + lsig
+        lp = lp - 0.5 * (r * r).sum(-1) - n_obs * lsig
+        return lp
+
+    return D, logp
+
+
+def radon_expand(data=None):
+    """(expand function of a numpy block ``[N, D]``, names, shapes, dims, coords) of the radon model's reported variables"""
+    data = data or synthetic_radon_data()
+    n = int(np.max(data["county_idx"])) + 1
+    o_raw, o_lsd, o_floor, o_craw, o_lcsd, o_lsig = 1, n, n + 1, n + 2, 2 * n + 1, 2 * n + 2
+
+    def expand(x, **_data):
+        x = np.asarray(x)
+
+        def ext(v):
+            m = v.shape[-1] + 1
+            s = v.sum(-1, keepdims=True)
+            norm = s / (np.sqrt(m) + m)
+            return np.concatenate([v, norm - s / np.sqrt(m)], -1) - norm
+
+        raw, craw = ext(x[:, o_raw:o_raw + n - 1]), ext(x[:, o_craw:o_craw + n - 1])
+        sd, csd = np.exp(x[:, o_lsd]), np.exp(x[:, o_lcsd])
+        return {"intercept": x[:, 0], "county_raw": raw, "county_sd": sd, "county_effect": raw * sd[:, None], "floor_effect": x[:, o_floor],
+                "county_floor_raw": craw, "county_floor_sd": csd, "county_floor_effect": craw * csd[:, None], "sigma": np.exp(x[:, o_lsig])}
+
+    names = ["intercept", "county_raw", "county_sd", "county_effect", "floor_effect", "county_floor_raw", "county_floor_sd", "county_floor_effect", "sigma"]
+    shapes = [(), (n,), (), (n,), (), (n,), (), (n,), ()]
+    dims = {k: ("county",) for k in ("county_raw", "county_effect", "county_floor_raw", "county_floor_effect")}
+    return expand, names, shapes, dims, {"county": np.arange(n)}
+
+
+def radon_traced_model(data=None, compile=True, **kw):
+    """Config 3 with the backend BASELINE.json names — a torch log-density — compiled: :func:`nutpie_amd.from_torch_density` traces
+    ``radon_torch_density`` (``torch.fx``), differentiates the graph and compiles the generated HIP density into the model's own
+    resident kernel.  ``compile=False``: the same function evaluated eagerly behind the batched device callback (the data on the GPU)."""
+    from nutpie_amd.compiled_pyfunc import from_torch_density
+
+    D, logp = radon_torch_density(data, device="cpu" if compile else kw.pop("device", 0))
+    expand, names, shapes, dims, coords = radon_expand(data)
+    return from_torch_density(D, logp, compile=compile, expand_fn=expand, expanded_names=names, expanded_shapes=shapes, dims=dims, coords=coords, **kw)
+
+
 def radon_model(data=None, device=0, use_graph=False, expand_on_device=True):
     """Returns a :class:`~nutpie_amd.compiled_pyfunc.TorchFuncModel` for the radon model."""
     import torch

@@ -234,8 +234,24 @@ def _binary(op: str, a: Expr, b: Expr) -> Expr:
     return Expr(op, (a, b), _join(a, b))
 
 
+def _digamma_py(x: float) -> float:
+    """psi(x) the way the generated device code computes it (recurrence up to 10, then the asymptotic series)"""
+    if x <= 0.0:
+        if x == math.floor(x):
+            return math.nan
+        return _digamma_py(1.0 - x) - math.pi / math.tan(math.pi * x)
+    r = 0.0
+    while x < 10.0:
+        r -= 1.0 / x
+        x += 1.0
+    f = 1.0 / (x * x)
+    return r + math.log(x) - 0.5 / x - f * (1.0 / 12 - f * (1.0 / 120 - f * (1.0 / 252 - f * (1.0 / 240 - f * (1.0 / 132 - f * (691.0 / 32760 - f / 12))))))
+
+
 _UNARY_FOLD = {"neg": lambda v: -v, "exp": math.exp, "log": math.log, "log1p": math.log1p, "sqrt": math.sqrt,
-               "softplus": lambda v: max(v, 0.0) + math.log1p(math.exp(-abs(v))), "sigmoid": lambda v: 1.0 / (1.0 + math.exp(-v))}
+               "softplus": lambda v: max(v, 0.0) + math.log1p(math.exp(-abs(v))), "sigmoid": lambda v: 1.0 / (1.0 + math.exp(-v)),
+               "tanh": math.tanh, "expm1": math.expm1, "erf": math.erf, "erfc": math.erfc, "sin": math.sin, "cos": math.cos, "atan": math.atan,
+               "lgamma": math.lgamma, "digamma": _digamma_py, "abs": abs, "sign": lambda v: float((v > 0) - (v < 0))}
 
 
 def _unary(op: str, a) -> Expr:
@@ -274,6 +290,92 @@ def softplus(a):
 
 def sigmoid(a):
     return _unary("sigmoid", a)
+
+
+def tanh(a):
+    return _unary("tanh", a)
+
+
+def expm1(a):
+    return _unary("expm1", a)
+
+
+def erf(a):
+    return _unary("erf", a)
+
+
+def erfc(a):
+    return _unary("erfc", a)
+
+
+def sin(a):
+    return _unary("sin", a)
+
+
+def cos(a):
+    return _unary("cos", a)
+
+
+def atan(a):
+    return _unary("atan", a)
+
+
+def lgamma(a):
+    return _unary("lgamma", a)
+
+
+def digamma(a):
+    return _unary("digamma", a)
+
+
+def absolute(a):
+    return _unary("abs", a)
+
+
+def sign(a):
+    return _unary("sign", a)
+
+
+def _join3(c: Expr, a: Expr, b: Expr) -> Dim | None:
+    d = None
+    for v in (c, a, b):
+        if v.dim is not None:
+            if d is not None and v.dim is not d:
+                raise ValueError(f"operands live on different dimensions ({d.name!r}, {v.dim.name!r})")
+            d = v.dim
+    return d
+
+
+def select(c, a, b, strict: bool = True) -> Expr:
+    """``a`` where ``c > 0`` (``strict``) resp. ``c >= 0``, else ``b`` — element-wise; the condition carries no gradient."""
+    c, a, b = Expr.wrap(c), Expr.wrap(a), Expr.wrap(b)
+    if c.op == "const":
+        return a if (c.payload > 0.0 if strict else c.payload >= 0.0) else b
+    if a is b:
+        return a
+    return Expr("sel_gt" if strict else "sel_ge", (c, a, b), _join3(c, a, b))
+
+
+def pad(v: Expr, dim: Dim) -> Expr:
+    """``v`` (on a shorter dimension of fixed size) on the first elements of ``dim``, zero on the rest."""
+    v = Expr.wrap(v)
+    if v.dim is None or v.dim is dim:
+        return v
+    if v.dim.size is None or dim.size is None or v.dim.size > dim.size:
+        raise ValueError("pad() goes from a fixed-size dimension to a longer fixed-size dimension")
+    return Expr("pad", (v,), dim, None)
+
+
+def trunc(v: Expr, dim: Dim) -> Expr:
+    """The first ``dim.size`` elements of ``v`` (on a longer dimension of fixed size), as a value on ``dim``."""
+    v = Expr.wrap(v)
+    if v.dim is None or v.dim is dim:
+        return v
+    if v.dim.size is None or dim.size is None or v.dim.size < dim.size:
+        raise ValueError("trunc() goes from a fixed-size dimension to a shorter fixed-size dimension")
+    if v.op == "pad" and v.args[0].dim is dim:
+        return v.args[0]
+    return Expr("trunc", (v,), dim, None)
 
 
 def where_lt(dim: Dim, k: int, a, b) -> Expr:
@@ -417,6 +519,9 @@ def poisson_log_lpmf(y, eta, log_factorial) -> Expr:
 
 
 # --------------------------------------------------------------------------- reverse mode
+_TWO_OVER_SQRT_PI = 2.0 / math.sqrt(math.pi)
+
+
 def _topo(roots) -> list[Expr]:
     seen, order = set(), []
     stack = [(r, False) for r in roots]
@@ -499,6 +604,36 @@ def gradient(out: Expr, wrt: list[Expr]) -> list[Expr]:
             acc(a, g * (n * (1.0 - n)))
         elif n.op == "where_lt":
             acc(a, reduce_to(where_lt(d, n.payload, g, 0.0), d, a)); acc(b, reduce_to(where_lt(d, n.payload, 0.0, g), d, b))
+        elif n.op in ("sel_gt", "sel_ge"):
+            strict = n.op == "sel_gt"
+            va, vb = n.args[1], n.args[2]
+            acc(va, reduce_to(select(a, g, 0.0, strict), d, va)); acc(vb, reduce_to(select(a, 0.0, g, strict), d, vb))
+        elif n.op == "tanh":
+            acc(a, g * (1.0 - n * n))
+        elif n.op == "expm1":
+            acc(a, g * (n + 1.0))
+        elif n.op == "erf":
+            acc(a, g * (_TWO_OVER_SQRT_PI * exp(-(a * a))))
+        elif n.op == "erfc":
+            acc(a, g * (-_TWO_OVER_SQRT_PI * exp(-(a * a))))
+        elif n.op == "sin":
+            acc(a, g * cos(a))
+        elif n.op == "cos":
+            acc(a, -(g * sin(a)))
+        elif n.op == "atan":
+            acc(a, g / (1.0 + a * a))
+        elif n.op == "lgamma":
+            acc(a, g * digamma(a))
+        elif n.op == "digamma":
+            raise NotImplementedError("the derivative of digamma (trigamma) is not available")
+        elif n.op == "abs":
+            acc(a, g * sign(a))
+        elif n.op == "sign":
+            pass
+        elif n.op == "pad":
+            acc(a, trunc(g, a.dim) if g.dim is not None else g)
+        elif n.op == "trunc":
+            acc(a, pad(g, a.dim) if g.dim is not None else where_lt(a.dim, d.size, g, 0.0))
         elif n.op == "bcast":
             acc(a, reduce_to(g, d, a))
         elif n.op == "sum":
@@ -513,6 +648,17 @@ def gradient(out: Expr, wrt: list[Expr]) -> list[Expr]:
 
 
 # --------------------------------------------------------------------------- numpy evaluation (expand step; the tests' checker)
+_NP_UNARY = ("tanh", "expm1", "erf", "erfc", "sin", "cos", "atan", "lgamma", "digamma", "abs", "sign")
+
+
+def _np_unary(op: str, a: np.ndarray) -> np.ndarray:
+    if op in ("erf", "erfc", "lgamma", "digamma"):
+        import scipy.special as sp
+
+        return {"erf": sp.erf, "erfc": sp.erfc, "lgamma": sp.gammaln, "digamma": sp.digamma}[op](a)
+    return {"tanh": np.tanh, "expm1": np.expm1, "sin": np.sin, "cos": np.cos, "atan": np.arctan, "abs": np.abs, "sign": np.sign}[op](a)
+
+
 def evaluate(nodes: list[Expr], x: np.ndarray, data: dict[str, Any]) -> list[np.ndarray]:
     """Values of ``nodes`` for a block of positions ``x[N, D]``: scalars as ``[N]``, dimensioned nodes as ``[N, len]``."""
     x = np.atleast_2d(np.asarray(x, dtype=np.float64))
@@ -577,6 +723,18 @@ def evaluate(nodes: list[Expr], x: np.ndarray, data: dict[str, Any]) -> list[np.
             elif n.op == "where_lt":
                 L = dim_len(n.dim)
                 v = np.where((np.arange(L) < n.payload)[None, :], np.broadcast_to(a, (N, L)), np.broadcast_to(b, (N, L)))
+            elif n.op in ("sel_gt", "sel_ge"):
+                c3 = [val[x_.id] for x_ in n.args]
+                if n.dim is not None:
+                    c3 = [np.broadcast_to(t[:, None] if t.ndim == 1 else t, (N, dim_len(n.dim))) for t in c3]
+                v = np.where(c3[0] > 0 if n.op == "sel_gt" else c3[0] >= 0, c3[1], c3[2])
+            elif n.op in _NP_UNARY:
+                v = _np_unary(n.op, a)
+            elif n.op == "pad":
+                v = np.zeros((N, dim_len(n.dim)))
+                v[:, :a.shape[1]] = a
+            elif n.op == "trunc":
+                v = a[:, :dim_len(n.dim)]
             elif n.op == "bcast":
                 v = np.broadcast_to(a[:, None] if a.ndim == 1 else a, (N, dim_len(n.dim)))
             elif n.op == "sum":
@@ -627,17 +785,20 @@ class _Gen:
             self.out_vector = [(p, _bcast(g, p.dim) if g.dim is None else g) for p, g in zip(self.params, grads) if p.dim is not None]
         roots = [logp] + [g for _, g in self.out_scalar] + [g for _, g in self.out_vector]
         self.order = _topo(roots)
+        # names in the generated source count the nodes of THIS graph (node ids count every node ever made: the same model built
+        # twice would print two different sources, and the library cache is keyed by the source)
+        self.num: dict[int, int] = {n.id: k for k, n in enumerate(self.order)}
         self.level: dict[int, int] = {}
         for n in self.order:
             lv = max([self.level[a.id] for a in n.args], default=0)
-            if n.op in ("sum", "gather", "segsum") or (n.op == "elem" and n.args[0].op not in ("vparam", "data")):
+            if n.op in ("sum", "gather", "segsum") or (n.op in ("elem", "pad", "trunc") and n.args[0].op not in ("vparam", "data")):
                 lv += 1
             self.level[n.id] = lv
         # what lives in per-chain LDS: sources of gathers (unless they are parameters or data, read in place), arguments of
         # segment sums (stored grouped by target) ...
         self.stored: dict[Any, tuple[str, Dim]] = {}
         for n in self.order:
-            if n.op == "gather" and n.args[0].op not in ("vparam", "data"):
+            if n.op in ("gather", "pad", "trunc") and n.args[0].op not in ("vparam", "data"):
                 self.stored[n.args[0].id] = ("plain", n.args[0].dim)
             elif n.op == "segsum":
                 self.stored[("seg", n.args[0].id, n.payload.name)] = ("grouped", n.args[0].dim)
@@ -662,7 +823,7 @@ class _Gen:
                 if n.op == "segsum":
                     evaluated.setdefault(n.id, set()).add(lv[1])
                     continue               # (its argument was stored by an earlier loop)
-                if n.op == "gather":
+                if n.op in ("gather", "pad", "trunc"):
                     continue
                 stack.extend(n.args)
         for nid, levels in evaluated.items():
@@ -683,7 +844,7 @@ class _Gen:
                 seen.add(n.id)
                 if n.op == "vparam":
                     reads.setdefault(n.id, set()).add(key)
-                if n.op in ("stack", "gather", "segsum") or (n.id in self.stored and self.level[n.id] < key[1]):
+                if n.op in ("stack", "gather", "segsum", "pad", "trunc") or (n.id in self.stored and self.level[n.id] < key[1]):
                     continue
                 stack.extend(n.args)
         for nid, loops in reads.items():
@@ -720,6 +881,8 @@ class _Gen:
         stage_src, shared_fields = m._stage_source()
         if emit_stage:
             emit(stage_src)
+        if any(n.op == "digamma" for n in self.order):
+            emit(_DIGAMMA_SOURCE)
         emit(f"__device__ double {self.fn_name}(const NphipData& data, int dim, const double* x, double* g, double* lds, const double* shared, int lane) {{")
         # dimension lengths, data pointers (shared LDS where staged, else global), LDS scratch
         for d in m._dims.values():
@@ -756,7 +919,7 @@ class _Gen:
             U = max(1, min(_UNROLL, -(-n.dim.size // self.threads)))
             for u in range(U):
                 idx = f"(lane + {self.threads * u})"
-                emit(f"    const double H{nid}_{u} = ({idx} < {nv}) ? x[{off} + {idx}] : 0.0;")
+                emit(f"    const double H{self.num[nid]}_{u} = ({idx} < {nv}) ? x[{off} + {idx}] : 0.0;")
         max_level = max(self.level.values(), default=0)
         done_scalar: set[int] = set()
         self.L = L
@@ -782,7 +945,7 @@ class _Gen:
                 if n.dim is None and n.op != "sum" and self.level[n.id] == lv and n.id not in done_scalar:
                     assert scalar_ready(n), n
                     if n.op != "const":
-                        emit(f"    const double s{n.id} = {self.scalar_rhs(n)};")
+                        emit(f"    const double s{self.num[n.id]} = {self.scalar_rhs(n)};")
                     done_scalar.add(n.id)
             stacks = [n for n in self.order if n.op == "stack" and self.level[n.id] == lv]
             if stacks:
@@ -832,7 +995,7 @@ class _Gen:
     def sref(self, n: Expr) -> str:
         if n.op == "const":
             return _lit(n.payload)
-        return f"s{n.id}"
+        return f"s{self.num[n.id]}"
 
     def scalar_rhs(self, n: Expr) -> str:
         if n.op == "sparam":
@@ -858,7 +1021,7 @@ class _Gen:
         by_id = {n.id: n for n in self.order}
         emit(f"    // level {lv}, over {d.name}")
         for n in sums:
-            emit(f"    double s{n.id} = 0.0;")
+            emit(f"    double s{self.num[n.id]} = 0.0;")
         emit(f"    for (int i0 = lane; i0 < n_{d.name}; i0 += {T * U}) {{")
         stages: list[list[str]] = [[], [], [], [], []]   # 0 direct reads, 1 dependent reads, 2 segment sums, 3 arithmetic, 4 stores / sums
         seg: dict[tuple, list[tuple[str, str]]] = {}     # (iteration, index) -> [(accumulator, array)]: one inner loop for all of them
@@ -871,11 +1034,11 @@ class _Gen:
                     return self.sref(n)
                 if n.id in memo:
                     return memo[n.id]
-                name = f"v{n.id}_{u}"
+                name = f"v{self.num[n.id]}_{u}"
                 if n.id in self.stored and self.level[n.id] < lv:
                     stages[0].append(f"        const double {name} = {self.store_name[n.id]}[j_{u}];")
                 elif n.op == "vparam" and n.id in self.hoisted:
-                    name = f"H{n.id}_{u}"       # (read before the first loop; lanes past the end hold 0 and are never used)
+                    name = f"H{self.num[n.id]}_{u}"       # (read before the first loop; lanes past the end hold 0 and are never used)
                 elif n.op == "vparam":
                     off, nv = n.payload
                     full = d.size is not None and nv == d.size
@@ -901,6 +1064,16 @@ class _Gen:
                         stages[1].append(f"        const double {name} = D_{src.payload}[{iname}];")
                     else:
                         stages[1].append(f"        const double {name} = {self.store_name[src.id]}[{iname}];")
+                elif n.op in ("pad", "trunc"):
+                    # the same element of a value on a shorter (pad: zero beyond its end) or longer (trunc) dimension
+                    src = n.args[0]
+                    inside = f"(j_{u} < n_{src.dim.name})" if n.op == "pad" else None
+                    if src.op == "vparam":
+                        off, nv = src.payload
+                        stages[0].append(f"        const double {name} = (j_{u} < {nv}) ? x[{off} + j_{u}] : 0.0;")
+                    else:
+                        arr = f"D_{src.payload}" if src.op == "data" else self.store_name[src.id]
+                        stages[0].append(f"        const double {name} = " + (f"{inside} ? {arr}[j_{u}] : 0.0;" if inside else f"{arr}[j_{u}];"))
                 elif n.op == "segsum":
                     index = n.payload
                     arr = self.store_name[("seg", n.args[0].id, index.name)]
@@ -934,7 +1107,7 @@ class _Gen:
                 else:
                     stages[4].append(f"        {guard}{self.store_name[key]}[i_{u}] = {v};")
             for n in sums:
-                stages[4].append(f"        {guard}s{n.id} += {val(n.args[0])};")
+                stages[4].append(f"        {guard}s{self.num[n.id]} += {val(n.args[0])};")
             for p, gexpr in outs:
                 off, nv = p.payload
                 perm = getattr(p, "perm", None)
@@ -952,7 +1125,7 @@ class _Gen:
         emit("    }")
         mark(f"loop over {d.name}, level {lv}")
         # the loop's sums over the wave, several at a time
-        ids = [f"s{n.id}" for n in sums]
+        ids = [f"s{self.num[n.id]}" for n in sums]
         for k in range(0, len(ids), 4):
             grp = ids[k:k + 4]
             if len(grp) == 1:
@@ -998,7 +1171,37 @@ def _op_c(op: str, a: list[str]) -> str:
         return f"(fmax({a[0]}, 0.0) + log1p(exp(-fabs({a[0]}))))"
     if op == "sigmoid":
         return f"(1.0 / (1.0 + exp(-{a[0]})))"
+    if op in ("tanh", "expm1", "erf", "erfc", "sin", "cos", "atan", "lgamma"):
+        return f"{op}({a[0]})"
+    if op == "digamma":
+        return f"nphip_digamma({a[0]})"
+    if op == "abs":
+        return f"fabs({a[0]})"
+    if op == "sign":
+        return f"(double)(({a[0]} > 0.0) - ({a[0]} < 0.0))"
+    if op == "sel_gt":
+        return f"(({a[0]} > 0.0) ? {a[1]} : {a[2]})"
+    if op == "sel_ge":
+        return f"(({a[0]} >= 0.0) ? {a[1]} : {a[2]})"
     raise AssertionError(op)
+
+
+_DIGAMMA_SOURCE = """#ifndef NPHIP_DIGAMMA_DEFINED
+#define NPHIP_DIGAMMA_DEFINED
+// psi(x): reflection for x <= 0, the recurrence psi(x) = psi(x + 1) - 1/x up to 10, then the asymptotic series (to 1e-16)
+static __device__ double nphip_digamma(double x) {
+    double r = 0.0;
+    if (x <= 0.0) {
+        if (x == floor(x)) return NAN;
+        r = -3.14159265358979323846 / tan(3.14159265358979323846 * x);
+        x = 1.0 - x;
+    }
+    while (x < 10.0) { r -= 1.0 / x; x += 1.0; }
+    const double f = 1.0 / (x * x);
+    return r + log(x) - 0.5 / x - f * (1.0 / 12 - f * (1.0 / 120 - f * (1.0 / 252 - f * (1.0 / 240 - f * (1.0 / 132 - f * (691.0 / 32760 - f / 12))))));
+}
+#endif
+"""
 
 
 # --------------------------------------------------------------------------- the model
@@ -1392,7 +1595,8 @@ class Model:
             if how != "scalars":       # (vectors assembled by the scalar code are tiny and written by one lane: they stay)
                 gen.spilled.append(key)
 
-    def compile(self, *, init="uniform", resident: bool = True, coords=None, dims=None, waves_per_chain: int | None = None):
+    def compile(self, *, init="uniform", resident: bool = True, coords=None, dims=None, waves_per_chain: int | None = None,
+                expanded_names=None, expanded_shapes=None, expand_fn=None):
         """-> :class:`SymbolicModel` (a :class:`nutpie_amd.density.DensitySourceModel`).  ``waves_per_chain`` (1, 2, 4): wavefronts
         that evaluate one chain's density together — more than one pays with fewer chains than the device has SIMDs (1024), and a
         workgroup then holds ONE chain instead of four, i.e. a quarter of the per-chain LDS: the default (None) is one wave per
@@ -1415,9 +1619,11 @@ class Model:
             gen = _Gen(self, logp, grads, waves_per_chain)
         self._spill(gen, waves_per_chain)
         src, _ = gen.source()
-        return self._finish(src, gen, init=init, resident=resident, coords=coords, dims=dims, waves_per_chain=waves_per_chain)
+        return self._finish(src, gen, init=init, resident=resident, coords=coords, dims=dims, waves_per_chain=waves_per_chain,
+                            expanded_names=expanded_names, expanded_shapes=expanded_shapes, expand_fn=expand_fn)
 
-    def _finish(self, src, gen, *, init="uniform", resident=True, coords=None, dims=None, waves_per_chain=1):
+    def _finish(self, src, gen, *, init="uniform", resident=True, coords=None, dims=None, waves_per_chain=1, expanded_names=None, expanded_shapes=None,
+                expand_fn=None):
         from nutpie_amd.density import from_density_source
 
         dim_of = {k: d for k, d in self._dims.items()}
@@ -1513,6 +1719,16 @@ class Model:
             offs.append((off, e, perm))
             off += int(np.prod(shp, dtype=np.int64)) if shp else 1
         fixed = all(e.dim is None or e.dim.size is not None for e in nodes)   # (values on a data dimension change size with the data: host expand)
+        # A caller that names the reported variables itself (a traced torch density: one variable `x`, or the user's expand function):
+        # with a host function there is no generated expand; without one the generated rows are re-read under the caller's shapes
+        if expanded_names is not None:
+            out_names, out_shapes = list(expanded_names), [tuple(int(v) for v in shp) for shp in expanded_shapes]
+            if expand_fn is None and sum(int(np.prod(shp, dtype=np.int64)) if shp else 1 for shp in out_shapes) != off:
+                raise ValueError("expanded_shapes must hold as many values as the model reports")
+            if expand_fn is not None:
+                fixed = False
+        else:
+            out_names, out_shapes = names, shapes
         egen = _Gen(self, Expr.const(0.0), [], waves_per_chain, outputs=offs, fn_name="nphip_expand") if (fixed and det) else None
         expand_src = ""
         if egen is not None:
@@ -1529,14 +1745,31 @@ class Model:
         def scratch_per_chain(data):
             return sum(dim_len(d, data) for d in spilled_dims)
 
+        if expanded_names is None:
+            expand_host = expand
+        elif expand_fn is not None:
+            expand_host = expand_fn
+        else:
+            def expand_host(positions, /, **data):   # the model's own values in declaration order, re-read under the caller's names
+                vals = expand(positions, **data)
+                N = np.atleast_2d(np.asarray(positions)).shape[0]
+                flat = np.concatenate([np.asarray(vals[n]).reshape(N, -1) for n in names], axis=1)
+                out, at = {}, 0
+                for n, shp in zip(out_names, out_shapes):
+                    k = int(np.prod(shp, dtype=np.int64)) if shp else 1
+                    out[n] = flat[:, at:at + k].reshape(N, *shp)
+                    at += k
+                return out
+
         data0 = {k: v for k, v in self._data.items() if k != "scratch__"}
         src = src + ("\n" + expand_src if expand_src else "")
         base = from_density_source(self._n_dim, src, data0, lds_doubles_per_chain=lds_per_chain, lds_doubles_shared=lds_shared if staged else 0,
                                    expand_lds_doubles=expand_lds if expand_src else 0,
                                    scratch_doubles_per_chain=scratch_per_chain if spilled_dims else 0,
-                                   expand_fn=expand, expanded_names=names, expanded_shapes=shapes, coords={**auto_coords, **(coords or {})},
-                                   dims={**auto_dims, **(dims or {})}, init=init, resident=resident, waves_per_chain=waves_per_chain,
-                                   reparameterized_names=raw_names)
+                                   expand_fn=expand_host, expanded_names=out_names, expanded_shapes=out_shapes,
+                                   coords={**(auto_coords if expanded_names is None else {}), **(coords or {})},
+                                   dims={**(auto_dims if expanded_names is None else {}), **(dims or {})}, init=init, resident=resident, waves_per_chain=waves_per_chain,
+                                   reparameterized_names=raw_names if expanded_names is None else None)
         import dataclasses
 
         return _symbolic_model_class()(**{f.name: getattr(base, f.name) for f in dataclasses.fields(base)}, _front=self)
