@@ -77,13 +77,41 @@ def from_raw_callback(n_dim: int, logp_address: int, user_data: int = 0, *, name
 def compile_pymc_model(model, *, backend="numba", gradient_backend="pytensor", initial_points=None, jitter_rvs=None,
                        default_initialization_strategy="support_point", var_names=None, freeze_model=None, **kwargs):
     """Same keyword signature as the reference (compile_pymc.py:523-537).  A :class:`nutpie_amd.symbolic.Model` — this package's own
-    model front-end — is compiled to its generated device density (``initial_points``: explicit start positions, ``[chains, n_dim]``);
-    a PyMC model needs PyMC and PyTensor, which the target image does not have."""
+    model front-end — is compiled to its generated device density, with the reference's initial points (support point + U(-1, 1)
+    jitter; ``initial_points`` a dict of per-variable values, or explicit start positions ``[chains, n_dim]``).  A callable is taken
+    as a batched torch log-density ``logp(x[chains, n_dim]) -> [chains]`` (``n_dim=`` required) and goes through the tracer
+    (:mod:`nutpie_amd.torch_trace`).  A PyMC model needs PyMC and PyTensor, which the target image does not have."""
     from nutpie_amd import symbolic
 
     if isinstance(model, symbolic.Model):
         extra = {k: kwargs[k] for k in ("resident", "waves_per_chain", "coords", "dims") if k in kwargs}
-        return model.compile(init="uniform" if initial_points is None else initial_points, **extra)
+        # the reference's initial points (compile_pymc.py:593-602): support point + U(-1, 1) jitter on `jitter_rvs` (default: every
+        # free variable); `initial_points` = {variable: constrained value} overrides a support point.  An array [chains, n_dim]
+        # is taken as explicit start positions; default_initialization_strategy="prior" has no counterpart (the front-end does not
+        # know a variable's prior as a distribution) and is refused.
+        if isinstance(initial_points, dict) or initial_points is None:
+            if default_initialization_strategy not in ("support_point", "moment"):
+                raise ValueError(f"default_initialization_strategy={default_initialization_strategy!r} is not supported (use 'support_point')")
+            jitter = None if jitter_rvs is None else {getattr(v, "name", v) for v in jitter_rvs}
+            init = model.jittered_init(initial_points, jitter)
+        else:
+            init = np.asarray(initial_points, dtype=np.float64)
+        return model.compile(init=init, **extra)
+    if callable(model) and not hasattr(model, "free_RVs"):
+        # a torch log-density (what PyTensor's mode="PYTORCH" linker emits for a model's logp): traced and compiled
+        from nutpie_amd.compiled_pyfunc import from_torch_density
+
+        if "n_dim" not in kwargs:
+            raise TypeError("compile_pymc_model(torch_logp, n_dim=...) needs the length of the unconstrained vector")
+        from nutpie_amd.density import JitteredInit
+
+        n_dim = int(kwargs.pop("n_dim"))
+        if initial_points is None or (isinstance(initial_points, np.ndarray) and initial_points.ndim == 1):
+            center = np.zeros(n_dim) if initial_points is None else np.asarray(initial_points, dtype=np.float64)
+            init = JitteredInit(center=center, jitter=np.ones(n_dim) if jitter_rvs is None else np.asarray(jitter_rvs, dtype=np.float64))
+        else:
+            init = np.asarray(initial_points, dtype=np.float64)
+        return from_torch_density(n_dim, model, compile=kwargs.pop("compile", True), init=init, **kwargs)
     if find_spec("pymc") is None:
         raise ImportError(
             "pymc is not installed in this environment.  Write the model with nutpie_amd.symbolic (expressions -> generated "

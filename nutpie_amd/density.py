@@ -248,6 +248,27 @@ class DeviceData:
         self.ptr = self.block.data_ptr()
 
 
+@dataclass(frozen=True)
+class JitteredInit:
+    """PyMC's initial points (the reference's default for PyMC models: ``make_initial_point_fn(default_strategy="support_point",
+    jitter_rvs=set(model.free_RVs))``, ``python/nutpie/compile_pymc.py:593-602``): every chain starts at the model's support point
+    on the unconstrained scale plus U(-1, 1) on every coordinate that belongs to a jittered variable.  ``center[D]``; ``jitter[D]``
+    = 1 where the coordinate is jittered.  The reference draws the jitter from a seed the chain's generator hands to
+    ``initial_point_fn`` (``src/pymc.rs:505-534``); here the stream is keyed by (seed, global chain id), so the points do not depend
+    on how the chains are sharded over GPUs."""
+
+    center: Any
+    jitter: Any
+
+    def points(self, seed: int, n_chains: int) -> np.ndarray:
+        c = np.asarray(self.center, dtype=np.float64).reshape(-1)
+        j = np.broadcast_to(np.asarray(self.jitter, dtype=np.float64), c.shape)
+        pts = np.empty((n_chains, c.size))
+        for chain in range(n_chains):
+            pts[chain] = c + j * np.random.default_rng([int(seed) & 0xFFFFFFFFFFFFFFFF, chain, 0x1417]).uniform(-1.0, 1.0, c.size)
+        return pts
+
+
 # --------------------------------------------------------------------------- the model front-end
 @dataclass(frozen=True)
 class DensitySourceModel(CompiledModel):
@@ -371,6 +392,10 @@ class DensitySourceModel(CompiledModel):
             model = _lib.NativeDeviceCallbackModel(self._n_dim, lib.logp_addr, C.addressof(batch), keep_alive=(lib, dd, batch))
         if isinstance(self._init, str):
             model.set_init(self._init)
+        elif isinstance(self._init, JitteredInit):
+            if settings is None:
+                raise ValueError("jittered initial points need the settings (seed, num_chains)")
+            model.set_init("explicit", self._init.points(int(settings.seed), int(settings.num_chains)))
         else:
             model.set_init("explicit", np.asarray(self._init, dtype=np.float64))
         if lib.expand_addr is not None:

@@ -1225,6 +1225,8 @@ class Model:
         self._det_dims: dict[str, tuple[str, ...]] = {}       # reported values on a product of two dimensions: the order of the axes in the trace
         self._products: dict[str, tuple[Dim, Dim, Index, Index]] = {}   # product dimension -> (rows, columns, index to rows, index to columns)
         self._unconstrained: dict[str, tuple[str, int, int]] = {}       # parameter -> (name of its unconstrained value, offset, free values)
+        self._transforms: dict[str, tuple] = {}      # parameter -> (kind, lower, upper, shape): what initial_point inverts
+        self._initvals: dict[str, Any] = {}          # parameter -> the constrained value its chains start around (PyMC's `initval`)
         self._staged = True
 
     # ---- declarations
@@ -1320,7 +1322,7 @@ class Model:
         return self._products[expr.dim.name]
 
     def param(self, name: str, dim: str | None = None, size: int | None = None, lower: float | None = None, upper: float | None = None,
-              zero_sum: bool = False, simplex: bool = False, dims: tuple[str, str] | None = None) -> Expr:
+              zero_sum: bool = False, simplex: bool = False, dims: tuple[str, str] | None = None, initval=None) -> Expr:
         """A free parameter.  Scalar, or a vector over ``dim``.  ``lower`` / ``upper``: PyMC's default transforms — ``lower + exp(raw)``,
         ``upper - exp(raw)``, or ``lower + (upper - lower) sigmoid(raw)`` with both — with the log-Jacobian added to the density;
         ``zero_sum``: the vector sums to zero (``size - 1`` free values, PyMC's isometric ZeroSumTransform — no Jacobian term);
@@ -1330,6 +1332,11 @@ class Model:
         COLUMN sums to zero along ``rows`` (``pmd.ZeroSumNormal(core_dims=(rows,), dims=(rows, cols))``: ``(rows - 1) x cols`` free values)."""
         if name in self._param_names:
             raise ValueError(f"parameter {name!r} is defined twice")
+        # ``initval``: the (constrained) value the chains start around — PyMC's support point of the variable; without one the
+        # unconstrained value 0 (the support point of a Normal(0, .), a ZeroSumNormal, a uniform Dirichlet, a HalfNormal(1) ...)
+        self._transforms[name] = ("zero_sum" if zero_sum else "simplex" if simplex else "bounds", lower, upper, dims)
+        if initval is not None:
+            self._initvals[name] = initval
         if dims is not None:
             return self._param_2d(name, dims, lower, upper, zero_sum, simplex)
         self._param_names.append(name)
@@ -1460,6 +1467,62 @@ class Model:
         pos[order] = np.arange(a.size, dtype=np.int32)
         data[name + "__pos"] = pos
         data[name + "__rows"] = rows
+
+    def unconstrain(self, name: str, value) -> np.ndarray:
+        """The unconstrained coordinates of a parameter at a constrained value (the forward direction of PyMC's transforms:
+        ``LogTransform``, ``IntervalTransform``, ``ZeroSumTransform.forward`` = ``extend_axis_rev``, ``SimplexTransform.forward``)."""
+        kind, lower, upper, dims = self._transforms[name]
+        _, off, n_free = self._unconstrained[name]
+        v = np.asarray(value, dtype=np.float64)
+        if kind == "zero_sum":
+            if dims is not None:
+                r, c = self._dims[dims[0]].size, self._dims[dims[1]].size
+                v = np.broadcast_to(v, (r, c))
+                norm = (-v[-1:] * math.sqrt(r)) / (math.sqrt(r) + r)           # per column (the zero-sum axis is `rows`)
+                return (v[:-1] + norm).reshape(-1)
+            n = n_free + 1
+            v = np.broadcast_to(v, (n,))
+            return v[:-1] + (-v[-1] * math.sqrt(n)) / (math.sqrt(n) + n)
+        if kind == "simplex":
+            v = np.broadcast_to(v, (n_free + 1,))
+            lv = np.log(v)
+            return lv[:-1] - lv.sum() / (n_free + 1)
+        v = np.broadcast_to(v, (n_free,)) if v.ndim <= 1 else v.reshape(-1)
+        if lower is None and upper is None:
+            return v.astype(np.float64)
+        with np.errstate(all="ignore"):       # (a value outside the support gives NaN: initial_point refuses it by name)
+            if upper is None:
+                return np.log(v - lower)
+            if lower is None:
+                return np.log(upper - v)
+            t = (v - lower) / (upper - lower)
+            return np.log(t) - np.log1p(-t)
+
+    def initial_point(self, overrides: dict[str, Any] | None = None) -> np.ndarray:
+        """The model's support point on the unconstrained scale: every parameter at its ``initval`` (``overrides`` first; PyMC's
+        ``initial_points`` / ``overrides`` of ``make_initial_point_fn``), 0 where none was given."""
+        x = np.zeros(self._n_dim)
+        vals = {**self._initvals, **(overrides or {})}
+        for name, value in vals.items():
+            if name not in self._unconstrained:
+                raise ValueError(f"initial point for an unknown parameter {name!r}")
+            _, off, n_free = self._unconstrained[name]
+            u = np.asarray(self.unconstrain(name, value), dtype=np.float64).reshape(-1)
+            if u.size != n_free or not np.all(np.isfinite(u)):
+                raise ValueError(f"the initial value of {name!r} does not lie inside its support")
+            x[off:off + n_free] = u
+        return x
+
+    def jittered_init(self, overrides: dict[str, Any] | None = None, jitter_rvs=None):
+        """PyMC's default initial points (reference compile_pymc.py:593-602): the support point plus U(-1, 1) on the unconstrained
+        coordinates of ``jitter_rvs`` (None: every parameter)."""
+        from nutpie_amd.density import JitteredInit
+
+        mask = np.zeros(self._n_dim)
+        for name, (_, off, n_free) in self._unconstrained.items():
+            if jitter_rvs is None or name in jitter_rvs:
+                mask[off:off + n_free] = 1.0
+        return JitteredInit(center=self.initial_point(overrides), jitter=mask)
 
     def add_logp(self, term) -> None:
         term = Expr.wrap(term)
@@ -1619,6 +1682,8 @@ class Model:
             gen = _Gen(self, logp, grads, waves_per_chain)
         self._spill(gen, waves_per_chain)
         src, _ = gen.source()
+        if isinstance(init, str) and init == "support_point":
+            init = self.jittered_init()
         return self._finish(src, gen, init=init, resident=resident, coords=coords, dims=dims, waves_per_chain=waves_per_chain,
                             expanded_names=expanded_names, expanded_shapes=expanded_shapes, expand_fn=expand_fn)
 

@@ -504,8 +504,17 @@ def _run(gm, it: _Interp, x_shape, data_values: dict[str, Any]):
             return type(a)(val(v) for v in a)
         return a
 
+    def to_host(v):
+        if isinstance(v, torch.Tensor):
+            return v.detach().cpu()
+        if isinstance(v, (list, tuple)):
+            return type(v)(to_host(t) for t in v)
+        return v
+
     def const_call(node, args, kwargs):
-        return node.target(*args, **kwargs)
+        # (constants live on the host whatever device the function was traced on)
+        kwargs = {k: (torch.device("cpu") if k == "device" else v) for k, v in kwargs.items()}
+        return to_host(node.target(*args, **kwargs))
 
     def any_traced(v) -> bool:
         if isinstance(v, (list, tuple)):
@@ -532,7 +541,7 @@ def _run(gm, it: _Interp, x_shape, data_values: dict[str, Any]):
             continue
         if node.op == "get_attr":
             t = getattr(gm, node.target)
-            env[node] = t.detach() if isinstance(t, torch.Tensor) else t
+            env[node] = to_host(t)
             continue
         if node.op == "output":
             out = val(node.args[0])
@@ -839,12 +848,25 @@ def trace(logp_fn: Callable, n_dim: int, *, batched: bool = True, shared_data: d
 
     validate = Distribution._validate_args
     Distribution.set_default_validate_args(False)
-    try:
+    def run_make_fx(device):
         with torch.no_grad():
-            gm = make_fx(fn)(example, *[tens[k] for k in names])
+            return make_fx(fn)(example.to(device), *[tens[k].to(device) for k in names])
+
+    try:
+        try:
+            gm = run_make_fx("cpu")
+        except RuntimeError as e:
+            # the function closes over tensors that live on the GPU (what the eager path needs): trace there, the constants of
+            # the trace are brought to the host below
+            if "same device" in str(e) and torch.cuda.is_available():
+                gm = run_make_fx("cuda")
+            else:
+                raise
     except RuntimeError as e:
         if "tracing tensor" in str(e) or "data-dependent" in str(e):
             raise UnsupportedTorchOp("Python control flow on the values of x (" + str(e).split(" - ")[0][-60:] + ")") from e
+        if "same device" in str(e):
+            raise UnsupportedTorchOp("the function mixes tensors of several devices and no GPU is here to trace it on") from e
         raise
     finally:
         Distribution.set_default_validate_args(validate)

@@ -164,6 +164,12 @@ def lib():
     return _lib
 
 
+def set_variant(min_refresh: int = 3, search_mode: int = 2, late_sym: int = 1, last_bar: int = 1, floor_windows: int = 0) -> None:
+    """Experiment knobs of the sensitivity study (nuts_oracle.h: oracle_set_variant); the defaults are the restatement the parity
+    tests run.  Process-global: reset with ``set_variant()``."""
+    lib().oracle_set_variant(int(min_refresh), int(search_mode), int(late_sym), int(last_bar), int(floor_windows))
+
+
 def default_settings(**kw) -> Settings:
     s = Settings()
     lib().oracle_default_settings(C.byref(s))

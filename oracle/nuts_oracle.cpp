@@ -375,6 +375,18 @@ struct SumMean {
     }
     double value() const { return running ? total : (count ? total / (double)count : 0.0); }
 };
+// ---- experiment knobs (oracle_set_variant): which of the RECALLED details of nuts-rs' warm-up the oracle follows.  The defaults are
+// the restatement every parity test runs; the other values exist for the sensitivity study of the reference-held evidence
+// (scratch/r5_reference_sensitivity.py, profiles/r5_reference_sensitivity.txt) and are never set by a test of the engine.
+struct Variant {
+    int min_refresh = 3;     // draws the foreground estimator needs before a mass-matrix refresh reads it
+    int search_mode = 2;     // initial step-size search: 0 never, 1 at the initial point only, 2 also after the first data-driven mass matrix
+    int late_sym = 1;        // the symmetric acceptance statistic drives dual averaging once no estimator switch can follow (and in the final window)
+    int last_bar = 1;        // the last tuning draw sets step_size = step_size_bar
+    int floor_windows = 0;   // window bounds as (frac * T) truncated instead of ceil
+};
+static Variant g_variant;
+
 struct Collector {
     SumMean mean, mean_sym;
     void set_running(bool r) { mean.running = r; mean_sym.running = r; }
@@ -785,6 +797,11 @@ struct Chain {
         early_end = (uint64_t)std::ceil((double)S.num_tune * S.early_window);
         uint64_t ssw = (uint64_t)std::ceil((double)S.num_tune * S.step_size_window);
         final_window = (S.num_tune > ssw ? S.num_tune - ssw : 0) + 1;
+        if (g_variant.floor_windows) {
+            early_end = (uint64_t)((double)S.num_tune * S.early_window);
+            ssw = (uint64_t)((double)S.num_tune * S.step_size_window);
+            final_window = S.num_tune > ssw ? S.num_tune - ssw : 0;
+        }
     }
 
     // Model::init_position: src/pyfunc.rs:540-544 (U(-2,2)), src/stan.rs:798-808 (N(0,1))
@@ -851,7 +868,7 @@ struct Chain {
     // mass-matrix refresh from the foreground estimator [A.9];
     // formulas corroborated in-tree by python/nutpie/normalizing_flow.py:1906-1915.
     bool update_mass_matrix() {
-        if (fg_q.count < 3) return false;
+        if (fg_q.count < (uint64_t)g_variant.min_refresh) return false;
         const size_t n = model->dim;
         if (S.use_grad_based_mass_matrix) {
             for (size_t i = 0; i < n; ++i) {
@@ -895,6 +912,7 @@ struct Chain {
                 H.sig2[i] = std::isfinite(val) ? val : 1.0;
             }
         }
+        if (g_variant.search_mode == 0) { H.step_size = S.initial_step; da.init(S.initial_step, S.da_k, S.da_t0, S.da_gamma); return true; }
         return step_size_search(0xffffffffu);
     }
 
@@ -923,9 +941,9 @@ struct Chain {
                 if (force_update || (draw - last_update >= S.mass_matrix_update_freq)) did_change = update_mass_matrix();
                 if (did_change) last_update = draw;
             }
-            if (is_late) da.advance(last_accept_sym, S.target_accept);
+            if (is_late && g_variant.late_sym) da.advance(last_accept_sym, S.target_accept);
             else da.advance(last_accept, S.target_accept);
-            if (did_change && has_initial_mm) {
+            if (did_change && has_initial_mm && g_variant.search_mode == 2) {
                 has_initial_mm = false;
                 if (!step_size_search((uint32_t)draw)) return false;
             } else {
@@ -933,8 +951,8 @@ struct Chain {
             }
             return true;
         }
-        da.advance(last_accept_sym, S.target_accept);
-        update_stepsize((uint32_t)draw, draw == S.num_tune - 1);
+        da.advance(g_variant.late_sym ? last_accept_sym : last_accept, S.target_accept);
+        update_stepsize((uint32_t)draw, g_variant.last_bar && draw == S.num_tune - 1);
         return true;
     }
 
@@ -1110,6 +1128,11 @@ int oracle_sample_callback(const oracle_settings_t* s, uint64_t dim, oracle_logp
         return std::unique_ptr<Model>(std::move(m));
     };
     return run_sampler(s, dim, mk, init_points, out, seconds);
+}
+
+void oracle_set_variant(int min_refresh, int search_mode, int late_sym, int last_bar, int floor_windows) {
+    g_variant.min_refresh = min_refresh; g_variant.search_mode = search_mode; g_variant.late_sym = late_sym;
+    g_variant.last_bar = last_bar; g_variant.floor_windows = floor_windows;
 }
 
 const char* oracle_last_error(void) { return g_last_error.c_str(); }

@@ -4,7 +4,7 @@
  * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only
  * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
  *
- * PARITY UNPINNED: the algorithm this file restates lives in the crates.io
+ * PARITY UNPINNED value for value (statistical pins on reference-held outputs: item 10 below): the algorithm this file restates lives in the crates.io
  * dependency `nuts-rs 0.18.3` (reference Cargo.toml:24, Cargo.lock:2295-2298),
  * whose source is not in /root/reference and cannot be built here (no Rust
  * toolchain, no network).  The oracle follows SURVEY.md Appendix A (a restatement
@@ -45,6 +45,24 @@
  *  8. RNG: Philox4x32-10 counter streams keyed by (seed, global chain, draw, purpose) and Box-Muller normals instead of the
  *     crate's ChaCha8 + ziggurat; summation in the engine's fixed order (`waves_per_chain`).  By construction, not by
  *     evidence: the crate's stream cannot be reproduced without the crate.
+ * 10. WHAT THE REFERENCE-HELD NUMBERS SAY ABOUT ALL THIS (round 5; scratch/r5_reference_sensitivity.py -> profiles/r5_reference_sensitivity.txt,
+ *     asserted by tests/test_oracle_reference_pins.py and, for the engine, tests/test_gpu_reference_fixtures.py).  Value-for-value
+ *     parity stays unpinned (the crate's RNG stream), but two bodies of evidence in the reference's tree are outputs of nuts-rs:
+ *     (a) the FINAL step sizes and last-draw gradient counts of 36 chains in the frozen docs (docs/_freeze; three analytic models,
+ *         default settings; tests/golden/reference_doc_step_sizes.json).  The restatement reproduces them: z = +0.7 / +0.5 / +0.1 for the
+ *         three models' means (KS p 0.36 / 0.42 / 0.90), the same non-power-of-two gradient counts (9, 11, 13, 19, 27: a doubling
+ *         stops inside the sub-tree that turns) with the same mean.  These numbers REJECT: plain instead of symmetric acceptance
+ *         in the late windows (z = +4.7), target_accept 0.75 / 0.85 (z = -10 / +13), dual-averaging gamma 0.1 (z = -7), the last
+ *         tuning draw keeping its step instead of step_size_bar (spread x 8).  They cannot tell apart: early_window 0.3 / 0.5,
+ *         step_size_window 0.10 / 0.15, switch frequencies 10 / 20 and 80 / 50, a refresh from 1 / 3 / 10 draws (departure 3), when
+ *         the step-size search runs (departure 6), truncated window bounds (departure 2), t0, k.
+ *     (b) the HalfNormal files.  Stan flavour (2 x 10 draws): every statistic between ranks 0.29 and 0.78 of 2000 runs of its shape.
+ *         PyMC flavour (2 x 100 draws): lag-1 autocorrelation 0.993, repeat fraction 0.04, deepest excursion (min log a = -8.1)
+ *         0.017 — inside the 0.5 - 99.5 % band —, but pooled mean 0.560 and median 0.375 at rank 0.0015, and NO variant of the
+ *         recalled constants above, nor PyMC's initial points instead of U(-2, 2), moves them (0.0000 - 0.0065 across the 17
+ *         variants); conditional on an excursion as deep as the file's (1.8 % of runs) they stay at 0.000 - 0.003.  The file spends
+ *         half of its 200 draws below a = 0.375 in three separate excursions to the left tail; this sampler's runs of that shape do
+ *         not.  OPEN: either a 1-in-500 realisation or a difference that none of the recalled knobs expresses.
  *  9. `step_size_adapt_method = "adam"` (Adam on log step size, src/wrapper.rs:344-376): beta1 0.9, beta2 0.999, eps 1e-8 are
  *     the textbook constants; the crate's are unknown.  SURVEY §2 marks the option out of scope; it is kept only because
  *     the settings surface accepts the value.
@@ -163,6 +181,10 @@ int oracle_sample_callback(const oracle_settings_t* s, uint64_t dim, oracle_logp
                            const double* init_points, oracle_trace_t* out, double* seconds);
 
 const char* oracle_last_error(void);
+
+/* Experiment knobs for the sensitivity study of the reference-held evidence (scratch/r5_reference_sensitivity.py): which of the
+ * recalled details of the crate's warm-up the oracle follows.  Defaults (3, 2, 1, 1, 0) = the restatement every parity test runs. */
+void oracle_set_variant(int min_refresh, int search_mode, int late_sym, int last_bar, int floor_windows);
 
 /* ---- unit-level entry points for known-answer tests ---- */
 void oracle_philox(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t out[4]);

@@ -1,0 +1,42 @@
+"""Extracts the reference-held sampler outputs of the reference's FROZEN documentation (``/root/reference/docs/_freeze/*/
+execute-results/html.json``: the executed cells of docs/index.qmd, stan-usage.qmd, pymc-usage.qmd) into a small fixture.
+
+The docs run ``nutpie.sample(compiled)`` with default settings (6 chains, tune 400, draws 1000) and the rendered progress table
+shows, per chain, the FINAL step size and the gradient evaluations of the last draw.  The models are tiny and analytic, so the
+numbers can be compared with ensembles of this repository's sampler: they are the only outputs of nuts-rs itself in the
+reference's tree besides the three HalfNormal files under tests/reference/.
+
+Run in the build container (reads /root/reference; the GPU box has no such directory):
+    python tests/golden/make_reference_doc_step_sizes.py
+"""
+import json
+import os
+import re
+
+DOCS = "/root/reference/docs"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_doc_step_sizes.json")
+
+
+def tables(doc):
+    md = json.load(open(f"{DOCS}/_freeze/{doc}/execute-results/html.json"))["result"]["markdown"]
+    out = []
+    for body in re.findall(r'<tbody id="chain-details">(.*?)</tbody>', md, re.S):
+        rows = re.findall(r"<td>(\d+)</td>\s*<td>(\d+)</td>\s*<td>([\d.]+)</td>\s*<td>(\d+)</td>", body)
+        out.append([{"draws": int(a), "divergences": int(b), "step_size": float(c), "gradients_last_draw": int(d)} for a, b, c, d in rows])
+    return out
+
+
+idx, stan, pymc = tables("index"), tables("stan-usage"), tables("pymc-usage")
+fixture = {
+    "_source": "docs/_freeze/{index,stan-usage,pymc-usage}/execute-results/html.json of the reference (progress tables of the executed cells)",
+    "_settings": "nutpie.sample(compiled): 6 chains, tune 400, draws 1000, every other setting default",
+    # mu ~ N(0, 1); obs ~ N(mu, 1), observed [1, 2, 3]   (docs/index.qmd:39-46 through PyMC, :66-91 and docs/stan-usage.qmd:57-84 through Stan)
+    "normal_1d": {"posterior": "N(1.5, 1/4)", "runs": [idx[0], idx[1], stan[0]], "cites": ["docs/index.qmd:39-46", "docs/index.qmd:66-91", "docs/stan-usage.qmd:57-84"]},
+    # intercept, slope ~ N(0, 1); y ~ N(intercept + slope * x, 0.1), x = [1, 2, 3], observed [1, 2, 3]   (docs/pymc-usage.qmd:53-79 and :173-187)
+    "regression_x123": {"posterior": "precision [[301, 600], [600, 1401]], X'y / sigma^2 = [600, 1400]", "runs": [pymc[0], pymc[1]],
+                        "cites": ["docs/pymc-usage.qmd:53-79", "docs/pymc-usage.qmd:173-187"]},
+    # the same model after with_data(x=[4, 5, 6])   (docs/pymc-usage.qmd:191-194)
+    "regression_x456": {"posterior": "precision [[301, 1500], [1500, 7701]], X'y / sigma^2 = [600, 3200]", "runs": [pymc[2]], "cites": ["docs/pymc-usage.qmd:191-194"]},
+}
+json.dump(fixture, open(OUT, "w"), indent=1)
+print(OUT, {k: [len(r) for r in v["runs"]] for k, v in fixture.items() if not k.startswith("_")})

@@ -182,9 +182,15 @@ def test_autograd_logp_wrapper():
     lp, g = f(x)
     assert torch.allclose(lp, -0.5 * ((x / scale) ** 2).sum(-1)) and torch.allclose(g, -x / scale**2)
     assert not lp.requires_grad and not g.requires_grad
-    m = from_torch_density(3, lambda x, s: -0.5 * ((x / s) ** 2).sum(-1), shared_data={"s": scale})
+    m = from_torch_density(3, lambda x, s: -0.5 * ((x / s) ** 2).sum(-1), shared_data={"s": scale}, compile=False)
     lp2, g2 = m._make_logp_func()(x, **m._shared_data)
     assert torch.equal(lp2, lp) and torch.equal(g2, g) and m.n_dim == 3
+    # the default ("auto") traces the function and compiles it into the engine instead (tests/test_torch_trace_cpu.py)
+    mc = from_torch_density(3, lambda x, s: -0.5 * ((x / s) ** 2).sum(-1), shared_data={"s": scale})
+    assert type(mc).__name__ == "TracedTorchModel" and mc.n_dim == 3
+    lp3, g3 = mc.logp_and_grad_numpy(x.numpy())
+    np.testing.assert_allclose(lp3, lp.numpy(), rtol=1e-13)
+    np.testing.assert_allclose(g3, g.numpy(), rtol=1e-13)
 
 
 def test_arviz_conversion_follows_the_installed_version(monkeypatch):

@@ -1,0 +1,90 @@
+"""The oracle against numbers nuts-rs itself produced and the reference's tree holds (CPU; the engine's counterpart — the same
+comparison on the GPU, engine == oracle bit for bit — is tests/test_gpu_reference_fixtures.py).
+
+A. ``tests/golden/reference_doc_step_sizes.json`` — the FINAL step sizes of 36 chains in the reference's frozen documentation
+   (docs/_freeze, extracted by tests/golden/make_reference_doc_step_sizes.py): three analytic models under default settings.  They
+   pin what the step size converges to: the acceptance statistic (A.6), dual averaging and its constants (A.7), the symmetric
+   statistic in the late windows and ``step_size_bar`` on the last tuning draw (A.8) — profiles/r5_reference_sensitivity.txt shows
+   which recalled details these numbers can tell apart (plain acceptance late: z = +4.7; target 0.75 / 0.85: z = -10 / +13;
+   dual-averaging gamma 0.1: z = -7; the last draw keeping its step: spread x 8) and which they cannot (window lengths, switch
+   frequencies, the minimum count of a refresh, when the step-size search runs).
+B. ``tests/golden/reference_halfnormal_stan.txt`` (2 x 10 draws, N(0, 1) initial points) ranked inside an ensemble of runs of its shape.
+"""
+import ctypes
+import json
+import os
+
+import numpy as np
+import pytest
+from scipy import stats
+
+from tests.conftest import FIXTURES, GOLDEN
+
+DOC = json.load(open(os.path.join(GOLDEN, "reference_doc_step_sizes.json")))
+
+
+def gaussian(name):
+    """(diag, offdiag, mean) of the model's posterior precision — tridiagonal, so the oracle's analytic model covers it"""
+    if name == "normal_1d":                                   # mu ~ N(0, 1), y = [1, 2, 3] ~ N(mu, 1): posterior N(1.5, 1/4)
+        return np.array([4.0]), None, np.array([1.5])
+    x = np.array([1.0, 2.0, 3.0]) if name == "regression_x123" else np.array([4.0, 5.0, 6.0])
+    X = np.stack([np.ones(3), x], 1)                          # intercept, slope ~ N(0, 1); y = [1, 2, 3] ~ N(X b, 0.1)
+    P = np.eye(2) + X.T @ X / 0.01
+    return np.diag(P).copy(), np.array([P[0, 1]]), np.linalg.solve(P, X.T @ np.array([1.0, 2.0, 3.0]) / 0.01)
+
+
+def doc_values(name, key):
+    return np.array([row[key] for run in DOC[name]["runs"] for row in run], dtype=np.float64)
+
+
+@pytest.mark.parametrize("name", ["normal_1d", "regression_x123", "regression_x456"])
+def test_final_step_sizes_of_the_reference_docs(oracle, name):
+    diag, off, mu = gaussian(name)
+    n = 1000
+    s = oracle.default_settings(seed=11, num_chains=n, num_tune=400, num_draws=20, n_threads=8, init_kind=2)
+    pts = np.random.default_rng(5).uniform(-1, 1, size=(n, len(diag)))          # PyMC: support point 0 + U(-1, 1)
+    tr = oracle.sample_tridiag(s, diag, off, mu=mu, init_points=pts)
+    ours = tr.stats["step_size"][:, 400]                                        # the step size sampling runs with
+    assert np.array_equal(ours, tr.stats["step_size"][:, 401]) and not tr.stats["diverging"][:, 400:].any()
+    ref = doc_values(name, "step_size")
+    z = (ref.mean() - ours.mean()) / (ours.std() / np.sqrt(len(ref)))
+    print(f"{name}: reference {ref.mean():.3f} +- {ref.std(ddof=1):.3f} (n = {len(ref)}), oracle {ours.mean():.3f} +- {ours.std():.3f}, z = {z:+.2f}")
+    assert abs(z) < 3.0
+    assert stats.ks_2samp(ref, ours).pvalue > 0.01
+    lo, hi = np.percentile(ours, [0.1, 99.9])
+    assert np.all((ref > lo - 0.005) & (ref < hi + 0.005))                      # (the docs print two decimals)
+    # gradient evaluations of the chain's last draw.  The reference's counts are not all 2^depth - 1 (9, 11, 13, 19, 27 appear): a
+    # doubling whose new half meets a U-turn in one of its sub-trees stops building there (`extend` returns at the first
+    # turning sub-tree) — the restatement produces the same counts, with the same mean
+    g_ref = doc_values(name, "gradients_last_draw")
+    g = tr.stats["n_steps"][:, 400:].ravel()
+    support = set(np.unique(g).tolist())
+    assert set(g_ref.astype(int).tolist()) <= support, (sorted(set(g_ref.astype(int).tolist()) - support), sorted(support))
+    zg = (g_ref.mean() - g.mean()) / (g.std() / np.sqrt(len(g_ref)))
+    print(f"   gradients in a sampling draw: reference mean {g_ref.mean():.2f}, oracle {g.mean():.2f} (z = {zg:+.2f}); oracle support {sorted(support)}")
+    assert abs(zg) < 3.0
+    assert stats.binomtest(int(np.sum(g_ref == 1)), len(g_ref), float(np.mean(g == 1))).pvalue > 0.01
+
+
+def run_shape_stats(a):
+    """statistics of one run a[2 chains, n draws]"""
+    l = np.log(a)
+    lc = l - l.mean(1, keepdims=True)
+    return {"pooled_mean": a.mean(), "median": np.median(a), "lag1_log": float((lc[:, 1:] * lc[:, :-1]).sum() / max((lc * lc).sum(), 1e-300)),
+            "repeat_fraction": np.mean(a[:, 1:] == a[:, :-1]), "min_log": l.min(), "max": a.max()}
+
+
+def test_stan_halfnormal_fixture_lies_in_the_bulk_of_the_ensemble(oracle):
+    """tests/test_stan.py:282-302 returns the first 10 draws of 2 chains (seed 123, tune 100, N(0, 1) initial points): 2000 runs of
+    that shape; every statistic of the reference's 20 values inside the 0.5 - 99.5 % band."""
+    fix = ctypes.CDLL(os.path.join(FIXTURES, "libbs_standin.so"))
+    R = 2000
+    s = oracle.default_settings(seed=123, num_chains=2 * R, num_tune=100, num_draws=10, n_threads=8, init_kind=1)
+    tr = oracle.sample_callback(s, 1, ctypes.cast(fix.halfnormal_logp, ctypes.c_void_p).value)
+    a = np.exp(tr.draws[:, 100:, 0]).reshape(R, 2, 10)
+    ens = [run_shape_stats(a[r]) for r in range(R)]
+    ref = run_shape_stats(np.loadtxt(os.path.join(GOLDEN, "reference_halfnormal_stan.txt")).reshape(2, 10))
+    ranks = {k: float(np.mean(np.array([e[k] for e in ens]) < v)) for k, v in ref.items()}
+    print("ranks of the Stan fixture:", {k: round(v, 3) for k, v in ranks.items()})
+    for k, r in ranks.items():
+        assert 0.005 <= r <= 0.995, (k, r)

@@ -279,3 +279,43 @@ def test_expression_table_does_not_outlive_its_models():
     del m, _
     gc.collect()
     assert len(S.Expr._table) < before
+
+
+def test_initial_points_follow_pymc_support_point_plus_jitter():
+    """reference compile_pymc.py:593-602: ``make_initial_point_fn(default_strategy="support_point", jitter_rvs=set(model.free_RVs))`` —
+    the support point on the unconstrained scale plus U(-1, 1); ``initial_points`` overrides per variable; the transforms' forward
+    directions are PyMC's (log, interval, ZeroSumTransform, SimplexTransform)."""
+    import nutpie_amd
+    from nutpie_amd import symbolic as S
+    from nutpie_amd.density import JitteredInit
+
+    m = S.Model()
+    a = m.param("a", lower=0.0, initval=2.0)
+    b = m.param("b", dim="k", size=4, simplex=True, initval=[0.1, 0.2, 0.3, 0.4])
+    c = m.param("c", dim="j", size=3, zero_sum=True, initval=[1.0, -3.0, 2.0])
+    d = m.param("d", lower=-1.0, upper=3.0)
+    e = m.param("e", dims=("j", "k"), zero_sum=True)
+    m.add_logp(-a + S.log(b).sum() - (c * c).sum() - d * d - (e * e).sum())
+    x0 = m.initial_point()
+    assert x0.shape == (m.n_dim,) == (1 + 3 + 2 + 1 + 8,)
+    cm = m.compile(init="support_point")
+    assert isinstance(cm._init, JitteredInit)
+    back = cm._expand_draws(x0[None, None, :])                      # constrain(unconstrain(initval)) == initval
+    np.testing.assert_allclose(back["a"], [[2.0]], rtol=1e-14)
+    np.testing.assert_allclose(back["b"][0, 0], [0.1, 0.2, 0.3, 0.4], rtol=1e-13)
+    np.testing.assert_allclose(back["c"][0, 0], [1.0, -3.0, 2.0], rtol=1e-13, atol=1e-14)
+    np.testing.assert_allclose(back["d"], [[1.0]], atol=1e-14)      # no initval: unconstrained 0 = the middle of the interval
+    assert np.all(back["e"] == 0)
+    pts = cm._init.points(seed=7, n_chains=64)
+    assert pts.shape == (64, m.n_dim) and np.all(np.abs(pts - x0) <= 1.0) and np.abs(pts - x0).max() > 0.9
+    np.testing.assert_array_equal(pts[:8], cm._init.points(seed=7, n_chains=8))         # a chain's point does not depend on the number of chains
+    assert not np.array_equal(pts, cm._init.points(seed=8, n_chains=64))
+    # compile_pymc_model: the reference's keywords
+    cm2 = nutpie_amd.compile_pymc_model(m, initial_points={"d": 2.5}, jitter_rvs={"a", "d"})
+    _, off_d, _ = m._unconstrained["d"]
+    assert abs(cm2._init.center[off_d] - np.log(3.5 / 0.5)) < 1e-14
+    assert cm2._init.jitter.sum() == 2.0 and cm2._init.jitter[0] == 1.0 and cm2._init.jitter[off_d] == 1.0
+    with pytest.raises(ValueError, match="inside its support"):
+        m.initial_point({"a": -1.0})
+    with pytest.raises(ValueError, match="not supported"):
+        nutpie_amd.compile_pymc_model(m, default_initialization_strategy="prior")
