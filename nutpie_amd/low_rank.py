@@ -33,10 +33,75 @@ from dataclasses import dataclass
 
 import numpy as np
 
-K_MAX = 16            # columns kept per chain (the reference has no such knob; windows of <= 64 draws span <= 128 directions)
-WINDOW_MAX = 64       # draws (and gradients) per estimate
+K_MAX = 16            # columns kept per chain (the reference has no such knob)
+BASIS_DRAWS = 32      # draws (thinned evenly from the window) that span the subspace of the low-rank part: with their gradients 64
+                      # directions, the order of the eigenproblems (the engine's own batched solver); the DIAGONAL part uses every draw
+WINDOW_MAX = 256      # draws of a foreground window that are read at all (the most recent ones)
+MIN_WINDOW = 12       # a window shorter than this says too little: no hand-in
+SETTLE = 4            # draws after a hand-in that are not used (the chain re-runs its step-size search there)
 HOLD_LAUNCHES = 3     # looks (a launch, or a few ms of launches) a stopped chain waits for company before it is handed in on its own
-SWITCH_FRACTIONS = (0.08, 0.2, 0.4, 0.65)   # of num_tune: window boundaries; the last leaves 35 % of warm-up to the step size
+MAX_HAND_INS = 15     # pause draws the engine holds (engine_types.h: pause_draws[16])
+
+
+def window_schedule(num_tune: int, early_window: float = 0.3, step_size_window: float = 0.15, switch_freq: int = 80, early_switch_freq: int = 10,
+                    update_freq: int = 10):
+    """The reference's warm-up windows for ``LowRank`` settings — the SAME foreground / background schedule as ``diag``
+    (``src/wrapper.rs:198-240``: ``window_switch_freq`` / ``mass_matrix_switch_freq``, ``early_window_switch_freq`` are set on Diag AND
+    LowRank settings; nuts-rs' ``GlobalStrategy::adapt``, SURVEY App. A.8): the background estimator becomes the foreground one every
+    ``early_switch_freq`` draws during the first ``early_window`` of warm-up and every ``switch_freq`` draws afterwards, as long as a
+    whole background window still fits before the final step-size window; the metric is refreshed from the foreground — the draws
+    since the SECOND-LAST switch — every ``update_freq`` draws (10 for low-rank settings, recalled) and stays fixed for the last
+    ``step_size_window`` of warm-up.
+
+    Returns ``[(pause, start)]``: the chain stops after ``pause`` finished draws and its metric is estimated from ``draws[start:pause]``.
+    What differs from the reference, and why: (1) a hand-in stops the chain until the host has estimated (an engine launch or two),
+    so the refreshes are THINNED — during the early windows the engine's own diagonal adaptation runs (same windows, on the device,
+    free) and the first low-rank metric is handed in at the first switch of the main phase, i.e. from a window that starts after
+    the early phase and after the step size has settled; from there every switch, refreshes no closer than ``switch_freq / 2`` draws,
+    and the last refresh before the final window — at most MAX_HAND_INS; (2) the draws right after a hand-in (SETTLE) are not used."""
+    T = int(num_tune)
+    early_end = int(np.ceil(T * early_window))
+    final = max(0, T - int(np.ceil(T * step_size_window))) + 1          # the engine's bound: draws d < final adapt the metric
+    final = min(final, T)
+    switches, bg = [], 1                                                 # (the estimators see the initial point)
+    for d in range(final):
+        freq = early_switch_freq if d < early_end else switch_freq
+        bg += 1
+        if bg >= freq and not (freq + d > final):
+            switches.append(d + 1)
+            bg = 0
+    late = [c for c in switches if c > early_end]
+    out, last = [], None
+
+    def window_start(p):
+        before = [c for c in switches if c <= p]
+        return before[-2] if len(before) >= 2 else 0
+
+    cands = sorted(set(late) | {c for c in range(update_freq, final, update_freq) if late and c > late[0]} | ({final - 1} if final - 1 > early_end else set()))
+    for p in cands:
+        if p <= 0 or p >= T:
+            continue
+        start = window_start(p)
+        if last is not None and last <= start < last + SETTLE:
+            start = min(last + SETTLE, p - MIN_WINDOW)      # (a window that begins right at a hand-in skips the draws of its step-size search)
+        if p - start < MIN_WINDOW:
+            continue
+        is_switch, is_last = p in late, p == cands[-1]
+        if last is not None and not is_switch and not is_last and p - last < max(switch_freq // 2, update_freq):
+            continue
+        if is_last and last is not None and p - last < update_freq:
+            continue
+        out.append((p, start))
+        last = p
+    if len(out) > MAX_HAND_INS:
+        keep = np.unique(np.round(np.linspace(0, len(out) - 1, MAX_HAND_INS)).astype(int))
+        out = [out[i] for i in keep]
+    if not out and T >= 2 * MIN_WINDOW:
+        # a warm-up too short for a main-phase switch: one hand-in before the final window, from everything after the early phase
+        p = max(MIN_WINDOW, final - 1)
+        if p < T:
+            out = [(p, max(0, min(early_end, p - MIN_WINDOW)))]
+    return out
 
 
 @dataclass
@@ -107,13 +172,14 @@ def _eigh_psd(A):
     return torch.linalg.eigh(A)
 
 
-def estimate(x, gx, gamma: float, cutoff: float, k_max: int = K_MAX) -> Transform:
+def estimate(x, gx, gamma: float, cutoff: float, k_max: int = K_MAX, basis_draws: int | None = None) -> Transform:
     """The low-rank metric of every chain from its window: ``x``, ``gx``: [n, m, D] draws and gradients in model space.
 
-    scaling      s_i = sqrt(std(x_i) / std(g_i))                       (the diagonal "diag" adaptation uses the same ratio,
+    scaling      s_i = sqrt(std(x_i) / std(g_i)) over ALL m draws        (the diagonal "diag" adaptation uses the same ratio,
                                                                         python/nutpie/normalizing_flow.py:1906-1915)
-    subspace     orthonormal Q of span{scaled draws, scaled gradients}  (eigh of the 2m x 2m Gram matrix)
-    projected    Cx = Px'Px / m + gamma I,  Cg = Pg'Pg / m + gamma I
+    subspace     orthonormal Q of span{scaled draws, scaled gradients} of ``basis_draws`` draws thinned evenly from the window
+                 (None: all of them) — eigh of the 2b x 2b Gram matrix; the whole space when 2b >= D
+    projected    Cx = Px'Px / b + gamma I,  Cg = Pg'Pg / b + gamma I
     metric       S = Cx # Cg^-1 (geometric mean: S Cg S = Cx), eigh(S) -> the k_max eigenvalues furthest from 1 in log scale
                  among those outside [1/cutoff, cutoff]; V = Q W
     """
@@ -128,17 +194,36 @@ def estimate(x, gx, gamma: float, cutoff: float, k_max: int = K_MAX) -> Transfor
     sg = gx.std(1, unbiased=True)
     stds = torch.sqrt(sx / sg)
     stds = torch.where(torch.isfinite(stds) & (stds > 0), stds, torch.ones_like(stds)).clamp(1e-10, 1e10)
+    gmean = gx.mean(1, keepdim=True)
+    if basis_draws is not None and m > basis_draws:
+        pick = torch.as_tensor(np.unique(np.round(np.linspace(0, m - 1, basis_draws)).astype(np.int64)), device=x.device)
+        x, gx = x.index_select(1, pick), gx.index_select(1, pick)
+        m = int(pick.numel())
     X = (x - mean[:, None, :]) / stds[:, None, :]
-    G = (gx - gx.mean(1, keepdim=True)) * stds[:, None, :]
-    Z = torch.cat([X, G], 1)                                   # [n, 2m, D]
-    ev, U = _eigh_psd(Z @ Z.transpose(1, 2))           # [n, 2m], [n, 2m, 2m]
-    keep = ev > (1e-10 * ev[:, -1:].clamp_min(1e-300))
-    scale = torch.where(keep, ev.clamp_min(1e-300).rsqrt(), torch.zeros_like(ev))
-    Q = Z.transpose(1, 2) @ (U * scale[:, None, :])            # [n, D, 2m], orthonormal columns (zero where dropped)
-    Px, Pg = X @ Q, G @ Q                                      # [n, m, 2m]
-    eye = torch.eye(2 * m, dtype=x.dtype, device=x.device)
+    G = (gx - gmean) * stds[:, None, :]
+    if 2 * m >= D:
+        # the window spans the whole space: work in it directly (Q = I)
+        r = D
+        Q = None
+        Px, Pg = X, G
+        keep = torch.ones(n, r, dtype=torch.bool, device=x.device)
+    else:
+        r = 2 * m
+        Z = torch.cat([X, G], 1)                                   # [n, 2m, D]
+        ev, U = _eigh_psd(Z @ Z.transpose(1, 2))                   # [n, 2m], [n, 2m, 2m]
+        keep = ev > (1e-10 * ev[:, -1:].clamp_min(1e-300))
+        scale = torch.where(keep, ev.clamp_min(1e-300).rsqrt(), torch.zeros_like(ev))
+        Q = Z.transpose(1, 2) @ (U * scale[:, None, :])            # [n, D, 2m], orthonormal columns (zero where dropped)
+        Px, Pg = X @ Q, G @ Q                                      # [n, m, 2m]
+    eye = torch.eye(r, dtype=x.dtype, device=x.device)
     Cx = Px.transpose(1, 2) @ Px / m + gamma * eye
     Cg = Pg.transpose(1, 2) @ Pg / m + gamma * eye
+    # a Gram matrix that overflowed (large finite draws) says as little as a non-finite window: the identity for that chain
+    fin = (torch.isfinite(Cx).flatten(1).all(1) & torch.isfinite(Cg).flatten(1).all(1))
+    if not bool(fin.all()):
+        Cx = torch.where(fin[:, None, None], Cx, eye.expand_as(Cx))
+        Cg = torch.where(fin[:, None, None], Cg, eye.expand_as(Cg))
+        stds = torch.where(fin[:, None], stds, torch.ones_like(stds))
     # S = Cg^-1/2 (Cg^1/2 Cx Cg^1/2)^1/2 Cg^-1/2
     eg, Ug = _eigh_psd(Cg)
     eg = eg.clamp_min(1e-300)
@@ -163,18 +248,19 @@ def estimate(x, gx, gamma: float, cutoff: float, k_max: int = K_MAX) -> Transfor
     live = ((W * W) * keep[:, :, None].to(W.dtype)).sum(1) > 0.5     # eigenvectors inside the span of the window (not the dropped columns of Q)
     log_es = torch.where(live, es.log(), torch.full_like(es, float("nan")))
     centre = torch.nan_to_num(torch.nanmedian(log_es, dim=1).values, nan=0.0).exp()       # [n]
+    centre = torch.where(ok[:, 0, 0], centre, torch.ones_like(centre))                     # (a window that was thrown away: exactly the identity)
     es = es / centre[:, None]
     stds = stds * centre.sqrt()[:, None]
     score = es.log().abs()
     outside = (score > float(np.log(cutoff))) & live
     score = torch.where(outside, score, torch.full_like(score, -1.0))
-    k = min(k_max, 2 * m)
+    k = min(k_max, r)
     top = torch.topk(score, k, dim=1)
     sel = top.indices                                           # [n, k]
     lam = torch.gather(es, 1, sel)
     used = top.values > 0
-    Wsel = torch.gather(W, 2, sel[:, None, :].expand(n, 2 * m, k))
-    V = Q @ Wsel                                                # [n, D, k]
+    Wsel = torch.gather(W, 2, sel[:, None, :].expand(n, r, k))
+    V = Wsel if Q is None else Q @ Wsel                         # [n, D, k]
     d = torch.where(used, lam.sqrt() - 1.0, torch.zeros_like(lam))
     V = V * used[:, None, :].to(V.dtype)
     if k < k_max:
@@ -183,9 +269,16 @@ def estimate(x, gx, gamma: float, cutoff: float, k_max: int = K_MAX) -> Transfor
     return Transform(mean, stds, V.contiguous(), d.contiguous())
 
 
+def schedule_of(settings):
+    """:func:`window_schedule` from a settings object (the keys of ``src/wrapper.rs:198-240``; ``mass_matrix_update_freq`` keeps the
+    engine's default of 1 unless set: the low-rank default of 10 applies then)"""
+    upd = int(settings.mass_matrix_update_freq)
+    return window_schedule(int(settings.num_tune), float(settings.early_window), float(settings.step_size_window), int(settings.mass_matrix_switch_freq),
+                           int(settings.early_window_switch_freq), upd if upd > 1 else 10)
+
+
 def pause_draws(num_tune: int):
-    out = sorted({int(round(f * num_tune)) for f in SWITCH_FRACTIONS if int(round(f * num_tune)) >= 12})
-    return [d for d in out if d < num_tune]
+    return [p for p, _ in window_schedule(num_tune)]
 
 
 def metric_of(T: Transform):
@@ -199,11 +292,14 @@ class LowRankSampler:
     the host thread that drives it and hands the engine a new metric at every boundary.  Same handle surface as ``PySampler``
     (wait / pause / resume / abort / is_finished / progress / inspect / take_results); the trace is in model space throughout."""
 
-    def __init__(self, inner, device, gamma, cutoff, pauses):
+    def __init__(self, inner, device, gamma, cutoff, schedule):
         self._inner = inner
         self._device = device
         self._gamma, self._cutoff = float(gamma), float(cutoff)
-        self._pauses = list(pauses)
+        self._schedule = [(int(p), int(a)) for p, a in schedule]    # (pause draw, first draw of its window): window_schedule
+        self._pauses = [p for p, _ in self._schedule]
+        self._had_columns = np.zeros(inner.num_chains, dtype=bool)  # per chain: its current metric has a low-rank part
+        self.fallbacks = 0            # hand-ins that kept only the diagonal part because the last low-rank metric deepened the chain's trees
         self._chain_next = np.zeros(inner.num_chains, dtype=np.int64)   # per chain: index of the next boundary it stops at
         self._stream = None           # the estimator's stream (made on its thread)
         self._lock = threading.Lock()
@@ -233,7 +329,12 @@ class LowRankSampler:
         pool = ThreadPoolExecutor(1)
         try:
             held = 0
-            per_look, probe_ms, probe_n = 1, 0.0, 0                # launches between two looks: fixed after the first three
+            # launches between two looks at the chains: one launch of a kernel that evaluates inside the launch (hundreds of gradient
+            # evaluations per chain), sixteen of a model whose launches are one evaluation each.  Decided from the model's kind, not
+            # from a clock: when the looks happen decides which chains are estimated together, and a job must be reproducible
+            kind = type(getattr(self._inner, "_model", None)).__name__
+            resident = kind in ("TridiagGaussianModel", "JitDensityModel") or (kind in ("HostCallbackModel", "BridgeStanModel") and self._inner.host_mode == "resident")
+            per_look = int(getattr(self._inner, "launches_per_look", 0)) or (1 if resident else 16)
             job = None                                             # the estimate in flight
             busy = np.zeros(self._inner.num_chains, dtype=bool)    # chains whose estimate is in flight
             while True:
@@ -252,14 +353,6 @@ class LowRankSampler:
                     if done:
                         break
                     if pending:
-                        # a few ms of engine time between two looks at the chains: one launch of a resident kernel (hundreds of
-                        # gradient evaluations per chain), sixteen of a model whose launches are one evaluation each.  Decided
-                        # once: when the looks happen decides which chains are estimated together, and a job must not depend
-                        # on the clock.
-                        if probe_n >= 0:
-                            probe_ms, probe_n = probe_ms + ms, probe_n + cnt
-                            if probe_n >= 3:
-                                per_look, probe_n = (1 if probe_ms / probe_n >= 0.5 else 16), -1
                         code = self._inner.waiting_codes()
                         wait = (code == 1) & ~busy
                         if wait.any():
@@ -287,6 +380,11 @@ class LowRankSampler:
         grads = device_tensor(self._inner.device_ptr("gradient"), (n, T, D), "float64", self._device)
         return draws, grads
 
+    def _n_steps(self):
+        from nutpie_amd.distributed import device_tensor
+
+        return device_tensor(self._inner.device_ptr("n_steps"), (self._inner.num_chains, self._inner.total_draws), "int64", self._device)
+
     def _estimate(self, chains, at):
         """(worker thread) New metrics for the stopped ``chains``; ``at``: the index of the boundary each one is at.  Chains at the
         same boundary are one batch.  -> [(chains, boundary index, sigma^2, V, lambda, log entry)], ready to install."""
@@ -300,33 +398,53 @@ class LowRankSampler:
             if self._stream is None:
                 self._stream = torch.cuda.Stream(self._device)
         with torch.no_grad(), (torch.cuda.stream(self._stream) if cuda else contextlib.nullcontext()):
+            n_steps = None
             for i in np.unique(at):
                 t0 = time.perf_counter()
                 grp = chains[at == i]
-                hi, lo = self._pauses[i], (self._pauses[i - 1] if i else 0)
-                m = min(WINDOW_MAX, max(4, (hi - lo) * 2 // 3))
+                hi, lo = self._schedule[i]
+                lo = max(lo, hi - WINDOW_MAX)
                 if len(grp) == draws.shape[0]:
-                    x, g = draws[:, hi - m:hi], grads[:, hi - m:hi]
+                    x, g = draws[:, lo:hi], grads[:, lo:hi]
                 else:
                     idx = torch.as_tensor(grp, device=draws.device)
-                    x, g = draws[idx, hi - m:hi], grads[idx, hi - m:hi]
-                T_new = estimate(x, g, self._gamma, self._cutoff)
+                    x, g = draws[idx, lo:hi], grads[idx, lo:hi]
+                T_new = estimate(x, g, self._gamma, self._cutoff, basis_draws=BASIS_DRAWS)
                 sig2, V, lam = metric_of(T_new)
+                # A chain whose LAST low-rank metric deepened its trees (mean leapfrogs per draw of the window just finished against
+                # the window before that hand-in) keeps only the diagonal part this time: a metric estimated from a chain still in
+                # transit can point the columns the wrong way, and the next window would be estimated from max-depth draws
+                bad = np.zeros(len(grp), dtype=bool)
+                if i >= 1 and self._had_columns[grp].any():
+                    if n_steps is None:
+                        n_steps = self._n_steps()
+                    p_prev, a_prev = self._schedule[i - 1]
+                    idx = torch.as_tensor(grp, device=draws.device)
+                    after = n_steps[idx, min(p_prev + SETTLE, hi - 1):hi].double().mean(1)
+                    before = n_steps[idx, max(a_prev, p_prev - (hi - p_prev)):p_prev].double().mean(1)
+                    bad = ((after > 1.3 * before + 1.0).cpu().numpy()) & self._had_columns[grp]
+                    if bad.any():
+                        b = torch.as_tensor(bad, device=lam.device)
+                        lam = torch.where(b[:, None], torch.ones_like(lam), lam)
+                        V = torch.where(b[:, None, None], torch.zeros_like(V), V)
                 # only the columns some chain uses (estimate() puts a chain's used columns first): every column handed in costs
                 # every leapfrog of every chain a dot product and an update in both halves of the step
                 k_used = int((lam != 1.0).sum(1).max().item()) if lam.numel() else 0
+                has = ((lam != 1.0).sum(1) > 0).cpu().numpy() if lam.numel() else np.zeros(len(grp), dtype=bool)
                 V, lam = V[:, :k_used].contiguous(), lam[:, :k_used].contiguous()
-                cols = float((T_new.d != 0).sum(1).double().mean())
+                cols = float((lam != 1.0).sum(1).double().mean()) if k_used else 0.0
                 if cuda:
                     self._stream.synchronize()
-                out.append((grp, int(i), sig2, V if k_used else None, lam if k_used else None, (hi, cols, time.perf_counter() - t0, len(grp))))
+                out.append((grp, int(i), sig2, V if k_used else None, lam if k_used else None, (hi, cols, time.perf_counter() - t0, len(grp)), has, int(bad.sum())))
         return out
 
     def _install(self, metrics):
         """(driver thread, between two launches) hand the estimated metrics to the engine"""
-        for grp, i, sig2, V, lam, entry in metrics:
+        for grp, i, sig2, V, lam, entry, has, n_bad in metrics:
             self._inner.set_metric(grp, sig2, V, lam)
             self._chain_next[grp] = i + 1
+            self._had_columns[grp] = has
+            self.fallbacks += n_bad
             self.switch_log.append(entry)
 
     def _adapt(self, chains):
@@ -406,11 +524,12 @@ def make_sampler(compiled_model, settings, init_mean, cores, progress_type, extr
         raise RuntimeError("adaptation='low_rank' needs a GPU: the nutpie-hip engine has no CPU fallback")
     if not engine_kw.get("store_draws", True):
         raise ValueError("adaptation='low_rank' estimates the metric from the stored draws: store_draws=False cannot be combined with it")
-    pauses = pause_draws(int(settings.num_tune))
+    schedule = schedule_of(settings)
+    pauses = [p for p, _ in schedule]
     inner_settings = settings.clone()
     inner_settings.update(low_rank_metric=True, store_gradient=True)   # the estimator needs the gradients of the window's draws
     inner_settings.set_pause_draws(pauses)
     device = int(engine_kw.get("device", 0) or 0)
     inner = compiled_model._make_sampler(inner_settings, init_mean, cores, progress_type, extra_callback, extra_callback_rate, store,
                                          **{**engine_kw, "manual": True})
-    return LowRankSampler(inner, device, settings._low_rank["mass_matrix_gamma"], settings._low_rank["mass_matrix_eigval_cutoff"], pauses)
+    return LowRankSampler(inner, device, settings._low_rank["mass_matrix_gamma"], settings._low_rank["mass_matrix_eigval_cutoff"], schedule)

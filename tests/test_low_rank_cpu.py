@@ -84,7 +84,50 @@ def test_estimator_degenerate_windows_fall_back_to_the_diagonal():
     x = torch.randn(n, 40, D, generator=g, dtype=torch.float64)
     T = lr.estimate(x, -x, gamma=1e-5, cutoff=4.0)
     assert (T.d == 0).all()
-    assert lr.pause_draws(400) == [32, 80, 160, 260] and lr.pause_draws(20) == [13] and lr.pause_draws(10) == []
+
+
+def test_window_schedule_follows_the_reference_keys():
+    """src/wrapper.rs:198-240: `window_switch_freq`, `early_window_switch_freq` (and `early_window`, `step_size_window`) are set on Diag
+    AND LowRank settings — the low-rank estimator runs on the diagonal adaptation's foreground / background windows.  The hand-ins
+    are the main-phase switches and thinned refreshes; a window is the foreground: the draws since the second-last switch."""
+    from nutpie_amd import low_rank as lr
+
+    # tune 400, defaults: early phase until draw 120 (switches every 10 draws: 9, 19, ... 119), one main-phase switch at 199 (the
+    # next, 279, could not collect 80 more draws before the final window at 341); refreshes every >= 40 draws, the last at 340
+    assert lr.window_schedule(400) == [(199, 119), (240, 119), (280, 119), (320, 119), (340, 119)]
+    assert lr.pause_draws(400) == [199, 240, 280, 320, 340]
+    # the keys move it: more frequent main switches -> shorter, later windows
+    s = lr.window_schedule(400, switch_freq=50, early_switch_freq=20)
+    assert [p for p, _ in s][:3] == [169, 200, 219] and s[2] == (219, 169) and s[-1][0] == 340
+    # early_window / step_size_window: where the main phase starts and the metric freezes
+    s = lr.window_schedule(1000, early_window=0.1, step_size_window=0.3)
+    assert s[0][1] >= 90 and s[-1][0] <= 700 and all(b > a for (a, _), (b, _) in zip(s, s[1:]))
+    for T in (30, 100, 200, 400, 1000, 4000):
+        s = lr.window_schedule(T)
+        assert 1 <= len(s) <= lr.MAX_HAND_INS and all(lr.MIN_WINDOW <= p - a and 0 <= a < p < T for p, a in s)
+    assert lr.window_schedule(10) == []
+
+
+def test_estimator_uses_every_draw_for_the_diagonal_and_a_thinned_basis_for_the_columns():
+    from nutpie_amd import low_rank as lr
+
+    g = torch.Generator().manual_seed(2)
+    n, m, D = 2, 120, 90
+    scale = torch.exp(torch.randn(D, generator=g, dtype=torch.float64))
+    z = torch.randn(n, m, D, generator=g, dtype=torch.float64)
+    z[:, :, 0] = z[:, :, 1] * 0.98 + 0.2 * z[:, :, 0]                 # one strongly correlated pair
+    x = z * scale
+    P = torch.eye(D, dtype=torch.float64)
+    gx = -(x / scale**2)
+    full = lr.estimate(x, gx, 1e-5, 2.0)
+    thin = lr.estimate(x, gx, 1e-5, 2.0, basis_draws=32)
+    # the diagonal part before re-centring is the same ratio of standard deviations over all 120 draws: the thinned estimate differs
+    # from the full one by its re-centring factor only
+    ratio = thin.stds / full.stds
+    assert torch.allclose(ratio, ratio[:, :1].expand_as(ratio), rtol=1e-10)
+    assert (thin.d != 0).sum() <= (full.d != 0).sum() + 4 and torch.isfinite(thin.V).all()
+    y = torch.randn(n, D, generator=g, dtype=torch.float64)
+    assert torch.allclose(thin.inverse(thin.forward(y)), y, atol=1e-9)
 
 
 @pytest.mark.parametrize("n,D,m,seed,gamma,cutoff,tol", [(4, 30, 48, 3, 1e-5, 2.0, 1e-9), (2, 60, 64, 7, 1e-3, 4.0, 1e-9), (3, 120, 40, 5, 1e-5, 2.0, 1e-4)])
@@ -123,6 +166,7 @@ class _FakeEngine:
     def __init__(self, n, total, dim, pauses, speed, seed=0):
         g = torch.Generator().manual_seed(seed)
         self.num_chains, self.total_draws, self.dim = n, total, dim
+        self.launches_per_look = 1                       # (a launch of this engine is many draws, like a resident kernel's)
         self.draws = torch.randn(n, total, dim, generator=g, dtype=torch.float64)
         self.grads = -self.draws * torch.exp(torch.randn(n, 1, dim, generator=g, dtype=torch.float64)) + 0.1 * torch.randn(n, total, dim, generator=g, dtype=torch.float64)
         self.pauses, self.speed = list(pauses), np.asarray(speed)
@@ -166,23 +210,26 @@ def test_driver_hands_every_chain_its_own_windows_without_lock_step():
     from nutpie_amd import low_rank as lr
 
     n, total, dim = 6, 240, 8
-    pauses = [60, 120, 180]
+    schedule = [(60, 20), (120, 60), (180, 60)]
+    pauses = [p for p, _ in schedule]
     eng = _FakeEngine(n, total, dim, pauses, speed=[1, 40, 40, 30, 40, 20])
 
     class Driver(lr.LowRankSampler):
         def _views(self):
             return self._inner.draws, self._inner.grads
 
-    smp = Driver(eng, 0, 1e-5, 2.0, pauses)
+        def _n_steps(self):
+            return torch.ones(n, total, dtype=torch.int64)
+
+    smp = Driver(eng, 0, 1e-5, 2.0, schedule)
     smp.wait(timeout_seconds=120)
     assert smp.is_finished() and (eng.at == total).all()
     by_chain = {c: [e for e in eng.log if e[1] == c] for c in range(n)}
     for c, entries in by_chain.items():
         assert [e[2] for e in entries] == pauses, f"chain {c}: boundaries {[e[2] for e in entries]}"
         for i, (_, _, hi, sig2, _) in enumerate(entries):
-            lo = pauses[i - 1] if i else 0
-            m = min(lr.WINDOW_MAX, max(4, (hi - lo) * 2 // 3))
-            T = lr.estimate(eng.draws[c:c + 1, hi - m:hi], eng.grads[c:c + 1, hi - m:hi], 1e-5, 2.0)
+            lo = schedule[i][1]
+            T = lr.estimate(eng.draws[c:c + 1, lo:hi], eng.grads[c:c + 1, lo:hi], 1e-5, 2.0, basis_draws=lr.BASIS_DRAWS)
             assert torch.allclose(sig2, (T.stds * T.stds)[0], rtol=1e-12, atol=0), f"chain {c}, boundary {hi}: not its own window"
     # the crawling chain reaches its first boundary after every other chain has passed its last one
     first_slow = by_chain[0][0][0]
