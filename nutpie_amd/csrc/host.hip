@@ -217,6 +217,8 @@ int nphip_settings_get_u64(const nphip_settings_t* s, const char* name, uint64_t
     else if (n == "seed") *out = s->seed;
     else if (n == "mass_matrix_switch_freq" || n == "window_switch_freq") *out = s->mass_matrix_switch_freq;
     else if (n == "early_window_switch_freq") *out = s->early_mass_matrix_switch_freq;
+    else if (n == "mass_matrix_update_freq") *out = s->mass_matrix_update_freq;
+    else if (n == "num_try_init") *out = s->num_try_init;
     else if (n == "check_turning") *out = s->check_turning;
     else if (n == "store_mass_matrix") *out = s->store_mass_matrix;
     else if (n == "use_grad_based_mass_matrix") *out = s->use_grad_based_estimate;

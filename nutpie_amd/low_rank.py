@@ -34,8 +34,10 @@ from dataclasses import dataclass
 import numpy as np
 
 K_MAX = 16            # columns kept per chain (the reference has no such knob)
-BASIS_DRAWS = 32      # draws (thinned evenly from the window) that span the subspace of the low-rank part: with their gradients 64
-                      # directions, the order of the eigenproblems (the engine's own batched solver); the DIAGONAL part uses every draw
+BASIS_DRAWS = None    # draws (thinned evenly from the window) that span the subspace of the low-rank part; the DIAGONAL part uses every
+                      # draw.  None: 32 (with their gradients 64 directions: the order the engine's own batched eigensolver is fastest at,
+                      # 1.8 ms per 512 problems) for models of up to 256 dimensions, 64 (order 128: 12 ms) above — measured on the D = 500
+                      # demo: 0.31 relative error of the posterior sd with 32, 0.09 with 64 (profiles/r5_low_rank_schedule.txt)
 WINDOW_MAX = 256      # draws of a foreground window that are read at all (the most recent ones)
 MIN_WINDOW = 12       # a window shorter than this says too little: no hand-in
 SETTLE = 4            # draws after a hand-in that are not used (the chain re-runs its step-size search there)
@@ -44,7 +46,7 @@ MAX_HAND_INS = 15     # pause draws the engine holds (engine_types.h: pause_draw
 
 
 def window_schedule(num_tune: int, early_window: float = 0.3, step_size_window: float = 0.15, switch_freq: int = 80, early_switch_freq: int = 10,
-                    update_freq: int = 10):
+                    update_freq: int = 10, early_hand_ins: bool = True):
     """The reference's warm-up windows for ``LowRank`` settings — the SAME foreground / background schedule as ``diag``
     (``src/wrapper.rs:198-240``: ``window_switch_freq`` / ``mass_matrix_switch_freq``, ``early_window_switch_freq`` are set on Diag AND
     LowRank settings; nuts-rs' ``GlobalStrategy::adapt``, SURVEY App. A.8): the background estimator becomes the foreground one every
@@ -78,15 +80,28 @@ def window_schedule(num_tune: int, early_window: float = 0.3, step_size_window: 
         return before[-2] if len(before) >= 2 else 0
 
     cands = sorted(set(late) | {c for c in range(update_freq, final, update_freq) if late and c > late[0]} | ({final - 1} if final - 1 > early_end else set()))
+    early_pick = None
+    if early_hand_ins:
+        # the early phase: the reference refreshes the metric there too, every few draws from the 10 - 20 draws since the second-last
+        # early switch.  Here ONE hand-in, at the last early switch, from the second half of the early phase (measured, profiles/
+        # r5_low_rank_schedule.txt: hand-ins from 16 - 20 draws at 19 / 39 / 79 / 119 cost radon 2 x the engine time and its warm-up
+        # 40 % more leapfrogs; none at all leaves a hard target — D = 500, six directions of variance x 400 — in transit when
+        # the main phase starts, 0.42 relative error of the posterior sd against 0.25)
+        early = [c for c in switches if c <= early_end]
+        if early and early[-1] >= 4 * MIN_WINDOW:
+            early_pick = early[-1]
+            cands = sorted(set(cands) | {early_pick})
     for p in cands:
         if p <= 0 or p >= T:
             continue
         start = window_start(p)
+        if p == early_pick:
+            start = p // 2
         if last is not None and last <= start < last + SETTLE:
             start = min(last + SETTLE, p - MIN_WINDOW)      # (a window that begins right at a hand-in skips the draws of its step-size search)
         if p - start < MIN_WINDOW:
             continue
-        is_switch, is_last = p in late, p == cands[-1]
+        is_switch, is_last = (p in late) or p == early_pick, p == cands[-1]
         if last is not None and not is_switch and not is_last and p - last < max(switch_freq // 2, update_freq):
             continue
         if is_last and last is not None and p - last < update_freq:
@@ -269,6 +284,10 @@ def estimate(x, gx, gamma: float, cutoff: float, k_max: int = K_MAX, basis_draws
     return Transform(mean, stds, V.contiguous(), d.contiguous())
 
 
+def basis_draws_for(dim: int) -> int:
+    return int(BASIS_DRAWS) if BASIS_DRAWS else (32 if dim <= 256 else 64)
+
+
 def schedule_of(settings):
     """:func:`window_schedule` from a settings object (the keys of ``src/wrapper.rs:198-240``; ``mass_matrix_update_freq`` keeps the
     engine's default of 1 unless set: the low-rank default of 10 applies then)"""
@@ -409,7 +428,7 @@ class LowRankSampler:
                 else:
                     idx = torch.as_tensor(grp, device=draws.device)
                     x, g = draws[idx, lo:hi], grads[idx, lo:hi]
-                T_new = estimate(x, g, self._gamma, self._cutoff, basis_draws=BASIS_DRAWS)
+                T_new = estimate(x, g, self._gamma, self._cutoff, basis_draws=basis_draws_for(x.shape[2]))
                 sig2, V, lam = metric_of(T_new)
                 # A chain whose LAST low-rank metric deepened its trees (mean leapfrogs per draw of the window just finished against
                 # the window before that hand-in) keeps only the diagonal part this time: a metric estimated from a chain still in

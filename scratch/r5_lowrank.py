@@ -8,7 +8,7 @@ import nutpie_amd
 from nutpie_amd import _lib, low_rank
 from nutpie_amd.radon import radon_symbolic_model
 
-what = sys.argv[1] if len(sys.argv) > 1 else "all"
+what = (sys.argv[1] if len(sys.argv) > 1 else "all") if __name__ == "__main__" else "none"
 
 
 def job(m, adaptation, chains, tune, draws, seed=20260926, **kw):

@@ -92,16 +92,18 @@ def test_window_schedule_follows_the_reference_keys():
     are the main-phase switches and thinned refreshes; a window is the foreground: the draws since the second-last switch."""
     from nutpie_amd import low_rank as lr
 
-    # tune 400, defaults: early phase until draw 120 (switches every 10 draws: 9, 19, ... 119), one main-phase switch at 199 (the
-    # next, 279, could not collect 80 more draws before the final window at 341); refreshes every >= 40 draws, the last at 340
-    assert lr.window_schedule(400) == [(199, 119), (240, 119), (280, 119), (320, 119), (340, 119)]
-    assert lr.pause_draws(400) == [199, 240, 280, 320, 340]
+    # tune 400, defaults: early phase until draw 120 (switches every 10 draws: 9, 19, ... 119) — ONE hand-in there, at its last switch,
+    # from its second half; one main-phase switch at 199 (the next, 279, could not collect 80 more draws before the final window at
+    # 341), its window the foreground = the draws since the second-last switch; refreshes every >= 40 draws, the last at 340
+    assert lr.window_schedule(400) == [(119, 59), (199, 123), (240, 119), (280, 119), (320, 119), (340, 119)]
+    assert lr.pause_draws(400) == [119, 199, 240, 280, 320, 340]
+    assert lr.window_schedule(400, early_hand_ins=False) == [(199, 119), (240, 119), (280, 119), (320, 119), (340, 119)]
     # the keys move it: more frequent main switches -> shorter, later windows
-    s = lr.window_schedule(400, switch_freq=50, early_switch_freq=20)
+    s = lr.window_schedule(400, switch_freq=50, early_switch_freq=20, early_hand_ins=False)
     assert [p for p, _ in s][:3] == [169, 200, 219] and s[2] == (219, 169) and s[-1][0] == 340
     # early_window / step_size_window: where the main phase starts and the metric freezes
     s = lr.window_schedule(1000, early_window=0.1, step_size_window=0.3)
-    assert s[0][1] >= 90 and s[-1][0] <= 700 and all(b > a for (a, _), (b, _) in zip(s, s[1:]))
+    assert s[0] == (99, 49) and s[1][1] >= 99 and s[-1][0] <= 700 and all(b > a for (a, _), (b, _) in zip(s, s[1:]))
     for T in (30, 100, 200, 400, 1000, 4000):
         s = lr.window_schedule(T)
         assert 1 <= len(s) <= lr.MAX_HAND_INS and all(lr.MIN_WINDOW <= p - a and 0 <= a < p < T for p, a in s)
@@ -229,7 +231,7 @@ def test_driver_hands_every_chain_its_own_windows_without_lock_step():
         assert [e[2] for e in entries] == pauses, f"chain {c}: boundaries {[e[2] for e in entries]}"
         for i, (_, _, hi, sig2, _) in enumerate(entries):
             lo = schedule[i][1]
-            T = lr.estimate(eng.draws[c:c + 1, lo:hi], eng.grads[c:c + 1, lo:hi], 1e-5, 2.0, basis_draws=lr.BASIS_DRAWS)
+            T = lr.estimate(eng.draws[c:c + 1, lo:hi], eng.grads[c:c + 1, lo:hi], 1e-5, 2.0, basis_draws=lr.basis_draws_for(dim))
             assert torch.allclose(sig2, (T.stds * T.stds)[0], rtol=1e-12, atol=0), f"chain {c}, boundary {hi}: not its own window"
     # the crawling chain reaches its first boundary after every other chain has passed its last one
     first_slow = by_chain[0][0][0]
