@@ -533,6 +533,29 @@ def job_rate(smp, t_create):
     return out
 
 
+def job_roofline(key, leapfrogs_per_s, waves):
+    """`roofline` of a whole job whose kernel has a PMC summary in profiles/traffic.json (round 5: config 3's compiled densities): the
+    resident kernels keep the chain state on chip — the resource that binds is instruction issue on the SIMDs the job occupies."""
+    try:
+        e = json.load(open(TRAFFIC_JSON)).get(key)
+    except OSError:
+        e = None
+    if not e:
+        return None
+    ipl = e["insts_per_leapfrog"]["total"]
+    peak = min(waves, N_SIMD * 8) * CLOCK_HZ / CYCLES_PER_ISSUE / 1e9
+    ach = ipl * leapfrogs_per_s / 1e9
+    gbs = e["bytes_per_leapfrog"] * leapfrogs_per_s / 1e9
+    return {"bound": "issue", "achieved": ach, "peak": peak, "unit": "G wave-instructions/s", "frac": ach / peak,
+            "frac_of_whole_device": ach / (N_SIMD * CLOCK_HZ / CYCLES_PER_ISSUE / 1e9), "resident_waves": waves,
+            "insts_per_leapfrog": e["insts_per_leapfrog"], "pmc_issuing_fraction_of_wave_cycles": e["issuing_fraction"],
+            "pmc_waiting_fraction_of_wave_cycles": e["waiting_fraction"],
+            "hbm_measured": {"GB/s": gbs, "frac_of_peak": gbs / HBM_PEAK_GBS, "bytes_per_leapfrog": e["bytes_per_leapfrog"], "note": e.get("note")},
+            "source": e["source"], "pmc_config": e["config"],
+            "note": "whole job (warm-up included) over engine time; achieved = PMC instructions per leapfrog x leapfrogs/s; peak = one instruction per 4 cycles "
+                    "for each of the job's waves (512 chains occupy 512 of the 1024 SIMDs)"}
+
+
 def other_configs(env, args):
     """Bounded runs of the BASELINE.json configs the headline does not cover, on this GPU (rank 0, N = 1).  Each entry is a
     whole `sample`-shaped job (its wall time from sampler creation to the last draw, leapfrogs from the trace)."""
@@ -559,6 +582,7 @@ def other_configs(env, args):
         t0 = time.perf_counter()
         r = job_rate(m._make_sampler(settings(512, 400, 1000), None, 1, None, None, None, None), t0)
         r["workload"] = "radon (D = 173, 85 counties, 919 observations), 512 chains, tune 400 + draws 1000; density generated by nutpie_amd.symbolic, compiled into its own resident kernel"
+        r["roofline"] = job_roofline("config3_compiled_density", r["leapfrogs_per_s"], 512)
         return r
 
     def c3_low_rank():
@@ -588,6 +612,7 @@ def other_configs(env, args):
         t0 = time.perf_counter()
         r = job_rate(m._make_sampler(settings(512, 400, 1000), None, 1, None, None, None, None), t0)
         r["trace_and_compile_s"] = compile_s
+        r["roofline"] = job_roofline("config3_traced_torch_density", r["leapfrogs_per_s"], 512)
         r["workload"] = ("radon, 512 chains, tune 400 + draws 1000; the model is a TORCH log-density (forward pass only, nutpie_amd.radon.radon_torch_density) that "
                          "nutpie_amd.from_torch_density traces (torch.fx), differentiates and compiles into its own resident kernel")
         return r

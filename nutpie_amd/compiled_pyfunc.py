@@ -244,6 +244,10 @@ class TorchFuncModel(CompiledModel):
         g = torch.zeros((n, D), dtype=torch.float64, device=dev)
         lp = torch.zeros((n,), dtype=torch.float64, device=dev)
         logp_fn = partial(self._make_logp_func(), **self._shared_data)
+        # A function marked ``writes_staging`` has the form f(x, out_logp, out_grad) and fills the engine's buffers with `out=` operations
+        # only: no copy kernels, and — nothing being allocated — the engine can capture `graph_steps` x (its kernel, this callback)
+        # into one HIP graph (host.hip: iteration_graph)
+        in_place = bool(getattr(logp_fn.func, "writes_staging", False))
         streams = {}
         graph = None
         if self._use_graph:
@@ -252,14 +256,20 @@ class TorchFuncModel(CompiledModel):
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
                 for _ in range(3):
-                    val, grad = logp_fn(q)
+                    if in_place:
+                        logp_fn(q, lp, g)
+                    else:
+                        val, grad = logp_fn(q)
             torch.cuda.current_stream(dev).wait_stream(side)
             torch.cuda.synchronize(dev)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                val, grad = logp_fn(q)
-                lp.copy_(val.reshape(n).to(torch.float64))
-                g.copy_(grad.reshape(n, D).to(torch.float64))
+                if in_place:
+                    logp_fn(q, lp, g)
+                else:
+                    val, grad = logp_fn(q)
+                    lp.copy_(val.reshape(n).to(torch.float64))
+                    g.copy_(grad.reshape(n, D).to(torch.float64))
             q.zero_()
 
         def cb(n_chains, dim, _q, _g, _lp, stream_ptr):
@@ -271,6 +281,8 @@ class TorchFuncModel(CompiledModel):
             with torch.cuda.stream(st):
                 if graph is not None:
                     graph.replay()
+                elif in_place:
+                    logp_fn(q, lp, g)         # writes the engine's staging buffers itself: no copies, nothing allocated
                 else:
                     val, grad = logp_fn(q)
                     lp.copy_(val.reshape(n).to(torch.float64))

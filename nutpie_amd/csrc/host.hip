@@ -17,6 +17,7 @@
 #include <cstring>
 #include <functional>
 #include <memory>
+#include <map>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -1207,6 +1208,7 @@ bool nphip_sampler::iteration_graph(bool& all_done) {
         if (ok) ok = hipGraphInstantiate(&cb_graph, g, nullptr, nullptr, 0) == hipSuccess;
         if (g) (void)hipGraphDestroy(g);
         if (!ok) {  // not capturable (e.g. a callback that allocates): keep stepping the plain way
+            if (getenv("NPHIP_DEBUG")) fprintf(stderr, "nphip: graph_steps: the (kernel, callback) sequence could not be captured (%s): stepping without a graph\n", hipGetErrorString(hipGetLastError()));
             (void)hipGetLastError();
             cb_graph = nullptr;
             cb_graph_steps = 0;
@@ -1919,13 +1921,27 @@ static int batched_eigh_mode(uint64_t n_batch, uint64_t order, double* a_device,
     if (order == 0 || order > 128) { set_error("nphip_batched_eigh: the order must be 1..128 (the matrix lives in LDS)"); return NPHIP_ERR; }
     if (n_batch == 0) return NPHIP_OK;
     if (!a_device || !w_device) { set_error("nphip_batched_eigh: null device pointer"); return NPHIP_ERR; }
-    int* d_status = nullptr;
-    if (!hip_ok(hipMalloc((void**)&d_status, n_batch * sizeof(int)), "hipMalloc")) return NPHIP_ERR;
+    // The status buffer is kept between calls (one per device, grown on demand): hipFree synchronises the whole device — the estimator's
+    // worker thread would wait for the engine's launch on another stream, which is exactly the overlap the low-rank driver is built
+    // around.  The mutex serialises callers that share the buffer.
+    static std::mutex mu;
+    static std::map<int, std::pair<int*, uint64_t>> cache;
+    std::lock_guard<std::mutex> lk(mu);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    auto& slot = cache[dev];
+    if (slot.second < n_batch) {
+        if (slot.first) (void)hipFree(slot.first);
+        slot = {nullptr, 0};
+        const uint64_t cap = std::max<uint64_t>(n_batch, 1024);
+        if (!hip_ok(hipMalloc((void**)&slot.first, cap * sizeof(int)), "hipMalloc")) return NPHIP_ERR;
+        slot.second = cap;
+    }
+    int* d_status = slot.first;
     std::vector<int> st(n_batch, 0);
     bool ok = hip_ok((hipError_t)nphip_linalg_launch_eigh(n_batch, order, a_device, w_device, d_status, stream, mode), "launch k_batched_eigh") &&
-              hip_ok(hipStreamSynchronize((hipStream_t)stream), "hipStreamSynchronize") &&
-              hip_ok(hipMemcpy(st.data(), d_status, n_batch * sizeof(int), hipMemcpyDeviceToHost), "D2H status");
-    (void)hipFree(d_status);
+              hip_ok(hipMemcpyAsync(st.data(), d_status, n_batch * sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream), "D2H status") &&
+              hip_ok(hipStreamSynchronize((hipStream_t)stream), "hipStreamSynchronize");
     if (!ok) return NPHIP_ERR;
     for (uint64_t i = 0; i < n_batch; ++i)
         if (st[i] != 0) { set_error("nphip_batched_eigh: the QL iteration of matrix " + std::to_string(i) + " did not converge"); return NPHIP_ERR; }

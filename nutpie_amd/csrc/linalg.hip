@@ -86,7 +86,9 @@ __global__ __launch_bounds__(kThreads) void k_batched_eigh(int n, double* __rest
         const int i = idx / n, j = idx - i * n;
         const double a = (j <= i) ? A[idx] : A[(size_t)j * n + i];   // the lower triangle is the matrix
         V[i * ld + j] = a;
-        amax = fmax(amax, fabs(a));
+        // (fmax drops a NaN operand: a matrix with SOME non-finite entries would pass the test below and spin through every sweep
+        //  of every eigenvalue on NaNs — ADVICE r4; anything that is not a finite number makes the maximum infinite instead)
+        amax = (fabs(a) <= 1.0e300) ? fmax(amax, fabs(a)) : __builtin_inf();
     }
     amax = block_max(amax, red, tid);
     if (!(amax > 0.0) || !(amax < 1.0e300)) {   // zero (or non-finite) matrix: eigenvalues 0 (or NaN), eigenvectors the unit vectors

@@ -39,6 +39,7 @@ import ctypes as C
 import dataclasses
 import hashlib
 import os
+import re
 import struct
 import subprocess
 import tempfile
@@ -112,7 +113,11 @@ def struct_source(layout) -> str:
     return "\n".join(lines)
 
 
+_EXPAND_DEFINITION = re.compile(r"__device__\s+double\s+nphip_expand\s*\(")
+
+
 def generated_source(user_source: str, layout) -> str:
+    has_expand = bool(_EXPAND_DEFINITION.search(user_source))     # a DEFINITION, not a mention in a comment or a call
     return "\n".join([
         "// generated by nutpie_amd.density: one model's density compiled into the engine's resident kernel",
         "#include <hip/hip_runtime.h>",
@@ -121,8 +126,8 @@ def generated_source(user_source: str, layout) -> str:
         "__device__ double nphip_density(const NphipData& data, int dim, const double* x, double* grad, double* lds, const double* shared, int lane);",
         "__device__ void nphip_density_stage(const NphipData& data, double* shared, int thread, int n_threads);",
         "// the model also defines its expand step as a device function (nphip_expand: generated by nutpie_amd.symbolic)",
-        "#define NPHIP_JIT_EXPAND 1" if "nphip_expand(" in user_source else "",
-        "__device__ double nphip_expand(const NphipData& data, int dim, const double* x, double* out, double* lds, const double* shared, int lane);" if "nphip_expand(" in user_source else "",
+        "#define NPHIP_JIT_EXPAND 1" if has_expand else "",
+        "__device__ double nphip_expand(const NphipData& data, int dim, const double* x, double* out, double* lds, const double* shared, int lane);" if has_expand else "",
         '#include "kernels.hip"',
         "// the engine's wave reduction (sum over the 64 lanes in the contract's order; the same value in every lane)",
         "// `lds` and `shared` are LDS: through these casts the compiler emits ds_read / ds_write instead of flat accesses",
@@ -144,6 +149,19 @@ def generated_source(user_source: str, layout) -> str:
         "static __device__ __forceinline__ void nphip_chain_sum2(double& a, double& b) { double v[2] = {a, b}; nphip_chain_sumN(v); a = v[0]; b = v[1]; }",
         "static __device__ __forceinline__ void nphip_chain_sum3(double& a, double& b, double& c) { double v[3] = {a, b, c}; nphip_chain_sumN(v); a = v[0]; b = v[1]; c = v[2]; }",
         "static __device__ __forceinline__ void nphip_chain_sum4(double& a, double& b, double& c, double& d) { double v[4] = {a, b, c, d}; nphip_chain_sumN(v); a = v[0]; b = v[1]; c = v[2]; d = v[3]; }",
+        "// the largest value over all threads of the chain (every thread gets it)",
+        "static __device__ __forceinline__ double nphip_chain_max(double v) {",
+        "    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));",
+        "    if (NPHIP_JIT_W > 1) {",
+        "        __shared__ double mx_[NPHIP_JIT_W];",
+        "        __syncthreads();",
+        "        if ((threadIdx.x & 63) == 0) mx_[threadIdx.x >> 6] = v;",
+        "        __syncthreads();",
+        "        v = mx_[0];",
+        "        for (int w = 1; w < NPHIP_JIT_W; ++w) v = fmax(v, mx_[w]);",
+        "    }",
+        "    return v;",
+        "}",
         "static __device__ __forceinline__ void nphip_chain_barrier() {",
         '    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");',
         "    if (NPHIP_JIT_W == 1) __builtin_amdgcn_wave_barrier(); else __syncthreads();",

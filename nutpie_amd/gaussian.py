@@ -102,12 +102,22 @@ def dense_gaussian(dim: int, seed: int = BENCH_RNG_SEED, cond_lo=1e-2, cond_hi=1
     prec = 0.5 * (prec + prec.T)
 
     def make_logp():
-        P = torch.as_tensor(prec, dtype=torch.float64, device=torch.device("cuda", device))
+        dev = torch.device("cuda", device)
+        negP = torch.as_tensor(-prec, dtype=torch.float64, device=dev)
+        half = torch.full((dim,), 0.5, dtype=torch.float64, device=dev)
+        tmp = {}
 
-        def logp(x):
-            g = -(x @ P)
-            return 0.5 * (x * g).sum(-1), g
+        def logp(x, out_logp, out_grad):
+            # three kernels, all writing preallocated buffers: grad = -x P (fp64 GEMM) into the engine's staging buffer, x * grad, and its
+            # row sums times 1/2 (a GEMV) into the staging log-density
+            t = tmp.get(x.shape[0])
+            if t is None:
+                t = tmp[x.shape[0]] = torch.empty_like(x)
+            torch.mm(x, negP, out=out_grad)
+            torch.mul(x, out_grad, out=t)
+            torch.mv(t, half, out=out_logp)
 
+        logp.writes_staging = True
         return logp
 
     model = from_torchfunc(dim, make_logp)

@@ -193,7 +193,7 @@ def estimate(x, gx, gamma: float, cutoff: float, k_max: int = K_MAX, basis_draws
     scaling      s_i = sqrt(std(x_i) / std(g_i)) over ALL m draws        (the diagonal "diag" adaptation uses the same ratio,
                                                                         python/nutpie/normalizing_flow.py:1906-1915)
     subspace     orthonormal Q of span{scaled draws, scaled gradients} of ``basis_draws`` draws thinned evenly from the window
-                 (None: all of them) — eigh of the 2b x 2b Gram matrix; the whole space when 2b >= D
+                 (None: all of them) — eigh of the 2b x 2b Gram matrix; the whole space when b - 1 >= D
     projected    Cx = Px'Px / b + gamma I,  Cg = Pg'Pg / b + gamma I
     metric       S = Cx # Cg^-1 (geometric mean: S Cg S = Cx), eigh(S) -> the k_max eigenvalues furthest from 1 in log scale
                  among those outside [1/cutoff, cutoff]; V = Q W
@@ -216,8 +216,8 @@ def estimate(x, gx, gamma: float, cutoff: float, k_max: int = K_MAX, basis_draws
         m = int(pick.numel())
     X = (x - mean[:, None, :]) / stds[:, None, :]
     G = (gx - gmean) * stds[:, None, :]
-    if 2 * m >= D:
-        # the window spans the whole space: work in it directly (Q = I)
+    if m - 1 >= D:
+        # draws and gradients each span the whole space: work in it directly (Q = I)
         r = D
         Q = None
         Px, Pg = X, G

@@ -50,7 +50,8 @@ from typing import Any
 
 import numpy as np
 
-__all__ = ["Model", "Expr", "Matrix", "exp", "log", "log1p", "sqrt", "softplus", "sigmoid", "where_lt", "elem", "stack", "normal_lpdf",
+__all__ = ["Model", "Expr", "Matrix", "exp", "log", "log1p", "sqrt", "softplus", "sigmoid", "tanh", "expm1", "erf", "erfc", "sin", "cos", "atan", "lgamma", "digamma",
+           "absolute", "sign", "select", "pad", "trunc", "where_lt", "elem", "stack", "normal_lpdf",
            "halfnormal_lpdf", "student_t_lpdf", "cauchy_lpdf", "halfcauchy_lpdf", "exponential_lpdf", "lognormal_lpdf", "gamma_lpdf",
            "bernoulli_logit_lpmf", "poisson_log_lpmf", "dirichlet_lpdf", "flat_lpdf"]
 
@@ -176,6 +177,13 @@ class Expr:
         if self.dim is None:
             raise ValueError("sum() of a scalar")
         return Expr("sum", (self,), None, None)
+
+    def max(self, constant: bool = False) -> "Expr":
+        """The largest element.  ``constant``: a value the result does not depend on in exact arithmetic (the shift of a softmax or a
+        log-sum-exp) — no gradient flows through it; otherwise the gradient goes to the element(s) that attain it."""
+        if self.dim is None:
+            return self
+        return Expr("max", (self,), None, "constant" if constant else None)
 
     def __repr__(self):
         return f"<{self.op}#{self.id}{'@' + self.dim.name if self.dim else ''}>"
@@ -638,6 +646,9 @@ def gradient(out: Expr, wrt: list[Expr]) -> list[Expr]:
             acc(a, reduce_to(g, d, a))
         elif n.op == "sum":
             acc(a, g)                      # the same scalar for every element
+        elif n.op == "max":
+            if n.payload != "constant":
+                acc(a, select(a - n, g, 0.0, strict=False))
         elif n.op == "gather":
             acc(a, _segsum(g, n.payload))
         elif n.op == "segsum":
@@ -739,6 +750,8 @@ def evaluate(nodes: list[Expr], x: np.ndarray, data: dict[str, Any]) -> list[np.
                 v = np.broadcast_to(a[:, None] if a.ndim == 1 else a, (N, dim_len(n.dim)))
             elif n.op == "sum":
                 v = a.sum(axis=1)
+            elif n.op == "max":
+                v = a.max(axis=1)
             elif n.op == "gather":
                 v = a[:, np.asarray(data[n.payload.name], dtype=np.int64)]
             elif n.op == "segsum":
@@ -791,7 +804,7 @@ class _Gen:
         self.level: dict[int, int] = {}
         for n in self.order:
             lv = max([self.level[a.id] for a in n.args], default=0)
-            if n.op in ("sum", "gather", "segsum") or (n.op in ("elem", "pad", "trunc") and n.args[0].op not in ("vparam", "data")):
+            if n.op in ("sum", "max", "gather", "segsum") or (n.op in ("elem", "pad", "trunc") and n.args[0].op not in ("vparam", "data")):
                 lv += 1
             self.level[n.id] = lv
         # what lives in per-chain LDS: sources of gathers (unless they are parameters or data, read in place), arguments of
@@ -857,7 +870,7 @@ class _Gen:
         roots: dict[tuple[int, int], list[Expr]] = {}
         by_id = {n.id: n for n in self.order}
         for n in self.order:
-            if n.op == "sum":
+            if n.op in ("sum", "max"):
                 a = n.args[0]
                 roots.setdefault((id(a.dim), self.level[a.id]), []).append(a)
         for key, (how, _) in self.stored.items():
@@ -942,7 +955,7 @@ class _Gen:
         for lv in range(max_level + 2):
             # scalars of this level (sums were produced by the loops of the level below)
             for n in self.order:
-                if n.dim is None and n.op != "sum" and self.level[n.id] == lv and n.id not in done_scalar:
+                if n.dim is None and n.op not in ("sum", "max") and self.level[n.id] == lv and n.id not in done_scalar:
                     assert scalar_ready(n), n
                     if n.op != "const":
                         emit(f"    const double s{self.num[n.id]} = {self.scalar_rhs(n)};")
@@ -958,7 +971,7 @@ class _Gen:
             mark(f"scalars of level {lv}")
             # loops of this level, one per dimension that has something to produce here
             for d in m._dims.values():
-                sums = [n for n in self.order if n.op == "sum" and n.args[0].dim is d and self.level[n.args[0].id] == lv]
+                sums = [n for n in self.order if n.op in ("sum", "max") and n.args[0].dim is d and self.level[n.args[0].id] == lv]
                 stores = []
                 for key, (how, sd) in self.stored.items():
                     if sd is not d or how == "scalars":
@@ -1021,7 +1034,7 @@ class _Gen:
         by_id = {n.id: n for n in self.order}
         emit(f"    // level {lv}, over {d.name}")
         for n in sums:
-            emit(f"    double s{self.num[n.id]} = 0.0;")
+            emit(f"    double s{self.num[n.id]} = {'0.0' if n.op == 'sum' else '-INFINITY'};")
         emit(f"    for (int i0 = lane; i0 < n_{d.name}; i0 += {T * U}) {{")
         stages: list[list[str]] = [[], [], [], [], []]   # 0 direct reads, 1 dependent reads, 2 segment sums, 3 arithmetic, 4 stores / sums
         seg: dict[tuple, list[tuple[str, str]]] = {}     # (iteration, index) -> [(accumulator, array)]: one inner loop for all of them
@@ -1107,7 +1120,8 @@ class _Gen:
                 else:
                     stages[4].append(f"        {guard}{self.store_name[key]}[i_{u}] = {v};")
             for n in sums:
-                stages[4].append(f"        {guard}s{self.num[n.id]} += {val(n.args[0])};")
+                acc_ = f"s{self.num[n.id]}"
+                stages[4].append(f"        {guard}{acc_} += {val(n.args[0])};" if n.op == "sum" else f"        {guard}{acc_} = fmax({acc_}, {val(n.args[0])});")
             for p, gexpr in outs:
                 off, nv = p.payload
                 perm = getattr(p, "perm", None)
@@ -1125,7 +1139,10 @@ class _Gen:
         emit("    }")
         mark(f"loop over {d.name}, level {lv}")
         # the loop's sums over the wave, several at a time
-        ids = [f"s{self.num[n.id]}" for n in sums]
+        for n in sums:
+            if n.op == "max":
+                emit(f"    s{self.num[n.id]} = nphip_chain_max(s{self.num[n.id]});")
+        ids = [f"s{self.num[n.id]}" for n in sums if n.op == "sum"]
         for k in range(0, len(ids), 4):
             grp = ids[k:k + 4]
             if len(grp) == 1:
@@ -1374,12 +1391,16 @@ class Model:
             if lower is not None or upper is not None:
                 raise ValueError("simplex and bounds exclude each other")
             # y = (raw, -sum raw);  value = softmax(y) = softmax(y + sum raw): z = raw + s on the free elements, 0 on the last
+            # (shifted by the largest exponent, as PyMC's SimplexTransform does: exp cannot overflow during a warm-up excursion; the
+            #  shift cancels in value and in the Jacobian, so no gradient flows through it)
             n = d.size
             s = raw.sum()
-            e = exp(where_lt(d, n - 1, raw + s, 0.0))
+            z = where_lt(d, n - 1, raw + s, 0.0)
+            shift = z.max(constant=True)
+            e = exp(z - shift)
             total = e.sum()
             value = e / total
-            self._terms.append(math.log(n) + n * s - n * log(total))     # log |det d value[:n-1] / d raw|
+            self._terms.append(math.log(n) + n * s - n * (shift + log(total)))     # log |det d value[:n-1] / d raw|
         else:
             value, jac = self._constrain(raw, lower, upper)
             if jac is not None:

@@ -724,6 +724,41 @@ def _run(gm, it: _Interp, x_shape, data_values: dict[str, Any]):
             r = it.sum(a0, dims, args[2] if len(args) > 2 else kwargs.get("keepdim", False))
             cnt = _numel(it.shape_of(a0)) // max(_numel(r.shape), 1)
             env[node] = _Sym(r.expr * (1.0 / cnt), r.shape)
+        elif base in ("amax", "amin", "max", "min", "logsumexp", "_softmax", "_log_softmax", "softmax", "log_softmax"):
+            # reductions by the maximum — over ALL elements of the tensor (one chain's vector): the IR's `max` is dimension -> scalar
+            v_ = it.sym(a0)
+            dims = args[1] if len(args) > 1 else kwargs.get("dim")
+            if base in ("max", "min") and len(args) > 1:
+                raise UnsupportedTorchOp(f"{name} along an axis (values and indices)")
+            shp = v_.shape
+            nd = len(shp)
+            if dims is None or (isinstance(dims, (list, tuple)) and len(dims) == 0):
+                dims = list(range(nd))
+            if isinstance(dims, int):
+                dims = [dims]
+            dims = sorted({d_ % nd for d_ in dims}) if nd else []
+            if _numel(tuple(s_ for i_, s_ in enumerate(shp) if i_ not in dims)) != 1:
+                raise UnsupportedTorchOp(f"{name} along an axis of a tensor with more than one row (only whole-vector maxima have a counterpart)")
+            keep = bool(args[2] if len(args) > 2 else kwargs.get("keepdim", False)) if base in ("amax", "amin", "logsumexp") else False
+            oshape = tuple(1 if i_ in dims else s_ for i_, s_ in enumerate(shp)) if keep else tuple(s_ for i_, s_ in enumerate(shp) if i_ not in dims)
+            e = v_.expr
+            if base in ("amax", "max"):
+                env[node] = _Sym(e.max() if e.dim is not None else e, oshape)
+            elif base in ("amin", "min"):
+                env[node] = _Sym(-((-e).max()) if e.dim is not None else e, oshape)
+            elif e.dim is None:      # all elements equal
+                n_ = float(_numel(shp))
+                env[node] = _Sym(e + math.log(n_), oshape) if base == "logsumexp" else _Sym(Expr.const(1.0 / n_) if "log" not in base else Expr.const(-math.log(n_)), shp)
+            else:
+                m_ = e.max(constant=True)            # the shift: cancels exactly, no gradient through it
+                ex = S.exp(e - m_)
+                tot = ex.sum()
+                if base == "logsumexp":
+                    env[node] = _Sym(m_ + S.log(tot), oshape)
+                elif base in ("_softmax", "softmax"):
+                    env[node] = _Sym(ex / tot, shp)
+                else:
+                    env[node] = _Sym((e - m_) - S.log(tot), shp)
         elif base == "dot" or base == "vdot":
             env[node] = it.sum(B(args[0], args[1], lambda x, y: x * y))
         elif base in ("mv", "mm", "matmul", "bmm"):

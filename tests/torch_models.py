@@ -178,3 +178,24 @@ def autograd(density_fn, x, batched: bool, shared):
     lp = density_fn(xt, **sh) if batched else torch.stack([density_fn(row, **sh) for row in xt])
     (g,) = torch.autograd.grad(lp.sum(), xt)
     return lp.detach().numpy().reshape(-1), g.numpy()
+
+
+def softmax_mixture():
+    """a categorical likelihood through ``log_softmax`` of the whole logit vector, a two-component mixture through ``logsumexp``,
+    ``amax`` as a soft barrier"""
+    rng = np.random.default_rng(21)
+    K = 6
+    counts = _t(rng.integers(1, 30, size=K).astype(np.float64))
+    obs = _t(rng.normal(size=40) + 1.5)
+
+    def logp(x):
+        logits, mu, log_w = x[:K], x[K:K + 2], x[K + 2:K + 4]
+        ll = (counts * torch.log_softmax(logits, -1)).sum()
+        comp = torch.log_softmax(log_w, 0)
+        mix = torch.stack([torch.logsumexp(torch.stack([comp[0] - 0.5 * (o - mu[0]) ** 2, comp[1] - 0.5 * (o - mu[1]) ** 2]), 0) for o in obs[:8]]).sum()
+        return ll + mix - 0.5 * (logits * logits).sum() - 0.05 * torch.amax(logits) - 0.5 * (mu * mu).sum() / 9.0 - 0.5 * (log_w * log_w).sum()
+
+    return K + 4, logp, False, {}
+
+
+ALL["softmax_mixture"] = softmax_mixture
