@@ -272,21 +272,27 @@ class TorchFuncModel(CompiledModel):
                     g.copy_(grad.reshape(n, D).to(torch.float64))
             q.zero_()
 
+        q_base = q.data_ptr()
+
         def cb(n_chains, dim, _q, _g, _lp, stream_ptr):
             # run the torch work on the engine's stream: no cross-stream synchronisation needed
             st = streams.get(stream_ptr)
             if st is None:
                 st = torch.cuda.ExternalStream(stream_ptr, device=dev) if stream_ptr else torch.cuda.default_stream(dev)
                 streams[stream_ptr] = st
+            # (engine option host_groups: the callback is asked for ONE group of chains — the pointers are rows of the staging buffers)
+            lo = (int(_q) - q_base) // (8 * D) if _q else 0
+            whole = lo == 0 and int(n_chains) == n
+            qv, gv, lpv = (q, g, lp) if whole else (q[lo:lo + n_chains], g[lo:lo + n_chains], lp[lo:lo + n_chains])
             with torch.cuda.stream(st):
-                if graph is not None:
+                if graph is not None and whole:
                     graph.replay()
                 elif in_place:
-                    logp_fn(q, lp, g)         # writes the engine's staging buffers itself: no copies, nothing allocated
+                    logp_fn(qv, lpv, gv)         # writes the engine's staging buffers itself: no copies, nothing allocated
                 else:
-                    val, grad = logp_fn(q)
-                    lp.copy_(val.reshape(n).to(torch.float64))
-                    g.copy_(grad.reshape(n, D).to(torch.float64))
+                    val, grad = logp_fn(qv)
+                    lpv.copy_(val.reshape(-1).to(torch.float64))
+                    gv.copy_(grad.reshape(-1, D).to(torch.float64))
             return 0
 
         model = _lib.DeviceCallbackModel(D, cb)

@@ -661,6 +661,7 @@ struct nphip_sampler {
     uint64_t cb_replays = 0;
     uint64_t cb_polls = 0;
     bool iteration_callback(bool& all_done, int& have);
+    bool iteration_callback_groups(bool& all_done, int& have);
     // host callbacks, zero-copy staging: chains in groups, each on its own stream, completion by a flag in pinned memory
     // (no stream synchronisation): the kernel of one group runs while the host evaluates the rows of the other
     static constexpr int kMaxGroups = 8;
@@ -669,6 +670,7 @@ struct nphip_sampler {
     uint64_t grp_lo[kMaxGroups + 1] = {};
     unsigned grp_seq[kMaxGroups] = {};
     bool grp_primed = false;
+    int cb_groups = 0;   // device callbacks in groups of chains (launch.host_groups >= 2): group g's (kernel, callback) on its own stream
     volatile unsigned long long* h_grp_flag = nullptr;  // pinned [groups][4]
     // Resident launches (kernels.hip: REMOTE): a group's kernel stays on the device for `persist_evals` evaluations; an evaluation
     // is a rendezvous — the kernel publishes its positions and the sequence number, the host evaluates the rows and answers
@@ -1002,6 +1004,19 @@ bool nphip_sampler::setup() {
             }
         }
     }
+    if (model.kind == 2 && launch.host_groups >= 2 && !launch.manual && launch.graph_steps <= 0 && n >= 8) {
+        // Device callbacks in groups (round 5): the chains in `host_groups` contiguous groups, each with a stream of its
+        // own on which its k_advance launch and its callback alternate — while one group's callback runs (a GEMM, a torch function) the
+        // other group's engine kernel does.  No flag and no host synchronisation: stream order is the only dependency, the callback
+        // gets the group's rows of the staging buffers (pointers offset, n_chains = the group's).  Bounds on whole workgroups.
+        const uint64_t per_wg = (W == 1) ? 4 : 1, wgs = (n + per_wg - 1) / per_wg;
+        n_groups = (int)std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)launch.host_groups, (uint64_t)kMaxGroups, wgs}));
+        grp_lo[0] = 0;
+        for (int g = 1; g < n_groups; ++g) grp_lo[g] = (wgs * (uint64_t)g / (uint64_t)n_groups) * per_wg;
+        grp_lo[n_groups] = n;
+        for (int g = 0; g < n_groups; ++g) HIP_TRY(hipStreamCreateWithFlags(&grp_stream[g], hipStreamNonBlocking));
+        cb_groups = n_groups;
+    }
     if (model.init_kind == 2) {
         if (model.n_init_points < launch.chain_offset + n) { set_error("explicit init points do not cover all chains"); return false; }
         double* ip = nullptr;
@@ -1137,8 +1152,61 @@ void nphip_sampler::eval_ranges(const RowRange* rg, int nr) {
     timed_batches += 1;
 }
 
+// Device callbacks in groups: one step of every group.  The first step runs on the main stream (it follows the set-up work there).
+bool nphip_sampler::iteration_callback_groups(bool& all_done, int& have) {
+    if ((cb_polls & 7) == 0) {
+        const int slot = (int)((cb_polls >> 3) & 1);
+        if (!cb_ev[slot] && !hip_ok(hipEventCreate(&cb_ev[slot]), "hipEventCreate")) return false;
+        if (cb_polls >= 16 && !hip_ok(hipEventSynchronize(cb_ev[slot]), "hipEventSynchronize")) return false;
+        if (!hip_ok(hipMemcpyAsync(h_counters, args.counters, 16, hipMemcpyDeviceToHost, grp_stream[n_groups - 1]), "copy counters")) return false;
+        if (!hip_ok(hipEventRecord(cb_ev[slot], grp_stream[n_groups - 1]), "hipEventRecord")) return false;
+    }
+    ++cb_polls;
+    volatile unsigned long long* hc = h_counters;
+    if (hc[1] > 0) {
+        for (int g = 0; g < n_groups; ++g) (void)hipStreamSynchronize(grp_stream[g]);
+        set_error(chain_error_message());
+        return false;
+    }
+    if (hc[0] >= n) {
+        all_done = true;
+        for (int g = 0; g < n_groups; ++g)
+            if (!hip_ok(hipStreamSynchronize(grp_stream[g]), "hipStreamSynchronize")) return false;
+        return true;
+    }
+    for (int g = 0; g < n_groups; ++g) {
+        LaunchSlice sl;
+        memset(&sl, 0, sizeof(sl));
+        sl.chain_lo = (int)grp_lo[g];
+        sl.chain_n = (int)(grp_lo[g + 1] - grp_lo[g]);
+        sl.grp = -1;
+        sl.materialise = materialise ? 1 : 0;
+        args.max_evals = 0;
+        args.have_result = have;
+        if (!hip_ok(launch_advance(args, d_args, false, W, grp_stream[g], &sl), "launch k_advance")) return false;
+        launches.fetch_add(g == 0 ? 1 : 0);    // (a step of all groups counts once)
+        const uint64_t lo = grp_lo[g];
+        const int rc = model.dev_fn((uint64_t)sl.chain_n, dim, args.qeval + lo * dim, args.geval + lo * dim, args.ueval + lo, (void*)grp_stream[g], model.user);
+        if (rc < 0) {
+            for (int o = 0; o < n_groups; ++o) (void)hipStreamSynchronize(grp_stream[o]);
+            set_error("device logp callback failed (code " + std::to_string(rc) + ")");
+            return false;
+        }
+    }
+    materialise = false;
+    have = 1;
+    return true;
+}
+
 bool nphip_sampler::iteration_callback(bool& all_done, int& have) {
     if (model.kind == 2 && cb_graph_steps > 0 && have == 1 && !kernel_ms_acc) return iteration_graph(all_done);
+    if (model.kind == 2 && cb_groups > 1 && !kernel_ms_acc) {
+        if (!grp_primed) {   // everything enqueued on the main stream so far (set-up, the chains' start) precedes the groups' first launches
+            if (!hip_ok(hipStreamSynchronize(stream), "hipStreamSynchronize")) return false;
+            grp_primed = true;
+        }
+        return iteration_callback_groups(all_done, have);
+    }
     if (!launch_kernel(false, have)) return false;
     if (model.kind == 1) {
         // host callback: D2H positions, evaluate rows on the host pool, H2D gradients
@@ -1501,7 +1569,7 @@ void nphip_sampler::run() {
         bool ok;
         {
             std::lock_guard<std::mutex> run_lk(mu_run);
-            ok = (fused || dens) ? iteration_fused(all_done) : (remote ? iteration_remote(all_done) : (n_groups > 0 ? iteration_pipelined(all_done) : iteration_callback(all_done, have)));
+            ok = (fused || dens) ? iteration_fused(all_done) : (remote ? iteration_remote(all_done) : ((n_groups > 0 && cb_groups == 0) ? iteration_pipelined(all_done) : iteration_callback(all_done, have)));
         }
         seconds.store(std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count());
         if (!ok) { fail(t_error); break; }
@@ -1646,7 +1714,7 @@ int nphip_sampler_host_mode(const nphip_sampler_t* s) {
     if (s->model.kind != 1) return NPHIP_HOST_MODE_NONE;
     if (s->remote) return NPHIP_HOST_MODE_RESIDENT;
     if (s->remote_fell_back) return NPHIP_HOST_MODE_FELL_BACK;
-    return s->n_groups > 0 ? NPHIP_HOST_MODE_GROUPS : NPHIP_HOST_MODE_LAUNCH_PER_EVALUATION;
+    return (s->n_groups > 0 && s->cb_groups == 0) ? NPHIP_HOST_MODE_GROUPS : NPHIP_HOST_MODE_LAUNCH_PER_EVALUATION;
 }
 
 static bool read_ctl(nphip_sampler_t* s, std::vector<Ctl>& h) {

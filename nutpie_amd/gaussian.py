@@ -110,9 +110,10 @@ def dense_gaussian(dim: int, seed: int = BENCH_RNG_SEED, cond_lo=1e-2, cond_hi=1
         def logp(x, out_logp, out_grad):
             # three kernels, all writing preallocated buffers: grad = -x P (fp64 GEMM) into the engine's staging buffer, x * grad, and its
             # row sums times 1/2 (a GEMV) into the staging log-density
-            t = tmp.get(x.shape[0])
+            key = (x.data_ptr(), x.shape[0])       # (engine option host_groups: groups of chains run concurrently on their own streams)
+            t = tmp.get(key)
             if t is None:
-                t = tmp[x.shape[0]] = torch.empty_like(x)
+                t = tmp[key] = torch.empty_like(x)
             torch.mm(x, negP, out=out_grad)
             torch.mul(x, out_grad, out=t)
             torch.mv(t, half, out=out_logp)

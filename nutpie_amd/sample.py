@@ -283,6 +283,7 @@ def sample(
     device: int | None = None,
     waves_per_chain: int = 0,
     store_draws: bool = True,
+    host_groups: int = 0,
     **kwargs,
 ):
     """Sample the posterior of a compiled model on an MI355X.
@@ -296,7 +297,8 @@ def sample(
 
     Engine-specific: ``waves_per_chain`` (0 = a function of the dimension only, so that a chain's result never
     depends on how many chains run with it; with fewer than ~256 chains and a fused model of D >= 512,
-    ``waves_per_chain=4`` is about 20 % faster), ``store_draws``, ``device``.
+    ``waves_per_chain=4`` is about 20 % faster), ``store_draws``, ``device``, ``host_groups`` (callback models: the chains in that
+    many groups, each group's engine kernel and callback on a stream of its own — one group's callback overlaps another's kernel).
     """
     # behaviour (accepted keywords, warnings, error texts) documented at reference sample.py:979-1070; written independently
     adaptation, grad_based = _legacy_adaptation(adaptation, kwargs)
@@ -313,6 +315,8 @@ def sample(
         init_mean = np.zeros(compiled_model.n_dim)
 
     engine_kwargs = {"waves_per_chain": waves_per_chain, "store_draws": store_draws}
+    if host_groups:
+        engine_kwargs["host_groups"] = int(host_groups)
     if device is not None:
         engine_kwargs["device"] = device
 

@@ -667,3 +667,28 @@ def test_low_rank_adaptation_on_a_correlated_gaussian():
     assert "gradient" not in lr.sample_stats                       # the estimator's gradients stay internal
     assert lr.sample_stats.attrs["inference_library_settings"].count('"adaptation": "low_rank"') == 1
 
+
+
+def test_device_callback_in_groups_draws_the_same():
+    """Engine option ``host_groups`` for a batched device callback (round 5): the chains in groups, each group's engine kernel and
+    callback on a stream of its own so that one group's callback overlaps the other's kernel.  A callback whose rows do not depend on
+    what else is in the batch gives the same trace, bit for bit, as one launch and one callback for all chains."""
+    import torch
+
+    sd = torch.exp(torch.linspace(-1.0, 1.0, 37, dtype=torch.float64, device="cuda"))
+
+    def make_logp():
+        def f(x):
+            z = x / sd
+            return -0.5 * (z * z).sum(-1), -z / sd
+
+        return f
+
+    m = nutpie_amd.from_torchfunc(37, make_logp)
+    kw = dict(chains=96, tune=120, draws=60, seed=4, progress_bar=False)
+    a = nutpie_amd.sample(m, **kw)
+    for groups in (2, 3):
+        b = nutpie_amd.sample(m, host_groups=groups, **kw)
+        assert np.array_equal(a.posterior.x.values, b.posterior.x.values)
+        assert np.array_equal(a.sample_stats.n_steps.values, b.sample_stats.n_steps.values)
+    np.testing.assert_allclose(a.posterior.x.values.std((0, 1)), sd.cpu().numpy(), rtol=0.12)
