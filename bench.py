@@ -54,6 +54,7 @@ from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -210,7 +211,7 @@ def measured_traffic(dim, W, lean):
     return (e["bytes_per_leapfrog"], e["source"]) if e else (None, None)
 
 
-def roofline(dim, W, chains, leap_per_launch, avg_kernel_s):
+def roofline(dim, W, chains, leap_per_launch, avg_kernel_s, leap_per_draw=None):
     """The `roofline` object of the JSON line (module docstring).  Live: the kernel duration.  From profiles/: bytes and
     instructions per leapfrog of this kernel at the timed configuration."""
     e = pmc_entry(dim, W)
@@ -236,13 +237,24 @@ def roofline(dim, W, chains, leap_per_launch, avg_kernel_s):
         waves = min(chains * W, N_SIMD * 8)
         peak = waves * CLOCK_HZ / CYCLES_PER_ISSUE / 1e9
         ach = ipl * leap_per_launch / avg_kernel_s / 1e9
-        # the honest companion figure (VERDICT r3): of the instructions the kernel issues per leapfrog, how many are the fp64 operations
-        # the mathematics needs — 19 per element (leapfrog 9, gradient 5, logp 1, level-0 criterion 4), 16 elements per lane at D = 1000
-        useful = 19.0 * ((dim + 127) // 128) * 2
+        # the honest companion figure (VERDICT r3, r4): of the instructions the kernel issues per leapfrog, how many are the fp64 operations
+        # the mathematics needs — per element 19 for the leaf itself (leapfrog 9, gradient 5, logp 1, level-0 criterion 4) plus the
+        # U-turn criteria of the merge levels >= 1 a leaf closes: 3 criteria x 6 operations per level, and a tree of final depth dd closes
+        # (2^dd - 1 - dd) such levels and dd top-level merges (2.5 criteria on average) over its 2^dd - 1 leaves
+        elems = ((dim + 127) // 128) * 2
+        dd = math.log2((leap_per_draw or 31.0) + 1.0)
+        leaves = 2.0 ** dd - 1.0
+        levels_per_leaf = max(0.0, (leaves - dd) / leaves)
+        top_per_leaf = dd / leaves
+        per_elem = 19.0 + 18.0 * levels_per_leaf + 15.0 * top_per_leaf
+        useful = per_elem * elems
         out["useful_work"] = {"useful_fp64_insts_per_leapfrog": useful, "fraction_of_issued": useful / ipl,
                               "fraction_of_issue_slots": useful * leap_per_launch / avg_kernel_s / 1e9 / peak,
-                              "note": "19 fp64 operations per element x elements per lane; everything else the kernel issues is tree bookkeeping, reductions, "
-                                      "register traffic (AGPR moves, SGPR spill lanes) and address arithmetic"}
+                              "per_element": {"leaf": 19.0, "merge_levels_per_leaf": levels_per_leaf, "top_level_merges_per_leaf": top_per_leaf, "total": per_elem},
+                              "leapfrogs_per_draw": leap_per_draw,
+                              "note": "fp64 operations per element (leaf 19 + merge criteria of the levels a leaf closes, from the measured leapfrogs per draw) x elements "
+                                      "per lane; everything else the kernel issues is tree bookkeeping, reductions, register traffic (AGPR moves, SGPR spill "
+                                      "lanes) and address arithmetic"}
         out.update({"bound": "issue", "achieved": ach, "peak": peak, "unit": "G wave-instructions/s", "frac": ach / peak,
                     "issue": {"insts_per_leapfrog": e["insts_per_leapfrog"], "pmc_issuing_fraction_of_wave_cycles": e.get("issuing_fraction"),
                               "pmc_waiting_fraction_of_wave_cycles": e.get("waiting_fraction"), "resident_waves": waves,
@@ -617,6 +629,25 @@ def other_configs(env, args):
                          "nutpie_amd.from_torch_density traces (torch.fx), differentiates and compiles into its own resident kernel")
         return r
 
+    def c3_two_jobs():
+        # 512 chains are 512 wavefronts on 1024 SIMDs: a second, independent 512-chain job (its own sampler, driver thread and stream)
+        # runs beside the first on the other half of the device
+        from nutpie_amd.radon import radon_symbolic_model
+
+        m = radon_symbolic_model().compile()
+        t0 = time.perf_counter()
+        smps = [m._make_sampler(settings(512, 400, 1000, seed=20260926 + k), None, 1, None, None, None, None) for k in range(2)]
+        for smp in smps:
+            smp.wait()
+        wall = time.perf_counter() - t0
+        n = sum(int(smp._copy("n_steps", np.int64).sum()) for smp in smps)
+        secs = [smp.seconds for smp in smps]
+        for smp in smps:
+            smp.close()
+        return {"leapfrogs_per_s": n / max(secs), "leapfrogs_per_s_over_wall": n / wall, "job_s": secs, "wall_incl_setup_s": wall, "leapfrogs": n,
+                "workload": "TWO independent radon jobs of 512 chains each (generated density), started together: each occupies half of the SIMDs; "
+                            "rate = leapfrogs of both / the longer job's engine time"}
+
     def c3_torch():
         from nutpie_amd.radon import radon_model
 
@@ -651,6 +682,7 @@ def other_configs(env, args):
 
     leg("config3_radon_generated_density", c3_generated)
     leg("config3_radon_generated_density_low_rank", c3_low_rank)
+    leg("config3_two_concurrent_512_chain_jobs", c3_two_jobs)
     leg("config3_radon_torch_density", c3_traced)
     leg("config3_radon_torch_density_eager", c3_torch)
     leg("config4_eight_schools_host_callback", c4)
@@ -703,7 +735,9 @@ def main(argv=None):
                         "leapfrogs_per_s_kernel_time": leapfrogs / (kms / 1e3), "note": "all chains through tune = 400 draws (untimed set-up of the "
                         "bench; includes initial points, step-size search, mass-matrix adaptation; wall time includes progress polling)"}
     smp.step(args.warmup)
-    tuning0 = sum(p.tuning for p in smp.progress())
+    prog0 = smp.progress()
+    tuning0 = sum(p.tuning for p in prog0)
+    draws0 = sum(p.finished_draws for p in prog0)
     try:
         elapsed, leap, kernel_ms, prog = timed_launches(env, smp, K, num_tune + n_draws)
     except InvalidRegion as e:
@@ -715,6 +749,7 @@ def main(argv=None):
     leap, kernel_ms_sum = env.all_sum([leap, kernel_ms])
     kernel_ms = kernel_ms_sum / world
     draws_stored = int(sum(p.finished_draws for p in prog)) if store else 0
+    draws_in_region = env.all_sum([float(sum(p.finished_draws for p in prog) - draws0)])[0]
     smp.close()
 
     avg_kernel_s = kernel_ms / 1000.0 / K
@@ -728,7 +763,7 @@ def main(argv=None):
                    "evals_per_launch": E, "leapfrogs_per_step": leap / K, "phase": args.phase, "positions_stored": store,
                    "draws_finished_all_chains": draws_stored, "timed_region_s": elapsed,
                    "chains_tuning_at_start": int(tuning0), "chains_tuning_at_end": int(tuning1), "parallelism": f"chains{world}"},
-        "roofline": roofline(args.dim, W, args.chains, leap_per_launch, avg_kernel_s),
+        "roofline": roofline(args.dim, W, args.chains, leap_per_launch, avg_kernel_s, leap_per_draw=(leap / draws_in_region) if draws_in_region > 0 else None),
         "ranks": {"world": world, "backend": (dist.get_backend() if dist is not None else None),
                   "collective_ranks": (dist.get_world_size() if dist is not None else 1), "per_rank": per_rank,
                   "launched_by": "torch.distributed.run" if "RANK" in os.environ else "single process",
