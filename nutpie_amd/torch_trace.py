@@ -461,6 +461,33 @@ class _Interp:
         return _Sym(base.expr + add, base.shape)
 
 
+def _scatter_replace(it: "_Interp", base, src, target_flat: np.ndarray) -> _Sym:
+    """``base`` with the elements ``target_flat`` (one per element of ``src``, all different) replaced by ``src``"""
+    torch = it.torch
+    if len(np.unique(target_flat)) != target_flat.size:
+        raise UnsupportedTorchOp("an indexed assignment with repeated indices (the result depends on the order of the writes; accumulate with index_add)")
+    if isinstance(base, torch.Tensor):
+        base = torch.nan_to_num(base.to(torch.float64), nan=0.0, posinf=0.0, neginf=0.0)      # (torch.empty: whatever was in memory)
+    b = it.sym(base)
+    n_out = _numel(b.shape)
+    sv = it.sym(src)
+    se = sv.expr
+    n_src = target_flat.size
+    if n_out == 1:
+        return _Sym(se if se.dim is None else S.elem(se, 0), b.shape)
+    if se.dim is None:
+        se = S._bcast(se, it.dim(n_src)) if n_src > 1 else se
+    mask = np.zeros(n_out)
+    mask[target_flat] = 1.0
+    if n_src == 1:
+        placed = se                                     # one element: the scalar, selected by the mask
+    else:
+        placed = S._segsum(se, it.index(target_flat, n_src, n_out))
+    if mask.all():
+        return _Sym(placed, b.shape)
+    return _Sym(S.select(it.data(mask) - 0.5, placed, b.expr), b.shape)
+
+
 def _pow_const(e: Expr, c: float) -> Expr:
     if c == 0.0:
         return Expr.const(1.0)
@@ -564,6 +591,8 @@ def _run(gm, it: _Interp, x_shape, data_values: dict[str, Any]):
         name = tgt.__name__ if hasattr(tgt, "__name__") else str(tgt)
         pkt = getattr(tgt, "overloadpacket", None)
         base = pkt.__name__ if pkt is not None else name
+        if base.endswith("_copy") and base not in ("_to_copy", "lift_fresh_copy"):
+            base = base[:-5]                      # (functionalised views: slice_copy, select_copy, view_copy, expand_copy ... move data like their views)
         a0 = args[0] if args else None
 
         # ---------------- the position vector: pieces become parameters
@@ -738,7 +767,32 @@ def _run(gm, it: _Interp, x_shape, data_values: dict[str, Any]):
                 dims = [dims]
             dims = sorted({d_ % nd for d_ in dims}) if nd else []
             if _numel(tuple(s_ for i_, s_ in enumerate(shp) if i_ not in dims)) != 1:
-                raise UnsupportedTorchOp(f"{name} along an axis of a tensor with more than one row (only whole-vector maxima have a counterpart)")
+                # along ONE short axis of a tensor with several rows (a multinomial logit: log_softmax of [observations, classes]): the
+                # maximum of every row as a chain of selects over the axis' slices, then the shifted sums as segment sums
+                if len(dims) != 1 or shp[dims[0]] > 32:
+                    raise UnsupportedTorchOp(f"{name} along an axis of more than 32 elements of a tensor with several rows")
+                ax = dims[0]
+                keep = bool(args[2] if len(args) > 2 else kwargs.get("keepdim", False)) if base in ("amax", "amin", "logsumexp") else False
+                sign = -1.0 if base in ("amin", "min") else 1.0
+                cols = [it.move(v_, lambda t, k_=k_: t.select(ax, k_).unsqueeze(ax)) for k_ in range(shp[ax])]
+                m_ = cols[0] if sign > 0 else _Sym(-cols[0].expr, cols[0].shape)
+                for c_ in cols[1:]:
+                    ce = c_.expr if sign > 0 else -c_.expr
+                    m_ = _Sym(S.select(ce - m_.expr, ce, m_.expr, False), m_.shape)
+                squeeze = (lambda sv: sv if keep else it.move(sv, lambda t: t.squeeze(ax)))
+                if base in ("amax", "amin", "max", "min"):
+                    env[node] = squeeze(_Sym(m_.expr if sign > 0 else -m_.expr, m_.shape))
+                    continue
+                sh = B(v_, m_, lambda x_, y_: x_ - y_)
+                ex = U(sh, S.exp)
+                tot = it.sum(ex, [ax], True)
+                if base == "logsumexp":
+                    env[node] = squeeze(B(m_, U(tot, S.log), lambda x_, y_: x_ + y_))
+                elif base in ("_softmax", "softmax"):
+                    env[node] = B(ex, tot, lambda x_, y_: x_ / y_)
+                else:
+                    env[node] = B(sh, U(tot, S.log), lambda x_, y_: x_ - y_)
+                continue
             keep = bool(args[2] if len(args) > 2 else kwargs.get("keepdim", False)) if base in ("amax", "amin", "logsumexp") else False
             oshape = tuple(1 if i_ in dims else s_ for i_, s_ in enumerate(shp)) if keep else tuple(s_ for i_, s_ in enumerate(shp) if i_ not in dims)
             e = v_.expr
@@ -834,9 +888,27 @@ def _run(gm, it: _Interp, x_shape, data_values: dict[str, Any]):
                 tflat = np.zeros(1, dtype=np.int64)
             del tmap
             env[node] = it.scatter_add(args[0], src, tflat)
+        elif base == "copy":
+            src = it.sym(args[1])
+            shp = it.shape_of(args[0])
+            env[node] = _Sym(it.broadcast(src, shp), shp)
+        elif base in ("slice_scatter", "select_scatter", "diagonal_scatter"):
+            base_shape = it.shape_of(args[0])
+            view = {"slice_scatter": torch.ops.aten.slice.Tensor, "select_scatter": torch.ops.aten.select.int, "diagonal_scatter": torch.ops.aten.diagonal.default}[base]
+            tmap = view(torch.arange(_numel(base_shape), dtype=torch.int64).reshape(base_shape), *args[2:], **kwargs)
+            src = it.sym(args[1])
+            srcb = _Sym(it.broadcast(src, tuple(tmap.shape)), tuple(tmap.shape))
+            env[node] = _scatter_replace(it, args[0], srcb, tmap.reshape(-1).numpy())
+        elif base == "index_put" and not (args[3] if len(args) > 3 else kwargs.get("accumulate", False)):
+            idx = args[1]
+            if any_traced(idx):
+                raise UnsupportedTorchOp("index_put with a traced index")
+            base_shape = it.shape_of(args[0])
+            tmap = torch.ops.aten.index.Tensor(torch.arange(_numel(base_shape), dtype=torch.int64).reshape(base_shape), idx)
+            src = it.sym(args[2])
+            srcb = _Sym(it.broadcast(src, tuple(tmap.shape)), tuple(tmap.shape))
+            env[node] = _scatter_replace(it, args[0], srcb, tmap.reshape(-1).numpy())
         elif base == "index_put":
-            if not (args[3] if len(args) > 3 else kwargs.get("accumulate", False)):
-                raise UnsupportedTorchOp("index_put without accumulate")
             idx = args[1]
             if any_traced(idx):
                 raise UnsupportedTorchOp("index_put with a traced index")
@@ -884,8 +956,11 @@ def trace(logp_fn: Callable, n_dim: int, *, batched: bool = True, shared_data: d
     validate = Distribution._validate_args
     Distribution.set_default_validate_args(False)
     def run_make_fx(device):
+        # (functionalised first: `y.mul_(2)`, `out[:3] = y`, `tot.index_add_(0, idx, a)` become out-of-place operations + scatters)
+        from torch.func import functionalize
+
         with torch.no_grad():
-            return make_fx(fn)(example.to(device), *[tens[k].to(device) for k in names])
+            return make_fx(functionalize(fn, remove="mutations_and_views"))(example.to(device), *[tens[k].to(device) for k in names])
 
     try:
         try:

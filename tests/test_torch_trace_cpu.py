@@ -128,3 +128,15 @@ def test_generated_source_of_a_traced_model_compiles_for_gfx950():
     D, fn, batched, shared = TM.gamma_poisson()           # (lgamma / digamma helper, selects, segment sums)
     m = nutpie_amd.from_torch_density(D, fn, compile=True, batched=False)
     assert os.path.exists(m.library_path())
+
+
+def test_an_indexed_assignment_with_repeated_indices_is_refused():
+    idx = torch.tensor([0, 1, 1])
+
+    def logp(x):
+        tot = torch.zeros(2, dtype=x.dtype)
+        tot[idx] += x[:3]                 # (eager torch keeps ONE of the two writes to tot[1]: not a sum)
+        return -(tot * tot).sum()
+
+    with pytest.raises(UnsupportedTorchOp, match="repeated indices"):
+        trace(logp, 3, batched=False)

@@ -199,3 +199,52 @@ def softmax_mixture():
 
 
 ALL["softmax_mixture"] = softmax_mixture
+
+
+def inplace_ops():
+    """in-place operations and indexed assignments (functionalised by the tracer): ``y.mul_``, ``y += 1``, ``out[:3] = y``, ``out[3] = s``,
+    ``tot[perm] += v`` with distinct indices, ``index_add_`` with repeated ones"""
+    idx = torch.tensor([0, 2, 1, 2, 0, 1, 1])
+    perm = torch.tensor([2, 0, 1])
+
+    def logp(x):
+        a, b = x[:7], x[7:10]
+        tot = torch.ones(3, dtype=x.dtype)
+        tot[perm] += b * b
+        tot2 = torch.zeros(3, dtype=x.dtype)
+        tot2.index_add_(0, idx, a)
+        y = b.clone()
+        y.mul_(2.0)
+        y += 1.0
+        out = torch.empty(4, dtype=x.dtype)
+        out[:3] = y
+        out[3] = a.sum()
+        return -(tot * b).sum() - 0.5 * (tot2 * tot2).sum() - 0.5 * (out * out).sum() - 0.5 * (a * a).sum()
+
+    return 10, logp, False, {}
+
+
+ALL["inplace_ops"] = inplace_ops
+
+
+def multinomial_logit():
+    """a categorical regression: ``log_softmax`` along the class axis of [observations, classes] logits, a 2-D coefficient matrix with
+    its last class pinned to zero (``cat`` with a constant), ``logsumexp`` / ``amax`` along an axis"""
+    rng = np.random.default_rng(17)
+    N, P, K = 60, 3, 4
+    X = _t(rng.normal(size=(N, P)))
+    ycls = torch.as_tensor(rng.integers(0, K, size=N))
+    onehot = torch.nn.functional.one_hot(ycls, K).to(torch.float64)
+
+    def logp(x):
+        W = x[: P * (K - 1)].reshape(P, K - 1)
+        b = x[P * (K - 1):]
+        eta = torch.cat([X @ W + b, torch.zeros(N, 1, dtype=x.dtype)], 1)           # [N, K]
+        ll = (onehot * torch.log_softmax(eta, -1)).sum()
+        reg = -0.01 * torch.logsumexp(eta, 1).sum() - 0.01 * torch.amax(eta, 1).sum()
+        return ll + reg - 0.5 * (W * W).sum() - 0.5 * (b * b).sum()
+
+    return P * (K - 1) + (K - 1), logp, False, {}
+
+
+ALL["multinomial_logit"] = multinomial_logit
