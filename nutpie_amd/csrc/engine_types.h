@@ -191,7 +191,9 @@ struct Args {
     // v = M^-1 p of the state, which the U-turn criteria read instead of recomputing sigma^2 p
     int32_t pvec;          // vectors per P-slot: 2 (p, rho) or 3 (p, rho, v)
     int32_t lr_on;         // the job may receive host metrics: lr_V / lr_lam / lr_std are allocated
-    double* lr_V;          // [n][kLrMax][ld]  orthonormal columns (rows here), zero beyond dim and beyond lr_k
+    float* lr_V;           // [n][kLrMax][ld]  orthonormal columns (rows here), zero beyond dim and beyond lr_k — SINGLE precision in memory (round 5):
+                           // the columns' traffic bounds the low-rank leapfrog (four passes per step), every operation on them is fp64 on the
+                           // values fp32 holds; the metric that is applied is the one of the rounded columns (include/nphip_spec.h)
     double* lr_lam;        // [n][kLrMax]      eigenvalues
     double* lr_std;        // [n][ld]          sqrt(sigma^2)
     const void* dens_data;       // the model's data block (device memory; layout defined by the generated prelude of the density source)

@@ -177,6 +177,13 @@ typedef NPHIP_LDS double* LdsDouble;
 
 __device__ __forceinline__ double2 ld2(const double* p, int64_t i) { return *(const NPHIP_GLOBAL double2*)(p + i); }
 __device__ __forceinline__ void st2(double* p, int64_t i, double2 v) { *(NPHIP_GLOBAL double2*)(p + i) = v; }
+// a pair of single-precision values as doubles (the columns of the low-rank metric: fp32 in memory, every operation on them fp64)
+__device__ __forceinline__ double2 ld2f(const float* p, int64_t i) {
+    const float2 f = *(const NPHIP_GLOBAL float2*)(p + i);
+    double2 v;
+    v.x = (double)f.x; v.y = (double)f.y;
+    return v;
+}
 __device__ __forceinline__ double ld1(const double* p, int64_t i) { return *(const NPHIP_GLOBAL double*)(p + i); }
 __device__ __forceinline__ void st1(double* p, int64_t i, double v) { *(NPHIP_GLOBAL double*)(p + i) = v; }
 // the same with a 32-bit byte offset per lane: with a uniform base the access is `global_load ... v_off, s[base:base+1]` — ONE
@@ -322,7 +329,7 @@ struct Machine {
     // 18 us per launch)
     static constexpr bool LRK = NV == -1 || LR;
     __device__ __forceinline__ bool lr_job() const { return LRK && A.lr_on != 0; }
-    __device__ __forceinline__ const double* LRV(int j) const { return A.lr_V + ((size_t)chain * kLrMax + j) * ld; }
+    __device__ __forceinline__ const float* LRV(int j) const { return A.lr_V + ((size_t)chain * kLrMax + j) * ld; }
     __device__ __forceinline__ double* EST(int64_t e, int k) const { return est + (size_t)(e * 4 + k) * ld; }
     __device__ __forceinline__ bool leader() const { return lane == 0 && wave == 0; }
     // chain-wide sums.  Consecutive reductions alternate between two LDS areas: by the time an area is written again
@@ -480,7 +487,7 @@ struct Machine {
         for (int j0 = 0; j0 < kLrMax; j0 += 4) if (j0 < kq) {
             double2 vj[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) vj[t] = ld2(LRV(j0 + t), i);
+            for (int t = 0; t < 4; ++t) vj[t] = ld2f(LRV(j0 + t), i);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 S_.a[j0 + t].x = fma(vj[t].x, u.x, S_.a[j0 + t].x);
@@ -490,7 +497,7 @@ struct Machine {
         if (kq != k) {
 #pragma unroll
             for (int j = 0; j < kLrMax; ++j) if (j >= kq && j < k) {
-                const double2 vj = ld2(LRV(j), i);
+                const double2 vj = ld2f(LRV(j), i);
                 S_.a[j].x = fma(vj.x, u.x, S_.a[j].x);
                 S_.a[j].y = fma(vj.y, u.y, S_.a[j].y);
             }
@@ -516,7 +523,7 @@ struct Machine {
         for (int j0 = 0; j0 < kLrMax; j0 += 4) if (j0 < kq) {
             double2 vj[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) vj[t] = ld2(LRV(j0 + t), i);
+            for (int t = 0; t < 4; ++t) vj[t] = ld2f(LRV(j0 + t), i);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 w.x = fma(vj[t].x, cf[j0 + t], w.x);
@@ -526,7 +533,7 @@ struct Machine {
         if (kq != k) {
 #pragma unroll
             for (int j = 0; j < kLrMax; ++j) if (j >= kq && j < k) {
-                const double2 vj = ld2(LRV(j), i);
+                const double2 vj = ld2f(LRV(j), i);
                 w.x = fma(vj.x, cf[j], w.x);
                 w.y = fma(vj.y, cf[j], w.y);
             }
@@ -553,7 +560,7 @@ struct Machine {
         if constexpr (KC > 0) {
             double2 vj[KC];
 #pragma unroll
-            for (int t = 0; t < KC; ++t) vj[t] = ld2(LRV(t), i);
+            for (int t = 0; t < KC; ++t) vj[t] = ld2f(LRV(t), i);
 #pragma unroll
             for (int t = 0; t < KC; ++t) {
                 S_.a[t].x = fma(vj[t].x, u.x, S_.a[t].x);
@@ -565,7 +572,7 @@ struct Machine {
         if constexpr (KC > 0) {
             double2 vj[KC];
 #pragma unroll
-            for (int t = 0; t < KC; ++t) vj[t] = ld2(LRV(t), i);
+            for (int t = 0; t < KC; ++t) vj[t] = ld2f(LRV(t), i);
 #pragma unroll
             for (int t = 0; t < KC; ++t) {
                 w.x = fma(vj[t].x, cf[t], w.x);
@@ -3910,7 +3917,7 @@ __global__ void k_set_metric(const Args* __restrict__ Ap, int n, const int64_t* 
         A.sig2[(size_t)ch * A.ld + i] = s2;
         A.lr_std[(size_t)ch * A.ld + i] = sqrt(s2);
         for (int j = 0; j < kLrMax; ++j)
-            A.lr_V[((size_t)ch * kLrMax + j) * A.ld + i] = (j < k && i < A.dim) ? V[((size_t)blockIdx.x * k + j) * A.dim + i] : 0.0;
+            A.lr_V[((size_t)ch * kLrMax + j) * A.ld + i] = (j < k && i < A.dim) ? (float)V[((size_t)blockIdx.x * k + j) * A.dim + i] : 0.0f;   // (rounded to nearest: the contract)
     }
     if (threadIdx.x < kLrMax) A.lr_lam[(size_t)ch * kLrMax + threadIdx.x] = (int)threadIdx.x < k ? lam[(size_t)blockIdx.x * k + threadIdx.x] : 1.0;
     __syncthreads();

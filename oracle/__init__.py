@@ -80,7 +80,9 @@ class Settings(C.Structure):
             self.metric_draws[i] = int(d)
         self.metric_sig2 = sig2.ctypes.data
         if k:
-            V = np.ascontiguousarray(V, dtype=np.float64)
+            # (the contract stores the columns in single precision — include/nphip_spec.h, engine_types.h: lr_V — and computes with the
+            #  values fp32 holds: the oracle is handed the same rounded columns)
+            V = np.ascontiguousarray(np.asarray(V, dtype=np.float64).astype(np.float32), dtype=np.float64)
             lam = np.ascontiguousarray(lam, dtype=np.float64)
             assert V.shape == (U, n, k, sig2.shape[2]) and lam.shape == (U, n, k)
             self._keep += [V, lam]
