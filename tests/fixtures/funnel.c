@@ -1,0 +1,26 @@
+/*
+ * funnel.c — test fixture (written for this repo; not reference code).
+ *
+ * Neal's funnel as the reference's documentation defines it (docs/sample-stats.qmd:18-22):
+ *   log_sigma ~ Normal(0, 1);  x[5] ~ Normal(0, exp(log_sigma))          D = 6, x = (log_sigma, x_0 .. x_4)
+ * with the reference's raw C logp callback signature (src/pymc.rs:23-29).  The reference's frozen docs hold the final step sizes,
+ * last-draw gradient counts and divergence counts of 6 chains of nuts-rs on this model (tests/golden/reference_doc_step_sizes.json:
+ * "funnel_diag"): tests/test_oracle_reference_pins.py runs the oracle on it.
+ */
+#include <math.h>
+#include <stdint.h>
+
+int64_t funnel_logp(uint64_t dim, const double* x, double* grad, double* logp, void* user) {
+    (void)user;
+    if (dim != 6) return -1;
+    const double ls = x[0], inv_var = exp(-2.0 * ls);
+    double ss = 0.0;
+    for (int i = 1; i < 6; ++i) {
+        ss += x[i] * x[i];
+        grad[i] = -x[i] * inv_var;
+    }
+    /* -ls^2/2 - 5 ls - sum x^2 / (2 sigma^2)  (constants dropped) */
+    *logp = -0.5 * ls * ls - 5.0 * ls - 0.5 * ss * inv_var;
+    grad[0] = -ls - 5.0 + ss * inv_var;
+    return 0;
+}

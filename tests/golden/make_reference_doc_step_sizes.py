@@ -26,7 +26,7 @@ def tables(doc):
     return out
 
 
-idx, stan, pymc = tables("index"), tables("stan-usage"), tables("pymc-usage")
+idx, stan, pymc, stats = tables("index"), tables("stan-usage"), tables("pymc-usage"), tables("sample-stats")
 fixture = {
     "_source": "docs/_freeze/{index,stan-usage,pymc-usage}/execute-results/html.json of the reference (progress tables of the executed cells)",
     "_settings": "nutpie.sample(compiled): 6 chains, tune 400, draws 1000, every other setting default",
@@ -37,6 +37,10 @@ fixture = {
                         "cites": ["docs/pymc-usage.qmd:53-79", "docs/pymc-usage.qmd:173-187"]},
     # the same model after with_data(x=[4, 5, 6])   (docs/pymc-usage.qmd:191-194)
     "regression_x456": {"posterior": "precision [[301, 1500], [1500, 7701]], X'y / sigma^2 = [600, 3200]", "runs": [pymc[2]], "cites": ["docs/pymc-usage.qmd:191-194"]},
+    # Neal's funnel: log_sigma ~ N(0, 1); x[5] ~ N(0, exp(log_sigma)); nutpie.sample(compiled, tune=1000, seed=42, ...)   (docs/sample-stats.qmd:18-35)
+    "funnel_diag": {"settings": "tune 1000, draws 1000, adaptation diag (default)", "runs": [stats[0]], "cites": ["docs/sample-stats.qmd:18-35"]},
+    # the same model with adaptation="low_rank" (docs/sample-stats.qmd:256-268): default mass_matrix_eigval_cutoff / mass_matrix_gamma
+    "funnel_low_rank": {"settings": "tune 1000, draws 1000, adaptation low_rank", "runs": [stats[1]], "cites": ["docs/sample-stats.qmd:256-268"]},
 }
 json.dump(fixture, open(OUT, "w"), indent=1)
 print(OUT, {k: [len(r) for r in v["runs"]] for k, v in fixture.items() if not k.startswith("_")})
