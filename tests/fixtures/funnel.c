@@ -24,3 +24,21 @@ int64_t funnel_logp(uint64_t dim, const double* x, double* grad, double* logp, v
     grad[0] = -ls - 5.0 + ss * inv_var;
     return 0;
 }
+
+/* docs/sample-stats.qmd:141-145: x ~ Normal(0, 1); y ~ Normal(x, 0.01); z[100] ~ Normal(y, 1).  D = 102, position (x, y, z_0 .. z_99). */
+int64_t correlated_102d_logp(uint64_t dim, const double* q, double* grad, double* logp, void* user) {
+    (void)user;
+    if (dim != 102) return -1;
+    const double x = q[0], y = q[1], r = (y - x) * 1.0e4;       /* (y - x) / 0.01^2 */
+    double lp = -0.5 * x * x - 0.5 * (y - x) * r, sz = 0.0;
+    for (int i = 0; i < 100; ++i) {
+        const double d = q[2 + i] - y;
+        lp -= 0.5 * d * d;
+        sz += d;
+        grad[2 + i] = -d;
+    }
+    grad[0] = -x + r;
+    grad[1] = -r + sz;
+    *logp = lp;
+    return 0;
+}

@@ -39,8 +39,10 @@ fixture = {
     "regression_x456": {"posterior": "precision [[301, 1500], [1500, 7701]], X'y / sigma^2 = [600, 3200]", "runs": [pymc[2]], "cites": ["docs/pymc-usage.qmd:191-194"]},
     # Neal's funnel: log_sigma ~ N(0, 1); x[5] ~ N(0, exp(log_sigma)); nutpie.sample(compiled, tune=1000, seed=42, ...)   (docs/sample-stats.qmd:18-35)
     "funnel_diag": {"settings": "tune 1000, draws 1000, adaptation diag (default)", "runs": [stats[0]], "cites": ["docs/sample-stats.qmd:18-35"]},
-    # the same model with adaptation="low_rank" (docs/sample-stats.qmd:256-268): default mass_matrix_eigval_cutoff / mass_matrix_gamma
-    "funnel_low_rank": {"settings": "tune 1000, draws 1000, adaptation low_rank", "runs": [stats[1]], "cites": ["docs/sample-stats.qmd:256-268"]},
+    # x ~ N(0, 1); y ~ N(x, 0.01); z[100] ~ N(y, 1)  — 102 dimensions, one very stiff direction; nutpie.sample(compiled, tune=1000, seed=42, ...) with
+    # the default ("diag") adaptation   (docs/sample-stats.qmd:141-157; the frozen output is the SECOND progress table of that page: the page's
+    # low_rank cell, :256-268, is not in the frozen results)
+    "correlated_102d": {"settings": "tune 1000, draws 1000, adaptation diag (default)", "runs": [stats[1]], "cites": ["docs/sample-stats.qmd:141-157"]},
 }
 json.dump(fixture, open(OUT, "w"), indent=1)
 print(OUT, {k: [len(r) for r in v["runs"]] for k, v in fixture.items() if not k.startswith("_")})

@@ -224,3 +224,28 @@ def test_engine_reproduces_the_final_step_sizes_of_the_reference_docs(hip, name)
     g_ref, g = doc_values(name, "gradients_last_draw"), np.asarray(got.stats["n_steps"])[:, 400:].ravel()
     assert set(g_ref.astype(int).tolist()) <= set(np.unique(g).tolist())
     assert abs(g_ref.mean() - g.mean()) / (g.std() / np.sqrt(len(g_ref))) < 3.0
+
+
+@pytest.mark.parametrize("key", ["funnel_diag", "correlated_102d"])
+def test_engine_on_the_funnel_and_the_correlated_model_of_the_reference_docs(hip, key):
+    """docs/sample-stats.qmd (tune 1000, default adaptation; tests/golden/reference_doc_step_sizes.json): Neal's funnel and the 102-dimensional
+    Gaussian with one stiff direction, written with the front-end and sampled on their resident kernels — final step sizes, gradients per
+    draw and divergences of 1024 chains against the six chains of nuts-rs (the oracle's side: tests/test_oracle_reference_pins.py)."""
+    import json
+
+    from scratch.r5_funnel_pin import correlated_102d, funnel
+
+    ref = json.load(open(os.path.join(GOLDEN, "reference_doc_step_sizes.json")))[key]["runs"][0]
+    model = nutpie_amd.compile_pymc_model((funnel if key == "funnel_diag" else correlated_102d)())
+    tr = nutpie_amd.sample(model, chains=1024, tune=1000, draws=400, seed=42, progress_bar=False)
+    st = tr.sample_stats
+    step, g, div = st.step_size.values[:, -1], st.n_steps.values.ravel(), st.diverging.values.sum(1) * (1000 / 400)
+    r_step, r_last, r_div = (np.array([row[k] for row in ref], dtype=np.float64) for k in ("step_size", "gradients_last_draw", "divergences"))
+    z = (r_step.mean() - step.mean()) / (step.std() / np.sqrt(len(r_step)))
+    print(f"{key}: reference step {r_step.mean():.3f}, engine {step.mean():.3f} +- {step.std():.3f} (z = {z:+.2f}); gradients per draw reference {r_last.mean():.1f}, engine {g.mean():.1f}")
+    assert abs(z) < 3.0
+    assert set(r_last.astype(int).tolist()) <= set(np.unique(g).tolist())
+    if key == "correlated_102d":
+        assert abs(r_last.mean() - g.mean()) / (g.std() / np.sqrt(len(r_last))) < 3.0 and div.sum() == 0
+    else:
+        assert np.all(r_div <= np.percentile(div, 99.5)) and stats.mannwhitneyu(r_div, div).pvalue > 0.01

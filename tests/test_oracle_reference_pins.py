@@ -94,9 +94,7 @@ def test_funnel_of_the_reference_docs(oracle):
     """docs/sample-stats.qmd:18-35: Neal's funnel (log_sigma ~ N(0, 1), x[5] ~ N(0, exp(log_sigma))), tune 1000 + draws 1000, default
     ("diag") adaptation — 6 chains of nuts-rs: final step sizes 0.34 .. 0.53, divergences 21 / 24 / 0 / 13 / 0 / 5, 7 gradients in the last
     draw of five chains and 15 in one.  A non-Gaussian pin: the step size the warm-up converges to on a target whose curvature varies by
-    orders of magnitude, and how often the sampling phase diverges with it.  (The docs' SECOND run of this model, adaptation="low_rank"
-    — step sizes 0.13 .. 0.22, 31 gradients, no divergence —, is NOT reproduced by this repository's low-rank estimator, whose metric on
-    the funnel stays the diagonal one: profiles/r5_funnel_pin.txt.)"""
+    orders of magnitude, and how often the sampling phase diverges with it."""
     import subprocess
 
     src, out = os.path.join(FIXTURES, "funnel.c"), os.path.join(FIXTURES, "libfunnel.so")
@@ -122,3 +120,31 @@ def test_funnel_of_the_reference_docs(oracle):
     # the reference's divergence counts lie inside this sampler's per-chain distribution (the progress table counts the sampling phase)
     assert np.all(r_div <= np.percentile(div, 99.5)) and stats.mannwhitneyu(r_div, div).pvalue > 0.01
     assert set(r_last.astype(int).tolist()) <= set(np.unique(last).tolist())
+
+
+def test_correlated_102_dimensional_model_of_the_reference_docs(oracle):
+    """docs/sample-stats.qmd:141-157: x ~ N(0, 1), y ~ N(x, 0.01), z[100] ~ N(y, 1) under the default adaptation, tune 1000 — 6 chains of
+    nuts-rs: final step sizes 0.13 .. 0.22, 31 gradients in the last draw of five chains and 15 in one, no divergence.  102 dimensions with
+    one very stiff direction a diagonal metric cannot remove: pins the step size AND the tree depth the adapted sampler ends up with."""
+    import subprocess
+
+    src, out = os.path.join(FIXTURES, "funnel.c"), os.path.join(FIXTURES, "libfunnel.so")
+    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        subprocess.run(["gcc", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-o", out, src, "-lm"], check=True)
+    fix = ctypes.CDLL(out)
+    n = 256
+    s = oracle.default_settings(seed=42, num_chains=n, num_tune=1000, num_draws=200, n_threads=8, init_kind=2)
+    pts = np.random.default_rng(3).uniform(-1, 1, size=(n, 102))
+    tr = oracle.sample_callback(s, 102, ctypes.cast(fix.correlated_102d_logp, ctypes.c_void_p).value, init_points=pts)
+    step = tr.stats["step_size"][:, -1]
+    g = tr.stats["n_steps"][:, 1000:].ravel()
+    ref = DOC["correlated_102d"]["runs"][0]
+    r_step, r_last, r_div = (np.array([row[k] for row in ref], dtype=np.float64) for k in ("step_size", "gradients_last_draw", "divergences"))
+    z = (r_step.mean() - step.mean()) / (step.std() / np.sqrt(len(r_step)))
+    zg = (r_last.mean() - g.mean()) / (g.std() / np.sqrt(len(r_last)))
+    print(f"correlated 102-d: reference step {r_step.mean():.3f} +- {r_step.std(ddof=1):.3f}, oracle {step.mean():.3f} +- {step.std():.3f} (z = {z:+.2f}); gradients per draw: "
+          f"reference {sorted(r_last.astype(int).tolist())} (mean {r_last.mean():.1f}), oracle mean {g.mean():.1f} (z = {zg:+.2f}), P(31) = {np.mean(g == 31):.2f}, P(15) = {np.mean(g == 15):.2f}; "
+          f"oracle divergences in the sampling phase: {int(tr.stats['diverging'][:, 1000:].sum())}")
+    assert abs(z) < 3.0 and abs(zg) < 3.0
+    assert set(r_last.astype(int).tolist()) <= set(np.unique(g).tolist())
+    assert r_div.sum() == 0 and tr.stats["diverging"][:, 1000:].mean() < 1e-3
