@@ -64,6 +64,16 @@ def run_shape_stats(a):
 STAT_NAMES = ["pooled mean", "median", "lag-1 autocorr of log a", "repeat fraction", "min log a"]
 
 
+fix2 = ctypes.CDLL(os.path.join(ROOT, "tests", "fixtures", "libfunnel.so"))
+
+
+def callback_step_sizes(fn, dim, settings_kw, n):
+    s = oracle.default_settings(seed=42, num_chains=n, num_tune=1000, num_draws=40, n_threads=8, init_kind=2, **settings_kw)
+    pts = np.random.default_rng(3).uniform(-1, 1, size=(n, dim))
+    tr = oracle.sample_callback(s, dim, ctypes.cast(fn, ctypes.c_void_p).value, init_points=pts)
+    return tr.stats["step_size"][:, -1], tr.stats["n_steps"][:, 1000:].ravel()
+
+
 def halfnormal_ensemble(settings_kw, flavour, init_override=None):
     s = oracle.default_settings(seed=123, num_chains=2 * R, num_tune=100, num_draws=100, n_threads=8, **settings_kw)
     pts = None
@@ -115,9 +125,12 @@ out("B: HalfNormal files: rank of the reference's statistic inside the ensemble 
 out()
 refs = {k: doc_values(k, "step_size") for k in ("normal_1d", "regression_x123", "regression_x456")}
 ref_f1 = {k: np.mean(doc_values(k, "gradients_last_draw") == 1) for k in refs}
-hdr = f"{'variant':28s} | " + " | ".join(f"{k:>32s}" for k in refs) + " | numba: " + " ".join(f"{n[:11]:>11s}" for n in STAT_NAMES) + " | stan: mean  repeat"
+hdr = f"{'variant':28s} | " + " | ".join(f"{k:>32s}" for k in refs) + " | " + f"{'funnel (tune 1000)':>24s} | {'correlated 102-d (tune 1000)':>36s}" + " | numba: " + " ".join(f"{n[:11]:>11s}" for n in STAT_NAMES) + " | stan: mean  repeat"
 out(hdr)
+ref_fun, ref_102 = doc_values("funnel_diag", "step_size"), doc_values("correlated_102d", "step_size")
+ref_102g = doc_values("correlated_102d", "gradients_last_draw")
 out(f"{'(reference)':28s} | " + " | ".join(f"n={len(v):2d} mean {v.mean():.3f} sd {v.std(ddof=1):.3f} f1 {ref_f1[k]:.2f}" for k, v in refs.items())
+    + f" | n=6 mean {ref_fun.mean():.3f} sd {ref_fun.std(ddof=1):.3f} | n=6 mean {ref_102.mean():.3f} sd {ref_102.std(ddof=1):.3f} grads {ref_102g.mean():.1f}"
     + " | " + " ".join(f"{v:11.3f}" for v in run_shape_stats(ref_numba)) + " | " + " ".join(f"{v:6.3f}" for v in run_shape_stats(ref_stan)[[0, 3]]))
 for label, skw, vkw in VARIANTS:
     oracle.set_variant(**vkw)
@@ -127,6 +140,10 @@ for label, skw, vkw in VARIANTS:
         z = (v.mean() - ss.mean()) / (ss.std() / np.sqrt(len(v)))
         p = stats.ks_2samp(v, ss).pvalue
         cells.append(f"{ss.mean():.3f}±{ss.std():.3f} z{z:+5.1f} p{p:.2f} f1 {np.mean(nlast == 1):.2f}")
+    sf, _ = callback_step_sizes(fix2.funnel_logp, 6, skw, 300)
+    cells.append(f"{sf.mean():.3f}±{sf.std():.3f} z{(ref_fun.mean() - sf.mean()) / (sf.std() / np.sqrt(6)):+5.1f}".rjust(24))
+    s1, g1 = callback_step_sizes(fix2.correlated_102d_logp, 102, skw, 128)
+    cells.append(f"{s1.mean():.3f}±{s1.std():.3f} z{(ref_102.mean() - s1.mean()) / (s1.std() / np.sqrt(6)):+5.1f} grads {g1.mean():.1f}".rjust(36))
     ens = halfnormal_ensemble(skw, "numba")
     rk = [np.mean(ens[:, j] < run_shape_stats(ref_numba)[j]) for j in range(5)]
     ens_s = halfnormal_ensemble(skw, "stan")
@@ -136,4 +153,6 @@ oracle.set_variant()
 # the initial points of the flavour matter little: the base variant with U(-2, 2) everywhere
 ens = halfnormal_ensemble({}, "numba", init_override="uniform")
 out(f"{'base, init U(-2, 2)':28s} | " + " " * 104 + " | " + " ".join(f"{np.mean(ens[:, j] < run_shape_stats(ref_numba)[j]):11.4f}" for j in range(5)))
+out()
+out("(funnel / correlated 102-d: docs/sample-stats.qmd, tune 1000, 300 / 128 chains per ensemble; z as in A; grads = mean gradients per sampling draw, reference 28.3)")
 open(os.path.join(ROOT, "profiles", "r5_reference_sensitivity.txt"), "w").write("\n".join(lines) + "\n")
