@@ -27,13 +27,24 @@ def tables(doc):
 
 
 idx, stan, pymc, stats = tables("index"), tables("stan-usage"), tables("pymc-usage"), tables("sample-stats")
+
+
+def ess_values():
+    """`az.ess(trace)` of the first regression run (docs/pymc-usage.qmd:105-108): the bulk effective sample sizes of 6 x 1000 draws"""
+    import html
+
+    md = json.load(open(f"{DOCS}/_freeze/pymc-usage/execute-results/html.json"))["result"]["markdown"]
+    seg = html.unescape(re.sub(r"<[^>]+>", " ", md[md.find("az.ess"):][:40000]))
+    return {name: float(re.search(name + r"\s*\(\)\s*float64\s*[\d.e+]+\s*array\(([\d.]+)\)", seg).group(1)) for name in ("intercept", "slope")}
+
+
 fixture = {
     "_source": "docs/_freeze/{index,stan-usage,pymc-usage}/execute-results/html.json of the reference (progress tables of the executed cells)",
     "_settings": "nutpie.sample(compiled): 6 chains, tune 400, draws 1000, every other setting default",
     # mu ~ N(0, 1); obs ~ N(mu, 1), observed [1, 2, 3]   (docs/index.qmd:39-46 through PyMC, :66-91 and docs/stan-usage.qmd:57-84 through Stan)
     "normal_1d": {"posterior": "N(1.5, 1/4)", "runs": [idx[0], idx[1], stan[0]], "cites": ["docs/index.qmd:39-46", "docs/index.qmd:66-91", "docs/stan-usage.qmd:57-84"]},
     # intercept, slope ~ N(0, 1); y ~ N(intercept + slope * x, 0.1), x = [1, 2, 3], observed [1, 2, 3]   (docs/pymc-usage.qmd:53-79 and :173-187)
-    "regression_x123": {"posterior": "precision [[301, 600], [600, 1401]], X'y / sigma^2 = [600, 1400]", "runs": [pymc[0], pymc[1]],
+    "regression_x123": {"posterior": "precision [[301, 600], [600, 1401]], X'y / sigma^2 = [600, 1400]", "runs": [pymc[0], pymc[1]], "bulk_ess_of_the_first_run": ess_values(),
                         "cites": ["docs/pymc-usage.qmd:53-79", "docs/pymc-usage.qmd:173-187"]},
     # the same model after with_data(x=[4, 5, 6])   (docs/pymc-usage.qmd:191-194)
     "regression_x456": {"posterior": "precision [[301, 1500], [1500, 7701]], X'y / sigma^2 = [600, 3200]", "runs": [pymc[2]], "cites": ["docs/pymc-usage.qmd:191-194"]},
