@@ -125,12 +125,10 @@ class _Interp:
     def data(self, t, name: str | None = None) -> Expr:
         """a constant float tensor as a data array of the model (on the dimension of its number of elements)"""
         a = np.ascontiguousarray(t.detach().cpu().numpy() if hasattr(t, "detach") else t, dtype=np.float64).reshape(-1)
-        if a.size == 1:
-            return Expr.const(float(a[0]))
+        if a.size == 1 or (a.size > 1 and np.all(a == a[0])):
+            return Expr.const(float(a[0]))           # (also +-inf: `where(inside, logp, -inf)` of a bounds check)
         if not np.all(np.isfinite(a)):
-            raise UnsupportedTorchOp("a constant with non-finite entries meets a traced value")
-        if a.size > 1 and np.all(a == a[0]):
-            return Expr.const(float(a[0]))
+            raise UnsupportedTorchOp("a constant array with non-finite entries meets a traced value")
         key = (a.size, a.tobytes())
         hit = self.const_cache.get(key)
         if hit is not None:

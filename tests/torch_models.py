@@ -248,3 +248,27 @@ def multinomial_logit():
 
 
 ALL["multinomial_logit"] = multinomial_logit
+
+
+def bounds_checked():
+    """what a compiled PyMC logp looks like: every term guarded by its parameter check (``where(sigma > 0, logp, -inf)``, ``switch`` with a
+    constant array of -inf), ``full_like`` / ``broadcast_to`` allocations, a ``set_subtensor`` (``index_put`` with distinct indices)"""
+    rng = np.random.default_rng(4)
+    yv = _t(rng.normal(size=30) * 1.3 + 0.4)
+
+    def logp(x):
+        mu, log_sigma, nu_raw = x[0], x[1], x[2]
+        sigma = torch.exp(log_sigma)
+        nu = 2.0 + torch.nn.functional.softplus(nu_raw)
+        z = (yv - mu) / sigma
+        t_lp = torch.lgamma(0.5 * (nu + 1.0)) - torch.lgamma(0.5 * nu) - 0.5 * torch.log(nu * math.pi) - log_sigma - 0.5 * (nu + 1.0) * torch.log1p(z * z / nu)
+        t_lp = torch.where(sigma > 0, t_lp, torch.full_like(t_lp, -math.inf))
+        t_lp = torch.where(torch.broadcast_to(nu > 0, t_lp.shape), t_lp, -math.inf)
+        prior = torch.zeros(3, dtype=x.dtype)
+        prior[torch.tensor([2, 0, 1])] = torch.stack([-0.5 * nu_raw ** 2, -0.5 * (mu / 5.0) ** 2, -0.5 * log_sigma ** 2 + log_sigma])
+        return t_lp.sum() + prior.sum()
+
+    return 3, logp, False, {}
+
+
+ALL["bounds_checked"] = bounds_checked
