@@ -144,9 +144,63 @@ __device__ __forceinline__ void wave_sumN(double (&v)[N]) {
     for (int n = 0; n < N; ++n) v[n] = readlane_f64(v[n], 0) + readlane_f64(v[n], 32);
 }
 
+// TWO, FOUR or EIGHT wave sums with the lanes halved along the way (round 5): the same additions on the same operands as
+// wave_sumN — the bits of the contract's order — in 29 / 50 / 95 instructions instead of 40 / 80 / 160 (described for four).  After stage 1 a register holds value 0's pair sums in the even lanes and
+// value 1's in the odd ones (X; Y likewise for values 2, 3); after stage 2 lane 4i + c holds the sum of value c over quad i (Z).  From there
+// only the lanes that end in the result are kept up: the contract adds, per row of 16 lanes, (q0 + q1) + (q3 + q2) — in the butterfly every lane
+// of a quad holds the quad's sum, so lane 0's mirror partners 7, 15 stand for quads 1, 3 —, then row 0 + row 1, then the two halves of the wave.
+// (The selections by lane parity are v_cndmask: DPP's bank mask selects quads of lanes, not lanes of a quad.)
+// Here B = Z + shr4(Z) has q1 + q0 in lanes 4..7 and q3 + q2 in lanes 12..15 (IEEE addition commutes bit for bit), C = B + shr8(B) has
+// (q3 + q2) + (q1 + q0) in lanes 12..15, D = C + swizzle16(C) row 0 + row 1 there, and the result is lane 12 + c of the lower half plus lane
+// 44 + c of the upper one.
+__device__ __forceinline__ double swz4_f64(double x) {  // value of lane l ^ 4
+    int lo = __builtin_amdgcn_ds_swizzle(__double2loint(x), 0x101F);
+    int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(x), 0x101F);
+    return __hiloint2double(hi, lo);
+}
+// one halving step: lanes whose bit `sel` is clear go on with a, the others with b; the partner (CTRL) hands over what this lane does not keep
+template <int CTRL>
+__device__ __forceinline__ double halve(bool sel, double a, double b) {
+    const double keep = sel ? b : a, give = sel ? a : b;
+    return keep + dpp_f64<CTRL>(give);
+}
+template <int N>
+__device__ __forceinline__ void wave_sumN_halving(double (&v)[N]) {
+    static_assert(N == 2 || N == 4 || N == 8, "");
+    const unsigned lane_ = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const bool b0 = (lane_ & 1u) != 0u, b1 = (lane_ & 2u) != 0u, b2 = (lane_ & 4u) != 0u;
+    if constexpr (N == 2) {
+        double X = halve<0xB1>(b0, v[0], v[1]);          // even lanes: value 0, odd lanes: value 1
+        X = X + dpp_f64<0x4E>(X);                          // l ^ 2 keeps the parity
+        const double B = X + dpp_f64<0x114>(X), C_ = B + dpp_f64<0x118>(B), D_ = C_ + swz16_f64(C_);
+        v[0] = readlane_f64(D_, 12) + readlane_f64(D_, 44);
+        v[1] = readlane_f64(D_, 13) + readlane_f64(D_, 45);
+    } else if constexpr (N == 4) {
+        const double X = halve<0xB1>(b0, v[0], v[1]), Y = halve<0xB1>(b0, v[2], v[3]);
+        const double Z = halve<0x4E>(b1, X, Y);            // lane 4i + c: value c summed over quad i
+        const double B = Z + dpp_f64<0x114>(Z), C_ = B + dpp_f64<0x118>(B), D_ = C_ + swz16_f64(C_);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = readlane_f64(D_, 12 + c) + readlane_f64(D_, 44 + c);
+    } else {
+        const double X0 = halve<0xB1>(b0, v[0], v[1]), Y0 = halve<0xB1>(b0, v[2], v[3]);
+        const double X1 = halve<0xB1>(b0, v[4], v[5]), Y1 = halve<0xB1>(b0, v[6], v[7]);
+        const double Za = halve<0x4E>(b1, X0, Y0), Zb = halve<0x4E>(b1, X1, Y1);
+        // stage 3: the contract's partner 7 - l holds the OTHER quad's sum of the same value, as lane l ^ 4 does here
+        const double keep = b2 ? Zb : Za, give = b2 ? Za : Zb;
+        const double Wv = keep + swz4_f64(give);           // lanes 8i + c: values 0..3 over eight lanes, 8i + 4 + c: values 4..7
+        const double C_ = Wv + dpp_f64<0x118>(Wv), D_ = C_ + swz16_f64(C_);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = readlane_f64(D_, 8 + c) + readlane_f64(D_, 40 + c);
+    }
+}
+
 template <int W, int N, bool TRAILING_BARRIER = true>
 __device__ __forceinline__ void reduceN(double (&v)[N], NPHIP_LDS double* red) {
+#ifndef NPHIP_NO_HALVING_SUM
+    if constexpr (N == 2 || N == 4 || N == 8) wave_sumN_halving(v); else wave_sumN(v);
+#else
     wave_sumN(v);
+#endif
     if (W > 1) {
         const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
         if (lane == 0) {

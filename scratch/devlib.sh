@@ -11,5 +11,6 @@ if [ -n "$3" ]; then SRC=kernels_variant_$1.hip; sed "$3" kernels.hip > $SRC; cm
 [ -n "$3" ] && rm -f $SRC
 [ -f /tmp/dev_host.o ] && [ /tmp/dev_host.o -nt host.hip ] && [ /tmp/dev_host.o -nt engine_types.h ] || /opt/rocm/bin/hipcc $F -c host.hip -o /tmp/dev_host.o
 mkdir -p ../../scratch/libs
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../scratch/libs/$1.so /tmp/dev_$1_k.o /tmp/dev_host.o -pthread
+[ -f linalg.o ] || /opt/rocm/bin/hipcc $F -c linalg.hip -o linalg.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../scratch/libs/$1.so /tmp/dev_$1_k.o /tmp/dev_host.o linalg.o -pthread
 ls -la ../../scratch/libs/$1.so
