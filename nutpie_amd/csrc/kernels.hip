@@ -194,10 +194,12 @@ __device__ __forceinline__ void wave_sumN_halving(double (&v)[N]) {
     }
 }
 
-template <int W, int N, bool TRAILING_BARRIER = true>
+// HALVE = false: the plain butterfly (the lean kernels: their register file is full, the selects of the halving steps cost them 48 more bytes of
+// scratch per lane and 4 % more memory traffic — measured: 32.6 -> 36.1 ms per launch at D = 10 000)
+template <int W, int N, bool TRAILING_BARRIER = true, bool HALVE = true>
 __device__ __forceinline__ void reduceN(double (&v)[N], NPHIP_LDS double* red) {
 #ifndef NPHIP_NO_HALVING_SUM
-    if constexpr (N == 2 || N == 4 || N == 8) wave_sumN_halving(v); else wave_sumN(v);
+    if constexpr (HALVE && (N == 2 || N == 4 || N == 8)) wave_sumN_halving(v); else wave_sumN(v);
 #else
     wave_sumN(v);
 #endif
@@ -391,7 +393,7 @@ struct Machine {
     template <int N>
     __device__ __forceinline__ void rsum(double (&v)[N]) {
         static_assert(N <= 16, "a reduction area holds 16 values per wave");
-        reduceN<W, N, false>(v, red + (W > 1 ? rflip * 16 * W : 0));
+        reduceN<W, N, false, !LEAN>(v, red + (W > 1 ? rflip * 16 * W : 0));
         rflip ^= 1;
     }
     __device__ __forceinline__ void rsum2(double& a, double& b) {
