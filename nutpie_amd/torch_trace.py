@@ -811,6 +811,29 @@ def _run(gm, it: _Interp, x_shape, data_values: dict[str, Any]):
                     env[node] = _Sym(ex / tot, shp)
                 else:
                     env[node] = _Sym((e - m_) - S.log(tot), shp)
+        elif base in ("cumsum", "logcumsumexp") and base == "cumsum":
+            # a prefix sum along a short axis (ordered cut points: PyMC's `ordered` transform is a cumsum of exponentials): every output element
+            # sums the elements before it — a gather of the (i, j <= i) pairs and a segment sum back, n (n + 1) / 2 terms
+            v_ = it.sym(a0)
+            shp = v_.shape
+            ax = (args[1] if len(args) > 1 else kwargs.get("dim")) % max(len(shp), 1)
+            n_ax = shp[ax] if shp else 1
+            if n_ax > 64:
+                raise UnsupportedTorchOp("cumsum along an axis of more than 64 elements")
+            if v_.expr.dim is None:
+                ramp = torch.arange(1, n_ax + 1, dtype=torch.float64).reshape([n_ax if i_ == ax else 1 for i_ in range(len(shp))]).expand(shp)
+                env[node] = B(v_, ramp, lambda x_, y_: x_ * y_)
+            else:
+                n_ = _numel(shp)
+                flat = torch.arange(n_, dtype=torch.int64).reshape(shp)
+                src, dst = [], []
+                for i_ in range(n_ax):
+                    for j_ in range(i_ + 1):
+                        src.append(flat.select(ax, j_).reshape(-1))
+                        dst.append(flat.select(ax, i_).reshape(-1))
+                src, dst = torch.cat(src).numpy(), torch.cat(dst).numpy()
+                pairs = v_.expr[it.index(src, src.size, n_)]
+                env[node] = _Sym(S._segsum(pairs, it.index(dst, dst.size, n_)), shp)
         elif base == "dot" or base == "vdot":
             env[node] = it.sum(B(args[0], args[1], lambda x, y: x * y))
         elif base in ("mv", "mm", "matmul", "bmm"):

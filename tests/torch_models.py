@@ -272,3 +272,26 @@ def bounds_checked():
 
 
 ALL["bounds_checked"] = bounds_checked
+
+
+def ordered_logistic():
+    """an ordinal regression: cut points through PyMC's ``ordered`` transform (first raw value, then a ``cumsum`` of exponentials), category
+    probabilities as differences of sigmoids, one ``index`` per observation"""
+    rng = np.random.default_rng(8)
+    N, K = 80, 5
+    xcov = _t(rng.normal(size=N))
+    ycat = torch.as_tensor(rng.integers(0, K, size=N))
+
+    def logp(x):
+        beta, raw = x[0], x[1:K]
+        cuts = torch.cat([raw[:1], raw[:1] + torch.cumsum(torch.exp(raw[1:]), 0)])          # K - 1 increasing cut points
+        eta = beta * xcov
+        cdf = torch.sigmoid(cuts[None, :] - eta[:, None])                                       # [N, K - 1]
+        p = torch.cat([cdf, torch.ones(N, 1, dtype=x.dtype)], 1) - torch.cat([torch.zeros(N, 1, dtype=x.dtype), cdf], 1)
+        ll = torch.log(p[torch.arange(N), ycat]).sum()
+        return ll - 0.5 * beta * beta - 0.5 * (raw * raw).sum() / 4.0 + raw[1:].sum()
+
+    return K, logp, False, {}
+
+
+ALL["ordered_logistic"] = ordered_logistic
