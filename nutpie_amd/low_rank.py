@@ -62,6 +62,7 @@ def window_schedule(num_tune: int, early_window: float = 0.3, step_size_window: 
     the early phase and after the step size has settled; from there every switch, refreshes no closer than ``switch_freq / 2`` draws,
     and the last refresh before the final window — at most MAX_HAND_INS; (2) the draws right after a hand-in (SETTLE) are not used."""
     T = int(num_tune)
+    switch_freq, early_switch_freq, update_freq = max(1, int(switch_freq)), max(1, int(early_switch_freq)), max(1, int(update_freq))
     early_end = int(np.ceil(T * early_window))
     final = max(0, T - int(np.ceil(T * step_size_window))) + 1          # the engine's bound: draws d < final adapt the metric
     final = min(final, T)

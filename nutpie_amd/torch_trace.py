@@ -114,6 +114,7 @@ class _Interp:
         self.index_cache: dict[tuple, S.Index] = {}
         self.data_names = list(data_names)
         self.named: dict[int, str] = {}         # id(tensor of a shared-data placeholder) -> its name in the model's data
+        self._alive: list = []                  # (the tensors those ids belong to: an id is only unique while its object lives)
         if whole:
             d = self.dim(self.n_dim)
             self.x_expr = Expr("vparam", (), d, (0, self.n_dim)) if self.n_dim > 1 else Expr("sparam", (), None, 0)
@@ -205,6 +206,7 @@ class _Interp:
             f = v.to(torch.float64)
             if id(v) in self.named:
                 self.named[id(f)] = self.named[id(v)]
+                self._alive.append(f)
             return _Sym(self.data(f), tuple(v.shape))
         if isinstance(v, (int, float, bool, np.floating, np.integer)):
             return _Sym(Expr.const(float(v)), ())
@@ -563,6 +565,7 @@ def _run(gm, it: _Interp, x_shape, data_values: dict[str, Any]):
                 env[node] = t
                 if isinstance(t, torch.Tensor):
                     it.named[id(t)] = name                            # keeps its name in the model's data when it is used as it is
+                    it._alive.append(t)
             continue
         if node.op == "get_attr":
             t = getattr(gm, node.target)
