@@ -1004,7 +1004,7 @@ bool nphip_sampler::setup() {
             }
         }
     }
-    if (model.kind == 2 && launch.host_groups >= 2 && !launch.manual && launch.graph_steps <= 0 && n >= 8) {
+    if (model.kind == 2 && launch.host_groups >= 2 && !launch.manual && n >= 8) {
         // Device callbacks in groups (round 5): the chains in `host_groups` contiguous groups, each with a stream of its
         // own on which its k_advance launch and its callback alternate — while one group's callback runs (a GEMM, a torch function) the
         // other group's engine kernel does.  No flag and no host synchronisation: stream order is the only dependency, the callback
@@ -1199,7 +1199,13 @@ bool nphip_sampler::iteration_callback_groups(bool& all_done, int& have) {
 }
 
 bool nphip_sampler::iteration_callback(bool& all_done, int& have) {
-    if (model.kind == 2 && cb_graph_steps > 0 && have == 1 && !kernel_ms_acc) return iteration_graph(all_done);
+    if (model.kind == 2 && cb_graph_steps > 0 && have == 1 && !kernel_ms_acc) {
+        if (cb_groups > 1 && !cb_graph) {   // the steps before the capture ran on the groups' streams: the graph (launched on the main one) follows them
+            for (int g = 0; g < n_groups; ++g)
+                if (!hip_ok(hipStreamSynchronize(grp_stream[g]), "hipStreamSynchronize")) return false;
+        }
+        return iteration_graph(all_done);
+    }
     if (model.kind == 2 && cb_groups > 1 && !kernel_ms_acc) {
         if (!grp_primed) {   // everything enqueued on the main stream so far (set-up, the chains' start) precedes the groups' first launches
             if (!hip_ok(hipStreamSynchronize(stream), "hipStreamSynchronize")) return false;
@@ -1264,7 +1270,33 @@ bool nphip_sampler::iteration_graph(bool& all_done) {
     if (!cb_graph) {
         hipGraph_t g = nullptr;
         bool ok = hipStreamBeginCapture(stream, hipStreamCaptureModeRelaxed) == hipSuccess;
-        if (ok) {
+        if (ok && cb_groups > 1) {
+            // groups of chains as parallel branches of ONE graph (round 5): the capture forks from the main stream into every group's stream,
+            // each branch is that group's `cb_graph_steps` x (k_advance slice, callback on the group's rows), and joins again — the device
+            // overlaps one group's callback with another's kernel, and the host launches one graph per `cb_graph_steps` steps
+            args.max_evals = 0;
+            args.have_result = 1;
+            hipEvent_t fork = nullptr;
+            ok = hipEventCreateWithFlags(&fork, hipEventDisableTiming) == hipSuccess && hipEventRecord(fork, stream) == hipSuccess;
+            std::vector<hipEvent_t> joins((size_t)n_groups, nullptr);
+            for (int gi = 0; ok && gi < n_groups; ++gi) {
+                ok = hipStreamWaitEvent(grp_stream[gi], fork, 0) == hipSuccess;
+                LaunchSlice sl;
+                memset(&sl, 0, sizeof(sl));
+                sl.chain_lo = (int)grp_lo[gi];
+                sl.chain_n = (int)(grp_lo[gi + 1] - grp_lo[gi]);
+                sl.grp = -1;
+                const uint64_t lo = grp_lo[gi];
+                for (int i = 0; ok && i < cb_graph_steps; ++i)
+                    ok = launch_advance(args, d_args, false, W, grp_stream[gi], &sl) == hipSuccess &&
+                         model.dev_fn((uint64_t)sl.chain_n, dim, args.qeval + lo * dim, args.geval + lo * dim, args.ueval + lo, (void*)grp_stream[gi], model.user) >= 0;
+                ok = ok && hipEventCreateWithFlags(&joins[(size_t)gi], hipEventDisableTiming) == hipSuccess &&
+                     hipEventRecord(joins[(size_t)gi], grp_stream[gi]) == hipSuccess && hipStreamWaitEvent(stream, joins[(size_t)gi], 0) == hipSuccess;
+            }
+            ok = (hipStreamEndCapture(stream, &g) == hipSuccess) && ok && g != nullptr;
+            if (fork) (void)hipEventDestroy(fork);
+            for (hipEvent_t e : joins) if (e) (void)hipEventDestroy(e);
+        } else if (ok) {
             args.max_evals = 0;
             args.have_result = 1;
             for (int i = 0; ok && i < cb_graph_steps; ++i) {

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import nutpie_amd
 from nutpie_amd import _lib
 m = nutpie_amd.dense_gaussian(1000)
-for label, kw in (("plain", {}), ("graph_steps=16", {"graph_steps": 16}), ("host_groups=2", {"host_groups": 2}), ("host_groups=4", {"host_groups": 4})):
+for label, kw in (("plain", {}), ("graph_steps=16", {"graph_steps": 16}), ("host_groups=2", {"host_groups": 2}), ("host_groups=2 + graph_steps=16", {"host_groups": 2, "graph_steps": 16}), ("host_groups=4 + graph_steps=16", {"host_groups": 4, "graph_steps": 16})):
     for rep in range(2):
         s = _lib.PyNutsSettings.Diag(1); s.update(num_tune=30, num_draws=10, num_chains=1024)
         t = time.perf_counter()

@@ -669,6 +669,14 @@ def test_low_rank_adaptation_on_a_correlated_gaussian():
 
 
 
+def hip_settings(kw):
+    from nutpie_amd import _lib
+
+    s = _lib.PyNutsSettings.Diag(kw["seed"])
+    s.update(num_tune=kw["tune"], num_draws=kw["draws"], num_chains=kw["chains"])
+    return s
+
+
 def test_device_callback_in_groups_draws_the_same():
     """Engine option ``host_groups`` for a batched device callback (round 5): the chains in groups, each group's engine kernel and
     callback on a stream of its own so that one group's callback overlaps the other's kernel.  A callback whose rows do not depend on
@@ -691,4 +699,10 @@ def test_device_callback_in_groups_draws_the_same():
         b = nutpie_amd.sample(m, host_groups=groups, **kw)
         assert np.array_equal(a.posterior.x.values, b.posterior.x.values)
         assert np.array_equal(a.sample_stats.n_steps.values, b.sample_stats.n_steps.values)
+    # ... and with the groups as parallel branches of one captured HIP graph (graph_steps): the same trace again
+    s = hip_settings(kw)
+    smp = m._make_sampler(s, None, 1, None, None, None, None, host_groups=2, graph_steps=8)
+    smp.wait()
+    got = smp.take_results()
+    assert np.array_equal(np.asarray(got.draws)[:, 120:], a.posterior.x.values)
     np.testing.assert_allclose(a.posterior.x.values.std((0, 1)), sd.cpu().numpy(), rtol=0.12)
