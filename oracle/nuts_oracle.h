@@ -65,7 +65,9 @@
  *         PyMC flavour (2 x 100 draws): lag-1 autocorrelation 0.993, repeat fraction 0.04, deepest excursion (min log a = -8.1)
  *         0.017 — inside the 0.5 - 99.5 % band —, but pooled mean 0.560 and median 0.375 at rank 0.0015, and NO variant of the
  *         recalled constants above, nor PyMC's initial points instead of U(-2, 2), moves them (0.0000 - 0.0065 across the 17
- *         variants); conditional on an excursion as deep as the file's (1.8 % of runs) they stay at 0.000 - 0.003.  The file spends
+ *         variants); conditional on an excursion as deep as the file's (1.8 % of runs) they stay at 0.000 - 0.003.  The reference's CHANGELOG.md:124 ("Update
+ *         reference draws due to change in window lengths") says the files were regenerated for window lengths that may differ from the recalled
+ *         ones: an 81-point grid over the four window constants (profiles/r5_window_grid.txt) leaves both ranks at <= 0.005 everywhere.  The file spends
  *         half of its 200 draws below a = 0.375 in three separate excursions to the left tail; this sampler's runs of that shape do
  *         not.  OPEN: either a 1-in-500 realisation or a difference that none of the recalled knobs expresses.
  *  9. `step_size_adapt_method = "adam"` (Adam on log step size, src/wrapper.rs:344-376): beta1 0.9, beta2 0.999, eps 1e-8 are
