@@ -158,6 +158,19 @@ __device__ __forceinline__ double swz4_f64(double x) {  // value of lane l ^ 4
     int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(x), 0x101F);
     return __hiloint2double(hi, lo);
 }
+// lower half of the wave + upper half, in every lane (the contract's last addition: lane 0 + lane 32): v_permlane32_swap (gfx950) exchanges lanes
+// 32..63 of its first operand with lanes 0..31 of its second — given the same value twice it returns the lower half in both halves and the
+// upper half in both halves
+__device__ __forceinline__ double halves_sum_f64(double x) {
+#ifndef NPHIP_NO_PERMLANE_SWAP
+    const int lo = __double2loint(x), hi = __double2hiint(x);
+    const auto r0 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto r1 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double(r1[0], r0[0]) + __hiloint2double(r1[1], r0[1]);
+#else
+    return x;
+#endif
+}
 // one halving step: lanes whose bit `sel` is clear go on with a, the others with b; the partner (CTRL) hands over what this lane does not keep
 template <int CTRL>
 __device__ __forceinline__ double halve(bool sel, double a, double b) {
@@ -173,14 +186,26 @@ __device__ __forceinline__ void wave_sumN_halving(double (&v)[N]) {
         double X = halve<0xB1>(b0, v[0], v[1]);          // even lanes: value 0, odd lanes: value 1
         X = X + dpp_f64<0x4E>(X);                          // l ^ 2 keeps the parity
         const double B = X + dpp_f64<0x114>(X), C_ = B + dpp_f64<0x118>(B), D_ = C_ + swz16_f64(C_);
+#ifndef NPHIP_NO_PERMLANE_SWAP
+        const double T_ = halves_sum_f64(D_);
+        v[0] = readlane_f64(T_, 12);
+        v[1] = readlane_f64(T_, 13);
+#else
         v[0] = readlane_f64(D_, 12) + readlane_f64(D_, 44);
         v[1] = readlane_f64(D_, 13) + readlane_f64(D_, 45);
+#endif
     } else if constexpr (N == 4) {
         const double X = halve<0xB1>(b0, v[0], v[1]), Y = halve<0xB1>(b0, v[2], v[3]);
         const double Z = halve<0x4E>(b1, X, Y);            // lane 4i + c: value c summed over quad i
         const double B = Z + dpp_f64<0x114>(Z), C_ = B + dpp_f64<0x118>(B), D_ = C_ + swz16_f64(C_);
+#ifndef NPHIP_NO_PERMLANE_SWAP
+        const double T_ = halves_sum_f64(D_);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = readlane_f64(T_, 12 + c);
+#else
 #pragma unroll
         for (int c = 0; c < 4; ++c) v[c] = readlane_f64(D_, 12 + c) + readlane_f64(D_, 44 + c);
+#endif
     } else {
         const double X0 = halve<0xB1>(b0, v[0], v[1]), Y0 = halve<0xB1>(b0, v[2], v[3]);
         const double X1 = halve<0xB1>(b0, v[4], v[5]), Y1 = halve<0xB1>(b0, v[6], v[7]);
@@ -189,8 +214,14 @@ __device__ __forceinline__ void wave_sumN_halving(double (&v)[N]) {
         const double keep = b2 ? Zb : Za, give = b2 ? Za : Zb;
         const double Wv = keep + swz4_f64(give);           // lanes 8i + c: values 0..3 over eight lanes, 8i + 4 + c: values 4..7
         const double C_ = Wv + dpp_f64<0x118>(Wv), D_ = C_ + swz16_f64(C_);
+#ifndef NPHIP_NO_PERMLANE_SWAP
+        const double T_ = halves_sum_f64(D_);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = readlane_f64(T_, 8 + c);
+#else
 #pragma unroll
         for (int c = 0; c < 8; ++c) v[c] = readlane_f64(D_, 8 + c) + readlane_f64(D_, 40 + c);
+#endif
     }
 }
 
