@@ -141,7 +141,12 @@ def generated_source(user_source: str, layout) -> str:
         "// data.scratch__ when the model asked for scratch in device memory (scratch_doubles_per_chain)",
         "#define NPHIP_CHAIN_SLOT (NPHIP_JIT_W == 1 ? (int)(blockIdx.x * 4 + (threadIdx.x >> 6)) : (int)blockIdx.x)",
         "template <int N> static __device__ __forceinline__ void nphip_chain_sumN(double (&v)[N]) {",
-        "    if (NPHIP_JIT_W == 1) { if constexpr (N == 2 || N == 4 || N == 8) nphip::wave_sumN_halving(v); else nphip::wave_sumN(v); return; }   // (the same bits either way)",
+        "    if (NPHIP_JIT_W == 1) {   // (the same bits whichever way the wave sums are taken: kernels.hip, wave_sumN_halving)",
+        "        if constexpr (N == 2 || N == 4 || N == 8) nphip::wave_sumN_halving(v);",
+        "        else if constexpr (N == 3) { double w[4] = {v[0], v[1], v[2], 0.0}; nphip::wave_sumN_halving(w); v[0] = w[0]; v[1] = w[1]; v[2] = w[2]; }",
+        "        else nphip::wave_sumN(v);",
+        "        return;",
+        "    }",
         "    __shared__ double red_[8 * NPHIP_JIT_W];",
         "    nphip::reduceN<NPHIP_JIT_W, N>(v, (NPHIP_LDS double*)red_);",
         "}",
