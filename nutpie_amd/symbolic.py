@@ -45,6 +45,7 @@ positions that did not come out of a sampler are evaluated with numpy from the s
 from __future__ import annotations
 
 import math
+import os
 import weakref
 from typing import Any
 
@@ -56,6 +57,7 @@ __all__ = ["Model", "Expr", "Matrix", "exp", "log", "log1p", "sqrt", "softplus",
            "bernoulli_logit_lpmf", "poisson_log_lpmf", "dirichlet_lpdf", "flat_lpdf"]
 
 _WAVE = 64
+_SEG_BATCH = os.environ.get("NUTPIE_AMD_SEG_MODE", "select") != "loop"   # (developer switch: "loop" = plain loops over a segment)
 _UNROLL = 4   # iterations of a loop whose reads are issued together (a lone wave waits out every access otherwise)
 
 
@@ -925,6 +927,7 @@ class _Gen:
             else:
                 emit(f"    const auto M{k} = NPHIP_LDS_PTR(double, lds + ({lds_off}));")
                 lds_off += f" + n_{dim.name}"
+        self.spilled_names = {self.store_name[key] for key in self.spilled}
         by_id_ = {n.id: n for n in self.order}
         for nid in sorted(self.hoisted):
             n = by_id_[nid]
@@ -1025,6 +1028,17 @@ class _Gen:
                 return f"D_{v.payload}[{c}]"
             return f"{self.store_name[v.id]}[{c}]"
         return _op_c(n.op, [self.sref(a) for a in n.args])
+
+    def seg_cap(self, iname: str, u: int, T: int, U: int, n_acc: int) -> int:
+        """how many elements of its range every lane reads up front in unrolled iteration ``u`` of a loop: the longest range that
+        iteration meets in the model's data (at most 32, at most 64 values in flight)"""
+        rows = self.m._data.get(iname + "__rows")
+        if rows is None:
+            return 0
+        lens = np.diff(np.asarray(rows, dtype=np.int64))
+        mine = lens[(np.arange(lens.size) % (T * U)) // T == u]
+        longest = int(mine.max()) if mine.size else 0
+        return 0 if longest < 3 else min(longest, 32, max(1, 64 // max(1, n_acc)))
 
     # ---- one wave-wide loop
     def loop(self, d: Dim, lv: int, sums, stores, outs, mark=lambda label: None):
@@ -1129,10 +1143,24 @@ class _Gen:
                 stages[4].append(f"        if (i_{u} < {nv}) g[{off} + {at}] = {val(gexpr)};")
         # all segment sums of one index in one inner loop per unrolled iteration (walking the ranges of several iterations side by
         # side was measured: the extra compares cost more than the overlapped reads save — config 3: 44.7 -> 40.7 M leapfrogs/s)
+        # The first `cap` elements of every range are read at once and added under a comparison (x + 0.0 == x: the same additions in
+        # the same order as the loop, which stays for what a range has beyond `cap`): a loop with a trip count per lane pays an LDS
+        # round trip per four elements and up to three lone iterations at its end.  `cap` is the longest range THIS iteration of
+        # the loop meets in the data the model is compiled with (other data: still exact, the rest loop takes what is longer).
+        # Reads past the end of a range are other ranges' elements or, at the end of the array, whatever follows in the workgroup's
+        # LDS — never used; arrays in device memory keep the plain loop.  (config 3, same box: profiles/r5_generated_density_loop_ab.txt)
         for (u, iname), accs in seg.items():
             stages[2].append("        double " + ", ".join(f"{a} = 0.0" for a, _ in accs) + ";")
+            cap = self.seg_cap(iname, u, T, U, len(accs)) if _SEG_BATCH and all(arr not in self.spilled_names for _, arr in accs) else 0
+            r0, r1 = f"r0{iname}_{u}", f"r1{iname}_{u}"
+            if cap:
+                stages[2].append(f"        const int n{iname}_{u} = {r1} - {r0};")
+                for t in range(cap):
+                    stages[2].append("        const double " + ", ".join(f"{a}_k{t} = {arr}[{r0} + {t}]" for a, arr in accs) + ";")
+                for t in range(cap):
+                    stages[2].append("        " + " ".join(f"{a} += ({t} < n{iname}_{u}) ? {a}_k{t} : 0.0;" for a, _ in accs))
             stages[2].append("#pragma unroll 4")
-            stages[2].append(f"        for (int k = r0{iname}_{u}; k < r1{iname}_{u}; ++k) {{ " + " ".join(f"{a} += {arr}[k];" for a, arr in accs) + " }")
+            stages[2].append(f"        for (int k = {r0}{f' + {cap}' if cap else ''}; k < {r1}; ++k) {{ " + " ".join(f"{a} += {arr}[k];" for a, arr in accs) + " }")
         for st in stages:
             for line in st:
                 emit(line)
