@@ -3581,7 +3581,8 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) __attribute__((amdgpu_waves_
     extern __shared__ __attribute__((aligned(16))) double s_dyn[];  // a.sig_lds: sigma^2 of the chain [ld]
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     // a launch covers the chains [sl.chain_lo, sl.chain_lo + sl.chain_n): all of them, or one group of a pipelined host-callback job
-    const int64_t chain = sl.chain_lo + ((W == 1) ? (int64_t)blockIdx.x * 4 + wib : (int64_t)blockIdx.x);
+    const int cpb = (W == 1 && REMOTE && NPHIP_JIT != 0) ? sl.cpb : 4;   // chains of this workgroup (LaunchSlice::cpb)
+    const int64_t chain = sl.chain_lo + ((W == 1) ? (int64_t)blockIdx.x * cpb + wib : (int64_t)blockIdx.x);
     if (NV > 0 && W == 1 && !REMOTE) {
         // stage the fused model in LDS once per workgroup: mu | a | b shifted by one with -0.0 sentinels
         const int64_t ld = A.ld;
@@ -3596,11 +3597,12 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) __attribute__((amdgpu_waves_
     }
 #if NPHIP_JIT
     if (REMOTE) {   // the model's shared LDS block: filled once per workgroup and launch, by all of its threads
+        if (threadIdx.x == 0) nphip_chains_per_block_ = cpb;   // (NPHIP_CHAIN_SLOT of the generated prelude)
         nphip_density_stage(*(const NphipData*)A.dens_data, (double*)s_dyn + (size_t)(W == 1 ? 4 : 1) * A.dens_lds_doubles, (int)threadIdx.x, (int)blockDim.x);
         __syncthreads();
     }
 #endif
-    if (chain >= (int64_t)sl.chain_lo + sl.chain_n) return;
+    if (chain >= (int64_t)sl.chain_lo + sl.chain_n || (W == 1 && wib >= cpb)) return;
     if (REMOTE && !NPHIP_JIT) {
         // Roll call: chains of a resident launch wait for each other inside the kernel, so all of them must be on the device
         // before any starts.  Each arrives once; the last one sets the verdict GO.  A chain that has waited 5 ms sets it to FAIL
@@ -4136,6 +4138,7 @@ __global__ __launch_bounds__(NPHIP_JIT_W == 1 ? 256 : 64 * NPHIP_JIT_W) void k_d
     // the chain's position and gradient rows in LDS, as in the resident kernel (the density reads x[] several times)
     const int ldp = (dim + 1) & ~1;
     double* rows = shared + shared_doubles + (size_t)slot * 2 * ldp;
+    if (threadIdx.x == 0) nphip_chains_per_block_ = CPB;
     nphip_density_stage(*data, shared, (int)threadIdx.x, (int)blockDim.x);
     if (rows_in_lds && chain < n_chains) for (int i = tid; i < dim; i += TPC) rows[i] = q[chain * (uint64_t)dim + i];
     __syncthreads();
@@ -4155,8 +4158,13 @@ __global__ __launch_bounds__(NPHIP_JIT_W == 1 ? 256 : 64 * NPHIP_JIT_W) void k_d
 extern "C" {
 // nphip_jit_launch_fn (host.hip): one launch of the resident kernel over the slice's chains
 int nphip_jit_launch(const nphip::Args* d_args, int max_evals, void* stream, const nphip::LaunchSlice* sl, uint64_t dyn_lds_bytes) {
-    const dim3 g(NPHIP_JIT_W == 1 ? ((unsigned)sl->chain_n + 3) / 4 : (unsigned)sl->chain_n), b(NPHIP_JIT_W == 1 ? 256 : 64 * NPHIP_JIT_W);
-    hipLaunchKernelGGL((nphip::k_advance<false, NPHIP_JIT_W, NPHIP_JIT_NV, false, true, (NPHIP_JIT_LR != 0)>), g, b, (size_t)dyn_lds_bytes, (hipStream_t)stream, d_args, max_evals, 0, *sl);
+    // one wave per chain: four chains per workgroup when the job fills the device's 1024 SIMDs, fewer to reach all 256 CUs otherwise
+    // (NPHIP_JIT_CPB=1|2|4 overrides: measurements)
+    static const int forced = [] { const char* e = getenv("NPHIP_JIT_CPB"); const int v = e ? atoi(e) : 0; return (v == 1 || v == 2 || v == 4) ? v : 0; }();
+    nphip::LaunchSlice s2 = *sl;
+    s2.cpb = forced ? forced : (sl->chain_n > 512 ? 4 : (sl->chain_n > 256 ? 2 : 1));
+    const dim3 g(NPHIP_JIT_W == 1 ? ((unsigned)sl->chain_n + s2.cpb - 1) / s2.cpb : (unsigned)sl->chain_n), b(NPHIP_JIT_W == 1 ? 256 : 64 * NPHIP_JIT_W);
+    hipLaunchKernelGGL((nphip::k_advance<false, NPHIP_JIT_W, NPHIP_JIT_NV, false, true, (NPHIP_JIT_LR != 0)>), g, b, (size_t)dyn_lds_bytes, (hipStream_t)stream, d_args, max_evals, 0, s2);
     return (int)hipGetLastError();
 }
 int nphip_jit_w(void) { return NPHIP_JIT_W; }
@@ -4194,6 +4202,7 @@ __global__ __launch_bounds__(NPHIP_JIT_W == 1 ? 256 : 64 * NPHIP_JIT_W) void k_e
     const int slot = NPHIP_JIT_W == 1 ? (int)(threadIdx.x >> 6) : 0, tid = NPHIP_JIT_W == 1 ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
     const uint64_t row = (uint64_t)blockIdx.x * CPB + slot;
     double* shared = s_scratch + (size_t)CPB * lds_doubles;
+    if (threadIdx.x == 0) nphip_chains_per_block_ = CPB;
     nphip_density_stage(*data, shared, (int)threadIdx.x, (int)blockDim.x);
     __syncthreads();
     if (row >= n_rows) return;

@@ -128,6 +128,8 @@ def generated_source(user_source: str, layout) -> str:
         "// the model also defines its expand step as a device function (nphip_expand: generated by nutpie_amd.symbolic)",
         "#define NPHIP_JIT_EXPAND 1" if has_expand else "",
         "__device__ double nphip_expand(const NphipData& data, int dim, const double* x, double* out, double* lds, const double* shared, int lane);" if has_expand else "",
+        "// chains per workgroup of the running launch (one wave per chain): written by the kernels before their first barrier — LaunchSlice::cpb",
+        "__shared__ int nphip_chains_per_block_;",
         '#include "kernels.hip"',
         "// the engine's wave reduction (sum over the 64 lanes in the contract's order; the same value in every lane)",
         "// `lds` and `shared` are LDS: through these casts the compiler emits ds_read / ds_write instead of flat accesses",
@@ -137,9 +139,9 @@ def generated_source(user_source: str, layout) -> str:
         "// the same over ALL threads of the chain (waves_per_chain > 1: wave totals added in wave order through LDS; every thread gets the",
         "// same value), the number of threads that evaluate one chain's density, and the barrier between its phases",
         "#define NPHIP_CHAIN_THREADS (64 * NPHIP_JIT_W)",
-        "// which of the launch's resident chains this is (one wave per chain: four per workgroup) — the index of its block of",
+        "// which of the launch's resident chains this is (one wave per chain: up to four per workgroup) — the index of its block of",
         "// data.scratch__ when the model asked for scratch in device memory (scratch_doubles_per_chain)",
-        "#define NPHIP_CHAIN_SLOT (NPHIP_JIT_W == 1 ? (int)(blockIdx.x * 4 + (threadIdx.x >> 6)) : (int)blockIdx.x)",
+        "#define NPHIP_CHAIN_SLOT (NPHIP_JIT_W == 1 ? (int)(blockIdx.x * nphip_chains_per_block_ + (threadIdx.x >> 6)) : (int)blockIdx.x)",
         "template <int N> static __device__ __forceinline__ void nphip_chain_sumN(double (&v)[N]) {",
         "    if (NPHIP_JIT_W == 1) {   // (the same bits whichever way the wave sums are taken: kernels.hip, wave_sumN_halving)",
         "        if constexpr (N == 2 || N == 4 || N == 8) nphip::wave_sumN_halving(v);",
