@@ -63,6 +63,18 @@ template <int W>
 // lean kernels: the unrolled chunk sweeps must stay sweeps — without a fence per chunk the scheduler issues the loads of
 // all chunks first and the allocator spills the resident state to make room for them
 #define NPHIP_CHUNK_FENCE(k) __builtin_amdgcn_sched_barrier(0)
+// one wave per chain: up to this many chunks per lane the kernel is built for two waves per SIMD (256 registers each).
+// Not the kernel of a runtime-compiled density: its workgroup's LDS (four chains' scratch + the model's shared block) leaves one
+// workgroup per CU anyway, and the density wants the registers — radon, 512 / 2048 chains, same box: 56.6 -> 62.1 / 96.2 -> 107.7 M
+// leapfrogs/s for the traced torch density, 50.3 -> 51.5 / 90.6 -> 93.7 for the one written as expressions (profiles/r5_jit_occupancy.txt);
+// a small density stays below 256 registers by itself.
+#ifndef NPHIP_W1_OCC2_MAX
+#if NPHIP_JIT
+#define NPHIP_W1_OCC2_MAX 0
+#else
+#define NPHIP_W1_OCC2_MAX 3
+#endif
+#endif
 // register kernels with several waves per chain: up to this many chunks per wave run two waves per SIMD (256 registers each)
 #ifndef NPHIP_RW_OCC2_MAX
 #define NPHIP_RW_OCC2_MAX 4
@@ -3570,7 +3582,7 @@ struct Machine {
 // `Ap` points to the engine's argument block in device memory (written once at set-up); it is read through
 // the constant address space, i.e. with scalar loads into SGPRs.  Per-launch scalars are kernel parameters.
 template <bool FUSED, int W, int NV, bool LEAN = false, bool REMOTE = false, bool LR = false>
-__global__ __launch_bounds__(W == 1 ? 256 : 64 * W) __attribute__((amdgpu_waves_per_eu(LEAN ? NPHIP_LEAN_OCC(W) : ((NV > 0 && !LR && NV <= (W == 1 ? 3 : NPHIP_RW_OCC2_MAX)) ? 2 : ((!FUSED && NV == 0 && !REMOTE) ? NPHIP_CB_OCC(W) : 1)), LEAN ? NPHIP_LEAN_OCC(W) : ((NV > 0 && !LR && NV <= (W == 1 ? 3 : NPHIP_RW_OCC2_MAX)) ? 2 : 8)))) void k_advance(const Args* __restrict__ Ap, int max_evals, int have_result, const LaunchSlice sl) {
+__global__ __launch_bounds__(W == 1 ? 256 : 64 * W) __attribute__((amdgpu_waves_per_eu(LEAN ? NPHIP_LEAN_OCC(W) : ((NV > 0 && !LR && NV <= (W == 1 ? NPHIP_W1_OCC2_MAX : NPHIP_RW_OCC2_MAX)) ? 2 : ((!FUSED && NV == 0 && !REMOTE) ? NPHIP_CB_OCC(W) : 1)), LEAN ? NPHIP_LEAN_OCC(W) : ((NV > 0 && !LR && NV <= (W == 1 ? NPHIP_W1_OCC2_MAX : NPHIP_RW_OCC2_MAX)) ? 2 : 8)))) void k_advance(const Args* __restrict__ Ap, int max_evals, int have_result, const LaunchSlice sl) {
     const NPHIP_CONST Args& A = *(const NPHIP_CONST Args*)Ap;
     constexpr int WAVES = (W == 1) ? 4 : W;
     __shared__ Ctl s_ctl[WAVES];
