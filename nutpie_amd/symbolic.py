@@ -901,7 +901,7 @@ class _Gen:
         emit(f"__device__ double {self.fn_name}(const NphipData& data, int dim, const double* x, double* g, double* lds, const double* shared, int lane) {{")
         # dimension lengths, data pointers (shared LDS where staged, else global), LDS scratch
         for d in m._dims.values():
-            emit(f"    const int n_{d.name} = {d.len_c()};")
+            emit(f"    const int n_{d.name} = {m._len_c(d)};")
         off_expr = "0"
         for name, kind, dim in shared_fields:
             n_c = _field_len_c(name, dim, m._matrix_cols.get(name, 1))
@@ -1273,6 +1273,7 @@ class Model:
         self._transforms: dict[str, tuple] = {}      # parameter -> (kind, lower, upper, shape): what initial_point inverts
         self._initvals: dict[str, Any] = {}          # parameter -> the constrained value its chains start around (PyMC's `initval`)
         self._staged = True
+        self._specialize = True     # lengths of data dimensions are compile-time constants of the generated source (compile(specialize=...))
 
     # ---- declarations
     def dim(self, name: str, size: int | None = None) -> Dim:
@@ -1605,6 +1606,11 @@ class Model:
             total = total + t
         return total
 
+    def _len_c(self, d: Dim) -> str:
+        """C expression of a dimension's length: a constant, also for a data dimension when the source is specialised to the data it is
+        compiled with (constant loop bounds and LDS offsets: config 3 +9 % — with_data compiles again when a length changes)"""
+        return str(d.len_py(self._data)) if (self._specialize and d.size is None) else d.len_c()
+
     def _stage_source(self):
         """``nphip_density_stage`` + the order of the staged fields: doubles first, then the 32-bit integers (each rounded up to a
         whole double)."""
@@ -1613,7 +1619,7 @@ class Model:
             return "", fields
         L = ["__device__ void nphip_density_stage(const NphipData& data, double* shared, int thread, int n_threads) {"]
         for d in self._dims.values():
-            L.append(f"    const int n_{d.name} = {d.len_c()};")
+            L.append(f"    const int n_{d.name} = {self._len_c(d)};")
         L.append("    double* at = shared;")
         for name, kind, dim in fields:
             n = _field_len_c(name, dim, self._matrix_cols.get(name, 1))
@@ -1708,13 +1714,23 @@ class Model:
                 gen.spilled.append(key)
 
     def compile(self, *, init="uniform", resident: bool = True, coords=None, dims=None, waves_per_chain: int | None = None,
-                expanded_names=None, expanded_shapes=None, expand_fn=None):
+                expanded_names=None, expanded_shapes=None, expand_fn=None, specialize: bool = True):
         """-> :class:`SymbolicModel` (a :class:`nutpie_amd.density.DensitySourceModel`).  ``waves_per_chain`` (1, 2, 4): wavefronts
         that evaluate one chain's density together — more than one pays with fewer chains than the device has SIMDs (1024), and a
         workgroup then holds ONE chain instead of four, i.e. a quarter of the per-chain LDS: the default (None) is one wave per
         chain unless the model's scratch (one double per observation and gathered value) only fits with more."""
         from nutpie_amd.density import from_density_source
+        import copy
 
+        # (the compiled model keeps a snapshot of the front-end: what is decided here — staging, specialisation, the LDS plan — belongs
+        #  to THIS compilation, and the same Model may be compiled again with other options)
+        self = copy.copy(self)
+        self._data = dict(self._data)
+        # ``specialize``: the lengths of the data arrays become constants of the source (with_data compiles again — a cached library
+        # or a few seconds of hipcc — when one of them changes); False: one library for data of any length
+        self._specialize = bool(specialize)
+        self._compile_kw = dict(init=init, resident=resident, coords=coords, dims=dims, waves_per_chain=waves_per_chain, expanded_names=expanded_names,
+                                expanded_shapes=expanded_shapes, expand_fn=expand_fn, specialize=specialize)
         logp = self.logp_expr()
         grads = gradient(logp, self._params)
         self._staged = 8 * self._shared_doubles_unconditional(self._data) <= self.STAGE_LIMIT
@@ -1932,6 +1948,13 @@ def _symbolic_model_class():
                         rows = len(new[name]) // f._matrix_cols.get(name, 1) if kind in ("double", "int") else 0
                         if dd is d and kind in ("double", "int") and not name.endswith("__rows") and rows != n:
                             raise ValueError(f"data on dimension {d.name!r} must share one length ({name!r} has {rows}, {d.runtime_len!r} has {n})")
+            # a source specialised to the lengths of its data: other lengths are another source (compiled now, or found in the cache)
+            if f._specialize and any(d.size is None and d.len_py(new) != d.len_py(f._data) for d in f._dims.values()):
+                import copy
+
+                g = copy.copy(f)
+                g._data = {k: v for k, v in new.items() if k != "scratch__"}
+                return g.compile(**f._compile_kw)
             # what compile() decided from the ORIGINAL data: re-derive the shapes of values on a data dimension, and refuse — here,
             # not after the run — data that no longer fit the LDS plan (staging, waves per chain, spilled arrays)
             need, budget = f._plan_check(new)

@@ -13,7 +13,9 @@ from nutpie_amd.radon import radon_symbolic_model, radon_traced_model
 
 chains = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 tag = f"cpb={os.environ.get('NPHIP_JIT_CPB', 'auto')} chains={chains}"
-for label, make in (("generated", lambda: radon_symbolic_model().compile()), ("traced", radon_traced_model)):
+spec = os.environ.get("SPECIALIZE", "1") != "0"
+tag += f" specialize={int(spec)}"
+for label, make in (("generated", lambda: radon_symbolic_model().compile(specialize=spec)), ("traced", radon_traced_model)):
     m = make()
     for rep in range(2):
         s = hip.PyNutsSettings.Diag(20260926)

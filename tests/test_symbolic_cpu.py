@@ -91,7 +91,7 @@ def test_compiles_for_gfx950_and_swaps_data_without_recompiling(tmp_path, monkey
     from nutpie_amd.density import compile_density, data_layout
 
     m = zoo.poisson_offsets()
-    compiled = m.compile()
+    compiled = m.compile(specialize=False)     # one library for data of any length
     path = compile_density(compiled._source, data_layout(compiled._data), compiled.n_dim)
     assert os.path.exists(path)
     rng = np.random.default_rng(0)
@@ -103,6 +103,16 @@ def test_compiles_for_gfx950_and_swaps_data_without_recompiling(tmp_path, monkey
 
     swapped = compiled.with_data(y=y2, log_fact=gammaln(y2 + 1.0), site_idx=site, prior_scale=3.0)
     assert compile_density(swapped._source, data_layout(swapped._data), swapped.n_dim) == path
+    # the default: the lengths of the data are constants of the source — new values of the same length keep the library, another
+    # length is another source (compiled when it is first used)
+    special = zoo.poisson_offsets().compile()
+    n1 = len(special._data["y"])
+    assert f"const int n_obs = {n1};" in special._source and "data.n_y" not in special._source
+    same = special.with_data(y=special._data["y"] + 1.0, log_fact=gammaln(special._data["y"] + 2.0))
+    assert same._source == special._source
+    other = special.with_data(y=y2, log_fact=gammaln(y2 + 1.0), site_idx=site, prior_scale=3.0)
+    assert f"const int n_obs = {n2};" in other._source and len(other._data["site_idx__pos"]) == n2
+    assert np.allclose(other.logp_and_grad_numpy(0.1 * np.ones((1, other.n_dim)))[0], swapped.logp_and_grad_numpy(0.1 * np.ones((1, other.n_dim)))[0])
     assert len(swapped._data["site_idx__pos"]) == n2 and swapped._data["site_idx__rows"][-1] == n2
     lds, shared = swapped._lds()
     lds0, shared0 = compiled._lds()
@@ -161,10 +171,15 @@ def test_waves_per_chain_follow_the_lds_the_model_needs():
     assert big._waves == 2 and big._lds()[1] == 0            # (and its data are read through L2: too much to stage)
     assert zoo.radon(synthetic_radon_data(n_obs=3000)).compile(waves_per_chain=4)._waves == 4
     # nothing fits: four chains per workgroup again, the two observation-sized arrays of adjoints in device memory (data.scratch__)
-    huge = zoo.radon(synthetic_radon_data(n_obs=40000)).compile()
+    huge = zoo.radon(synthetic_radon_data(n_obs=40000)).compile(specialize=False)
     assert huge._waves == 1 and huge._scratch(huge._data) == 80000 and "NPHIP_CHAIN_SLOT" in huge._source
     assert huge._lds()[0] < 4096 and huge.with_data(y=np.zeros(10), floor=np.zeros(10), county=np.zeros(10, dtype=int))._scratch(
         {"y": np.zeros(10)}) == 20
+    # the default (a source specialised to the lengths of its data): data of another length are planned — and compiled — afresh
+    huge = zoo.radon(synthetic_radon_data(n_obs=40000)).compile()
+    assert huge._waves == 1 and huge._scratch(huge._data) == 80000 and "const int n_obs = 40000;" in huge._source
+    small = huge.with_data(y=np.zeros(10), floor=np.zeros(10), county=np.zeros(10, dtype=int))
+    assert small._waves == 1 and not small._scratch and "NPHIP_CHAIN_SLOT" not in small._source and "const int n_obs = 10;" in small._source
 
 
 @pytest.mark.parametrize("name,waves", [("nested", 2), ("regression", 4)])
@@ -265,8 +280,12 @@ def test_with_data_rederives_shapes_and_checks_the_plan():
     assert cm2.shapes == {"mu": (), "resid": (9,)} and cm.shapes["resid"] == (5,)
     ex = cm2._expand_draws(np.zeros((2, 3, 1)))
     assert ex["resid"].shape == (2, 3, 9) and np.array_equal(ex["resid"][0, 0], np.arange(9.0))
+    # one library for data of any length (specialize=False): data that outgrow its LDS plan are refused here ...
     with pytest.raises(ValueError, match="do not fit the LDS plan"):
-        cm.with_data(y=np.zeros(200_000))
+        m.compile(specialize=False).with_data(y=np.zeros(200_000))
+    # ... the default compiles for the new length, with a plan of its own (here: the observation-sized array in device memory)
+    big = cm.with_data(y=np.zeros(200_000))
+    assert big.shapes["resid"] == (200_000,) and "const int n_obs = 200000;" in big._source
 
 
 def test_expression_table_does_not_outlive_its_models():
