@@ -218,8 +218,8 @@ struct LaunchSlice {
     int grp_lo[9];         // group g = chains [grp_lo[g], grp_lo[g + 1])
     unsigned grp_seq[8];   // sequence number of each group's first evaluation in this launch
     // runtime-compiled densities, one wave per chain (set by nphip_jit_launch, read by its kernel only): chains per workgroup.  4 fills
-    // every SIMD of a CU; a job with fewer chains than the device has SIMDs is spread over all CUs instead (2 or 1 per workgroup: the
-    // chains of a workgroup share its LDS bandwidth, and a density moves ~100 KB through it per evaluation)
+    // every SIMD of a CU; a job with no more chains than the device has CUs gets a CU per chain instead (the chains of a workgroup share
+    // its LDS bandwidth, and a density moves ~100 KB through it per evaluation)
     int cpb;
 };
 

@@ -4170,11 +4170,14 @@ __global__ __launch_bounds__(NPHIP_JIT_W == 1 ? 256 : 64 * NPHIP_JIT_W) void k_d
 extern "C" {
 // nphip_jit_launch_fn (host.hip): one launch of the resident kernel over the slice's chains
 int nphip_jit_launch(const nphip::Args* d_args, int max_evals, void* stream, const nphip::LaunchSlice* sl, uint64_t dyn_lds_bytes) {
-    // one wave per chain: four chains per workgroup when the job fills the device's 1024 SIMDs, fewer to reach all 256 CUs otherwise
-    // (NPHIP_JIT_CPB=1|2|4 overrides: measurements)
+    // one wave per chain: four chains per workgroup (every SIMD of a CU), or ONE when the job has no more chains than the device has
+    // CUs: the chains of a workgroup share its LDS bandwidth (256 chains: +9-12 %, profiles/r5_jit_chains_per_workgroup.txt).  Not two
+    // per workgroup up to 512 chains: +1-3 % for that job, but its 256 workgroups then hold every CU's LDS and a second job of the
+    // same size no longer runs beside it (two concurrent 512-chain jobs: 70 instead of ~115 M leapfrogs/s).  (NPHIP_JIT_CPB=1|2|4
+    // overrides: measurements)
     static const int forced = [] { const char* e = getenv("NPHIP_JIT_CPB"); const int v = e ? atoi(e) : 0; return (v == 1 || v == 2 || v == 4) ? v : 0; }();
     nphip::LaunchSlice s2 = *sl;
-    s2.cpb = forced ? forced : (sl->chain_n > 512 ? 4 : (sl->chain_n > 256 ? 2 : 1));
+    s2.cpb = forced ? forced : (sl->chain_n > 256 ? 4 : 1);
     const dim3 g(NPHIP_JIT_W == 1 ? ((unsigned)sl->chain_n + s2.cpb - 1) / s2.cpb : (unsigned)sl->chain_n), b(NPHIP_JIT_W == 1 ? 256 : 64 * NPHIP_JIT_W);
     hipLaunchKernelGGL((nphip::k_advance<false, NPHIP_JIT_W, NPHIP_JIT_NV, false, true, (NPHIP_JIT_LR != 0)>), g, b, (size_t)dyn_lds_bytes, (hipStream_t)stream, d_args, max_evals, 0, s2);
     return (int)hipGetLastError();

@@ -75,8 +75,8 @@ def test_radon_resident_kernel_equals_the_device_callback_path(hip):
 
 @pytest.mark.parametrize("chains", [264, 516])
 def test_chains_per_workgroup_do_not_change_the_draws(hip, chains):
-    # a job that does not fill the device's 1024 SIMDs is spread over all CUs: one chain per workgroup up to 256 chains (every test
-    # above), two up to 512, four beyond (LaunchSlice::cpb) — the draws are those of the launch-per-evaluation path either way
+    # one chain per workgroup up to 256 chains (every test above), four beyond (LaunchSlice::cpb) — the draws are those of the
+    # launch-per-evaluation path either way
     kw = dict(chains=chains, tune=40, draws=15, seed=5)
     a = run(radon_density_model(), **kw)
     b = run(radon_density_model(resident=False), **kw)
