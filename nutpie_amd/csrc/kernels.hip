@@ -361,7 +361,10 @@ struct SCache {
 // LR (NV > 0, not LEAN; round 4): the register-resident leaf under the low-rank metric M^-1 = D^1/2 (I + V (Lambda - I) V') D^1/2 —
 // the cursor's velocity v = M^-1 p is a sixth resident vector, every P-slot carries it as a third vector (Args::pvec = 3), the k
 // columns of V are streamed from L2 against the resident momentum (k dots + k updates per half step), and the LDS ring is not used.
-template <bool FUSED, int W, int NV = 0, bool LEAN = false, bool REMOTE = false, bool LR = false>
+// TAG: nothing but a distinct type — the out-of-line rare paths (rare_end_draw, rare_phase_fn) are members, and a function shared by two
+// kernels with different register budgets (k_advance<..., WIDE>) is compiled for the larger one: the capped kernel would report its
+// callee's 288 registers and lose its second wave per SIMD (measured: 4096 chains of D = 256 at 396 instead of 614 M leapfrogs/s)
+template <bool FUSED, int W, int NV = 0, bool LEAN = false, bool REMOTE = false, bool LR = false, int TAG = 0>
 struct Machine {
     static constexpr bool INK = FUSED || REMOTE;   // evaluations happen inside the kernel: a launch runs many steps
     // launch-per-evaluation kernels: the end of a draw is cut into slices of a launch each (engine_types.h: PH_DRAW_END / PH_DRAW_BEGIN)
@@ -3581,8 +3584,12 @@ struct Machine {
 
 // `Ap` points to the engine's argument block in device memory (written once at set-up); it is read through
 // the constant address space, i.e. with scalar loads into SGPRs.  Per-launch scalars are kernel parameters.
-template <bool FUSED, int W, int NV, bool LEAN = false, bool REMOTE = false, bool LR = false>
-__global__ __launch_bounds__(W == 1 ? 256 : 64 * W) __attribute__((amdgpu_waves_per_eu(LEAN ? NPHIP_LEAN_OCC(W) : ((NV > 0 && !LR && NV <= (W == 1 ? NPHIP_W1_OCC2_MAX : NPHIP_RW_OCC2_MAX)) ? 2 : ((!FUSED && NV == 0 && !REMOTE) ? NPHIP_CB_OCC(W) : 1)), LEAN ? NPHIP_LEAN_OCC(W) : ((NV > 0 && !LR && NV <= (W == 1 ? NPHIP_W1_OCC2_MAX : NPHIP_RW_OCC2_MAX)) ? 2 : 8)))) void k_advance(const Args* __restrict__ Ap, int max_evals, int have_result, const LaunchSlice sl) {
+// WIDE: the same kernel without the two-waves-per-SIMD register cap of the small one-wave kernels — what a job that brings at most one
+// wave per SIMD (<= 1024 chains) is launched with: 2 / 3 chunks per lane spill 24 / 75 VGPRs under the cap (D = 256 / 384, 1024 chains:
+// 385 -> 424 / 297 -> 378 M leapfrogs/s without it); with 4096 chains the second wave per SIMD is worth more (616 against 437 / 404
+// against 389: profiles/r5_small_kernels_register_cap.txt)
+template <bool FUSED, int W, int NV, bool LEAN = false, bool REMOTE = false, bool LR = false, bool WIDE = false>
+__global__ __launch_bounds__(W == 1 ? 256 : 64 * W) __attribute__((amdgpu_waves_per_eu(LEAN ? NPHIP_LEAN_OCC(W) : ((NV > 0 && !LR && !WIDE && NV <= (W == 1 ? NPHIP_W1_OCC2_MAX : NPHIP_RW_OCC2_MAX)) ? 2 : ((!FUSED && NV == 0 && !REMOTE) ? NPHIP_CB_OCC(W) : 1)), LEAN ? NPHIP_LEAN_OCC(W) : ((NV > 0 && !LR && !WIDE && NV <= (W == 1 ? NPHIP_W1_OCC2_MAX : NPHIP_RW_OCC2_MAX)) ? 2 : 8)))) void k_advance(const Args* __restrict__ Ap, int max_evals, int have_result, const LaunchSlice sl) {
     const NPHIP_CONST Args& A = *(const NPHIP_CONST Args*)Ap;
     constexpr int WAVES = (W == 1) ? 4 : W;
     __shared__ Ctl s_ctl[WAVES];
@@ -3679,9 +3686,9 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) __attribute__((amdgpu_waves_
         const int64_t left = (int64_t)sl.chain_n - (int64_t)blockIdx.x * 4;
         c->hs_wgn = (W > 1) ? 1 : (left < 4 ? left : 4);   // chains of this workgroup (W == 1: four; group bounds are multiples of 4)
     }
-    Machine<FUSED, W, NV, LEAN, REMOTE, LR> m(A, c, (LdsDouble)s_red, chain, (LdsDouble)s_par, (LdsDouble)s_ring + ((LEAN || LR) ? 0 : (size_t)wib * 4 * 128 * (NV > 0 ? NV : 1)),
+    Machine<FUSED, W, NV, LEAN, REMOTE, LR, (WIDE ? 1 : 0)> m(A, c, (LdsDouble)s_red, chain, (LdsDouble)s_par, (LdsDouble)s_ring + ((LEAN || LR) ? 0 : (size_t)wib * 4 * 128 * (NV > 0 ? NV : 1)),
                             (LdsDouble)s_edge);
-    __shared__ double s_park[(!FUSED && NV == 0 && W > 1) ? Machine<FUSED, W, NV, LEAN, REMOTE, LR>::kParkMax * W : 2];
+    __shared__ double s_park[(!FUSED && NV == 0 && W > 1) ? Machine<FUSED, W, NV, LEAN, REMOTE, LR, (WIDE ? 1 : 0)>::kParkMax * W : 2];
     m.parked = (LdsDouble)s_park;
     m.run(max_evals, have_result != 0, (LEAN || ((NV == 0 || NV == -1) && W >= 8 && A.sig_lds)) ? (LdsDouble)s_dyn : nullptr, sl.materialise != 0);
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -3858,8 +3865,13 @@ hipError_t launch_fam_w1(const Args& a, const Args* d_args, hipStream_t st, cons
         case NPHIP_DEV_W1NV: hipLaunchKernelGGL((k_advance<true, 1, NPHIP_DEV_W1NV>), g, b, 0, st, d_args, me, hr, sl); break;
 #elif !defined(NPHIP_DEV_BUILD)
         case 1: hipLaunchKernelGGL((k_advance<true, 1, 1>), g, b, 0, st, d_args, me, hr, sl); break;
-        case 2: hipLaunchKernelGGL((k_advance<true, 1, 2>), g, b, 0, st, d_args, me, hr, sl); break;
-        case 3: hipLaunchKernelGGL((k_advance<true, 1, 3>), g, b, 0, st, d_args, me, hr, sl); break;
+        // (2, 3 chunks per lane: built for two waves per SIMD — unless the job has no second wave to bring: k_advance<..., WIDE>)
+        case 2: if (sl.chain_n <= 1024) hipLaunchKernelGGL((k_advance<true, 1, 2, false, false, false, true>), g, b, 0, st, d_args, me, hr, sl);
+                else hipLaunchKernelGGL((k_advance<true, 1, 2>), g, b, 0, st, d_args, me, hr, sl);
+                break;
+        case 3: if (sl.chain_n <= 1024) hipLaunchKernelGGL((k_advance<true, 1, 3, false, false, false, true>), g, b, 0, st, d_args, me, hr, sl);
+                else hipLaunchKernelGGL((k_advance<true, 1, 3>), g, b, 0, st, d_args, me, hr, sl);
+                break;
         case 4: hipLaunchKernelGGL((k_advance<true, 1, 4>), g, b, 0, st, d_args, me, hr, sl); break;
         case 5: hipLaunchKernelGGL((k_advance<true, 1, 5>), g, b, 0, st, d_args, me, hr, sl); break;
         case 6: hipLaunchKernelGGL((k_advance<true, 1, 6>), g, b, 0, st, d_args, me, hr, sl); break;

@@ -150,6 +150,23 @@ def test_correlated_gaussian_all_geometries(hip, oracle, dim, waves):
     assert np.array_equal(got.stats["mass_matrix_inv"], want.stats["mass_matrix_inv"])
 
 
+@pytest.mark.parametrize("dim", [200, 380])
+def test_small_kernels_with_and_without_the_register_cap_draw_the_same(hip, oracle, dim):
+    # 2 / 3 chunks per lane: a job of up to 1024 chains (at most one wave per SIMD) runs the kernel built without the two-waves-per-SIMD
+    # register cap (k_advance<..., WIDE>), a larger one the capped kernel: chains are keyed by their global id, so the first chains
+    # of a 1100-chain job are the chains of a small one — and those are the oracle's
+    model = ar1_gaussian(dim)
+    m = hip.TridiagGaussianModel(model.diag, model.offdiag)
+    big, W = run_engine(hip, m, chains=1100, tune=40, draws=10, seed=dim)
+    small, _ = run_engine(hip, m, chains=24, tune=40, draws=10, seed=dim)
+    assert W == 1
+    assert np.array_equal(big.draws[:24], small.draws) and np.array_equal(big.draws[-1].shape, small.draws[0].shape)
+    for k in ("n_steps", "energy", "step_size", "diverging"):
+        assert np.array_equal(np.asarray(big.stats[k])[:24], np.asarray(small.stats[k])), k
+    want = oracle.sample_tridiag(oracle_settings(oracle, chains=24, tune=40, draws=10, seed=dim, W=1), model.diag, model.offdiag)
+    assert_trace_equal(small, want)
+
+
 @pytest.mark.parametrize("dim", [5, 300, 1000])
 def test_streaming_kernel_single_wave_bit_identical(hip, oracle, dim):
     # the memory-resident (streaming) fused kernel with one wave per chain — the family used for D > 1024,
