@@ -291,6 +291,10 @@ class _Interp:
             return _Bool(("ge", ea - eb), shape)
         if kind == "le":
             return _Bool(("ge", eb - ea), shape)
+        if kind == "eq":
+            return _Bool(("and", ("ge", ea - eb), ("ge", eb - ea)), shape)
+        if kind == "ne":
+            return _Bool(("not", ("and", ("ge", ea - eb), ("ge", eb - ea))), shape)
         raise UnsupportedTorchOp(f"comparison {kind} of traced values")
 
     def as_bool(self, v) -> _Bool:
@@ -729,8 +733,11 @@ def _run(gm, it: _Interp, x_shape, data_values: dict[str, Any]):
             if hi is not None:
                 r = B(r, hi, lambda x, y: S.select(y - x, x, y, False))
             env[node] = r
-        elif base in ("gt", "lt", "ge", "le"):
+        elif base in ("gt", "lt", "ge", "le", "eq", "ne"):
             env[node] = it.compare(args[0], args[1], base)
+        elif base == "logaddexp":
+            # max(a, b) + log1p(exp(-|a - b|))
+            env[node] = B(args[0], args[1], lambda x, y: S.select(x - y, x, y, False) + S.log1p(S.exp(-S.absolute(x - y))))
         elif base in ("logical_not", "bitwise_not"):
             b_ = it.as_bool(a0)
             env[node] = _Bool(("not", b_.tree), b_.shape)
@@ -754,6 +761,35 @@ def _run(gm, it: _Interp, x_shape, data_values: dict[str, Any]):
             r = it.sum(a0, dims, args[2] if len(args) > 2 else kwargs.get("keepdim", False))
             cnt = _numel(it.shape_of(a0)) // max(_numel(r.shape), 1)
             env[node] = _Sym(r.expr * (1.0 / cnt), r.shape)
+        elif base in ("var", "std"):
+            # (sum of squared deviations from the mean) / (n - correction) over the given axes
+            dims = args[1] if len(args) > 1 else kwargs.get("dim")
+            corr = kwargs.get("correction", 1)
+            if isinstance(dims, bool):       # the overload var(x, unbiased)
+                corr, dims = (1 if dims else 0), None
+            corr = 1 if corr is None else corr
+            keep = kwargs.get("keepdim", False)
+            m_ = it.sum(a0, dims, True)
+            cnt = _numel(it.shape_of(a0)) // max(_numel(m_.shape), 1)
+            if cnt - corr <= 0:
+                raise UnsupportedTorchOp(f"{name} of {cnt} element(s) with correction {corr}")
+            dev = B(a0, _Sym(m_.expr * (1.0 / cnt), m_.shape), lambda x, y: x - y)
+            r = it.sum(_Sym(dev.expr * dev.expr, dev.shape), dims, keep)
+            e_ = r.expr * (1.0 / (cnt - corr))
+            env[node] = _Sym(S.sqrt(e_) if base == "std" else e_, r.shape)
+        elif base == "linalg_vector_norm":
+            ord_ = args[1] if len(args) > 1 else kwargs.get("ord", 2)
+            dims = args[2] if len(args) > 2 else kwargs.get("dim")
+            keep = args[3] if len(args) > 3 else kwargs.get("keepdim", False)
+            v_ = it.sym(a0)
+            if ord_ in (2, 2.0):
+                r = it.sum(_Sym(v_.expr * v_.expr, v_.shape), dims, keep)
+                env[node] = _Sym(S.sqrt(r.expr), r.shape)
+            elif ord_ in (1, 1.0):
+                r = it.sum(_Sym(S.absolute(v_.expr), v_.shape), dims, keep)
+                env[node] = r
+            else:
+                raise UnsupportedTorchOp(f"{name} with ord = {ord_}")
         elif base in ("amax", "amin", "max", "min", "logsumexp", "_softmax", "_log_softmax", "softmax", "log_softmax"):
             # reductions by the maximum — over ALL elements of the tensor (one chain's vector): the IR's `max` is dimension -> scalar
             v_ = it.sym(a0)

@@ -17,9 +17,9 @@ sys.path.insert(0, os.path.dirname(__file__))
 import torch_models as TM  # noqa: E402
 
 
-@pytest.mark.parametrize("name", list(TM.ALL))
+@pytest.mark.parametrize("name", list(TM.ALL) + list(TM.CPU_ONLY))
 def test_traced_density_and_gradient_equal_autograd(name):
-    D, fn, batched, shared = TM.ALL[name]()
+    D, fn, batched, shared = {**TM.ALL, **TM.CPU_ONLY}[name]()
     tr = trace(fn, D, batched=batched, shared_data=shared)
     cm = tr.compile()
     assert cm.n_dim == D and cm.shapes == {"x": (D,)}

@@ -295,3 +295,35 @@ def ordered_logistic():
 
 
 ALL["ordered_logistic"] = ordered_logistic
+
+
+# ---- models of the CPU tests only (tests/test_torch_trace_cpu.py): operations mapped onto the IR after the last GPU call of round 5 — the
+# IR operations they use have generated device code that the GPU suite covers through the models above
+CPU_ONLY = {}
+
+
+def negbin_and_pairwise():
+    """``torch.distributions.NegativeBinomial`` / ``Categorical`` (an ``eq`` against a scalar, masks from ``ne``), ``logaddexp`` of two
+    component densities, ``linalg.norm`` of a block, ``var`` / ``std`` of another (with and without Bessel's correction, along an axis)"""
+    rng = np.random.default_rng(33)
+    N = 30
+    X = _t(rng.normal(size=(N, 3)))
+    cnt = _t(rng.poisson(3.0, N).astype(np.float64))
+    y = _t(rng.normal(size=N))
+    cls = torch.as_tensor(rng.integers(0, 3, N))
+    dist = torch.distributions
+
+    def logp(x):
+        beta, b0, r, mu, z = x[:3], x[3], x[4], x[5:7], x[7:13]
+        ll = dist.NegativeBinomial(r.exp(), logits=X @ beta + b0).log_prob(cnt).sum()
+        ll = ll + torch.logaddexp(dist.Normal(mu[0], 1.0).log_prob(y), dist.Normal(mu[1], 1.0).log_prob(y) - 0.3).sum()
+        ll = ll + dist.Categorical(logits=x[13:16]).log_prob(cls).sum()
+        zz = z.reshape(2, 3)
+        ll = ll - torch.linalg.norm(z) - 0.1 * torch.linalg.vector_norm(zz, ord=1) - zz.var(dim=1).sum() - z.std() - zz.var(dim=0, correction=0).sum()
+        ll = ll + torch.where(cnt != 3.0, cnt * 0.01 * b0, -0.02 * b0 * b0).sum()
+        return ll - 0.5 * (x * x).sum() / 4.0
+
+    return 16, logp, False, {}
+
+
+CPU_ONLY["negbin_and_pairwise"] = negbin_and_pairwise
