@@ -875,6 +875,15 @@ def _run(gm, it: _Interp, x_shape, data_values: dict[str, Any]):
                 env[node] = _Sym(S._segsum(pairs, it.index(dst, dst.size, n_)), shp)
         elif base == "dot" or base == "vdot":
             env[node] = it.sum(B(args[0], args[1], lambda x, y: x * y))
+        elif base == "linalg_solve_triangular":
+            # A X = B (left) or X A = B with a CONSTANT triangular A (the scale_tril of a MultivariateNormal): a product with A^-1
+            A_, B_ = args[0], args[1]
+            if not it.is_const(A_):
+                raise UnsupportedTorchOp(f"{name} with a traced matrix (a covariance that depends on parameters)")
+            eye = torch.eye(A_.shape[-1], dtype=A_.dtype)
+            Ainv = torch.linalg.solve_triangular(A_, eye.expand_as(A_).contiguous(), upper=bool(kwargs.get("upper", False)),
+                                                 left=True, unitriangular=bool(kwargs.get("unitriangular", False)))
+            env[node] = it.matmul_like(Ainv, B_) if kwargs.get("left", True) else it.matmul_like(B_, Ainv)
         elif base in ("mv", "mm", "matmul", "bmm"):
             env[node] = it.matmul_like(args[0], args[1])
         elif base == "addmm" or base == "addmv":

@@ -304,7 +304,8 @@ CPU_ONLY = {}
 
 def negbin_and_pairwise():
     """``torch.distributions.NegativeBinomial`` / ``Categorical`` (an ``eq`` against a scalar, masks from ``ne``), ``logaddexp`` of two
-    component densities, ``linalg.norm`` of a block, ``var`` / ``std`` of another (with and without Bessel's correction, along an axis)"""
+    component densities, ``linalg.norm`` of a block, ``var`` / ``std`` of another (with and without Bessel's correction, along an axis), a
+    ``MultivariateNormal`` with a constant ``scale_tril``"""
     rng = np.random.default_rng(33)
     N = 30
     X = _t(rng.normal(size=(N, 3)))
@@ -321,9 +322,12 @@ def negbin_and_pairwise():
         zz = z.reshape(2, 3)
         ll = ll - torch.linalg.norm(z) - 0.1 * torch.linalg.vector_norm(zz, ord=1) - zz.var(dim=1).sum() - z.std() - zz.var(dim=0, correction=0).sum()
         ll = ll + torch.where(cnt != 3.0, cnt * 0.01 * b0, -0.02 * b0 * b0).sum()
+        # a multivariate normal with a constant Cholesky factor: solve_triangular with a constant matrix = a product with its inverse
+        ll = ll + dist.MultivariateNormal(x[16:19], scale_tril=L).log_prob(X).sum()
         return ll - 0.5 * (x * x).sum() / 4.0
 
-    return 16, logp, False, {}
+    L = torch.tril(_t(rng.normal(size=(3, 3)))) * 0.3 + torch.eye(3, dtype=torch.float64)
+    return 19, logp, False, {}
 
 
 CPU_ONLY["negbin_and_pairwise"] = negbin_and_pairwise
