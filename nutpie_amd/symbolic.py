@@ -54,7 +54,8 @@ import numpy as np
 __all__ = ["Model", "Expr", "Matrix", "exp", "log", "log1p", "sqrt", "softplus", "sigmoid", "tanh", "expm1", "erf", "erfc", "sin", "cos", "atan", "lgamma", "digamma",
            "absolute", "sign", "select", "pad", "trunc", "where_lt", "elem", "stack", "normal_lpdf",
            "halfnormal_lpdf", "student_t_lpdf", "cauchy_lpdf", "halfcauchy_lpdf", "exponential_lpdf", "lognormal_lpdf", "gamma_lpdf",
-           "bernoulli_logit_lpmf", "poisson_log_lpmf", "dirichlet_lpdf", "flat_lpdf"]
+           "inverse_gamma_lpdf", "beta_lpdf", "laplace_lpdf", "logistic_lpdf", "weibull_lpdf", "uniform_lpdf",
+           "bernoulli_logit_lpmf", "binomial_logit_lpmf", "negative_binomial_log_lpmf", "poisson_log_lpmf", "dirichlet_lpdf", "flat_lpdf"]
 
 _WAVE = 64
 _SEG_BATCH = os.environ.get("NUTPIE_AMD_SEG_MODE", "select") != "loop"   # (developer switch: "loop" = plain loops over a segment)
@@ -453,12 +454,20 @@ def halfnormal_lpdf(x, sigma) -> Expr:
     return -0.5 * (z * z) - log(sigma) + 0.5 * math.log(2.0 / math.pi)
 
 
-def student_t_lpdf(x, nu: float, mu, sigma) -> Expr:
-    """``nu`` is a Python number (its log-gamma terms are folded on the host)."""
+def _is_number(v) -> bool:
+    return isinstance(v, (int, float, np.integer, np.floating))
+
+
+def student_t_lpdf(x, nu, mu, sigma) -> Expr:
+    """``nu``: a Python number (its log-gamma terms are folded on the host) or an expression (a parameter: ``lgamma`` in the kernel)."""
     x, mu, sigma = Expr.wrap(x), Expr.wrap(mu), Expr.wrap(sigma)
-    nu = float(nu)
     z = (x - mu) / sigma
-    c = math.lgamma(0.5 * (nu + 1.0)) - math.lgamma(0.5 * nu) - 0.5 * math.log(nu * math.pi)
+    if _is_number(nu):
+        nu = float(nu)
+        c = math.lgamma(0.5 * (nu + 1.0)) - math.lgamma(0.5 * nu) - 0.5 * math.log(nu * math.pi)
+        return c - log(sigma) - (0.5 * (nu + 1.0)) * log1p((z * z) / nu)
+    nu = Expr.wrap(nu)
+    c = lgamma(0.5 * (nu + 1.0)) - lgamma(0.5 * nu) - 0.5 * log(nu * math.pi)
     return c - log(sigma) - (0.5 * (nu + 1.0)) * log1p((z * z) / nu)
 
 
@@ -489,11 +498,75 @@ def lognormal_lpdf(x, mu, sigma) -> Expr:
     return -0.5 * (z * z) - log(sigma) - lx - _HALF_LOG_2PI
 
 
-def gamma_lpdf(x, alpha: float, beta) -> Expr:
-    """x > 0; the shape ``alpha`` is a Python number (its log-gamma is folded on the host), the rate ``beta`` an expression."""
+def gamma_lpdf(x, alpha, beta) -> Expr:
+    """x > 0; the shape ``alpha`` is a Python number (its log-gamma is folded on the host) or an expression, the rate ``beta`` an
+    expression."""
     x, beta = Expr.wrap(x), Expr.wrap(beta)
-    alpha = float(alpha)
-    return alpha * log(beta) - math.lgamma(alpha) + (alpha - 1.0) * log(x) - beta * x
+    if _is_number(alpha):
+        alpha = float(alpha)
+        return alpha * log(beta) - math.lgamma(alpha) + (alpha - 1.0) * log(x) - beta * x
+    alpha = Expr.wrap(alpha)
+    return alpha * log(beta) - lgamma(alpha) + (alpha - 1.0) * log(x) - beta * x
+
+
+def inverse_gamma_lpdf(x, alpha, beta) -> Expr:
+    """x > 0; shape ``alpha`` (number or expression), scale ``beta``."""
+    x, beta = Expr.wrap(x), Expr.wrap(beta)
+    lg = math.lgamma(float(alpha)) if _is_number(alpha) else lgamma(Expr.wrap(alpha))
+    alpha = float(alpha) if _is_number(alpha) else Expr.wrap(alpha)
+    return alpha * log(beta) - lg - (alpha + 1.0) * log(x) - beta / x
+
+
+def beta_lpdf(x, a, b) -> Expr:
+    """0 < x < 1 (a ``lower=0, upper=1`` parameter); ``a``, ``b`` numbers or expressions."""
+    x = Expr.wrap(x)
+    if _is_number(a) and _is_number(b):
+        a, b = float(a), float(b)
+        const = math.lgamma(a + b) - math.lgamma(a) - math.lgamma(b)
+        return const + (a - 1.0) * log(x) + (b - 1.0) * log1p(-x)
+    a, b = Expr.wrap(a), Expr.wrap(b)
+    return lgamma(a + b) - lgamma(a) - lgamma(b) + (a - 1.0) * log(x) + (b - 1.0) * log1p(-x)
+
+
+def laplace_lpdf(x, mu, b) -> Expr:
+    x, mu, b = Expr.wrap(x), Expr.wrap(mu), Expr.wrap(b)
+    return -math.log(2.0) - log(b) - absolute(x - mu) / b
+
+
+def logistic_lpdf(x, mu, s_) -> Expr:
+    x, mu, s_ = Expr.wrap(x), Expr.wrap(mu), Expr.wrap(s_)
+    z = (x - mu) / s_
+    return -z - log(s_) - 2.0 * softplus(-z)
+
+
+def weibull_lpdf(x, alpha, beta) -> Expr:
+    """x > 0; shape ``alpha``, scale ``beta`` (PyMC's parametrisation)."""
+    x, alpha, beta = Expr.wrap(x), Expr.wrap(alpha), Expr.wrap(beta)
+    lz = log(x) - log(beta)
+    return log(alpha) - log(beta) + (alpha - 1.0) * lz - exp(alpha * lz)
+
+
+def uniform_lpdf(x, lower: float, upper: float) -> Expr:
+    """lower < x < upper (a parameter with these bounds): the constant ``-log(upper - lower)``."""
+    return Expr.const(-math.log(float(upper) - float(lower)))
+
+
+def binomial_logit_lpmf(y, n, eta, log_binomial) -> Expr:
+    """y successes of n trials (data), eta the logit, ``log_binomial`` = data holding log C(n, y)."""
+    y, n, eta = Expr.wrap(y), Expr.wrap(n), Expr.wrap(eta)
+    return y * eta - n * softplus(eta) + Expr.wrap(log_binomial)
+
+
+def negative_binomial_log_lpmf(y, eta, phi, log_factorial) -> Expr:
+    """y counts (data), eta = log mean, ``phi`` the over-dispersion (PyMC's ``alpha``: variance = mu + mu^2 / phi; number or expression),
+    ``log_factorial`` = data holding lgamma(y + 1)."""
+    y, eta = Expr.wrap(y), Expr.wrap(eta)
+    if _is_number(phi):
+        raise ValueError("negative_binomial_log_lpmf: phi is a parameter or data expression (lgamma(y + phi) depends on the observation)")
+    phi = Expr.wrap(phi)
+    lphi = log(phi)
+    lse = softplus(eta - lphi) + lphi               # log(mu + phi)
+    return lgamma(y + phi) - lgamma(phi) - Expr.wrap(log_factorial) + y * (eta - lse) + phi * (lphi - lse)
 
 
 def dirichlet_lpdf(p, a) -> Expr:

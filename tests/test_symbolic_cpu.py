@@ -338,3 +338,61 @@ def test_initial_points_follow_pymc_support_point_plus_jitter():
         m.initial_point({"a": -1.0})
     with pytest.raises(ValueError, match="not supported"):
         nutpie_amd.compile_pymc_model(m, default_initialization_strategy="prior")
+
+
+def test_densities_of_the_front_end_against_scipy():
+    """every ``*_lpdf`` / ``*_lpmf`` of the front-end on a model of its own: the value against ``scipy.stats`` at random points (the
+    parameters of the density are model parameters where the function takes expressions: their gradient is the symbolic one, checked
+    by central differences)"""
+    from scipy import stats
+    from scipy.special import gammaln
+
+    rng = np.random.default_rng(5)
+    yv = rng.normal(size=7)
+    pos = np.abs(rng.normal(size=7)) + 0.2
+    unit = rng.uniform(0.05, 0.95, size=7)
+    cnt = rng.poisson(4.0, 7).astype(np.float64)
+    ntr = cnt + rng.integers(0, 5, 7)
+
+    def build(fn):
+        m = S.Model()
+        a = m.param("a", lower=0.0)
+        b = m.param("b", lower=0.0)
+        c = m.param("c")
+        d = {k: m.data(k, v, dim="obs") for k, v in dict(y=yv, pos=pos, unit=unit, cnt=cnt, ntr=ntr, lf=gammaln(cnt + 1.0),
+                                                           lb=gammaln(ntr + 1.0) - gammaln(cnt + 1.0) - gammaln(ntr - cnt + 1.0)).items()}
+        m.add_logp(fn(a, b, c, d).sum())
+        return m.compile()
+
+    cases = {
+        "student_t (nu a parameter)": (lambda a, b, c, d: S.student_t_lpdf(d["y"], a + 1.0, c, b), lambda a, b, c: stats.t.logpdf(yv, a + 1.0, c, b)),
+        "student_t (nu a number)": (lambda a, b, c, d: S.student_t_lpdf(d["y"], 3.5, c, b), lambda a, b, c: stats.t.logpdf(yv, 3.5, c, b)),
+        "gamma (shape a parameter)": (lambda a, b, c, d: S.gamma_lpdf(d["pos"], a, b), lambda a, b, c: stats.gamma.logpdf(pos, a, scale=1.0 / b)),
+        "inverse_gamma": (lambda a, b, c, d: S.inverse_gamma_lpdf(d["pos"], a, b), lambda a, b, c: stats.invgamma.logpdf(pos, a, scale=b)),
+        "inverse_gamma (number)": (lambda a, b, c, d: S.inverse_gamma_lpdf(d["pos"], 2.5, b), lambda a, b, c: stats.invgamma.logpdf(pos, 2.5, scale=b)),
+        "beta": (lambda a, b, c, d: S.beta_lpdf(d["unit"], a, b), lambda a, b, c: stats.beta.logpdf(unit, a, b)),
+        "beta (numbers)": (lambda a, b, c, d: S.beta_lpdf(d["unit"], 2.0, 3.5) + 0.0 * c, lambda a, b, c: stats.beta.logpdf(unit, 2.0, 3.5)),
+        "laplace": (lambda a, b, c, d: S.laplace_lpdf(d["y"], c, b), lambda a, b, c: stats.laplace.logpdf(yv, c, b)),
+        "logistic": (lambda a, b, c, d: S.logistic_lpdf(d["y"], c, b), lambda a, b, c: stats.logistic.logpdf(yv, c, b)),
+        "weibull": (lambda a, b, c, d: S.weibull_lpdf(d["pos"], a, b), lambda a, b, c: stats.weibull_min.logpdf(pos, a, scale=b)),
+        "binomial_logit": (lambda a, b, c, d: S.binomial_logit_lpmf(d["cnt"], d["ntr"], c, d["lb"]), lambda a, b, c: stats.binom.logpmf(cnt, ntr, 1.0 / (1.0 + np.exp(-c)))),
+        "negative_binomial_log": (lambda a, b, c, d: S.negative_binomial_log_lpmf(d["cnt"], c, a, d["lf"]),
+                                  lambda a, b, c: stats.nbinom.logpmf(cnt, a, a / (a + np.exp(c)))),
+    }
+    for name, (fn, ref) in cases.items():
+        cm = build(fn)
+        x = rng.normal(size=(5, 3)) * 0.5
+        lp, g = cm.logp_and_grad_numpy(x)
+        for i, row in enumerate(x):
+            a, b, c = np.exp(row[0]), np.exp(row[1]), row[2]
+            want = ref(a, b, c).sum() + row[0] + row[1]          # (+ the log-Jacobians of the two positive parameters)
+            assert abs(lp[i] - want) < 1e-10 * max(1.0, abs(want)), (name, lp[i], want)
+        h = 1e-6
+        for j in range(3):
+            e = np.zeros(3)
+            e[j] = h
+            fd = (cm.logp_and_grad_numpy(x + e)[0] - cm.logp_and_grad_numpy(x - e)[0]) / (2 * h)
+            np.testing.assert_allclose(g[:, j], fd, rtol=2e-6, atol=2e-6, err_msg=name)
+    assert S.uniform_lpdf(0.3, -1.0, 3.0).is_const(-np.log(4.0))
+    with pytest.raises(ValueError, match="phi is a parameter"):
+        S.negative_binomial_log_lpmf(1.0, 0.0, 2.0, 0.0)
