@@ -1441,19 +1441,22 @@ class Model:
         return self._products[expr.dim.name]
 
     def param(self, name: str, dim: str | None = None, size: int | None = None, lower: float | None = None, upper: float | None = None,
-              zero_sum: bool = False, simplex: bool = False, dims: tuple[str, str] | None = None, initval=None) -> Expr:
+              zero_sum: bool = False, simplex: bool = False, dims: tuple[str, str] | None = None, initval=None, ordered: bool = False) -> Expr:
         """A free parameter.  Scalar, or a vector over ``dim``.  ``lower`` / ``upper``: PyMC's default transforms — ``lower + exp(raw)``,
         ``upper - exp(raw)``, or ``lower + (upper - lower) sigmoid(raw)`` with both — with the log-Jacobian added to the density;
         ``zero_sum``: the vector sums to zero (``size - 1`` free values, PyMC's isometric ZeroSumTransform — no Jacobian term);
         ``simplex``: positive and sums to one (``size - 1`` free values: the softmax of the zero-sum extension of the free values —
         PyMC's SimplexTransform, the default transform of ``pm.Dirichlet`` — with its log-Jacobian).
+        ``ordered``: an increasing vector (PyMC's ``ordered`` transform: the cut points of an ordinal regression) — the first element
+        free, every further one the one before plus ``exp(raw)``, with the log-Jacobian ``sum(raw[1:])``; up to 64 elements (the prefix
+        sums are a gather of the (i, j <= i) pairs and a segment sum: n (n + 1) / 2 terms).
         ``dims=(rows, cols)``: a two-dimensional parameter, a value on ``product(rows, cols)`` (row-major); with ``zero_sum`` every
         COLUMN sums to zero along ``rows`` (``pmd.ZeroSumNormal(core_dims=(rows,), dims=(rows, cols))``: ``(rows - 1) x cols`` free values)."""
         if name in self._param_names:
             raise ValueError(f"parameter {name!r} is defined twice")
         # ``initval``: the (constrained) value the chains start around — PyMC's support point of the variable; without one the
         # unconstrained value 0 (the support point of a Normal(0, .), a ZeroSumNormal, a uniform Dirichlet, a HalfNormal(1) ...)
-        self._transforms[name] = ("zero_sum" if zero_sum else "simplex" if simplex else "bounds", lower, upper, dims)
+        self._transforms[name] = ("zero_sum" if zero_sum else "simplex" if simplex else "ordered" if ordered else "bounds", lower, upper, dims)
         if initval is not None:
             self._initvals[name] = initval
         if dims is not None:
@@ -1465,8 +1468,8 @@ class Model:
             self._unconstrained[name] = (name + ("_log__" if (lower is not None and upper is None) else "_interval__" if lower is not None else
                                                  "_upper__" if upper is not None else ""), self._n_dim, 1)
             self._n_dim += 1
-            if zero_sum or simplex:
-                raise ValueError("zero_sum / simplex need a vector parameter")
+            if zero_sum or simplex or ordered:
+                raise ValueError("zero_sum / simplex / ordered need a vector parameter")
             value, jac = self._constrain(raw, lower, upper)
             if jac is not None:
                 self._terms.append(jac)
@@ -1480,7 +1483,9 @@ class Model:
         n_free = d.size - 1 if (zero_sum or simplex) else d.size
         raw = Expr("vparam", (), d, (self._n_dim, n_free))
         self._params.append(raw)
-        self._unconstrained[name] = (name + ("_zerosum__" if zero_sum else "_simplex__" if simplex else "_log__" if (lower is not None and upper is None) else
+        if ordered and (zero_sum or simplex or lower is not None or upper is not None or d.size > 64):
+            raise ValueError("ordered excludes zero_sum, simplex and bounds, and takes up to 64 elements")
+        self._unconstrained[name] = (name + ("_zerosum__" if zero_sum else "_simplex__" if simplex else "_ordered__" if ordered else "_log__" if (lower is not None and upper is None) else
                                              "_interval__" if lower is not None else "_upper__" if upper is not None else ""), self._n_dim, n_free)
         self._n_dim += n_free
         if zero_sum:
@@ -1503,6 +1508,19 @@ class Model:
             total = e.sum()
             value = e / total
             self._terms.append(math.log(n) + n * s - n * (shift + log(total)))     # log |det d value[:n-1] / d raw|
+        elif ordered:
+            n = d.size
+            step = where_lt(d, 1, raw, exp(raw))          # the first element itself, then the positive increments
+            if n == 1:
+                value = raw
+            else:
+                pairs = self.dim(f"{name}_pairs", n * (n + 1) // 2)
+                src = np.array([j for i in range(n) for j in range(i + 1)])
+                dst = np.array([i for i in range(n) for j in range(i + 1)])
+                i_src = self.index(f"{name}_pair_src", src, dim=pairs.name, into=d.name)
+                i_dst = self.index(f"{name}_pair_dst", dst, dim=pairs.name, into=d.name)
+                value = _segsum(step[i_src], i_dst)
+                self._terms.append(raw.sum() - elem(raw, 0))   # log |det d value / d raw| = sum of raw[1:]
         else:
             value, jac = self._constrain(raw, lower, upper)
             if jac is not None:
@@ -1610,6 +1628,10 @@ class Model:
             v = np.broadcast_to(v, (n_free + 1,))
             lv = np.log(v)
             return lv[:-1] - lv.sum() / (n_free + 1)
+        if kind == "ordered":
+            v = np.broadcast_to(v, (n_free,)).astype(np.float64)
+            with np.errstate(all="ignore"):       # (a value that does not increase gives NaN: initial_point refuses it by name)
+                return np.concatenate([v[:1], np.log(np.diff(v))])
         v = np.broadcast_to(v, (n_free,)) if v.ndim <= 1 else v.reshape(-1)
         if lower is None and upper is None:
             return v.astype(np.float64)
