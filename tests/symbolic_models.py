@@ -240,7 +240,44 @@ def collinear_regression(seed=2, n=400):
     return m
 
 
-ALL = {"collinear_regression": collinear_regression, "store_extra": store_extra, "dirichlet_counts": dirichlet_counts, "dims_model": dims_model, "no_prior": no_prior, "uniform_det": uniform_det, "radon": radon, "logistic": logistic, "poisson_offsets": poisson_offsets, "scalar_only": scalar_only, "regression": regression,
+def ordinal_regression(seed=9, n=60, K=5):
+    """ordered cut points (``param(ordered=True)``: PyMC's ``ordered`` transform) of an ordinal regression"""
+    rng = np.random.default_rng(seed)
+    xcov = rng.normal(size=n)
+    ycat = rng.integers(0, K, n)
+    m = S.Model()
+    cut = m.param("cut", dim="cutpoint", size=K - 1, ordered=True, initval=list(np.linspace(-1.5, 1.5, K - 1)))
+    beta = m.param("beta")
+    xd = m.data("x", xcov, dim="obs")
+    lo_idx = m.index("lo_idx", np.clip(ycat - 1, 0, K - 2), dim="obs", into="cutpoint")
+    hi_idx = m.index("hi_idx", np.clip(ycat, 0, K - 2), dim="obs", into="cutpoint")
+    is_first = m.data("is_first", (ycat == 0).astype(np.float64), dim="obs")
+    is_last = m.data("is_last", (ycat == K - 1).astype(np.float64), dim="obs")
+    eta = beta * xd
+    p_hi = is_last + (1.0 - is_last) * S.sigmoid(cut[hi_idx] - eta)
+    p_lo = (1.0 - is_first) * S.sigmoid(cut[lo_idx] - eta)
+    m.add_logp(S.log(p_hi - p_lo).sum() + S.normal_lpdf(cut, 0.0, 3.0).sum() + S.normal_lpdf(beta, 0.0, 2.0))
+    return m
+
+
+def more_densities(seed=0, n=50):
+    """the densities added at the end of round 5, shape parameters as model parameters (``lgamma`` / ``digamma`` in the kernel)"""
+    from scipy.special import gammaln
+
+    rng = np.random.default_rng(seed)
+    cnt = rng.poisson(4.0, n).astype(float)
+    ntr = cnt + rng.integers(0, 5, n)
+    m = S.Model()
+    phi, c, a, b = m.param("phi", lower=0.0), m.param("c"), m.param("a", lower=0.0), m.param("b", lower=0.0)
+    y, lf, u = m.data("cnt", cnt, dim="obs"), m.data("lf", gammaln(cnt + 1), dim="obs"), m.data("u", rng.uniform(0.1, 0.9, n), dim="obs")
+    nt, lb = m.data("ntr", ntr, dim="obs"), m.data("lb", gammaln(ntr + 1) - gammaln(cnt + 1) - gammaln(ntr - cnt + 1), dim="obs")
+    m.add_logp(S.negative_binomial_log_lpmf(y, c, phi, lf).sum() + S.beta_lpdf(u, a, b).sum() + S.student_t_lpdf(y, a + 1.0, c, b).sum()
+               + S.weibull_lpdf(u, a, b).sum() + S.laplace_lpdf(u, c, b).sum() + S.logistic_lpdf(u, c, b).sum() + S.inverse_gamma_lpdf(u, a, b).sum()
+               + S.gamma_lpdf(u, a, b).sum() + S.binomial_logit_lpmf(y, nt, c, lb).sum())
+    return m
+
+
+ALL = {"ordinal_regression": ordinal_regression, "more_densities": more_densities, "collinear_regression": collinear_regression, "store_extra": store_extra, "dirichlet_counts": dirichlet_counts, "dims_model": dims_model, "no_prior": no_prior, "uniform_det": uniform_det, "radon": radon, "logistic": logistic, "poisson_offsets": poisson_offsets, "scalar_only": scalar_only, "regression": regression,
        "plain_regression": plain_regression, "eight_schools": eight_schools, "nested": nested}
 
 # models whose library is also built for the low-rank metric ahead of time (tests/test_gpu_density.py; __graft_entry__.build)
