@@ -297,8 +297,7 @@ def ordered_logistic():
 ALL["ordered_logistic"] = ordered_logistic
 
 
-# ---- models of the CPU tests only (tests/test_torch_trace_cpu.py): operations mapped onto the IR after the last GPU call of round 5 — the
-# IR operations they use have generated device code that the GPU suite covers through the models above
+# ---- models that only the CPU tests use (tests/test_torch_trace_cpu.py) — none at the moment
 CPU_ONLY = {}
 
 
@@ -330,4 +329,4 @@ def negbin_and_pairwise():
     return 19, logp, False, {}
 
 
-CPU_ONLY["negbin_and_pairwise"] = negbin_and_pairwise
+ALL["negbin_and_pairwise"] = negbin_and_pairwise
