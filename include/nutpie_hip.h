@@ -106,6 +106,12 @@ typedef int (*nphip_device_logp_fn)(uint64_t n_chains, uint64_t dim, const doubl
  * offdiag[dim-1]); mu/offdiag may be NULL.  Covers N(0,I), diagonal and AR(1) Gaussians.
  * Host pointers; copied. */
 nphip_model_t* nphip_model_tridiag_gaussian(uint64_t dim, const double* mu, const double* diag, const double* offdiag);
+/* Dense-precision Gaussian: logp(x) = -1/2 (x-mu)' P (x-mu), P symmetric [dim][dim] row-major (BASELINE.json configs[1] read as a DENSE
+ * correlated Gaussian — SURVEY.md 8d variant (ii)); mu may be NULL.  Host pointers; copied.  The reference has no such model: its user
+ * writes the density as a per-chain callable (src/pyfunc.rs:206-230) and nuts-rs calls it once per chain and leapfrog; here the gradients
+ * of ALL chains of a step are one fp64 GEMM on the matrix cores, hand-written (csrc/dense_tile.h: v_mfma_f64_16x16x4_f64, fixed summation
+ * order — include/nphip_spec.h), inside the engine: no callback, no staging round trip through a framework. */
+nphip_model_t* nphip_model_dense_gaussian(uint64_t dim, const double* mu, const double* P);
 nphip_model_t* nphip_model_host_callback(uint64_t dim, nphip_raw_logp_fn fn, void* user_data, int n_threads);
 nphip_model_t* nphip_model_device_callback(uint64_t dim, nphip_device_logp_fn fn, void* user_data);
 /* BridgeStan flavour (reference src/stan.rs:454-463): each row is evaluated as
@@ -291,6 +297,11 @@ int nphip_test_detmath(int device, int fn, uint64_t n, const double* x, double* 
  * sub-diagonal (entry i couples i and i + 1); mode 2: also Q, returned in a (T = Q' A Q); mode 3: the decomposition, with w[0..6] of every
  * matrix replaced by cycle counts (tridiagonalisation, Q, QL recurrence, QL application, rotations, sweeps, total) */
 int nphip_test_eigh_stage(uint64_t n_batch, uint64_t order, double* a_device, double* w_device, void* stream, int mode);
+/* the dense Gaussian's evaluation on n rows (host arrays): grad[n][dim] = -P (x - mu) by the engine's MFMA GEMM, logp[n] = 1/2 (x - mu).grad in
+ * the summation order of `waves` waves per chain */
+int nphip_test_dense_grad(int device, int waves, uint64_t n, uint64_t dim, const double* x, const double* mu, const double* P, double* grad, double* logp);
+/* measured fp64 matrix-core rate of the device (v_mfma_f64_16x16x4_f64 back to back on every SIMD), in TFLOP/s: the peak the dense model's roofline is priced against */
+int nphip_test_mfma_f64_rate(int device, double* tflops);
 /* dot product in the engine's summation order with W waves */
 int nphip_test_dot(int device, int waves, uint64_t n, const double* x, const double* y, double* out);
 /* host-only: the evaluation pool of the host-callback path (spin-waiting workers, `use` threads per batch); row r of batch b

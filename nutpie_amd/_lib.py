@@ -140,6 +140,9 @@ def lib():
             L.nphip_settings_to_json.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
             L.nphip_model_tridiag_gaussian.restype = C.c_void_p
             L.nphip_model_tridiag_gaussian.argtypes = [C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+            L.nphip_model_dense_gaussian.restype = C.c_void_p
+            L.nphip_model_dense_gaussian.argtypes = [C.c_uint64, C.c_void_p, C.c_void_p]
+            L.nphip_test_dense_grad.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
             L.nphip_model_host_callback.restype = C.c_void_p
             L.nphip_model_host_callback.argtypes = [C.c_uint64, C.c_void_p, C.c_void_p, C.c_int]
             L.nphip_model_device_callback.restype = C.c_void_p
@@ -434,6 +437,46 @@ class TridiagGaussianModel(_Model):
             raise ValueError("mu must have length dim")
         p = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)  # noqa: E731
         super().__init__(lib().nphip_model_tridiag_gaussian(C.c_uint64(dim), p(m), p(diag), p(off)), dim)
+
+
+class DenseGaussianModel(_Model):
+    """Dense-precision Gaussian ``logp(x) = -1/2 (x-mu)' P (x-mu)`` evaluated by the engine's own fp64 MFMA GEMM
+    (``nphip_model_dense_gaussian``): BASELINE.json configs[1] read as a dense correlated Gaussian."""
+
+    def __init__(self, precision, mu=None):
+        P = np.ascontiguousarray(precision, dtype=np.float64)
+        if P.ndim != 2 or P.shape[0] != P.shape[1]:
+            raise ValueError("precision must be a square matrix")
+        dim = P.shape[0]
+        m = None if mu is None else np.ascontiguousarray(mu, dtype=np.float64)
+        if m is not None and m.shape != (dim,):
+            raise ValueError("mu must have length dim")
+        h = lib().nphip_model_dense_gaussian(C.c_uint64(dim), None if m is None else m.ctypes.data_as(C.c_void_p), P.ctypes.data_as(C.c_void_p))
+        if not h:
+            raise ValueError(_err())
+        super().__init__(h, dim)
+
+
+def mfma_f64_rate(device=0):
+    """Measured fp64 matrix-core rate of the device in TFLOP/s (``nphip_test_mfma_f64_rate``)."""
+    v = C.c_double(0.0)
+    lib().nphip_test_mfma_f64_rate.argtypes = [C.c_int, C.POINTER(C.c_double)]
+    if lib().nphip_test_mfma_f64_rate(int(device), C.byref(v)) != NPHIP_OK:
+        raise RuntimeError(_err())
+    return float(v.value)
+
+
+def test_dense_grad(x, precision, mu=None, waves=1, device=0):
+    """Test hook: the engine's dense-Gaussian evaluation (gradient GEMM + log-density) of the rows of ``x`` on the device."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    P = np.ascontiguousarray(precision, dtype=np.float64)
+    n, dim = x.shape
+    m = np.zeros(dim) if mu is None else np.ascontiguousarray(mu, dtype=np.float64)
+    g, lp = np.empty_like(x), np.empty(n)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    if lib().nphip_test_dense_grad(int(device), int(waves), C.c_uint64(n), C.c_uint64(dim), p(x), p(m), p(P), p(g), p(lp)) != NPHIP_OK:
+        raise RuntimeError(_err())
+    return g, lp
 
 
 class HostCallbackModel(_Model):

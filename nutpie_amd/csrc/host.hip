@@ -32,6 +32,8 @@ hipError_t launch_advance(const Args& a, const Args* d_args, bool fused, int W, 
 hipError_t launch_resume(const Args* d_args, int n, const int64_t* d_chains, const double* d_pos, bool fused, hipStream_t st);
 hipError_t launch_set_metric(const Args* d_args, int n, const int64_t* d_chains, int k, const double* sig2, const double* V, const double* lam, int* d_taken, hipStream_t st);
 hipError_t launch_remote(const Args* d_args, int W, int nv, hipStream_t st, const LaunchSlice& sl);
+hipError_t launch_dense_grad(const double* X, const double* Pp, const double* mu, double* G, double* logp, int64_t n, int64_t D, int64_t KP, int W, hipStream_t st);
+hipError_t launch_mfma_f64_rate(double* out, int blocks, int iters, hipStream_t st);
 hipError_t launch_test_detmath(int fn, uint64_t n, const double* x, double* y, hipStream_t st);
 hipError_t launch_test_dot(int W, uint64_t n, const double* x, const double* y, double* out, hipStream_t st);
 }  // namespace nphip
@@ -318,6 +320,8 @@ struct nphip_model {
     std::shared_ptr<BsExpand> bs_expand;
     uint64_t dim = 0;
     std::vector<double> mu, a, b;
+    bool dense = false;              // kind 2 driven by the engine's own gradient kernels (nphip_model_dense_gaussian): prec = P [dim][dim]
+    std::shared_ptr<std::vector<double>> prec;
     nphip_raw_logp_fn host_fn = nullptr;
     nphip_device_logp_fn dev_fn = nullptr;
     void* user = nullptr;
@@ -362,6 +366,22 @@ nphip_model_t* nphip_model_device_callback(uint64_t dim, nphip_device_logp_fn fn
     if (dim == 0 || !fn) { set_error("device callback model needs dim > 0 and a function"); return nullptr; }
     auto* m = new nphip_model();
     m->kind = 2; m->dim = dim; m->dev_fn = fn; m->user = user_data;
+    return m;
+}
+// Dense-precision Gaussian: the model's evaluation is the engine's own fp64 MFMA GEMM (kernels.hip part 10, dense_tile.h) behind the
+// device-callback path — `dev_fn` is set by the sampler once the matrix is on its device (setup()).
+nphip_model_t* nphip_model_dense_gaussian(uint64_t dim, const double* mu, const double* P) {
+    if (dim == 0 || !P) { set_error("dense Gaussian model needs dim > 0 and a precision matrix"); return nullptr; }
+    for (uint64_t i = 0; i < dim; ++i)
+        for (uint64_t j = 0; j < i; ++j)
+            if (!(P[i * dim + j] == P[j * dim + i])) {
+                set_error("the precision matrix must be symmetric (P[" + std::to_string(i) + "][" + std::to_string(j) + "] != P[" + std::to_string(j) + "][" + std::to_string(i) + "])");
+                return nullptr;
+            }
+    auto* m = new nphip_model();
+    m->kind = 2; m->dense = true; m->dim = dim;
+    m->mu.assign(dim, 0.0); if (mu) m->mu.assign(mu, mu + dim);
+    m->prec = std::make_shared<std::vector<double>>(P, P + dim * dim);
     return m;
 }
 nphip_model_t* nphip_model_jit_density(uint64_t dim, void* launch_fn, int nv, const void* data_device, uint64_t lds_bytes_per_chain,
@@ -639,6 +659,12 @@ struct nphip_sampler {
         return true;
     }
 
+    // dense-precision Gaussian (model.dense): the padded matrix and mean on this device; the evaluation = two kernel launches
+    struct DenseDev { const double* Pp = nullptr; const double* mu = nullptr; int64_t KP = 0; int W = 1; } dense_dev;
+    static int dense_dev_fn(uint64_t n_chains, uint64_t dim, const double* q, double* grad, double* logp, void* stream, void* user) {
+        const DenseDev* d = (const DenseDev*)user;
+        return launch_dense_grad(q, d->Pp, d->mu, grad, logp, (int64_t)n_chains, (int64_t)dim, d->KP, d->W, (hipStream_t)stream) == hipSuccess ? 0 : -1;
+    }
     bool setup();
     void run();
     bool manual = false;
@@ -1003,6 +1029,17 @@ bool nphip_sampler::setup() {
                 for (int g = 0; g < n_groups; ++g) HIP_TRY(hipStreamCreateWithFlags(&grp_stream[g], hipStreamNonBlocking));
             }
         }
+    }
+    if (model.dense) {
+        // Pp [DP][KP]: rows padded to a multiple of 16 elements and 64 rows with zeros (dense_tile.h reads whole fragments), mu [KP]
+        const size_t KP = (dim + 15) / 16 * 16, DP = (dim + 63) / 64 * 64;
+        double *dP = nullptr, *dmu = nullptr;
+        if (!dalloc(&dP, DP * KP) || !dalloc(&dmu, KP)) return false;
+        HIP_TRY(hipMemcpy2DAsync(dP, KP * 8, model.prec->data(), dim * 8, dim * 8, dim, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(dmu, model.mu.data(), dim * 8, hipMemcpyHostToDevice, stream));
+        dense_dev.Pp = dP; dense_dev.mu = dmu; dense_dev.KP = (int64_t)KP; dense_dev.W = W;
+        model.dev_fn = &nphip_sampler::dense_dev_fn;
+        model.user = &dense_dev;
     }
     if (model.kind == 2 && launch.host_groups >= 2 && !launch.manual && n >= 8) {
         // Device callbacks in groups (round 5): the chains in `host_groups` contiguous groups, each with a stream of its
@@ -1639,7 +1676,8 @@ nphip_sampler_t* nphip_sampler_create(const nphip_settings_t* set, const nphip_m
         return nullptr;
     }
     if (!s->setup()) { s->release(); delete s; return nullptr; }
-    s->cb_graph_steps = (s->model.kind == 2 && s->launch.graph_steps > 0) ? s->launch.graph_steps : 0;
+    // (the dense Gaussian's evaluation is two kernel launches of the engine's own: always capturable — 16 steps per graph unless told otherwise)
+    s->cb_graph_steps = (s->model.kind == 2 && s->launch.graph_steps > 0) ? s->launch.graph_steps : ((s->model.dense && s->launch.graph_steps == 0) ? 16 : 0);
     s->want_pause = s->launch.start_paused != 0;
     s->manual = s->launch.manual != 0;
     if (!s->manual) s->th = std::thread([s] { s->run(); });
@@ -2061,6 +2099,50 @@ int nphip_test_detmath(int device, int fn, uint64_t n, const double* x, double* 
     return ok ? NPHIP_OK : NPHIP_ERR;
 }
 
+int nphip_test_mfma_f64_rate(int device, double* tflops) {
+    if (hipSetDevice(device) != hipSuccess) { set_error("hipSetDevice failed"); return NPHIP_ERR; }
+    hipDeviceProp_t prop;
+    if (!hip_ok(hipGetDeviceProperties(&prop, device), "hipGetDeviceProperties")) return NPHIP_ERR;
+    const int blocks = prop.multiProcessorCount * 2, iters = 4096;   // two workgroups of four waves per CU: two waves per SIMD
+    double* d = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    bool ok = hip_ok(hipMalloc((void**)&d, 64), "hipMalloc") && hip_ok(hipEventCreate(&e0), "event") && hip_ok(hipEventCreate(&e1), "event");
+    float best = 0.f;
+    for (int rep = 0; ok && rep < 4; ++rep) {   // (the first repetition warms the clocks up)
+        ok = hip_ok(hipEventRecord(e0, nullptr), "record") && hip_ok(launch_mfma_f64_rate(d, blocks, iters, nullptr), "launch") &&
+             hip_ok(hipEventRecord(e1, nullptr), "record") && hip_ok(hipEventSynchronize(e1), "sync");
+        float ms = 0.f;
+        ok = ok && hip_ok(hipEventElapsedTime(&ms, e0, e1), "elapsed");
+        if (ok && rep > 0 && (best == 0.f || ms < best)) best = ms;
+    }
+    if (ok) *tflops = (double)blocks * 4.0 * iters * 8.0 * 2048.0 / ((double)best * 1e-3) / 1e12;
+    if (ok && getenv("NPHIP_DEBUG")) {
+        double h[3] = {0, 0, 0};
+        (void)hipMemcpy(h, d, 24, hipMemcpyDeviceToHost);
+        fprintf(stderr, "nphip: fp64 MFMA rate: %.1f TFLOP/s over %.3f ms; one wave: %.1f shader cycles per MFMA issued (two waves per SIMD), shader clock %.0f MHz\n",
+                *tflops, best, h[1] / (iters * 8.0), h[1] / (h[2] / 100.0));
+    }
+    if (d) (void)hipFree(d);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    return ok ? NPHIP_OK : NPHIP_ERR;
+}
+int nphip_test_dense_grad(int device, int waves, uint64_t n, uint64_t dim, const double* x, const double* mu, const double* P, double* grad, double* logp) {
+    if (hipSetDevice(device) != hipSuccess) { set_error("hipSetDevice failed"); return NPHIP_ERR; }
+    const size_t KP = (dim + 15) / 16 * 16, DP = (dim + 63) / 64 * 64;
+    double *dx = nullptr, *dg = nullptr, *dl = nullptr, *dP = nullptr, *dmu = nullptr;
+    bool ok = hip_ok(hipMalloc((void**)&dx, n * dim * 8), "hipMalloc") && hip_ok(hipMalloc((void**)&dg, n * dim * 8), "hipMalloc") &&
+              hip_ok(hipMalloc((void**)&dl, n * 8), "hipMalloc") && hip_ok(hipMalloc((void**)&dP, DP * KP * 8), "hipMalloc") &&
+              hip_ok(hipMalloc((void**)&dmu, KP * 8), "hipMalloc");
+    ok = ok && hip_ok(hipMemset(dP, 0, DP * KP * 8), "hipMemset") && hip_ok(hipMemset(dmu, 0, KP * 8), "hipMemset") &&
+         hip_ok(hipMemcpy2D(dP, KP * 8, P, dim * 8, dim * 8, dim, hipMemcpyHostToDevice), "H2D P") &&
+         hip_ok(hipMemcpy(dmu, mu, dim * 8, hipMemcpyHostToDevice), "H2D mu") && hip_ok(hipMemcpy(dx, x, n * dim * 8, hipMemcpyHostToDevice), "H2D x");
+    ok = ok && hip_ok(launch_dense_grad(dx, dP, dmu, dg, dl, (int64_t)n, (int64_t)dim, (int64_t)KP, waves, nullptr), "launch dense grad") &&
+         hip_ok(hipDeviceSynchronize(), "sync") && hip_ok(hipMemcpy(grad, dg, n * dim * 8, hipMemcpyDeviceToHost), "D2H grad") &&
+         hip_ok(hipMemcpy(logp, dl, n * 8, hipMemcpyDeviceToHost), "D2H logp");
+    for (double* q : {dx, dg, dl, dP, dmu}) if (q) (void)hipFree(q);
+    return ok ? NPHIP_OK : NPHIP_ERR;
+}
 int nphip_test_dot(int device, int waves, uint64_t n, const double* x, const double* y, double* out) {
     if (hipSetDevice(device) != hipSuccess) { set_error("no HIP device"); return NPHIP_ERR; }
     double *dx = nullptr, *dy = nullptr, *dout = nullptr;

@@ -318,6 +318,10 @@ __device__ __forceinline__ void wait_vm0() {
 }
 __device__ __forceinline__ double clamp_mm(double v) { return v < 1e-20 ? 1e-20 : (v > 1e20 ? 1e20 : v); }
 
+}  // namespace nphip
+#include "dense_tile.h"   // the fp64 MFMA tile of the dense-precision Gaussian's gradient
+namespace nphip {
+
 // ----------------------------------------------------------------------------------------
 // the per-chain machine
 // ----------------------------------------------------------------------------------------
@@ -4254,6 +4258,120 @@ int nphip_jit_expand(uint64_t, uint64_t, uint64_t, const double*, double*, void*
 }  // extern "C"
 namespace nphip {
 #endif   // part 7
+
+#if NPHIP_HAS(10)
+// ----------------------------------------------------------------------------------------
+// Dense-precision Gaussian (nphip_model_dense_gaussian; BASELINE.json configs[1] variant (ii)): the gradient of ALL chains as one
+// fp64 GEMM on the matrix cores, hand-written (dense_tile.h) — the only place in the engine where MFMA applies: 2 D^2 flop per
+// chain and evaluation against the leapfrog's 10 D.  These two kernels are the launch-per-evaluation form (the model behind the
+// engine's own device-callback path: any number of chains, any dimension); the resident form calls the same tile from inside the
+// register-resident leaf (Machine<..., DENSEG>).
+// ----------------------------------------------------------------------------------------
+// G[chain][j] = -sum_k (X[chain][k] - mu[k]) Pp[j][k] for a 64 x 64 tile per workgroup (four waves, 32 x 32 each).  X, G: dense
+// [n][D]; Pp: [DP][KP] (DP = D rounded up to 64, KP to 16), zero-padded; mu: [KP].
+// Tile order: workgroup b runs on XCD b % 8 (round-robin dispatch); the tiles are dealt so that an XCD owns a contiguous run of
+// them — neighbouring tiles share their rows of X or of P in that XCD's L2.
+__global__ __launch_bounds__(256) void k_dense_grad(const double* __restrict__ X, const double* __restrict__ Pp, const double* __restrict__ mu,
+                                                    double* __restrict__ G, int64_t n, int64_t D, int64_t KP) {
+    const int64_t Mt = (n + 63) / 64, Nt = (D + 63) / 64, T = Mt * Nt, tpx = (T + 7) / 8;
+    const int64_t b = blockIdx.x, t = (b & 7) * tpx + (b >> 3);
+    if ((b >> 3) >= tpx || t >= T) return;
+    const int64_t mt = t / Nt, nt = t % Nt;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t r0 = mt * 64 + (wave >> 1) * 32, c0 = nt * 64 + (wave & 1) * 32;
+    if (r0 >= n || c0 >= D) return;   // (whole block of this wave outside the matrix)
+    const double* xrow[2];
+    const double* prow[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        int64_t i = r0 + 16 * r + (lane & 15);
+        i = i < n ? i : n - 1;    // (rows past the end: the last row again, never stored)
+        xrow[r] = X + (size_t)i * D;
+        prow[r] = Pp + (size_t)(c0 + 16 * r + (lane & 15)) * KP;
+    }
+    dg_v4 acc[2][2];
+    dense_block_32x32(xrow, prow, mu, D, lane, acc);
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int64_t j = c0 + 16 * c + (lane & 15);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int64_t i = r0 + 16 * r + (lane >> 4) + 4 * q;
+                if (i < n && j < D) st1(G, i * D + j, -acc[r][c][q]);
+            }
+        }
+}
+
+// logp[chain] = 1/2 sum_i z_i g_i (z = x - mu) in the engine's summation order with W waves per chain (include/nphip_spec.h)
+template <int W>
+__global__ __launch_bounds__(64 * W) void k_dense_logp(const double* __restrict__ X, const double* __restrict__ mu, const double* __restrict__ G,
+                                                       double* __restrict__ logp, int64_t n, int64_t D) {
+    __shared__ double red_[8 * W];
+    LdsDouble red = (LdsDouble)red_;
+    const int64_t chain = blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t nch = (D + 127) / 128;
+    const double* x = X + (size_t)chain * D;
+    const double* g = G + (size_t)chain * D;
+    double2 acc = {0.0, 0.0};
+    for (int64_t cc = wave; cc < nch; cc += W) {
+        const int64_t i = cc * 128 + 2 * lane;
+        const double2 xv = ld2_dense(x, i, D), gv = ld2_dense(g, i, D);
+        const double zx = xv.x - ((i < D) ? ld1(mu, i) : 0.0), zy = xv.y - ((i + 1 < D) ? ld1(mu, i + 1) : 0.0);
+        acc.x = fma(zx, gv.x, acc.x);
+        acc.y = fma(zy, gv.y, acc.y);
+    }
+    double a = acc.x + acc.y, bdummy = 0.0;
+    reduce2<W>(a, bdummy, red);
+    if (threadIdx.x == 0) logp[chain] = 0.5 * a;
+}
+
+// fp64 matrix-core issue rate, measured: every wave issues `iters` x 8 independent-accumulator v_mfma_f64_16x16x4_f64 back to back (no memory
+// traffic); the host divides the flops by the kernel's duration.  What bench.py prices the dense model's `mfma` roofline against, beside
+// the datasheet figure.
+__global__ __launch_bounds__(256) void k_mfma_f64_rate(double* out, int iters) {
+    dg_v4 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = (dg_v4){0.0, 0.0, 0.0, 0.0};
+    double a = 1.0 + 1e-9 * (double)threadIdx.x, b = 1.0 - 1e-9 * (double)threadIdx.x;
+    const long long c0 = (long long)__builtin_readcyclecounter(), w0 = wall_clock64();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+    }
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if (t == 12345.678) out[0] = t;   // (keeps the accumulators alive)
+    if (blockIdx.x == 0 && threadIdx.x == 0) {   // shader cycles and 100 MHz ticks of this wave's loop: cycles per MFMA and the clock it ran at
+        out[1] = (double)((long long)__builtin_readcyclecounter() - c0);
+        out[2] = (double)(wall_clock64() - w0);
+    }
+}
+hipError_t launch_mfma_f64_rate(double* out, int blocks, int iters, hipStream_t st) {
+    hipLaunchKernelGGL(k_mfma_f64_rate, dim3((unsigned)blocks), dim3(256), 0, st, out, iters);
+    return hipGetLastError();
+}
+
+hipError_t launch_dense_grad(const double* X, const double* Pp, const double* mu, double* G, double* logp, int64_t n, int64_t D, int64_t KP, int W,
+                             hipStream_t st) {
+    const int64_t Mt = (n + 63) / 64, Nt = (D + 63) / 64, T = Mt * Nt, tpx = (T + 7) / 8;
+    hipLaunchKernelGGL(k_dense_grad, dim3((unsigned)(8 * tpx)), dim3(256), 0, st, X, Pp, mu, G, n, D, KP);
+    if (logp) {
+        switch (W) {
+            case 1: hipLaunchKernelGGL(k_dense_logp<1>, dim3((unsigned)n), dim3(64), 0, st, X, mu, G, logp, n, D); break;
+            case 2: hipLaunchKernelGGL(k_dense_logp<2>, dim3((unsigned)n), dim3(128), 0, st, X, mu, G, logp, n, D); break;
+            case 4: hipLaunchKernelGGL(k_dense_logp<4>, dim3((unsigned)n), dim3(256), 0, st, X, mu, G, logp, n, D); break;
+            case 8: hipLaunchKernelGGL(k_dense_logp<8>, dim3((unsigned)n), dim3(512), 0, st, X, mu, G, logp, n, D); break;
+            case 16: hipLaunchKernelGGL(k_dense_logp<16>, dim3((unsigned)n), dim3(1024), 0, st, X, mu, G, logp, n, D); break;
+            default: return hipErrorInvalidValue;
+        }
+    }
+    return hipGetLastError();
+}
+#endif   // part 10
 
 #if NPHIP_HAS(0)
 // ----------------------------------------------------------------------------------------

@@ -190,7 +190,7 @@ def compile_density(user_source: str, layout, ndim: int, *, waves: int = 1, verb
         raise ValueError("waves_per_chain must be 1, 2 or 4")
     nv = ((int(ndim) + 127) // 128 + waves - 1) // waves   # chunks of 128 dimensions per wave
     src = generated_source(user_source, layout)
-    deps = [os.path.join(_CSRC, f) for f in ("kernels.hip", "engine_types.h")] + [os.path.join(_INCLUDE, "nphip_spec.h")]
+    deps = [os.path.join(_CSRC, f) for f in ("kernels.hip", "engine_types.h", "dense_tile.h")] + [os.path.join(_INCLUDE, "nphip_spec.h")]
     h = hashlib.sha256()
     h.update(src.encode())
     for d in deps:

@@ -1,8 +1,10 @@
 """Analytic Gaussian targets (BASELINE.json configs 1, 2 and 5).
 
 ``TridiagGaussian`` is evaluated inside the leapfrog kernel (fused analytic gradient);
-``dense_gaussian`` goes through the batched torch callback (its gradient is an fp64 GEMM and
-is deliberately kept out of the leapfrog kernel — SURVEY.md §7 "hard parts").
+``DenseGaussian`` (``dense_gaussian``) is the dense-precision variant: the gradients of all chains of a
+step are one fp64 GEMM on the matrix cores, hand-written inside the engine (``nphip_model_dense_gaussian``,
+csrc/dense_tile.h); ``dense_gaussian_torch`` is the same target behind the batched torch callback
+(rocBLAS), kept as the comparison.
 """
 
 from __future__ import annotations
@@ -59,6 +61,42 @@ class TridiagGaussian(CompiledModel):
         return np.linalg.inv(L)
 
 
+@dataclass(frozen=True)
+class DenseGaussian(CompiledModel):
+    """logp(x) = -1/2 (x - mu)' P (x - mu) with a dense symmetric precision matrix P (in-engine fp64 MFMA gradient)."""
+
+    precision: np.ndarray = None
+    mu: np.ndarray | None = None
+    name: str = "x"
+    init: str = "uniform"
+
+    @property
+    def n_dim(self):
+        return int(self.precision.shape[0])
+
+    @property
+    def shapes(self):
+        return {self.name: (self.n_dim,)}
+
+    @property
+    def coords(self):
+        return {}
+
+    def _make_model(self, init_mean=None, settings=None):
+        m = _lib.DenseGaussianModel(self.precision, self.mu)
+        m.set_init(self.init)
+        return m
+
+    def _make_sampler(self, settings, init_mean, cores, progress_type, extra_callback, extra_callback_rate, store, **engine_kw):
+        return _lib.PySampler.from_pyfunc(settings, cores, self._make_model(), progress_type, extra_callback, extra_callback_rate, store, **engine_kw)
+
+    def _expand_draws(self, draws):
+        return {self.name: draws}
+
+    def covariance(self):
+        return np.linalg.inv(np.asarray(self.precision, dtype=np.float64))
+
+
 def std_normal(dim: int) -> TridiagGaussian:
     """Config 1: D-dimensional standard normal."""
     return TridiagGaussian(dims={}, diag=np.ones(dim))
@@ -86,20 +124,30 @@ def ar1_gaussian(dim: int, rho: float = 0.9, scales=None, seed: int = BENCH_RNG_
     return TridiagGaussian(dims={}, diag=diag, offdiag=offdiag if dim > 1 else None)
 
 
-def dense_gaussian(dim: int, seed: int = BENCH_RNG_SEED, cond_lo=1e-2, cond_hi=1e2, device=0):
-    """Config 2 variant (ii): dense covariance S C S with C = Q diag(lam) Q', lam log-uniform.
-    Returns a batched torch model (gradient = fp64 GEMM via rocBLAS, outside the leapfrog kernel)."""
-    import torch
-
-    from nutpie_amd.compiled_pyfunc import from_torchfunc
-
+def dense_precision(dim: int, seed: int = BENCH_RNG_SEED, cond_lo=1e-2, cond_hi=1e2) -> np.ndarray:
+    """Precision matrix of config 2 variant (ii): covariance S C S with C = Q diag(lam) Q', Q random orthogonal,
+    lam log-uniform in [cond_lo, cond_hi], S = diag(exp(N(0,1))); inputs from numpy.random.default_rng(seed)."""
     rng = np.random.default_rng(seed)
     s = np.exp(rng.normal(size=dim))
     Q, _ = np.linalg.qr(rng.normal(size=(dim, dim)))
     lam = np.exp(rng.uniform(np.log(cond_lo), np.log(cond_hi), size=dim))
     prec = (Q / lam) @ Q.T
     prec = prec / np.outer(s, s)
-    prec = 0.5 * (prec + prec.T)
+    return 0.5 * (prec + prec.T)
+
+
+def dense_gaussian(dim: int, seed: int = BENCH_RNG_SEED, cond_lo=1e-2, cond_hi=1e2, device=0) -> DenseGaussian:
+    """Config 2 variant (ii) inside the engine: the gradient GEMM is the engine's own fp64 MFMA kernel."""
+    return DenseGaussian(dims={}, precision=dense_precision(dim, seed, cond_lo, cond_hi))
+
+
+def dense_gaussian_torch(dim: int, seed: int = BENCH_RNG_SEED, cond_lo=1e-2, cond_hi=1e2, device=0):
+    """The same target behind the batched torch callback (gradient = fp64 GEMM via rocBLAS, outside the leapfrog kernel)."""
+    import torch
+
+    from nutpie_amd.compiled_pyfunc import from_torchfunc
+
+    prec = dense_precision(dim, seed, cond_lo, cond_hi)
 
     def make_logp():
         dev = torch.device("cuda", device)

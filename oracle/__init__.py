@@ -256,6 +256,46 @@ def sample_tridiag(settings: Settings, diag, offdiag=None, mu=None, init_points=
     return Trace(draws, st, secs.value)
 
 
+def sample_dense(settings: Settings, precision, mu=None, init_points=None, tuned=False) -> Trace:
+    """Dense-precision Gaussian (the oracle counterpart of ``nphip_model_dense_gaussian``).  ``tuned``: the free-order SIMD build
+    (a speed baseline only, as ``sample_tridiag_tuned``)."""
+    global _tuned
+    P = np.ascontiguousarray(precision, dtype=np.float64)
+    dim = P.shape[0]
+    assert P.shape == (dim, dim)
+    mu = _vec(mu, dim)
+    ip = None
+    if init_points is not None:
+        ip = np.ascontiguousarray(np.asarray(init_points, dtype=np.float64))
+        assert ip.shape == (int(settings.num_chains), dim)
+    draws, st, tr = _alloc(settings, dim)
+    secs = C.c_double(0)
+    if tuned:
+        if _tuned is None:
+            if not os.path.exists(_TUNED_PATH):
+                build(force=True)
+            _tuned = C.CDLL(_TUNED_PATH)
+            _tuned.oracle_last_error.restype = C.c_char_p
+        L = _tuned
+    else:
+        L = lib()
+    rc = L.oracle_sample_dense(C.byref(settings), C.c_uint64(dim), _p(mu), _p(P), _p(ip), C.byref(tr), C.byref(secs))
+    if rc != 0:
+        raise RuntimeError(L.oracle_last_error().decode())
+    return Trace(draws, st, secs.value)
+
+
+def dense_grad(x, precision, mu=None, waves=1):
+    """One evaluation of the dense model on the rows of ``x``: ``(grad[n, dim], logp[n])``."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    P = np.ascontiguousarray(precision, dtype=np.float64)
+    n, dim = x.shape
+    mu = _vec(mu, dim)
+    g, lp = np.empty_like(x), np.empty(n)
+    lib().oracle_dense_grad(C.c_uint64(n), C.c_uint64(dim), _p(x), _p(mu), _p(P), C.c_int(waves), _p(g), _p(lp))
+    return g, lp
+
+
 def sample_callback(settings: Settings, dim: int, fn, user=None, init_points=None) -> Trace:
     """fn: either a ctypes function pointer (LOGP_FN / raw address) or a Python callable
     ``f(x: ndarray) -> (logp, grad)`` wrapped here."""

@@ -307,6 +307,50 @@ struct TridiagModel : Model {
     }
 };
 
+// Dense-precision Gaussian of the engine (nphip_model_dense_gaussian; nutpie_amd/csrc/dense_tile.h):
+//   z = q - mu ; acc_j = sum_k z_k P[j][k] by fused multiply-adds, ONE accumulator per j from +0.0, in the order
+//   k = k0 + 4 t + s  for k0 = 0, 16, ... / s = 0..3 / t = 0..3 (k >= dim skipped) ; g_j = -acc_j ; logp = 0.5 * dot(z, g)
+// (the order in which the engine's fp64 matrix-core tile consumes a row: include/nphip_spec.h "dense gradient").
+void dense_grad(const double* P, size_t dim, const double* z, double* grad) {
+#ifdef ORACLE_TUNED
+    for (size_t j = 0; j < dim; ++j) {
+        const double* row = P + j * dim;
+        double acc = 0.0;
+#pragma omp simd reduction(+ : acc)
+        for (size_t k = 0; k < dim; ++k) acc += z[k] * row[k];
+        grad[j] = -acc;
+    }
+#else
+    // eight rows at a time: eight independent accumulator chains (each chain is sequential by contract)
+    for (size_t j0 = 0; j0 < dim; j0 += 8) {
+        const size_t nj = dim - j0 < 8 ? dim - j0 : 8;
+        double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        for (size_t k0 = 0; k0 < dim; k0 += 16)
+            for (size_t s = 0; s < 4; ++s)
+                for (size_t t = 0; t < 4; ++t) {
+                    const size_t k = k0 + 4 * t + s;
+                    if (k >= dim) continue;
+                    const double zk = z[k];
+                    for (size_t u = 0; u < nj; ++u) acc[u] = std::fma(zk, P[(j0 + u) * dim + k], acc[u]);
+                }
+        for (size_t u = 0; u < nj; ++u) grad[j0 + u] = -acc[u];
+    }
+#endif
+}
+
+struct DenseModel : Model {
+    const double* P = nullptr;   // [dim][dim] row-major, symmetric (borrowed)
+    std::vector<double> mu, z;
+    Geometry geo{1};
+    int64_t logp(const double* q, double* grad, double* logp_out) override {
+        z.resize(dim);
+        for (size_t i = 0; i < dim; ++i) z[i] = q[i] - mu[i];
+        dense_grad(P, dim, z.data(), grad);
+        *logp_out = 0.5 * det_dot(z.data(), grad, dim, geo);
+        return 0;
+    }
+};
+
 struct CallbackModel : Model {
     oracle_logp_fn fn = nullptr;
     void* user = nullptr;
@@ -1128,6 +1172,27 @@ int oracle_sample_callback(const oracle_settings_t* s, uint64_t dim, oracle_logp
         return std::unique_ptr<Model>(std::move(m));
     };
     return run_sampler(s, dim, mk, init_points, out, seconds);
+}
+
+int oracle_sample_dense(const oracle_settings_t* s, uint64_t dim, const double* mu, const double* P, const double* init_points,
+                        oracle_trace_t* out, double* seconds) {
+    auto mk = [&]() {
+        auto m = std::make_unique<DenseModel>();
+        m->dim = dim;
+        m->geo = Geometry{s->waves_per_chain};
+        m->P = P;
+        m->mu.assign(dim, 0.0); if (mu) m->mu.assign(mu, mu + dim);
+        return std::unique_ptr<Model>(std::move(m));
+    };
+    return run_sampler(s, dim, mk, init_points, out, seconds);
+}
+
+// one evaluation of the dense model on n rows: grad[n][dim], logp[n]
+void oracle_dense_grad(uint64_t n, uint64_t dim, const double* x, const double* mu, const double* P, int waves, double* grad, double* logp) {
+    DenseModel m;
+    m.dim = dim; m.P = P; m.geo = Geometry{waves};
+    m.mu.assign(dim, 0.0); if (mu) m.mu.assign(mu, mu + dim);
+    for (uint64_t i = 0; i < n; ++i) m.logp(x + i * dim, grad + i * dim, logp + i);
 }
 
 void oracle_set_variant(int min_refresh, int search_mode, int late_sym, int last_bar, int floor_windows) {

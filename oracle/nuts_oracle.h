@@ -200,6 +200,11 @@ double oracle_logaddexp(double a, double b);
 void oracle_w_leaf(double neg_energy_error, double* m, int64_t* e);
 void oracle_w_add(double m1, int64_t e1, double m2, int64_t e2, double* m, int64_t* e);
 void oracle_normals(uint64_t seed, uint32_t chain, uint32_t draw, uint32_t purpose, uint64_t n, double* out);
+/* Dense-precision Gaussian logp(x) = -1/2 (x-mu)' P (x-mu) with the engine's gradient summation order (nutpie_amd/csrc/dense_tile.h,
+ * include/nphip_spec.h "dense gradient"): the oracle counterpart of nphip_model_dense_gaussian.  P [dim][dim] row-major, borrowed. */
+int oracle_sample_dense(const oracle_settings_t* s, uint64_t dim, const double* mu, const double* P, const double* init_points,
+                        oracle_trace_t* out, double* seconds);
+void oracle_dense_grad(uint64_t n, uint64_t dim, const double* x, const double* mu, const double* P, int waves, double* grad, double* logp);
 double oracle_dot(const double* x, const double* y, uint64_t n, int waves);
 /* one leapfrog on the tridiag model; state arrays are in/out. returns energy U'+K'. */
 double oracle_leapfrog_tridiag(uint64_t dim, const double* mu, const double* diag, const double* offdiag,

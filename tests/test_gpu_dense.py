@@ -1,0 +1,87 @@
+"""The dense-precision Gaussian inside the engine (nphip_model_dense_gaussian; BASELINE.json configs[1] read as a DENSE correlated
+Gaussian, SURVEY.md §8d variant (ii)): its gradient is the engine's own fp64 matrix-core GEMM (nutpie_amd/csrc/dense_tile.h).
+
+The matrix core accumulates the four products of one v_mfma_f64_16x16x4_f64 as a chain of fused multiply-adds, so the GEMM's
+summation order is a contract (include/nphip_spec.h "dense gradient") the CPU oracle restates with std::fma — tolerance ZERO:
+gradients, log-densities, draws and every statistic are compared bit for bit, as for the fused tridiagonal models."""
+import numpy as np
+import pytest
+
+from nutpie_amd.gaussian import dense_precision
+from tests.conftest import assert_trace_equal
+from tests.test_gpu_parity import oracle_settings, run_engine
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from nutpie_amd import _lib
+
+    _lib.lib()
+    return _lib
+
+
+@pytest.mark.parametrize("n,dim", [(1, 1), (5, 3), (64, 64), (65, 63), (70, 100), (33, 257), (128, 1000), (300, 1023)])
+@pytest.mark.parametrize("waves", [1, 4])
+def test_gradient_gemm_is_the_contract_fma_chain(hip, oracle, n, dim, waves):
+    """Ragged shapes on purpose: rows that end inside a fragment (dim % 16 != 0), odd row lengths (rows of the dense staging
+    buffers then start on 8-byte boundaries), partial tiles in both directions, a single chain."""
+    rng = np.random.default_rng(1000 * n + dim)
+    P = dense_precision(dim, seed=3)
+    mu = rng.normal(size=dim)
+    x = rng.normal(size=(n, dim)) * 3
+    g, lp = hip.test_dense_grad(x, P, mu, waves=waves)
+    go, lpo = oracle.dense_grad(x, P, mu, waves=waves)
+    assert np.array_equal(g, go), f"gradient: {int((g != go).sum())} of {g.size} elements differ"
+    assert np.array_equal(lp, lpo)
+    ref = -(x - mu) @ P                                   # and the restatement is the mathematics (free summation order: rounding)
+    np.testing.assert_allclose(g, ref, rtol=0, atol=1e-11 * np.abs(ref).max())
+
+
+def test_non_finite_rows_stay_in_their_row(hip, oracle):
+    """A chain whose position is not finite (a diverged trajectory) must not leak into the gradients of its neighbours in the
+    tile — in particular not through the zero-padded tail of the last k-step (0 * inf)."""
+    dim, n = 100, 20
+    P = dense_precision(dim, seed=4)
+    x = np.random.default_rng(0).normal(size=(n, dim))
+    x[7, 3] = np.inf
+    x[11, 99] = np.nan
+    g, lp = hip.test_dense_grad(x, P)
+    go, lpo = oracle.dense_grad(x, P)
+    ok = np.ones(n, bool)
+    ok[[7, 11]] = False
+    assert np.array_equal(g[ok], go[ok]) and np.array_equal(lp[ok], lpo[ok])
+    assert not np.isfinite(g[7]).any() and not np.isfinite(lp[[7, 11]]).any()
+
+
+def test_unsymmetric_matrix_is_refused(hip):
+    P = dense_precision(5, seed=1)
+    P[1, 3] += 1e-3
+    with pytest.raises(ValueError, match="symmetric"):
+        hip.DenseGaussianModel(P)
+
+
+@pytest.mark.parametrize("dim,chains,launch", [(100, 8, {}), (100, 8, {"graph_steps": -1}), (37, 5, {}), (300, 70, {}), (1000, 6, {}),
+                                                (100, 16, {"host_groups": 2})])
+def test_dense_gaussian_bit_identical_to_the_oracle(hip, oracle, dim, chains, launch):
+    """A whole job — warm-up with step-size search and mass-matrix adaptation, then sampling — against oracle.sample_dense."""
+    P = dense_precision(dim, seed=5, cond_lo=0.1, cond_hi=10)
+    mu = np.linspace(-1, 1, dim)
+    tune, draws = (60, 20) if dim < 1000 else (30, 8)
+    got, W = run_engine(hip, hip.DenseGaussianModel(P, mu), chains=chains, tune=tune, draws=draws, seed=11, launch=launch)
+    want = oracle.sample_dense(oracle_settings(oracle, chains=chains, tune=tune, draws=draws, seed=11, W=W), P, mu)
+    assert_trace_equal(got, want)
+
+
+def test_dense_gaussian_through_sample(hip):
+    """The front door: nutpie_amd.sample on the dense model recovers the covariance's leading moments."""
+    import nutpie_amd
+
+    dim = 20
+    m = nutpie_amd.dense_gaussian(dim, seed=2, cond_lo=0.5, cond_hi=2)
+    tr = nutpie_amd.sample(m, draws=400, tune=300, chains=64, seed=3, progress_bar=False)
+    x = np.asarray(tr.posterior["x"]).reshape(-1, dim)
+    cov = m.covariance()
+    assert np.abs(x.mean(0)).max() < 5 * np.sqrt(np.diag(cov).max() / 2000)
+    np.testing.assert_allclose(np.cov(x.T), cov, atol=0.15 * np.abs(cov).max())

@@ -366,3 +366,48 @@ def test_sampler_under_a_handed_in_low_rank_metric(oracle):
     U0 = -np.concatenate([lr.stats["logp"][:, tune - 1:tune], lr.stats["logp"][:, tune:-1]], 1)
     assert abs((K0 - U0).mean() - D / 2) < 0.4
     assert lr.stats["diverging"][:, 25:].sum() == 0
+
+
+def test_dense_model_is_the_gaussian_and_its_order_is_the_contract(oracle):
+    """oracle.dense_grad: -P (x - mu) with ONE fma chain per output in the order k = k0 + 4 t + s (k0 step 16, s = 0..3, t = 0..3) — the
+    order in which the engine's fp64 matrix-core tile consumes a row (nutpie_amd/csrc/dense_tile.h) — and logp = 1/2 (x - mu) . grad in
+    the engine's summation geometry."""
+    import math
+
+    from nutpie_amd.gaussian import dense_precision
+
+    rng = np.random.default_rng(0)
+    for dim in (1, 3, 16, 37, 100):
+        P = dense_precision(dim, seed=dim)
+        mu = rng.normal(size=dim)
+        x = rng.normal(size=(4, dim))
+        g, lp = oracle.dense_grad(x, P, mu, waves=1)
+        np.testing.assert_allclose(g, -(x - mu) @ P, rtol=0, atol=1e-12 * np.abs(P).max() * dim)
+        np.testing.assert_allclose(lp, -0.5 * np.einsum("ij,jk,ik->i", x - mu, P, x - mu), rtol=1e-12)
+        # the order, restated in Python on row 0
+        z = x[0] - mu
+        for j in (0, dim - 1):
+            acc = 0.0
+            for k0 in range(0, dim, 16):
+                for s in range(4):
+                    for t in range(4):
+                        k = k0 + 4 * t + s
+                        if k < dim:
+                            acc = math.fma(z[k], P[j, k], acc) if hasattr(math, "fma") else float(np.float64(np.longdouble(z[k]) * np.longdouble(P[j, k]) + np.longdouble(acc)))
+            if hasattr(math, "fma"):
+                assert g[0, j] == -acc
+            else:
+                assert abs(g[0, j] + acc) <= 2e-16 * max(1.0, abs(acc)) * dim
+        assert lp[0] == 0.5 * oracle.dot(z, g[0], waves=1)
+
+
+def test_dense_sampler_recovers_the_covariance(oracle):
+    from nutpie_amd.gaussian import dense_precision
+
+    dim = 6
+    P = dense_precision(dim, seed=9, cond_lo=0.5, cond_hi=2)
+    tr = oracle.sample_dense(oracle.default_settings(seed=4, num_chains=16, num_tune=300, num_draws=500, n_threads=8), P)
+    x = tr.draws[:, 300:].reshape(-1, dim)
+    cov = np.linalg.inv(P)
+    np.testing.assert_allclose(np.cov(x.T), cov, atol=0.12 * np.abs(cov).max())
+    assert not tr.stats["diverging"][:, 300:].any()
