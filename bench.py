@@ -160,9 +160,55 @@ def cpu_baseline(model, seed, target_seconds):
     }
 
 
+def cpu_leg(run, chains_total, tune, draws, target_seconds, what, tuned_run=None):
+    """`cpu_baseline` of one leg: the CPU oracle ("port") on this box's host cores on a BOUNDED sample of the leg's workload — the same
+    density, settings and seed; one chain per thread on min(chains, cores) threads (the reference's `cores` model:
+    python/nutpie/sample.py:856-857, 1061-1070); as many of the workload's chains as fit `target_seconds` (all of them when they do).
+    `run(chains, tune, draws, threads)` -> oracle Trace.  `tuned_run`: the same with the free-order SIMD build (a second, faster CPU number)."""
+    cores = effective_cores()
+    cal_tune = max(4, min(tune, 20))
+    cal = run(min(cores, chains_total), cal_tune, 4, cores)
+    n_cal = float(cal.stats["n_steps"].sum())
+    rate = n_cal / max(cal.seconds, 1e-6)
+    per_chain = n_cal / min(cores, chains_total) / (cal_tune + 4) * (tune + draws) * 1.5   # (later draws take longer trees than the first ones)
+    chains = int(min(chains_total, max(min(cores, chains_total), (rate * target_seconds / max(per_chain, 1.0)) // cores * cores)))
+    tr = run(chains, tune, draws, cores)
+    if tr.seconds < target_seconds / 3.0 and chains < chains_total:   # the estimate was pessimistic (early warm-up draws are the expensive ones): once more, larger
+        chains = int(min(chains_total, max(chains, (chains * target_seconds / max(tr.seconds, 1e-3)) // cores * cores)))
+        tr = run(chains, tune, draws, cores)
+    n = int(tr.stats["n_steps"].sum())
+    out = {"value": n / tr.seconds, "unit": "leapfrog steps/s", "cores": min(cores, chains), "kind": "port",
+           "sample": f"CPU oracle (oracle/: C++ restatement of nuts-rs diag-NUTS) on {what}: {chains} of the workload's {chains_total} chains, tune {tune} + draws {draws}, "
+                     f"one chain per thread on {min(cores, chains)} threads (host: {os.cpu_count()} logical CPUs, cgroup/affinity limit {cores}): {n} leapfrogs in {tr.seconds:.2f} s"}
+    if tuned_run is not None:
+        try:
+            tt, chains_t = tuned_run(chains, tune, draws, cores), chains
+            if tt.seconds < target_seconds / 3.0 and chains_t < chains_total:   # (much faster than the port: a sample of its own size)
+                chains_t = int(min(chains_total, max(chains_t, (chains_t * target_seconds / max(tt.seconds, 1e-3)) // cores * cores)))
+                tt = tuned_run(chains_t, tune, draws, cores)
+            nt = int(tt.stats["n_steps"].sum())
+            out["tuned"] = {"value": nt / tt.seconds, "unit": "leapfrog steps/s", "cores": min(cores, chains), "kind": "tuned",
+                            "sample": f"the same sampler built for speed (AVX2 + FMA, free summation order: not a checker), {chains_t} chains: {nt} leapfrogs in {tt.seconds:.2f} s"}
+        except Exception as e:   # optional evidence
+            out["tuned"] = {"error": repr(e)}
+    return out
+
+
+def with_cpu(leg, cpu):
+    """Attach a leg's CPU baseline and the ratio (also where it is below 1)."""
+    leg["cpu_baseline"] = cpu
+    if cpu and "value" in cpu and leg.get("leapfrogs_per_s"):
+        leg["gpu_over_cpu"] = leg["leapfrogs_per_s"] / cpu["value"]
+        if "tuned" in cpu and "value" in cpu["tuned"]:
+            leg["gpu_over_cpu_tuned"] = leg["leapfrogs_per_s"] / cpu["tuned"]["value"]
+    return leg
+
+
 def run_job(hip, model, args, device, chain_offset, dims_for_ess, world=1):
-    """The complete job: tune 400 + draws 1000 on this GPU's chains; returns wall seconds, leapfrogs, ESS."""
-    from nutpie_amd.ess import ess_bulk
+    """The complete job: tune 400 + draws 1000 on this GPU's chains; returns wall seconds, leapfrogs, ESS — the bulk ESS of EVERY
+    dimension (min over all dimensions), computed on the GPU that holds the trace (nutpie_amd.ess.ess_bulk_all: one batched
+    sort + one batched FFT per block of dimensions); `dims_for_ess` are also evaluated by the per-dimension CPU routine as a cross-check."""
+    from nutpie_amd.ess import ess_bulk, ess_bulk_all
 
     s = hip.PyNutsSettings.Diag(args.seed)
     s.update(num_tune=400, num_draws=1000, num_chains=args.chains * world)
@@ -176,24 +222,27 @@ def run_job(hip, model, args, device, chain_offset, dims_for_ess, world=1):
     div = smp._copy("diverging", np.bool_)
     depth = smp._copy("depth", np.int64)
     step = smp._copy("step_size", np.float64)
-    ess = None
-    try:
-        from nutpie_amd.distributed import device_tensor
+    from nutpie_amd.distributed import device_tensor
+    import torch
 
-        d = device_tensor(smp.device_ptr("draws"), (args.chains, 1400, args.dim), "float64", device)
-        import torch
-
-        sub = d[:, 400:, torch.as_tensor(dims_for_ess, device=d.device)].cpu().numpy()
-    except Exception:
-        sub = smp._copy("draws", np.float64, vec=True)[:, 400:, dims_for_ess]
-    ess = [float(ess_bulk(sub[:, :, k])) for k in range(sub.shape[2])]
+    d = device_tensor(smp.device_ptr("draws"), (args.chains, 1400, args.dim), "float64", device)
+    t_ess = time.perf_counter()
+    ess_all = ess_bulk_all(d[:, 400:, :], block=25)
+    torch.cuda.synchronize()
+    t_ess = time.perf_counter() - t_ess
+    sub = d[:, 400:, torch.as_tensor(dims_for_ess, device=d.device)].cpu().numpy()
+    ess_cpu = np.array([float(ess_bulk(sub[:, :, k])) for k in range(sub.shape[2])])
+    del d
     smp.close()
+    ess = ess_all
     return {
+        "ess_seconds_on_device": t_ess, "ess_argmin_dim": int(np.nanargmin(ess_all)), "ess_median": float(np.nanmedian(ess_all)), "ess_max": float(np.nanmax(ess_all)),
+        "ess_cross_check": {"dims": [int(k) for k in dims_for_ess], "max_rel_diff_device_vs_cpu_routine": float(np.max(np.abs(ess_all[dims_for_ess] - ess_cpu) / ess_cpu))},
         "seconds": secs, "alloc_seconds": t_alloc, "leapfrogs": int(n_steps.sum()), "leapfrogs_tune": int(n_steps[:, :400].sum()),
         "leapfrogs_sample": int(n_steps[:, 400:].sum()), "leapfrogs_per_s": float(n_steps.sum() / secs),
         "mean_depth_sample": float(depth[:, 400:].mean()), "divergences_sample": int(div[:, 400:].sum()),
-        "final_step_size_mean": float(step[:, -1].mean()), "ess_dims": len(dims_for_ess), "ess_min": float(np.min(ess)),
-        "ess_min_per_s": float(np.min(ess) / secs), "chains": args.chains, "draws": 1000, "tune": 400,
+        "final_step_size_mean": float(step[:, -1].mean()), "ess_dims": int(len(ess)), "ess_min": float(np.nanmin(ess)),
+        "ess_min_per_s": float(np.nanmin(ess) / secs), "chains": args.chains, "draws": 1000, "tune": 400,
     }
 
 
@@ -528,6 +577,24 @@ def config5_shard(env, args):
     }
     if timing.get("gather_s") and timing.get("bytes_gathered") and env.world > 1:
         out["gather"]["GB_per_s_into_root"] = timing["bytes_gathered"] * (env.world - 1) / env.world / timing["gather_s"] / 1e9
+    if env.rank == 0 and not env.stub and not args.no_cpu_baseline:
+        # the CPU beside it: the oracle on the same 10 000-dimensional target (rank 0 only: the other ranks wait in the next collective)
+        try:
+            import oracle
+
+            oracle.build()
+
+            def run(chains_, tune_, draws_, threads):
+                return oracle.sample_tridiag(oracle.default_settings(seed=args.seed, num_chains=chains_, num_tune=tune_, num_draws=draws_, n_threads=threads), model.diag, model.offdiag)
+
+            def run_t(chains_, tune_, draws_, threads):
+                return oracle.sample_tridiag_tuned(oracle.default_settings(seed=args.seed, num_chains=chains_, num_tune=tune_, num_draws=draws_, n_threads=threads), model.diag, model.offdiag)
+
+            out["cpu_baseline"] = cpu_leg(run, chains, tune, 8, min(6.0, args.cpu_seconds), f"the {dim}-dim AR(1) Gaussian of this leg", tuned_run=run_t)
+            out["gpu_over_cpu"] = out["value"] / env.world / out["cpu_baseline"]["value"]
+            out["gpu_over_cpu_note"] = "one GPU's rate over the host's (the CPU sample is dominated by warm-up draws; the rate per leapfrog does not depend on the phase)"
+        except Exception as e:
+            out["cpu_baseline"] = {"error": repr(e)}
     return out
 
 
@@ -669,15 +736,115 @@ def other_configs(env, args):
         r = job_rate(smp, t0)
         r["host_mode"] = mode
         r["workload"] = "eight schools (D = 10, non-centred), 256 chains, tune 400 + draws 1000; raw C logp callback on the host (the reference's signature), PCIe inclusive"
+        bpl = 56.0 * 10
+        r["roofline"] = {"bound": "hbm", "achieved": bpl * r["leapfrogs_per_s"] / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bpl * r["leapfrogs_per_s"] / 1e9 / HBM_PEAK_GBS,
+                         "traffic": None, "note": "SURVEY.md 8d algorithmic bytes (56 D per leapfrog, opaque gradient) x leapfrogs/s: a 10-dimensional model moves nothing — the leg is bound by the "
+                                                  "round trip to the host's callback (one rendezvous over PCIe per evaluation of a group of chains), not by any device resource"}
+        r["divergences_note"] = "eight schools' funnel diverges now and then at target_accept 0.8 also in the non-centred form: the count is the sampler's, the same order in the CPU oracle's run beside it"
         return r
 
-    def c2_dense():
-        import nutpie_amd
+    cpu_s = 0.0 if args.no_cpu_baseline else min(6.0, args.cpu_seconds)
 
-        m = nutpie_amd.dense_gaussian(1000, device=env.device)
+    def oracle_mod():
+        import oracle
+
+        oracle.build()
+        return oracle
+
+    def c3_cpu():
+        # the CPU beside config 3: the oracle sampling the radon density as a raw C callback (tests/fixtures/radon_host.c: the same 85 counties /
+        # 919 observations, D = 173, the reference's callback signature) — what nuts-rs does with a numba cfunc
+        import ctypes
+
+        from nutpie_amd.radon import synthetic_radon_data
+
+        oracle = oracle_mod()
+        host = ctypes.CDLL(os.path.join(ROOT, "tests", "fixtures", "libradon_host.so"))
+        host.radon_host_create.restype = ctypes.c_void_p
+        host.radon_host_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        data = synthetic_radon_data()
+        n = int(data["county_idx"].max()) + 1
+        cty = np.ascontiguousarray(data["county_idx"], dtype=np.int32)
+        fl, y = np.ascontiguousarray(data["floor"]), np.ascontiguousarray(data["log_radon"])
+        hh = host.radon_host_create(n, len(y), cty.ctypes.data, fl.ctypes.data, y.ctypes.data)
+        fn = ctypes.cast(host.radon_host_logp, ctypes.c_void_p).value
+
+        def run(chains_, tune_, draws_, threads, tuned=False):
+            return oracle.sample_callback(oracle.default_settings(seed=20260926, num_chains=chains_, num_tune=tune_, num_draws=draws_, n_threads=threads), 2 * n + 3, fn, user=hh, tuned=tuned)
+
+        return cpu_leg(run, 512, 400, 1000, cpu_s, "the radon density as a raw C logp callback (tests/fixtures/radon_host.c)", tuned_run=lambda *a: run(*a, tuned=True))
+
+    def c4_cpu():
+        import ctypes
+
+        oracle = oracle_mod()
+        fix = ctypes.CDLL(os.path.join(ROOT, "tests", "fixtures", "libeight_schools.so"))
+        fn = ctypes.cast(fix.eight_schools_logp, ctypes.c_void_p).value
+
+        def run(chains_, tune_, draws_, threads, tuned=False):
+            return oracle.sample_callback(oracle.default_settings(seed=21, num_chains=chains_, num_tune=tune_, num_draws=draws_, n_threads=threads, init_kind=1), 10, fn, tuned=tuned)
+
+        # (the port emulates the engine's 64-lane summation geometry on every dot product — at 10 dimensions that emulation IS its cost; the
+        #  `tuned` entry, plain loops, is the CPU number to compare a 10-dimensional model with)
+        return cpu_leg(run, 256, 400, 1000, cpu_s, "the same eight-schools C callback (tests/fixtures/eight_schools.c)", tuned_run=lambda *a: run(*a, tuned=True))
+
+    def c2_dense():
+        # BASELINE.json configs[1] read as a DENSE correlated Gaussian (SURVEY.md 8d variant (ii)) INSIDE the engine: the gradients of all chains
+        # of an evaluation round are one fp64 GEMM on the matrix cores, hand-written (csrc/dense_tile.h), called from the middle of the
+        # register-resident leaf (kernels.hip: DENSEG / dg_round) — one resident launch runs 256 rounds.  Measured like the headline: a short
+        # warm-up (untimed), then a timed region of launches in the sampling phase; the whole bounded job of round 5's line beside it.
+        from nutpie_amd.gaussian import dense_precision
+
+        D, chains, tune = 1000, 1024, 60
+        P = dense_precision(D)
+        model = hip.DenseGaussianModel(P)
+        E = 256
+        K = 24
+        smp = hip.PySampler(settings(chains, tune, 96, seed=1), model, device=env.device, store_draws=False, evals_per_launch=E, manual=True)
+        mode = smp.host_mode
+        warm = warm_up_to_sampling(smp, batch=4)
+        smp.step(2)
+        elapsed, leap, kernel_ms, _ = timed_launches(env, smp, K, tune + 96)
+        smp.close()
+        rate = leap / elapsed
+        peak = hip.mfma_f64_rate(env.device)
+        flops = 2.0 * D * D
+        r = {"leapfrogs_per_s": rate, "timed_region_s": elapsed, "steps": K, "ms_per_step": 1000.0 * elapsed / K, "kernel_ms_per_launch": kernel_ms / K,
+             "rounds_per_launch": E, "us_per_round": 1e6 * (kernel_ms / 1000.0) / (K * E), "useful_leapfrogs_per_round_and_chain": leap / (K * E * chains),
+             "host_mode": mode, "waves_per_chain": 1,
+             "warmup": {"leapfrogs": warm[0], "launches": warm[1], "kernel_ms": warm[2], "wall_s": warm[3]},
+             "roofline": {"bound": "mfma", "kernel": "k_advance<callback,W=1,NV=8,REMOTE,DENSEG> (the launch-wide gradient GEMM inside the register-resident leaf)",
+                          "achieved": flops * rate / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": flops * rate / 1e12 / peak, "traffic": None,
+                          "flops_per_leapfrog": flops, "peak_datasheet_TFLOPs": 78.6, "frac_of_datasheet": flops * rate / 1e12 / 78.6,
+                          "note": "achieved = 2 D^2 flop per leapfrog x leapfrogs/s of the timed region (the whole step: leaf + rendezvous + GEMM); peak = the fp64 matrix-core "
+                                  "rate MEASURED on this device in this run (v_mfma_f64_16x16x4_f64 back to back on every SIMD: 96 cycles per instruction at 2.4 GHz — "
+                                  "nphip_test_mfma_f64_rate; MI355X_MICROARCH.md lists no fp64 MFMA figure, the datasheet's 78.6 TFLOP/s is beside it)"},
+             "workload": f"dense {D}-dim Gaussian (condition 1e4), {chains} chains, gradient = the engine's own fp64 MFMA GEMM inside the resident kernel; "
+                         f"warm-up tune {tune} (untimed), then {K} launches of {E} evaluation rounds in the sampling phase"}
+        # the bounded whole job of round 5's line (tune 30 + draws 10, job-level rate: tail and warm-up phases included), both forms of the model
+        t0 = time.perf_counter()
+        r["bounded_job"] = job_rate(hip.PySampler(settings(chains, 30, 10, seed=1), hip.DenseGaussianModel(P), device=env.device, store_draws=False), t0)
+        t0 = time.perf_counter()
+        r["bounded_job_launch_per_evaluation"] = job_rate(hip.PySampler(settings(chains, 30, 10, seed=1), hip.DenseGaussianModel(P), device=env.device, store_draws=False, host_persist=1), t0)
+        if cpu_s > 0:
+            oracle = oracle_mod()
+
+            def run(chains_, tune_, draws_, threads):
+                return oracle.sample_dense(oracle.default_settings(seed=1, num_chains=chains_, num_tune=tune_, num_draws=draws_, n_threads=threads), P)
+
+            def run_t(chains_, tune_, draws_, threads):
+                return oracle.sample_dense(oracle.default_settings(seed=1, num_chains=chains_, num_tune=tune_, num_draws=draws_, n_threads=threads), P, tuned=True)
+
+            with_cpu(r, cpu_leg(run, chains, 8, 2, cpu_s, "the same dense Gaussian (oracle.sample_dense: the contract's fma chain per gradient element)", tuned_run=run_t))
+        return r
+
+    def c2_dense_torch():
+        from nutpie_amd.gaussian import dense_gaussian_torch
+
+        m = dense_gaussian_torch(1000, device=env.device)
         t0 = time.perf_counter()
         r = job_rate(m._make_sampler(settings(1024, 30, 10, seed=1), None, 1, None, None, None, None, store_draws=False), t0)
-        r["workload"] = "dense 1000-dim Gaussian (condition 1e4), 1024 chains, gradient = fp64 GEMM (rocBLAS via torch) behind the batched device callback; bounded sample: tune 30 + draws 10"
+        r["workload"] = "dense 1000-dim Gaussian, 1024 chains, gradient = fp64 GEMM (rocBLAS via torch) behind the batched device callback (round 5's path, kept as the comparison); bounded sample: tune 30 + draws 10"
         return r
 
     leg("config3_radon_generated_density", c3_generated)
@@ -686,7 +853,26 @@ def other_configs(env, args):
     leg("config3_radon_torch_density", c3_traced)
     leg("config3_radon_torch_density_eager", c3_torch)
     leg("config4_eight_schools_host_callback", c4)
-    leg("config2ii_dense_gaussian_gemm_callback", c2_dense)
+    leg("config2ii_dense_gaussian_in_engine_mfma", c2_dense)
+    leg("config2ii_dense_gaussian_gemm_callback", c2_dense_torch)
+    if cpu_s > 0:
+        # the CPU path timed beside every leg (rank 0, same run): one baseline per workload, attached to each leg that runs it
+        try:
+            cpu3 = c3_cpu()
+        except Exception as e:
+            cpu3 = {"error": repr(e)}
+        for k in list(out):
+            if k.startswith("config3_") and "error" not in out[k]:
+                with_cpu(out[k], cpu3)
+        try:
+            cpu4 = c4_cpu()
+        except Exception as e:
+            cpu4 = {"error": repr(e)}
+        if "error" not in out["config4_eight_schools_host_callback"]:
+            with_cpu(out["config4_eight_schools_host_callback"], cpu4)
+        d_ = out.get("config2ii_dense_gaussian_in_engine_mfma", {})
+        if "cpu_baseline" in d_ and "error" not in out["config2ii_dense_gaussian_gemm_callback"]:
+            with_cpu(out["config2ii_dense_gaussian_gemm_callback"], d_["cpu_baseline"])
     return out
 
 

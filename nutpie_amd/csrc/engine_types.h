@@ -199,7 +199,17 @@ struct Args {
     const void* dens_data;       // the model's data block (device memory; layout defined by the generated prelude of the density source)
     int32_t dens_lds_doubles;    // LDS scratch per wave the density asked for, in doubles (dynamic LDS of the launch)
     int32_t dens_shared_doubles; // LDS shared by the chains of a workgroup (the model's data staged once per launch: nphip_density_stage)
+    // dense-precision Gaussian, resident form (kernels.hip: Machine<..., DG>): the padded precision matrix [DP][KP] (DP = dim rounded up to 64,
+    // KP to 16; zeros beyond dim), the padded mean [KP], and the rendezvous words of the clusters of workgroups — per cluster two counters
+    // (positions written / gradients written) on a 128-byte line each, zeroed by the host before every launch; word 0 of the last line:
+    // a rendezvous timed out (everybody leaves)
+    const double* dg_P;
+    const double* dg_mu;
+    int64_t dg_KP;
+    unsigned long long* dg_sync;   // kDgSyncWords 64-bit words (layout: kernels.hip, kDg*)
+    int32_t dg_variant, dg_pad_;   // measurement switches (NPHIP_DG_VARIANT): bit 0 no fences, bit 1 agent-scope accesses to the exchanged rows, bit 2 no GEMM
 };
+constexpr int kDgSyncWords = 128 * 32 + 16 + 16 + 8 * 256 / 2;   // = kDgWords of kernels.hip: 128 clusters x 2 lines, abort line, seat counts, seat table
 constexpr unsigned long long kGoLast = 1ull << 32;      // finish this evaluation's step, then leave the kernel at the boundary
 constexpr unsigned long long kGoSeqMask = 0xffffffffull;
 constexpr unsigned long long kPubAllDone = 1ull << 62, kPubError = 1ull << 63;   // resident launches: flags beside the published sequence number

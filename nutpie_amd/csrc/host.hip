@@ -32,6 +32,7 @@ hipError_t launch_advance(const Args& a, const Args* d_args, bool fused, int W, 
 hipError_t launch_resume(const Args* d_args, int n, const int64_t* d_chains, const double* d_pos, bool fused, hipStream_t st);
 hipError_t launch_set_metric(const Args* d_args, int n, const int64_t* d_chains, int k, const double* sig2, const double* V, const double* lam, int* d_taken, hipStream_t st);
 hipError_t launch_remote(const Args* d_args, int W, int nv, hipStream_t st, const LaunchSlice& sl);
+hipError_t launch_dense_resident(const Args* d_args, int nv, int max_evals, hipStream_t st, const LaunchSlice sl);
 hipError_t launch_dense_grad(const double* X, const double* Pp, const double* mu, double* G, double* logp, int64_t n, int64_t D, int64_t KP, int W, hipStream_t st);
 hipError_t launch_mfma_f64_rate(double* out, int blocks, int iters, hipStream_t st);
 hipError_t launch_test_detmath(int fn, uint64_t n, const double* x, double* y, hipStream_t st);
@@ -661,6 +662,16 @@ struct nphip_sampler {
 
     // dense-precision Gaussian (model.dense): the padded matrix and mean on this device; the evaluation = two kernel launches
     struct DenseDev { const double* Pp = nullptr; const double* mu = nullptr; int64_t KP = 0; int W = 1; } dense_dev;
+    // ... and its resident form (kernels.hip: k_advance<..., DENSEG>): the register-resident leaf with the launch-wide GEMM as the
+    // evaluation in its middle — driven like a fused model (a launch runs `evals_per_launch` evaluations of every chain).  A launch whose
+    // roll call fails (the device was busy: not every chain resident) has touched nothing and is simply repeated; after three in a row the
+    // job goes on with a launch per evaluation.
+    bool dg = false, dg_fell_back = false;
+    int dg_fail = 0;
+    unsigned dg_launch_id = 0;
+    unsigned long long dg_fail_seen = 0;
+    volatile unsigned long long* h_dg_abort = nullptr;   // pinned [2]: the rendezvous-timed-out word after each launch
+    bool dg_check(int slot);
     static int dense_dev_fn(uint64_t n_chains, uint64_t dim, const double* q, double* grad, double* logp, void* stream, void* user) {
         const DenseDev* d = (const DenseDev*)user;
         return launch_dense_grad(q, d->Pp, d->mu, grad, logp, (int64_t)n_chains, (int64_t)dim, d->KP, d->W, (hipStream_t)stream) == hipSuccess ? 0 : -1;
@@ -802,7 +813,8 @@ bool nphip_sampler::setup() {
     T = set.num_tune + set.num_draws;
     fused = model.kind == 0;
     dens = model.kind == 3;
-    W = dens ? model.jit_w : (launch.waves_per_chain ? launch.waves_per_chain : (model.kind == 2 ? choose_waves_callback(dim) : choose_waves(dim)));
+    // (the dense Gaussian up to 1024 dimensions: one wave per chain — the geometry of its resident kernel, whichever form runs)
+    W = dens ? model.jit_w : (launch.waves_per_chain ? launch.waves_per_chain : (model.kind == 2 && !(model.dense && dim <= 1024) ? choose_waves_callback(dim) : choose_waves(dim)));
     const bool lrm = set.low_rank_metric;
     if (dens && lrm != model.jit_lr) {
         set_error(lrm ? "this library's resident kernel was not built for the low-rank metric (compile it with -DNPHIP_JIT_LR=1 and say so with nphip_model_jit_low_rank), or use its batched device callback"
@@ -1040,6 +1052,23 @@ bool nphip_sampler::setup() {
         dense_dev.Pp = dP; dense_dev.mu = dmu; dense_dev.KP = (int64_t)KP; dense_dev.W = W;
         model.dev_fn = &nphip_sampler::dense_dev_fn;
         model.user = &dense_dev;
+        // the resident form: every chain on the device at once (one workgroup of four chains per CU), state in registers
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) cus = 0;
+        dg = W == 1 && dim <= 1024 && (n + 3) / 4 <= (uint64_t)cus && !lrm && !set.store_divergences &&
+             set.pause_draws.empty() && !launch.no_register_kernel && launch.host_persist != 1 && launch.host_groups < 2;
+        if (dg) {
+            args.dg_P = dP; args.dg_mu = dmu; args.dg_KP = (int64_t)KP;
+            { const char* e = getenv("NPHIP_DG_VARIANT"); args.dg_variant = e ? atoi(e) : 0; }
+            args.reg_nv = (int32_t)(args.ld / 128);
+            unsigned long long* f = nullptr;
+            if (!dalloc(&args.dg_sync, (size_t)kDgSyncWords) || !dalloc(&args.grp_go_dev, 16 * kMaxGroups) || !palloc(&f, 4 * kMaxGroups)) return false;
+            args.grp_flag = f;
+            h_grp_flag = f;
+            unsigned long long* ab = nullptr;
+            if (!palloc(&ab, 2)) return false;
+            h_dg_abort = ab;
+        }
     }
     if (model.kind == 2 && launch.host_groups >= 2 && !launch.manual && n >= 8) {
         // Device callbacks in groups (round 5): the chains in `host_groups` contiguous groups, each with a stream of its
@@ -1098,7 +1127,8 @@ std::string nphip_sampler::chain_error_message() {
 bool nphip_sampler::launch_kernel(bool fused_, int have) {
     // (a runtime-compiled density costs microseconds per evaluation: 512 per launch is milliseconds of kernel already, and the
     //  job's tail — chains that are done wait for the launch to end — shrinks with the launch)
-    args.max_evals = (fused_ || dens) ? (launch.evals_per_launch > 0 ? launch.evals_per_launch : (dens ? 512 : default_evals_per_launch(dim))) : 0;
+    // (the dense Gaussian's resident form: an evaluation round of the whole launch is ~50 us at 1024 chains x 1000 dimensions)
+    args.max_evals = (fused_ || dens || dg) ? (launch.evals_per_launch > 0 ? launch.evals_per_launch : (dg ? 256 : (dens ? 512 : default_evals_per_launch(dim)))) : 0;
     args.have_result = have;
     if (kernel_ms_acc) {
         while (tev.size() < 2 * (timed_launches + 1)) {
@@ -1116,6 +1146,20 @@ bool nphip_sampler::launch_kernel(bool fused_, int have) {
         const int rc = model.jit_launch(d_args, args.max_evals, (void*)stream, &sl,
                                         cpb * model.jit_lds_bytes + model.jit_shared_bytes + cpb * 2 * (uint64_t)args.ld * 8);
         if (rc != 0) { set_error(std::string("launch of the runtime-compiled density kernel: ") + hipGetErrorString((hipError_t)rc)); return false; }
+    } else if (dg) {
+        LaunchSlice sl;
+        memset(&sl, 0, sizeof(sl));
+        sl.chain_lo = 0; sl.chain_n = (int)n; sl.grp = -1; sl.seq = ++dg_launch_id; sl.n_grp = 1;
+        for (int g = 1; g <= kMaxGroups; ++g) sl.grp_lo[g] = (int)n;
+        if (!hip_ok(hipMemsetAsync(args.dg_sync, 0, (size_t)kDgSyncWords * 8, stream), "hipMemsetAsync")) return false;
+        if (!hip_ok(launch_dense_resident(d_args, args.reg_nv, args.max_evals, stream, sl), "launch k_advance (dense, resident)")) return false;
+    } else if (materialise && model.dense) {
+        // the launches before this one were resident ones (they defer the first half of a tree leapfrog into the leaf): this one performs it
+        LaunchSlice sl;
+        memset(&sl, 0, sizeof(sl));
+        sl.chain_lo = 0; sl.chain_n = (int)n; sl.grp = -1; sl.materialise = 1;
+        materialise = false;
+        if (!hip_ok(launch_advance(args, d_args, fused_, W, stream, &sl), "launch k_advance")) return false;
     } else if (!hip_ok(launch_advance(args, d_args, fused_, W, stream), "launch k_advance")) return false;
     if (kernel_ms_acc) {
         if (!hip_ok(hipEventRecord(tev[2 * timed_launches + 1], stream), "hipEventRecord")) return false;
@@ -1136,14 +1180,47 @@ bool nphip_sampler::iteration_fused(bool& all_done) {
     const int slot = (int)(fused_k & 1);
     if (!ev_f[0] && (!hip_ok(hipEventCreateWithFlags(&ev_f[0], hipEventDisableTiming), "hipEventCreate") ||
                      !hip_ok(hipEventCreateWithFlags(&ev_f[1], hipEventDisableTiming), "hipEventCreate"))) return false;
-    if (!launch_kernel(!dens, 0)) return false;
+    if (!launch_kernel(!dens && !dg, 0)) return false;
     if (!hip_ok(hipMemcpyAsync(h_counters + 2 * slot, args.counters, 16, hipMemcpyDeviceToHost, stream), "copy counters")) return false;
+    if (dg && !hip_ok(hipMemcpyAsync((void*)(h_dg_abort + slot), args.dg_sync + (size_t)128 * 32, 8, hipMemcpyDeviceToHost, stream), "copy abort word")) return false;
     if (!hip_ok(hipEventRecord(ev_f[slot], stream), "hipEventRecord")) return false;
     fused_k += 1;
     if (fused_k < 2) return true;
     // the launch before this one: by now it has the device to itself no longer — its successor is queued behind it
     if (!hip_ok(hipEventSynchronize(ev_f[slot ^ 1]), "hipEventSynchronize")) return false;
+    if (dg && !dg_check(slot ^ 1)) return false;
     return check_counters(slot ^ 1, all_done);
+}
+
+// The dense Gaussian's resident launches, looked at one launch late (as the counters are): a rendezvous that timed out is an error (it
+// cannot happen after a roll call that succeeded, short of a device fault); a roll call that failed is a launch that did nothing.
+bool nphip_sampler::dg_check(int slot) {
+    if (h_dg_abort[slot] != 0ull) {
+        (void)hipStreamSynchronize(stream);
+        set_error("dense Gaussian, resident kernel: a rendezvous of the launch-wide gradient GEMM timed out");
+        return false;
+    }
+    if (getenv("NPHIP_DEBUG") && dg_launch_id <= 2) {
+        unsigned seats[8];
+        (void)hipMemcpy(seats, args.dg_sync + 128 * 32 + 16, sizeof(seats), hipMemcpyDeviceToHost);
+        fprintf(stderr, "nphip: dense resident launch: workgroups per die %u %u %u %u %u %u %u %u\n", seats[0], seats[1], seats[2], seats[3], seats[4], seats[5], seats[6], seats[7]);
+    }
+    const unsigned long long failed_id = h_grp_flag[3];
+    if (failed_id != 0ull && failed_id != dg_fail_seen) {
+        dg_fail_seen = failed_id;
+        if (++dg_fail >= 3) {
+            // the device does not hold all chains at once (something else is running on it): a launch per evaluation from here on
+            if (!hip_ok(hipStreamSynchronize(stream), "hipStreamSynchronize")) return false;
+            dg = false;
+            dg_fell_back = true;
+            materialise = true;
+            manual_have = 0;
+            fused_k = 0;
+        }
+    } else if (failed_id == dg_fail_seen) {
+        dg_fail = 0;
+    }
+    return true;
 }
 
 // Host callback on the rows [lo, lo + cnt) of the staging buffers (the reference calls the same function pointer once per
@@ -1638,7 +1715,7 @@ void nphip_sampler::run() {
         bool ok;
         {
             std::lock_guard<std::mutex> run_lk(mu_run);
-            ok = (fused || dens) ? iteration_fused(all_done) : (remote ? iteration_remote(all_done) : ((n_groups > 0 && cb_groups == 0) ? iteration_pipelined(all_done) : iteration_callback(all_done, have)));
+            ok = (fused || dens || dg) ? iteration_fused(all_done) : (remote ? iteration_remote(all_done) : ((n_groups > 0 && cb_groups == 0) ? iteration_pipelined(all_done) : iteration_callback(all_done, have)));
         }
         seconds.store(std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count());
         if (!ok) { fail(t_error); break; }
@@ -1712,13 +1789,14 @@ int nphip_sampler_step(nphip_sampler_t* s, uint64_t n_launches, double* kernel_m
     bool all_done = false, ok = true;
     auto t0 = std::chrono::steady_clock::now();
     for (uint64_t i = 0; i < n_launches && !all_done; ++i) {
-        ok = (s->fused || s->dens) ? s->iteration_fused(all_done) : s->iteration_callback(all_done, s->manual_have);
+        ok = (s->fused || s->dens || s->dg) ? s->iteration_fused(all_done) : s->iteration_callback(all_done, s->manual_have);
         if (!ok) break;
         if (launches_done) *launches_done += 1;
     }
     s->kernel_ms_acc = nullptr;
     if (ok) ok = hip_ok(hipStreamSynchronize(s->stream), "hipStreamSynchronize");
-    if (ok && (s->fused || s->dens) && s->fused_k > 0 && !all_done) ok = s->check_counters((int)((s->fused_k - 1) & 1), all_done);   // (the last launch, too)
+    if (ok && s->dg && s->fused_k > 0) ok = s->dg_check((int)((s->fused_k - 1) & 1));
+    if (ok && (s->fused || s->dens || s->dg) && s->fused_k > 0 && !all_done) ok = s->check_counters((int)((s->fused_k - 1) & 1), all_done);   // (the last launch, too)
     if (ok && kernel_ms) {
         for (size_t i = 0; i < s->timed_launches && ok; ++i) {
             float ms = 0.f;
@@ -1781,6 +1859,7 @@ uint64_t nphip_sampler_total_draws(const nphip_sampler_t* s) { return s->T; }
 double nphip_sampler_seconds(const nphip_sampler_t* s) { return s->seconds.load(); }
 uint64_t nphip_sampler_launches(const nphip_sampler_t* s) { return s->launches.load(); }
 int nphip_sampler_host_mode(const nphip_sampler_t* s) {
+    if (s->model.dense) return s->dg ? NPHIP_HOST_MODE_RESIDENT : (s->dg_fell_back ? NPHIP_HOST_MODE_FELL_BACK : NPHIP_HOST_MODE_LAUNCH_PER_EVALUATION);
     if (s->model.kind != 1) return NPHIP_HOST_MODE_NONE;
     if (s->remote) return NPHIP_HOST_MODE_RESIDENT;
     if (s->remote_fell_back) return NPHIP_HOST_MODE_FELL_BACK;

@@ -322,6 +322,166 @@ __device__ __forceinline__ double clamp_mm(double v) { return v < 1e-20 ? 1e-20 
 #include "dense_tile.h"   // the fp64 MFMA tile of the dense-precision Gaussian's gradient
 namespace nphip {
 
+// ---- dense-precision Gaussian, resident form: one evaluation ROUND of the whole launch ------------------------------------------
+// The register-resident leaf keeps a chain's state in VGPRs and calls its evaluation in the middle (REMOTE).  For the dense Gaussian
+// the evaluation of ALL chains is one GEMM, so the call is a rendezvous of workgroups: every wave has written its position row ->
+// barrier -> each workgroup computes a 64 x 64 tile of G = -(X - mu) P on the matrix cores (dense_tile.h; four waves, 32 x 32 each)
+// -> barrier -> every wave reads its gradient row back and goes on with its leaf.  No launch, no trip of the chain state through
+// memory, no host.
+// Who waits for whom: the GEMM of a row block needs only the positions of ITS chains, and a chain only its own row of G.  So the
+// 16 workgroups whose 64 chains form one row block are a CLUSTER that synchronises among itself (two counters per cluster), and the
+// clusters drift apart freely.  Workgroup b runs on XCD b % 8 (round-robin dispatch): cluster = (b % 8) + 8 * (b / 128), so a cluster's
+// positions and gradients stay in ONE XCD's L2; member j = (b / 8) % 16 of m computes the column tiles j, j + m, ...
+// Every wave of the launch takes part in every round (a chain that has finished, or a wave without a chain, as a ghost): the
+// counters' targets are multiples of the cluster size.  A wait that lasts a second gives up, flags the launch and everybody leaves.
+// WHO IS IN A CLUSTER is decided at run time (dg_register / dg_enroll, k_advance): every workgroup reads the XCC_ID of the die it was
+// dispatched to and takes the next seat of that die; sixteen consecutive seats are a cluster.  All members of a cluster then share ONE L2
+// — the coherence point for everything they exchange: a position or gradient row is visible to the other members once its store has
+// been acknowledged (vmcnt), and a reader only has to drop its own CU's L1 (buffer_inv sc0: the workgroup-scope acquire of threadgroup-
+// split mode).  The agent-scope alternative — an L2 write-back and an L2 invalidate around every rendezvous, which a cluster spanning dies
+// needs — cost 20 us of a 98 us round, most of it by evicting the precision matrix from L2 every round (profiles/r6_dense_resident.txt).
+// Per wave in LDS (g_dgwho + 24 * wave): [0] cluster (global index: die * 16 + cluster of the die), [1] member, [2] members, [3] die,
+// [4] seat, [8 .. 8 + members) the members' workgroup ids (row r of the cluster's block is chain 4 * id[r / 4] + r % 4).
+__shared__ int g_dgwho[4 * 24];
+constexpr int kDgMaxClusters = 128;                    // 8 dies x 16 clusters of 16 workgroups
+constexpr int kDgAbort = kDgMaxClusters * 32;          // word offsets into Args::dg_sync: the abort word (a line of its own)
+constexpr int kDgSeats = kDgAbort + 16;                // seats taken per die [8] (32-bit)
+constexpr int kDgTable = kDgSeats + 16;                // workgroup id of every seat [8][256] (32-bit)
+constexpr int kDgWords = kDgTable + 8 * 256 / 2;       // (size of dg_sync in 64-bit words)
+static_assert(kDgWords == kDgSyncWords, "engine_types.h: kDgSyncWords");
+__device__ __forceinline__ int64_t dg_chain_of(const NPHIP_LDS int* who, int r) { return 4 * (int64_t)who[8 + (r >> 2)] + (r & 3); }
+// kernel start, every thread of the workgroup: take a seat on this die (static: the seats a round-robin dispatch would give)
+__device__ __forceinline__ void dg_register(const NPHIP_CONST Args& A) {
+    if (threadIdx.x == 0) {
+        unsigned die, seat;
+        if (A.dg_variant & 64) { die = blockIdx.x & 7u; seat = blockIdx.x >> 3; }
+        else {
+            die = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u;   // hwreg(HW_REG_XCC_ID, 0, 4)
+            seat = atomicAdd((unsigned*)(A.dg_sync + kDgSeats) + die, 1u);
+        }
+        __hip_atomic_store((unsigned*)(A.dg_sync + kDgTable) + die * 256u + seat, (unsigned)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        for (int w = 0; w < 4; ++w) { g_dgwho[24 * w + 3] = (int)die; g_dgwho[24 * w + 4] = (int)seat; }
+    }
+    __syncthreads();
+}
+// after the roll call (every workgroup of the launch has taken its seat), every wave: who are the members of my cluster
+__device__ __forceinline__ void dg_enroll(const NPHIP_CONST Args& A) {
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    NPHIP_LDS int* who = (NPHIP_LDS int*)g_dgwho + 24 * wib;
+    const int die = who[3], seat = who[4];
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    int taken;
+    if (A.dg_variant & 64) { const int G = (int)gridDim.x; taken = (G - die + 7) / 8; }
+    else taken = (int)__hip_atomic_load((unsigned*)(A.dg_sync + kDgSeats) + die, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int cl = seat >> 4, left = taken - 16 * cl, m = left > 16 ? 16 : left;
+    if (lane < 16) {
+        int id = 0;
+        if (lane < m) {
+            if (A.dg_variant & 64) id = die + 8 * (16 * cl + lane);
+            else id = (int)__hip_atomic_load((unsigned*)(A.dg_sync + kDgTable) + die * 256 + 16 * cl + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        who[8 + lane] = id;
+    }
+    if (lane == 0) { who[0] = die * 16 + cl; who[1] = seat & 15; who[2] = m; }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ void dg_wait(unsigned long long* ctr, unsigned long long want, unsigned long long* abort_word) {
+    const long long t0 = wall_clock64();   // 100 MHz
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+        __builtin_amdgcn_s_sleep(1);
+        if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) break;
+        if (wall_clock64() - t0 > 100000000ll) { __hip_atomic_store(abort_word, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    }
+}
+// prof (measurement, dg_variant & 32): this wave's cycle counters — [8] wait for the positions, [9] the GEMM, [10] wait for the gradients (shader
+// cycles), [11] the whole round in 100 MHz ticks, [12] rounds
+__device__ __forceinline__ void dg_round(const NPHIP_CONST Args& A, int round, int64_t n_chains, NPHIP_LDS int64_t* prof = nullptr) {
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const NPHIP_LDS int* who = (const NPHIP_LDS int*)g_dgwho + 24 * wib;
+    const int who_member = who[1], who_m = who[2];
+    unsigned long long* arrive = A.dg_sync + (size_t)who[0] * 32;
+    unsigned long long* done = arrive + 16;
+    unsigned long long* abort_word = A.dg_sync + kDgAbort;
+    const unsigned long long want = (unsigned long long)who_m * (unsigned long long)(round + 1);
+    // How the exchanged rows become visible.  Writers: a plain store is in the die's L2 — the cache every member of the cluster shares — once it
+    // is acknowledged (wait_vm0): no write-back.  Readers must not be served a stale line by their OWN CU's L1.  Measured on the device
+    // (profiles/r6_dense_resident.txt): `buffer_inv sc0` does not drop it outside threadgroup-split mode (wrong gradients); `buffer_inv sc1` does,
+    // but it also empties the die's L2 of everything it may not keep across an agent-scope acquire — the precision matrix included (+6 us of
+    // GEMM per round).  So (default) ONE wave of the workgroup issues it, once per round, before the position rows are read; the gradient
+    // rows are never read through the L1 at all: their one reader takes them by agent-scope loads (Machine::ge_ld).  dg_variant & 128
+    // (A/B): every wave invalidates after both waits and the gradient rows are read by plain loads.
+    const bool inv_both = (A.dg_variant & 128) != 0;
+    wait_vm0();          // this wave's position row is on its way to L2
+    __syncthreads();     // ... and so are the rows of the workgroup's other chains
+    const int variant = A.dg_variant;
+    const bool profiling = (variant & 32) && prof != nullptr;
+    long long pc0 = 0, pw0 = 0, pc1 = 0, pc2 = 0;
+    if (profiling) { pc0 = (long long)__builtin_readcyclecounter(); pw0 = wall_clock64(); }
+    if (wib == 0) {
+        if (lane == 0) {
+            __hip_atomic_fetch_add(arrive, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            dg_wait(arrive, want, abort_word);
+        }
+        if (!inv_both) asm volatile("buffer_inv sc1" ::: "memory");
+    }
+    __syncthreads();
+    if (inv_both) asm volatile("buffer_inv sc1" ::: "memory");
+    if (profiling) pc1 = (long long)__builtin_readcyclecounter();
+    // ---- this workgroup's tiles: rows = the cluster's chains, columns = tiles member, member + m, ...
+    const int64_t D = A.dim, KP = A.dg_KP;
+    const int rh = wib >> 1, ch = wib & 1;
+    const bool rows_live = 8 * rh < who_m;   // (a small cluster has no chains in the upper half of its block)
+    if (rows_live) {
+        const int64_t Nt = (D + 63) / 64;
+        const double* xrow[2];
+        int64_t crow[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            int64_t cn = dg_chain_of(who, 32 * rh + 16 * r + (lane & 15));
+            cn = (((32 * rh + 16 * r + (lane & 15)) >> 2) < who_m && cn < n_chains) ? cn : dg_chain_of(who, 0);    // (rows without a chain: a row that exists, never stored)
+            crow[r] = cn;
+            xrow[r] = A.qeval + (size_t)cn * D;
+        }
+        (void)crow;
+        for (int64_t nt = who_member; nt < Nt; nt += who_m) {
+            const int64_t c0 = nt * 64 + 32 * ch;
+            if (c0 >= D) continue;
+            const double* prow[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) prow[c] = A.dg_P + (size_t)(c0 + 16 * c + (lane & 15)) * KP;
+            dg_v4 acc[2][2];
+            dense_block_32x32(xrow, prow, A.dg_mu, D, lane, acc);
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int64_t j = c0 + 16 * c + (lane & 15);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int rr = 32 * rh + 16 * r + (lane >> 4) + 4 * q;
+                        const int64_t cn = dg_chain_of(who, rr);
+                        if ((rr >> 2) < who_m && cn < n_chains && j < D) st1(A.geval, cn * D + j, -acc[r][c][q]);
+                    }
+                }
+        }
+    }
+    wait_vm0();
+    if (profiling) pc2 = (long long)__builtin_readcyclecounter();
+    __syncthreads();
+    if (wib == 0 && lane == 0) {
+        __hip_atomic_fetch_add(done, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        dg_wait(done, want, abort_word);
+    }
+    __syncthreads();
+    if (inv_both) asm volatile("buffer_inv sc1" ::: "memory");
+    if (profiling && lane == 0) {
+        const long long pc3 = (long long)__builtin_readcyclecounter();
+        prof[8] += pc1 - pc0; prof[9] += pc2 - pc1; prof[10] += pc3 - pc2; prof[11] += wall_clock64() - pw0; prof[12] += 1;
+    }
+}
+
 // ----------------------------------------------------------------------------------------
 // the per-chain machine
 // ----------------------------------------------------------------------------------------
@@ -374,6 +534,7 @@ struct Machine {
     // launch-per-evaluation kernels: the end of a draw is cut into slices of a launch each (engine_types.h: PH_DRAW_END / PH_DRAW_BEGIN)
     static constexpr bool SLICED = !INK && NV == 0;
     static constexpr bool DENS = REMOTE && (NPHIP_JIT != 0);   // ... by calling the model's own device function (runtime-compiled density)
+    static constexpr bool DG = REMOTE && (NPHIP_JIT == 0) && TAG == 2;   // ... by the launch-wide GEMM of the dense-precision Gaussian (dg_round)
     LdsDouble dens_lds = nullptr;   // DENS: this wave's LDS scratch for the density
     LdsDouble dens_shared = nullptr;   // DENS: the workgroup's shared LDS (staged by nphip_density_stage at kernel start)
     LdsDouble dens_rows = nullptr;     // DENS: this wave's position row [ld] and gradient row [ld] in LDS (the leaf's evaluations)
@@ -422,6 +583,19 @@ struct Machine {
         }
     }
 
+    // this chain's rows of the dense staging buffers (callback models)
+    __device__ __forceinline__ void qe_st(int64_t i, double2 v) const { st2_dense(A.qeval + (size_t)chain * D, i, D, v); }
+    // (DG: the row was written by other workgroups inside this launch — agent-scope loads, which no L1 serves: dg_round)
+    __device__ __forceinline__ double2 ge_ld(int64_t i) const {
+        const double* row = A.geval + (size_t)chain * D;
+        if (DG && !(A.dg_variant & 128)) {
+            double2 v;
+            v.x = (i < D) ? __hip_atomic_load(row + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+            v.y = (i + 1 < D) ? __hip_atomic_load(row + i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+            return v;
+        }
+        return ld2_dense(row, i, D);
+    }
     __device__ __forceinline__ double* Q(int64_t b) const { return qp + (size_t)b * 2 * ld; }
     __device__ __forceinline__ double* G(int64_t b) const { return qp + (size_t)b * 2 * ld + ld; }
     // vectors per P-slot: (p, rho), and with the low-rank metric (memory-resident kernels only) the velocity v = M^-1 p as well
@@ -567,7 +741,7 @@ struct Machine {
                 if (i + 1 >= D) v.y = 0.0;
             }
             st2(q, i, v);
-            if (!FUSED) st2_dense(A.qeval + (size_t)chain * D, i, D, v);
+            if (!FUSED) qe_st(i, v);
         }
         c->eval_buf = 0;
     }
@@ -794,7 +968,7 @@ struct Machine {
                 qq.x = fma(eps, s1.x * w.x, q2.x);
                 qq.y = fma(eps, s1.y * w.y, q2.y);
                 st2(qn, i, qq);
-                if (!FUSED) st2_dense(A.qeval + (size_t)chain * D, i, D, qq);
+                if (!FUSED) qe_st(i, qq);
             }
             if (FUSED) chain_sync<W>();
             return;
@@ -809,7 +983,7 @@ struct Machine {
                 qq.y = fma(eps, s2.y * ph.y, q2.y);
                 st2(qn, i, qq);
                 st2(pn, i, ph);
-                if (!FUSED) st2_dense(A.qeval + (size_t)chain * D, i, D, qq);
+                if (!FUSED) qe_st(i, qq);
             }
         } else
         chunks(
@@ -822,7 +996,7 @@ struct Machine {
                 qq.y = fma(eps, v.d.y * ph.y, v.a.y);
                 st2(qn, i, qq);
                 st2(pn, i, ph);
-                if (!FUSED) st2_dense(A.qeval + (size_t)chain * D, i, D, qq);
+                if (!FUSED) qe_st(i, qq);
             });
         if (FUSED) chain_sync<W>();  // the fused model reads neighbouring elements of q'
     }
@@ -863,7 +1037,7 @@ struct Machine {
         } else {
             if (REMOTE) remote_eval(lp, code);
             else { lp = A.ueval[chain]; code = A.ecode ? A.ecode[chain] : 0; }
-            NPHIP_FOR_CHUNKS(i) st2(g, i, ld2_dense(A.geval + (size_t)chain * D, i, D));
+            NPHIP_FOR_CHUNKS(i) st2(g, i, ge_ld(i));
         }
     }
 
@@ -942,6 +1116,26 @@ struct Machine {
             return;
         }
 #endif
+        if (DG) {
+            // the position is in this chain's staging row; one round of the launch-wide GEMM later the gradient is in its gradient row.
+            // Ctl::hs_seq counts the rounds this wave has taken part in (every wave takes part in all hs_n of the launch: k_advance)
+            dg_round(A, (int)c->hs_seq, A.n_chains, (NPHIP_LDS int64_t*)c->prof);
+            c->hs_seq = c->hs_seq + 1;
+            // logp = 1/2 (x - mu) . grad in the contract's summation order (nphip_spec.h), as the launch-per-evaluation form computes it
+            const double* xr = A.qeval + (size_t)chain * D;
+            double2 acc = {0.0, 0.0};
+            NPHIP_FOR_CHUNKS(i) {
+                const double2 xv = ld2_dense(xr, i, D), gv = ge_ld(i);
+                const double zx = xv.x - ((i < D) ? ld1(A.dg_mu, i) : 0.0), zy = xv.y - ((i + 1 < D) ? ld1(A.dg_mu, i + 1) : 0.0);
+                acc.x = fma(zx, gv.x, acc.x);
+                acc.y = fma(zy, gv.y, acc.y);
+            }
+            double a_ = acc.x + acc.y, b_ = 0.0;
+            rsum2(a_, b_);
+            lp = 0.5 * a_;
+            code = 0;
+            return;
+        }
         remote_sync();
         lp = A.ueval[chain];
         code = A.ecode ? A.ecode[chain] : 0;
@@ -1202,7 +1396,7 @@ struct Machine {
                 accL.x = fma(z.x, gg.x, accL.x);
                 accL.y = fma(z.y, gg.y, accL.y);
             } else {
-                gg = ld2_dense(A.geval + (size_t)chain * D, i, D);
+                gg = ge_ld(i);
             }
             double2 ph = ld2(pn, i), s2 = ld2(sig2, i), r2 = ld2(rp, i);
             double2 pv, rr;
@@ -1346,7 +1540,7 @@ struct Machine {
                     qq.y = fma(eps, s2[k].y * ph2.y, q2[k].y);
                     st2b(Q(nextq), ob, qq);
                     st2b(P(nextp), ob, ph2);
-                    st2_dense(A.qeval + (size_t)chain * D, i, D, qq);
+                    qe_st(i, qq);
                 }
                 T_.tp[k] = pv; T_.tr[k] = rr;
             }
@@ -2047,9 +2241,8 @@ struct Machine {
                 for (int k = 0; k < NVX; ++k) if (k < nk) *(NPHIP_LDS double2*)(dens_rows + ridx(k)) = X.q[k];
                 remote_eval(lp_remote, code_remote, true);
             } else {
-                double* qe = A.qeval + (size_t)chain * D;
 #pragma unroll
-                for (int k = 0; k < NVX; ++k) if (k < nk) st2_dense(qe, ridx(k), D, X.q[k]);
+                for (int k = 0; k < NVX; ++k) if (k < nk) qe_st(ridx(k), X.q[k]);
                 remote_eval(lp_remote, code_remote);
             }
         } else {
@@ -2065,7 +2258,7 @@ struct Machine {
                 if (ridx(k) >= D) gg.x = 0.0;         // (the density writes grad[0 .. dim) only)
                 if (ridx(k) + 1 >= D) gg.y = 0.0;
             } else if (REMOTE) {
-                gg = ld2_dense(A.geval + (size_t)chain * D, ridx(k), D);
+                gg = ge_ld(ridx(k));
             } else {
                 double2 a, b01;          // b01 = b_{i-1}, b_i ; b2 = b_{i+1}
                 double b2, edge_zl, edge_zr;
@@ -3476,8 +3669,8 @@ struct Machine {
             const int64_t ph = c->phase;
             if (ph == PH_DONE || ph == PH_ERROR || ph == PH_WAIT_HOST) {
                 // a resident launch: the group's rendezvous counts every chain, so a finished one keeps answering the roll
-                if (REMOTE && !DENS) { while (c->hs_last == 0) remote_sync(); }
-                break;
+                if (REMOTE && !DENS && !DG) { while (c->hs_last == 0) remote_sync(); }
+                break;   // (DG: the remaining rounds of the launch are taken as a ghost, in k_advance)
             }
             if (SLICED && (ph == PH_DRAW_END || ph == PH_DRAW_BEGIN)) {
                 // a slice of the end of a draw: a launch's worth of work by itself, and it consumes no evaluation (whatever the
@@ -3492,9 +3685,9 @@ struct Machine {
                 break;
             }
             if (ph != PH_START && ph != PH_RESUME_SS) {   // (those two consume no evaluation)
-                if (REMOTE && !DENS) {
+                if (REMOTE && !DENS && !DG) {
                     if (c->hs_last != 0) break;   // the host asked the launch to end at this boundary
-                } else if (FUSED || DENS) {
+                } else if (FUSED || DENS || DG) {
                     if (budget <= 0) break;
                     --budget;
                 } else {
@@ -3564,9 +3757,9 @@ struct Machine {
 #endif
                 if (rare || (!HOT && c->phase != PH_TREE)) break;   // (leaf_reg leaves the tree only through a rare path)
                 // the next leaf of the run: same admission test as at the top of the outer loop
-                if (REMOTE && !DENS) {
+                if (REMOTE && !DENS && !DG) {
                     if (c->hs_last != 0) { out_of_budget = true; break; }
-                } else if (FUSED || DENS) {
+                } else if (FUSED || DENS || DG) {
                     if (budget <= 0) { out_of_budget = true; break; }
                     --budget;
                 } else {
@@ -3592,7 +3785,8 @@ struct Machine {
 // wave per SIMD (<= 1024 chains) is launched with: 2 / 3 chunks per lane spill 24 / 75 VGPRs under the cap (D = 256 / 384, 1024 chains:
 // 385 -> 424 / 297 -> 378 M leapfrogs/s without it); with 4096 chains the second wave per SIMD is worth more (616 against 437 / 404
 // against 389: profiles/r5_small_kernels_register_cap.txt)
-template <bool FUSED, int W, int NV, bool LEAN = false, bool REMOTE = false, bool LR = false, bool WIDE = false>
+// DENSEG: the resident form of the dense-precision Gaussian (REMOTE with the launch-wide GEMM as the evaluation: Machine<..., DG>, dg_round)
+template <bool FUSED, int W, int NV, bool LEAN = false, bool REMOTE = false, bool LR = false, bool WIDE = false, bool DENSEG = false>
 __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) __attribute__((amdgpu_waves_per_eu(LEAN ? NPHIP_LEAN_OCC(W) : ((NV > 0 && !LR && !WIDE && NV <= (W == 1 ? NPHIP_W1_OCC2_MAX : NPHIP_RW_OCC2_MAX)) ? 2 : ((!FUSED && NV == 0 && !REMOTE) ? NPHIP_CB_OCC(W) : 1)), LEAN ? NPHIP_LEAN_OCC(W) : ((NV > 0 && !LR && !WIDE && NV <= (W == 1 ? NPHIP_W1_OCC2_MAX : NPHIP_RW_OCC2_MAX)) ? 2 : 8)))) void k_advance(const Args* __restrict__ Ap, int max_evals, int have_result, const LaunchSlice sl) {
     const NPHIP_CONST Args& A = *(const NPHIP_CONST Args*)Ap;
     constexpr int WAVES = (W == 1) ? 4 : W;
@@ -3625,7 +3819,10 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) __attribute__((amdgpu_waves_
         __syncthreads();
     }
 #endif
-    if (chain >= (int64_t)sl.chain_lo + sl.chain_n || (W == 1 && wib >= cpb)) return;
+    if (DENSEG) dg_register(A);
+    // (DENSEG: a wave without a chain — the last workgroup's spare waves — still takes part in every round of the launch-wide GEMM)
+    const bool dg_spare = DENSEG && chain >= (int64_t)sl.chain_lo + sl.chain_n;
+    if (!DENSEG && (chain >= (int64_t)sl.chain_lo + sl.chain_n || (W == 1 && wib >= cpb))) return;
     if (REMOTE && !NPHIP_JIT) {
         // Roll call: chains of a resident launch wait for each other inside the kernel, so all of them must be on the device
         // before any starts.  Each arrives once; the last one sets the verdict GO.  A chain that has waited 5 ms sets it to FAIL
@@ -3640,7 +3837,7 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) __attribute__((amdgpu_waves_
             unsigned long long v = __hip_atomic_load(verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if ((v >> 8) == (unsigned long long)sl.seq) {
                 state = (unsigned)(v & 0xff);
-            } else if (atomicAdd(cnt, 1u) + 1u == (unsigned)sl.chain_n) {
+            } else if (!dg_spare && atomicAdd(cnt, 1u) + 1u == (unsigned)sl.chain_n) {
                 atomicExch(cnt, 0u);
                 for (;;) {
                     if (atomicCAS(verdict, v, mine | kRollGo) == v) { state = (unsigned)kRollGo; break; }
@@ -3672,6 +3869,11 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) __attribute__((amdgpu_waves_
         }
         if (state != (unsigned)kRollGo) return;
     }
+    if (DENSEG) dg_enroll(A);
+    if (DENSEG && dg_spare) {
+        for (int r = 0; r < max_evals; ++r) dg_round(A, r, (int64_t)sl.chain_n);
+        return;
+    }
     if (LEAN && threadIdx.x == 0) { s_edge[0] = 0.0; s_edge[2 * W * NV + 1] = 0.0; }   // (the first barrier is in the sigma^2 staging)
     LdsCtl c = (LdsCtl)&s_ctl[wib];
 #ifdef NPHIP_PROFILE
@@ -3689,12 +3891,16 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) __attribute__((amdgpu_waves_
         c->hs_seq = (int64_t)sl.grp_seq[g]; c->hs_last = 0; c->hs_grp = g; c->hs_n = sl.grp_lo[g + 1] - sl.grp_lo[g];
         const int64_t left = (int64_t)sl.chain_n - (int64_t)blockIdx.x * 4;
         c->hs_wgn = (W > 1) ? 1 : (left < 4 ? left : 4);   // chains of this workgroup (W == 1: four; group bounds are multiples of 4)
+        if (DENSEG) { c->hs_seq = 0; c->hs_n = max_evals; }    // rounds of the launch-wide GEMM taken / to take
     }
-    Machine<FUSED, W, NV, LEAN, REMOTE, LR, (WIDE ? 1 : 0)> m(A, c, (LdsDouble)s_red, chain, (LdsDouble)s_par, (LdsDouble)s_ring + ((LEAN || LR) ? 0 : (size_t)wib * 4 * 128 * (NV > 0 ? NV : 1)),
+    Machine<FUSED, W, NV, LEAN, REMOTE, LR, (DENSEG ? 2 : (WIDE ? 1 : 0))> m(A, c, (LdsDouble)s_red, chain, (LdsDouble)s_par, (LdsDouble)s_ring + ((LEAN || LR) ? 0 : (size_t)wib * 4 * 128 * (NV > 0 ? NV : 1)),
                             (LdsDouble)s_edge);
-    __shared__ double s_park[(!FUSED && NV == 0 && W > 1) ? Machine<FUSED, W, NV, LEAN, REMOTE, LR, (WIDE ? 1 : 0)>::kParkMax * W : 2];
+    __shared__ double s_park[(!FUSED && NV == 0 && W > 1) ? Machine<FUSED, W, NV, LEAN, REMOTE, LR, (DENSEG ? 2 : (WIDE ? 1 : 0))>::kParkMax * W : 2];
     m.parked = (LdsDouble)s_park;
     m.run(max_evals, have_result != 0, (LEAN || ((NV == 0 || NV == -1) && W >= 8 && A.sig_lds)) ? (LdsDouble)s_dyn : nullptr, sl.materialise != 0);
+    if (DENSEG) {   // the rounds this chain did not need (it finished, stopped, or its last steps consumed no evaluation): as a ghost
+        while (c->hs_seq < (int64_t)max_evals) { dg_round(A, (int)c->hs_seq, (int64_t)sl.chain_n, (NPHIP_LDS int64_t*)c->prof); c->hs_seq = c->hs_seq + 1; }
+    }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 #ifdef NPHIP_PROFILE
     if (!FUSED && NV == 0) c->prof[15] += (int64_t)__builtin_readcyclecounter() - tk0_;   // callback kernels: the chain's whole launch
@@ -3733,7 +3939,7 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) __attribute__((amdgpu_waves_
 #define NPHIP_PART -1
 #endif
 #define NPHIP_HAS(p) (NPHIP_PART == -1 || NPHIP_PART == (p))
-#if defined(NPHIP_DEV_LEAN) || defined(NPHIP_DEV_W1NV) || defined(NPHIP_DEV_CB_W) || defined(NPHIP_DEV_W1NV_LR) || defined(NPHIP_DEV_RW_LR_W)
+#if defined(NPHIP_DEV_LEAN) || defined(NPHIP_DEV_W1NV) || defined(NPHIP_DEV_CB_W) || defined(NPHIP_DEV_W1NV_LR) || defined(NPHIP_DEV_RW_LR_W) || defined(NPHIP_DEV_DG_NV)
 #define NPHIP_DEV_BUILD 1   // one kernel instantiation only: seconds instead of minutes
 #endif
 
@@ -4136,6 +4342,32 @@ hipError_t launch_remote_wn(const Args* d_args, int W, int nv, hipStream_t st, c
 #undef NPHIP_LAUNCH_REMOTE
 #endif   // part 6
 
+
+#if NPHIP_HAS(11)
+// Resident launch of the dense-precision Gaussian (k_advance<..., REMOTE, DENSEG>): one wave per chain, `nv` chunks of 128 dimensions,
+// every chain of the job on the device at once (<= 1024: one workgroup of four chains per CU) — the launch's roll call makes sure.
+hipError_t launch_dense_resident(const Args* d_args, int nv, int max_evals, hipStream_t st, const LaunchSlice sl) {
+    const dim3 g((unsigned)((sl.chain_n + 3) / 4)), b(256);
+#define NPHIP_LAUNCH_DG(NN) hipLaunchKernelGGL((k_advance<false, 1, NN, false, true, false, false, true>), g, b, 0, st, d_args, max_evals, 0, sl)
+    switch (nv) {
+#ifdef NPHIP_DEV_DG_NV
+        case NPHIP_DEV_DG_NV: NPHIP_LAUNCH_DG(NPHIP_DEV_DG_NV); break;
+#else
+        case 1: NPHIP_LAUNCH_DG(1); break;
+        case 2: NPHIP_LAUNCH_DG(2); break;
+        case 3: NPHIP_LAUNCH_DG(3); break;
+        case 4: NPHIP_LAUNCH_DG(4); break;
+        case 5: NPHIP_LAUNCH_DG(5); break;
+        case 6: NPHIP_LAUNCH_DG(6); break;
+        case 7: NPHIP_LAUNCH_DG(7); break;
+        case 8: NPHIP_LAUNCH_DG(8); break;
+#endif
+        default: return hipErrorInvalidValue;
+    }
+#undef NPHIP_LAUNCH_DG
+    return hipGetLastError();
+}
+#endif   // part 11
 
 #if NPHIP_PART == 7
 // ----------------------------------------------------------------------------------------

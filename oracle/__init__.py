@@ -296,9 +296,20 @@ def dense_grad(x, precision, mu=None, waves=1):
     return g, lp
 
 
-def sample_callback(settings: Settings, dim: int, fn, user=None, init_points=None) -> Trace:
+def _tuned_lib():
+    global _tuned
+    if _tuned is None:
+        if not os.path.exists(_TUNED_PATH):
+            build(force=True)
+        _tuned = C.CDLL(_TUNED_PATH)
+        _tuned.oracle_last_error.restype = C.c_char_p
+    return _tuned
+
+
+def sample_callback(settings: Settings, dim: int, fn, user=None, init_points=None, tuned=False) -> Trace:
     """fn: either a ctypes function pointer (LOGP_FN / raw address) or a Python callable
-    ``f(x: ndarray) -> (logp, grad)`` wrapped here."""
+    ``f(x: ndarray) -> (logp, grad)`` wrapped here.  ``tuned``: the free-order SIMD build (a speed baseline only: its floats
+    are not the contract's)."""
     keep = None
     if callable(fn) and not isinstance(fn, (int, C._CFuncPtr)):
         pyfn = fn
@@ -324,10 +335,11 @@ def sample_callback(settings: Settings, dim: int, fn, user=None, init_points=Non
         ip = np.ascontiguousarray(np.asarray(init_points, dtype=np.float64))
     draws, st, tr = _alloc(settings, dim)
     secs = C.c_double(0)
-    rc = lib().oracle_sample_callback(C.byref(settings), C.c_uint64(dim), fnptr, C.c_void_p(user), _p(ip), C.byref(tr), C.byref(secs))
+    L = _tuned_lib() if tuned else lib()
+    rc = L.oracle_sample_callback(C.byref(settings), C.c_uint64(dim), fnptr, C.c_void_p(user), _p(ip), C.byref(tr), C.byref(secs))
     del keep
     if rc != 0:
-        raise RuntimeError(lib().oracle_last_error().decode())
+        raise RuntimeError(L.oracle_last_error().decode())
     return Trace(draws, st, secs.value)
 
 

@@ -62,15 +62,34 @@ def test_unsymmetric_matrix_is_refused(hip):
         hip.DenseGaussianModel(P)
 
 
-@pytest.mark.parametrize("dim,chains,launch", [(100, 8, {}), (100, 8, {"graph_steps": -1}), (37, 5, {}), (300, 70, {}), (1000, 6, {}),
-                                                (100, 16, {"host_groups": 2})])
-def test_dense_gaussian_bit_identical_to_the_oracle(hip, oracle, dim, chains, launch):
+# launch-per-evaluation form (host_persist = 1: the two kernels behind the engine's device-callback path, with and without the HIP graph, in
+# groups) and the RESIDENT form (default up to 1024 dimensions: the register-resident leaf with the launch-wide GEMM as its evaluation —
+# clusters of workgroups that rendezvous inside the kernel; partial clusters, spare waves, chains that finish early, short launches)
+@pytest.mark.parametrize("dim,chains,launch,mode", [
+    (100, 8, {"host_persist": 1}, "launch-per-evaluation"), (100, 8, {"host_persist": 1, "graph_steps": -1}, "launch-per-evaluation"),
+    (37, 5, {"host_persist": 1}, "launch-per-evaluation"), (300, 70, {"host_persist": 1}, "launch-per-evaluation"),
+    (100, 16, {"host_groups": 2}, "launch-per-evaluation"), (1100, 6, {}, "launch-per-evaluation"),
+    (100, 8, {}, "resident"), (37, 5, {}, "resident"), (100, 1, {}, "resident"), (300, 70, {"evals_per_launch": 7}, "resident"),
+    (1000, 6, {}, "resident"), (129, 1024, {}, "resident"), (257, 301, {"evals_per_launch": 64}, "resident"), (1024, 130, {}, "resident")])
+def test_dense_gaussian_bit_identical_to_the_oracle(hip, oracle, dim, chains, launch, mode):
     """A whole job — warm-up with step-size search and mass-matrix adaptation, then sampling — against oracle.sample_dense."""
     P = dense_precision(dim, seed=5, cond_lo=0.1, cond_hi=10)
     mu = np.linspace(-1, 1, dim)
-    tune, draws = (60, 20) if dim < 1000 else (30, 8)
-    got, W = run_engine(hip, hip.DenseGaussianModel(P, mu), chains=chains, tune=tune, draws=draws, seed=11, launch=launch)
+    tune, draws = (60, 20) if dim < 1000 and chains < 1000 else (30, 8)
+    info = {}
+    got, W = run_engine(hip, hip.DenseGaussianModel(P, mu), chains=chains, tune=tune, draws=draws, seed=11, launch=launch, info=info)
+    assert info["host_mode"] == mode
     want = oracle.sample_dense(oracle_settings(oracle, chains=chains, tune=tune, draws=draws, seed=11, W=W), P, mu)
+    assert_trace_equal(got, want)
+
+
+def test_resident_form_at_the_benchmark_shape(hip, oracle):
+    """BASELINE.json configs[1] as a dense Gaussian: 1000 dimensions x 1024 chains — every CU holds a workgroup, every die two clusters."""
+    P = dense_precision(1000)
+    info = {}
+    got, W = run_engine(hip, hip.DenseGaussianModel(P), chains=1024, tune=4, draws=2, seed=1, info=info)
+    assert info["host_mode"] == "resident" and W == 1
+    want = oracle.sample_dense(oracle_settings(oracle, chains=1024, tune=4, draws=2, seed=1, W=1), P)
     assert_trace_equal(got, want)
 
 
