@@ -26,7 +26,17 @@ def tables(doc):
     return out
 
 
-idx, stan, pymc, stats = tables("index"), tables("stan-usage"), tables("pymc-usage"), tables("sample-stats")
+idx, stan, pymc, stats, nf = tables("index"), tables("stan-usage"), tables("pymc-usage"), tables("sample-stats"), tables("nf-adapt")
+
+
+def nf_adapt_totals():
+    """docs/nf-adapt.qmd:107-122: the printed totals of the run WITHOUT normalizing flows (the second `Number of gradient evaluations` /
+    `Minimum effective sample size` pair of the page; the first is the flow run)"""
+    md = json.load(open(f"{DOCS}/_freeze/nf-adapt/execute-results/html.json"))["result"]["markdown"]
+    pairs = re.findall(r"Number of gradient evaluations: (\d+)\s+Minimum effective sample size: ([\d.]+)", md)
+    assert len(pairs) == 2, pairs
+    return {"with_flow": {"gradient_evaluations": int(pairs[0][0]), "min_ess": float(pairs[0][1])},
+            "diag": {"gradient_evaluations": int(pairs[1][0]), "min_ess": float(pairs[1][1])}}
 
 
 def ess_values():
@@ -39,7 +49,7 @@ def ess_values():
 
 
 fixture = {
-    "_source": "docs/_freeze/{index,stan-usage,pymc-usage}/execute-results/html.json of the reference (progress tables of the executed cells)",
+    "_source": "docs/_freeze/{index,stan-usage,pymc-usage,sample-stats,nf-adapt}/execute-results/html.json of the reference (progress tables of the executed cells)",
     "_settings": "nutpie.sample(compiled): 6 chains, tune 400, draws 1000, every other setting default",
     # mu ~ N(0, 1); obs ~ N(mu, 1), observed [1, 2, 3]   (docs/index.qmd:39-46 through PyMC, :66-91 and docs/stan-usage.qmd:57-84 through Stan)
     "normal_1d": {"posterior": "N(1.5, 1/4)", "runs": [idx[0], idx[1], stan[0]], "cites": ["docs/index.qmd:39-46", "docs/index.qmd:66-91", "docs/stan-usage.qmd:57-84"]},
@@ -54,6 +64,11 @@ fixture = {
     # the default ("diag") adaptation   (docs/sample-stats.qmd:141-157; the frozen output is the SECOND progress table of that page: the page's
     # low_rank cell, :256-268, is not in the frozen results)
     "correlated_102d": {"settings": "tune 1000, draws 1000, adaptation diag (default)", "runs": [stats[1]], "cites": ["docs/sample-stats.qmd:141-157"]},
+    # log_sigma ~ N(0, 1); x[100] ~ N(0, exp(log_sigma / 2)) — 101 dimensions; nutpie.sample(compiled, seed=1): defaults (6 chains, tune 400, draws 1000,
+    # "diag").  The page prints the TOTAL gradient evaluations of the run incl. warm-up and the minimum bulk ESS: the only reference-held number that
+    # integrates the whole warm-up (docs/nf-adapt.qmd:60-78, 115-122; the first progress table of the page is this run, the second the flow run)
+    "funnel_101d": {"settings": "6 chains, tune 400, draws 1000, adaptation diag (default), seed 1", "runs": [nf[0]], "totals": nf_adapt_totals()["diag"],
+                    "cites": ["docs/nf-adapt.qmd:60-78", "docs/nf-adapt.qmd:115-122"]},
 }
 json.dump(fixture, open(OUT, "w"), indent=1)
 print(OUT, {k: [len(r) for r in v["runs"]] for k, v in fixture.items() if not k.startswith("_")})

@@ -277,6 +277,36 @@ def more_densities(seed=0, n=50):
     return m
 
 
+# ---- the models of the reference's frozen documentation whose outputs tests/golden/reference_doc_step_sizes.json holds
+def funnel():
+    """docs/sample-stats.qmd:18-22: log_sigma ~ N(0, 1); x[5] ~ N(0, exp(log_sigma))"""
+    m = S.Model()
+    ls = m.param("log_sigma")
+    x = m.param("x", dim="k", size=5)
+    m.add_logp(S.normal_lpdf(ls, 0.0, 1.0) + S.normal_lpdf(x, 0.0, S.exp(ls)).sum())
+    return m
+
+
+def correlated_102d():
+    """docs/sample-stats.qmd:141-145: x ~ N(0, 1); y ~ N(x, 0.01); z[100] ~ N(y, 1)"""
+    m = S.Model()
+    x, y = m.param("x"), m.param("y")
+    z = m.param("z", dim="k", size=100)
+    m.add_logp(S.normal_lpdf(x, 0.0, 1.0) + S.normal_lpdf(y, x, 0.01) + S.normal_lpdf(z, y, 1.0).sum())
+    return m
+
+
+def funnel_101d():
+    """docs/nf-adapt.qmd:60-64: log_sigma ~ N(0, 1); x[100] ~ N(0, exp(log_sigma / 2))"""
+    m = S.Model()
+    ls = m.param("log_sigma")
+    x = m.param("x", dim="k", size=100)
+    m.add_logp(S.normal_lpdf(ls, 0.0, 1.0) + S.normal_lpdf(x, 0.0, S.exp(0.5 * ls)).sum())
+    return m
+
+
+DOC_MODELS = {"funnel_diag": funnel, "correlated_102d": correlated_102d, "funnel_101d": funnel_101d}
+
 ALL = {"ordinal_regression": ordinal_regression, "more_densities": more_densities, "collinear_regression": collinear_regression, "store_extra": store_extra, "dirichlet_counts": dirichlet_counts, "dims_model": dims_model, "no_prior": no_prior, "uniform_det": uniform_det, "radon": radon, "logistic": logistic, "poisson_offsets": poisson_offsets, "scalar_only": scalar_only, "regression": regression,
        "plain_regression": plain_regression, "eight_schools": eight_schools, "nested": nested}
 

@@ -233,10 +233,10 @@ def test_engine_on_the_funnel_and_the_correlated_model_of_the_reference_docs(hip
     draw and divergences of 1024 chains against the six chains of nuts-rs (the oracle's side: tests/test_oracle_reference_pins.py)."""
     import json
 
-    from scratch.r5_funnel_pin import correlated_102d, funnel
+    from tests.symbolic_models import DOC_MODELS
 
     ref = json.load(open(os.path.join(GOLDEN, "reference_doc_step_sizes.json")))[key]["runs"][0]
-    model = nutpie_amd.compile_pymc_model((funnel if key == "funnel_diag" else correlated_102d)())
+    model = nutpie_amd.compile_pymc_model(DOC_MODELS[key]())
     tr = nutpie_amd.sample(model, chains=1024, tune=1000, draws=400, seed=42, progress_bar=False)
     st = tr.sample_stats
     step, g, div = st.step_size.values[:, -1], st.n_steps.values.ravel(), st.diverging.values.sum(1) * (1000 / 400)
@@ -249,3 +249,37 @@ def test_engine_on_the_funnel_and_the_correlated_model_of_the_reference_docs(hip
         assert abs(r_last.mean() - g.mean()) / (g.std() / np.sqrt(len(r_last))) < 3.0 and div.sum() == 0
     else:
         assert np.all(r_div <= np.percentile(div, 99.5)) and stats.mannwhitneyu(r_div, div).pvalue > 0.01
+
+
+def test_engine_total_gradient_evaluations_of_the_101_dimensional_funnel(hip):
+    """docs/nf-adapt.qmd:60-78, 115-122: the 101-dimensional funnel under the default adaptation, seed 1 — nuts-rs took 124 219 gradient evaluations
+    for 6 chains x (400 + 1000) draws, warm-up INCLUDED (tests/golden/reference_doc_step_sizes.json: "funnel_101d"; the oracle's side with the details:
+    tests/test_oracle_reference_pins.py).  The model written with the front-end, 1020 chains = 170 runs of the reference's shape on the resident
+    kernel of its generated density: the reference's total, step sizes and minimum ESS inside the engine's ensemble."""
+    import json
+
+    from nutpie_amd.ess import ess_bulk_all
+    from tests.symbolic_models import DOC_MODELS
+
+    ref = json.load(open(os.path.join(GOLDEN, "reference_doc_step_sizes.json")))["funnel_101d"]
+    model = nutpie_amd.compile_pymc_model(DOC_MODELS["funnel_101d"]())
+    R = 170
+    tr = nutpie_amd.sample(model, chains=6 * R, tune=400, draws=1000, seed=1, progress_bar=False)
+    per_chain = (tr.sample_stats.n_steps.values.sum(1) + tr.warmup_sample_stats.n_steps.values.sum(1)).astype(np.float64)
+    runs = per_chain.reshape(R, 6).sum(1)
+    r_total = ref["totals"]["gradient_evaluations"]
+    rank_total = float(np.mean(runs < r_total))
+    z_total = (r_total / 6 - per_chain.mean()) / (per_chain.std() / np.sqrt(6))
+    step = tr.sample_stats.step_size.values[:, -1]
+    r_step = np.array([row["step_size"] for row in ref["runs"][0]])
+    z_step = (r_step.mean() - step.mean()) / (step.std() / np.sqrt(6))
+    x = np.concatenate([tr.posterior["log_sigma"].values[..., None], tr.posterior["x"].values], axis=2)
+    ess = np.array([np.nanmin(ess_bulk_all(x[6 * r:6 * r + 6], block=101)) for r in range(R)])
+    rank_ess = float(np.mean(ess < ref["totals"]["min_ess"]))
+    print(f"101-d funnel on the engine: gradient evaluations per run {runs.mean():.0f} +- {runs.std():.0f}, reference {r_total} (rank {rank_total:.3f}, z = {z_total:+.2f}); "
+          f"step {step.mean():.3f} +- {step.std():.3f}, reference {r_step.mean():.3f} (z = {z_step:+.2f}); min ESS per run pct 5/50/95 {np.percentile(ess, [5, 50, 95]).round(1)}, "
+          f"reference {ref['totals']['min_ess']:.1f} (rank {rank_ess:.2f})")
+    assert 0.005 <= rank_total <= 0.995 and abs(z_total) < 3.0
+    assert abs(z_step) < 3.0
+    assert 0.02 <= rank_ess <= 0.98
+    assert tr.sample_stats.diverging.values.sum(1).mean() < 1.0

@@ -167,3 +167,46 @@ def test_effective_sample_size_of_the_reference_docs(oracle):
     print(f"bulk ESS of 6000 draws: reference {ref['intercept']:.0f} / {ref['slope']:.0f}, this sampler {ours.mean(0).round(0)} +- {ours.std(0).round(0)}, ranks {ranks}")
     assert all(0.005 <= r <= 0.995 for r in ranks)
     assert abs(ours[:, 0].mean() / ref["intercept"] - 1.0) < 0.25
+
+
+def test_total_gradient_evaluations_of_the_101_dimensional_funnel(oracle):
+    """docs/nf-adapt.qmd:60-78, 115-122 (frozen output): log_sigma ~ N(0, 1), x[100] ~ N(0, exp(log_sigma / 2)); ``nutpie.sample(compiled, seed=1)``
+    under the default adaptation — 6 chains x (400 + 1000) draws of nuts-rs took **124 219 gradient evaluations in total, warm-up included**, reached a
+    minimum bulk ESS of 31.46, final step sizes 0.28 .. 0.45, no divergence.  Every other reference-held number sees only the END of the warm-up (the
+    final step size, the last draw); this one integrates its COST: the early windows, the step-size searches, the trees hitting maxdepth while the
+    metric is still poor.  30 runs of the reference's shape (180 chains): the reference's total, mean step and minimum ESS must lie inside them."""
+    import subprocess
+
+    from nutpie_amd.ess import ess_bulk_all
+
+    src, out = os.path.join(FIXTURES, "funnel.c"), os.path.join(FIXTURES, "libfunnel.so")
+    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        subprocess.run(["gcc", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-o", out, src, "-lm"], check=True)
+    fix = ctypes.CDLL(out)
+    ref = DOC["funnel_101d"]
+    R = 30
+    n = 6 * R
+    s = oracle.default_settings(seed=1, num_chains=n, num_tune=400, num_draws=1000, n_threads=8, init_kind=2)
+    pts = np.random.default_rng(7).uniform(-1, 1, size=(n, 101))                      # PyMC: support point 0 + U(-1, 1)
+    tr = oracle.sample_callback(s, 101, ctypes.cast(fix.funnel_101d_logp, ctypes.c_void_p).value, init_points=pts)
+    per_chain = tr.stats["n_steps"].sum(1).astype(np.float64)                          # warm-up + sampling, as the page sums them
+    r_total = ref["totals"]["gradient_evaluations"]
+    boot = per_chain[np.random.default_rng(0).integers(0, n, size=(4000, 6))].sum(1)   # runs of six chains drawn from the 180
+    rank_total = float(np.mean(boot < r_total))
+    z_total = (r_total / 6 - per_chain.mean()) / (per_chain.std() / np.sqrt(6))
+    step = tr.stats["step_size"][:, -1]
+    r_step = np.array([row["step_size"] for row in ref["runs"][0]])
+    z_step = (r_step.mean() - step.mean()) / (step.std() / np.sqrt(6))
+    ess = np.array([np.nanmin(ess_bulk_all(tr.draws[6 * r:6 * r + 6, 400:, :], block=101)) for r in range(R)])
+    rank_ess = float(np.mean(ess < ref["totals"]["min_ess"]))
+    print(f"101-d funnel: gradient evaluations per run, oracle {6 * per_chain.mean():.0f} +- {boot.std():.0f}, reference {r_total} (rank {rank_total:.3f}, z = {z_total:+.2f}); "
+          f"warm-up share {tr.stats['n_steps'][:, :400].sum() / per_chain.sum():.2f}; step {step.mean():.3f} +- {step.std():.3f}, reference {r_step.mean():.3f} (z = {z_step:+.2f}); "
+          f"min ESS per run pct 5/50/95 {np.percentile(ess, [5, 50, 95]).round(1)}, reference {ref['totals']['min_ess']:.1f} (rank {rank_ess:.2f})")
+    assert 0.005 <= rank_total <= 0.995 and abs(z_total) < 3.0
+    assert abs(z_step) < 3.0
+    lo, hi = np.percentile(step, [0.5, 99.5])
+    assert np.all((r_step > lo - 0.005) & (r_step < hi + 0.005))
+    assert 0.02 <= rank_ess <= 0.98
+    r_last = np.array([row["gradients_last_draw"] for row in ref["runs"][0]])
+    assert set(r_last.tolist()) <= set(np.unique(tr.stats["n_steps"][:, 400:]).tolist())
+    assert tr.stats["diverging"][:, 400:].sum(1).mean() < 1.0                          # (the reference's six chains: none)
