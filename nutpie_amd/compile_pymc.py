@@ -80,11 +80,26 @@ def compile_pymc_model(model, *, backend="numba", gradient_backend="pytensor", i
     model front-end — is compiled to its generated device density, with the reference's initial points (support point + U(-1, 1)
     jitter; ``initial_points`` a dict of per-variable values, or explicit start positions ``[chains, n_dim]``).  A callable is taken
     as a batched torch log-density ``logp(x[chains, n_dim]) -> [chains]`` (``n_dim=`` required) and goes through the tracer
-    (:mod:`nutpie_amd.torch_trace`).  A PyMC model needs PyMC and PyTensor, which the target image does not have."""
+    (:mod:`nutpie_amd.torch_trace`).  A PyMC model needs PyMC and PyTensor, which the target image does not have.
+
+    ``var_names`` as the reference (compile_pymc.py:821-822): ``None`` stores every computed variable, ``[]`` none, a list only those named;
+    the free variables are always stored.  ``freeze_model`` (compile_pymc.py:587-592: data and dimension lengths become constants of the
+    compiled function): ``None`` / ``True`` = the front-end's default (data lengths are constants of the generated source; ``with_data``
+    compiles again when one changes), ``False`` = one library for data of any length.  Keyword arguments the engine does not know are an
+    error, not dropped."""
     from nutpie_amd import symbolic
 
+    if backend not in ("numba", "jax", "hip"):
+        raise ValueError(f"backend={backend!r}: the reference knows 'numba' and 'jax' (both name the engine here), this package also 'hip'")
     if isinstance(model, symbolic.Model):
-        extra = {k: kwargs[k] for k in ("resident", "waves_per_chain", "coords", "dims") if k in kwargs}
+        known = ("resident", "waves_per_chain", "coords", "dims")
+        unknown = sorted(set(kwargs) - set(known))
+        if unknown:
+            raise TypeError(f"compile_pymc_model() got unexpected keyword arguments {unknown} (the front-end takes {list(known)})")
+        extra = {k: kwargs[k] for k in known if k in kwargs}
+        extra["var_names"] = var_names
+        if freeze_model is not None:
+            extra["specialize"] = bool(freeze_model)
         # the reference's initial points (compile_pymc.py:593-602): support point + U(-1, 1) jitter on `jitter_rvs` (default: every
         # free variable); `initial_points` = {variable: constrained value} overrides a support point.  An array [chains, n_dim]
         # is taken as explicit start positions; default_initialization_strategy="prior" has no counterpart (the front-end does not
@@ -106,6 +121,25 @@ def compile_pymc_model(model, *, backend="numba", gradient_backend="pytensor", i
         from nutpie_amd.density import JitteredInit
 
         n_dim = int(kwargs.pop("n_dim"))
+        if freeze_model is False:
+            raise ValueError("freeze_model=False has no meaning for a traced torch log-density: the trace holds the data's shapes as constants")
+        if var_names is not None:
+            # a traced density reports what its expand function returns (default: the free vector `x`, which is always stored)
+            names = kwargs.get("expanded_names")
+            wanted = {getattr(v, "name", v) for v in var_names}
+            if names is None:
+                if wanted - {"x"}:
+                    raise KeyError(f"var_names: the model reports no variable named {sorted(wanted - {'x'})}")
+            else:
+                unknown = wanted - set(names)
+                if unknown:
+                    raise KeyError(f"var_names: the model reports no variable named {sorted(unknown)}")
+                keep = [i for i, n_ in enumerate(names) if n_ in wanted]
+                user_expand = kwargs["expand_fn"]
+                kept_names = [names[i] for i in keep]
+                kwargs["expanded_names"] = kept_names
+                kwargs["expanded_shapes"] = [kwargs["expanded_shapes"][i] for i in keep]
+                kwargs["expand_fn"] = lambda x, **kw_: {k: v for k, v in user_expand(x, **kw_).items() if k in kept_names}
         if initial_points is None or (isinstance(initial_points, np.ndarray) and initial_points.ndim == 1):
             center = np.zeros(n_dim) if initial_points is None else np.asarray(initial_points, dtype=np.float64)
             init = JitteredInit(center=center, jitter=np.ones(n_dim) if jitter_rvs is None else np.asarray(jitter_rvs, dtype=np.float64))

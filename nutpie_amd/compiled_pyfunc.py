@@ -422,12 +422,15 @@ def from_torch_density(ndim: int, density_fn: Callable, *, compile: Any = "auto"
         try:
             return traced_model(ndim, density_fn, batched=batched, waves_per_chain=waves_per_chain,
                                 **{k: v for k, v in kwargs.items() if k not in ("use_graph", "expand_device_fn")})
-        except UnsupportedTorchOp as e:
+        except (UnsupportedTorchOp, NotImplementedError, ValueError, RuntimeError) as e:
+            # "auto": whatever keeps the function from becoming a resident kernel — an operation the tracer cannot map, a derivative the IR
+            # does not have, dimensions the front-end cannot join, a library that does not compile or fit the LDS — leaves the eager path,
+            # which runs any differentiable torch function.  compile=True reports it instead.
             if compile is True:
                 raise
             import warnings
 
-            warnings.warn(f"the torch log-density is evaluated eagerly (one launch per operation): {e}", UserWarning, stacklevel=2)
+            warnings.warn(f"the torch log-density is evaluated eagerly (one launch per operation): {type(e).__name__}: {e}", UserWarning, stacklevel=2)
     if not batched:
         raise ValueError("batched=False needs the compiled path")
 

@@ -439,6 +439,14 @@ class DensitySourceModel(CompiledModel):
             raise RuntimeError("a device density needs a GPU: the nutpie-hip engine has no CPU fallback")
         device = int(engine_kw.get("device", 0) or 0)
         model = self._make_model(settings=settings, device=device)
+        if int(engine_kw.get("host_groups", 0) or 0) >= 2 and (callable(self._scratch) or self._scratch):
+            # groups of chains run their (kernel, callback) pairs CONCURRENTLY on streams of their own, and the batched form of a density counts
+            # its scratch slots (NPHIP_CHAIN_SLOT) from 0 in every launch: two groups would share the blocks of data.scratch__ — a data race.
+            # A model that spills scratch to device memory runs ungrouped.
+            import warnings
+
+            warnings.warn("host_groups is ignored for a density with device-memory scratch (concurrent groups would share its scratch blocks)", UserWarning, stacklevel=3)
+            engine_kw = {**engine_kw, "host_groups": 0}
         if not engine_kw.get("waves_per_chain") and (self._waves > 1 or self._n_dim <= 1024):
             # the batched form runs the engine with as many waves per chain as the resident kernel has: a chain's sums are taken
             # in the same order either way, so both forms of one library draw identically

@@ -34,12 +34,17 @@ def device_tensor(ptr: int, shape, dtype="float64", device=0):
     return torch.as_tensor(_Arr(), device=torch.device("cuda", device))
 
 
-def gather_arrays(local: dict, n_local: int, group=None, dst: int = 0):
+def gather_arrays(local: dict, n_local: int, group=None, dst: int = 0, stats: dict | None = None):
     """Gather per-rank arrays whose leading axis is the local chain axis.
 
     ``local``: name -> torch.Tensor (CPU for gloo, GPU for nccl/RCCL) or numpy array, leading dim
-    ``n_local``.  Returns name -> concatenated tensor (global chain order) on ``dst``, None elsewhere.
-    """
+    ``n_local``.  Returns name -> tensor of all chains (global chain order) on ``dst``, None elsewhere.
+
+    The root receives every array into ONE pre-allocated buffer ``[world * nmax, ...]`` — the receive list handed to ``gather`` are
+    views of it — and returns (a view of) that buffer: root memory is 1 x the payload, not ``world`` receive buffers plus their
+    concatenation (config 5 at 8 ranks: 12 GB of thinned draws instead of 24).  Ragged shards (``num_chains`` not a multiple of
+    the world size) are padded to ``nmax`` rows for the collective and closed up in place.  ``stats`` (optional dict) receives
+    ``root_bytes_allocated`` and ``payload_bytes`` on the root."""
     import torch
     import torch.distributed as dist
 
@@ -48,7 +53,9 @@ def gather_arrays(local: dict, n_local: int, group=None, dst: int = 0):
     counts = [None] * world
     dist.all_gather_object(counts, int(n_local), group=group)
     nmax = max(counts)
+    total = int(sum(counts))
     out = {} if rank == dst else None
+    allocated = payload = 0
     for name in sorted(local):
         t = local[name]
         if isinstance(t, np.ndarray):
@@ -57,10 +64,22 @@ def gather_arrays(local: dict, n_local: int, group=None, dst: int = 0):
         if t.shape[0] != nmax:  # pad ragged shards so every rank sends the same shape
             pad = torch.zeros((nmax - t.shape[0], *t.shape[1:]), dtype=t.dtype, device=t.device)
             t = torch.cat([t, pad], 0)
-        bufs = [torch.empty_like(t) for _ in range(world)] if rank == dst else None
-        dist.gather(t, bufs, dst=dst, group=group)
         if rank == dst:
-            out[name] = torch.cat([b[: counts[r]] for r, b in enumerate(bufs)], 0)
+            big = torch.empty((world * nmax, *t.shape[1:]), dtype=t.dtype, device=t.device)
+            allocated += big.numel() * big.element_size()
+            dist.gather(t, [big[r * nmax:(r + 1) * nmax] for r in range(world)], dst=dst, group=group)
+            if total != world * nmax:   # close the gaps the padding left (shards move towards the front: never over unread rows)
+                at = 0
+                for r, cnt in enumerate(counts):
+                    if at != r * nmax and cnt:
+                        big[at:at + cnt] = big[r * nmax:r * nmax + cnt].clone()
+                    at += cnt
+            out[name] = big[:total]
+            payload += total * (big[0].numel() if big.shape[0] else 0) * big.element_size()
+        else:
+            dist.gather(t, None, dst=dst, group=group)
+    if stats is not None and rank == dst:
+        stats["root_bytes_allocated"], stats["payload_bytes"] = int(allocated), int(payload)
     return out
 
 
@@ -158,7 +177,7 @@ def gather_trace(sampler, n_local: int, num_chains: int, *, group=None, thin: in
         dist.barrier(group=group)
         sync()
         t0 = time.perf_counter()
-    gathered = gather_arrays(local, n_local, group=group)
+    gathered = gather_arrays(local, n_local, group=group, stats=timing)
     if timing is not None:
         sync()
         timing["gather_s"] = time.perf_counter() - t0

@@ -1809,11 +1809,16 @@ class Model:
                 gen.spilled.append(key)
 
     def compile(self, *, init="uniform", resident: bool = True, coords=None, dims=None, waves_per_chain: int | None = None,
-                expanded_names=None, expanded_shapes=None, expand_fn=None, specialize: bool = True):
+                expanded_names=None, expanded_shapes=None, expand_fn=None, specialize: bool = True, var_names=None):
         """-> :class:`SymbolicModel` (a :class:`nutpie_amd.density.DensitySourceModel`).  ``waves_per_chain`` (1, 2, 4): wavefronts
         that evaluate one chain's density together — more than one pays with fewer chains than the device has SIMDs (1024), and a
         workgroup then holds ONE chain instead of four, i.e. a quarter of the per-chain LDS: the default (None) is one wave per
-        chain unless the model's scratch (one double per observation and gathered value) only fits with more."""
+        chain unless the model's scratch (one double per observation and gathered value) only fits with more.
+
+        ``var_names`` (reference ``compile_pymc.py:821-822``, ``tests/test_pymc.py:425-468``): which of the variables that are COMPUTED from a
+        draw go to the trace — the deterministics and the constrained values of transformed parameters.  ``None``: all of them; ``[]``: none;
+        ``["b"]``: only ``b``.  The free variables themselves (untransformed parameters under their own name, transformed ones under their
+        unconstrained name) are always stored, as in the reference; a name that the model does not report is an error."""
         from nutpie_amd.density import from_density_source
         import copy
 
@@ -1825,7 +1830,15 @@ class Model:
         # or a few seconds of hipcc — when one of them changes); False: one library for data of any length
         self._specialize = bool(specialize)
         self._compile_kw = dict(init=init, resident=resident, coords=coords, dims=dims, waves_per_chain=waves_per_chain, expanded_names=expanded_names,
-                                expanded_shapes=expanded_shapes, expand_fn=expand_fn, specialize=specialize)
+                                expanded_shapes=expanded_shapes, expand_fn=expand_fn, specialize=specialize, var_names=var_names)
+        if var_names is not None:
+            wanted = {getattr(v, "name", v) for v in var_names}
+            unknown = wanted - {n for n, _ in self._det}
+            if unknown:
+                raise KeyError(f"var_names: the model reports no variable named {sorted(unknown)}")
+            transformed = {p for p, (u, _, _) in self._unconstrained.items() if u != p}
+            free = set(self._param_names) - transformed          # (reported under their own name: the free variables of the reference's trace)
+            self._det = [(n, e) for n, e in self._det if n in wanted or n in free]
         logp = self.logp_expr()
         grads = gradient(logp, self._params)
         self._staged = 8 * self._shared_doubles_unconditional(self._data) <= self.STAGE_LIMIT

@@ -501,7 +501,8 @@ def _pow_const(e: Expr, c: float) -> Expr:
         return S.sqrt(e)
     if c == -0.5:
         return 1.0 / S.sqrt(e)
-    if c == float(int(c)) and abs(c) <= 16:
+    if c == float(int(c)) and abs(c) <= 2 ** 20:
+        # every integer exponent by repeated squaring: exp(c log x) is NaN for a negative base, where torch (and the mathematics) has a value
         k = int(abs(c))
         result, base = None, e
         while k:
@@ -511,7 +512,32 @@ def _pow_const(e: Expr, c: float) -> Expr:
             if k:
                 base = base * base
         return result if c > 0 else 1.0 / result
-    return S.exp(c * S.log(e))      # (a positive base: a negative one has no real non-integer power)
+    return S.exp(c * S.log(e))      # (a non-integer power: a negative base has none — NaN here as in torch)
+
+
+def _provably_positive(e: Expr) -> bool:
+    """conservative: exp(.), positive constants, and sums / products / quotients / square roots of such"""
+    op = getattr(e, "op", None)
+    if op == "const":
+        try:
+            return float(e.payload) > 0.0
+        except Exception:
+            return False
+    if op == "exp":
+        return True
+    if op in ("add", "mul", "div"):
+        return all(_provably_positive(a) for a in e.args)
+    if op == "sqrt":
+        return _provably_positive(e.args[0])
+    return False
+
+
+def _pow_traced(x: Expr, y: Expr) -> Expr:
+    # x ** y with a traced exponent is exp(y log x): right for a positive base only (torch has values for negative bases with integer-valued
+    # exponents, which cannot be told at trace time) — anything else is left to the eager path
+    if not _provably_positive(x):
+        raise UnsupportedTorchOp("pow with a traced exponent needs a base that is positive by construction (exp(.), a positive constant, sums / products of such)")
+    return S.exp(y * S.log(x))
 
 
 def _scalar(v) -> float:
@@ -690,7 +716,7 @@ def _run(gm, it: _Interp, x_shape, data_values: dict[str, Any]):
                     raise UnsupportedTorchOp("a non-positive constant to a traced power")
                 env[node] = U(args[1], lambda y: S.exp(math.log(c) * y))
             else:
-                env[node] = B(args[0], args[1], lambda x, y: S.exp(y * S.log(x)))
+                env[node] = B(args[0], args[1], _pow_traced)
         elif base in ("sqrt", "exp", "log", "log1p", "sigmoid", "tanh", "expm1", "erf", "erfc", "sin", "cos", "atan", "lgamma", "digamma", "sign"):
             env[node] = U(a0, lambda x: S._unary(base, x))
         elif base == "abs":
@@ -1141,7 +1167,12 @@ def traced_model(ndim: int, density_fn: Callable, *, batched: bool = True, share
         kw = dict(init=init, coords=coords, dims=dims, waves_per_chain=waves_per_chain, resident=resident)
         if expand_fn is not None:
             kw.update(expand_fn=user_expand, expanded_names=list(expanded_names), expanded_shapes=[tuple(s_) for s_ in expanded_shapes])
-        base = tr.compile(**kw)
+        try:
+            base = tr.compile(**kw)
+        except UnsupportedTorchOp:
+            raise
+        except NotImplementedError as e:   # (e.g. symbolic.gradient: an operation whose derivative the IR does not have)
+            raise UnsupportedTorchOp(str(e)) from e
         cls = _traced_model_class()
         fields = {f.name: getattr(base, f.name) for f in dataclasses.fields(base)}
         if reparameterized_names is not None:

@@ -144,3 +144,20 @@ def test_world_size_must_agree_with_gpus():
     r, out, _ = _run_bench("--gpus", "2", "--engine-stub", STUB, env_extra={"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0",
                                                                           "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29999"})
     assert r.returncode != 0 and "must agree" in (r.stderr + r.stdout)
+
+
+def test_eight_ranks_through_the_spawn_path_with_config5s_layout_scaled_down():
+    """`bench.py --gpus 8` through its own spawn path (eight gloo ranks, stand-in engine): config 5's layout — every rank owns
+    a contiguous block of chains of a long row — scaled down; ONE gather per array into ONE buffer on the root (root memory = 1 x payload),
+    chains in global order, the line says collective_ranks 8, and only rank 0 prints."""
+    r, out, lines = _run_bench("--gpus", "8", "--engine-stub", STUB, "--chains", "6", "--dim", "16", "--config5-dim", "200",
+                               "--steps", "2", "--warmup", "1", "--config5-launches", "2", timeout=480)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(lines) == 1 and out["n_gpus"] == 8
+    ranks = out["ranks"]
+    assert ranks["world"] == 8 and ranks["collective_ranks"] == 8 and [p["rank"] for p in ranks["per_rank"]] == list(range(8))
+    g = out["config5_shard"]["gather"]
+    assert g["collective_ranks"] == 8 and g["check"]["chains_gathered"] == 48 and g["check"]["moments_shape"] == [48, 200]
+    assert g["bytes_gathered"] == 8 * g["bytes_local"]
+    assert g["root_bytes_allocated"] == g["payload_bytes"] == g["bytes_gathered"]          # one receive buffer, no concatenated copy
+    assert "cpu_baseline" not in out["config5_shard"] and "other_configs" not in out       # CPU legs: N = 1 only

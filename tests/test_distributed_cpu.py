@@ -132,3 +132,36 @@ def test_eight_rank_layout_of_config_5(tmp_path):
     assert np.array_equal(got["draws"], full.draws[:, ::2])
     assert np.array_equal(got["n_steps"], full.stats["n_steps"]) and np.array_equal(got["diverging"], full.stats["diverging"])
     assert got["total"][0] == full.stats["n_steps"].sum()
+
+
+def _ragged_gather_worker(rank, world, port, out_path):
+    import torch
+    import torch.distributed as dist
+
+    from nutpie_amd.distributed import gather_arrays, shard_chains
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    total = 11                                            # 11 chains over 3 ranks: 4 + 4 + 3 (ragged: padded for the collective, closed up on the root)
+    off, n = shard_chains(total, world, rank)
+    local = {"a": torch.arange(off, off + n, dtype=torch.float64)[:, None].repeat(1, 5), "b": torch.arange(off, off + n, dtype=torch.int64)}
+    stats = {}
+    g = gather_arrays(local, n, stats=stats)
+    if rank == 0:
+        ok = bool((g["a"][:, 0] == torch.arange(total, dtype=torch.float64)).all() and (g["b"] == torch.arange(total)).all() and g["a"].shape == (total, 5))
+        nmax = 4
+        ok = ok and stats["root_bytes_allocated"] == world * nmax * (5 * 8 + 8) and stats["payload_bytes"] == total * (5 * 8 + 8)
+        open(out_path, "w").write("ok" if ok else f"bad {g} {stats}")
+    dist.destroy_process_group()
+
+
+def test_gather_into_one_buffer_handles_ragged_shards(tmp_path):
+    import socket
+
+    import torch.multiprocessing as mp
+
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    out = str(tmp_path / "r.txt")
+    mp.spawn(_ragged_gather_worker, args=(3, port, out), nprocs=3, join=True)
+    assert open(out).read() == "ok"

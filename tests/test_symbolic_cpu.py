@@ -449,3 +449,35 @@ def test_ordered_transform_and_an_ordinal_regression():
     os.remove(path)
     with pytest.raises(ValueError, match="ordered excludes"):
         S.Model().param("c", dim="k", size=3, ordered=True, lower=0.0)
+
+
+def test_var_names_filter_the_computed_variables_as_the_reference_does():
+    """tests/test_pymc.py:425-468 of the reference: var_names=None stores the deterministics b and c, [] neither, ["b"] only b — the free variables
+    always (a transformed parameter's free variable is its unconstrained value)."""
+    import nutpie_amd
+
+    def make():
+        m = S.Model()
+        a = m.param("a", dim="k", size=3)
+        sd = m.param("sd", lower=0.0)
+        m.add_logp(S.normal_lpdf(a, -0.1, 1.0).sum() + S.normal_lpdf(sd, 0.0, 1.0))
+        b = -0.1 * a
+        m.deterministic("b", b)
+        m.deterministic("c", -0.1 * b)
+        return m
+
+    names = lambda **kw: list(nutpie_amd.compile_pymc_model(make(), **kw).shapes)  # noqa: E731
+    assert names(var_names=None) == ["a", "sd", "b", "c", "sd_log__"]
+    assert names(var_names=[]) == ["a", "sd_log__"]
+    assert names(var_names=["b"]) == ["a", "b", "sd_log__"]
+    assert names(var_names=["sd", "c"]) == ["a", "sd", "c", "sd_log__"]
+    with pytest.raises(KeyError, match="zz"):
+        names(var_names=["zz"])
+    with pytest.raises(TypeError, match="bogus"):
+        nutpie_amd.compile_pymc_model(make(), bogus=1)
+    # freeze_model (compile_pymc.py:587-592) = whether the data's lengths are constants of the generated source
+    assert "sd_log__" in names(freeze_model=False) and "sd_log__" in names(freeze_model=True)
+    # the filtered expand step evaluates
+    cm = nutpie_amd.compile_pymc_model(make(), var_names=["b"])
+    out = cm._expand_func(np.zeros((2, 4)))
+    assert set(out) == {"a", "b", "sd_log__"} and out["b"].shape == (2, 3)

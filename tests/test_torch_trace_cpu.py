@@ -140,3 +140,67 @@ def test_an_indexed_assignment_with_repeated_indices_is_refused():
 
     with pytest.raises(UnsupportedTorchOp, match="repeated indices"):
         trace(logp, 3, batched=False)
+
+
+def test_integer_powers_of_negative_bases_have_their_values():
+    """x ** 20 (and x ** -3, x ** 17) at negative x: repeated squaring, not exp(c log x) — which is NaN there, silently turning the sign of a
+    coordinate into a region of rejections."""
+    def logp(x):
+        return -(x[:, 0] ** 20) - 0.1 * x[:, 1] ** 17 + 0.01 * (2.0 + x[:, 2] * x[:, 2]) ** -3 - 0.5 * (x * x).sum(-1)
+
+    cm = trace(logp, 3).compile()
+    x = np.array([[-0.9, -1.1, -0.3], [0.7, 0.5, 2.0], [-1.05, 1.2, -2.0]])
+    lp, g = cm.logp_and_grad_numpy(x)
+    lp0, g0 = TM.autograd(logp, x, True, {})
+    assert np.isfinite(lp).all() and np.isfinite(g).all()
+    np.testing.assert_allclose(lp, lp0, rtol=1e-12)
+    np.testing.assert_allclose(g, g0, rtol=1e-11)
+
+
+def test_a_traced_exponent_needs_a_base_that_is_positive_by_construction():
+    def ok(x):
+        return (torch.exp(x[:, 0]) ** x[:, 1]) * 0.1 - 0.5 * (x * x).sum(-1)
+
+    x = np.random.default_rng(2).normal(size=(5, 2))
+    lp, g = trace(ok, 2).compile().logp_and_grad_numpy(x)
+    lp0, g0 = TM.autograd(ok, x, True, {})
+    np.testing.assert_allclose(lp, lp0, rtol=1e-12)
+    np.testing.assert_allclose(g, g0, rtol=1e-11, atol=1e-13)
+
+    def bad(x):
+        return (x[:, 0] ** x[:, 1]) - 0.5 * (x * x).sum(-1)
+
+    with pytest.raises(UnsupportedTorchOp, match="positive by construction"):
+        trace(bad, 2)
+
+
+def test_auto_falls_back_when_the_gradient_has_no_counterpart():
+    """compile="auto": a function that traces but whose derivative the IR does not have (digamma -> trigamma) takes the eager path with a
+    warning, as the docstring says; compile=True names the reason."""
+    def logp(x):
+        return torch.digamma(torch.exp(x)).sum(-1) - 0.5 * (x * x).sum(-1)
+
+    with pytest.raises((UnsupportedTorchOp, NotImplementedError)):
+        nutpie_amd.from_torch_density(5, logp, compile=True)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        m = nutpie_amd.from_torch_density(5, logp)          # "auto"
+    assert any("eagerly" in str(x.message) for x in w)
+    assert m.n_dim == 5 and not hasattr(m, "library_path")   # the batched-callback model of from_torchfunc
+
+
+def test_var_names_of_a_traced_model_filter_the_expand_functions_variables():
+    def logp(x):
+        return -0.5 * (x * x).sum(-1)
+
+    def expand(x):
+        return {"x": x, "y": np.exp(x[:, :1])}
+
+    kw = dict(n_dim=3, expand_fn=expand, expanded_names=["x", "y"], expanded_shapes=[(3,), (1,)])
+    assert list(nutpie_amd.compile_pymc_model(logp, **kw).shapes) == ["x", "y"]
+    m = nutpie_amd.compile_pymc_model(logp, var_names=["y"], **kw)
+    assert list(m.shapes) == ["y"]
+    with pytest.raises(KeyError):
+        nutpie_amd.compile_pymc_model(logp, var_names=["nope"], **kw)
+    with pytest.raises(ValueError, match="freeze_model"):
+        nutpie_amd.compile_pymc_model(logp, n_dim=3, freeze_model=False)
