@@ -915,7 +915,7 @@ bool nphip_sampler::setup() {
     //  the rare path — kernels.hip: replay_divergence)
     if (fused && W == 1 && !launch.no_register_kernel) {
         const int nchunks = (int)(args.ld / 128);  // one kernel instantiation per exact chunk count (straight-line code)
-        if (nchunks <= 8) args.reg_nv = nchunks;
+        if (nchunks <= 8 || (getenv("NPHIP_DEV_W1_WIDE") && nchunks <= 12)) args.reg_nv = nchunks;   // (9 .. 12: developer libraries only, kernels.hip: Machine::NORING)
     }
     // memory-resident fused kernel, one wave per chain (store_divergences, no_register_kernel): cache the cursor's
     // (sigma^2, grad, p, rho) in VGPRs between leaves.  With more waves per chain the cache costs occupancy (measured).
@@ -1046,7 +1046,7 @@ bool nphip_sampler::setup() {
         // Pp [DP][KP]: rows padded to a multiple of 16 elements and 64 rows with zeros (dense_tile.h reads whole fragments), mu [KP]
         const size_t KP = (dim + 15) / 16 * 16, DP = (dim + 63) / 64 * 64;
         double *dP = nullptr, *dmu = nullptr;
-        if (!dalloc(&dP, DP * KP) || !dalloc(&dmu, KP)) return false;
+        if (!dalloc(&dP, DP * KP) || !dalloc(&dmu, std::max<size_t>(KP, (size_t)args.ld))) return false;   // (mu: zeros up to the padded row length)
         HIP_TRY(hipMemcpy2DAsync(dP, KP * 8, model.prec->data(), dim * 8, dim * 8, dim, hipMemcpyHostToDevice, stream));
         HIP_TRY(hipMemcpyAsync(dmu, model.mu.data(), dim * 8, hipMemcpyHostToDevice, stream));
         dense_dev.Pp = dP; dense_dev.mu = dmu; dense_dev.KP = (int64_t)KP; dense_dev.W = W;

@@ -534,6 +534,11 @@ struct Machine {
     // launch-per-evaluation kernels: the end of a draw is cut into slices of a launch each (engine_types.h: PH_DRAW_END / PH_DRAW_BEGIN)
     static constexpr bool SLICED = !INK && NV == 0;
     static constexpr bool DENS = REMOTE && (NPHIP_JIT != 0);   // ... by calling the model's own device function (runtime-compiled density)
+    // NORING (developer builds only, -DNPHIP_DEV_W1NV=9..12): one wave per chain with more than 8 chunks per lane — the leaf of the 8-chunk kernels without
+    // their LDS ring (four rings of that width do not fit a CU's LDS): every (p, rho) summary goes to its P-slot, the level-1 merges read them back from L2.
+    // Measured in round 6 against the shipped two waves per chain (profiles/r6_step_at_d1025_one_wave_no_ring_rejected.txt): D = 1100 114.5 against 123.2 M
+    // leapfrogs/s, D = 1280 68 against 124 (the 10-chunk leaf spills), D = 1536 44 against 110 — the ring is worth more than the second wave costs.  Not shipped.
+    static constexpr bool NORING = !LEAN && !LR && W == 1 && NV > 8;
     static constexpr bool DG = REMOTE && (NPHIP_JIT == 0) && TAG == 2;   // ... by the launch-wide GEMM of the dense-precision Gaussian (dg_round)
     LdsDouble dens_lds = nullptr;   // DENS: this wave's LDS scratch for the density
     LdsDouble dens_shared = nullptr;   // DENS: the workgroup's shared LDS (staged by nphip_density_stage at kernel start)
@@ -1103,7 +1108,9 @@ struct Machine {
     // wave's own stores of the position are made visible to all of its lanes first, the density's stores of the gradient after.
     // (DENS, rows_in_lds: the leaf keeps the position and gradient rows of its evaluations in LDS — the density's accesses to
     //  them are LDS accesses instead of L2 round trips; the rare paths use the staging rows in memory, as the callbacks do)
-    __device__ __forceinline__ void remote_eval(double& lp, int64_t& code, bool rows_in_lds = false) {
+    // (DG, want_lp = false: the register-resident leaf takes logp = 1/2 (x - mu) . grad out of its own pass over the gradient row — the same
+    //  per-lane fma chains, summed with the leaf's other reductions: the same bits, one pass over the row and one wave reduction fewer)
+    __device__ __forceinline__ void remote_eval(double& lp, int64_t& code, bool rows_in_lds = false, bool want_lp = true) {
 #if NPHIP_JIT
         if (DENS) {
             chain_sync<W>();   // (several waves per chain: every wave has written its chunks of the position)
@@ -1121,6 +1128,8 @@ struct Machine {
             // Ctl::hs_seq counts the rounds this wave has taken part in (every wave takes part in all hs_n of the launch: k_advance)
             dg_round(A, (int)c->hs_seq, A.n_chains, (NPHIP_LDS int64_t*)c->prof);
             c->hs_seq = c->hs_seq + 1;
+            code = 0;
+            if (!want_lp) return;
             // logp = 1/2 (x - mu) . grad in the contract's summation order (nphip_spec.h), as the launch-per-evaluation form computes it
             const double* xr = A.qeval + (size_t)chain * D;
             double2 acc = {0.0, 0.0};
@@ -2243,7 +2252,7 @@ struct Machine {
             } else {
 #pragma unroll
                 for (int k = 0; k < NVX; ++k) if (k < nk) qe_st(ridx(k), X.q[k]);
-                remote_eval(lp_remote, code_remote);
+                remote_eval(lp_remote, code_remote, false, !DG);
             }
         } else {
             publish_edges(z);
@@ -2259,6 +2268,11 @@ struct Machine {
                 if (ridx(k) + 1 >= D) gg.y = 0.0;
             } else if (REMOTE) {
                 gg = ge_ld(ridx(k));
+                if (DG) {   // logp's sum rides along (z = x - mu; mu is padded with zeros to the row's length)
+                    const double2 mu = ld2(A.dg_mu, ridx(k));
+                    accL.x = fma(X.q[k].x - mu.x, gg.x, accL.x);
+                    accL.y = fma(X.q[k].y - mu.y, gg.y, accL.y);
+                }
             } else {
                 double2 a, b01;          // b01 = b_{i-1}, b_i ; b2 = b_{i+1}
                 double b2, edge_zl, edge_zr;
@@ -2335,7 +2349,7 @@ struct Machine {
         X.dirty_qg = true;
         X.dirty_pr = true;
         // the two most recent summaries a level-1 merge needs stay on chip
-        if (!LR) {
+        if (!LR && !NORING) {
             if ((j & 3) == 1) { ring_write(0, X.p, X.r); X.ring_leaf0 = j; }
             else if ((j & 3) == 2) { ring_write(1, X.p, X.r); X.ring_leaf1 = j; }
         }
@@ -2350,7 +2364,7 @@ struct Machine {
         const int64_t tp2 = (int64_t)__builtin_readcyclecounter();
         c->prof[0] += tp1 - tp0; c->prof[6] += tp2 - tp1;
 #endif
-        const double K = 0.5 * v4[0], lp = REMOTE ? lp_remote : 0.5 * v4[1];
+        const double K = 0.5 * v4[0], lp = (REMOTE && !DG) ? lp_remote : 0.5 * v4[1];
         const bool turn0 = (v4[2] < 0.0) || (v4[3] < 0.0);
         if (REMOTE && code_remote < 0) { X.dirty_qg = X.dirty_pr = false; hot_save(H); finish_chain(PH_ERROR, CE_FATAL_LOGP); return true; }
         // ---- NutsTree::extend / merge_into, unrolled (same decisions as cont_tree)
@@ -2451,7 +2465,7 @@ struct Machine {
 #ifdef NPHIP_PROFILE
             const int64_t tp3 = (int64_t)__builtin_readcyclecounter();
 #endif
-            store_state(X, T_q == newq, LR || ((j & 3) == 0) || ((j & 7) == 1));   // (low-rank: no ring, every summary goes to its slot)
+            store_state(X, T_q == newq, LR || NORING || ((j & 3) == 0) || ((j & 7) == 1));   // (low-rank, wide rows: no ring, every summary goes to its slot)
             issue_leaf_hot(H);
 #ifdef NPHIP_PROFILE
             c->prof[7] += (int64_t)__builtin_readcyclecounter() - tp3;
@@ -3793,7 +3807,7 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) __attribute__((amdgpu_waves_
     __shared__ Ctl s_ctl[WAVES];
     __shared__ double s_red[W == 1 ? 8 : 32 * WAVES];   // two alternating reduction areas of 16 values per wave (one wave per chain: DPP only)
     __shared__ __attribute__((aligned(16))) double s_par[(NV > 0 && W == 1) ? 3 * 128 * NV + 8 : 2];
-    __shared__ __attribute__((aligned(16))) double s_ring[(NV > 0 && !LEAN && !LR) ? WAVES * 4 * 128 * NV : 2];  // per wave: 2 slots x (p, rho)
+    __shared__ __attribute__((aligned(16))) double s_ring[(NV > 0 && !LEAN && !LR && !(W == 1 && NV > 8)) ? WAVES * 4 * 128 * NV : 2];  // per wave: 2 slots x (p, rho)
     __shared__ double s_edge[(NV > 0 && W > 1) ? 2 * W * NV + 2 : 2];   // lean kernels: padded with one 0.0 at each end
     extern __shared__ __attribute__((aligned(16))) double s_dyn[];  // a.sig_lds: sigma^2 of the chain [ld]
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
@@ -3893,7 +3907,7 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) __attribute__((amdgpu_waves_
         c->hs_wgn = (W > 1) ? 1 : (left < 4 ? left : 4);   // chains of this workgroup (W == 1: four; group bounds are multiples of 4)
         if (DENSEG) { c->hs_seq = 0; c->hs_n = max_evals; }    // rounds of the launch-wide GEMM taken / to take
     }
-    Machine<FUSED, W, NV, LEAN, REMOTE, LR, (DENSEG ? 2 : (WIDE ? 1 : 0))> m(A, c, (LdsDouble)s_red, chain, (LdsDouble)s_par, (LdsDouble)s_ring + ((LEAN || LR) ? 0 : (size_t)wib * 4 * 128 * (NV > 0 ? NV : 1)),
+    Machine<FUSED, W, NV, LEAN, REMOTE, LR, (DENSEG ? 2 : (WIDE ? 1 : 0))> m(A, c, (LdsDouble)s_red, chain, (LdsDouble)s_par, (LdsDouble)s_ring + ((LEAN || LR || (W == 1 && NV > 8)) ? 0 : (size_t)wib * 4 * 128 * (NV > 0 ? NV : 1)),
                             (LdsDouble)s_edge);
     __shared__ double s_park[(!FUSED && NV == 0 && W > 1) ? Machine<FUSED, W, NV, LEAN, REMOTE, LR, (DENSEG ? 2 : (WIDE ? 1 : 0))>::kParkMax * W : 2];
     m.parked = (LdsDouble)s_park;
@@ -4093,6 +4107,7 @@ hipError_t launch_fam_w1(const Args& a, const Args* d_args, hipStream_t st, cons
     return hipGetLastError();
 }
 #endif
+
 
 #if NPHIP_HAS(8)
 // register-resident, one wave per chain, under the low-rank metric (settings.low_rank_metric; Machine<..., LR>): D <= 1024
