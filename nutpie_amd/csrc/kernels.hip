@@ -343,6 +343,10 @@ namespace nphip {
 // Per wave in LDS (g_dgwho + 24 * wave): [0] cluster (global index: die * 16 + cluster of the die), [1] member, [2] members, [3] die,
 // [4] seat, [8 .. 8 + members) the members' workgroup ids (row r of the cluster's block is chain 4 * id[r / 4] + r % 4).
 __shared__ int g_dgwho[4 * 24];
+// (Measured and rejected, round 6 — profiles/r6_dense_resident.txt: touching the P-slot operands of the leaf's merge cascade ahead of time
+//  (global_load_lds into a dump, one dword per 128-byte line).  A round waits for the slowest of a cluster's 64 leaves, and 4 % of the leaves take
+//  more than 20 us — the deep cascades.  Issued after the round, in front of the leaf's own loads: 74.9 against 74.0 us per round (loads return in
+//  order); issued when the wave has finished its GEMM tile: 78.8 (the wave's wait for its gradient stores now waits for them too).)
 constexpr int kDgMaxClusters = 128;                    // 8 dies x 16 clusters of 16 workgroups
 constexpr int kDgAbort = kDgMaxClusters * 32;          // word offsets into Args::dg_sync: the abort word (a line of its own)
 constexpr int kDgSeats = kDgAbort + 16;                // seats taken per die [8] (32-bit)
@@ -418,7 +422,13 @@ __device__ __forceinline__ void dg_round(const NPHIP_CONST Args& A, int round, i
     const int variant = A.dg_variant;
     const bool profiling = (variant & 32) && prof != nullptr;
     long long pc0 = 0, pw0 = 0, pc1 = 0, pc2 = 0;
-    if (profiling) { pc0 = (long long)__builtin_readcyclecounter(); pw0 = wall_clock64(); }
+    if (profiling) {
+        pc0 = (long long)__builtin_readcyclecounter(); pw0 = wall_clock64();
+        if (lane == 0 && prof[6] != 0) {   // the leaf between two rounds: < 5, < 10, < 15, < 20, < 30, >= 30 us
+            const long long dt = pw0 - prof[6];
+            prof[dt < 500 ? 0 : (dt < 1000 ? 1 : (dt < 1500 ? 2 : (dt < 2000 ? 3 : (dt < 3000 ? 4 : 5))))] += 1;
+        }
+    }
     if (wib == 0) {
         if (lane == 0) {
             __hip_atomic_fetch_add(arrive, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -479,6 +489,7 @@ __device__ __forceinline__ void dg_round(const NPHIP_CONST Args& A, int round, i
     if (profiling && lane == 0) {
         const long long pc3 = (long long)__builtin_readcyclecounter();
         prof[8] += pc1 - pc0; prof[9] += pc2 - pc1; prof[10] += pc3 - pc2; prof[11] += wall_clock64() - pw0; prof[12] += 1;
+        prof[6] = wall_clock64();
     }
 }
 

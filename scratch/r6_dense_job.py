@@ -26,5 +26,7 @@ if int(os.environ.get("NPHIP_DG_VARIANT", "0")) & 32:
     _lib.lib().nphip_sampler_profile(smp._h, out)
     pr = list(out)
     r = max(1, pr[12])
+    h = pr[0:6]
+    print("time between two rounds (the leaf), share of (wave, round) pairs: " + ", ".join(f"{lab} {v / max(1, sum(h)):.3f}" for lab, v in zip(("<5us", "<10us", "<15us", "<20us", "<30us", ">=30us"), h)), flush=True)
     print(f"per wave and round (whole job): wait-positions {pr[8] / r:.0f} cyc, GEMM {pr[9] / r:.0f} cyc, wait-gradients {pr[10] / r:.0f} cyc, round {pr[11] / r / 100:.1f} us", flush=True)
 smp.close()
