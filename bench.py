@@ -34,17 +34,21 @@ Extra objects in the JSON line:
   cpu_baseline_tuned — the same C++ sampler built for speed (AVX2 + FMA, free summation order): the honest
                   CPU number; the port is bit-reproducible scalar code.
   tuning_phase  — leapfrogs and kernel-time rate of the (untimed) warm-up that precedes the timed region.
-  job           — the complete sampling job (tune 400 + draws 1000) wall time, total leapfrogs, min bulk
-                  ESS over a subset of dimensions and ESS/s (the second half of BASELINE.json's metric).
+  job           — the complete sampling job (tune 400 + draws 1000) wall time, total leapfrogs, min bulk ESS over ALL
+                  dimensions (computed on the GPU that holds the trace) and ESS/s (the second half of BASELINE.json's metric).
   ranks         — world size, backend, and per rank: device, leapfrogs and kernel time of the timed region (N > 1: what a
                   scaling record is checked against).
   config5_shard — BASELINE.json configs[4]'s per-GPU shard on every rank (10 000 dimensions x 1024 chains, lean kernel): a
                   timed region of >= 10 launches in the sampling phase with its own `roofline` (bound "hbm"), then the
                   job runs to its end and its trace goes to rank 0 in ONE gather (nutpie_amd.distributed.gather_trace:
                   draws thinned on the device + per-chain moments + statistics) — seconds, bytes, ranks of the collective.
-  other_configs — (N = 1) bounded runs of the remaining BASELINE.json configs on this GPU: config 3 (radon, 512 chains) with
-                  the generated density and with the torch density, config 4 (eight schools, 256 chains, host C callback),
-                  config 2 (ii) (dense Gaussian, gradient = fp64 GEMM behind the device callback).
+  other_configs — (N = 1) runs of the remaining BASELINE.json configs on this GPU: config 3 (radon, 512 chains) with the generated
+                  density and with the torch density (also its cold compile time), config 4 (eight schools, 256 chains, host C
+                  callback), config 2 (ii) (dense 1000-dim Gaussian) INSIDE the engine — the hand-written fp64 MFMA gradient in the
+                  resident kernel: a timed region in the sampling phase with an `mfma` roofline against the matrix-core rate measured
+                  in the same run — and behind the rocBLAS callback of round 5.  EVERY leg carries `cpu_baseline` (the oracle on the same
+                  density, a bounded sample on this box's cores; `tuned` = its free-order SIMD build) and `gpu_over_cpu`, also where it
+                  is below 1 (config 4: a 10-dimensional host callback is faster on 16 CPU threads than through the GPU).
 
 Launching: under torch.distributed.run (RANK in the environment) this process is one rank.  WITHOUT it, `--gpus N` with
 N > 1 re-executes itself under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`,
@@ -691,6 +695,27 @@ def other_configs(env, args):
         t0 = time.perf_counter()
         r = job_rate(m._make_sampler(settings(512, 400, 1000), None, 1, None, None, None, None), t0)
         r["trace_and_compile_s"] = compile_s
+        # what a user pays the first time: the same model traced and compiled with an EMPTY cache (hipcc on this box's host cores; the
+        # figure above found the library the ahead-of-time build left in the tree)
+        import shutil
+        import tempfile
+
+        cold_dir = tempfile.mkdtemp(prefix="nutpie_amd_cold_cache_")
+        old = os.environ.get("NUTPIE_AMD_CACHE")
+        os.environ["NUTPIE_AMD_CACHE"] = cold_dir
+        try:
+            t_c = time.perf_counter()
+            radon_traced_model().library_path()
+            r["cold_compile_s"] = time.perf_counter() - t_c
+        except Exception as e:
+            r["cold_compile_s"] = None
+            r["cold_compile_error"] = repr(e)
+        finally:
+            if old is None:
+                os.environ.pop("NUTPIE_AMD_CACHE", None)
+            else:
+                os.environ["NUTPIE_AMD_CACHE"] = old
+            shutil.rmtree(cold_dir, ignore_errors=True)
         r["roofline"] = job_roofline("config3_traced_torch_density", r["leapfrogs_per_s"], 512)
         r["workload"] = ("radon, 512 chains, tune 400 + draws 1000; the model is a TORCH log-density (forward pass only, nutpie_amd.radon.radon_torch_density) that "
                          "nutpie_amd.from_torch_density traces (torch.fx), differentiates and compiles into its own resident kernel")
@@ -809,12 +834,20 @@ def other_configs(env, args):
         rate = leap / elapsed
         peak = hip.mfma_f64_rate(env.device)
         flops = 2.0 * D * D
+        try:
+            pmc = json.load(open(TRAFFIC_JSON)).get("config2ii_dense_resident")
+        except OSError:
+            pmc = None
         r = {"leapfrogs_per_s": rate, "timed_region_s": elapsed, "steps": K, "ms_per_step": 1000.0 * elapsed / K, "kernel_ms_per_launch": kernel_ms / K,
              "rounds_per_launch": E, "us_per_round": 1e6 * (kernel_ms / 1000.0) / (K * E), "useful_leapfrogs_per_round_and_chain": leap / (K * E * chains),
              "host_mode": mode, "waves_per_chain": 1,
              "warmup": {"leapfrogs": warm[0], "launches": warm[1], "kernel_ms": warm[2], "wall_s": warm[3]},
              "roofline": {"bound": "mfma", "kernel": "k_advance<callback,W=1,NV=8,REMOTE,DENSEG> (the launch-wide gradient GEMM inside the register-resident leaf)",
-                          "achieved": flops * rate / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": flops * rate / 1e12 / peak, "traffic": None,
+                          "achieved": flops * rate / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": flops * rate / 1e12 / peak,
+                          "traffic": (pmc["bytes_per_leapfrog"] * leap / K) if pmc else None,
+                          "hbm_measured": ({"bytes_per_leapfrog": pmc["bytes_per_leapfrog"], "GB/s": pmc["bytes_per_leapfrog"] * rate / 1e9, "frac_of_peak": pmc["bytes_per_leapfrog"] * rate / 1e9 / HBM_PEAK_GBS,
+                                            "source": pmc["source"], "note": "the precision matrix streams through the dies' L2s every round (8 MB against 4 MB of L2): L2 misses that the Infinity Cache serves are in these counters"} if pmc else None),
+                          "pmc_issuing_fraction_of_wave_cycles": (pmc or {}).get("issuing_fraction"), "pmc_waiting_fraction_of_wave_cycles": (pmc or {}).get("waiting_fraction"),
                           "flops_per_leapfrog": flops, "peak_datasheet_TFLOPs": 78.6, "frac_of_datasheet": flops * rate / 1e12 / 78.6,
                           "note": "achieved = 2 D^2 flop per leapfrog x leapfrogs/s of the timed region (the whole step: leaf + rendezvous + GEMM); peak = the fp64 matrix-core "
                                   "rate MEASURED on this device in this run (v_mfma_f64_16x16x4_f64 back to back on every SIMD: 96 cycles per instruction at 2.4 GHz — "

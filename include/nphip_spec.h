@@ -289,4 +289,22 @@ NPHIP_HD void nphip_normal_pair(nphip_u32x4 r, double* z0, double* z1) {
 #define NPHIP_LANES 64
 #define NPHIP_CHUNK 128
 
+/* ------------------------------------------------------------------------- */
+/* Dense gradient (nphip_model_dense_gaussian)                               */
+/* ------------------------------------------------------------------------- */
+/*
+ * logp(x) = -1/2 (x - mu)' P (x - mu), P symmetric [D][D].  With z = x - mu (one subtraction per element):
+ *   acc_j = sum_k z_k * P[j][k]  as ONE chain of fused multiply-adds per output j, starting from +0.0, in the order
+ *           for k0 = 0, 16, 32, ...:  for s = 0..3:  for t = 0..3:   k = k0 + 4 t + s        (k >= D is skipped)
+ *   g_j   = -acc_j
+ *   logp  = 1/2 * dot(z, g)   in the reduction geometry above (W waves per chain)
+ * The order of k is the order in which the engine's fp64 matrix-core tile (nutpie_amd/csrc/dense_tile.h) consumes a row:
+ * lane (row, t) of an operand fragment holds the four consecutive elements k0 + 4 t .. k0 + 4 t + 3, v_mfma_f64_16x16x4_f64
+ * number s of a k0-step takes element s of every lane, and the matrix core adds the four products of one instruction to the
+ * accumulator as fused multiply-adds in the order of t (established on the device: tests/test_gpu_dense.py compares the GEMM
+ * with a std::fma chain bit for bit).  Which workgroup, wave or launch computes an element does not enter: every output has
+ * exactly one accumulator.
+ */
+#define NPHIP_DENSE_KSTEP 16
+
 #endif /* NPHIP_SPEC_H */
