@@ -682,7 +682,7 @@ def other_configs(env, args):
         r = job_rate(smp, t0)
         r.update(hand_ins=len(log), estimating_s=float(sum(e[2] for e in log)), mean_columns=float(np.mean([e[1] for e in log])) if log else 0.0)
         r["workload"] = ("radon as above under adaptation='low_rank' (not a BASELINE config; SURVEY 8f N4): the metric on the register-resident leaf of the compiled "
-                         "density, window estimates (batched eigh on the device) handed to each chain as it stops; job_s is engine time, wall_incl_setup_s the job")
+                         "density, window estimates (nphip_low_rank_estimate: one kernel, a workgroup per chain) handed to each chain as it stops, chains that need no low-rank part released; job_s is engine time, wall_incl_setup_s the job")
         return r
 
     def c3_traced():

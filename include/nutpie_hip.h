@@ -275,6 +275,29 @@ int nphip_sampler_resume_at(nphip_sampler_t*, uint64_t n, const uint64_t* local_
  * (rounded to nearest on receipt; all arithmetic on it is fp64): the metric applied is that of the rounded columns. */
 int nphip_sampler_set_metric(nphip_sampler_t*, uint64_t n, const uint64_t* local_chains, uint64_t k, const double* sigma2, const double* V,
                              const double* lambda, int on_device);
+/* The same hand-in for chains that RUN (round 6): the metric is parked beside the chain (one staging row per chain; a parked metric that
+ * has not been taken yet is replaced) and the chain takes it ITSELF at the end of the draw it is working on — same position, a step-size
+ * search under the new metric, its own diagonal adaptation off from then on, exactly as after nphip_sampler_set_metric — so no chain
+ * ever stops for the host and no pause draws are needed.  Called between two nphip_sampler_step calls of a manual-mode sampler created
+ * with `low_rank_metric`.  Chains that have finished, failed, or are within one draw of the end of their warm-up ignore the hand-in;
+ * *n_taken (optional) receives the number of chains that parked it.  What nuts-rs does inline on the chain's own thread at an update
+ * of the mass matrix (src/wrapper.rs:307-334: mass_matrix_update_freq), with the estimate computed beside the running chains. */
+int nphip_sampler_stage_metric(nphip_sampler_t*, uint64_t n, const uint64_t* local_chains, uint64_t k, const double* sigma2, const double* V,
+                               const double* lambda, int on_device, uint64_t* n_taken);
+/* Draws every local chain has finished (draws[local_chain], optional) and its state (state[local_chain], optional: 0 running,
+ * 1 stopped at a pause draw, 2 finished or failed) in one read of the control blocks; returns the number of running chains, < 0 on error.
+ * (ChainProgress::finished_draws of every chain, src/wrapper.rs:66-82, for a driver that decides per chain.) */
+int64_t nphip_sampler_chain_draws(nphip_sampler_t*, int64_t* draws, uint8_t* state);
+/* Chains stopped at a pause draw go on as if they had not stopped: same metric, same step size, their own mass-matrix adaptation as it
+ * was (round 6).  What the low-rank driver does with a chain whose window shows no direction outside the eigenvalue cutoff and that has
+ * never been handed a metric: the diagonal metric it adapts itself — every draw, on the device — IS the metric the estimator would hand
+ * it, only fresher (the reference refreshes the diagonal part every mass_matrix_update_freq draws, src/wrapper.rs:198-240).  Every named
+ * chain must be stopped (nphip_sampler_waiting); an error names how many were not. */
+int nphip_sampler_release(nphip_sampler_t*, uint64_t n, const uint64_t* local_chains);
+/* Manual-mode samplers: evaluations per chain of the launches that follow (fused models, compiled densities, the dense Gaussian's resident
+ * form; 0 = the default).  A driver that looks at its chains between launches (low-rank hand-ins) takes short launches while chains can
+ * still stop and long ones afterwards; what a chain computes does not depend on where its launches end. */
+int nphip_sampler_set_evals_per_launch(nphip_sampler_t*, int32_t evals);
 /* Batched symmetric eigendecomposition on the device — the dense-linear-algebra kernel of the low-rank estimator (reference:
  * adaptation="low_rank", src/wrapper.rs:307-334; nuts-rs uses faer's self-adjoint eigendecomposition there, Cargo.lock faer 0.24).
  * a_device: [n_batch][order][order] row-major, the LOWER triangle is the matrix; on return column j of matrix b is the eigenvector
@@ -282,6 +305,28 @@ int nphip_sampler_set_metric(nphip_sampler_t*, uint64_t n, const uint64_t* local
  * tridiagonalisation, Q in place, implicit QL — nutpie_amd/csrc/linalg.hip).  Runs on `stream` and returns after it has finished
  * (the convergence status of every matrix is checked).  Used by nutpie_amd/low_rank.py::estimate for its four decompositions. */
 int nphip_batched_eigh(uint64_t n_batch, uint64_t order, double* a_device, double* w_device, void* stream);
+
+/* The window estimator of adaptation="low_rank" below the ABI (round 6; reference: the low-rank mass matrix of nuts-rs behind
+ * PyNutsSettings::LowRank, src/wrapper.rs:307-334, 725-729; python/nutpie/sample.py:921-933; docs/sampling-options.qmd:124-144 — the crate
+ * is not in the tree: the estimator follows the published description, as nutpie_amd/low_rank.py::estimate, which it restates, does).
+ * For each of n chains: from the window of m draws and their gradients — draws[chain * chain_stride + t * draw_stride + i], t < m, i < dim,
+ * device memory (the engine's own trace: nphip_sampler_device_ptr "draws" / "gradient" offset to the window's first draw), chain taken
+ * from chains_device[block] (device memory) or the block index when NULL —
+ *   sigma2[n][dim]      the diagonal scaling std(x) / std(g) over ALL m draws, re-centred on the median of the projected spectrum
+ *   V[n][k_max][dim]    row j = column j of V (orthonormal; zero rows beyond k_used[n])
+ *   lambda[n][k_max]    eigenvalues (1 beyond k_used)
+ * of  M^-1 = D^1/2 (I + V (Lambda - I) V') D^1/2:  the geometric mean of the draw covariance and the inverse gradient covariance
+ * (regularised by gamma) projected onto the span of the n_pick basis draws pick[0 .. n_pick) (indices into the window, host memory) and their
+ * gradients, eigenvalues outside [1 / cutoff, cutoff] kept, at most k_max <= 16.  One workgroup per chain, LDS-resident, the four symmetric
+ * eigenproblems of order 2 n_pick <= 64 by a one-sided Jacobi method (nutpie_amd/csrc/lowrank_est.hip).  scratch: n * 4112 doubles of
+ * device memory.  max_workgroups (0 = one per chain): the launch's size — a workgroup wants a CU's LDS to itself, so beside a
+ * running engine kernel the caller caps it at the CUs that kernel leaves idle (a workgroup then takes several chains in turn).
+ * Asynchronous on `stream`.  nphip_low_rank_estimate_supported: whether a shape is inside what the kernel covers
+ * (dim <= 512, n_pick <= 32 and <= dim, k_max <= 16). */
+int nphip_low_rank_estimate_supported(uint64_t dim, uint64_t m, uint64_t n_pick, uint64_t k_max);
+int nphip_low_rank_estimate(uint64_t n, uint64_t dim, uint64_t m, uint64_t n_pick, const int32_t* pick, const double* draws, const double* grads,
+                            int64_t chain_stride, int64_t draw_stride, const int64_t* chains_device, double gamma, double cutoff, uint64_t k_max,
+                            double* sigma2, double* V, double* lambda, int32_t* k_used, double* scratch, uint64_t max_workgroups, void* stream);
 
 /* Developer aid: per-section cycle counters summed over chains; all zero unless the library was built
  * with -DNPHIP_PROFILE.  [0] leapfrog cycles [1] tree cycles (hot) [2] draw-end cycles [3..5] their counts. */

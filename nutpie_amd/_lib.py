@@ -165,7 +165,15 @@ def lib():
             L.nphip_sampler_waiting.restype = C.c_int64
             L.nphip_sampler_resume_at.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int]
             L.nphip_sampler_set_metric.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+            L.nphip_sampler_stage_metric.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+            L.nphip_sampler_chain_draws.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+            L.nphip_sampler_chain_draws.restype = C.c_int64
+            L.nphip_sampler_set_evals_per_launch.argtypes = [C.c_void_p, C.c_int32]
+            L.nphip_sampler_release.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
             L.nphip_batched_eigh.argtypes = [C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+            L.nphip_low_rank_estimate_supported.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]
+            L.nphip_low_rank_estimate.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
+                                                  C.c_double, C.c_double, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
             L.nphip_test_eigh_stage.argtypes = [C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
             L.nphip_launch_defaults.argtypes = [C.POINTER(_Launch)]
             L.nphip_default_evals_per_launch.argtypes = [C.c_uint64]
@@ -832,7 +840,34 @@ class PySampler:
         if rc != NPHIP_OK:
             raise RuntimeError(_err())
 
-    def set_metric(self, chains, sig2, V=None, lam=None):
+    def release(self, chains):
+        """Chains stopped at a pause draw go on as if they had not stopped (``nphip_sampler_release``)."""
+        self._require()
+        ch = np.ascontiguousarray(chains, dtype=np.uint64)
+        if lib().nphip_sampler_release(self._h, C.c_uint64(len(ch)), ch.ctypes.data_as(C.c_void_p)) != NPHIP_OK:
+            raise RuntimeError(_err())
+
+    def set_evals_per_launch(self, evals: int):
+        """Manual mode: evaluations per chain of the launches that follow (0: the default)."""
+        self._require()
+        if lib().nphip_sampler_set_evals_per_launch(self._h, C.c_int32(int(evals))) != NPHIP_OK:
+            raise RuntimeError(_err())
+
+    def chain_draws(self):
+        """(draws finished per local chain, state per chain: 0 running / 1 stopped at a pause draw / 2 finished or failed)."""
+        self._require()
+        draws = np.zeros(self.num_chains, dtype=np.int64)
+        state = np.zeros(self.num_chains, dtype=np.uint8)
+        if lib().nphip_sampler_chain_draws(self._h, draws.ctypes.data_as(C.c_void_p), state.ctypes.data_as(C.c_void_p)) < 0:
+            raise RuntimeError(_err())
+        return draws, state
+
+    def stage_metric(self, chains, sig2, V=None, lam=None):
+        """The hand-in of :meth:`set_metric` for chains that RUN (``nphip_sampler_stage_metric``): each chain takes the metric itself
+        at the end of the draw it is working on.  Returns the number of chains that parked it (chains past their warm-up do not)."""
+        return self.set_metric(chains, sig2, V, lam, _staged=True)
+
+    def set_metric(self, chains, sig2, V=None, lam=None, _staged=False):
         """A new metric ``M^-1 = D^1/2 (I + V (Lambda - I) V') D^1/2`` for chains stopped at a pause draw (settings
         ``low_rank_metric``): ``sig2[n, dim]``, ``V[n, k, dim]`` (row j = column j of V), ``lam[n, k]`` — numpy arrays or CUDA
         tensors.  The chains keep their positions, re-run the step-size search and go on."""
@@ -853,6 +888,12 @@ class PySampler:
             ptrs = [a.ctypes.data_as(C.c_void_p) if a is not None else None for a in arrs]
         if k:
             assert tuple(arrs[1].shape) == (n, k, d) and tuple(arrs[2].shape) == (n, k)
+        if _staged:
+            taken = C.c_uint64(0)
+            rc = lib().nphip_sampler_stage_metric(self._h, C.c_uint64(n), ch.ctypes.data_as(C.c_void_p), C.c_uint64(k), ptrs[0], ptrs[1], ptrs[2], int(on_device), C.byref(taken))
+            if rc != NPHIP_OK:
+                raise RuntimeError(_err())
+            return int(taken.value)
         rc = lib().nphip_sampler_set_metric(self._h, C.c_uint64(n), ch.ctypes.data_as(C.c_void_p), C.c_uint64(k), ptrs[0], ptrs[1], ptrs[2], int(on_device))
         if rc != NPHIP_OK:
             raise RuntimeError(_err())
@@ -936,6 +977,46 @@ def batched_eigh(A, _stage=0):
     if rc != NPHIP_OK:
         raise RuntimeError(_err())
     return w, V
+
+
+def low_rank_estimate_supported(dim: int, m: int, n_pick: int, k_max: int) -> bool:
+    return bool(lib().nphip_low_rank_estimate_supported(C.c_uint64(int(dim)), C.c_uint64(int(m)), C.c_uint64(int(n_pick)), C.c_uint64(int(k_max))))
+
+
+def low_rank_estimate(draws, grads, chains, lo, hi, pick, gamma, cutoff, k_max=16, max_workgroups=0):
+    """``nphip_low_rank_estimate`` (nutpie_amd/csrc/lowrank_est.hip): the low-rank metric of ``chains`` (a CUDA int64 tensor of rows of
+    ``draws``, or None for all rows) from the window ``draws[:, lo:hi]``, ``grads[:, lo:hi]`` — CUDA float64 tensors ``[n_all, T, D]``
+    with contiguous rows, e.g. views of the engine's trace — and the basis draws ``pick`` (indices into the window).  Returns
+    ``(sigma2[n, D], V[n, k_max, D], lam[n, k_max], k_used[n] int32)`` on torch's current stream, nothing synchronised."""
+    import torch
+
+    if not (draws.is_cuda and grads.is_cuda and draws.dtype == torch.float64 and grads.dtype == torch.float64 and draws.dim() == 3 and draws.shape == grads.shape):
+        raise ValueError("low_rank_estimate: CUDA float64 tensors [chains, draws, dim] of one shape")
+    if draws.stride(2) != 1 or grads.stride(2) != 1 or draws.stride() != grads.stride():
+        raise ValueError("low_rank_estimate: rows must be contiguous and both arrays laid out alike")
+    D, m = int(draws.shape[2]), int(hi) - int(lo)
+    pick = np.ascontiguousarray(pick, dtype=np.int32)
+    n = int(draws.shape[0]) if chains is None else int(chains.numel())
+    if chains is not None and not (chains.is_cuda and chains.dtype == torch.int64 and chains.is_contiguous()):
+        raise ValueError("low_rank_estimate: chains must be a contiguous CUDA int64 tensor")
+    dev = draws.device
+    sig2 = torch.empty(n, D, dtype=torch.float64, device=dev)
+    V = torch.empty(n, int(k_max), D, dtype=torch.float64, device=dev)
+    lam = torch.empty(n, int(k_max), dtype=torch.float64, device=dev)
+    k_used = torch.empty(n, dtype=torch.int32, device=dev)
+    scratch = torch.empty(max(n, 1), 4112, dtype=torch.float64, device=dev)
+    off = int(lo) * int(draws.stride(1)) * 8
+    with torch.cuda.device(dev):
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        rc = lib().nphip_low_rank_estimate(C.c_uint64(n), C.c_uint64(D), C.c_uint64(m), C.c_uint64(len(pick)), pick.ctypes.data_as(C.c_void_p),
+                                           C.c_void_p(draws.data_ptr() + off), C.c_void_p(grads.data_ptr() + off), C.c_int64(int(draws.stride(0))),
+                                           C.c_int64(int(draws.stride(1))), None if chains is None else C.c_void_p(chains.data_ptr()), C.c_double(float(gamma)),
+                                           C.c_double(float(cutoff)), C.c_uint64(int(k_max)), C.c_void_p(sig2.data_ptr()), C.c_void_p(V.data_ptr()),
+                                           C.c_void_p(lam.data_ptr()), C.c_void_p(k_used.data_ptr()), C.c_void_p(scratch.data_ptr()), C.c_uint64(int(max_workgroups)), st)
+    if rc != NPHIP_OK:
+        raise RuntimeError("nphip_low_rank_estimate refused the shape (dim <= 512, at most 32 basis draws, k_max <= 16, cutoff > 1, gamma > 0)")
+    low_rank_estimate.last_scratch = scratch   # (diagnostics: words 4096.. of every chain's row — scratch/r6_lr_native.py)
+    return sig2, V, lam, k_used
 
 
 def default_evals_per_launch(dim: int) -> int:

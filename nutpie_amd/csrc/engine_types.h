@@ -97,6 +97,9 @@ struct Ctl {
     // supplied (sigma^2, V, lambda) — M^-1 = D^1/2 (I + V (Lambda - I) V') D^1/2 with lr_k columns — and the chain's own
     // mass-matrix adaptation is off
     int64_t host_metric, lr_k;
+    // a metric handed in while the chain RUNS (nphip_sampler_stage_metric): k + 1 of the metric waiting in Args::st_* — the chain
+    // takes it between two draws of its warm-up (finish_draw) and goes on through a step-size search; 0 = nothing waits
+    int64_t staged;
     // resident host-callback launches (k_advance<..., REMOTE>): the evaluation this chain publishes next, whether the host
     // has asked the launch to end at the next boundary, and the group it reports to (set at kernel start; transient)
     int64_t hs_seq, hs_last, hs_grp, hs_n, hs_wgn, hs_box;
@@ -196,6 +199,11 @@ struct Args {
                            // values fp32 holds; the metric that is applied is the one of the rounded columns (include/nphip_spec.h)
     double* lr_lam;        // [n][kLrMax]      eigenvalues
     double* lr_std;        // [n][ld]          sqrt(sigma^2)
+    // metrics handed in while the chains run (Ctl::staged): the chain copies its rows into (sigma^2, lr_std, lr_V, lr_lam) itself,
+    // between two draws — no chain ever stops for the host
+    double* st_sig2;       // [n][ld]
+    float* st_V;           // [n][kLrMax][ld]
+    double* st_lam;        // [n][kLrMax]
     const void* dens_data;       // the model's data block (device memory; layout defined by the generated prelude of the density source)
     int32_t dens_lds_doubles;    // LDS scratch per wave the density asked for, in doubles (dynamic LDS of the launch)
     int32_t dens_shared_doubles; // LDS shared by the chains of a workgroup (the model's data staged once per launch: nphip_density_stage)

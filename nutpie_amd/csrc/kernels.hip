@@ -3641,6 +3641,12 @@ struct Machine {
             A.st_accept_sym[o] = c->acc_sym_sum;
         }
         c->draw = draw + 1;
+        if (lr_job() && c->staged != 0) {
+            // a metric the host handed in while this chain was running (nphip_sampler_stage_metric): taken here, between two draws of
+            // the warm-up — same position, new step-size search (what PH_RESUME_SS does for a chain that had stopped for it)
+            if (draw + 1 < A.s.num_tune) { apply_staged(); c->phase = PH_RESUME_SS; return; }
+            c->staged = 0;
+        }
         for (int i = 0; i < A.s.n_pause; ++i) {
             if (A.s.pause_draws[i] == draw + 1 && draw + 1 < T) {   // the host takes over between two draws (engine_types.h: PH_WAIT_HOST)
                 c->phase = PH_WAIT_HOST;
@@ -3655,6 +3661,31 @@ struct Machine {
 #ifdef NPHIP_PROFILE
         c->prof[14] += (int64_t)__builtin_readcyclecounter() - t0_;
 #endif
+    }
+
+    // The staged metric of this chain (Args::st_*) becomes its metric: the copy k_set_metric makes for a stopped chain, made by the
+    // chain itself.  Every later read of (sigma^2, lr_std, lr_V, lr_lam) is a vector load of this workgroup behind the barrier /
+    // program order of the rare path (as for the sigma^2 position_pass rewrites); the scalar cache is dropped for lr_lam.
+    __device__ void apply_staged() {
+        const int k = (int)c->staged - 1;
+        const double* s2 = A.st_sig2 + (size_t)chain * ld;
+        double* sd = A.lr_std + (size_t)chain * ld;
+        const float* sv = A.st_V + (size_t)chain * kLrMax * ld;
+        float* lv = A.lr_V + (size_t)chain * kLrMax * ld;
+        NPHIP_FOR_CHUNKS(i) {
+            const double2 v = ld2(s2, i);
+            st2(sig2, i, v);
+            double2 r; r.x = sqrt(v.x); r.y = sqrt(v.y);
+            st2(sd, i, r);
+            for (int j = 0; j < kLrMax; ++j) *(NPHIP_GLOBAL float2*)(lv + (size_t)j * ld + i) = *(const NPHIP_GLOBAL float2*)(sv + (size_t)j * ld + i);
+        }
+        if (wave == 0 && lane < kLrMax) A.lr_lam[(size_t)chain * kLrMax + lane] = A.st_lam[(size_t)chain * kLrMax + lane];
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        __builtin_amdgcn_s_dcache_inv();
+        if (W > 1) __syncthreads();
+        c->host_metric = 1;
+        c->lr_k = k;
+        c->staged = 0;
     }
 
     // rare phases: initial point, step-size search (memory-resident passes; not performance critical)
@@ -4276,6 +4307,34 @@ __global__ void k_set_metric(const Args* __restrict__ Ap, int n, const int64_t* 
         c->phase = PH_RESUME_SS;
         atomicAdd(taken, 1);   // (the host compares with n: a chain that was not stopped keeps its metric, and the caller is told)
     }
+}
+
+// The same metric for chains that RUN (nphip_sampler_stage_metric; between two launches): it is parked in Args::st_* and the chain takes
+// it itself at the end of its current draw (Machine::apply_staged) — as long as it is still in its warm-up; a chain that is past it, has
+// finished or failed is not counted in `taken`.  A metric that is still parked is replaced.
+__global__ void k_stage_metric(const Args* __restrict__ Ap, int n, const int64_t* __restrict__ chains, int k, const double* __restrict__ sig2,
+                               const double* __restrict__ V, const double* __restrict__ lam, int* __restrict__ taken) {
+    const Args& A = *Ap;
+    if ((int)blockIdx.x >= n) return;
+    const int64_t ch = chains[blockIdx.x];
+    Ctl* c = A.ctl + ch;
+    if (c->phase == PH_DONE || c->phase == PH_ERROR || c->draw + 1 >= A.s.num_tune) return;
+    for (int64_t i = threadIdx.x; i < A.ld; i += blockDim.x) {
+        A.st_sig2[(size_t)ch * A.ld + i] = i < A.dim ? sig2[(size_t)blockIdx.x * A.dim + i] : 1.0;
+        for (int j = 0; j < kLrMax; ++j)
+            A.st_V[((size_t)ch * kLrMax + j) * A.ld + i] = (j < k && i < A.dim) ? (float)V[((size_t)blockIdx.x * k + j) * A.dim + i] : 0.0f;
+    }
+    if (threadIdx.x < kLrMax) A.st_lam[(size_t)ch * kLrMax + threadIdx.x] = (int)threadIdx.x < k ? lam[(size_t)blockIdx.x * k + threadIdx.x] : 1.0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        c->staged = k + 1;
+        atomicAdd(taken, 1);
+    }
+}
+
+hipError_t launch_stage_metric(const Args* d_args, int n, const int64_t* d_chains, int k, const double* sig2, const double* V, const double* lam, int* d_taken, hipStream_t st) {
+    hipLaunchKernelGGL(k_stage_metric, dim3((unsigned)n), dim3(256), 0, st, d_args, n, d_chains, k, sig2, V, lam, d_taken);
+    return hipGetLastError();
 }
 
 hipError_t launch_set_metric(const Args* d_args, int n, const int64_t* d_chains, int k, const double* sig2, const double* V, const double* lam, int* d_taken, hipStream_t st) {

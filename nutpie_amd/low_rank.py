@@ -42,6 +42,8 @@ WINDOW_MAX = 256      # draws of a foreground window that are read at all (the m
 MIN_WINDOW = 12       # a window shorter than this says too little: no hand-in
 SETTLE = 4            # draws after a hand-in that are not used (the chain re-runs its step-size search there)
 HOLD_LAUNCHES = 3     # looks (a launch, or a few ms of launches) a stopped chain waits for company before it is handed in on its own
+ESTIMATOR_CAP = None   # workgroups of the estimator kernel beside a running engine kernel: None = the CUs that kernel leaves idle, 0 = one per chain
+SHORT_LAUNCH_DIV = 4  # launches while chains can still stop at a boundary: the default length divided by this (the fast driver)
 MAX_HAND_INS = 15     # pause draws the engine holds (engine_types.h: pause_draws[16])
 
 
@@ -212,7 +214,7 @@ def estimate(x, gx, gamma: float, cutoff: float, k_max: int = K_MAX, basis_draws
     stds = torch.where(torch.isfinite(stds) & (stds > 0), stds, torch.ones_like(stds)).clamp(1e-10, 1e10)
     gmean = gx.mean(1, keepdim=True)
     if basis_draws is not None and m > basis_draws:
-        pick = torch.as_tensor(np.unique(np.round(np.linspace(0, m - 1, basis_draws)).astype(np.int64)), device=x.device)
+        pick = torch.as_tensor(basis_pick(m, basis_draws), device=x.device)
         x, gx = x.index_select(1, pick), gx.index_select(1, pick)
         m = int(pick.numel())
     X = (x - mean[:, None, :]) / stds[:, None, :]
@@ -289,6 +291,51 @@ def basis_draws_for(dim: int) -> int:
     return int(BASIS_DRAWS) if BASIS_DRAWS else (32 if dim <= 256 else 64)
 
 
+def basis_pick(m: int, basis_draws: int | None):
+    """Indices (into a window of ``m`` draws) of the draws that span the subspace of the low-rank part: all of them, or ``basis_draws``
+    thinned evenly — what :func:`estimate` selects."""
+    if basis_draws is not None and m > basis_draws:
+        return np.unique(np.round(np.linspace(0, m - 1, basis_draws)).astype(np.int64))
+    return np.arange(m, dtype=np.int64)
+
+
+RELEASE_WITHOUT_COLUMNS = True   # a chain on its own diagonal metric whose window needs no low-rank part is released, not handed a frozen diagonal
+
+
+def torch_index(mask, like):
+    import torch
+
+    return torch.as_tensor(np.nonzero(mask)[0], device=like.device)
+
+
+NATIVE_ESTIMATOR = True   # the estimator as one kernel below the C-ABI (nphip_low_rank_estimate) wherever it covers the shape
+
+
+def estimate_window(draws, grads, chains, lo: int, hi: int, gamma: float, cutoff: float, k_max: int = K_MAX, basis_draws: int | None = None,
+                    max_workgroups: int = 0):
+    """(sigma^2 [n, D], V rows [n, k_max, D], lambda [n, k_max]) of ``chains`` (indices, or None for all) from the window
+    ``[lo, hi)`` of the trace arrays ``draws`` / ``grads`` ``[n_all, T, D]`` — :func:`estimate` + :func:`metric_of`, computed by the engine's
+    own kernel (``nphip_low_rank_estimate``: one workgroup per chain, nothing copied out of the trace, one launch) where that covers
+    the shape: up to 512 dimensions with at most 32 basis draws."""
+    import torch
+
+    D, m = int(draws.shape[2]), int(hi) - int(lo)
+    pick = basis_pick(m, basis_draws)
+    if NATIVE_ESTIMATOR and draws.is_cuda and k_max <= 16 and len(pick) <= D:
+        from nutpie_amd import _lib
+
+        if _lib.low_rank_estimate_supported(D, m, len(pick), k_max):
+            idx = None if chains is None else torch.as_tensor(np.asarray(chains, dtype=np.int64), device=draws.device)
+            sig2, V, lam, _ = _lib.low_rank_estimate(draws, grads, idx, lo, hi, pick, gamma, cutoff, k_max, max_workgroups)
+            return sig2, V, lam
+    if chains is None:
+        x, g = draws[:, lo:hi], grads[:, lo:hi]
+    else:
+        idx = torch.as_tensor(np.asarray(chains, dtype=np.int64), device=draws.device)
+        x, g = draws[idx, lo:hi], grads[idx, lo:hi]
+    return metric_of(estimate(x, g, gamma, cutoff, k_max=k_max, basis_draws=basis_draws))
+
+
 def schedule_of(settings):
     """:func:`window_schedule` from a settings object (the keys of ``src/wrapper.rs:198-240``; ``mass_matrix_update_freq`` keeps the
     engine's default of 1 unless set: the low-rank default of 10 applies then)"""
@@ -319,6 +366,7 @@ class LowRankSampler:
         self._schedule = [(int(p), int(a)) for p, a in schedule]    # (pause draw, first draw of its window): window_schedule
         self._pauses = [p for p, _ in self._schedule]
         self._had_columns = np.zeros(inner.num_chains, dtype=bool)  # per chain: its current metric has a low-rank part
+        self._handed = np.zeros(inner.num_chains, dtype=bool)       # per chain: it has been handed a metric (its own diagonal adaptation is off)
         self.fallbacks = 0            # hand-ins that kept only the diagonal part because the last low-rank metric deepened the chain's trees
         self._chain_next = np.zeros(inner.num_chains, dtype=np.int64)   # per chain: index of the next boundary it stops at
         self._stream = None           # the estimator's stream (made on its thread)
@@ -329,7 +377,11 @@ class LowRankSampler:
         self._abort = False
         self._done = False
         self._error = None
-        self.switch_log = []          # (boundary draw, mean number of columns used, seconds spent estimating, chains handed in)
+        # the estimator kernel's launch is capped at the CUs the engine's kernel leaves idle (one wave per chain, four chains per workgroup
+        # from 257 chains on; a CU per chain below that): 0 = no cap (the other drivers estimate while nothing of the engine's needs a CU)
+        self._estimator_workgroups = 0
+        self.switch_log = []          # (boundary draw, mean number of columns used, seconds spent estimating, chains handed in, seconds since the start)
+        self._t_start = time.perf_counter()
         self._thread = threading.Thread(target=self._run, daemon=True)
         self._thread.start()
 
@@ -355,6 +407,8 @@ class LowRankSampler:
             kind = type(getattr(self._inner, "_model", None)).__name__
             resident = kind in ("TridiagGaussianModel", "JitDensityModel") or (kind in ("HostCallbackModel", "BridgeStanModel") and self._inner.host_mode == "resident")
             per_look = int(getattr(self._inner, "launches_per_look", 0)) or (1 if resident else 16)
+            if self._native_estimator():   # (the windows go to the engine's own estimator kernel: a driver without lock-step rules)
+                return self._run_fast(pool, kind, resident, per_look)
             job = None                                             # the estimate in flight
             busy = np.zeros(self._inner.num_chains, dtype=bool)    # chains whose estimate is in flight
             while True:
@@ -392,6 +446,64 @@ class LowRankSampler:
                 self._done = True
                 self._cv.notify_all()
 
+    def _run_fast(self, pool, kind, resident, per_look):
+        """The driver when the windows go to the engine's own estimator kernel (``estimate_window``: its result for a chain does not
+        depend on what else is in the batch, so WHO is handed in together may depend on the clock — what a chain is handed, and at
+        which draw, does not: the job stays reproducible from its seed).  Nothing waits for anything it does not need: the engine
+        takes one launch after the other — a quarter of their usual length while chains can still stop, so that a chain that stops
+        is seen within a millisecond —; whenever no estimate is in flight, every chain that has stopped by then goes into the next
+        one (worker thread, own stream); a finished estimate is installed between two launches.  (Measured and rejected,
+        scratch/r6_lr_wall.py: the estimate BETWEEN two launches with the device to itself — radon, 512 chains: 118 hand-ins of
+        4.4 ms with nothing else running, 0.84 s of wall against 0.41.)"""
+        short = 0
+        if resident and per_look == 1 and kind in ("TridiagGaussianModel", "JitDensityModel") and hasattr(self._inner, "set_evals_per_launch"):
+            from nutpie_amd import _lib
+
+            short = max(16, (512 if kind == "JitDensityModel" else _lib.default_evals_per_launch(self._inner.dim)) // SHORT_LAUNCH_DIV)
+            self._inner.set_evals_per_launch(short)
+        n_ch = int(self._inner.num_chains)
+        self._estimator_workgroups = max(8, 256 - (n_ch if n_ch <= 256 else (n_ch + 3) // 4) - 8) if ESTIMATOR_CAP is None else int(ESTIMATOR_CAP)
+        job = None
+        while True:
+            with self._cv:
+                while self._paused and not self._abort:
+                    self._cv.wait()
+                if self._abort:
+                    break
+            with self._step_lock:
+                pending = bool((self._chain_next < len(self._pauses)).any())
+                if short and not pending:
+                    self._inner.set_evals_per_launch(0)   # (nothing stops any more: the default launch length)
+                    short = 0
+                done, cnt, ms = self._inner.step(per_look if pending else 16)
+                if done:
+                    break
+                if not pending:
+                    continue
+                code = self._inner.waiting_codes()
+                if job is not None and (job.done() or not (code == 0).any()):
+                    self._install(job.result())
+                    job = None
+                    code = self._inner.waiting_codes()
+                if job is None:
+                    wait = code == 1
+                    if wait.any():
+                        grp = np.nonzero(wait)[0]
+                        job = pool.submit(self._estimate, grp, self._chain_next[grp].copy())
+
+    def _native_estimator(self):
+        """Whether this job's windows go to ``nphip_low_rank_estimate`` (a GPU trace of a shape the kernel covers)."""
+        try:
+            import torch
+
+            from nutpie_amd import _lib
+
+            D = int(self._inner.dim)
+            return bool(NATIVE_ESTIMATOR and torch.cuda.is_available() and hasattr(self._inner, "device_ptr") and
+                        _lib.low_rank_estimate_supported(D, WINDOW_MAX, min(basis_draws_for(D), D), K_MAX) and basis_draws_for(D) <= 32)
+        except Exception:  # noqa: BLE001 - (a stand-in engine of the CPU tests)
+            return False
+
     def _views(self):
         from nutpie_amd.distributed import device_tensor
 
@@ -424,13 +536,8 @@ class LowRankSampler:
                 grp = chains[at == i]
                 hi, lo = self._schedule[i]
                 lo = max(lo, hi - WINDOW_MAX)
-                if len(grp) == draws.shape[0]:
-                    x, g = draws[:, lo:hi], grads[:, lo:hi]
-                else:
-                    idx = torch.as_tensor(grp, device=draws.device)
-                    x, g = draws[idx, lo:hi], grads[idx, lo:hi]
-                T_new = estimate(x, g, self._gamma, self._cutoff, basis_draws=basis_draws_for(x.shape[2]))
-                sig2, V, lam = metric_of(T_new)
+                sig2, V, lam = estimate_window(draws, grads, None if len(grp) == draws.shape[0] else grp, lo, hi, self._gamma, self._cutoff,
+                                               basis_draws=basis_draws_for(draws.shape[2]), max_workgroups=self._estimator_workgroups)
                 # A chain whose LAST low-rank metric deepened its trees (mean leapfrogs per draw of the window just finished against
                 # the window before that hand-in) keeps only the diagonal part this time: a metric estimated from a chain still in
                 # transit can point the columns the wrong way, and the next window would be estimated from max-depth draws
@@ -449,19 +556,34 @@ class LowRankSampler:
                         V = torch.where(b[:, None, None], torch.zeros_like(V), V)
                 # only the columns some chain uses (estimate() puts a chain's used columns first): every column handed in costs
                 # every leapfrog of every chain a dot product and an update in both halves of the step
-                k_used = int((lam != 1.0).sum(1).max().item()) if lam.numel() else 0
-                has = ((lam != 1.0).sum(1) > 0).cpu().numpy() if lam.numel() else np.zeros(len(grp), dtype=bool)
+                n_cols = (lam != 1.0).sum(1).cpu().numpy() if lam.numel() else np.zeros(len(grp), dtype=np.int64)   # (the one synchronisation)
+                k_used = int(n_cols.max()) if len(n_cols) else 0
+                has = n_cols > 0
                 V, lam = V[:, :k_used].contiguous(), lam[:, :k_used].contiguous()
-                cols = float((lam != 1.0).sum(1).double().mean()) if k_used else 0.0
+                cols = float(n_cols.mean()) if k_used else 0.0
                 if cuda:
                     self._stream.synchronize()
-                out.append((grp, int(i), sig2, V if k_used else None, lam if k_used else None, (hi, cols, time.perf_counter() - t0, len(grp)), has, int(bad.sum())))
+                out.append((grp, int(i), sig2, V if k_used else None, lam if k_used else None, (hi, cols, time.perf_counter() - t0, len(grp), t0 - self._t_start), has, int(bad.sum())))
         return out
 
     def _install(self, metrics):
         """(driver thread, between two launches) hand the estimated metrics to the engine"""
         for grp, i, sig2, V, lam, entry, has, n_bad in metrics:
-            self._inner.set_metric(grp, sig2, V, lam)
+            # A chain whose window shows no direction outside the cutoff, and that runs on the diagonal metric it adapts itself, simply
+            # goes on: that metric is the estimator's diagonal part, refreshed every draw on the device instead of at six boundaries
+            # (measured, radon, 512 chains: a chain still in transit at its first boundary was frozen on the metric of those 59 draws
+            # for the next 80 — 120 leapfrogs per draw — and the job ended with it: scratch/r6_lr_wall.py).  A chain that has been
+            # handed a metric before keeps being handed one (its own estimators stopped then).
+            free = ~np.asarray(has, dtype=bool) & ~self._handed[grp] if RELEASE_WITHOUT_COLUMNS and hasattr(self._inner, "release") else np.zeros(len(grp), dtype=bool)
+            if free.all():
+                self._inner.release(grp)
+            else:
+                if free.any():
+                    self._inner.release(grp[free])
+                    keep = torch_index(~free, sig2)
+                    sig2, V, lam = sig2[keep], (None if V is None else V[keep]), (None if lam is None else lam[keep])
+                self._inner.set_metric(grp[~free], sig2, V, lam)
+                self._handed[grp[~free]] = True
             self._chain_next[grp] = i + 1
             self._had_columns[grp] = has
             self.fallbacks += n_bad

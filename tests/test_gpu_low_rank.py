@@ -229,3 +229,139 @@ def test_estimator_on_the_gpu_against_its_cpu_oracle(hip):
         assert np.abs(got - want).max() <= 1e-7 * np.abs(want).max()
     T1 = lr.estimate(xt[2:3], gt[2:3], 1e-5, 2.0)
     assert torch.equal(T1.stds, T.stds[2:3]) and torch.equal(T1.V, T.V[2:3]) and torch.equal(T1.d, T.d[2:3])   # no dependence on the batch
+
+
+def _window_problem(rng, n, m, D, n_dir, factor=25.0):
+    B = rng.normal(size=(n, D, n_dir))
+    scales = np.exp(rng.normal(size=(n, D)))
+    Sigma = np.stack([np.diag(scales[c] ** 2) + factor * (scales[c][:, None] * B[c]) @ (scales[c][:, None] * B[c]).T for c in range(n)])
+    x = np.stack([rng.multivariate_normal(np.zeros(D), Sigma[c], size=m) for c in range(n)]) + 2.0
+    g = -np.stack([np.linalg.solve(Sigma[c], (x[c] - 2.0).T).T for c in range(n)])
+    return x, g
+
+
+@pytest.mark.parametrize("n,m,D,basis,n_dir,cutoff", [(6, 30, 30, None, 3, 2.0), (5, 80, 173, 32, 4, 2.0), (3, 256, 40, 32, 2, 3.0), (4, 20, 64, 32, 5, 2.0),
+                                                      (3, 12, 5, 32, 1, 2.0), (2, 64, 300, 32, 6, 100.0)])
+def test_native_estimator_kernel_against_the_torch_formulation_and_the_cpu_oracle(hip, n, m, D, basis, n_dir, cutoff):
+    """nphip_low_rank_estimate (one kernel, Jacobi eigensolvers, reads the window out of a trace-shaped array through a chain list)
+    against low_rank.estimate (torch) — and, where every draw is a basis draw, against the numpy restatement — through the dense
+    metric, which does not depend on order, sign or basis of the columns."""
+    import torch
+
+    from nutpie_amd import low_rank as lr
+    from oracle import low_rank_estimator as ref
+
+    rng = np.random.default_rng(100 + D)
+    x, g = _window_problem(rng, n, m, D, n_dir)
+    # a trace-shaped array: more chains and draws than the window, the window somewhere inside
+    n_all, T, lo = n + 3, m + 17, 9
+    chains = rng.permutation(n_all)[:n]
+    tr_x, tr_g = rng.normal(size=(n_all, T, D)), rng.normal(size=(n_all, T, D))
+    tr_x[chains, lo:lo + m], tr_g[chains, lo:lo + m] = x, g
+    dx, dg = torch.as_tensor(tr_x, device="cuda"), torch.as_tensor(tr_g, device="cuda")
+    pick = lr.basis_pick(m, basis)
+    if len(pick) > D:
+        assert not hip.low_rank_estimate_supported(D, m, len(pick), lr.K_MAX)   # (the full-space branch of estimate(): not the kernel's)
+        return
+    assert hip.low_rank_estimate_supported(D, m, len(pick), lr.K_MAX)
+    sig2, V, lam, k_used = hip.low_rank_estimate(dx, dg, torch.as_tensor(chains, device="cuda"), lo, lo + m, pick, 1e-5, cutoff, lr.K_MAX)
+    sig2, V, lam, k_used = sig2.cpu().numpy(), V.cpu().numpy(), lam.cpu().numpy(), k_used.cpu().numpy()
+    T_t = lr.estimate(torch.as_tensor(x, device="cuda"), torch.as_tensor(g, device="cuda"), 1e-5, cutoff, basis_draws=basis)
+    s2_t, V_t, lam_t = (t.cpu().numpy() for t in lr.metric_of(T_t))
+    for c in range(n):
+        got = ref.dense_metric(sig2[c], V[c].T, lam[c])
+        want = ref.dense_metric(s2_t[c], V_t[c].T, lam_t[c])
+        # Where the basis has full rank (2b <= D) the formulation is ill-conditioned in ANY arithmetic: the geometric mean goes through
+        # Cg^1/2 Cx Cg^1/2, whose condition number is the product of two that are 1 / gamma each — two exact-arithmetic-equal
+        # formulations evaluated with LAPACK differ by 5e-4 on these problems (the kernel works in the eigenbasis of Cg, estimate() does
+        # not; tests/test_low_rank_cpu.py allows estimate() 1e-4 against the numpy restatement for the same reason).  With a
+        # rank-deficient basis the dropped directions take the small eigenvalues with them and everything agrees to rounding.
+        tol = 1e-6 if 2 * len(pick) > D else 3e-3
+        assert np.abs(got - want).max() <= tol * np.abs(want).max(), (c, np.abs(got - want).max() / np.abs(want).max())
+        assert k_used[c] == int((lam_t[c] != 1.0).sum()) and (lam[c][k_used[c]:] == 1.0).all() and (V[c][k_used[c]:] == 0.0).all()
+        vu = V[c][:k_used[c]]
+        assert np.abs(vu @ vu.T - np.eye(k_used[c])).max() < 1e-9          # orthonormal columns
+        if basis is None or m <= basis:
+            want2 = ref.dense_metric(*ref.estimate_chain(x[c], g[c], 1e-5, cutoff, lr.K_MAX))
+            assert np.abs(got - want2).max() <= max(10 * tol, 1e-6) * np.abs(want2).max()
+    assert k_used.max() >= 1 or cutoff > 50   # (the problems have strong directions: the test is not about empty metrics)
+    # a window with a non-finite entry: exactly the identity for that chain, the others untouched
+    tr_x[chains[1], lo + 3, D // 2] = np.inf
+    s2b, Vb, lamb, kb = hip.low_rank_estimate(torch.as_tensor(tr_x, device="cuda"), dg, torch.as_tensor(chains, device="cuda"), lo, lo + m, pick, 1e-5, cutoff, lr.K_MAX)
+    assert (s2b[1] == 1.0).all() and (Vb[1] == 0.0).all() and (lamb[1] == 1.0).all() and int(kb[1]) == 0
+    assert np.array_equal(s2b[0].cpu().numpy(), sig2[0]) and np.array_equal(Vb[0].cpu().numpy(), V[0])
+    # estimate_window takes the kernel on the GPU and gives what estimate() + metric_of() give
+    s2w, Vw, lamw = lr.estimate_window(dx, dg, chains, lo, lo + m, 1e-5, cutoff, basis_draws=basis)
+    assert np.array_equal(s2w.cpu().numpy(), sig2) and np.array_equal(Vw.cpu().numpy(), V)
+
+
+def test_staged_metric_is_the_metric_handed_in_at_a_pause(hip):
+    """nphip_sampler_stage_metric: a chain that RUNS takes the parked metric at the end of the draw it is working on — the same job, bit
+    for bit, as one whose chains stop at that draw (pause draws) and are handed the metric there (nphip_sampler_set_metric)."""
+    dim, chains, tune, draws, k, seed = 48, 12, 60, 12, 3, 11
+    rng = np.random.default_rng(3)
+    pauses = [20, 41]
+    sig2, V, lam = random_metrics(rng, len(pauses), chains, dim, k)
+    ar = ar1_gaussian(dim, rho=0.9, scales=np.exp(rng.normal(size=dim)))
+    model = hip.TridiagGaussianModel(ar.diag, ar.offdiag)
+    sig2 *= 0.05
+    want, W = run_engine_with_metrics(hip, model, pauses, sig2, V, lam, chains=chains, tune=tune, draws=draws, seed=seed)
+    s = hip.PyNutsSettings.Diag(seed)
+    s.update(num_tune=tune, num_draws=draws, num_chains=chains, low_rank_metric=True)
+    smp = hip.PySampler(s, model, manual=True, evals_per_launch=1)     # (one evaluation per launch: a chain's draw counter moves by at most one per look)
+    nxt = np.zeros(chains, dtype=int)
+    for _ in range(200000):
+        done, _, _ = smp.step(1)
+        if done:
+            break
+        d, state = smp.chain_draws()
+        for u, p in enumerate(pauses):
+            grp = np.nonzero((nxt == u) & (d == p - 1) & (state == 0))[0]
+            if len(grp):
+                assert smp.stage_metric(grp, sig2[u][grp], V[u][grp], lam[u][grp]) == len(grp)
+                nxt[grp] = u + 1
+    assert done and (nxt == len(pauses)).all()
+    assert smp.waves_per_chain == W
+    assert_trace_equal(smp.take_results(), want)
+    # a chain past its warm-up ignores a hand-in, and says so
+    smp = hip.PySampler(s, model, manual=True)
+    while True:
+        done, _, _ = smp.step(1)
+        d, state = smp.chain_draws()
+        if done or (d >= tune).all():
+            break
+    assert smp.stage_metric(np.arange(chains), sig2[0], V[0], lam[0]) == 0
+
+
+@pytest.mark.parametrize("kind", ["fused", "host_callback"])
+def test_released_chains_go_on_as_if_they_had_not_stopped(hip, fixture_lib, kind):
+    """nphip_sampler_release: a job whose chains stop at pause draws and are released there equals, bit for bit, the job without pause
+    draws — the metric, the step size and the chain's own mass-matrix adaptation are what they were."""
+    chains, tune, draws, seed = 10, 70, 15, 4
+    if kind == "fused":
+        ar = ar1_gaussian(200, rho=0.8, scales=np.exp(np.random.default_rng(1).normal(size=200)))
+        make = lambda: hip.TridiagGaussianModel(ar.diag, ar.offdiag)   # noqa: E731
+    else:
+        make = lambda: hip.HostCallbackModel(10, fn_addr(fixture_lib.eight_schools_logp))   # noqa: E731
+    s = hip.PyNutsSettings.Diag(seed)
+    s.update(num_tune=tune, num_draws=draws, num_chains=chains, low_rank_metric=True)
+    plain = hip.PySampler(s, make(), manual=True)
+    while not plain.step(8)[0]:
+        pass
+    want = plain.take_results()
+    s2 = s.clone()
+    s2.set_pause_draws([13, 40, 41])
+    smp = hip.PySampler(s2, make(), manual=True)
+    released = 0
+    for _ in range(100000):
+        done, _, _ = smp.step(3)
+        if done:
+            break
+        w = np.nonzero(smp.waiting())[0]
+        if len(w):
+            smp.release(w)
+            released += len(w)
+    assert done and released == 3 * chains
+    assert_trace_equal(smp.take_results(), want)
+    with pytest.raises(RuntimeError, match="not stopped"):
+        hip.PySampler(s2, make(), manual=True).release(np.arange(chains))   # (nothing has stopped yet)
