@@ -202,7 +202,9 @@ typedef struct {
                                  * (256: the group's kernel stays on the device with the chain state in registers, publishes its
                                  * positions, waits for the host's word in pinned memory and goes on), N > 1 = that many,
                                  * 1 = one launch per evaluation; -N (tests) = leave the resident mode after N evaluations, the
-                                 * way a failed roll call does */
+                                 * way a failed roll call does.  The dense-precision Gaussian (nphip_model_dense_gaussian): 0 = its resident
+                                 * form when the job fills the die-local clusters of workgroups that share a round's GEMM (otherwise a launch
+                                 * per evaluation is faster: DESIGN.md section 12), 1 = a launch per evaluation, N > 1 = the resident form */
     int32_t reserved_;
 } nphip_launch_t;
 

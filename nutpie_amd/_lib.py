@@ -91,7 +91,7 @@ _lib_lock = threading.Lock()
 
 def build(force: bool = False) -> str:
     """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(_CSRC, f) for f in ("kernels.hip", "host.hip", "linalg.hip", "engine_types.h", "dense_tile.h", "Makefile")]
+    srcs = [os.path.join(_CSRC, f) for f in ("kernels.hip", "host.hip", "linalg.hip", "lowrank_est.hip", "engine_types.h", "dense_tile.h", "Makefile")]
     srcs += [os.path.join(_HERE, "..", "include", f) for f in ("nutpie_hip.h", "nphip_spec.h")]
     stale = not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(s) for s in srcs)
     if force or stale:

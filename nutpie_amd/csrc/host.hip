@@ -1072,8 +1072,16 @@ bool nphip_sampler::setup() {
         // the resident form: every chain on the device at once (one workgroup of four chains per CU), state in registers
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) cus = 0;
+        // ... when the job is large enough for it: a cluster is formed from workgroups of ONE die (8 of them, workgroups dealt round-robin), and
+        // its members share the column tiles of the GEMM — with fewer than half as many workgroups per die as there are tiles (64 columns each)
+        // a member computes three or more tiles per round and a launch per evaluation is faster (measured, scratch/r6_dense_small.py:
+        // D = 1000: 128 chains 0.69 against 1.05 M leapfrogs/s, 256 chains 2.38 against 2.00; D = 256: 16 chains 0.28 against 0.52, 64 chains
+        // 1.59 against 1.39).  launch.host_persist > 1 forces the resident form.
+        const uint64_t wgs_per_die = std::max<uint64_t>(1, ((n + 3) / 4) / 8), n_tiles = (dim + 63) / 64;
+        const uint64_t tiles_per_member = (n_tiles + std::min<uint64_t>(16, wgs_per_die) - 1) / std::min<uint64_t>(16, wgs_per_die);
         dg = W == 1 && dim <= 1024 && (n + 3) / 4 <= (uint64_t)cus && !lrm && !set.store_divergences &&
-             set.pause_draws.empty() && !launch.no_register_kernel && launch.host_persist != 1 && launch.host_groups < 2;
+             set.pause_draws.empty() && !launch.no_register_kernel && launch.host_persist != 1 && launch.host_groups < 2 &&
+             (tiles_per_member <= 2 || launch.host_persist > 1);
         if (dg) {
             args.dg_P = dP; args.dg_mu = dmu; args.dg_KP = (int64_t)KP;
             { const char* e = getenv("NPHIP_DG_VARIANT"); args.dg_variant = e ? atoi(e) : 0; }

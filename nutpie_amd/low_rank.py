@@ -555,11 +555,14 @@ class LowRankSampler:
                         lam = torch.where(b[:, None], torch.ones_like(lam), lam)
                         V = torch.where(b[:, None, None], torch.zeros_like(V), V)
                 # only the columns some chain uses (estimate() puts a chain's used columns first): every column handed in costs
-                # every leapfrog of every chain a dot product and an update in both halves of the step
-                n_cols = (lam != 1.0).sum(1).cpu().numpy() if lam.numel() else np.zeros(len(grp), dtype=np.int64)   # (the one synchronisation)
+                # every leapfrog of every chain a dot product and an update in both halves of the step.  Counted on the host from one
+                # small copy (the one synchronisation; no torch kernel in the path of a hand-in without columns: a torch kernel's
+                # first launch in a process costs tens of milliseconds, which a 0.3 s job sees)
+                n_cols = (lam.cpu().numpy() != 1.0).sum(1) if lam.numel() else np.zeros(len(grp), dtype=np.int64)
                 k_used = int(n_cols.max()) if len(n_cols) else 0
                 has = n_cols > 0
-                V, lam = V[:, :k_used].contiguous(), lam[:, :k_used].contiguous()
+                if k_used:
+                    V, lam = V[:, :k_used].contiguous(), lam[:, :k_used].contiguous()
                 cols = float(n_cols.mean()) if k_used else 0.0
                 if cuda:
                     self._stream.synchronize()

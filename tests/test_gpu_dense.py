@@ -69,8 +69,12 @@ def test_unsymmetric_matrix_is_refused(hip):
     (100, 8, {"host_persist": 1}, "launch-per-evaluation"), (100, 8, {"host_persist": 1, "graph_steps": -1}, "launch-per-evaluation"),
     (37, 5, {"host_persist": 1}, "launch-per-evaluation"), (300, 70, {"host_persist": 1}, "launch-per-evaluation"),
     (100, 16, {"host_groups": 2}, "launch-per-evaluation"), (1100, 6, {}, "launch-per-evaluation"),
-    (100, 8, {}, "resident"), (37, 5, {}, "resident"), (100, 1, {}, "resident"), (300, 70, {"evals_per_launch": 7}, "resident"),
-    (1000, 6, {}, "resident"), (129, 1024, {}, "resident"), (257, 301, {"evals_per_launch": 64}, "resident"), (1024, 130, {}, "resident")])
+    (100, 8, {}, "resident"), (37, 5, {}, "resident"), (100, 1, {}, "resident"), (300, 70, {"evals_per_launch": 7, "host_persist": 2}, "resident"),
+    (1000, 6, {"host_persist": 2}, "resident"), (129, 1024, {}, "resident"), (257, 301, {"evals_per_launch": 64}, "resident"),
+    (1024, 130, {"host_persist": 2}, "resident"),
+    # (round 6: a job too small for its clusters — a member of a die-local cluster would compute three or more column tiles per round — takes
+    #  the launch-per-evaluation form by itself; host_persist = 2 above forces the resident form onto such shapes)
+    (1000, 6, {}, "launch-per-evaluation"), (1024, 130, {}, "launch-per-evaluation"), (300, 70, {}, "launch-per-evaluation")])
 def test_dense_gaussian_bit_identical_to_the_oracle(hip, oracle, dim, chains, launch, mode):
     """A whole job — warm-up with step-size search and mass-matrix adaptation, then sampling — against oracle.sample_dense."""
     P = dense_precision(dim, seed=5, cond_lo=0.1, cond_hi=10)

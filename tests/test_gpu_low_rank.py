@@ -295,20 +295,22 @@ def test_native_estimator_kernel_against_the_torch_formulation_and_the_cpu_oracl
     assert np.array_equal(s2w.cpu().numpy(), sig2) and np.array_equal(Vw.cpu().numpy(), V)
 
 
-def test_staged_metric_is_the_metric_handed_in_at_a_pause(hip):
+@pytest.mark.parametrize("dim,k,launch", [(48, 3, {}), (48, 0, dict(no_register_kernel=True)), (1300, 4, {}), (300, 11, {})])
+def test_staged_metric_is_the_metric_handed_in_at_a_pause(hip, dim, k, launch):
     """nphip_sampler_stage_metric: a chain that RUNS takes the parked metric at the end of the draw it is working on — the same job, bit
-    for bit, as one whose chains stop at that draw (pause draws) and are handed the metric there (nphip_sampler_set_metric)."""
-    dim, chains, tune, draws, k, seed = 48, 12, 60, 12, 3, 11
+    for bit, as one whose chains stop at that draw (pause draws) and are handed the metric there (nphip_sampler_set_metric).  One and two
+    waves per chain on the register-resident leaf, the memory-resident kernels, a metric without columns."""
+    chains, tune, draws, seed = 12, 60, 12, 11
     rng = np.random.default_rng(3)
     pauses = [20, 41]
     sig2, V, lam = random_metrics(rng, len(pauses), chains, dim, k)
     ar = ar1_gaussian(dim, rho=0.9, scales=np.exp(rng.normal(size=dim)))
     model = hip.TridiagGaussianModel(ar.diag, ar.offdiag)
     sig2 *= 0.05
-    want, W = run_engine_with_metrics(hip, model, pauses, sig2, V, lam, chains=chains, tune=tune, draws=draws, seed=seed)
+    want, W = run_engine_with_metrics(hip, model, pauses, sig2, V, lam, chains=chains, tune=tune, draws=draws, seed=seed, launch=launch)
     s = hip.PyNutsSettings.Diag(seed)
     s.update(num_tune=tune, num_draws=draws, num_chains=chains, low_rank_metric=True)
-    smp = hip.PySampler(s, model, manual=True, evals_per_launch=1)     # (one evaluation per launch: a chain's draw counter moves by at most one per look)
+    smp = hip.PySampler(s, model, manual=True, evals_per_launch=1, **launch)     # (one evaluation per launch: a chain's draw counter moves by at most one per look)
     nxt = np.zeros(chains, dtype=int)
     for _ in range(200000):
         done, _, _ = smp.step(1)
@@ -318,7 +320,7 @@ def test_staged_metric_is_the_metric_handed_in_at_a_pause(hip):
         for u, p in enumerate(pauses):
             grp = np.nonzero((nxt == u) & (d == p - 1) & (state == 0))[0]
             if len(grp):
-                assert smp.stage_metric(grp, sig2[u][grp], V[u][grp], lam[u][grp]) == len(grp)
+                assert smp.stage_metric(grp, sig2[u][grp], V[u][grp] if k else None, lam[u][grp] if k else None) == len(grp)
                 nxt[grp] = u + 1
     assert done and (nxt == len(pauses)).all()
     assert smp.waves_per_chain == W
@@ -330,7 +332,7 @@ def test_staged_metric_is_the_metric_handed_in_at_a_pause(hip):
         d, state = smp.chain_draws()
         if done or (d >= tune).all():
             break
-    assert smp.stage_metric(np.arange(chains), sig2[0], V[0], lam[0]) == 0
+    assert smp.stage_metric(np.arange(chains), sig2[0], V[0] if k else None, lam[0] if k else None) == 0
 
 
 @pytest.mark.parametrize("kind", ["fused", "host_callback"])
