@@ -805,7 +805,8 @@ static int choose_waves(uint64_t dim) {
     // 2048 < D <= 4096: register kernels with the LDS ring; 4096 < D <= 10240: lean register kernels, state in VGPRs + AGPRs.
     // Measured (profiles/r2_grid_b_lean_w8_vs_w4.txt, 1024 chains): 4 waves per chain beat 8 from D = 7000 up (10.2 vs 6.9 M
     // leapfrogs/s at D = 10 000: at 8 waves the 256-VGPR budget spills the state) and tie below.
-    if (dim <= 10240) return 4;
+    // 10240 < D <= 12288 (round 6): the same kernels with 21 .. 24 chunks per wave — they spill, and run 1.3 - 1.6 x the memory-resident ones
+    if (dim <= 12288) return 4;
     return 8;  // memory-resident kernels; measured at D = 10 000: W = 8 (5.5 M leapfrogs/s) beats 4 (5.0) and 16 (3.6)
 }
 
@@ -912,7 +913,7 @@ bool nphip_sampler::setup() {
         const int64_t per_wave = ((int64_t)((dim + 127) / 128) + W - 1) / W;
         if (W == 8 && per_wave >= 1 && per_wave <= 10) { lean_nc = (int)per_wave; args.ld = per_wave * W * 128; }
         // (experimental geometry: 4 waves per chain with the state spread over VGPRs + AGPRs, one wave per SIMD)
-        if (W == 4 && per_wave > 8 && per_wave <= 20) { lean_nc = (int)per_wave; args.ld = per_wave * W * 128; }
+        if (W == 4 && per_wave > 8 && per_wave <= 24) { lean_nc = (int)per_wave; args.ld = per_wave * W * 128; }   // (21 .. 24, round 6: the build spills and still beats the memory-resident kernels)
     }
     // host-callback models with several waves per chain (1024 < D <= 4096): the same padding, so that resident launches can
     // run them on the register-resident leaf (8 chunks per wave at most)

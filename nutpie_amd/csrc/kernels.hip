@@ -2605,7 +2605,7 @@ struct Machine {
     // whole summary fits (3 x 48 KB); above, the first KP chunks of p and KR chunks of rho of every wave do (D = 10 000: 18 of
     // the 20 chunks of p) and the rest goes through its P-slot as before.  Every wave touches only its own chunks: no barrier.
     // The LDS part is written back at a launch boundary (flush).
-    static constexpr int LR_FREE = (LEAN && W == 4) ? (163840 - 8192 - NVX * W * (NPHIP_CHUNK * 8)) / (W * (NPHIP_CHUNK * 8)) : 0;   // chunks per wave
+    static constexpr int LR_FREE = (LEAN && W == 4) ? (163840 - (NVX > 20 ? 12288 : 8192) - NVX * W * (NPHIP_CHUNK * 8)) / (W * (NPHIP_CHUNK * 8)) : 0;   // chunks per wave (the kernel's static LDS grows with the edge buffer: 8.1 KB at 20 chunks)
     static constexpr int KP = LR_FREE < 0 ? 0 : (LR_FREE < NVX ? LR_FREE : NVX);
     static constexpr int KR = (LR_FREE - KP) < 0 ? 0 : ((LR_FREE - KP) < NVX ? (LR_FREE - KP) : NVX);
     static constexpr bool LRING = KP > 0;
@@ -4011,7 +4011,7 @@ hipError_t launch_fam_mem(const Args& a, const Args* d_args, bool fused, int W, 
 static size_t lean_dyn_lds(const Args& a, int W) {
     size_t dyn = (size_t)a.ld * 8;
     if (W == 4) {
-        const long chunk_bytes = 4 * 1024, free_chunks = (163840 - 8192 - (long)a.reg_nv * chunk_bytes) / chunk_bytes;
+        const long chunk_bytes = 4 * 1024, free_chunks = (163840 - (a.reg_nv > 20 ? 12288 : 8192) - (long)a.reg_nv * chunk_bytes) / chunk_bytes;   // (= Machine::LR_FREE)
         dyn += (size_t)std::max(0l, std::min(free_chunks, 2l * a.reg_nv)) * chunk_bytes;
     }
     return dyn;
@@ -4019,7 +4019,7 @@ static size_t lean_dyn_lds(const Args& a, int W) {
 #define NPHIP_LAUNCH_LEAN(WW, NN) hipLaunchKernelGGL((k_advance<true, WW, NN, true>), g, b, dyn, st, d_args, a.max_evals, a.have_result, sl)
 
 #if NPHIP_HAS(1)
-// lean register-resident kernels, 4 waves per chain (4096 < D <= 10240): state spread over VGPRs + AGPRs (one wave per SIMD), 9..20
+// lean register-resident kernels, 4 waves per chain (4096 < D <= 12288): state spread over VGPRs + AGPRs (one wave per SIMD), 9..24
 // chunks per wave; one workgroup = one chain
 hipError_t launch_fam_lean4(const Args& a, const Args* d_args, hipStream_t st, const LaunchSlice sl) {
     const dim3 g((unsigned)sl.chain_n), b(256);
@@ -4043,6 +4043,14 @@ hipError_t launch_fam_lean4(const Args& a, const Args* d_args, hipStream_t st, c
         case 18: NPHIP_LAUNCH_LEAN(4, 18); break;
         case 19: NPHIP_LAUNCH_LEAN(4, 19); break;
         case 20: NPHIP_LAUNCH_LEAN(4, 20); break;
+        // 21 .. 24 chunks per wave (10 240 < D <= 12 288, round 6): the state no longer fits the 512 registers of a lane — 16 per chunk beside
+        // a working set of ~130 — and the build spills (22 chunks: 216 bytes of scratch per lane, 24: 456); still 1.6 x / 1.3 x the
+        // memory-resident kernels that ran these rows before (D = 11 264: 8.6 against 5.4 M leapfrogs/s, D = 12 000: 6.5 against 5.0;
+        // profiles/r6_lean4_beyond_20_chunks.txt)
+        case 21: NPHIP_LAUNCH_LEAN(4, 21); break;
+        case 22: NPHIP_LAUNCH_LEAN(4, 22); break;
+        case 23: NPHIP_LAUNCH_LEAN(4, 23); break;
+        case 24: NPHIP_LAUNCH_LEAN(4, 24); break;
 #endif
         default: return hipErrorInvalidValue;
     }

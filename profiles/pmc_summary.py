@@ -3,13 +3,16 @@ usage: python profiles/pmc_summary.py gpurun_out/pmc_<tag>/ [skip_first_n_dispat
 A negative second argument keeps only the LAST n dispatches of the kernel — the timed region of bench.py (its K timed launches
 come last: warm-up of the chains, W warm launches, K timed launches)."""
 import glob
+import os
 import sqlite3
 import sys
+
+KERNEL = os.environ.get("PMC_KERNEL", "k_advance")   # substring of the kernel's name (round 6: k_lr_estimate)
 
 d = sys.argv[1]
 skip = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 which = f"the last {-skip} dispatches" if skip < 0 else f"first {skip} dispatches skipped"
-print(f"# PMC counters for k_advance dispatches in {d} (mean per dispatch, {which})")
+print(f"# PMC counters for {KERNEL} dispatches in {d} (mean per dispatch, {which})")
 for f in sorted(glob.glob(d + "/*_results.db")):
     db = sqlite3.connect(f)
     cur = db.cursor()
@@ -18,7 +21,7 @@ for f in sorted(glob.glob(d + "/*_results.db")):
     ik, ic, iv, idp = cols.index("kernel_name") if "kernel_name" in cols else None, cols.index("counter_name"), cols.index("value"), cols.index("dispatch_id")
     agg = {}
     for r in rows:
-        if ik is not None and "k_advance" not in str(r[ik]):
+        if ik is not None and KERNEL not in str(r[ik]):
             continue
         agg.setdefault(r[ic], {}).setdefault(r[idp], 0.0)
         agg[r[ic]][r[idp]] += r[iv]

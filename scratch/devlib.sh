@@ -12,5 +12,6 @@ if [ -n "$3" ]; then SRC=kernels_variant_$1.hip; sed "$3" kernels.hip > $SRC; cm
 [ -f /tmp/dev_host.o ] && [ /tmp/dev_host.o -nt host.hip ] && [ /tmp/dev_host.o -nt engine_types.h ] || /opt/rocm/bin/hipcc $F -c host.hip -o /tmp/dev_host.o
 mkdir -p ../../scratch/libs
 [ -f linalg.o ] || /opt/rocm/bin/hipcc $F -c linalg.hip -o linalg.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../scratch/libs/$1.so /tmp/dev_$1_k.o /tmp/dev_host.o linalg.o -pthread
+[ -f lowrank_est.o ] || /opt/rocm/bin/hipcc $F -c lowrank_est.hip -o lowrank_est.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../scratch/libs/$1.so /tmp/dev_$1_k.o /tmp/dev_host.o linalg.o lowrank_est.o -pthread
 ls -la ../../scratch/libs/$1.so

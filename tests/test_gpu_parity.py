@@ -128,7 +128,10 @@ def test_engine_matches_committed_golden_vectors(hip, name):
                                        # the default geometry of BASELINE.json config 5
                                        (900, 8), (2000, 8), (4200, 8), (6000, 8), (7100, 8), (8192, 8), (10000, 8), (10240, 8),
                                        # lean kernels with 4 waves per chain (state in VGPRs + AGPRs), 9..20 chunks per wave
-                                       (4200, 4), (5000, 4), (7100, 4), (9000, 4), (10000, 4), (10240, 4)])
+                                       (4200, 4), (5000, 4), (7100, 4), (9000, 4), (10000, 4), (10240, 4),
+                                       # ... 21..24 chunks per wave (round 6: the state spills; the default geometry up to D = 12288), and the
+                                       # memory-resident kernels beyond
+                                       (10300, 4), (11264, 4), (12000, 4), (12288, 4), (12289, 8)])
 def test_correlated_gaussian_all_geometries(hip, oracle, dim, waves):
     rng = np.random.default_rng(dim)
     sd = np.exp(0.7 * rng.normal(size=dim))
@@ -260,7 +263,8 @@ DIV_KEYS = ("divergence_start", "divergence_end", "divergence_momentum", "diverg
     (2600, 4, dict(evals_per_launch=9)),
     (5000, 0, {}),                                       # lean register kernels, 4 / 8 waves per chain
     (5000, 8, dict(evals_per_launch=11)),
-    (11000, 0, {}),                                      # memory-resident, 8 waves per chain
+    (11000, 0, {}),                                      # lean, 22 chunks per wave (spilling build)
+    (13000, 0, {}),                                      # memory-resident, 8 waves per chain
 ])
 def test_divergence_records_bit_identical(hip, oracle, dim, waves, launch):
     # store_divergences (python/nutpie/sample.py:631-650, tests/test_pymc.py:303-349): the state a failed leapfrog started from
