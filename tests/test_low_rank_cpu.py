@@ -257,3 +257,80 @@ def test_estimator_ignores_a_window_with_non_finite_entries():
     assert torch.equal(got.stds[1], torch.ones(7, dtype=torch.float64)) and not got.d[1].any() and not got.V[1].any()
     sig2, V, lam = lr.metric_of(got)
     assert torch.isfinite(sig2).all() and torch.isfinite(V).all() and torch.isfinite(lam).all()
+
+
+def test_basis_pick_is_what_estimate_thins_to():
+    from nutpie_amd import low_rank as lr
+
+    assert np.array_equal(lr.basis_pick(20, 32), np.arange(20)) and np.array_equal(lr.basis_pick(40, None), np.arange(40))
+    p = lr.basis_pick(100, 32)
+    assert len(p) == 32 and p[0] == 0 and p[-1] == 99 and (np.diff(p) >= 3).all()      # evenly thinned, ends included
+    # (the rule of the estimator kernel's C-ABI: rint(t (m - 1) / (b - 1)) — numpy's linspace + round-half-even)
+    assert np.array_equal(p, np.rint(np.arange(32) * (99 / 31)).astype(np.int64))
+
+
+def test_estimate_window_on_the_cpu_is_estimate_on_the_window():
+    """estimate_window (the driver's entry: the kernel on the GPU) falls back to estimate() + metric_of() where there is no kernel."""
+    from nutpie_amd import low_rank as lr
+
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(5, 90, 12, generator=g, dtype=torch.float64)
+    x[:, :, 0] *= 20.0
+    gx = -x * torch.exp(torch.randn(12, generator=g, dtype=torch.float64))
+    s2, V, lam = lr.estimate_window(x, gx, [3, 1], 10, 70, 1e-5, 2.0, basis_draws=32)
+    want = lr.metric_of(lr.estimate(x[[3, 1], 10:70], gx[[3, 1], 10:70], 1e-5, 2.0, basis_draws=32))
+    for a, b in zip((s2, V, lam), want):
+        assert torch.equal(a, b)
+
+
+def test_driver_releases_chains_that_need_no_low_rank_part():
+    """A chain on its own diagonal metric whose window shows nothing outside the cutoff is RELEASED (it goes on adapting that metric
+    itself); a chain that needs columns is handed the metric, and from then on is handed one at every boundary."""
+    from nutpie_amd import low_rank as lr
+
+    n, total, dim = 4, 200, 6
+    schedule = [(60, 20), (120, 60)]
+    pauses = [p for p, _ in schedule]
+
+    class Engine(_FakeEngine):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            self.released = []
+
+        def release(self, chains):
+            chains = np.asarray(chains)
+            assert self.waiting[chains].all()
+            for c in chains:
+                self.released.append((int(c), int(self.at[c])))
+                self.passed[c] += 1
+                self.waiting[c] = False
+
+    eng = Engine(n, total, dim, pauses, speed=[30, 30, 20, 30])
+    # chain 0: two dimensions correlated at 0.995 — after the diagonal scaling one direction stays far outside the cutoff in every window
+    Sigma = torch.eye(dim, dtype=torch.float64)
+    Sigma[0, 1] = Sigma[1, 0] = 0.995
+    z = torch.randn(total, dim, generator=torch.Generator().manual_seed(9), dtype=torch.float64)
+    eng.draws[0] = z @ torch.linalg.cholesky(Sigma).T
+    eng.grads[0] = -torch.linalg.solve(Sigma, eng.draws[0].T).T
+
+    class Driver(lr.LowRankSampler):
+        def _views(self):
+            return self._inner.draws, self._inner.grads
+
+        def _n_steps(self):
+            return torch.ones(n, total, dtype=torch.int64)
+
+    smp = Driver(eng, 0, 1e-5, 2.0, schedule)
+    smp.wait(timeout_seconds=120)
+    handed = {c for _, c, _, _, _ in eng.log}
+    rel = {c for c, _ in eng.released}
+    assert smp.is_finished() and handed | rel == set(range(n))
+    for c in range(n):
+        k_at = [lr.metric_of(lr.estimate(eng.draws[c:c + 1, lo:hi], eng.grads[c:c + 1, lo:hi], 1e-5, 2.0, basis_draws=lr.basis_draws_for(dim)))[2] for hi, lo in schedule]
+        needs = [bool((k != 1.0).any()) for k in k_at]
+        got_metric = sorted(at for _, cc, at, _, _ in eng.log if cc == c)
+        got_release = sorted(at for cc, at in eng.released if cc == c)
+        # handed a metric from the first boundary that needs one on; released before that
+        first = needs.index(True) if True in needs else len(needs)
+        assert got_release == pauses[:first] and got_metric == pauses[first:], (c, needs, got_release, got_metric)
+    assert 0 in handed       # (the test is not vacuous: chain 0 needs columns)
