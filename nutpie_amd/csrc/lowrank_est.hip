@@ -6,13 +6,17 @@
 //
 // Why a kernel of its own (round 6): the torch formulation is ~150 launches plus four batched eigendecompositions whose QL recurrence is
 // one wave's sequential work — 7 ms per hand-in whether one chain has stopped or 240, while a 512-chain radon job covers 8 draws per
-// millisecond: the warm-up's six hand-ins cost more than the warm-up.  Here: one workgroup per chain, everything between the window in
-// the trace and (sigma^2, V, lambda) in LDS —
+// millisecond: the warm-up's six hand-ins cost more than the warm-up.  Here: one workgroup per chain (or several chains in turn: the
+// launch is capped at the CUs a running engine kernel leaves idle), everything between the window in the trace and (sigma^2, V, lambda)
+// in LDS —
 //   moments over the window -> scaled basis rows Z (never materialised: rebuilt from the trace where needed) -> Gram matrix ->
-//   orthonormal basis of the span (eigenvectors of the Gram matrix) -> projected covariances Cx, Cg -> their geometric mean in the
-//   eigenbasis of Cg -> its spectrum, re-centred on the median -> the k_max directions furthest from 1 outside [1 / cutoff, cutoff]
-// — with the four symmetric eigenproblems solved by a one-sided Jacobi method (Hestenes): 32 column pairs per step rotate in
-// parallel, 8 lanes per pair, one barrier per step; no sequential recurrence anywhere.
+//   its PIVOTED CHOLESKY factor L, whose rows are the basis rows in an orthonormal basis Q of their span (Z_perm = L Q') ->
+//   projected covariances Cx, Cg from the rows of L -> CHOLESKY Cg = R R' -> the geometric mean S = R^-T (R' Cx R)^1/2 R^-1 ->
+//   its spectrum, re-centred on the median -> the k_max directions furthest from 1 outside [1 / cutoff, cutoff] -> V = Z_perm' L^-T W_sel
+// — with the two symmetric eigenproblems that are left (the square root, the spectrum of S) solved by a one-sided Jacobi method
+// (Hestenes): 32 column pairs per step rotate in parallel, 16 lanes per pair (one DPP row), one barrier per step; no sequential
+// recurrence anywhere.  (The first build solved four eigenproblems — Gram matrix and Cg too: 55 Jacobi sweeps per chain instead of 24;
+// DESIGN.md 10.1 has the history and the numbers.)
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
