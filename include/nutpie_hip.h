@@ -273,7 +273,8 @@ int nphip_sampler_resume_at(nphip_sampler_t*, uint64_t n, const uint64_t* local_
  * from then on.  Until the first call a chain runs on the diagonal metric it adapts itself, exactly as without the setting.
  * Manual-mode samplers only.  Every named chain must be stopped at a pause draw (nphip_sampler_waiting): chains that are not keep
  * their metric and the call returns an error naming how many (the stopped ones among them have taken the new one).  The window
- * estimator that produces (sigma2, V, lambda) lives above the C-ABI (nutpie_amd/low_rank.py).  The engine keeps V in SINGLE precision
+ * estimator that produces (sigma2, V, lambda): nphip_low_rank_estimate below (round 6; before that, and for shapes it does not cover,
+ * above the C-ABI: nutpie_amd/low_rank.py::estimate).  The engine keeps V in SINGLE precision
  * (rounded to nearest on receipt; all arithmetic on it is fp64): the metric applied is that of the rounded columns. */
 int nphip_sampler_set_metric(nphip_sampler_t*, uint64_t n, const uint64_t* local_chains, uint64_t k, const double* sigma2, const double* V,
                              const double* lambda, int on_device);

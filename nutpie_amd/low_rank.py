@@ -11,12 +11,14 @@ kernels apply ``v = M^-1 p`` in the leapfrog, draw ``p ~ N(0, M)`` and carry the
 (``kernels.hip``: ``lf1`` / ``lf2`` / ``sample_momentum_lr`` / ``turning``; round 4: also the register-resident leaf, ``Machine<..., LR>``
 — fused models up to D = 4096 and compiled densities; the oracle restates the same arithmetic and the two are
 compared bit for bit, tests/test_gpu_low_rank.py) — for EVERY model flavour: fused, raw C callbacks, BridgeStan, device
-callbacks, runtime-compiled densities.  What stays above the C-ABI is the window ESTIMATOR, below: chains stop between two
-draws at the window boundaries (``nphip_settings_set_pause_draws``), the host estimates every chain's ``(sigma^2, V, lambda)``
-from the window's draws and gradients — batched eigendecompositions on the GPU (the engine's ``nphip_batched_eigh`` up to order 64,
-rocSOLVER above), the chains that have stopped at once, on a worker thread while the others run — hands it to the engine
-(``nphip_sampler_set_metric``) and the chains go on from where they are, through a new step-size search, as nuts-rs does when
-the mass matrix changes.  The estimator follows the published description (Seyboldt et al., "Preconditioning Hamiltonian Monte
+callbacks, runtime-compiled densities.  The DRIVER of the adaptation is here: chains stop between two draws at the window
+boundaries (``nphip_settings_set_pause_draws``), every stopped chain's ``(sigma^2, V, lambda)`` is estimated from the window's
+draws and gradients — round 6: by ONE kernel below the C-ABI (``nphip_low_rank_estimate``, nutpie_amd/csrc/lowrank_est.hip: a
+workgroup per chain, straight out of the engine's trace) for models of up to 256 dimensions; above that by :func:`estimate`,
+the torch formulation the kernel restates (batched eigendecompositions on the engine's ``nphip_batched_eigh`` up to order 64,
+rocSOLVER above) —, on a worker thread while the other chains run, and handed to the engine (``nphip_sampler_set_metric``);
+the chains go on from where they are, through a new step-size search, as nuts-rs does when the mass matrix changes.  A chain
+that needs no low-rank part and still adapts its own diagonal is released unchanged (``nphip_sampler_release``).  The estimator follows the published description (Seyboldt et al., "Preconditioning Hamiltonian Monte
 Carlo by minimizing Fisher divergence"); the crate is not in the tree — PARITY UNPINNED, like the rest of the sampler.
 
 (Round 2 obtained the same sampler as a linear re-parametrisation around the density — ``y = L^-1 (x - m)`` with the engine's
