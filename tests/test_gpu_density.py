@@ -249,3 +249,38 @@ def test_low_rank_job_is_reproducible_from_its_seed(hip):
     # and no chain is handed a metric it cannot integrate under (a singular geometric mean used to give lambda = 1e-300: NaN energies
     # and a diverging draw after draw until the next boundary — low_rank.estimate clamps the spectrum to its exact bounds)
     assert np.isfinite(a.warmup_sample_stats["energy"].values).all()
+
+
+def test_released_chains_of_a_compiled_density_go_on_unchanged(hip):
+    """nphip_sampler_release on the resident kernel of a compiled density (what the low-rank driver does with every chain of a model
+    that needs no low-rank part): pauses + release = the job without pauses, bit for bit."""
+    import sys
+
+    sys.path.insert(0, os.path.dirname(__file__))
+    import symbolic_models as zoo
+
+    m = zoo.ALL["radon"]().compile()
+    chains, tune, draws = 12, 50, 12
+
+    def run(pauses):
+        s = hip.PyNutsSettings.LowRank(5)
+        s.update(num_tune=tune, num_draws=draws, num_chains=chains, low_rank_metric=True, store_gradient=True)
+        if pauses:
+            s.set_pause_draws(pauses)
+        smp = m._make_sampler(s, None, 1, None, None, None, None, manual=True, evals_per_launch=40)
+        released = 0
+        for _ in range(100000):
+            done, _, _ = smp.step(1)
+            if done:
+                break
+            w = np.nonzero(smp.waiting())[0]
+            if len(w):
+                smp.release(w)
+                released += len(w)
+        assert done and released == len(pauses) * chains
+        return smp.take_results()
+
+    got, want = run([9, 31, 32]), run([])
+    assert np.array_equal(got.draws, want.draws)
+    for k in ("n_steps", "depth", "energy", "step_size", "logp", "diverging"):
+        assert np.array_equal(np.asarray(got.stats[k]), np.asarray(want.stats[k])), k
