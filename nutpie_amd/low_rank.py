@@ -530,7 +530,10 @@ class LowRankSampler:
         if cuda:
             torch.cuda.set_device(self._device)
             if self._stream is None:
-                self._stream = torch.cuda.Stream(self._device)
+                # a HIGH-PRIORITY stream: streams of one priority share the device's few hardware queues round-robin, and an estimator
+                # stream that lands on the engine stream's queue serialises every estimate with the launch it should run beside
+                # (measured, scratch/r6_lr_outliers.py: two jobs of ten took 0.44 s instead of 0.33, every hand-in twice as long)
+                self._stream = torch.cuda.Stream(self._device, priority=-1)
         with torch.no_grad(), (torch.cuda.stream(self._stream) if cuda else contextlib.nullcontext()):
             n_steps = None
             for i in np.unique(at):
