@@ -2359,6 +2359,11 @@ struct Machine {
         X.reg_p = newp;
         X.dirty_qg = true;
         X.dirty_pr = true;
+        // (Measured and rejected in round 6, profiles/r6_headline_merge_operand_prefetch_rejected.txt: fetching the operands of the level >= 2 merges this
+        // leaf closes ahead of their use, from here — into 128 accumulation registers (a vector load can target them on gfx950): the allocator's own spills
+        // overflow into scratch, 5 x slower; one touch per cache line into one register, or into LDS by the memory-to-LDS loads (no register at all): the
+        // merges' loads then hit L2 and the level >= 1 checks cost 125 cycles per leaf less, of 2 k — they are issue, not latency — while the control flow
+        // added to this block costs the leapfrog's schedule 240: 209 against 217 M leapfrogs/s.)
         // the two most recent summaries a level-1 merge needs stay on chip
         if (!LR && !NORING) {
             if ((j & 3) == 1) { ring_write(0, X.p, X.r); X.ring_leaf0 = j; }
