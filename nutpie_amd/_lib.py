@@ -260,6 +260,7 @@ class PyNutsSettings:
         s = PyNutsSettings.Diag(seed)
         object.__setattr__(s, "_adaptation", "low_rank")
         object.__setattr__(s, "_low_rank", {"mass_matrix_eigval_cutoff": 100.0, "mass_matrix_gamma": 1e-5})
+        s.mass_matrix_update_freq = 10   # the low-rank default (recalled); a value the user sets afterwards — 1 included — is the schedule's
         return s
 
     @staticmethod

@@ -339,11 +339,10 @@ def estimate_window(draws, grads, chains, lo: int, hi: int, gamma: float, cutoff
 
 
 def schedule_of(settings):
-    """:func:`window_schedule` from a settings object (the keys of ``src/wrapper.rs:198-240``; ``mass_matrix_update_freq`` keeps the
-    engine's default of 1 unless set: the low-rank default of 10 applies then)"""
-    upd = int(settings.mass_matrix_update_freq)
+    """:func:`window_schedule` from a settings object (the keys of ``src/wrapper.rs:198-240``; ``PyNutsSettings.LowRank`` sets
+    ``mass_matrix_update_freq`` to its low-rank default of 10, and whatever the user sets afterwards — 1 included — is used as given)"""
     return window_schedule(int(settings.num_tune), float(settings.early_window), float(settings.step_size_window), int(settings.mass_matrix_switch_freq),
-                           int(settings.early_window_switch_freq), upd if upd > 1 else 10)
+                           int(settings.early_window_switch_freq), max(1, int(settings.mass_matrix_update_freq)))
 
 
 def pause_draws(num_tune: int):
@@ -677,7 +676,9 @@ def make_sampler(compiled_model, settings, init_mean, cores, progress_type, extr
     schedule = schedule_of(settings)
     pauses = [p for p, _ in schedule]
     inner_settings = settings.clone()
-    inner_settings.update(low_rank_metric=True, store_gradient=True)   # the estimator needs the gradients of the window's draws
+    # (the estimator needs the gradients of the window's draws; ``mass_matrix_update_freq`` paces the ESTIMATES — the engine's own diagonal part
+    # is refreshed with every draw, as before the key had a low-rank default)
+    inner_settings.update(low_rank_metric=True, store_gradient=True, mass_matrix_update_freq=1)
     inner_settings.set_pause_draws(pauses)
     device = int(engine_kw.get("device", 0) or 0)
     inner = compiled_model._make_sampler(inner_settings, init_mean, cores, progress_type, extra_callback, extra_callback_rate, store,

@@ -110,6 +110,23 @@ def test_window_schedule_follows_the_reference_keys():
     assert lr.window_schedule(10) == []
 
 
+def test_schedule_of_takes_the_update_frequency_as_set():
+    """``mass_matrix_update_freq`` (src/wrapper.rs:307-334): LowRank settings carry its low-rank default (10), and a value the user sets —
+    1 included — is the schedule's (an explicit 1 used to be read as "unset")."""
+    from nutpie_amd import _lib as hip
+    from nutpie_amd import low_rank as lr
+
+    s = hip.PyNutsSettings.LowRank(1)
+    s.update(num_tune=400)
+    assert s.mass_matrix_update_freq == 10
+    assert lr.schedule_of(s) == lr.window_schedule(400) == lr.window_schedule(400, update_freq=10)
+    s.mass_matrix_update_freq = 1
+    assert lr.schedule_of(s) == lr.window_schedule(400, update_freq=1)
+    s.mass_matrix_update_freq = 25
+    assert lr.schedule_of(s) == lr.window_schedule(400, update_freq=25)
+    assert hip.PyNutsSettings.Diag(1).mass_matrix_update_freq == 1
+
+
 def test_estimator_uses_every_draw_for_the_diagonal_and_a_thinned_basis_for_the_columns():
     from nutpie_amd import low_rank as lr
 
