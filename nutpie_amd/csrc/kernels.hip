@@ -2074,7 +2074,13 @@ struct Machine {
         uint32_t used_base, sub_used, draw;
         bool check;                           // U-turn criteria apply in this doubling
         double step, H0, acc, acc_sym, max_ee;
+        int32_t end_code;                     // leaf_reg: how the draw ended (end_code), for the one call of rare_end_draw behind the run of leaves
     };
+    // The leaf does not call the out-of-line end of a draw itself: it says how the draw ended, and run() makes the ONE call behind the loop of leaves,
+    // where nothing of the leaf's state is alive (a call in the middle of the leaf pins what is alive there to the registers its callee leaves alone).
+    static __device__ __forceinline__ int32_t end_code(bool diverging, bool maxdepth, bool store_div, bool div_has_end, bool regrad, bool replay) {
+        return 1 | (diverging ? 2 : 0) | (maxdepth ? 4 : 0) | (store_div ? 8 : 0) | (div_has_end ? 16 : 0) | (regrad ? 32 : 0) | (replay ? 64 : 0);
+    }
     static __device__ __forceinline__ int32_t rfl(int64_t v) { return __builtin_amdgcn_readfirstlane((int)v); }
     static __device__ __forceinline__ double rfl_f64(double v) {
         return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
@@ -2406,7 +2412,7 @@ struct Machine {
                 H.acc_sym += 2.0 * a / (1.0 + e);
             }
         }
-        if (diverged) { X.dirty_qg = X.dirty_pr = false; hot_save(H); rare_end_draw(A, c, red, chain, true, false, FUSED, ok, !REMOTE, FUSED); return true; }
+        if (diverged) { X.dirty_qg = X.dirty_pr = false; hot_save(H); H.end_code = end_code(true, false, FUSED, ok, !REMOTE, FUSED); return true; }
 #ifdef NPHIP_PROFILE
         int64_t tq = (int64_t)__builtin_readcyclecounter();
         c->prof[8] += tq - tp2;
@@ -2460,7 +2466,7 @@ struct Machine {
                         turn = sub_b(X, obp, obr);
                     }
                 }
-                if (turn) { X.dirty_qg = X.dirty_pr = false; hot_save(H); rare_end_draw(A, c, red, chain, false, false, false, false, !REMOTE); return true; }
+                if (turn) { X.dirty_qg = X.dirty_pr = false; hot_save(H); H.end_code = end_code(false, false, false, false, !REMOTE, false); return true; }
             }
 #ifdef NPHIP_PROFILE
             { const int64_t t_ = (int64_t)__builtin_readcyclecounter(); c->prof[k == 0 ? 9 : 10] += t_ - tq; tq = t_; }
@@ -2535,8 +2541,8 @@ struct Machine {
             c->depth = d + 1;
         }
         store_state(X, true, true);  // a new trajectory end is always written back
-        if (turn) { hot_save(H); rare_end_draw(A, c, red, chain, false, false, false, false, !REMOTE); return true; }
-        if (H.depth >= A.s.maxdepth) { hot_save(H); rare_end_draw(A, c, red, chain, false, true, false, false, !REMOTE); return true; }
+        if (turn) { hot_save(H); H.end_code = end_code(false, false, false, false, !REMOTE, false); return true; }
+        if (H.depth >= A.s.maxdepth) { hot_save(H); H.end_code = end_code(false, true, false, false, !REMOTE, false); return true; }
         start_doubling_hot(H);
         return false;
     }
@@ -3768,6 +3774,7 @@ struct Machine {
             Hot H;        // register-resident kernels (leaf_reg): the control words of the leaf loop
             constexpr bool HOT = NV > 0;
             if (HOT) hot_load(H);
+            H.end_code = 0;
             bool rare = false, out_of_budget = false;
             int lean_end = 0;
             const LeanRs lrs = lean_rs();
@@ -3833,6 +3840,10 @@ struct Machine {
                 flush(X);
             }
             sig_lds = nullptr;
+            if (HOT && !LEAN && H.end_code != 0) {
+                const int32_t ec = H.end_code;
+                rare_end_draw(A, c, red, chain, (ec & 2) != 0, (ec & 4) != 0, (ec & 8) != 0, (ec & 16) != 0, (ec & 32) != 0, (ec & 64) != 0);
+            }
             if (LEAN && lean_end != 0) rare_end_draw(A, c, red, chain, lean_end == 1 || lean_end == 4, lean_end == 3, lean_end == 1 || lean_end == 4, lean_end == 1, true, true);
             if (out_of_budget) break;
         }

@@ -449,7 +449,7 @@ def test_radon_device_callback_against_the_oracle(radon_device_lib, oracle):
         host.radon_host_free(hh)
 
 
-def _two_rank_worker(rank, world, port, out_path):
+def _two_rank_worker(rank, world, port, out_path, backend="nccl", one_gpu=False):
     import sys
 
     import torch
@@ -462,19 +462,23 @@ def _two_rank_worker(rank, world, port, out_path):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(rank)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    dev = 0 if one_gpu else rank
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
     try:
         diag = np.linspace(0.5, 3.0, 300)
 
         def make(offset, n_local):
             s = _lib.PyNutsSettings.Diag(8)
             s.update(num_tune=60, num_draws=20, num_chains=10)
-            return _lib.PySampler(s, _lib.TridiagGaussianModel(diag), device=rank, chain_offset=offset, n_local_chains=n_local)
+            return _lib.PySampler(s, _lib.TridiagGaussianModel(diag), device=dev, chain_offset=offset, n_local_chains=n_local)
 
-        smp, got = sample_sharded(make, 10, thin=2, stats=("n_steps", "depth", "step_size"), device=rank, moments_after=60)
+        smp, got = sample_sharded(make, 10, thin=2, stats=("n_steps", "depth", "step_size"), device=dev, moments_after=60)
         if rank == 0:
-            np.savez(out_path, **{k: v.cpu().numpy() for k, v in got.items()})
+            np.savez(out_path, **{k: (v.cpu().numpy() if hasattr(v, "cpu") else np.asarray(v)) for k, v in got.items()})
         dist.barrier()
         smp.close()
     finally:
@@ -504,6 +508,34 @@ def test_two_rank_rccl_sharding_matches_the_single_gpu_job(tmp_path):
     smp = _lib.PySampler(s, _lib.TridiagGaussianModel(np.linspace(0.5, 3.0, 300)))
     smp.wait()
     full = smp.take_results()
+    assert np.array_equal(got["draws"], full.draws[:, ::2])
+    for k in ("n_steps", "depth", "step_size"):
+        assert np.array_equal(got[k], np.asarray(full.stats[k])), k
+    np.testing.assert_allclose(got["draw_mean"], full.draws[:, 60:].mean(1), rtol=1e-12, atol=1e-14)
+
+
+def test_three_ranks_on_one_gpu_shard_the_job_chain_for_chain(tmp_path):
+    """What the one-GPU test box CAN run of the multi-GPU path with the real engine: three processes (ragged shards of 4 + 3 + 3 chains), each
+    with its own sampler on the same device, chains keyed by their GLOBAL id, the trace gathered to rank 0 (gloo: RCCL refuses two ranks on
+    one GPU) — equal to the one-process job chain for chain.  The RCCL form of the same run is the test above."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    from nutpie_amd import _lib
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    out = str(tmp_path / "three_rank.npz")
+    mp.spawn(_two_rank_worker, args=(3, port, out, "gloo", True), nprocs=3, join=True)
+    got = np.load(out)
+    s = _lib.PyNutsSettings.Diag(8)
+    s.update(num_tune=60, num_draws=20, num_chains=10)
+    smp = _lib.PySampler(s, _lib.TridiagGaussianModel(np.linspace(0.5, 3.0, 300)))
+    smp.wait()
+    full = smp.take_results()
+    assert got["draws"].shape == (10, 40, 300)
     assert np.array_equal(got["draws"], full.draws[:, ::2])
     for k in ("n_steps", "depth", "step_size"):
         assert np.array_equal(got[k], np.asarray(full.stats[k])), k
