@@ -675,6 +675,9 @@ struct Machine {
     // waves per chain the waves of a chain overlap each other's round trips and the extra code costs more than it saves (these
     // kernels run every path once per launch: measured at D = 1000, 8 waves per chain, 84 -> 137 us per launch).
     static constexpr bool BATCHED = (W == 1);
+    // The vector passes of a draw's end (gradient of the new draw, trace rows, momentum) with the reads of four chunks in flight: the kernels that run
+    // many steps per launch (the extra code is off their hot path; the launch-per-evaluation kernels run every path once per launch and keep the loops).
+    static constexpr bool PFRARE = INK;
     template <class LoadT, class BodyT>
     __device__ __forceinline__ void chunks(LoadT load, BodyT body) const {
         if (nch > 2) chunks_pf<4>(load, body);
@@ -930,8 +933,7 @@ struct Machine {
         double* p = P(kSlotInit);
         double* r = R(kSlotInit);
         double2 acc = {0.0, 0.0};
-        NPHIP_FOR_CHUNKS(i) {
-            double2 s2 = ld2(sig2, i);
+        auto one = [&](int64_t i, const double2& s2) {
             double2 v = {0.0, 0.0};
             if (i < D) {
                 double z0, z1;
@@ -944,7 +946,10 @@ struct Machine {
             if (lr_job()) { double2 vel; vel.x = s2.x * v.x; vel.y = s2.y * v.y; st2(VEL(kSlotInit), i, vel); }
             acc.x = fma(v.x, s2.x * v.x, acc.x);
             acc.y = fma(v.y, s2.y * v.y, acc.y);
-        }
+        };
+        // (PFRARE: sigma^2 of four chunks read ahead — a read behind the stores of the chunk before waits for them to complete)
+        if (PFRARE) chunks_pf<4>([&](int64_t i) { return ld2(sig2, i); }, one);
+        else NPHIP_FOR_CHUNKS(i) one(i, ld2(sig2, i));
         double a = acc.x + acc.y, b = 0.0;
         rsum2(a, b);
         return 0.5 * a;
@@ -1017,21 +1022,36 @@ struct Machine {
         if (FUSED) chain_sync<W>();  // the fused model reads neighbouring elements of q'
     }
 
-    // Fused tridiagonal-Gaussian gradient for the pair at i (nphip model contract).
-    __device__ __forceinline__ void tridiag_pair(const double* q, int64_t i, double2& z, double2& g) const {
-        double2 q2 = ld2(q, i), mu = ld2(A.m_mu, i), a = ld2(A.m_a, i), b = ld2(A.m_b, i);
-        z.x = q2.x - mu.x;
-        z.y = q2.y - mu.y;
-        double tx = a.x * z.x;
-        if (i > 0) tx = fma(ld1(A.m_b, i - 1), ld1(q, i - 1) - ld1(A.m_mu, i - 1), tx);
-        if (i + 1 < D) tx = fma(b.x, z.y, tx);
-        double ty = a.y * z.y;
-        ty = fma(b.x, z.x, ty);
-        if (i + 2 < D) ty = fma(b.y, ld1(q, i + 2) - ld1(A.m_mu, i + 2), ty);
+    // Fused tridiagonal-Gaussian gradient for the pair at i (nphip model contract): what it reads, and what it computes from that.
+    // Every read is unconditional (the neighbours' indices clamped, their terms taken or not by a select: the same operations on the same values) — a
+    // read behind a lane's condition is a block of its own with its own wait: three round trips to memory per chunk instead of one (round 6: 32 k
+    // cycles per draw for the gradient of the new draw at D = 1000).  Apart, so that a pass can have the reads of several chunks in flight (PFRARE).
+    struct TriIn { double2 q, mu, a, b; double bm, qm, mum, qp, mup; };
+    __device__ __forceinline__ TriIn tridiag_load(const double* q, int64_t i) const {
+        TriIn v;
+        const int64_t im = i > 0 ? i - 1 : 0, ip = i + 2 < D ? i + 2 : i;
+        v.q = ld2(q, i); v.mu = ld2(A.m_mu, i); v.a = ld2(A.m_a, i); v.b = ld2(A.m_b, i);
+        v.bm = ld1(A.m_b, im); v.qm = ld1(q, im); v.mum = ld1(A.m_mu, im);
+        v.qp = ld1(q, ip); v.mup = ld1(A.m_mu, ip);
+        return v;
+    }
+    __device__ __forceinline__ void tridiag_eval(const TriIn& v, int64_t i, double2& z, double2& g) const {
+        z.x = v.q.x - v.mu.x;
+        z.y = v.q.y - v.mu.y;
+        double tx = v.a.x * z.x;
+        const double tx1 = fma(v.bm, v.qm - v.mum, tx);
+        tx = (i > 0) ? tx1 : tx;
+        const double tx2 = fma(v.b.x, z.y, tx);
+        tx = (i + 1 < D) ? tx2 : tx;
+        double ty = v.a.y * z.y;
+        ty = fma(v.b.x, z.x, ty);
+        const double ty1 = fma(v.b.y, v.qp - v.mup, ty);
+        ty = (i + 2 < D) ? ty1 : ty;
         g.x = -tx;
         g.y = (i + 1 < D) ? -ty : 0.0;
         if (i >= D) g.x = 0.0;
     }
+    __device__ __forceinline__ void tridiag_pair(const double* q, int64_t i, double2& z, double2& g) const { tridiag_eval(tridiag_load(q, i), i, z, g); }
 
     // Position-only evaluation (initial point).  FUSED: compute; callback: copy staged gradient.
     __device__ void eval_position(int64_t buf, double& lp, int64_t& code) {
@@ -1039,13 +1059,15 @@ struct Machine {
         if (FUSED) {
             const double* q = Q(buf);
             double2 acc = {0.0, 0.0};
-            NPHIP_FOR_CHUNKS(i) {
+            auto one = [&](int64_t i, const TriIn& v) {
                 double2 z, gg;
-                tridiag_pair(q, i, z, gg);
+                tridiag_eval(v, i, z, gg);
                 st2(g, i, gg);
                 acc.x = fma(z.x, gg.x, acc.x);
                 acc.y = fma(z.y, gg.y, acc.y);
-            }
+            };
+            if (PFRARE) chunks_pf<4>([&](int64_t i) { return tridiag_load(q, i); }, one);
+            else NPHIP_FOR_CHUNKS(i) one(i, tridiag_load(q, i));
             double a = acc.x + acc.y, b = 0.0;
             rsum2(a, b);
             lp = 0.5 * a;
@@ -3192,35 +3214,57 @@ struct Machine {
         const size_t row = ((size_t)chain * T + draw) * D;
         const int64_t efg = c->fg, ebg = 1 - c->fg;
         const int64_t esrc = do_switch ? ebg : efg;
-        NPHIP_FOR_CHUNKS(i) {
-            double2 q2 = ld2(q, i), g2 = ld2(g, i);
+        // What the pass reads of a chunk, and what it does with it — apart, so that PFRARE has the reads of four chunks in flight ahead of their stores:
+        // the plain loop waits for the stores of a chunk to COMPLETE before the next read returns (loads and stores share a counter, and a load cannot
+        // pass a store to the same pool): three round trips to memory per chunk, 80 - 90 k cycles per warm-up draw at D = 1000 (round 6).
+        struct PassIn { double2 q, g, s, f[4], b[4]; };
+        const bool want_s = do_update || A.tr_mm != nullptr;
+        auto rd = [&](int64_t i) {
+            PassIn v;
+            v.q = ld2(q, i); v.g = ld2(g, i);
+            if (do_add) {
+                if (n_fg != 1) { v.f[0] = ld2(EST(efg, 0), i); v.f[1] = ld2(EST(efg, 1), i); v.f[2] = ld2(EST(efg, 2), i); v.f[3] = ld2(EST(efg, 3), i); }
+                if (n_bg != 1) { v.b[0] = ld2(EST(ebg, 0), i); v.b[1] = ld2(EST(ebg, 1), i); v.b[2] = ld2(EST(ebg, 2), i); v.b[3] = ld2(EST(ebg, 3), i); }
+            } else if (do_update) {
+                v.f[1] = ld2(EST(esrc, 1), i);
+                v.f[3] = ld2(EST(esrc, 3), i);
+            }
+            if (want_s) v.s = ld2(sig2, i);
+            return v;
+        };
+        // one estimator takes the draw in (Welford): -> its sums of squares (q, grad)
+        auto welford = [&](int64_t e, int64_t n, const double2 (&in)[4], int64_t i, const double2 q2, const double2 g2, double2& vq, double2& vg) {
+            double2 mq, mg;
+            if (n == 1) {
+                mq = q2; mg = g2; vq.x = vq.y = 0.0; vg.x = vg.y = 0.0;
+            } else {
+                const double inv = 1.0 / (double)n;
+                mq = in[0]; vq = in[1]; mg = in[2]; vg = in[3];
+                double d;
+                d = q2.x - mq.x; mq.x = fma(d, inv, mq.x); vq.x = fma(d, q2.x - mq.x, vq.x);
+                d = q2.y - mq.y; mq.y = fma(d, inv, mq.y); vq.y = fma(d, q2.y - mq.y, vq.y);
+                d = g2.x - mg.x; mg.x = fma(d, inv, mg.x); vg.x = fma(d, g2.x - mg.x, vg.x);
+                d = g2.y - mg.y; mg.y = fma(d, inv, mg.y); vg.y = fma(d, g2.y - mg.y, vg.y);
+            }
+            st2(EST(e, 0), i, mq); st2(EST(e, 1), i, vq); st2(EST(e, 2), i, mg); st2(EST(e, 3), i, vg);
+        };
+        auto body = [&](int64_t i, const PassIn& v) {
+            const double2 q2 = v.q, g2 = v.g;
             if (A.tr_draws) st2_dense(A.tr_draws + row, i, D, q2);
             if (A.tr_grad) st2_dense(A.tr_grad + row, i, D, g2);
             double2 src_m2q = {0.0, 0.0}, src_m2g = {0.0, 0.0};
             if (do_add) {
-                for (int t = 0; t < 2; ++t) {
-                    const int64_t e = t == 0 ? efg : ebg;
-                    const int64_t n = t == 0 ? n_fg : n_bg;  // count after adding
-                    double2 mq, vq, mg, vg;
-                    if (n == 1) {
-                        mq = q2; mg = g2; vq.x = vq.y = 0.0; vg.x = vg.y = 0.0;
-                    } else {
-                        const double inv = 1.0 / (double)n;
-                        mq = ld2(EST(e, 0), i); vq = ld2(EST(e, 1), i); mg = ld2(EST(e, 2), i); vg = ld2(EST(e, 3), i);
-                        double d;
-                        d = q2.x - mq.x; mq.x = fma(d, inv, mq.x); vq.x = fma(d, q2.x - mq.x, vq.x);
-                        d = q2.y - mq.y; mq.y = fma(d, inv, mq.y); vq.y = fma(d, q2.y - mq.y, vq.y);
-                        d = g2.x - mg.x; mg.x = fma(d, inv, mg.x); vg.x = fma(d, g2.x - mg.x, vg.x);
-                        d = g2.y - mg.y; mg.y = fma(d, inv, mg.y); vg.y = fma(d, g2.y - mg.y, vg.y);
-                    }
-                    st2(EST(e, 0), i, mq); st2(EST(e, 1), i, vq); st2(EST(e, 2), i, mg); st2(EST(e, 3), i, vg);
-                    if (e == esrc) { src_m2q = vq; src_m2g = vg; }
-                }
+                double2 vq, vg;
+                welford(efg, n_fg, v.f, i, q2, g2, vq, vg);   // (count after adding)
+                if (efg == esrc) { src_m2q = vq; src_m2g = vg; }
+                welford(ebg, n_bg, v.b, i, q2, g2, vq, vg);
+                if (ebg == esrc) { src_m2q = vq; src_m2g = vg; }
             } else if (do_update) {
-                src_m2q = ld2(EST(esrc, 1), i);
-                src_m2g = ld2(EST(esrc, 3), i);
+                src_m2q = v.f[1];
+                src_m2g = v.f[3];
             }
-            double2 s = ld2(sig2, i);
+            if (!want_s) return;
+            double2 s = v.s;
             if (do_update) {
                 const int64_t n_src = do_switch ? n_bg : n_fg;
                 double vx, vy;
@@ -3237,7 +3281,9 @@ struct Machine {
                 st2(sig2, i, s);
             }
             if (A.tr_mm) st2_dense(A.tr_mm + row, i, D, s);
-        }
+        };
+        if (PFRARE) chunks_pf<4>(rd, body);
+        else NPHIP_FOR_CHUNKS(i) body(i, rd(i));
 #ifdef NPHIP_PROFILE
         if (!INK) c->prof[10] += (int64_t)__builtin_readcyclecounter() - tpp0_;
 #endif
