@@ -677,7 +677,14 @@ struct Machine {
     static constexpr bool BATCHED = (W == 1);
     // The vector passes of a draw's end (gradient of the new draw, trace rows, momentum) with the reads of four chunks in flight: the kernels that run
     // many steps per launch (the extra code is off their hot path; the launch-per-evaluation kernels run every path once per launch and keep the loops).
-    static constexpr bool PFRARE = INK;
+    // NOT the lean kernels: with four waves per chain (512 registers per lane) the position pass AND the momentum pass in this form end in a memory
+    // access fault of the GPU (either one alone runs and is bit-identical, as are the eight-wave kernels: round 6, not understood — a draw's end is
+    // 2.5 % of their time, they keep the plain loops).
+#ifdef NPHIP_NO_PFRARE
+    static constexpr bool PFRARE = false;   // (developer builds: the plain loops)
+#else
+    static constexpr bool PFRARE = INK && !LEAN;
+#endif
     template <class LoadT, class BodyT>
     __device__ __forceinline__ void chunks(LoadT load, BodyT body) const {
         if (nch > 2) chunks_pf<4>(load, body);
@@ -948,8 +955,11 @@ struct Machine {
             acc.y = fma(v.y, s2.y * v.y, acc.y);
         };
         // (PFRARE: sigma^2 of four chunks read ahead — a read behind the stores of the chunk before waits for them to complete)
+#ifndef NPHIP_NO_PF_MOM
         if (PFRARE) chunks_pf<4>([&](int64_t i) { return ld2(sig2, i); }, one);
-        else NPHIP_FOR_CHUNKS(i) one(i, ld2(sig2, i));
+        else
+#endif
+        NPHIP_FOR_CHUNKS(i) one(i, ld2(sig2, i));
         double a = acc.x + acc.y, b = 0.0;
         rsum2(a, b);
         return 0.5 * a;
@@ -1066,8 +1076,11 @@ struct Machine {
                 acc.x = fma(z.x, gg.x, acc.x);
                 acc.y = fma(z.y, gg.y, acc.y);
             };
+#ifndef NPHIP_NO_PF_GRAD
             if (PFRARE) chunks_pf<4>([&](int64_t i) { return tridiag_load(q, i); }, one);
-            else NPHIP_FOR_CHUNKS(i) one(i, tridiag_load(q, i));
+            else
+#endif
+            NPHIP_FOR_CHUNKS(i) one(i, tridiag_load(q, i));
             double a = acc.x + acc.y, b = 0.0;
             rsum2(a, b);
             lp = 0.5 * a;
@@ -3282,8 +3295,11 @@ struct Machine {
             }
             if (A.tr_mm) st2_dense(A.tr_mm + row, i, D, s);
         };
+#ifndef NPHIP_NO_PF_POS
         if (PFRARE) chunks_pf<4>(rd, body);
-        else NPHIP_FOR_CHUNKS(i) body(i, rd(i));
+        else
+#endif
+        NPHIP_FOR_CHUNKS(i) body(i, rd(i));
 #ifdef NPHIP_PROFILE
         if (!INK) c->prof[10] += (int64_t)__builtin_readcyclecounter() - tpp0_;
 #endif
