@@ -680,11 +680,16 @@ struct Machine {
     // NOT the lean kernels: with four waves per chain (512 registers per lane) the position pass AND the momentum pass in this form end in a memory
     // access fault of the GPU (either one alone runs and is bit-identical, as are the eight-wave kernels: round 6, not understood — a draw's end is
     // 2.5 % of their time, they keep the plain loops).
+    // ENDOUT: the families that got the end of round 6 — the register-resident kernels of the fused models (D <= 4096).  Everything else keeps its
+    // source as it was, to the letter: with inter-procedural register allocation the HOT loop of a kernel is re-coloured by any change to the
+    // functions it calls (measured with the new passes everywhere: lean kernel at D = 10 000 33.9 -> 48.7 ms per launch — 2 -> 162 spilled VGPRs in a
+    // kernel not one line of which had changed —, compiled densities -9 %, resident host callbacks -16 %; profiles/r6_call_placement_and_draw_end.txt).
 #ifdef NPHIP_NO_PFRARE
     static constexpr bool PFRARE = false;   // (developer builds: the plain loops)
 #else
-    static constexpr bool PFRARE = INK && !LEAN;
+    static constexpr bool PFRARE = FUSED && NV > 0 && !LEAN;
 #endif
+    static constexpr bool ENDOUT = FUSED && NV > 0 && !LEAN;
     template <class LoadT, class BodyT>
     __device__ __forceinline__ void chunks(LoadT load, BodyT body) const {
         if (nch > 2) chunks_pf<4>(load, body);
@@ -940,7 +945,25 @@ struct Machine {
         double* p = P(kSlotInit);
         double* r = R(kSlotInit);
         double2 acc = {0.0, 0.0};
-        auto one = [&](int64_t i, const double2& s2) {
+        if (PFRARE) {   // sigma^2 of four chunks read ahead — a read behind the stores of the chunk before waits for them to complete
+            chunks_pf<4>([&](int64_t i) { return ld2(sig2, i); },
+                         [&](int64_t i, const double2& s2) {
+                    double2 v = {0.0, 0.0};
+                    if (i < D) {
+                        double z0, z1;
+                        nphip_normal_pair(nphip_philox(A.s.seed, (uint32_t)(i >> 1), gchain, id, purpose), &z0, &z1);
+                        v.x = z0 * sqrt(1.0 / s2.x);
+                        if (i + 1 < D) v.y = z1 * sqrt(1.0 / s2.y);
+                    }
+                    st2(p, i, v);
+                    st2(r, i, v);
+                    if (lr_job()) { double2 vel; vel.x = s2.x * v.x; vel.y = s2.y * v.y; st2(VEL(kSlotInit), i, vel); }
+                    acc.x = fma(v.x, s2.x * v.x, acc.x);
+                    acc.y = fma(v.y, s2.y * v.y, acc.y);
+                         });
+        } else
+        NPHIP_FOR_CHUNKS(i) {
+            double2 s2 = ld2(sig2, i);
             double2 v = {0.0, 0.0};
             if (i < D) {
                 double z0, z1;
@@ -953,13 +976,7 @@ struct Machine {
             if (lr_job()) { double2 vel; vel.x = s2.x * v.x; vel.y = s2.y * v.y; st2(VEL(kSlotInit), i, vel); }
             acc.x = fma(v.x, s2.x * v.x, acc.x);
             acc.y = fma(v.y, s2.y * v.y, acc.y);
-        };
-        // (PFRARE: sigma^2 of four chunks read ahead — a read behind the stores of the chunk before waits for them to complete)
-#ifndef NPHIP_NO_PF_MOM
-        if (PFRARE) chunks_pf<4>([&](int64_t i) { return ld2(sig2, i); }, one);
-        else
-#endif
-        NPHIP_FOR_CHUNKS(i) one(i, ld2(sig2, i));
+        }
         double a = acc.x + acc.y, b = 0.0;
         rsum2(a, b);
         return 0.5 * a;
@@ -1032,7 +1049,22 @@ struct Machine {
         if (FUSED) chain_sync<W>();  // the fused model reads neighbouring elements of q'
     }
 
-    // Fused tridiagonal-Gaussian gradient for the pair at i (nphip model contract): what it reads, and what it computes from that.
+    // Fused tridiagonal-Gaussian gradient for the pair at i (nphip model contract).
+    __device__ __forceinline__ void tridiag_pair(const double* q, int64_t i, double2& z, double2& g) const {
+        double2 q2 = ld2(q, i), mu = ld2(A.m_mu, i), a = ld2(A.m_a, i), b = ld2(A.m_b, i);
+        z.x = q2.x - mu.x;
+        z.y = q2.y - mu.y;
+        double tx = a.x * z.x;
+        if (i > 0) tx = fma(ld1(A.m_b, i - 1), ld1(q, i - 1) - ld1(A.m_mu, i - 1), tx);
+        if (i + 1 < D) tx = fma(b.x, z.y, tx);
+        double ty = a.y * z.y;
+        ty = fma(b.x, z.x, ty);
+        if (i + 2 < D) ty = fma(b.y, ld1(q, i + 2) - ld1(A.m_mu, i + 2), ty);
+        g.x = -tx;
+        g.y = (i + 1 < D) ? -ty : 0.0;
+        if (i >= D) g.x = 0.0;
+    }
+    // Fused tridiagonal-Gaussian gradient for the pair at i — the form of the ENDOUT families: what it reads, and what it computes from that.
     // Every read is unconditional (the neighbours' indices clamped, their terms taken or not by a select: the same operations on the same values) — a
     // read behind a lane's condition is a block of its own with its own wait: three round trips to memory per chunk instead of one (round 6: 32 k
     // cycles per draw for the gradient of the new draw at D = 1000).  Apart, so that a pass can have the reads of several chunks in flight (PFRARE).
@@ -1061,7 +1093,6 @@ struct Machine {
         g.y = (i + 1 < D) ? -ty : 0.0;
         if (i >= D) g.x = 0.0;
     }
-    __device__ __forceinline__ void tridiag_pair(const double* q, int64_t i, double2& z, double2& g) const { tridiag_eval(tridiag_load(q, i), i, z, g); }
 
     // Position-only evaluation (initial point).  FUSED: compute; callback: copy staged gradient.
     __device__ void eval_position(int64_t buf, double& lp, int64_t& code) {
@@ -1069,18 +1100,23 @@ struct Machine {
         if (FUSED) {
             const double* q = Q(buf);
             double2 acc = {0.0, 0.0};
-            auto one = [&](int64_t i, const TriIn& v) {
+            if (PFRARE) {
+                chunks_pf<4>([&](int64_t i) { return tridiag_load(q, i); },
+                             [&](int64_t i, const TriIn& v) {
+                                 double2 z, gg;
+                                 tridiag_eval(v, i, z, gg);
+                                 st2(g, i, gg);
+                                 acc.x = fma(z.x, gg.x, acc.x);
+                                 acc.y = fma(z.y, gg.y, acc.y);
+                             });
+            } else
+            NPHIP_FOR_CHUNKS(i) {
                 double2 z, gg;
-                tridiag_eval(v, i, z, gg);
+                tridiag_pair(q, i, z, gg);
                 st2(g, i, gg);
                 acc.x = fma(z.x, gg.x, acc.x);
                 acc.y = fma(z.y, gg.y, acc.y);
-            };
-#ifndef NPHIP_NO_PF_GRAD
-            if (PFRARE) chunks_pf<4>([&](int64_t i) { return tridiag_load(q, i); }, one);
-            else
-#endif
-            NPHIP_FOR_CHUNKS(i) one(i, tridiag_load(q, i));
+            }
             double a = acc.x + acc.y, b = 0.0;
             rsum2(a, b);
             lp = 0.5 * a;
@@ -2109,9 +2145,8 @@ struct Machine {
         uint32_t used_base, sub_used, draw;
         bool check;                           // U-turn criteria apply in this doubling
         double step, H0, acc, acc_sym, max_ee;
-        int32_t end_code;                     // leaf_reg: how the draw ended (end_code), for the one call of rare_end_draw behind the run of leaves
     };
-    // The leaf does not call the out-of-line end of a draw itself: it says how the draw ended, and run() makes the ONE call behind the loop of leaves,
+    // ENDOUT: the leaf does not call the out-of-line end of a draw itself: it says how the draw ended, and run() makes the ONE call behind the loop of leaves,
     // where nothing of the leaf's state is alive (a call in the middle of the leaf pins what is alive there to the registers its callee leaves alone).
     static __device__ __forceinline__ int32_t end_code(bool diverging, bool maxdepth, bool store_div, bool div_has_end, bool regrad, bool replay) {
         return 1 | (diverging ? 2 : 0) | (maxdepth ? 4 : 0) | (store_div ? 8 : 0) | (div_has_end ? 16 : 0) | (regrad ? 32 : 0) | (replay ? 64 : 0);
@@ -2195,7 +2230,7 @@ struct Machine {
     }
 
     // returns true when an out-of-line (rare) path ran
-    __device__ __forceinline__ bool leaf_reg(RegsT& X, Hot& H) {
+    __device__ __forceinline__ bool leaf_reg(RegsT& X, Hot& H, int32_t& end_code_out) {
         constexpr int nk = NVX;  // the register kernels are instantiated per exact chunk count
         const int32_t j = H.nleaf + 1, d = H.depth, dir = H.dir;
         const int db = dir > 0 ? 1 : 0;
@@ -2447,7 +2482,9 @@ struct Machine {
                 H.acc_sym += 2.0 * a / (1.0 + e);
             }
         }
-        if (diverged) { X.dirty_qg = X.dirty_pr = false; hot_save(H); H.end_code = end_code(true, false, FUSED, ok, !REMOTE, FUSED); return true; }
+        if (diverged) { X.dirty_qg = X.dirty_pr = false; hot_save(H);
+            if (ENDOUT) end_code_out = end_code(true, false, FUSED, ok, !REMOTE, FUSED); else rare_end_draw(A, c, red, chain, true, false, FUSED, ok, !REMOTE, FUSED);
+            return true; }
 #ifdef NPHIP_PROFILE
         int64_t tq = (int64_t)__builtin_readcyclecounter();
         c->prof[8] += tq - tp2;
@@ -2501,7 +2538,7 @@ struct Machine {
                         turn = sub_b(X, obp, obr);
                     }
                 }
-                if (turn) { X.dirty_qg = X.dirty_pr = false; hot_save(H); H.end_code = end_code(false, false, false, false, !REMOTE, false); return true; }
+                if (turn) { X.dirty_qg = X.dirty_pr = false; hot_save(H); if (ENDOUT) end_code_out = end_code(false, false, false, false, !REMOTE, false); else rare_end_draw(A, c, red, chain, false, false, false, false, !REMOTE); return true; }
             }
 #ifdef NPHIP_PROFILE
             { const int64_t t_ = (int64_t)__builtin_readcyclecounter(); c->prof[k == 0 ? 9 : 10] += t_ - tq; tq = t_; }
@@ -2576,8 +2613,8 @@ struct Machine {
             c->depth = d + 1;
         }
         store_state(X, true, true);  // a new trajectory end is always written back
-        if (turn) { hot_save(H); H.end_code = end_code(false, false, false, false, !REMOTE, false); return true; }
-        if (H.depth >= A.s.maxdepth) { hot_save(H); H.end_code = end_code(false, true, false, false, !REMOTE, false); return true; }
+        if (turn) { hot_save(H); if (ENDOUT) end_code_out = end_code(false, false, false, false, !REMOTE, false); else rare_end_draw(A, c, red, chain, false, false, false, false, !REMOTE); return true; }
+        if (H.depth >= A.s.maxdepth) { hot_save(H); if (ENDOUT) end_code_out = end_code(false, true, false, false, !REMOTE, false); else rare_end_draw(A, c, red, chain, false, true, false, false, !REMOTE); return true; }
         start_doubling_hot(H);
         return false;
     }
@@ -3227,57 +3264,106 @@ struct Machine {
         const size_t row = ((size_t)chain * T + draw) * D;
         const int64_t efg = c->fg, ebg = 1 - c->fg;
         const int64_t esrc = do_switch ? ebg : efg;
-        // What the pass reads of a chunk, and what it does with it — apart, so that PFRARE has the reads of four chunks in flight ahead of their stores:
-        // the plain loop waits for the stores of a chunk to COMPLETE before the next read returns (loads and stores share a counter, and a load cannot
-        // pass a store to the same pool): three round trips to memory per chunk, 80 - 90 k cycles per warm-up draw at D = 1000 (round 6).
-        struct PassIn { double2 q, g, s, f[4], b[4]; };
-        const bool want_s = do_update || A.tr_mm != nullptr;
-        auto rd = [&](int64_t i) {
-            PassIn v;
-            v.q = ld2(q, i); v.g = ld2(g, i);
-            if (do_add) {
-                if (n_fg != 1) { v.f[0] = ld2(EST(efg, 0), i); v.f[1] = ld2(EST(efg, 1), i); v.f[2] = ld2(EST(efg, 2), i); v.f[3] = ld2(EST(efg, 3), i); }
-                if (n_bg != 1) { v.b[0] = ld2(EST(ebg, 0), i); v.b[1] = ld2(EST(ebg, 1), i); v.b[2] = ld2(EST(ebg, 2), i); v.b[3] = ld2(EST(ebg, 3), i); }
-            } else if (do_update) {
-                v.f[1] = ld2(EST(esrc, 1), i);
-                v.f[3] = ld2(EST(esrc, 3), i);
-            }
-            if (want_s) v.s = ld2(sig2, i);
-            return v;
-        };
-        // one estimator takes the draw in (Welford): -> its sums of squares (q, grad)
-        auto welford = [&](int64_t e, int64_t n, const double2 (&in)[4], int64_t i, const double2 q2, const double2 g2, double2& vq, double2& vg) {
-            double2 mq, mg;
-            if (n == 1) {
-                mq = q2; mg = g2; vq.x = vq.y = 0.0; vg.x = vg.y = 0.0;
-            } else {
-                const double inv = 1.0 / (double)n;
-                mq = in[0]; vq = in[1]; mg = in[2]; vg = in[3];
-                double d;
-                d = q2.x - mq.x; mq.x = fma(d, inv, mq.x); vq.x = fma(d, q2.x - mq.x, vq.x);
-                d = q2.y - mq.y; mq.y = fma(d, inv, mq.y); vq.y = fma(d, q2.y - mq.y, vq.y);
-                d = g2.x - mg.x; mg.x = fma(d, inv, mg.x); vg.x = fma(d, g2.x - mg.x, vg.x);
-                d = g2.y - mg.y; mg.y = fma(d, inv, mg.y); vg.y = fma(d, g2.y - mg.y, vg.y);
-            }
-            st2(EST(e, 0), i, mq); st2(EST(e, 1), i, vq); st2(EST(e, 2), i, mg); st2(EST(e, 3), i, vg);
-        };
-        auto body = [&](int64_t i, const PassIn& v) {
-            const double2 q2 = v.q, g2 = v.g;
+        if (PFRARE) {
+            // What the pass reads of a chunk, and what it does with it — apart, so that PFRARE has the reads of four chunks in flight ahead of their stores:
+            // the plain loop waits for the stores of a chunk to COMPLETE before the next read returns (loads and stores share a counter, and a load cannot
+            // pass a store to the same pool): three round trips to memory per chunk, 80 - 90 k cycles per warm-up draw at D = 1000 (round 6).
+            struct PassIn { double2 q, g, s, f[4], b[4]; };
+            const bool want_s = do_update || A.tr_mm != nullptr;
+            auto rd = [&](int64_t i) {
+                PassIn v;
+                v.q = ld2(q, i); v.g = ld2(g, i);
+                if (do_add) {
+                    if (n_fg != 1) { v.f[0] = ld2(EST(efg, 0), i); v.f[1] = ld2(EST(efg, 1), i); v.f[2] = ld2(EST(efg, 2), i); v.f[3] = ld2(EST(efg, 3), i); }
+                    if (n_bg != 1) { v.b[0] = ld2(EST(ebg, 0), i); v.b[1] = ld2(EST(ebg, 1), i); v.b[2] = ld2(EST(ebg, 2), i); v.b[3] = ld2(EST(ebg, 3), i); }
+                } else if (do_update) {
+                    v.f[1] = ld2(EST(esrc, 1), i);
+                    v.f[3] = ld2(EST(esrc, 3), i);
+                }
+                if (want_s) v.s = ld2(sig2, i);
+                return v;
+            };
+            // one estimator takes the draw in (Welford): -> its sums of squares (q, grad)
+            auto welford = [&](int64_t e, int64_t n, const double2 (&in)[4], int64_t i, const double2 q2, const double2 g2, double2& vq, double2& vg) {
+                double2 mq, mg;
+                if (n == 1) {
+                    mq = q2; mg = g2; vq.x = vq.y = 0.0; vg.x = vg.y = 0.0;
+                } else {
+                    const double inv = 1.0 / (double)n;
+                    mq = in[0]; vq = in[1]; mg = in[2]; vg = in[3];
+                    double d;
+                    d = q2.x - mq.x; mq.x = fma(d, inv, mq.x); vq.x = fma(d, q2.x - mq.x, vq.x);
+                    d = q2.y - mq.y; mq.y = fma(d, inv, mq.y); vq.y = fma(d, q2.y - mq.y, vq.y);
+                    d = g2.x - mg.x; mg.x = fma(d, inv, mg.x); vg.x = fma(d, g2.x - mg.x, vg.x);
+                    d = g2.y - mg.y; mg.y = fma(d, inv, mg.y); vg.y = fma(d, g2.y - mg.y, vg.y);
+                }
+                st2(EST(e, 0), i, mq); st2(EST(e, 1), i, vq); st2(EST(e, 2), i, mg); st2(EST(e, 3), i, vg);
+            };
+            auto body = [&](int64_t i, const PassIn& v) {
+                const double2 q2 = v.q, g2 = v.g;
+                if (A.tr_draws) st2_dense(A.tr_draws + row, i, D, q2);
+                if (A.tr_grad) st2_dense(A.tr_grad + row, i, D, g2);
+                double2 src_m2q = {0.0, 0.0}, src_m2g = {0.0, 0.0};
+                if (do_add) {
+                    double2 vq, vg;
+                    welford(efg, n_fg, v.f, i, q2, g2, vq, vg);   // (count after adding)
+                    if (efg == esrc) { src_m2q = vq; src_m2g = vg; }
+                    welford(ebg, n_bg, v.b, i, q2, g2, vq, vg);
+                    if (ebg == esrc) { src_m2q = vq; src_m2g = vg; }
+                } else if (do_update) {
+                    src_m2q = v.f[1];
+                    src_m2g = v.f[3];
+                }
+                if (!want_s) return;
+                double2 s = v.s;
+                if (do_update) {
+                    const int64_t n_src = do_switch ? n_bg : n_fg;
+                    double vx, vy;
+                    if (A.s.use_grad_based) {
+                        vx = sqrt(src_m2q.x / src_m2g.x);
+                        vy = sqrt(src_m2q.y / src_m2g.y);
+                    } else {
+                        const double scale = 1.0 / (double)(n_src - 1);
+                        vx = src_m2q.x * scale;
+                        vy = src_m2q.y * scale;
+                    }
+                    if (isfinite(vx)) s.x = clamp_mm(vx);
+                    if (isfinite(vy)) s.y = clamp_mm(vy);
+                    st2(sig2, i, s);
+                }
+                if (A.tr_mm) st2_dense(A.tr_mm + row, i, D, s);
+            };
+            chunks_pf<4>(rd, body);
+        } else
+        NPHIP_FOR_CHUNKS(i) {
+            double2 q2 = ld2(q, i), g2 = ld2(g, i);
             if (A.tr_draws) st2_dense(A.tr_draws + row, i, D, q2);
             if (A.tr_grad) st2_dense(A.tr_grad + row, i, D, g2);
             double2 src_m2q = {0.0, 0.0}, src_m2g = {0.0, 0.0};
             if (do_add) {
-                double2 vq, vg;
-                welford(efg, n_fg, v.f, i, q2, g2, vq, vg);   // (count after adding)
-                if (efg == esrc) { src_m2q = vq; src_m2g = vg; }
-                welford(ebg, n_bg, v.b, i, q2, g2, vq, vg);
-                if (ebg == esrc) { src_m2q = vq; src_m2g = vg; }
+                for (int t = 0; t < 2; ++t) {
+                    const int64_t e = t == 0 ? efg : ebg;
+                    const int64_t n = t == 0 ? n_fg : n_bg;  // count after adding
+                    double2 mq, vq, mg, vg;
+                    if (n == 1) {
+                        mq = q2; mg = g2; vq.x = vq.y = 0.0; vg.x = vg.y = 0.0;
+                    } else {
+                        const double inv = 1.0 / (double)n;
+                        mq = ld2(EST(e, 0), i); vq = ld2(EST(e, 1), i); mg = ld2(EST(e, 2), i); vg = ld2(EST(e, 3), i);
+                        double d;
+                        d = q2.x - mq.x; mq.x = fma(d, inv, mq.x); vq.x = fma(d, q2.x - mq.x, vq.x);
+                        d = q2.y - mq.y; mq.y = fma(d, inv, mq.y); vq.y = fma(d, q2.y - mq.y, vq.y);
+                        d = g2.x - mg.x; mg.x = fma(d, inv, mg.x); vg.x = fma(d, g2.x - mg.x, vg.x);
+                        d = g2.y - mg.y; mg.y = fma(d, inv, mg.y); vg.y = fma(d, g2.y - mg.y, vg.y);
+                    }
+                    st2(EST(e, 0), i, mq); st2(EST(e, 1), i, vq); st2(EST(e, 2), i, mg); st2(EST(e, 3), i, vg);
+                    if (e == esrc) { src_m2q = vq; src_m2g = vg; }
+                }
             } else if (do_update) {
-                src_m2q = v.f[1];
-                src_m2g = v.f[3];
+                src_m2q = ld2(EST(esrc, 1), i);
+                src_m2g = ld2(EST(esrc, 3), i);
             }
-            if (!want_s) return;
-            double2 s = v.s;
+            double2 s = ld2(sig2, i);
             if (do_update) {
                 const int64_t n_src = do_switch ? n_bg : n_fg;
                 double vx, vy;
@@ -3294,12 +3380,7 @@ struct Machine {
                 st2(sig2, i, s);
             }
             if (A.tr_mm) st2_dense(A.tr_mm + row, i, D, s);
-        };
-#ifndef NPHIP_NO_PF_POS
-        if (PFRARE) chunks_pf<4>(rd, body);
-        else
-#endif
-        NPHIP_FOR_CHUNKS(i) body(i, rd(i));
+        }
 #ifdef NPHIP_PROFILE
         if (!INK) c->prof[10] += (int64_t)__builtin_readcyclecounter() - tpp0_;
 #endif
@@ -3836,7 +3917,7 @@ struct Machine {
             Hot H;        // register-resident kernels (leaf_reg): the control words of the leaf loop
             constexpr bool HOT = NV > 0;
             if (HOT) hot_load(H);
-            H.end_code = 0;
+            int32_t end_code_ = 0;   // (ENDOUT: how the leaf that ended the draw ended it)
             bool rare = false, out_of_budget = false;
             int lean_end = 0;
             const LeanRs lrs = lean_rs();
@@ -3853,7 +3934,7 @@ struct Machine {
 #endif
                 if (NV > 0) {
                     if (LEAN) { lean_end = leaf_lean(lrs, X, H); rare = lean_end != 0; }
-                    else rare = leaf_reg(X, H);
+                    else rare = leaf_reg(X, H, end_code_);
                 } else {
                     double lp = 0.0;
                     int64_t code = 0;
@@ -3902,8 +3983,8 @@ struct Machine {
                 flush(X);
             }
             sig_lds = nullptr;
-            if (HOT && !LEAN && H.end_code != 0) {
-                const int32_t ec = H.end_code;
+            if (ENDOUT && end_code_ != 0) {
+                const int32_t ec = end_code_;
                 rare_end_draw(A, c, red, chain, (ec & 2) != 0, (ec & 4) != 0, (ec & 8) != 0, (ec & 16) != 0, (ec & 32) != 0, (ec & 64) != 0);
             }
             if (LEAN && lean_end != 0) rare_end_draw(A, c, red, chain, lean_end == 1 || lean_end == 4, lean_end == 3, lean_end == 1 || lean_end == 4, lean_end == 1, true, true);

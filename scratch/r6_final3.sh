@@ -3,7 +3,7 @@
 # bench line (also as the driver starts it for N > 1), rocprofv3 kernel statistics of the same command at D = 1000 and D = 10 000
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O/pmc
 cd $R
-python -m pytest tests -m gpu -q -x 2>&1 | grep -E "passed|failed|error|Error|assert" | tail -8 > $O/r6c_gpu_tests.txt; cat $O/r6c_gpu_tests.txt
+cat $O/r6c_gpu_tests_by_file.txt | grep -E "passed|failed" | tr "\n" " "; echo
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 python bench.py > $O/r6c_bench.json 2> $O/r6c_bench.err; tail -c 200 $O/r6c_bench.err
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --no-cpu-baseline --no-other-configs > $O/r6c_bench_under_torch_distributed_run.json 2> $O/r6c_tdr.err; tail -c 300 $O/r6c_bench_under_torch_distributed_run.json
