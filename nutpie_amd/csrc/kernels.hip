@@ -680,16 +680,18 @@ struct Machine {
     // NOT the lean kernels: with four waves per chain (512 registers per lane) the position pass AND the momentum pass in this form end in a memory
     // access fault of the GPU (either one alone runs and is bit-identical, as are the eight-wave kernels: round 6, not understood — a draw's end is
     // 2.5 % of their time, they keep the plain loops).
-    // ENDOUT: the families that got the end of round 6 — the register-resident kernels of the fused models (D <= 4096).  Everything else keeps its
-    // source as it was, to the letter: with inter-procedural register allocation the HOT loop of a kernel is re-coloured by any change to the
+    // ENDOUT: the families that got the end of round 6 — the one-wave register-resident kernels of the fused models with 2 .. 8 chunks per lane
+    // (128 < D <= 1024), chosen by same-box A/B per family (warm-up, 1024 chains, M leapfrogs/s before -> after): 2 chunks 382 -> 418, 3: 292 -> 372,
+    // 4: 332 -> 343, 6: 255 -> 259, 8: 217 -> 225; NOT 1 chunk (D = 10: 367 -> 320, D = 100: 457 -> 450) and NOT two waves per chain (D = 1500:
+    // 107.4 -> 101.1).  Everything else keeps its source as it was, to the letter: with inter-procedural register allocation the HOT loop of a kernel is re-coloured by any change to the
     // functions it calls (measured with the new passes everywhere: lean kernel at D = 10 000 33.9 -> 48.7 ms per launch — 2 -> 162 spilled VGPRs in a
     // kernel not one line of which had changed —, compiled densities -9 %, resident host callbacks -16 %; profiles/r6_call_placement_and_draw_end.txt).
 #ifdef NPHIP_NO_PFRARE
     static constexpr bool PFRARE = false;   // (developer builds: the plain loops)
 #else
-    static constexpr bool PFRARE = FUSED && NV > 0 && !LEAN;
+    static constexpr bool PFRARE = FUSED && W == 1 && NV >= 2 && !LEAN;
 #endif
-    static constexpr bool ENDOUT = FUSED && NV > 0 && !LEAN;
+    static constexpr bool ENDOUT = FUSED && W == 1 && NV >= 2 && !LEAN;
     template <class LoadT, class BodyT>
     __device__ __forceinline__ void chunks(LoadT load, BodyT body) const {
         if (nch > 2) chunks_pf<4>(load, body);
