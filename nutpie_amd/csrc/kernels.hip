@@ -4149,7 +4149,7 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) __attribute__((amdgpu_waves_
 }
 
 // ----------------------------------------------------------------------------------------
-// launch tables.  The file is compiled as nine translation units in parallel (Makefile: -DNPHIP_PART=0..6, 8, 9), each instantiating
+// launch tables.  The file is compiled as twelve translation units in parallel (Makefile: -DNPHIP_PART=0..6, 8..12), each instantiating
 // one family of kernels; without NPHIP_PART (developer builds, see the NPHIP_DEV_* macros) everything is in one.
 // ----------------------------------------------------------------------------------------
 #ifndef NPHIP_PART
@@ -4289,6 +4289,20 @@ hipError_t launch_fam_rw(const Args& a, const Args* d_args, int W, hipStream_t s
 }
 #endif
 
+// The 8-chunk kernel (896 < D <= 1024: the headline's) is a translation unit of its own (part 12), compiled WITHOUT inter-procedural register
+// allocation (Makefile: -mllvm -enable-ipra=0): under the plain calling convention what lives across the kernel's calls sits in callee-saved
+// registers whatever the callees use — 4 spilled VGPRs / 18 spilled SGPRs instead of 0 / 37, and +2.4 % same-box (warm-up, 1024 chains: 223.1 224.5 ->
+// 228.5 230.0 M leapfrogs/s, bit-identical; profiles/r6_call_placement_and_draw_end.txt D).  Measured for this kernel only; the lean kernels lose by it
+// (D = 10 000: 15.4 -> 12.6 M leapfrogs/s).
+hipError_t launch_w1_nv8(const Args* d_args, hipStream_t st, const LaunchSlice sl, int me, int hr);
+#if NPHIP_HAS(12) && !defined(NPHIP_DEV_BUILD)
+hipError_t launch_w1_nv8(const Args* d_args, hipStream_t st, const LaunchSlice sl, int me, int hr) {
+    const dim3 g(((unsigned)sl.chain_n + 3) / 4), b(256);
+    hipLaunchKernelGGL((k_advance<true, 1, 8>), g, b, 0, st, d_args, me, hr, sl);
+    return hipGetLastError();
+}
+#endif
+
 #if NPHIP_HAS(0)
 // register-resident, one wave per chain (D <= 1024): four chains per workgroup, one instantiation per exact chunk count
 hipError_t launch_fam_w1(const Args& a, const Args* d_args, hipStream_t st, const LaunchSlice sl) {
@@ -4311,7 +4325,7 @@ hipError_t launch_fam_w1(const Args& a, const Args* d_args, hipStream_t st, cons
         case 5: hipLaunchKernelGGL((k_advance<true, 1, 5>), g, b, 0, st, d_args, me, hr, sl); break;
         case 6: hipLaunchKernelGGL((k_advance<true, 1, 6>), g, b, 0, st, d_args, me, hr, sl); break;
         case 7: hipLaunchKernelGGL((k_advance<true, 1, 7>), g, b, 0, st, d_args, me, hr, sl); break;
-        case 8: hipLaunchKernelGGL((k_advance<true, 1, 8>), g, b, 0, st, d_args, me, hr, sl); break;
+        case 8: return launch_w1_nv8(d_args, st, sl, me, hr);
 #endif
         default: return hipErrorInvalidValue;
     }
