@@ -13,7 +13,7 @@ import re
 HERE = os.path.dirname(os.path.abspath(__file__))
 # (dim, waves) -> (summary file, leapfrogs per launch of the profiled run, kernel, configuration of the profiled run)
 SOURCES = {
-    "1000:1": ("r5_d1000_timed_config_pmc.txt", 1024 * 2048, "k_advance<fused,W=1,NV=8>",
+    "1000:1": ("r6_d1000_timed_config_pmc.txt", 1024 * 2048, "k_advance<fused,W=1,NV=8>",
                "bench.py default: sampling phase, positions stored, 2048 leapfrogs per chain per launch; the timed launches"),
     "2000:2": ("r1_d2000_multiwave_kernel_pmc.txt", 1024 * 128, "k_advance<fused,W=2,NV=8>", "round 1: tuning phase, 128 leapfrogs per chain per launch"),
     "10000:4": ("r5_d10000_timed_config_pmc.txt", 1024 * 512, "k_advance<fused,W=4,NV=20,lean>",
