@@ -4289,16 +4289,33 @@ hipError_t launch_fam_rw(const Args& a, const Args* d_args, int W, hipStream_t s
 }
 #endif
 
-// The 8-chunk kernel (896 < D <= 1024: the headline's) is a translation unit of its own (part 12), compiled WITHOUT inter-procedural register
-// allocation (Makefile: -mllvm -enable-ipra=0): under the plain calling convention what lives across the kernel's calls sits in callee-saved
-// registers whatever the callees use — 4 spilled VGPRs / 18 spilled SGPRs instead of 0 / 37, and +2.4 % same-box (warm-up, 1024 chains: 223.1 224.5 ->
-// 228.5 230.0 M leapfrogs/s, bit-identical; profiles/r6_call_placement_and_draw_end.txt D).  Measured for this kernel only; the lean kernels lose by it
-// (D = 10 000: 15.4 -> 12.6 M leapfrogs/s).
-hipError_t launch_w1_nv8(const Args* d_args, hipStream_t st, const LaunchSlice sl, int me, int hr);
+// The one-wave kernels with 2 .. 8 chunks per lane (128 < D <= 1024: the ENDOUT family, the headline's among them) are a translation unit of their
+// own (part 12), compiled WITHOUT inter-procedural register allocation (Makefile: -mllvm -enable-ipra=0): their leaf makes no call, and under the
+// plain calling convention what lives across the kernel's few calls sits in callee-saved registers whatever the callees use.  Same-box A/B per
+// kernel (warm-up, 1024 chains, M leapfrogs/s): 8 chunks 223.1 224.5 -> 228.5 230.0 (4 / 18 spilled VGPRs / SGPRs instead of 0 / 37), 6: 264.9 260.4 ->
+// 266.5 265.3, 4: 345.6 343.1 -> 345.6 346.6, 3: 377.2 374.3 -> 381.1 383.8, 2: 417.7 418.6 -> 418.2 420.4; bit-identical.  Also the dense Gaussian's
+// resident kernels (part 11: 13.89 -> 14.00 M leapfrogs/s) and the compiled densities (density.py: config 3 60.7 -> 61.0, two / four waves per chain
+// +2.4 % / +5 %).  NOT the lean kernels (D = 10 000: 15.4 -> 12.6) and not the low-rank leaf (D = 1000, k = 16: 16.1 -> 14.7).
+// (profiles/r6_call_placement_and_draw_end.txt D)
+hipError_t launch_w1_noipra(int nv, const Args* d_args, hipStream_t st, const LaunchSlice sl, int me, int hr);
 #if NPHIP_HAS(12) && !defined(NPHIP_DEV_BUILD)
-hipError_t launch_w1_nv8(const Args* d_args, hipStream_t st, const LaunchSlice sl, int me, int hr) {
+hipError_t launch_w1_noipra(int nv, const Args* d_args, hipStream_t st, const LaunchSlice sl, int me, int hr) {
     const dim3 g(((unsigned)sl.chain_n + 3) / 4), b(256);
-    hipLaunchKernelGGL((k_advance<true, 1, 8>), g, b, 0, st, d_args, me, hr, sl);
+    switch (nv) {
+        // (2, 3 chunks per lane: built for two waves per SIMD — unless the job has no second wave to bring: k_advance<..., WIDE>)
+        case 2: if (sl.chain_n <= 1024) hipLaunchKernelGGL((k_advance<true, 1, 2, false, false, false, true>), g, b, 0, st, d_args, me, hr, sl);
+                else hipLaunchKernelGGL((k_advance<true, 1, 2>), g, b, 0, st, d_args, me, hr, sl);
+                break;
+        case 3: if (sl.chain_n <= 1024) hipLaunchKernelGGL((k_advance<true, 1, 3, false, false, false, true>), g, b, 0, st, d_args, me, hr, sl);
+                else hipLaunchKernelGGL((k_advance<true, 1, 3>), g, b, 0, st, d_args, me, hr, sl);
+                break;
+        case 4: hipLaunchKernelGGL((k_advance<true, 1, 4>), g, b, 0, st, d_args, me, hr, sl); break;
+        case 5: hipLaunchKernelGGL((k_advance<true, 1, 5>), g, b, 0, st, d_args, me, hr, sl); break;
+        case 6: hipLaunchKernelGGL((k_advance<true, 1, 6>), g, b, 0, st, d_args, me, hr, sl); break;
+        case 7: hipLaunchKernelGGL((k_advance<true, 1, 7>), g, b, 0, st, d_args, me, hr, sl); break;
+        case 8: hipLaunchKernelGGL((k_advance<true, 1, 8>), g, b, 0, st, d_args, me, hr, sl); break;
+        default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 #endif
@@ -4314,18 +4331,7 @@ hipError_t launch_fam_w1(const Args& a, const Args* d_args, hipStream_t st, cons
         case NPHIP_DEV_W1NV: hipLaunchKernelGGL((k_advance<true, 1, NPHIP_DEV_W1NV>), g, b, 0, st, d_args, me, hr, sl); break;
 #elif !defined(NPHIP_DEV_BUILD)
         case 1: hipLaunchKernelGGL((k_advance<true, 1, 1>), g, b, 0, st, d_args, me, hr, sl); break;
-        // (2, 3 chunks per lane: built for two waves per SIMD — unless the job has no second wave to bring: k_advance<..., WIDE>)
-        case 2: if (sl.chain_n <= 1024) hipLaunchKernelGGL((k_advance<true, 1, 2, false, false, false, true>), g, b, 0, st, d_args, me, hr, sl);
-                else hipLaunchKernelGGL((k_advance<true, 1, 2>), g, b, 0, st, d_args, me, hr, sl);
-                break;
-        case 3: if (sl.chain_n <= 1024) hipLaunchKernelGGL((k_advance<true, 1, 3, false, false, false, true>), g, b, 0, st, d_args, me, hr, sl);
-                else hipLaunchKernelGGL((k_advance<true, 1, 3>), g, b, 0, st, d_args, me, hr, sl);
-                break;
-        case 4: hipLaunchKernelGGL((k_advance<true, 1, 4>), g, b, 0, st, d_args, me, hr, sl); break;
-        case 5: hipLaunchKernelGGL((k_advance<true, 1, 5>), g, b, 0, st, d_args, me, hr, sl); break;
-        case 6: hipLaunchKernelGGL((k_advance<true, 1, 6>), g, b, 0, st, d_args, me, hr, sl); break;
-        case 7: hipLaunchKernelGGL((k_advance<true, 1, 7>), g, b, 0, st, d_args, me, hr, sl); break;
-        case 8: return launch_w1_nv8(d_args, st, sl, me, hr);
+        case 2: case 3: case 4: case 5: case 6: case 7: case 8: return launch_w1_noipra((int)a.reg_nv, d_args, st, sl, me, hr);   // (part 12)
 #endif
         default: return hipErrorInvalidValue;
     }
