@@ -21,8 +21,8 @@ SOURCES = {
 }
 # whole jobs (round 5, scratch/r5_pmc_jobs.py): the first line of the summary holds the job's leapfrogs and launches
 JOBS = {
-    "config3_compiled_density": ("r5_config3_compiled_density_pmc.txt", "k_advance<callback,W=1,NV=2,REMOTE> of the generated radon density (512 chains, tune 400 + draws 1000)"),
-    "config3_traced_torch_density": ("r5_config3_traced_torch_density_pmc.txt", "the same model traced from its torch log-density (nutpie_amd.torch_trace)"),
+    "config3_compiled_density": ("r6_config3_compiled_density_final_pmc.txt", "k_advance<callback,W=1,NV=2,REMOTE> of the generated radon density (512 chains, tune 400 + draws 1000)"),
+    "config3_traced_torch_density": ("r6_config3_traced_torch_density_final_pmc.txt", "the same model traced from its torch log-density (nutpie_amd.torch_trace)"),
     "low_rank_173_k4": ("r5_low_rank_d173_k4_pmc.txt", "k_advance<fused,W=1,NV=2,LR>: AR(1) Gaussian D = 173, 512 chains, 4 columns handed in; the launches after the hand-in"),
     "config2ii_dense_resident": ("r6_dense_resident_pmc.txt", "k_advance<callback,W=1,NV=8,REMOTE,DENSEG>: the dense 1000-dim Gaussian's resident kernel (launch-wide fp64 MFMA GEMM inside the leaf), 1024 chains; 12 launches of 256 evaluation rounds in the sampling phase (scratch/r6_dense_job.py)"),
     "low_rank_1000_k16": ("r5_low_rank_d1000_k16_pmc.txt", "k_advance<fused,W=1,NV=8,LR>: AR(1) Gaussian D = 1000, 1024 chains, 16 columns handed in; the launches after the hand-in"),
