@@ -675,17 +675,18 @@ struct Machine {
     // waves per chain the waves of a chain overlap each other's round trips and the extra code costs more than it saves (these
     // kernels run every path once per launch: measured at D = 1000, 8 waves per chain, 84 -> 137 us per launch).
     static constexpr bool BATCHED = (W == 1);
-    // The vector passes of a draw's end (gradient of the new draw, trace rows, momentum) with the reads of four chunks in flight: the kernels that run
-    // many steps per launch (the extra code is off their hot path; the launch-per-evaluation kernels run every path once per launch and keep the loops).
-    // NOT the lean kernels: with four waves per chain (512 registers per lane) the position pass AND the momentum pass in this form end in a memory
-    // access fault of the GPU (either one alone runs and is bit-identical, as are the eight-wave kernels: round 6, not understood — a draw's end is
-    // 2.5 % of their time, they keep the plain loops).
-    // ENDOUT: the families that got the end of round 6 — the one-wave register-resident kernels of the fused models with 2 .. 8 chunks per lane
-    // (128 < D <= 1024), chosen by same-box A/B per family (warm-up, 1024 chains, M leapfrogs/s before -> after): 2 chunks 382 -> 418, 3: 292 -> 372,
-    // 4: 332 -> 343, 6: 255 -> 259, 8: 217 -> 225; NOT 1 chunk (D = 10: 367 -> 320, D = 100: 457 -> 450) and NOT two waves per chain (D = 1500:
-    // 107.4 -> 101.1).  Everything else keeps its source as it was, to the letter: with inter-procedural register allocation the HOT loop of a kernel is re-coloured by any change to the
-    // functions it calls (measured with the new passes everywhere: lean kernel at D = 10 000 33.9 -> 48.7 ms per launch — 2 -> 162 spilled VGPRs in a
-    // kernel not one line of which had changed —, compiled densities -9 %, resident host callbacks -16 %; profiles/r6_call_placement_and_draw_end.txt).
+    // ENDOUT / PFRARE — what the end of round 6 changed about the END OF A DRAW, and for which kernels (profiles/r6_call_placement_and_draw_end.txt):
+    //   ENDOUT: the leaf reports how the draw ended and run() makes the one out-of-line call behind the loop of leaves (end_code, leaf_reg);
+    //   PFRARE: the draw end's vector passes (gradient of the new draw, trace row + estimators, momentum) read four chunks ahead of their stores
+    //           (chunks_pf<4>), and the fused gradient reads its neighbours unconditionally (tridiag_load / tridiag_eval).
+    // Both for the one-wave register-resident kernels of the fused models with 2 .. 8 chunks per lane (128 < D <= 1024), chosen by same-box A/B per
+    // family (warm-up, 1024 chains, M leapfrogs/s before -> after): 2 chunks 382 -> 418, 3: 292 -> 372, 4: 332 -> 343, 6: 255 -> 259, 8: 217 -> 225;
+    // NOT 1 chunk (D = 10: 367 -> 320, D = 100: 457 -> 450) and NOT two waves per chain (D = 1500: 107.4 -> 101.1).  Everything else keeps its source
+    // as it was, to the letter: with inter-procedural register allocation the HOT loop of a kernel is re-coloured by any change to the functions it
+    // calls — with the new passes in every family the lean kernel at D = 10 000 went from 33.9 to 48.7 ms per launch (2 -> 162 spilled VGPRs in a
+    // kernel not one line of which had changed) and the compiled densities lost 9 %; and the four-wave lean kernels end in a memory access fault of
+    // the GPU with the position AND the momentum pass in the read-ahead form (either alone runs and is bit-identical, as are the eight-wave kernels:
+    // not understood in the time left).
 #ifdef NPHIP_NO_PFRARE
     static constexpr bool PFRARE = false;   // (developer builds: the plain loops)
 #else
