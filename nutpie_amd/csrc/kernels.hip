@@ -686,13 +686,17 @@ struct Machine {
     // calls — with the new passes in every family the lean kernel at D = 10 000 went from 33.9 to 48.7 ms per launch (2 -> 162 spilled VGPRs in a
     // kernel not one line of which had changed) and the compiled densities lost 9 %; and the four-wave lean kernels end in a memory access fault of
     // the GPU with the position AND the momentum pass in the read-ahead form (either alone runs and is bit-identical, as are the eight-wave kernels:
-    // not understood in the time left).
+    // a lead at the very end: the read-ahead passes become functions of their own, rare_end_draw then CALLS, and under inter-procedural allocation the
+    // caller's view of what it clobbers may miss the nested callee — the same passes alone fault in the two-wave kernels, and run with the call behind
+    // the loop or without inter-procedural allocation).  Hence also NOT the low-rank leaf (LR): it is built with inter-procedural allocation (without it
+    // it loses 9 %), so its rare paths stay free of nested calls like every other family's built that way; the ENDOUT family itself is built without
+    // (part 12).
 #ifdef NPHIP_NO_PFRARE
     static constexpr bool PFRARE = false;   // (developer builds: the plain loops)
 #else
-    static constexpr bool PFRARE = FUSED && W == 1 && NV >= 2 && !LEAN;
+    static constexpr bool PFRARE = FUSED && W == 1 && NV >= 2 && !LEAN && !LR;
 #endif
-    static constexpr bool ENDOUT = FUSED && W == 1 && NV >= 2 && !LEAN;
+    static constexpr bool ENDOUT = FUSED && W == 1 && NV >= 2 && !LEAN && !LR;
     template <class LoadT, class BodyT>
     __device__ __forceinline__ void chunks(LoadT load, BodyT body) const {
         if (nch > 2) chunks_pf<4>(load, body);
