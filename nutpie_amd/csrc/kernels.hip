@@ -688,15 +688,14 @@ struct Machine {
     // the GPU with the position AND the momentum pass in the read-ahead form (either alone runs and is bit-identical, as are the eight-wave kernels:
     // a lead at the very end: the read-ahead passes become functions of their own, rare_end_draw then CALLS, and under inter-procedural allocation the
     // caller's view of what it clobbers may miss the nested callee — the same passes alone fault in the two-wave kernels, and run with the call behind
-    // the loop or without inter-procedural allocation).  Hence also NOT the low-rank leaf (LR): it is built with inter-procedural allocation (without it
-    // it loses 9 %), so its rare paths stay free of nested calls like every other family's built that way; the ENDOUT family itself is built without
-    // (part 12).
+    // the loop or without inter-procedural allocation; not verified in the ISA).  The low-rank leaf of the same geometry (LR, W == 1) is in the
+    // family: same-box D = 1000, k = 16: 14.0 -> 16.1 M leapfrogs/s (scratch/lr_reg.py; its draw end calls sample_momentum in either form).
 #ifdef NPHIP_NO_PFRARE
     static constexpr bool PFRARE = false;   // (developer builds: the plain loops)
 #else
-    static constexpr bool PFRARE = FUSED && W == 1 && NV >= 2 && !LEAN && !LR;
+    static constexpr bool PFRARE = FUSED && W == 1 && NV >= 2 && !LEAN;
 #endif
-    static constexpr bool ENDOUT = FUSED && W == 1 && NV >= 2 && !LEAN && !LR;
+    static constexpr bool ENDOUT = FUSED && W == 1 && NV >= 2 && !LEAN;
     template <class LoadT, class BodyT>
     __device__ __forceinline__ void chunks(LoadT load, BodyT body) const {
         if (nch > 2) chunks_pf<4>(load, body);
