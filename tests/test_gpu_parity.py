@@ -121,6 +121,9 @@ def test_engine_matches_committed_golden_vectors(hip, name):
 
 
 @pytest.mark.parametrize("dim,waves", [(1, 1), (2, 1), (127, 1), (128, 1), (129, 2), (1000, 1), (1000, 4), (2500, 2), (5003, 8), (9000, 16),
+                                       # one wave per chain with 2 .. 7 chunks per lane (with 8: the family whose draw end changed at the end of
+                                       # round 6 — the call behind the loop of leaves, read-ahead passes, no inter-procedural allocation)
+                                       (200, 1), (380, 1), (500, 1), (640, 1), (700, 1), (896, 1),
                                        # register-resident kernels with several waves per chain
                                        (1100, 2), (1500, 2), (2048, 2), (2500, 4), (3300, 4), (4096, 4),
                                        (256, 2), (700, 2), (1000, 2), (512, 4), (900, 4), (1536, 4),
