@@ -177,3 +177,22 @@ def test_default_launch_length_by_dimension():
     from nutpie_amd import _lib
 
     assert [_lib.default_evals_per_launch(d) for d in (1, 1000, 1024, 1025, 4096, 4097, 10000, 100000)] == [2048, 2048, 2048, 1024, 1024, 512, 512, 512]
+
+
+def test_build_configuration_of_the_families_measured_without_interprocedural_allocation():
+    """DESIGN.md §4 / profiles/r6_call_placement_and_draw_end.txt: the one-wave kernels with 2 .. 8 chunks per lane (kernels.hip part 12), the dense
+    Gaussian's resident kernels (part 11) and the compiled densities with the diagonal metric are built with ``-mllvm -enable-ipra=0`` — chosen by
+    same-box A/B per family; the lean kernels and the low-rank leaf lose by it.  A pin on the build files, so that the choice is not lost by accident."""
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    mk = open(os.path.join(root, "nutpie_amd", "csrc", "Makefile")).read()
+    assert "kernels_p12.o" in re.search(r"^PARTS = (.*)$", mk, re.M).group(1)
+    rule = re.search(r"^kernels_p11\.o kernels_p12\.o: kernels_p%\.o:.*\n\t(.*)$", mk, re.M)
+    assert rule and "-mllvm -enable-ipra=0" in rule.group(1) and "-DNPHIP_PART=$*" in rule.group(1)
+    generic = re.search(r"^kernels_p%\.o: kernels\.hip.*\n\t(.*)$", mk, re.M)
+    assert generic and "enable-ipra" not in generic.group(1)
+    src = open(os.path.join(root, "nutpie_amd", "csrc", "kernels.hip")).read()
+    assert "#if NPHIP_HAS(12) && !defined(NPHIP_DEV_BUILD)\nhipError_t launch_w1_noipra(" in src
+    dens = open(os.path.join(root, "nutpie_amd", "density.py")).read()
+    assert '(["-DNPHIP_JIT_LR=1"] if low_rank else ["-mllvm", "-enable-ipra=0"])' in dens
