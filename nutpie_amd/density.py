@@ -195,11 +195,11 @@ def compile_density(user_source: str, layout, ndim: int, *, waves: int = 1, verb
     h.update(src.encode())
     for d in deps:
         h.update(open(d, "rb").read())
-    # (no inter-procedural register allocation for the kernels with the diagonal metric: the leaf with the model's density inlined is coupled to the
-    # register use of the out-of-line draw end otherwise — config 3 same-box +0.5 % / +2.4 % / +5 % at 1 / 2 / 4 waves per chain; the low-rank leaf
-    # loses by it: DESIGN.md §4, profiles/r6_call_placement_and_draw_end.txt)
-    flags = (_FLAGS + ["-DNPHIP_JIT_DENSITY=1", "-DNPHIP_PART=7", f"-DNPHIP_JIT_NV={max(1, nv)}", f"-DNPHIP_JIT_W={waves}"]
-             + (["-DNPHIP_JIT_LR=1"] if low_rank else ["-mllvm", "-enable-ipra=0"]) + os.environ.get("NUTPIE_AMD_JIT_FLAGS", "").split())
+    # (no inter-procedural register allocation: the leaf with the model's density inlined is coupled to the register use of the out-of-line draw end
+    # otherwise — config 3 same-box +0.5 % / +2.4 % / +5 % at 1 / 2 / 4 waves per chain, its low-rank kernels +3.4 % (the FUSED models' low-rank leaf
+    # loses by it, csrc/Makefile): DESIGN.md §4, profiles/r6_call_placement_and_draw_end.txt)
+    flags = (_FLAGS + ["-mllvm", "-enable-ipra=0", "-DNPHIP_JIT_DENSITY=1", "-DNPHIP_PART=7", f"-DNPHIP_JIT_NV={max(1, nv)}", f"-DNPHIP_JIT_W={waves}"]
+             + (["-DNPHIP_JIT_LR=1"] if low_rank else []) + os.environ.get("NUTPIE_AMD_JIT_FLAGS", "").split())
     h.update(" ".join(flags).encode())
     out = os.path.join(cache_dir(), f"density_{h.hexdigest()[:24]}.so")
     if os.path.exists(out):

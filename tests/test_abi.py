@@ -181,8 +181,8 @@ def test_default_launch_length_by_dimension():
 
 def test_build_configuration_of_the_families_measured_without_interprocedural_allocation():
     """DESIGN.md §4 / profiles/r6_call_placement_and_draw_end.txt: the one-wave kernels with 2 .. 8 chunks per lane (kernels.hip part 12), the dense
-    Gaussian's resident kernels (part 11) and the compiled densities with the diagonal metric are built with ``-mllvm -enable-ipra=0`` — chosen by
-    same-box A/B per family; the lean kernels and the low-rank leaf lose by it.  A pin on the build files, so that the choice is not lost by accident."""
+    Gaussian's resident kernels (part 11) and the compiled densities are built with ``-mllvm -enable-ipra=0`` — chosen by
+    same-box A/B per family; the lean kernels and the fused models' low-rank leaf lose by it.  A pin on the build files, so that the choice is not lost by accident."""
     import re
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -195,4 +195,4 @@ def test_build_configuration_of_the_families_measured_without_interprocedural_al
     src = open(os.path.join(root, "nutpie_amd", "csrc", "kernels.hip")).read()
     assert "#if NPHIP_HAS(12) && !defined(NPHIP_DEV_BUILD)\nhipError_t launch_w1_noipra(" in src
     dens = open(os.path.join(root, "nutpie_amd", "density.py")).read()
-    assert '(["-DNPHIP_JIT_LR=1"] if low_rank else ["-mllvm", "-enable-ipra=0"])' in dens
+    assert 'flags = (_FLAGS + ["-mllvm", "-enable-ipra=0", "-DNPHIP_JIT_DENSITY=1"' in dens
